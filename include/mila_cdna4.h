@@ -1,0 +1,251 @@
+/*
+ * mila_cdna4.h -- C ABI of the MI355X (gfx950 / CDNA4) device backend for Mila's forward() hot path.
+ *
+ * This is the drop-in seam.  In the reference every device op ends in a free function of the form
+ *     void cuda_<op>_<dtype>(T* out, const T* in, ..., int dims..., cudaStream_t)
+ * declared in a .cuh header (SURVEY.md section 0 finding 3).  Each entry point below replaces one of
+ * those launchers one-for-one: raw device pointers, plain ints, an opaque stream handle, nothing
+ * retained after the call, no hidden allocation (scratch is passed in), all work enqueued on the
+ * given stream.  The "replaces" notes cite the reference declaration (paths relative to
+ * /root/reference/Mila/Src/Dnn/Compute/Devices/Cuda/Operations unless noted).
+ *
+ * Conventions
+ *   - return value: MILA_OK (0) or a negative MILA_E_* code; mila_cdna4_last_error() returns the
+ *     text of the last failure on the calling thread.  The reference throws std::invalid_argument /
+ *     std::runtime_error / CudaException from the same checks; the C++ op classes in
+ *     mila_amd/host rethrow these codes as the same exception types.
+ *   - bf16 tensors are `uint16_t` bit patterns, fp8 (OCP E4M3FN) and packed fp4 (E2M1, low nibble =
+ *     even column) are `uint8_t`, scales are `float`.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - pointers are DEVICE pointers unless the parameter name starts with host_.
+ */
+#ifndef MILA_CDNA4_H
+#define MILA_CDNA4_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define MILA_API __attribute__((visibility("default")))
+#else
+#define MILA_API
+#endif
+
+typedef void* mila_stream_t;
+
+enum {
+    MILA_OK = 0,
+    MILA_E_INVALID_ARGUMENT = -1, /* reference: std::invalid_argument                     */
+    MILA_E_UNSUPPORTED = -2,      /* reference: std::runtime_error("unsupported ...")     */
+    MILA_E_RUNTIME = -3,          /* reference: CudaException from cudaCheck              */
+    MILA_E_SCRATCH_TOO_SMALL = -4
+};
+
+/* ---------------------------------------------------------------------------------------------
+ * Runtime (counterpart of ExecutionContext<Cuda>: ../CudaExecutionContext.ixx:106-368 and the
+ * device memory resources).  Thin wrappers so that a host that does not include HIP headers (the
+ * reference's C++23 module units) can own streams and device memory.
+ * ------------------------------------------------------------------------------------------- */
+MILA_API const char* mila_cdna4_last_error(void);
+MILA_API int mila_cdna4_abi_version(void);
+MILA_API int mila_cdna4_device_count(int* count);
+MILA_API int mila_cdna4_set_device(int device);
+/* name: at least 64 bytes */
+MILA_API int mila_cdna4_device_info(int device, char* name, int* compute_units, size_t* hbm_bytes);
+MILA_API int mila_cdna4_stream_create(mila_stream_t* stream);
+MILA_API int mila_cdna4_stream_destroy(mila_stream_t stream);
+MILA_API int mila_cdna4_stream_synchronize(mila_stream_t stream);
+MILA_API int mila_cdna4_malloc(void** ptr, size_t bytes);
+MILA_API int mila_cdna4_free(void* ptr);
+MILA_API int mila_cdna4_host_alloc_pinned(void** host_ptr, size_t bytes);
+MILA_API int mila_cdna4_host_free_pinned(void* host_ptr);
+MILA_API int mila_cdna4_memcpy_h2d(void* dst, const void* host_src, size_t bytes, mila_stream_t stream);
+MILA_API int mila_cdna4_memcpy_d2h(void* host_dst, const void* src, size_t bytes, mila_stream_t stream);
+MILA_API int mila_cdna4_memcpy_d2d(void* dst, const void* src, size_t bytes, mila_stream_t stream);
+MILA_API int mila_cdna4_memset_zero(void* dst, size_t bytes, mila_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Linear -- decode (M == 1) matvec.  y[n] = sum_k x[k] * W[n,k] (+ bias[n]); fp32 accumulate,
+ * bf16 out.  replaces Linear/Kernels/Linear.cuh: cuda_matvec_decode_bf16 / _qfp8 / _qfp4
+ * (kernels Linear/Kernels/MatVec/CudaMatVecBias.Bf16.cu:134-181, :198-251, :271-508).
+ *   W layouts: bf16 [N,K]; fp8 [N,K] + scales[N] (scale applied once after the reduction);
+ *   fp4 packed [N,K/2] + scales[N,K/group], group in {64,128}.
+ *   K % 8 == 0 (bf16), K % 16 == 0 (fp8), K % 32 == 0 and K % group == 0 (fp4).
+ * ------------------------------------------------------------------------------------------- */
+MILA_API int mila_cdna4_matvec_bf16(uint16_t* y, const uint16_t* x, const uint16_t* W,
+                                    const uint16_t* bias, int K, int N, mila_stream_t stream);
+MILA_API int mila_cdna4_matvec_bf16_qfp8(uint16_t* y, const uint16_t* x, const uint8_t* W,
+                                         const float* scales, const uint16_t* bias, int K, int N,
+                                         mila_stream_t stream);
+MILA_API int mila_cdna4_matvec_bf16_qfp4(uint16_t* y, const uint16_t* x, const uint8_t* W_packed,
+                                         const float* scales, const uint16_t* bias, int K, int N,
+                                         int group, mila_stream_t stream);
+/* fp32 logits variant used for the lm_head so the 1e-3 relative bar is asserted on fp32
+ * (weight format selected by `fmt`: 0 bf16, 1 fp8 per-channel, 2 fp4 per-group). */
+MILA_API int mila_cdna4_matvec_f32out(float* y, const uint16_t* x, const void* W, const float* scales,
+                                      int fmt, int K, int N, int group, mila_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Linear -- prefill (M > 1) GEMM  Y[M,N] = X[M,K] * W[N,K]^T (+ bias), bf16 in/out, fp32 MFMA
+ * accumulate.  replaces the cuBLASLt NT plans (Linear/CudaLinearOp.ixx:798-824,
+ * Common/CublasLtLinearPlan.ixx:307-381) + cuda_add_bias (Fp8Prefill/CudaFp8Prefill.cu:239-256),
+ * and for quantized weights the 2-phase dequantize-to-scratch + GEMM path
+ * (Linear/CudaLinearOp.ixx:597-644, :716-764) by dequantizing in registers inside the GEMM (same
+ * arithmetic: weights rounded to bf16, fp32 accumulate).  K % 32 == 0.
+ * ------------------------------------------------------------------------------------------- */
+MILA_API int mila_cdna4_gemm_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W,
+                                  const uint16_t* bias, int M, int K, int N, mila_stream_t stream);
+MILA_API int mila_cdna4_gemm_bf16_w8a16(uint16_t* Y, const uint16_t* X, const uint8_t* W,
+                                        const float* scales, const uint16_t* bias, int M, int K,
+                                        int N, mila_stream_t stream);
+MILA_API int mila_cdna4_gemm_bf16_w4a16(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed,
+                                        const float* scales, const uint16_t* bias, int M, int K,
+                                        int N, int group, mila_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Linear -- quantize-on-load.  Integer outputs are bit-exact with the reference kernels.
+ * replaces cuda_quantize_fp8_per_channel (Linear/Kernels/Quantization/CudaFp8WeightQuantization.cu:
+ * 57-121,209-249) and cuda_quantize_fp4_per_group (CudaFp4WeightQuantization.cu:54-144,184-224).
+ * ------------------------------------------------------------------------------------------- */
+MILA_API int mila_cdna4_quantize_fp8_per_channel(uint8_t* dst, float* scales, const uint16_t* src_bf16,
+                                                 int N, int K, mila_stream_t stream);
+MILA_API int mila_cdna4_quantize_fp4_per_group(uint8_t* dst_packed, float* scales,
+                                               const uint16_t* src_bf16, int N, int K, int group,
+                                               mila_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention over a KV cache [B, NKV, capacity, HS] (bf16), row = abs_pos % capacity.
+ * replaces Attention/GQA/Kernels/CudaGqa.cuh: cuda_kvcache_write_kv_bf16 (Gqa.Cache.Bf16.cu:86),
+ * cuda_gqa_decode_attention_bf16 (+ fixup; Gqa.Decode.Bf16.cu:64-428) and the flash-prefill
+ * launchers (Gqa.Flash.Wmma.cu:246, Gqa.Flash.Fa2.cu:177).
+ *   decode: q [B, NH*HS], len = position + 1, keys [max(0,len-window), len) (window 0 = all).
+ *   prefill: q [B, chunk, NH*HS]; query t has absolute position pos_offset + t and sees keys
+ *            max(0,pos-window+1) .. pos.  The cache must already contain the chunk (kv_write first).
+ *   scale multiplies q.k before max/exp (Gemma passes 1.0).  HS in {64,128,256,512}.
+ * ------------------------------------------------------------------------------------------- */
+MILA_API int mila_cdna4_kv_write_bf16(uint16_t* Kc, uint16_t* Vc, const uint16_t* k, const uint16_t* v,
+                                      int B, int chunk, int NKV, int HS, int start_pos, int capacity,
+                                      mila_stream_t stream);
+MILA_API size_t mila_cdna4_attn_decode_scratch_bytes(int B, int NH, int HS);
+MILA_API int mila_cdna4_attn_decode_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t* Kc,
+                                         const uint16_t* Vc, void* scratch, size_t scratch_bytes,
+                                         int B, int NH, int NKV, int HS, int capacity, int len,
+                                         int window, float scale, mila_stream_t stream);
+MILA_API int mila_cdna4_attn_prefill_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t* Kc,
+                                          const uint16_t* Vc, int B, int chunk, int NH, int NKV, int HS,
+                                          int capacity, int pos_offset, int window, float scale,
+                                          mila_stream_t stream);
+/* GPT-2 multi-head attention on packed QKV [B,T,3C] -> [B,T,C], causal, scale 1/sqrt(HS).
+ * replaces Attention/MHA/CudaMhaOp.ixx:456-553 (permute + 2 batched GEMMs + softmax + unpermute). */
+MILA_API int mila_cdna4_mha_bf16(uint16_t* Y, const uint16_t* QKV, int B, int T, int C, int NH,
+                                 mila_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Normalisation / activations.
+ * rmsnorm: y = x * rsqrt(mean(x^2) + eps) * (w + w_offset) + b over `dim` strided by `inner`;
+ *   rstd (bf16, may be NULL) gets one value per slice.  replaces
+ *   Normalizations/RmsNorm/Kernels/RmsNorm.cuh:84-149 (RmsNorm.Bf16.cu:20-73).
+ * layernorm: replaces Normalizations/LayerNorm/Kernels (LayerNorm.Fp32.cu:20,206), bf16 row added.
+ * softmax:   replaces Normalizations/Softmax/Kernels/Softmax.Fp32.cu:56-88.
+ * gelu/geglu: replaces Activations/Gelu/Kernels/Gelu.Fp32.cu:29-40, Activations/Geglu/Kernels/
+ *   Geglu.cu:25-87 (row = [gate | up], y = gelu_tanh(gate) * up).
+ * residual:  replaces Residual/Kernels/Residual.Bf16.cu:15-40.
+ * ------------------------------------------------------------------------------------------- */
+MILA_API int mila_cdna4_rmsnorm_bf16(uint16_t* Y, uint16_t* rstd, const uint16_t* X, const uint16_t* w,
+                                     const uint16_t* b, int outer, int dim, int inner, float eps,
+                                     float w_offset, mila_stream_t stream);
+MILA_API int mila_cdna4_layernorm_bf16(uint16_t* Y, float* mean, float* rstd, const uint16_t* X,
+                                       const uint16_t* w, const uint16_t* b, int outer, int dim,
+                                       float eps, mila_stream_t stream);
+MILA_API int mila_cdna4_layernorm_fp32(float* Y, float* mean, float* rstd, const float* X,
+                                       const float* w, const float* b, int outer, int dim, float eps,
+                                       mila_stream_t stream);
+MILA_API int mila_cdna4_softmax_fp32(float* Y, const float* X, int outer, int dim, int inner,
+                                     mila_stream_t stream);
+MILA_API int mila_cdna4_softmax_bf16(uint16_t* Y, const uint16_t* X, int outer, int dim, int inner,
+                                     mila_stream_t stream);
+MILA_API int mila_cdna4_gelu_bf16(uint16_t* Y, const uint16_t* X, int64_t n, mila_stream_t stream);
+MILA_API int mila_cdna4_gelu_fp32(float* Y, const float* X, int64_t n, mila_stream_t stream);
+MILA_API int mila_cdna4_geglu_bf16(uint16_t* Y, const uint16_t* X, int tokens, int half,
+                                   mila_stream_t stream);
+MILA_API int mila_cdna4_residual_bf16(uint16_t* Y, const uint16_t* A, const uint16_t* B, int64_t n,
+                                      mila_stream_t stream);
+MILA_API int mila_cdna4_residual_fp32(float* Y, const float* A, const float* B, int64_t n,
+                                      mila_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * RoPE.  replaces Encodings/Rope/Kernels/Rope.cuh:29-182 (cache: Rope.Fp32.cu:27-59,288-321;
+ * rotation: Rope.Bf16.cu:28-118).  Half-split pairing (i, i+HS/2); cos/sin fp32 [max_seq, HS/2];
+ * pairs >= rotary_dim/2 (when 0 < rotary_dim < HS) are the identity.  In-place allowed
+ * (Qout == Qin).  decode == forward with T = 1 and pos_offset = position.
+ * ------------------------------------------------------------------------------------------- */
+MILA_API int mila_cdna4_rope_build_cache(float* cos_cache, float* sin_cache, int max_seq, int HS,
+                                         float base, int rotary_dim, mila_stream_t stream);
+MILA_API int mila_cdna4_rope_forward_bf16(uint16_t* Qout, uint16_t* Kout, const uint16_t* Qin,
+                                          const uint16_t* Kin, const float* cos_cache,
+                                          const float* sin_cache, int B, int T, int NH, int NKV, int HS,
+                                          int pos_offset, int max_seq, mila_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Glue.  Token ids are read from DEVICE memory (Embeddings/Kernels/TokenEmbedding.Bf16.cu:23-97);
+ * an id outside [0,vocab) raises a sticky device flag reported by mila_cdna4_check_index_error.
+ * embedding scale: y = bf16(float(x) * scale) when scale != 0 (Components/Embeddings/
+ * TokenEmbedding.ixx:179-181).  lpe: Encodings/Lpe/Kernels/Lpe.Fp32.cu:33-124 (bf16 row added).
+ * split3: ../Tensors/Operations/Kernels/Structural.cu:106.  scale: Math.Elementwise.cu:106-113.
+ * ------------------------------------------------------------------------------------------- */
+MILA_API int mila_cdna4_embedding_gather_bf16(uint16_t* Y, const int32_t* tokens, const uint16_t* table,
+                                              int n_tok, int C, int vocab, float scale,
+                                              int32_t* error_flag, mila_stream_t stream);
+MILA_API int mila_cdna4_lpe_bf16(uint16_t* Y, const int32_t* tokens, const uint16_t* wte,
+                                 const uint16_t* wpe, int B, int T, int C, int out_stride_T, int vocab,
+                                 int32_t* error_flag, mila_stream_t stream);
+MILA_API int mila_cdna4_split3_bf16(uint16_t* a, uint16_t* b, uint16_t* c, const uint16_t* X, int rows,
+                                    int na, int nb, int nc, mila_stream_t stream);
+MILA_API int mila_cdna4_scale_bf16(uint16_t* Y, const uint16_t* X, int64_t n, float s,
+                                   mila_stream_t stream);
+MILA_API int mila_cdna4_convert_f32_to_bf16(uint16_t* Y, const float* X, int64_t n, mila_stream_t stream);
+MILA_API int mila_cdna4_convert_bf16_to_f32(float* Y, const uint16_t* X, int64_t n, mila_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused decode-step kernels (GemmaBlock::decode,
+ * Components/Transformers/Gemma/Gemma.Block.ixx:287-356, as a fused schedule).  Each computes
+ * exactly what the listed chain of unfused ops computes, including every intermediate bf16 rounding,
+ * so results are bit-identical to calling the unfused entry points in sequence.
+ * ------------------------------------------------------------------------------------------- */
+/* y = Linear( rmsnorm(x; nw, eps) ), weight format `fmt` (0 bf16, 1 fp8, 2 fp4).  With
+ * `geglu` != 0, W has 2*N rows [gate | up] and y[n] = bf16( gelu_tanh(bf16(gate_n)) * bf16(up_n) ).
+ * With res != NULL the prologue is the sandwich tail of the previous sub-block:
+ *   r = bf16( res + bf16(rmsnorm(x; pw)) ) [* post_scale]; x' = rmsnorm(r; nw); r is written to
+ *   res_out by block 0. */
+typedef struct mila_fused_matvec_args {
+    uint16_t* y;              /* [N] bf16 output (or [N] after GeGLU)                         */
+    const uint16_t* x;        /* [K] bf16 input                                               */
+    const void* W;            /* weights in `fmt` layout                                      */
+    const float* scales;      /* fp8: [rows]; fp4: [rows, K/group]; bf16: NULL                */
+    const uint16_t* norm_w;   /* [K] rmsnorm weight applied to the matvec input, or NULL      */
+    const uint16_t* post_w;   /* [K] rmsnorm weight of the sandwich tail, or NULL             */
+    const uint16_t* res;      /* [K] residual input of the sandwich tail, or NULL             */
+    uint16_t* res_out;        /* [K] where r is stored (required when res != NULL)            */
+    float post_scale;         /* layer scalar applied to r (1.0f = none)                      */
+    float eps;
+    int fmt, K, N, group, geglu;
+} mila_fused_matvec_args;
+MILA_API int mila_cdna4_fused_norm_matvec(const mila_fused_matvec_args* host_args, mila_stream_t stream);
+
+/* q/k(/v) per-head RMSNorm + RoPE + KV-cache append for one decode token, in one launch:
+ *   q <- rope(rmsnorm(q; qw)), k' = rope(rmsnorm(k; kw)), v' = rmsnorm(v_src; vw or ones),
+ *   cache[pos % capacity] <- (k', v').  v_src == k (raw) on Gemma global layers. */
+MILA_API int mila_cdna4_fused_qkv_post(uint16_t* q_out, uint16_t* Kc, uint16_t* Vc, const uint16_t* q,
+                                       const uint16_t* k, const uint16_t* v_src, const uint16_t* qw,
+                                       const uint16_t* kw, const uint16_t* vw, const float* cos_cache,
+                                       const float* sin_cache, int NH, int NKV, int HS, int position,
+                                       int capacity, float eps, mila_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MILA_CDNA4_H */

@@ -1,0 +1,114 @@
+"""ctypes binding of the C ABI (include/mila_cdna4.h) for tests and bench plumbing.
+
+PyTorch is used only to own device memory and streams: every compute call goes through
+libmila_cdna4.so.  Loading fails loudly when the shared object is missing -- there is no
+fallback path of any kind.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmila_cdna4.so")
+
+MILA_OK = 0
+MILA_E_INVALID_ARGUMENT = -1
+MILA_E_UNSUPPORTED = -2
+MILA_E_RUNTIME = -3
+MILA_E_SCRATCH_TOO_SMALL = -4
+
+FMT_BF16, FMT_FP8, FMT_FP4 = 0, 1, 2
+
+
+class MilaError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("mila_cdna4 error %d: %s" % (code, text))
+        self.code = code
+
+
+class InvalidArgument(MilaError, ValueError):
+    """reference: std::invalid_argument"""
+
+
+_lib = None
+
+
+def load():
+    """Load libmila_cdna4.so (import torch first so both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -m mila_amd.build` (hipcc --offload-arch=gfx950); "
+                          "there is no fallback path" % LIB_PATH)
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64 first so there is one runtime in-process)
+    except Exception:
+        pass
+    _lib = C.CDLL(LIB_PATH)
+    _lib.mila_cdna4_last_error.restype = C.c_char_p
+    _lib.mila_cdna4_attn_decode_scratch_bytes.restype = C.c_size_t
+    return _lib
+
+
+class fused_matvec_args(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("x", C.c_void_p), ("W", C.c_void_p), ("scales", C.c_void_p),
+                ("norm_w", C.c_void_p), ("post_w", C.c_void_p), ("res", C.c_void_p), ("res_out", C.c_void_p),
+                ("post_scale", C.c_float), ("eps", C.c_float), ("fmt", C.c_int), ("K", C.c_int),
+                ("N", C.c_int), ("group", C.c_int), ("geglu", C.c_int)]
+
+
+def _ptr(t):
+    """device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "the C ABI takes dense tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc):
+    if rc == MILA_OK:
+        return
+    text = load().mila_cdna4_last_error().decode()
+    if rc == MILA_E_INVALID_ARGUMENT:
+        raise InvalidArgument(rc, text)
+    raise MilaError(rc, text)
+
+
+def call(name, *args):
+    """call mila_cdna4_<name>(*args, current torch stream) and raise on a non-zero status."""
+    fn = getattr(load(), "mila_cdna4_" + name)
+    conv = []
+    for a in args:
+        if a is None or isinstance(a, (C.c_void_p, C.c_float, C.c_int, C.c_int64, C.c_size_t)):
+            conv.append(a)
+        elif isinstance(a, float):
+            conv.append(C.c_float(a))
+        elif isinstance(a, int):
+            conv.append(C.c_int(a))
+        elif hasattr(a, "data_ptr"):
+            conv.append(_ptr(a))
+        else:
+            conv.append(a)
+    check(fn(*conv, _stream()))
+
+
+EXPORTED = [
+    "last_error", "abi_version", "device_count", "set_device", "device_info", "stream_create",
+    "stream_destroy", "stream_synchronize", "malloc", "free", "host_alloc_pinned", "host_free_pinned",
+    "memcpy_h2d", "memcpy_d2h", "memcpy_d2d", "memset_zero",
+    "matvec_bf16", "matvec_bf16_qfp8", "matvec_bf16_qfp4", "matvec_f32out",
+    "gemm_bf16", "gemm_bf16_w8a16", "gemm_bf16_w4a16",
+    "quantize_fp8_per_channel", "quantize_fp4_per_group",
+    "kv_write_bf16", "attn_decode_scratch_bytes", "attn_decode_bf16", "attn_prefill_bf16", "mha_bf16",
+    "rmsnorm_bf16", "layernorm_bf16", "layernorm_fp32", "softmax_fp32", "softmax_bf16",
+    "gelu_bf16", "gelu_fp32", "geglu_bf16", "residual_bf16", "residual_fp32",
+    "rope_build_cache", "rope_forward_bf16",
+    "embedding_gather_bf16", "lpe_bf16", "split3_bf16", "scale_bf16",
+    "convert_f32_to_bf16", "convert_bf16_to_f32",
+    "fused_norm_matvec", "fused_qkv_post",
+]

@@ -1,0 +1,428 @@
+// Attention over a (ring) KV cache: append, split-K flash-decode (+ combine), and the row-wise
+// prefill / MHA entry points.
+//
+// Semantics restated from the reference:
+//   * cache [B, NKV, capacity, HS] bf16, row = abs_pos % capacity   (Gqa.Cache.Bf16.cu:86-130)
+//   * Q head h reads KV head h / (NH/NKV)                            (Gqa.Decode.Bf16.cu:93-98)
+//   * a query at absolute position t sees keys max(0, t-window+1)..t when window > 0, else 0..t
+//     (Gqa.Prefill.Bf16.cu:76-81; decode band Gqa.Decode.Bf16.cu:100-105 -- the same set)
+//   * score = dot(q,k) * scale BEFORE max/exp                        (Gqa.Decode.Bf16.cu:212)
+//   * fp32 scores / probabilities / accumulators, bf16 only at the final store.
+//
+// CDNA4 design of the decode kernel (HBM/latency bound: 4-8 MB of K/V per layer):
+//   grid (splits, NKV, B*Tq), 256 threads = 4 waves.  A wave owns every 4th position of its
+//   split; a lane owns HS/64 contiguous elements of every row (16-byte loads at HS = 512), so one
+//   wave-instruction fetches one whole K (or V) row; q is kept packed (bf16 pairs) in registers
+//   and multiplied with v_dot2_f32_bf16; the 64-lane score reduction is a xor butterfly; online
+//   softmax state (m, l, O) lives in registers per wave and is merged across the 4 waves through
+//   LDS four heads at a time; split partials (m, l, O) go to caller-provided scratch and are
+//   merged by a second tiny kernel (a kernel boundary is cheaper than an in-kernel agent-scope
+//   acquire on this chip, MI355X_MICROARCH "boundary" vs "barrier-xcd").
+#include "common.h"
+
+namespace mila {
+
+constexpr int kMaxSplits = 64;
+
+// ---- KV append ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kv_write_bf16_kernel(uint16_t* __restrict__ Kc, uint16_t* __restrict__ Vc,
+                                                            const uint16_t* __restrict__ k,
+                                                            const uint16_t* __restrict__ v, int64_t total_vec,
+                                                            int chunk, int NKV, int HS, int start_pos, int capacity)
+{
+    const int hv = HS / 8;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += stride)
+    {
+        // source order [b, t, nkv, hs]
+        const int e = (int)(i % hv);
+        int64_t r = i / hv;
+        const int n = (int)(r % NKV);
+        r /= NKV;
+        const int t = (int)(r % chunk);
+        const int b = (int)(r / chunk);
+        const int row = (start_pos + t) % capacity;
+        const size_t dst = ((((size_t)b * NKV + n) * capacity + row) * hv + e) * 8;
+        st16(Kc + dst, ld16(k + i * 8));
+        st16(Vc + dst, ld16(v + i * 8));
+    }
+}
+
+// ---- generic addressing so one kernel serves the cache layout and GPT-2's packed QKV -----------------
+struct AttnParams
+{
+    uint16_t* Y;              // [B*Tq, NH*HS]
+    const uint16_t* Q;        // row (b*Tq+t): Q + (b*Tq+t)*q_row_stride + h*HS
+    const uint16_t* K;        // K + b*kv_b_stride + kvh*kv_h_stride + row*kv_r_stride
+    const uint16_t* V;
+    float* scratch;           // [B*Tq, NH, splits, HS+2] partials when splits > 1
+    int64_t q_row_stride, kv_b_stride, kv_h_stride, kv_r_stride;
+    int Tq, NH, NKV, capacity, pos_offset, window, splits;
+    float scale;
+};
+
+template <int EPL> struct RowVec;                        // EPL bf16 elements per lane
+template <> struct RowVec<8> { typedef u32x4 type; };
+template <> struct RowVec<4> { typedef u32x2 type; };
+template <> struct RowVec<2> { typedef uint32_t type; };
+
+template <int EPL>
+__device__ __forceinline__ void load_row(uint32_t (&dst)[EPL / 2], const uint16_t* p)
+{
+    if constexpr (EPL == 8)
+    {
+        const u32x4 v = ld16(p);
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+    }
+    else if constexpr (EPL == 4)
+    {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+        dst[0] = v[0]; dst[1] = v[1];
+    }
+    else
+    {
+        dst[0] = *reinterpret_cast<const uint32_t*>(p);
+    }
+}
+
+// HS = 64 * EPL (EPL in {2,4,8}) or HS = 64 handled as EPL = 2 on 32 active lanes (LANES = 32).
+template <int HS, int GS>
+__global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
+{
+    constexpr int EPL = (HS >= 128) ? HS / 64 : 2;
+    constexpr int NPAIR = EPL / 2;
+    constexpr int ACTIVE = HS / EPL;                       // lanes that own data (64, or 32 for HS = 64)
+    constexpr int HC = (GS < 4) ? GS : 4;                  // heads merged per LDS round
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* sm = reinterpret_cast<float*>(smem_raw);        // [4 waves][HC][HS + 2]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool owner = lane < ACTIVE;
+    const int split = blockIdx.x, kvh = blockIdx.y;
+    const int bt = blockIdx.z, b = bt / p.Tq, t = bt % p.Tq;
+    const int pos = p.pos_offset + t;
+    const int len = pos + 1;
+    const int band_begin = (p.window > 0) ? max(0, len - p.window) : 0;
+    const int band = len - band_begin;
+    const int chunk = (band + p.splits - 1) / p.splits;
+    const int begin = band_begin + split * chunk;
+    const int end = min(begin + chunk, len);
+
+    // q for the GS heads of this KV head, packed bf16 pairs
+    uint32_t q[GS][NPAIR];
+#pragma unroll
+    for (int g = 0; g < GS; ++g)
+    {
+        const uint16_t* qp = p.Q + (size_t)bt * p.q_row_stride + (size_t)(kvh * GS + g) * HS + lane * EPL;
+        if (owner) load_row<EPL>(q[g], qp);
+        else
+        {
+#pragma unroll
+            for (int e = 0; e < NPAIR; ++e) q[g][e] = 0u;
+        }
+    }
+    float m[GS], l[GS], o[GS][EPL];
+#pragma unroll
+    for (int g = 0; g < GS; ++g)
+    {
+        m[g] = -INFINITY;
+        l[g] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[g][e] = 0.0f;
+    }
+
+    const uint16_t* kbase = p.K + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride + lane * EPL;
+    const uint16_t* vbase = p.V + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride + lane * EPL;
+
+    for (int pp = begin + wave; pp < end; pp += 8)
+    {
+        // two positions per iteration: 4 row loads in flight per lane
+        const int p0 = pp, p1 = pp + 4;
+        const bool has1 = p1 < end;
+        uint32_t k0[NPAIR], v0[NPAIR], k1[NPAIR], v1[NPAIR];
+        const size_t r0 = (size_t)(p0 % p.capacity) * p.kv_r_stride;
+        const size_t r1 = (size_t)((has1 ? p1 : p0) % p.capacity) * p.kv_r_stride;
+        if (owner)
+        {
+            load_row<EPL>(k0, kbase + r0);
+            load_row<EPL>(k1, kbase + r1);
+            load_row<EPL>(v0, vbase + r0);
+            load_row<EPL>(v1, vbase + r1);
+        }
+        else
+        {
+#pragma unroll
+            for (int e = 0; e < NPAIR; ++e) { k0[e] = 0u; k1[e] = 0u; v0[e] = 0u; v1[e] = 0u; }
+        }
+#pragma unroll
+        for (int g = 0; g < GS; ++g)
+        {
+            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < NPAIR; ++e)
+            {
+                s0 = dot2_bf16(as_bf16x2(q[g][e]), as_bf16x2(k0[e]), s0);
+                s1 = dot2_bf16(as_bf16x2(q[g][e]), as_bf16x2(k1[e]), s1);
+            }
+            s0 = wave_sum(s0) * p.scale;
+            s1 = has1 ? wave_sum(s1) * p.scale : -INFINITY;
+            const float mn = fmaxf(m[g], fmaxf(s0, s1));
+            const float alpha = __expf(m[g] - mn);           // m = -inf first time: exp(-inf) = 0
+            const float e0 = __expf(s0 - mn), e1 = __expf(s1 - mn);
+            l[g] = l[g] * alpha + e0 + e1;
+            m[g] = mn;
+#pragma unroll
+            for (int e = 0; e < NPAIR; ++e)
+            {
+                o[g][2 * e] = o[g][2 * e] * alpha + e0 * bf16_lo(v0[e]) + e1 * bf16_lo(v1[e]);
+                o[g][2 * e + 1] = o[g][2 * e + 1] * alpha + e0 * bf16_hi(v0[e]) + e1 * bf16_hi(v1[e]);
+            }
+        }
+    }
+
+    // ---- merge the 4 waves through LDS, HC heads per round; wave w finalises head hc*HC + w ----
+    constexpr int STR = HS + 2;
+#pragma unroll
+    for (int hc = 0; hc < GS / HC; ++hc)
+    {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < HC; ++j)
+        {
+            const int g = hc * HC + j;
+            float* dst = sm + ((size_t)wave * HC + j) * STR;
+            if (owner)
+            {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) dst[lane * EPL + e] = o[g][e];
+            }
+            if (lane == 0) { dst[HS] = m[g]; dst[HS + 1] = l[g]; }
+        }
+        __syncthreads();
+        if (wave < HC)
+        {
+            const int j = wave, g = hc * HC + j;
+            float M = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) M = fmaxf(M, sm[((size_t)w * HC + j) * STR + HS]);
+            float L = 0.0f, acc[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+            {
+                const float* src = sm + ((size_t)w * HC + j) * STR;
+                const float mw = src[HS];
+                const float f = (mw == -INFINITY) ? 0.0f : __expf(mw - M);
+                L += src[HS + 1] * f;
+                if (owner)
+                {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) acc[e] += src[lane * EPL + e] * f;
+                }
+            }
+            const int h = kvh * GS + g;
+            if (p.splits == 1)
+            {
+                const float inv = (L > 0.0f) ? 1.0f / L : 0.0f;
+                uint16_t* y = p.Y + ((size_t)bt * p.NH + h) * HS + lane * EPL;
+                if (owner)
+                {
+#pragma unroll
+                    for (int e = 0; e < EPL; e += 2)
+                        *reinterpret_cast<uint32_t*>(y + e) = pack_bf16x2(acc[e] * inv, acc[e + 1] * inv);
+                }
+            }
+            else
+            {
+                float* dst = p.scratch + (((size_t)bt * p.NH + h) * p.splits + split) * STR;
+                if (owner)
+                {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) dst[lane * EPL + e] = acc[e];
+                }
+                if (lane == 0) { dst[HS] = M; dst[HS + 1] = L; }
+            }
+        }
+    }
+}
+
+// combine split partials: grid (NH, B*Tq), 64..256 threads over HS
+__global__ void attn_combine_kernel(uint16_t* __restrict__ Y, const float* __restrict__ scratch, int NH, int HS,
+                                    int splits)
+{
+    const int h = blockIdx.x, bt = blockIdx.y;
+    const int STR = HS + 2;
+    const float* base = scratch + ((size_t)bt * NH + h) * splits * STR;
+    float M = -INFINITY;
+    for (int s = 0; s < splits; ++s) M = fmaxf(M, base[(size_t)s * STR + HS]);
+    for (int d = threadIdx.x; d < HS; d += blockDim.x)
+    {
+        float L = 0.0f, acc = 0.0f;
+        for (int s = 0; s < splits; ++s)
+        {
+            const float* src = base + (size_t)s * STR;
+            const float ms = src[HS];
+            const float f = (ms == -INFINITY) ? 0.0f : __expf(ms - M);
+            L += src[HS + 1] * f;
+            acc += src[d] * f;
+        }
+        Y[((size_t)bt * NH + h) * HS + d] = f32_to_bf16_bits(L > 0.0f ? acc / L : 0.0f);
+    }
+}
+
+template <int HS, int GS>
+static int launch_rowwise(const AttnParams& p, int B, hipStream_t s)
+{
+    constexpr int HC = (GS < 4) ? GS : 4;
+    const size_t lds = (size_t)4 * HC * (HS + 2) * sizeof(float);
+    hipLaunchKernelGGL((attn_rowwise_kernel<HS, GS>), dim3(p.splits, p.NKV, B * p.Tq), dim3(256), lds, s, p);
+    int rc = check_hip(hipGetLastError(), "attn_rowwise");
+    if (rc) return rc;
+    if (p.splits > 1)
+    {
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(p.NH, B * p.Tq), dim3(HS >= 256 ? 256 : 64), 0, s, p.Y, p.scratch, p.NH,
+                           HS, p.splits);
+        rc = check_hip(hipGetLastError(), "attn_combine");
+    }
+    return rc;
+}
+
+template <int HS>
+static int dispatch_gs(const AttnParams& p, int B, hipStream_t s)
+{
+    switch (p.NH / p.NKV)
+    {
+        case 1: return launch_rowwise<HS, 1>(p, B, s);
+        case 2: return launch_rowwise<HS, 2>(p, B, s);
+        case 4: return launch_rowwise<HS, 4>(p, B, s);
+        case 8: return launch_rowwise<HS, 8>(p, B, s);
+        case 16: return launch_rowwise<HS, 16>(p, B, s);
+        default: return set_error(MILA_E_UNSUPPORTED, "attention: group size %d (NH/NKV) must be 1,2,4,8 or 16", p.NH / p.NKV);
+    }
+}
+
+static int dispatch_hs(int HS, const AttnParams& p, int B, hipStream_t s)
+{
+    switch (HS)
+    {
+        case 64: return dispatch_gs<64>(p, B, s);
+        case 128: return dispatch_gs<128>(p, B, s);
+        case 256: return dispatch_gs<256>(p, B, s);
+        case 512: return dispatch_gs<512>(p, B, s);
+        default: return set_error(MILA_E_UNSUPPORTED, "attention: head size %d must be 64, 128, 256 or 512", HS);
+    }
+}
+
+static int decode_splits(int B, int NKV, int band)
+{
+    // enough workgroups to cover the chip (~2 per CU), at least 32 positions per split
+    int cap = 512 / (NKV * B);
+    if (cap < 1) cap = 1;
+    int s = (band + 31) / 32;
+    if (s > cap) s = cap;
+    if (s > kMaxSplits) s = kMaxSplits;
+    if (s < 1) s = 1;
+    return s;
+}
+
+}  // namespace mila
+
+using namespace mila;
+
+extern "C" {
+
+int mila_cdna4_kv_write_bf16(uint16_t* Kc, uint16_t* Vc, const uint16_t* k, const uint16_t* v, int B, int chunk, int NKV,
+                             int HS, int start_pos, int capacity, mila_stream_t stream)
+{
+    MILA_REQUIRE(Kc && Vc && k && v, "kv_write_bf16: null pointer");
+    MILA_REQUIRE(B > 0 && chunk > 0 && NKV > 0 && HS > 0 && capacity > 0, "kv_write_bf16: bad sizes");
+    MILA_REQUIRE(HS % 8 == 0, "kv_write_bf16: HS=%d must be a multiple of 8", HS);
+    MILA_REQUIRE(start_pos >= 0, "kv_write_bf16: negative start position");
+    MILA_REQUIRE(chunk <= capacity, "kv_write_bf16: chunk %d exceeds the cache capacity %d", chunk, capacity);
+    const int64_t total_vec = (int64_t)B * chunk * NKV * (HS / 8);
+    int blocks = ceil_div(total_vec, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(kv_write_bf16_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), Kc, Vc, k, v, total_vec, chunk,
+                       NKV, HS, start_pos, capacity);
+    MILA_LAUNCH_CHECK("kv_write_bf16");
+}
+
+size_t mila_cdna4_attn_decode_scratch_bytes(int B, int NH, int HS)
+{
+    if (B <= 0 || NH <= 0 || HS <= 0) return 0;
+    return (size_t)B * NH * kMaxSplits * (HS + 2) * sizeof(float);
+}
+
+int mila_cdna4_attn_decode_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t* Kc, const uint16_t* Vc, void* scratch,
+                                size_t scratch_bytes, int B, int NH, int NKV, int HS, int capacity, int len, int window,
+                                float scale, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && Q && Kc && Vc, "attn_decode_bf16: null pointer");
+    MILA_REQUIRE(B > 0 && NH > 0 && NKV > 0 && NH % NKV == 0, "attn_decode_bf16: bad head counts (NH=%d NKV=%d)", NH, NKV);
+    MILA_REQUIRE(len > 0 && capacity > 0, "attn_decode_bf16: len and capacity must be positive (len=%d capacity=%d)", len, capacity);
+    MILA_REQUIRE(window >= 0, "attn_decode_bf16: negative window");
+    const int band = (window > 0 && window < len) ? window : len;
+    MILA_REQUIRE(band <= capacity, "attn_decode_bf16: live band %d exceeds the cache capacity %d", band, capacity);
+    AttnParams p;
+    p.Y = Y; p.Q = Q; p.K = Kc; p.V = Vc; p.scratch = reinterpret_cast<float*>(scratch);
+    p.q_row_stride = (int64_t)NH * HS;
+    p.kv_b_stride = (int64_t)NKV * capacity * HS;
+    p.kv_h_stride = (int64_t)capacity * HS;
+    p.kv_r_stride = HS;
+    p.Tq = 1; p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.pos_offset = len - 1; p.window = window;
+    p.splits = decode_splits(B, NKV, band);
+    p.scale = scale;
+    if (p.splits > 1)
+    {
+        const size_t need = (size_t)B * NH * p.splits * (HS + 2) * sizeof(float);
+        if (!scratch || scratch_bytes < need)
+            return set_error(MILA_E_SCRATCH_TOO_SMALL, "attn_decode_bf16: scratch %zu bytes < required %zu", scratch_bytes, need);
+    }
+    return dispatch_hs(HS, p, B, as_stream(stream));
+}
+
+int mila_cdna4_attn_prefill_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t* Kc, const uint16_t* Vc, int B, int chunk,
+                                 int NH, int NKV, int HS, int capacity, int pos_offset, int window, float scale,
+                                 mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && Q && Kc && Vc, "attn_prefill_bf16: null pointer");
+    MILA_REQUIRE(B > 0 && chunk > 0 && NH > 0 && NKV > 0 && NH % NKV == 0, "attn_prefill_bf16: bad sizes");
+    MILA_REQUIRE(pos_offset >= 0 && capacity > 0 && window >= 0, "attn_prefill_bf16: bad positions");
+    {
+        // every key a query of this chunk may see must still be resident in the ring
+        const int last = pos_offset + chunk - 1;
+        const int oldest_needed = (window > 0) ? max(0, pos_offset - window + 1) : 0;
+        MILA_REQUIRE(last - oldest_needed + 1 <= capacity,
+                     "attn_prefill_bf16: keys [%d,%d] do not fit the cache capacity %d", oldest_needed, last, capacity);
+    }
+    AttnParams p;
+    p.Y = Y; p.Q = Q; p.K = Kc; p.V = Vc; p.scratch = nullptr;
+    p.q_row_stride = (int64_t)NH * HS;
+    p.kv_b_stride = (int64_t)NKV * capacity * HS;
+    p.kv_h_stride = (int64_t)capacity * HS;
+    p.kv_r_stride = HS;
+    p.Tq = chunk; p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.pos_offset = pos_offset; p.window = window;
+    p.splits = 1;
+    p.scale = scale;
+    return dispatch_hs(HS, p, B, as_stream(stream));
+}
+
+int mila_cdna4_mha_bf16(uint16_t* Y, const uint16_t* QKV, int B, int T, int C, int NH, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && QKV, "mha_bf16: null pointer");
+    MILA_REQUIRE(B > 0 && T > 0 && C > 0 && NH > 0 && C % NH == 0, "mha_bf16: bad sizes (B=%d T=%d C=%d NH=%d)", B, T, C, NH);
+    const int HS = C / NH;
+    AttnParams p;
+    p.Y = Y; p.Q = QKV; p.K = QKV + C; p.V = QKV + 2 * C; p.scratch = nullptr;
+    p.q_row_stride = 3 * (int64_t)C;
+    p.kv_b_stride = (int64_t)T * 3 * C;
+    p.kv_h_stride = HS;
+    p.kv_r_stride = 3 * (int64_t)C;
+    p.Tq = T; p.NH = NH; p.NKV = NH; p.capacity = T; p.pos_offset = 0; p.window = 0;
+    p.splits = 1;
+    p.scale = 1.0f / sqrtf((float)HS);
+    return dispatch_hs(HS, p, B, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+// Shared device/host helpers for the gfx950 kernels.  CDNA4 only: wave = 64 lanes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mila_cdna4.h"
+
+namespace mila {
+
+// ---- host-side error plumbing ----------------------------------------------------------------
+int set_error(int code, const char* fmt, ...);   // runtime.hip; returns `code`
+int check_hip(hipError_t e, const char* what);   // MILA_OK or MILA_E_RUNTIME (+ message)
+
+#define MILA_REQUIRE(cond, ...)                                        \
+    do {                                                               \
+        if (!(cond)) return ::mila::set_error(MILA_E_INVALID_ARGUMENT, __VA_ARGS__); \
+    } while (0)
+
+#define MILA_LAUNCH_CHECK(name) return ::mila::check_hip(hipGetLastError(), name)
+
+static inline hipStream_t as_stream(mila_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
+
+constexpr int kWave = 64;
+constexpr int kNumCU = 256;     // MI355X
+
+// ---- vector types ----------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- bf16 <-> f32 ----------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ float bf16_lo(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+
+// RNE, NaN-preserving (hipcc lowers the cast to v_cvt_pk_bf16_f32 on gfx950).
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f)
+{
+    __bf16 h = static_cast<__bf16>(f);
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
+{
+    bf16x2 v;
+    v[0] = static_cast<__bf16>(lo);
+    v[1] = static_cast<__bf16>(hi);
+    return __builtin_bit_cast(uint32_t, v);
+}
+// round an f32 value to the nearest bf16 and return it as f32 (for fused kernels that must
+// reproduce the intermediate bf16 store of the unfused chain)
+__device__ __forceinline__ float round_bf16(float f) { return bf16_bits_to_f32(f32_to_bf16_bits(f)); }
+
+// ---- wave / block reductions (64 lanes) -------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Block-wide sum over `NW` waves; `red` is an LDS array of at least NW floats.  All threads get
+// the result.  Contains two barriers.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += red[i];
+    return t;
+}
+template <int NW>
+__device__ __forceinline__ float block_max(float v, float* red)
+{
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// ---- 16-byte global accesses -------------------------------------------------------------------
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+// streamed-once data (weights in decode): non-temporal so it does not evict x / KV from L2
+__device__ __forceinline__ u32x4 ld16_nt(const void* p)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+}
+__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+// ---- GELU (tanh) exactly as the reference functor writes it ------------------------------------
+// Components/Activations/Activation/Kernels/ElementwiseActivation.h:41-50
+__device__ __forceinline__ float gelu_tanh(float x)
+{
+    const float cube = 0.044715f * x * x * x;
+    return 0.5f * x * (1.0f + tanhf(0.7978845608f * (x + cube)));
+}
+
+// ---- FP8 E4M3FN / FP4 E2M1 decode ---------------------------------------------------------------
+// Hardware converts (gfx950): one instruction per 2 elements, scale operand 1.0f => exact values.
+__device__ __forceinline__ bf16x2 fp8x2_to_bf16x2(uint32_t word, bool hi_half)
+{
+    return hi_half ? __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(word, 1.0f, true)
+                   : __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(word, 1.0f, false);
+}
+__device__ __forceinline__ f32x2 fp8x2_to_f32x2(uint32_t word, bool hi_half)
+{
+    return hi_half ? __builtin_amdgcn_cvt_pk_f32_fp8(word, true) : __builtin_amdgcn_cvt_pk_f32_fp8(word, false);
+}
+// byte `B` (0..3) of `word` holds two E2M1 nibbles: low nibble = even column.
+template <int B>
+__device__ __forceinline__ bf16x2 fp4x2_to_bf16x2(uint32_t word)
+{
+    return __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(word, 1.0f, B);
+}
+// Software decode (bit arithmetic, no table): used by the self-test to validate the hardware
+// converts and by the cold paths.  magnitude index m (0..7) -> {0,.5,1,1.5,2,3,4,6}.
+__device__ __forceinline__ float fp4_decode_sw(uint32_t nib)
+{
+    const uint32_t m = nib & 7u;
+    // m<2: m*0.5 ; else (1 + (m&1)*0.5) * 2^((m>>1)-1)
+    const float mag = (m < 2u) ? 0.5f * (float)m : __uint_as_float(((126u + (m >> 1)) << 23) | ((m & 1u) << 22));
+    return (nib & 8u) ? -mag : mag;
+}
+__device__ __forceinline__ float fp8_decode_sw(uint32_t b)
+{
+    const uint32_t ex = (b >> 3) & 0xfu, man = b & 7u;
+    float mag;
+    if (ex == 0u) mag = (float)man * 0.001953125f;                       // man * 2^-9
+    else mag = __uint_as_float(((ex + 120u) << 23) | (man << 20));       // (1+man/8) * 2^(ex-7)
+    if (ex == 0xfu && man == 7u) mag = __uint_as_float(0x7fc00000u);
+    return (b & 0x80u) ? -mag : mag;
+}
+
+__device__ __forceinline__ float dot2_bf16(bf16x2 a, bf16x2 b, float c)
+{
+    return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false);
+}
+__device__ __forceinline__ bf16x2 as_bf16x2(uint32_t u) { return __builtin_bit_cast(bf16x2, u); }
+
+}  // namespace mila

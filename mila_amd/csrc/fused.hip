@@ -1,0 +1,98 @@
+// Fused decode-step glue for one token:
+//   q <- rope(rmsnorm(q; qw));  K[pos] <- rope(rmsnorm(k; kw));  V[pos] <- rmsnorm(v_src; vw | 1)
+// replaces, per layer, six launches of the unfused chain in GemmaBlock::decode
+// (Components/Transformers/Gemma/Gemma.Block.ixx:315-337: q_norm, k_norm, rope.decode(q,k), v_norm,
+// kvcache_write) with one.  Every step calls the canonical helpers of rms_common.h / rope_common.h
+// with the same lane->element assignment as the standalone kernels, so each intermediate bf16
+// rounding of the unfused chain is reproduced and the results are bit-identical.
+#include "common.h"
+#include "rms_common.h"
+#include "rope_common.h"
+
+namespace mila {
+
+struct QkvPostParams
+{
+    uint16_t* q_out;
+    uint16_t* Kc;
+    uint16_t* Vc;
+    const uint16_t* q;
+    const uint16_t* k;
+    const uint16_t* v_src;
+    const uint16_t* qw;
+    const uint16_t* kw;
+    const uint16_t* vw;
+    const float* cos_row;   // cache row of this position
+    const float* sin_row;
+    int NH, NKV, HS, row, capacity;
+    float eps;
+};
+
+// one wave per head row; rows [0,NH) = q, [NH,NH+NKV) = k, [NH+NKV, NH+2NKV) = v
+__global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostParams p)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int HS = p.HS, half = HS / 2, hv = half / 8;
+    if (r >= p.NH + 2 * p.NKV) return;
+    const uint16_t* src;
+    const uint16_t* w;
+    uint16_t* dst;
+    bool rotate;
+    if (r < p.NH)
+    {
+        src = p.q + (size_t)r * HS; w = p.qw; dst = p.q_out + (size_t)r * HS; rotate = true;
+    }
+    else if (r < p.NH + p.NKV)
+    {
+        const int n = r - p.NH;
+        src = p.k + (size_t)n * HS; w = p.kw; dst = p.Kc + ((size_t)n * p.capacity + p.row) * HS; rotate = true;
+    }
+    else
+    {
+        const int n = r - p.NH - p.NKV;
+        src = p.v_src + (size_t)n * HS; w = p.vw; dst = p.Vc + ((size_t)n * p.capacity + p.row) * HS; rotate = false;
+    }
+    const float rstd = rms_rstd_wave(src, HS, p.eps);
+    if (lane < hv)
+    {
+        const u32x4 xlo = ld16(src + (size_t)lane * 8), xhi = ld16(src + (size_t)(lane + hv) * 8);
+        u32x4 lo, hi;
+        if (w)
+        {
+            lo = rms_apply8(xlo, ld16(w + (size_t)lane * 8), rstd, 0.0f);
+            hi = rms_apply8(xhi, ld16(w + (size_t)(lane + hv) * 8), rstd, 0.0f);
+        }
+        else
+        {
+            lo = rms_apply8_now(xlo, rstd);
+            hi = rms_apply8_now(xhi, rstd);
+        }
+        if (rotate) rope_rotate8_vals(lo, hi, p.cos_row, p.sin_row, lane * 8);
+        st16(dst + (size_t)lane * 8, lo);
+        st16(dst + (size_t)(lane + hv) * 8, hi);
+    }
+}
+
+}  // namespace mila
+
+using namespace mila;
+
+extern "C" {
+
+int mila_cdna4_fused_qkv_post(uint16_t* q_out, uint16_t* Kc, uint16_t* Vc, const uint16_t* q, const uint16_t* k,
+                              const uint16_t* v_src, const uint16_t* qw, const uint16_t* kw, const uint16_t* vw,
+                              const float* cos_cache, const float* sin_cache, int NH, int NKV, int HS, int position,
+                              int capacity, float eps, mila_stream_t stream)
+{
+    MILA_REQUIRE(q_out && Kc && Vc && q && k && v_src && qw && kw && cos_cache && sin_cache, "fused_qkv_post: null pointer");
+    MILA_REQUIRE(NH > 0 && NKV > 0 && capacity > 0 && position >= 0, "fused_qkv_post: bad sizes");
+    MILA_REQUIRE(HS % 16 == 0 && HS >= 16 && HS <= 1024, "fused_qkv_post: HS=%d must be a multiple of 16 in [16,1024]", HS);
+    QkvPostParams p{q_out, Kc, Vc, q, k, v_src, qw, kw, vw, cos_cache + (size_t)position * (HS / 2),
+                    sin_cache + (size_t)position * (HS / 2), NH, NKV, HS, position % capacity, capacity, eps};
+    const int rows = NH + 2 * NKV;
+    hipLaunchKernelGGL(qkv_post_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, as_stream(stream), p);
+    MILA_LAUNCH_CHECK("fused_qkv_post");
+}
+
+}  // extern "C"

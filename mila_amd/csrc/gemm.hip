@@ -1,0 +1,311 @@
+// Prefill (M > 1) Linear on the matrix cores:  Y[M,N] = X[M,K] * W[N,K]^T (+ bias), bf16 in/out,
+// fp32 MFMA accumulate, for bf16 / fp8-per-channel / fp4-per-group weights.
+//
+// Replaces the cuBLASLt NT plans (OPS/Linear/CudaLinearOp.ixx:798-824) and, for quantized weights,
+// the reference's 2-phase path -- dequantize the whole matrix to a bf16 scratch
+// (Fp8Prefill/CudaFp8Prefill.cu:64-84, W4A16Gemm/CudaW4A16Gemm.cu:210-235), then GEMM -- by
+// dequantizing each weight tile in registers on its way to LDS: the same arithmetic
+// (w = bf16(decode(q) * scale), fp32 accumulate) without writing and re-reading N*K*2 bytes.
+// Bias follows the reference's prefill order: the GEMM result is rounded to bf16 first, then
+// bias is added in fp32 and rounded again (cuda_add_bias, CudaFp8Prefill.cu:239-256).
+//
+// Tile: 128 x 128 x 64 per 256-thread workgroup, 2 x 2 waves, each wave 64 x 64 as 2 x 2
+// v_mfma_f32_32x32x16_bf16 accumulators.  The product is computed transposed (A operand = W tile,
+// B operand = X tile) so that a lane's 4 consecutive accumulator registers are 4 consecutive
+// output columns n of one row m -> 8-byte stores.  LDS rows are 128 B (64 bf16 of K) with the
+// 16-byte slot index XOR-swizzled by (row >> 1) & 7, which makes every ds_read_b128 fragment
+// read conflict-free (MI355X LDS: 64 banks x 4 B, 16-lane groups for b128).  Global->LDS staging
+// goes through registers (the quantized formats must pass through VALU anyway), software
+// pipelined one K-tile ahead with two LDS buffers and one barrier per K-tile.  Workgroup ids are
+// remapped so that the workgroups sharing an XCD (id % 8) walk neighbouring tiles and share
+// their W / X panels in that XCD's L2.
+#include "common.h"
+
+namespace mila {
+
+enum { G_BF16 = 0, G_FP8 = 1, G_FP4 = 2 };
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kTileBytes = 128 * BK * 2;   // one operand tile in LDS (bf16)
+
+struct GemmParams
+{
+    uint16_t* Y;
+    const uint16_t* X;
+    const uint8_t* W;
+    const float* scales;
+    const uint16_t* bias;
+    int M, K, N, group;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+// registers holding one thread's share of a K-tile on its way to LDS
+template <int FMT> struct StageRegs;
+template <> struct StageRegs<G_BF16> { u32x4 x[4]; u32x4 w[4]; };
+template <> struct StageRegs<G_FP8> { u32x4 x[4]; u32x4 w[2]; };
+template <> struct StageRegs<G_FP4> { u32x4 x[4]; u32x4 w[1]; float sc; };
+
+template <int FMT>
+__device__ __forceinline__ void stage_load(StageRegs<FMT>& r, const GemmParams& p, int m0, int n0, int k0)
+{
+    const int tid = threadIdx.x;
+    // X tile: 128 rows x 8 slots(16 B); thread -> slots tid + 256*i
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        const int s = tid + 256 * i, row = s >> 3, slot = s & 7;
+        const int m = m0 + row, k = k0 + slot * 8;
+        r.x[i] = (m < p.M && k < p.K) ? ld16(p.X + (size_t)m * p.K + k) : u32x4{0u, 0u, 0u, 0u};
+    }
+    if constexpr (FMT == G_BF16)
+    {
+        const uint16_t* W = reinterpret_cast<const uint16_t*>(p.W);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            const int s = tid + 256 * i, row = s >> 3, slot = s & 7;
+            const int n = n0 + row, k = k0 + slot * 8;
+            r.w[i] = (n < p.N && k < p.K) ? ld16(W + (size_t)n * p.K + k) : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    else if constexpr (FMT == G_FP8)
+    {
+        // 128 rows x 4 segments of 16 fp8
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+        {
+            const int s = tid + 256 * i, row = s >> 2, seg = s & 3;
+            const int n = n0 + row, k = k0 + seg * 16;
+            r.w[i] = (n < p.N && k < p.K) ? ld16(p.W + (size_t)n * p.K + k) : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    else
+    {
+        // 128 rows x 2 segments of 32 fp4 (16 bytes)
+        const int row = tid >> 1, seg = tid & 1;
+        const int n = n0 + row, k = k0 + seg * 32;
+        const bool in = n < p.N && k < p.K;
+        r.w[0] = in ? ld16(p.W + ((size_t)n * p.K + k) / 2) : u32x4{0u, 0u, 0u, 0u};
+        r.sc = in ? p.scales[(size_t)n * (p.K / p.group) + k / p.group] : 0.0f;
+    }
+}
+
+template <int FMT>
+__device__ __forceinline__ void stage_store(const StageRegs<FMT>& r, const GemmParams& p, unsigned char* ldsX,
+                                            unsigned char* ldsW, int n0)
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        const int s = tid + 256 * i, row = s >> 3, slot = s & 7;
+        *reinterpret_cast<u32x4*>(ldsX + swz(row, slot)) = r.x[i];
+    }
+    if constexpr (FMT == G_BF16)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            const int s = tid + 256 * i, row = s >> 3, slot = s & 7;
+            *reinterpret_cast<u32x4*>(ldsW + swz(row, slot)) = r.w[i];
+        }
+    }
+    else if constexpr (FMT == G_FP8)
+    {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+        {
+            const int s = tid + 256 * i, row = s >> 2, seg = s & 3;
+            const int n = n0 + row;
+            const float sc = (n < p.N) ? p.scales[n] : 0.0f;
+            u32x4 lo, hi;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+            {
+                const f32x2 a = fp8x2_to_f32x2(r.w[i][d], false), b = fp8x2_to_f32x2(r.w[i][d], true);
+                lo[2 * d] = pack_bf16x2(a[0] * sc, a[1] * sc);
+                lo[2 * d + 1] = pack_bf16x2(b[0] * sc, b[1] * sc);
+                const f32x2 c = fp8x2_to_f32x2(r.w[i][d + 2], false), e = fp8x2_to_f32x2(r.w[i][d + 2], true);
+                hi[2 * d] = pack_bf16x2(c[0] * sc, c[1] * sc);
+                hi[2 * d + 1] = pack_bf16x2(e[0] * sc, e[1] * sc);
+            }
+            *reinterpret_cast<u32x4*>(ldsW + swz(row, seg * 2)) = lo;
+            *reinterpret_cast<u32x4*>(ldsW + swz(row, seg * 2 + 1)) = hi;
+        }
+    }
+    else
+    {
+        const int row = tid >> 1, seg = tid & 1;
+        const float sc = r.sc;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+        {
+            const uint32_t w = r.w[0][d];
+            u32x4 o;
+            const bf16x2 v0 = fp4x2_to_bf16x2<0>(w), v1 = fp4x2_to_bf16x2<1>(w), v2 = fp4x2_to_bf16x2<2>(w),
+                         v3 = fp4x2_to_bf16x2<3>(w);
+            o[0] = pack_bf16x2((float)v0[0] * sc, (float)v0[1] * sc);
+            o[1] = pack_bf16x2((float)v1[0] * sc, (float)v1[1] * sc);
+            o[2] = pack_bf16x2((float)v2[0] * sc, (float)v2[1] * sc);
+            o[3] = pack_bf16x2((float)v3[0] * sc, (float)v3[1] * sc);
+            *reinterpret_cast<u32x4*>(ldsW + swz(row, seg * 4 + d)) = o;
+        }
+    }
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 bufs][X tile | W tile]
+
+    // XCD-aware tile order: workgroups with equal (id % 8) share an XCD/L2 -> give them
+    // consecutive tiles along N within one M panel (bijective for any grid size)
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int xcd = id & 7, q = nwg >> 3, rem = nwg & 7;
+    const int tile = ((xcd < rem) ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wn = wave >> 1, wm = wave & 1;        // wave's 64x64 sub-tile: n half, m half
+    const int r32 = lane & 31, h = lane >> 5;
+
+    f32x16 acc[2][2];                               // [n tile][m tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    StageRegs<FMT> regs;
+    stage_load<FMT>(regs, p, m0, n0, 0);
+    stage_store<FMT>(regs, p, smem, smem + kTileBytes, n0);
+    __syncthreads();
+
+    for (int t = 0; t < nk; ++t)
+    {
+        unsigned char* cur = smem + (t & 1) * 2 * kTileBytes;
+        unsigned char* nxt = smem + ((t + 1) & 1) * 2 * kTileBytes;
+        const bool more = t + 1 < nk;
+        if (more) stage_load<FMT>(regs, p, m0, n0, (t + 1) * BK);
+
+        const unsigned char* lx = cur;
+        const unsigned char* lw = cur + kTileBytes;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+        {
+            // fragment: 8 bf16 of K starting at ks*16 + h*8  -> slot ks*2 + h
+            s16x8 fw[2], fx[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+            {
+                const int rw = wn * 64 + a * 32 + r32;
+                fw[a] = *reinterpret_cast<const s16x8*>(lw + swz(rw, ks * 2 + h));
+                const int rx = wm * 64 + a * 32 + r32;
+                fx[a] = *reinterpret_cast<const s16x8*>(lx + swz(rx, ks * 2 + h));
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, fw[a]), __builtin_bit_cast(bf16x8, fx[b]), acc[a][b], 0, 0, 0);
+        }
+        if (more) stage_store<FMT>(regs, p, nxt, nxt + kTileBytes, n0);
+        __syncthreads();
+    }
+
+    // D[n][m]: lane -> column m = r32 of the (b) m-tile; registers -> rows n = (e&3) + 8*(e>>2) + 4*h
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+        {
+            const int m = m0 + wm * 64 + b * 32 + r32;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+            {
+                const int n = n0 + wn * 64 + a * 32 + 8 * g + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e];
+                if (p.bias)
+                {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
+                }
+                uint16_t* dst = p.Y + (size_t)m * p.N + n;
+                if (n + 3 < p.N && (p.N & 3) == 0)
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                else
+                {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N) dst[e] = f32_to_bf16_bits(v[e]);
+                }
+            }
+        }
+}
+
+template <int FMT>
+static int launch_gemm(GemmParams p, hipStream_t s)
+{
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL(gemm_kernel<FMT>, dim3(nwg), dim3(256), 4 * kTileBytes, s, p);
+    MILA_LAUNCH_CHECK("gemm");
+}
+
+static int validate_gemm(const char* who, const void* Y, const void* X, const void* W, int M, int K, int N)
+{
+    MILA_REQUIRE(Y && X && W, "%s: null pointer", who);
+    MILA_REQUIRE(M > 0 && K > 0 && N > 0, "%s: M, K, N must be positive (%d,%d,%d)", who, M, K, N);
+    MILA_REQUIRE(K % 32 == 0, "%s: K=%d must be a multiple of 32", who, K);
+    return MILA_OK;
+}
+
+}  // namespace mila
+
+using namespace mila;
+
+extern "C" {
+
+int mila_cdna4_gemm_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N,
+                         mila_stream_t stream)
+{
+    int rc = validate_gemm("gemm_bf16", Y, X, W, M, K, N);
+    if (rc) return rc;
+    GemmParams p{Y, X, reinterpret_cast<const uint8_t*>(W), nullptr, bias, M, K, N, 0, 0, 0};
+    return launch_gemm<G_BF16>(p, as_stream(stream));
+}
+
+int mila_cdna4_gemm_bf16_w8a16(uint16_t* Y, const uint16_t* X, const uint8_t* W, const float* scales,
+                               const uint16_t* bias, int M, int K, int N, mila_stream_t stream)
+{
+    int rc = validate_gemm("gemm_bf16_w8a16", Y, X, W, M, K, N);
+    if (rc) return rc;
+    MILA_REQUIRE(scales != nullptr, "gemm_bf16_w8a16: per-channel scales are required");
+    GemmParams p{Y, X, W, scales, bias, M, K, N, 0, 0, 0};
+    return launch_gemm<G_FP8>(p, as_stream(stream));
+}
+
+int mila_cdna4_gemm_bf16_w4a16(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed, const float* scales,
+                               const uint16_t* bias, int M, int K, int N, int group, mila_stream_t stream)
+{
+    int rc = validate_gemm("gemm_bf16_w4a16", Y, X, W_packed, M, K, N);
+    if (rc) return rc;
+    MILA_REQUIRE(scales != nullptr, "gemm_bf16_w4a16: per-group scales are required");
+    MILA_REQUIRE(group == 64 || group == 128, "gemm_bf16_w4a16: group size must be 64 or 128 (got %d)", group);
+    MILA_REQUIRE(K % group == 0, "gemm_bf16_w4a16: K=%d must be a multiple of the group size %d", K, group);
+    GemmParams p{Y, X, W_packed, scales, bias, M, K, N, group, 0, 0};
+    return launch_gemm<G_FP4>(p, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,21 @@
+// Test / tuning hooks exported by the shared object but NOT part of the drop-in ABI
+// (include/mila_cdna4.h).  Used by tests/ and the micro-benchmarks only.
+#pragma once
+#include "../../include/mila_cdna4.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* override the matvec launch heuristics (0 = default): rows per wave, chunk positions in flight,
+ * maximum workgroups */
+MILA_API int mila_cdna4_tune_matvec(int R, int U, int max_blocks);
+/* decode all 256 byte values with the hardware converts used by the kernels:
+ * out_fp8[256] floats; out_fp4[512] floats (byte b -> [2b] low nibble, [2b+1] high nibble),
+ * each for the 4 byte positions of a dword: out_fp4 has 4*512 floats, out_fp8 4*256. */
+MILA_API int mila_cdna4_selftest_decode(float* out_fp8, float* out_fp4, mila_stream_t stream);
+/* streaming-copy ceiling: dst <- src with 16-byte accesses; used to report a measured HBM roof */
+MILA_API int mila_cdna4_stream_copy(void* dst, const void* src, size_t bytes, mila_stream_t stream);
+MILA_API int mila_cdna4_stream_read(float* sink, const void* src, size_t bytes, mila_stream_t stream);
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,381 @@
+// Decode (M == 1) Linear: y = W x (+ bias) for three weight formats, plus the fused
+// RMSNorm-prologue / GeGLU-epilogue variants used by the Gemma decode schedule.
+//
+// Replaces OPS/Linear/Kernels/MatVec/CudaMatVecBias.Bf16.cu:134-181 (bf16), :198-251 (fp8
+// per-channel, scale after the reduction) and :271-508 (fp4 per-group) -- re-derived for CDNA4:
+//   * HBM-bound: every weight byte is read exactly once with 16-byte non-temporal loads
+//     (1 KiB per wave-instruction), R rows x U chunk positions in flight per lane;
+//   * x (<= 64 KB) is staged once per workgroup in LDS and re-read with ds_read_b128, so the
+//     vector L1 only ever sees the weight stream;
+//   * one wave owns R whole rows (no cross-wave reduction, no barrier in the streaming loop);
+//     the 64-lane reduction is a xor butterfly;
+//   * fp8 / fp4 are expanded to bf16 pairs by the gfx950 v_cvt_scalef32_pk_bf16_{fp8,fp4}
+//     converts (scale operand 1.0 => exact) and multiplied with v_dot2_f32_bf16, fp32 accumulate;
+//     the fp4 group scale is folded with one FMA per 32-element chunk.
+#include "common.h"
+#include "internal.h"
+#include "rms_common.h"
+
+namespace mila {
+
+enum { FMT_BF16 = 0, FMT_FP8 = 1, FMT_FP4 = 2 };
+
+template <int FMT> struct Fmt;
+template <> struct Fmt<FMT_BF16> { static constexpr int kElemsPerChunk = 8; };
+template <> struct Fmt<FMT_FP8> { static constexpr int kElemsPerChunk = 16; };
+template <> struct Fmt<FMT_FP4> { static constexpr int kElemsPerChunk = 32; };
+
+// dot of one 16-byte weight chunk with the matching x values (bf16 pairs in LDS, 16-byte units)
+template <int FMT>
+__device__ __forceinline__ float chunk_dot(const u32x4 w, const u32x4* __restrict__ xs, int c, float acc)
+{
+    if constexpr (FMT == FMT_BF16)
+    {
+        const u32x4 xv = xs[c];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc = dot2_bf16(as_bf16x2(w[d]), as_bf16x2(xv[d]), acc);
+    }
+    else if constexpr (FMT == FMT_FP8)
+    {
+        const u32x4 x0 = xs[2 * c], x1 = xs[2 * c + 1];
+        acc = dot2_bf16(fp8x2_to_bf16x2(w[0], false), as_bf16x2(x0[0]), acc);
+        acc = dot2_bf16(fp8x2_to_bf16x2(w[0], true), as_bf16x2(x0[1]), acc);
+        acc = dot2_bf16(fp8x2_to_bf16x2(w[1], false), as_bf16x2(x0[2]), acc);
+        acc = dot2_bf16(fp8x2_to_bf16x2(w[1], true), as_bf16x2(x0[3]), acc);
+        acc = dot2_bf16(fp8x2_to_bf16x2(w[2], false), as_bf16x2(x1[0]), acc);
+        acc = dot2_bf16(fp8x2_to_bf16x2(w[2], true), as_bf16x2(x1[1]), acc);
+        acc = dot2_bf16(fp8x2_to_bf16x2(w[3], false), as_bf16x2(x1[2]), acc);
+        acc = dot2_bf16(fp8x2_to_bf16x2(w[3], true), as_bf16x2(x1[3]), acc);
+    }
+    else
+    {
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+        {
+            const u32x4 xv = xs[4 * c + d];
+            acc = dot2_bf16(fp4x2_to_bf16x2<0>(w[d]), as_bf16x2(xv[0]), acc);
+            acc = dot2_bf16(fp4x2_to_bf16x2<1>(w[d]), as_bf16x2(xv[1]), acc);
+            acc = dot2_bf16(fp4x2_to_bf16x2<2>(w[d]), as_bf16x2(xv[2]), acc);
+            acc = dot2_bf16(fp4x2_to_bf16x2<3>(w[d]), as_bf16x2(xv[3]), acc);
+        }
+    }
+    return acc;
+}
+
+struct MatvecParams
+{
+    void* y;
+    const uint16_t* x;
+    const uint8_t* W;
+    const float* scales;
+    const uint16_t* bias;
+    // prologue operands (PRO != 0)
+    const uint16_t* norm_w;
+    const uint16_t* post_w;
+    const uint16_t* res;
+    uint16_t* res_out;
+    float post_scale, eps;
+    int K, N, group;
+};
+
+// PRO: 0 = x as is; 1 = x <- rmsnorm(x; norm_w); 2 = sandwich tail (see mila_cdna4.h)
+// ROWS = R output columns per wave; with GEGLU each column reads two weight rows (n, N + n).
+template <int FMT, int R, int U, int PRO, bool GEGLU, bool F32OUT>
+__global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
+    __shared__ float red[8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    const int K = p.K, N = p.N;
+    const int nx16 = K / 8;   // 16-byte units of x
+
+    // ---- stage x into LDS (optionally through the fused RMSNorm prologue) ----
+    if constexpr (PRO == 0)
+    {
+        for (int i = tid; i < nx16; i += 256) xs[i] = ld16(p.x + (size_t)i * 8);
+    }
+    else if constexpr (PRO == 1)
+    {
+        const float rstd = rms_rstd_block256(p.x, K, p.eps, red);
+        for (int i = tid; i < nx16; i += 256)
+            xs[i] = rms_apply8(ld16(p.x + (size_t)i * 8), ld16(p.norm_w + (size_t)i * 8), rstd, 0.0f);
+    }
+    else
+    {
+        // a = bf16(rmsnorm(x; post_w)); r = bf16(res + a); r = bf16(r * post_scale)
+        const float rstd_a = rms_rstd_block256(p.x, K, p.eps, red);
+        for (int i = tid; i < nx16; i += 256)
+        {
+            const u32x4 a = rms_apply8(ld16(p.x + (size_t)i * 8), ld16(p.post_w + (size_t)i * 8), rstd_a, 0.0f);
+            const u32x4 rr = ld16(p.res + (size_t)i * 8);
+            u32x4 r;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+            {
+                float lo = round_bf16(bf16_lo(rr[d]) + bf16_lo(a[d]));
+                float hi = round_bf16(bf16_hi(rr[d]) + bf16_hi(a[d]));
+                if (p.post_scale != 1.0f) { lo = lo * p.post_scale; hi = hi * p.post_scale; }
+                r[d] = pack_bf16x2(lo, hi);
+            }
+            xs[i] = r;
+            if (blockIdx.x == 0) st16(p.res_out + (size_t)i * 8, r);
+        }
+        __syncthreads();
+        // x' = bf16(rmsnorm(r; norm_w)) computed from the LDS copy of r
+        const float rstd_r = rms_rstd_block256_lds(xs, K, p.eps, red);
+        for (int i = tid; i < nx16; i += 256)
+            xs[i] = rms_apply8(xs[i], ld16(p.norm_w + (size_t)i * 8), rstd_r, 0.0f);
+    }
+    __syncthreads();
+
+    constexpr int EPC = Fmt<FMT>::kElemsPerChunk;
+    const int nchunks = K / EPC;                       // 16-byte chunks per weight row
+    const size_t row_bytes = (size_t)nchunks * 16;
+    const int ngroups = (FMT == FMT_FP4) ? K / p.group : 0;
+    const int chunks_per_group = (FMT == FMT_FP4) ? p.group / EPC : 1;
+    constexpr int NR = GEGLU ? 2 * R : R;              // weight rows per wave step
+
+    const int total_waves = gridDim.x * 4;
+    const int n_rg = (N + R - 1) / R;
+    for (int rg = blockIdx.x * 4 + wib; rg < n_rg; rg += total_waves)
+    {
+        const int col0 = rg * R;
+        const uint8_t* wrow[NR];
+        const float* srow[NR];
+        bool valid[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+        {
+            const int col = col0 + (GEGLU ? (j >> 1) : j);
+            valid[j] = col < N;
+            const int row = (GEGLU && (j & 1)) ? (N + col) : col;
+            wrow[j] = p.W + (size_t)(valid[j] ? row : 0) * row_bytes;
+            srow[j] = (FMT == FMT_FP4) ? p.scales + (size_t)(valid[j] ? row : 0) * ngroups : nullptr;
+        }
+        float acc[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[j] = 0.0f;
+
+        for (int c0 = lane; c0 < nchunks; c0 += 64 * U)
+        {
+            u32x4 w[U][NR];
+            float sc[U][NR];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                const int c = c0 + 64 * u;
+                const bool in = c < nchunks;
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                {
+                    if (in && valid[j])
+                    {
+                        w[u][j] = ld16_nt(wrow[j] + (size_t)c * 16);
+                        if constexpr (FMT == FMT_FP4) sc[u][j] = srow[j][c / chunks_per_group];
+                    }
+                    else
+                    {
+                        w[u][j] = u32x4{0u, 0u, 0u, 0u};
+                        if constexpr (FMT == FMT_FP4) sc[u][j] = 0.0f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                const int c = min(c0 + 64 * u, nchunks - 1);
+#pragma unroll
+                for (int j = 0; j < NR; ++j)
+                {
+                    if constexpr (FMT == FMT_FP4)
+                        acc[j] = fmaf(sc[u][j], chunk_dot<FMT>(w[u][j], xs, c, 0.0f), acc[j]);
+                    else
+                        acc[j] = chunk_dot<FMT>(w[u][j], xs, c, acc[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[j] = wave_sum(acc[j]);
+
+        if (lane == 0)
+        {
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+            {
+                if (!valid[j]) continue;
+                const int col = col0 + (GEGLU ? (j >> 1) : j);
+                const int row = (GEGLU && (j & 1)) ? (N + col) : col;
+                float v = acc[j];
+                if constexpr (FMT == FMT_FP8) v = p.scales[row] * v;
+                if (p.bias) v += bf16_bits_to_f32(p.bias[row]);
+                acc[j] = v;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+            {
+                const int col = col0 + r;
+                if (col >= N) continue;
+                if constexpr (GEGLU)
+                {
+                    // unfused chain: gate/up stored as bf16 by the Linear, then
+                    // bf16(gelu_tanh(gate) * up) by the GeGLU kernel
+                    const float g = round_bf16(acc[2 * r]), up = round_bf16(acc[2 * r + 1]);
+                    reinterpret_cast<uint16_t*>(p.y)[col] = f32_to_bf16_bits(gelu_tanh(g) * up);
+                }
+                else if constexpr (F32OUT)
+                    reinterpret_cast<float*>(p.y)[col] = acc[r];
+                else
+                    reinterpret_cast<uint16_t*>(p.y)[col] = f32_to_bf16_bits(acc[r]);
+            }
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+static int g_tune_R = 0, g_tune_U = 0, g_tune_blocks = 0;
+
+template <int FMT, int R, int U, int PRO, bool GEGLU, bool F32OUT>
+static int launch(const MatvecParams& p, hipStream_t s)
+{
+    const int n_rg = (p.N + R - 1) / R;
+    const size_t lds = (size_t)p.K * 2;
+    int max_blocks = g_tune_blocks > 0 ? g_tune_blocks : kNumCU * 8;
+    int blocks = (n_rg + 3) / 4;
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((matvec_kernel<FMT, R, U, PRO, GEGLU, F32OUT>), dim3(blocks), dim3(256), lds, s, p);
+    MILA_LAUNCH_CHECK("matvec");
+}
+
+template <int FMT, int PRO, bool GEGLU, bool F32OUT>
+static int dispatch_RU(const MatvecParams& p, hipStream_t s)
+{
+    // rows in flight per wave: enough waves to fill 256 CUs first, then more rows per wave so the
+    // x re-reads from LDS amortise.  (tuned on MI355X)
+    int R = g_tune_R, U = g_tune_U;
+    const int rows = GEGLU ? 2 * p.N : p.N;
+    if (R == 0) R = GEGLU ? 1 : (rows >= 32768 ? 4 : (rows >= 8192 ? 2 : 1));
+    if (GEGLU && R > 2) R = 2;
+    if (U == 0) U = 2;
+    if (R == 1 && U == 1) return launch<FMT, 1, 1, PRO, GEGLU, F32OUT>(p, s);
+    if (R == 1 && U == 2) return launch<FMT, 1, 2, PRO, GEGLU, F32OUT>(p, s);
+    if (R == 1) return launch<FMT, 1, 4, PRO, GEGLU, F32OUT>(p, s);
+    if (R == 2 && U == 1) return launch<FMT, 2, 1, PRO, GEGLU, F32OUT>(p, s);
+    if (R == 2 && U == 2) return launch<FMT, 2, 2, PRO, GEGLU, F32OUT>(p, s);
+    if (R == 2) return launch<FMT, 2, 4, PRO, GEGLU, F32OUT>(p, s);
+    if constexpr (!GEGLU)
+    {
+        if (U == 1) return launch<FMT, 4, 1, PRO, GEGLU, F32OUT>(p, s);
+        return launch<FMT, 4, 2, PRO, GEGLU, F32OUT>(p, s);
+    }
+    return launch<FMT, 2, 2, PRO, GEGLU, F32OUT>(p, s);
+}
+
+static int validate(const char* who, const void* y, const void* x, const void* W, const float* scales,
+                    int fmt, int K, int N, int group)
+{
+    MILA_REQUIRE(y && x && W, "%s: null pointer (y=%p x=%p W=%p)", who, y, x, W);
+    MILA_REQUIRE(K > 0 && N > 0, "%s: K and N must be positive (K=%d N=%d)", who, K, N);
+    MILA_REQUIRE(K <= 32768, "%s: K=%d exceeds the 64 KB LDS staging limit (32768)", who, K);
+    if (fmt == FMT_BF16) MILA_REQUIRE(K % 8 == 0, "%s: K=%d must be a multiple of 8 for bf16 weights", who, K);
+    if (fmt == FMT_FP8)
+    {
+        MILA_REQUIRE(K % 16 == 0, "%s: K=%d must be a multiple of 16 for fp8 weights", who, K);
+        MILA_REQUIRE(scales != nullptr, "%s: fp8 weights need per-channel scales", who);
+    }
+    if (fmt == FMT_FP4)
+    {
+        MILA_REQUIRE(group == 64 || group == 128, "%s: fp4 group size must be 64 or 128 (got %d)", who, group);
+        MILA_REQUIRE(K % 32 == 0 && K % group == 0, "%s: K=%d must be a multiple of 32 and of the group size %d", who, K, group);
+        MILA_REQUIRE(scales != nullptr, "%s: fp4 weights need per-group scales", who);
+    }
+    MILA_REQUIRE(fmt >= 0 && fmt <= 2, "%s: unknown weight format %d", who, fmt);
+    return MILA_OK;
+}
+
+template <int PRO, bool GEGLU, bool F32OUT>
+static int dispatch_fmt(int fmt, const MatvecParams& p, hipStream_t s)
+{
+    switch (fmt)
+    {
+        case FMT_BF16: return dispatch_RU<FMT_BF16, PRO, GEGLU, F32OUT>(p, s);
+        case FMT_FP8: return dispatch_RU<FMT_FP8, PRO, GEGLU, F32OUT>(p, s);
+        default: return dispatch_RU<FMT_FP4, PRO, GEGLU, F32OUT>(p, s);
+    }
+}
+
+}  // namespace mila
+
+using namespace mila;
+
+extern "C" {
+
+int mila_cdna4_tune_matvec(int R, int U, int max_blocks)
+{
+    g_tune_R = R;
+    g_tune_U = U;
+    g_tune_blocks = max_blocks;
+    return MILA_OK;
+}
+
+int mila_cdna4_matvec_bf16(uint16_t* y, const uint16_t* x, const uint16_t* W, const uint16_t* bias, int K,
+                           int N, mila_stream_t stream)
+{
+    int rc = validate("matvec_bf16", y, x, W, nullptr, FMT_BF16, K, N, 0);
+    if (rc) return rc;
+    MatvecParams p{y, x, reinterpret_cast<const uint8_t*>(W), nullptr, bias, nullptr, nullptr, nullptr, nullptr, 1.0f, 0.0f, K, N, 0};
+    return dispatch_fmt<0, false, false>(FMT_BF16, p, as_stream(stream));
+}
+
+int mila_cdna4_matvec_bf16_qfp8(uint16_t* y, const uint16_t* x, const uint8_t* W, const float* scales,
+                                const uint16_t* bias, int K, int N, mila_stream_t stream)
+{
+    int rc = validate("matvec_bf16_qfp8", y, x, W, scales, FMT_FP8, K, N, 0);
+    if (rc) return rc;
+    MatvecParams p{y, x, W, scales, bias, nullptr, nullptr, nullptr, nullptr, 1.0f, 0.0f, K, N, 0};
+    return dispatch_fmt<0, false, false>(FMT_FP8, p, as_stream(stream));
+}
+
+int mila_cdna4_matvec_bf16_qfp4(uint16_t* y, const uint16_t* x, const uint8_t* W_packed, const float* scales,
+                                const uint16_t* bias, int K, int N, int group, mila_stream_t stream)
+{
+    int rc = validate("matvec_bf16_qfp4", y, x, W_packed, scales, FMT_FP4, K, N, group);
+    if (rc) return rc;
+    MatvecParams p{y, x, W_packed, scales, bias, nullptr, nullptr, nullptr, nullptr, 1.0f, 0.0f, K, N, group};
+    return dispatch_fmt<0, false, false>(FMT_FP4, p, as_stream(stream));
+}
+
+int mila_cdna4_matvec_f32out(float* y, const uint16_t* x, const void* W, const float* scales, int fmt, int K,
+                             int N, int group, mila_stream_t stream)
+{
+    int rc = validate("matvec_f32out", y, x, W, scales, fmt, K, N, group);
+    if (rc) return rc;
+    MatvecParams p{y, x, reinterpret_cast<const uint8_t*>(W), scales, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, 0.0f, K, N, group};
+    return dispatch_fmt<0, false, true>(fmt, p, as_stream(stream));
+}
+
+int mila_cdna4_fused_norm_matvec(const mila_fused_matvec_args* a, mila_stream_t stream)
+{
+    MILA_REQUIRE(a != nullptr, "fused_norm_matvec: null args");
+    const int rows = a->geglu ? 2 * a->N : a->N;
+    (void)rows;
+    int rc = validate("fused_norm_matvec", a->y, a->x, a->W, a->scales, a->fmt, a->K, a->N, a->group);
+    if (rc) return rc;
+    MILA_REQUIRE(a->norm_w != nullptr, "fused_norm_matvec: norm_w is required");
+    MILA_REQUIRE((a->res == nullptr) == (a->post_w == nullptr), "fused_norm_matvec: res and post_w go together");
+    if (a->res)
+    {
+        MILA_REQUIRE(a->res_out != nullptr, "fused_norm_matvec: res_out is required with res");
+        MILA_REQUIRE(a->res_out != a->res && a->res_out != a->x, "fused_norm_matvec: res_out must not alias res or x");
+    }
+    MatvecParams p{a->y, a->x, reinterpret_cast<const uint8_t*>(a->W), a->scales, nullptr, a->norm_w, a->post_w,
+                   a->res, a->res_out, a->post_scale, a->eps, a->K, a->N, a->group};
+    hipStream_t s = as_stream(stream);
+    if (a->res)
+        return a->geglu ? dispatch_fmt<2, true, false>(a->fmt, p, s) : dispatch_fmt<2, false, false>(a->fmt, p, s);
+    return a->geglu ? dispatch_fmt<1, true, false>(a->fmt, p, s) : dispatch_fmt<1, false, false>(a->fmt, p, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,227 @@
+// RMSNorm / LayerNorm / Softmax.
+//   rmsnorm:   OPS/Normalizations/RmsNorm/Kernels/RmsNorm.Bf16.cu:20-73 (warp per slice) -> here
+//              a 256-thread workgroup per long row (model-width rows), a wave per short row
+//              (per-head rows), 16-byte loads; strided (inner > 1) slices take the generic kernel.
+//   layernorm: CPU/CpuLayerNormOp.ixx:187-258 semantics (biased variance, two-pass), fp32 math.
+//   softmax:   CPU/CpuSoftmaxOp.ixx:167-215 / OPS/Normalizations/Softmax/Kernels/Softmax.Fp32.cu:56-88
+//              (thread per row there; a wave per row here, online max+sum in one pass).
+#include "common.h"
+#include "rms_common.h"
+
+namespace mila {
+
+// ---- RMSNorm ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_block_kernel(uint16_t* __restrict__ Y, uint16_t* __restrict__ rstd_out,
+                                                            const uint16_t* __restrict__ X,
+                                                            const uint16_t* __restrict__ w,
+                                                            const uint16_t* __restrict__ b, int dim, float eps,
+                                                            float w_offset)
+{
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    const uint16_t* x = X + row * dim;
+    uint16_t* y = Y + row * dim;
+    const float rstd = rms_rstd_block256(x, dim, eps, red);
+    if (threadIdx.x == 0 && rstd_out) rstd_out[row] = f32_to_bf16_bits(rstd);
+    for (int i = threadIdx.x; i < dim / 8; i += 256)
+    {
+        const u32x4 xv = ld16(x + (size_t)i * 8);
+        u32x4 r;
+        if (w == nullptr) r = rms_apply8_now(xv, rstd);
+        else if (b == nullptr) r = rms_apply8(xv, ld16(w + (size_t)i * 8), rstd, w_offset);
+        else r = rms_apply8_bias(xv, ld16(w + (size_t)i * 8), ld16(b + (size_t)i * 8), rstd, w_offset);
+        st16(y + (size_t)i * 8, r);
+    }
+}
+
+// wave per row, 4 rows per workgroup
+__global__ __launch_bounds__(256) void rmsnorm_wave_kernel(uint16_t* __restrict__ Y, uint16_t* __restrict__ rstd_out,
+                                                           const uint16_t* __restrict__ X,
+                                                           const uint16_t* __restrict__ w,
+                                                           const uint16_t* __restrict__ b, int rows, int dim,
+                                                           float eps, float w_offset)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const uint16_t* x = X + (size_t)row * dim;
+    uint16_t* y = Y + (size_t)row * dim;
+    const float rstd = rms_rstd_wave(x, dim, eps);
+    if (lane == 0 && rstd_out) rstd_out[row] = f32_to_bf16_bits(rstd);
+    for (int i = lane; i < dim / 8; i += 64)
+    {
+        const u32x4 xv = ld16(x + (size_t)i * 8);
+        u32x4 r;
+        if (w == nullptr) r = rms_apply8_now(xv, rstd);
+        else if (b == nullptr) r = rms_apply8(xv, ld16(w + (size_t)i * 8), rstd, w_offset);
+        else r = rms_apply8_bias(xv, ld16(w + (size_t)i * 8), ld16(b + (size_t)i * 8), rstd, w_offset);
+        st16(y + (size_t)i * 8, r);
+    }
+}
+
+// generic: slice = (outer, inner), elements strided by `inner`; wave per slice
+__global__ __launch_bounds__(256) void rmsnorm_strided_kernel(uint16_t* __restrict__ Y, uint16_t* __restrict__ rstd_out,
+                                                              const uint16_t* __restrict__ X,
+                                                              const uint16_t* __restrict__ w,
+                                                              const uint16_t* __restrict__ b, int slices, int dim,
+                                                              int inner, float eps, float w_offset)
+{
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= slices) return;
+    const int lane = threadIdx.x & 63;
+    const size_t base = (size_t)(idx / inner) * dim * inner + (idx % inner);
+    float ss = 0.0f;
+    for (int i = lane; i < dim; i += 64)
+    {
+        const float v = bf16_bits_to_f32(X[base + (size_t)i * inner]);
+        ss = fmaf(v, v, ss);
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)dim + eps);
+    if (lane == 0 && rstd_out) rstd_out[idx] = f32_to_bf16_bits(rstd);
+    for (int i = lane; i < dim; i += 64)
+    {
+        const float xv = bf16_bits_to_f32(X[base + (size_t)i * inner]);
+        const float ww = w ? bf16_bits_to_f32(w[i]) : 1.0f;
+        const float bb = b ? bf16_bits_to_f32(b[i]) : 0.0f;
+        Y[base + (size_t)i * inner] = f32_to_bf16_bits(rms_apply1(xv, ww, rstd, w ? w_offset : 0.0f, bb));
+    }
+}
+
+// ---- LayerNorm (row contiguous); T = float or bf16 bits ----------------------------------------
+template <typename T> __device__ __forceinline__ float load_f(const T* p, size_t i);
+template <> __device__ __forceinline__ float load_f<float>(const float* p, size_t i) { return p[i]; }
+template <> __device__ __forceinline__ float load_f<uint16_t>(const uint16_t* p, size_t i) { return bf16_bits_to_f32(p[i]); }
+template <typename T> __device__ __forceinline__ void store_f(T* p, size_t i, float v);
+template <> __device__ __forceinline__ void store_f<float>(float* p, size_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void store_f<uint16_t>(uint16_t* p, size_t i, float v) { p[i] = f32_to_bf16_bits(v); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(T* __restrict__ Y, float* __restrict__ mean_out,
+                                                        float* __restrict__ rstd_out, const T* __restrict__ X,
+                                                        const T* __restrict__ w, const T* __restrict__ b, int dim,
+                                                        float eps)
+{
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    const T* x = X + row * dim;
+    T* y = Y + row * dim;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < dim; i += 256) s += load_f(x, i);
+    const float mean = block_sum<4>(s, red) / (float)dim;
+    float v = 0.0f;
+    for (int i = threadIdx.x; i < dim; i += 256)
+    {
+        const float d = load_f(x, i) - mean;
+        v = fmaf(d, d, v);
+    }
+    const float var = block_sum<4>(v, red) / (float)dim;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (threadIdx.x == 0)
+    {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+    for (int i = threadIdx.x; i < dim; i += 256)
+    {
+        float n = rstd * (load_f(x, i) - mean);
+        if (w) n *= load_f(w, i);
+        if (b) n += load_f(b, i);
+        store_f(y, i, n);
+    }
+}
+
+// ---- Softmax along `dim` with stride `inner`; wave per slice -----------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_kernel(T* __restrict__ Y, const T* __restrict__ X, int slices, int dim,
+                                                      int inner)
+{
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= slices) return;
+    const int lane = threadIdx.x & 63;
+    const size_t base = (size_t)(idx / inner) * dim * inner + (idx % inner);
+    float m = -INFINITY;
+    for (int i = lane; i < dim; i += 64) m = fmaxf(m, load_f(X, base + (size_t)i * inner));
+    m = wave_max(m);
+    float s = 0.0f;
+    for (int i = lane; i < dim; i += 64) s += expf(load_f(X, base + (size_t)i * inner) - m);
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    for (int i = lane; i < dim; i += 64)
+        store_f(Y, base + (size_t)i * inner, expf(load_f(X, base + (size_t)i * inner) - m) * inv);
+}
+
+}  // namespace mila
+
+using namespace mila;
+
+extern "C" {
+
+int mila_cdna4_rmsnorm_bf16(uint16_t* Y, uint16_t* rstd, const uint16_t* X, const uint16_t* w, const uint16_t* b,
+                            int outer, int dim, int inner, float eps, float w_offset, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X, "rmsnorm_bf16: null pointer");
+    MILA_REQUIRE(outer > 0 && dim > 0 && inner > 0, "rmsnorm_bf16: outer/dim/inner must be positive (%d,%d,%d)", outer, dim, inner);
+    MILA_REQUIRE(!(b && !w), "rmsnorm_bf16: bias without weight is not a reference configuration");
+    hipStream_t s = as_stream(stream);
+    if (inner == 1 && dim % 8 == 0)
+    {
+        if (dim > 1024)
+            hipLaunchKernelGGL(rmsnorm_block_kernel, dim3(outer), dim3(256), 0, s, Y, rstd, X, w, b, dim, eps, w_offset);
+        else
+            hipLaunchKernelGGL(rmsnorm_wave_kernel, dim3(ceil_div(outer, 4)), dim3(256), 0, s, Y, rstd, X, w, b, outer,
+                               dim, eps, w_offset);
+    }
+    else
+    {
+        const int64_t slices = (int64_t)outer * inner;
+        MILA_REQUIRE(slices < (1ll << 31), "rmsnorm_bf16: too many slices");
+        hipLaunchKernelGGL(rmsnorm_strided_kernel, dim3(ceil_div(slices, 4)), dim3(256), 0, s, Y, rstd, X, w, b,
+                           (int)slices, dim, inner, eps, w_offset);
+    }
+    MILA_LAUNCH_CHECK("rmsnorm_bf16");
+}
+
+int mila_cdna4_layernorm_bf16(uint16_t* Y, float* mean, float* rstd, const uint16_t* X, const uint16_t* w,
+                              const uint16_t* b, int outer, int dim, float eps, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X, "layernorm_bf16: null pointer");
+    MILA_REQUIRE(outer > 0 && dim > 0, "layernorm_bf16: outer/dim must be positive (%d,%d)", outer, dim);
+    hipLaunchKernelGGL(layernorm_kernel<uint16_t>, dim3(outer), dim3(256), 0, as_stream(stream), Y, mean, rstd, X, w, b,
+                       dim, eps);
+    MILA_LAUNCH_CHECK("layernorm_bf16");
+}
+
+int mila_cdna4_layernorm_fp32(float* Y, float* mean, float* rstd, const float* X, const float* w, const float* b,
+                              int outer, int dim, float eps, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X, "layernorm_fp32: null pointer");
+    MILA_REQUIRE(outer > 0 && dim > 0, "layernorm_fp32: outer/dim must be positive (%d,%d)", outer, dim);
+    hipLaunchKernelGGL(layernorm_kernel<float>, dim3(outer), dim3(256), 0, as_stream(stream), Y, mean, rstd, X, w, b,
+                       dim, eps);
+    MILA_LAUNCH_CHECK("layernorm_fp32");
+}
+
+int mila_cdna4_softmax_fp32(float* Y, const float* X, int outer, int dim, int inner, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X, "softmax_fp32: null pointer");
+    MILA_REQUIRE(outer > 0 && dim > 0 && inner > 0, "softmax_fp32: outer/dim/inner must be positive");
+    const int64_t slices = (int64_t)outer * inner;
+    MILA_REQUIRE(slices < (1ll << 31), "softmax_fp32: too many slices");
+    hipLaunchKernelGGL(softmax_kernel<float>, dim3(ceil_div(slices, 4)), dim3(256), 0, as_stream(stream), Y, X,
+                       (int)slices, dim, inner);
+    MILA_LAUNCH_CHECK("softmax_fp32");
+}
+
+int mila_cdna4_softmax_bf16(uint16_t* Y, const uint16_t* X, int outer, int dim, int inner, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X, "softmax_bf16: null pointer");
+    MILA_REQUIRE(outer > 0 && dim > 0 && inner > 0, "softmax_bf16: outer/dim/inner must be positive");
+    const int64_t slices = (int64_t)outer * inner;
+    MILA_REQUIRE(slices < (1ll << 31), "softmax_bf16: too many slices");
+    hipLaunchKernelGGL(softmax_kernel<uint16_t>, dim3(ceil_div(slices, 4)), dim3(256), 0, as_stream(stream), Y, X,
+                       (int)slices, dim, inner);
+    MILA_LAUNCH_CHECK("softmax_bf16");
+}
+
+}  // extern "C"

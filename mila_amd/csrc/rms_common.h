@@ -1,0 +1,83 @@
+// Canonical RMSNorm arithmetic shared by the standalone kernels (norm.hip) and the fused decode
+// kernels (matvec.hip, fused.hip).  Fused and unfused paths call the SAME functions with the SAME
+// thread->element assignment, so their results are bit-identical (tests/test_fused_gpu.py).
+//
+// Arithmetic follows OPS/Normalizations/RmsNorm/Kernels/RmsNorm.Bf16.cu:47-72:
+//   rstd = rsqrtf(sum(x^2) / dim + eps);  y = bf16( x * rstd * (w + offset) + b ), all in fp32.
+#pragma once
+#include "common.h"
+
+namespace mila {
+
+__device__ __forceinline__ float sumsq8(const u32x4 v, float acc)
+{
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+    {
+        const float lo = bf16_lo(v[d]), hi = bf16_hi(v[d]);
+        acc = fmaf(lo, lo, acc);
+        acc = fmaf(hi, hi, acc);
+    }
+    return acc;
+}
+
+// 256-thread workgroup, row contiguous in global memory, dim % 8 == 0.  `red`: >= 4 floats of LDS.
+__device__ __forceinline__ float rms_rstd_block256(const uint16_t* __restrict__ x, int dim, float eps, float* red)
+{
+    float ss = 0.0f;
+    for (int i = threadIdx.x; i < dim / 8; i += 256) ss = sumsq8(ld16(x + (size_t)i * 8), ss);
+    ss = block_sum<4>(ss, red);
+    return rsqrtf(ss / (float)dim + eps);
+}
+// same, row already in LDS (16-byte units)
+__device__ __forceinline__ float rms_rstd_block256_lds(const u32x4* xs, int dim, float eps, float* red)
+{
+    float ss = 0.0f;
+    for (int i = threadIdx.x; i < dim / 8; i += 256) ss = sumsq8(xs[i], ss);
+    ss = block_sum<4>(ss, red);
+    return rsqrtf(ss / (float)dim + eps);
+}
+// one wave per row (dim <= 1024 rows: per-head q/k/v norms)
+__device__ __forceinline__ float rms_rstd_wave(const uint16_t* __restrict__ x, int dim, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    float ss = 0.0f;
+    for (int i = lane; i < dim / 8; i += 64) ss = sumsq8(ld16(x + (size_t)i * 8), ss);
+    ss = wave_sum(ss);
+    return rsqrtf(ss / (float)dim + eps);
+}
+
+__device__ __forceinline__ float rms_apply1(float x, float w, float rstd, float w_offset, float b)
+{
+    return x * rstd * (w + w_offset) + b;
+}
+// 8 elements: y = bf16(x * rstd * (w + off))
+__device__ __forceinline__ u32x4 rms_apply8(const u32x4 x, const u32x4 w, float rstd, float w_offset)
+{
+    u32x4 y;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+        y[d] = pack_bf16x2(rms_apply1(bf16_lo(x[d]), bf16_lo(w[d]), rstd, w_offset, 0.0f),
+                           rms_apply1(bf16_hi(x[d]), bf16_hi(w[d]), rstd, w_offset, 0.0f));
+    return y;
+}
+__device__ __forceinline__ u32x4 rms_apply8_bias(const u32x4 x, const u32x4 w, const u32x4 b, float rstd, float w_offset)
+{
+    u32x4 y;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+        y[d] = pack_bf16x2(rms_apply1(bf16_lo(x[d]), bf16_lo(w[d]), rstd, w_offset, bf16_lo(b[d])),
+                           rms_apply1(bf16_hi(x[d]), bf16_hi(w[d]), rstd, w_offset, bf16_hi(b[d])));
+    return y;
+}
+// no weight tensor: w == 1 (the reference kernel's `weight ? ... : 1.0f`)
+__device__ __forceinline__ u32x4 rms_apply8_now(const u32x4 x, float rstd)
+{
+    u32x4 y;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+        y[d] = pack_bf16x2(rms_apply1(bf16_lo(x[d]), 1.0f, rstd, 0.0f, 0.0f), rms_apply1(bf16_hi(x[d]), 1.0f, rstd, 0.0f, 0.0f));
+    return y;
+}
+
+}  // namespace mila

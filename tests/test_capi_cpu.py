@@ -1,0 +1,77 @@
+"""CPU-only checks of the drop-in boundary: the shared object builds for gfx950, loads, and exports
+every entry point include/mila_cdna4.h declares; argument validation rejects bad calls before any
+device work (the reference throws std::invalid_argument from the same checks)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from mila_amd import build, capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build()
+    return capi.load()
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mila_cdna4.h")).read()
+    return sorted(set(re.findall(r"MILA_API\s+[\w\s\*]+?\b(mila_cdna4_\w+)\s*\(", text)))
+
+
+def test_header_compiles_as_plain_c():
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c",
+                           os.path.join(ROOT, "include", "mila_cdna4.h")])
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared()
+    assert len(names) >= 45
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted("mila_cdna4_" + n for n in capi.EXPORTED) == names
+
+
+def test_code_object_targets_gfx950_only():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o",
+                          "--input=" + capi.LIB_PATH], capture_output=True, text=True).stdout
+    if not out.strip():
+        out = subprocess.run(["strings", "-n", "6", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+    assert "gfx942" not in out and "gfx90a" not in out and "sm_" not in out
+
+
+def test_validation_rejects_bad_arguments_without_touching_the_device(lib):
+    null = C.c_void_p(None)
+    one = C.c_void_p(16)     # never dereferenced: validation fails first
+    assert lib.mila_cdna4_matvec_bf16(null, one, one, null, 64, 8, null) == capi.MILA_E_INVALID_ARGUMENT
+    assert b"null pointer" in lib.mila_cdna4_last_error()
+    assert lib.mila_cdna4_matvec_bf16(one, one, one, null, 60, 8, null) == capi.MILA_E_INVALID_ARGUMENT
+    assert b"multiple of 8" in lib.mila_cdna4_last_error()
+    assert lib.mila_cdna4_matvec_bf16_qfp8(one, one, one, null, null, 64, 8, null) == capi.MILA_E_INVALID_ARGUMENT
+    assert lib.mila_cdna4_matvec_bf16_qfp4(one, one, one, one, null, 128, 8, 32, null) == capi.MILA_E_INVALID_ARGUMENT
+    assert lib.mila_cdna4_matvec_bf16_qfp4(one, one, one, one, null, 96, 8, 64, null) == capi.MILA_E_INVALID_ARGUMENT
+    assert lib.mila_cdna4_gemm_bf16(one, one, one, null, 4, 40, 8, null) == capi.MILA_E_INVALID_ARGUMENT
+    assert lib.mila_cdna4_quantize_fp4_per_group(one, one, one, 4, 100, 128, null) == capi.MILA_E_INVALID_ARGUMENT
+    assert lib.mila_cdna4_attn_decode_bf16(one, one, one, one, null, C.c_size_t(0), 1, 16, 3, 256, 64, 10, 0,
+                                           C.c_float(1.0), null) == capi.MILA_E_INVALID_ARGUMENT
+    assert lib.mila_cdna4_attn_decode_bf16(one, one, one, one, null, C.c_size_t(0), 1, 16, 8, 256, 64, 100, 0,
+                                           C.c_float(1.0), null) == capi.MILA_E_INVALID_ARGUMENT   # band > capacity
+    assert lib.mila_cdna4_rmsnorm_bf16(one, null, null, one, null, 1, 8, 1, C.c_float(1e-6), C.c_float(0), null) \
+        == capi.MILA_E_INVALID_ARGUMENT
+    assert lib.mila_cdna4_rope_forward_bf16(one, null, one, null, one, one, 1, 4, 2, 1, 64, 30, 32, null) \
+        == capi.MILA_E_INVALID_ARGUMENT
+    assert lib.mila_cdna4_abi_version() == 1
+    assert lib.mila_cdna4_attn_decode_scratch_bytes(1, 16, 512) == 16 * 64 * 514 * 4
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no fallback"):
+        capi.load()

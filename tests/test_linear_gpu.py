@@ -1,0 +1,324 @@
+"""GPU parity: Linear hot path (decode matvec x3 formats, quantize-on-load, prefill GEMM) against the
+CPU oracle, through the C ABI.  Reference scenarios: Tests/Dnn/Components/Linear/Linear.Cuda.cpp.
+
+Bars: integer outputs (fp8 bytes, fp4 nibbles, scales) bit-exact; bf16 outputs within 1 bf16 ulp of
+the float64 oracle fed the identical bf16-rounded operands (or within an absolute slack of
+2^-17 * sum|x||w| when heavy cancellation makes the result tiny); fp32 logits within 1e-3 relative
+(north star).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import orc
+from gpu_util import (assert_bf16_close, bits, dev_f32, dev_u16, dev_u8, empty_f32, empty_u16, empty_u8,
+                      host, rel_err)
+from mila_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights(rng, N, K, kind):
+    if kind == "closed_form":   # Linear.Cuda.cpp:70-75
+        o = np.arange(N)[:, None]
+        i = np.arange(K)[None, :]
+        W = (np.float32(0.1) * (((o * 13 + i * 7) % 17).astype(np.float32) - 8.0) / 17.0).astype(np.float32)
+    else:
+        W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    return orc.to_bf16_bits(W)
+
+
+def _slack(x, Wf):
+    return float(2.0 ** -17 * (np.abs(x).astype(np.float64) @ np.abs(Wf).astype(np.float64).T).max())
+
+
+def test_hardware_fp8_fp4_converts_match_the_reference_luts():
+    """v_cvt_scalef32_pk_bf16_{fp8,fp4} with scale 1.0 == the reference decode tables, every byte,
+    every byte position (OPS/Linear/Kernels/MatVec/CudaMatVecBias.Bf16.cu:20-25; Linear.Cuda.cpp:929)."""
+    o8, o4 = empty_f32(4 * 256), empty_f32(4 * 512)
+    capi.call("selftest_decode", o8, o4)
+    o8, o4 = host(o8).reshape(4, 256), host(o4).reshape(4, 512)
+    lut8 = orc.E4M3_LUT
+    for pos in range(4):
+        fin = ~np.isnan(lut8)
+        assert np.array_equal(o8[pos][fin], lut8[fin]), "fp8 byte position %d" % pos
+        assert np.all(np.isnan(o8[pos][~fin]))
+        exp = np.empty(512, np.float32)
+        exp[0::2] = orc.E2M1_LUT[np.arange(256) & 0xf]       # low nibble = even column
+        exp[1::2] = orc.E2M1_LUT[np.arange(256) >> 4]
+        assert np.array_equal(o4[pos], exp), "fp4 byte position %d" % pos
+
+
+@pytest.mark.parametrize("K,N", [(3840, 256), (64, 32), (4096, 77), (15360, 48), (8, 1), (8192, 130)])
+@pytest.mark.parametrize("kind", ["random", "closed_form"])
+@pytest.mark.parametrize("bias", [False, True])
+def test_matvec_bf16(K, N, kind, bias):
+    rng = np.random.default_rng(K * 7 + N)
+    Wb = _weights(rng, N, K, kind)
+    x = orc.round_bf16(rng.uniform(-1, 1, K).astype(np.float32))
+    bb = orc.to_bf16_bits(rng.uniform(-0.1, 0.1, N).astype(np.float32)) if bias else None
+    y = empty_u16(N)
+    capi.call("matvec_bf16", y, dev_u16(orc.to_bf16_bits(x)), dev_u16(Wb), dev_u16(bb) if bias else None, K, N)
+    exp = orc.linear_bf16w(x[None], Wb, bb)[0]
+    assert_bf16_close(bits(y), exp, 1, _slack(x, orc.from_bf16_bits(Wb)), "matvec_bf16")
+
+
+@pytest.mark.parametrize("K,N", [(3840, 256), (64, 32), (4096, 77), (15360, 48), (16, 3)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_matvec_fp8(K, N, bias):
+    rng = np.random.default_rng(K * 3 + N)
+    q, s = orc.quantize_fp8_per_channel(_weights(rng, N, K, "random"))
+    x = orc.round_bf16(rng.uniform(-1, 1, K).astype(np.float32))
+    bb = orc.to_bf16_bits(rng.uniform(-0.1, 0.1, N).astype(np.float32)) if bias else None
+    y = empty_u16(N)
+    capi.call("matvec_bf16_qfp8", y, dev_u16(orc.to_bf16_bits(x)), dev_u8(q), dev_f32(s), dev_u16(bb) if bias else None, K, N)
+    exp = orc.linear_fp8w(x[None], q, s, bb)[0]
+    assert_bf16_close(bits(y), exp, 1, _slack(x, orc.dequant_fp8(q, s)), "matvec_fp8")
+
+
+@pytest.mark.parametrize("K,N,G", [(3840, 256, 128), (128, 32, 128), (4096, 77, 64), (15360, 48, 128), (64, 5, 64),
+                                   (8192, 40, 128)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_matvec_fp4(K, N, G, bias):
+    rng = np.random.default_rng(K * 5 + N)
+    q, s = orc.quantize_fp4_per_group(_weights(rng, N, K, "random"), G)
+    x = orc.round_bf16(rng.uniform(-1, 1, K).astype(np.float32))
+    bb = orc.to_bf16_bits(rng.uniform(-0.1, 0.1, N).astype(np.float32)) if bias else None
+    y = empty_u16(N)
+    capi.call("matvec_bf16_qfp4", y, dev_u16(orc.to_bf16_bits(x)), dev_u8(q), dev_f32(s), dev_u16(bb) if bias else None, K, N, G)
+    exp = orc.linear_fp4w(x[None], q, s, G, bb)[0]
+    assert_bf16_close(bits(y), exp, 1, _slack(x, orc.dequant_fp4(q, s, G)), "matvec_fp4")
+
+
+@pytest.mark.parametrize("R,U", [(1, 1), (1, 4), (2, 1), (2, 2), (2, 4), (4, 1), (4, 2)])
+def test_matvec_every_launch_shape_gives_the_same_answer(R, U):
+    """rows-per-wave / unroll variants and a tiny grid (grid-stride path) are all parity-checked."""
+    rng = np.random.default_rng(R * 10 + U)
+    K, N, G = 3840, 203, 128
+    Wb = _weights(rng, N, K, "random")
+    q8, s8 = orc.quantize_fp8_per_channel(Wb)
+    q4, s4 = orc.quantize_fp4_per_group(Wb, G)
+    x = orc.round_bf16(rng.uniform(-1, 1, K).astype(np.float32))
+    xd = dev_u16(orc.to_bf16_bits(x))
+    lib = capi.load()
+    try:
+        lib.mila_cdna4_tune_matvec(R, U, 3)
+        y = empty_u16(N)
+        capi.call("matvec_bf16", y, xd, dev_u16(Wb), None, K, N)
+        assert_bf16_close(bits(y), orc.linear_bf16w(x[None], Wb)[0], 1, 1e-5, "bf16 R%d U%d" % (R, U))
+        capi.call("matvec_bf16_qfp8", y, xd, dev_u8(q8), dev_f32(s8), None, K, N)
+        assert_bf16_close(bits(y), orc.linear_fp8w(x[None], q8, s8)[0], 1, 1e-5, "fp8 R%d U%d" % (R, U))
+        capi.call("matvec_bf16_qfp4", y, xd, dev_u8(q4), dev_f32(s4), None, K, N, G)
+        assert_bf16_close(bits(y), orc.linear_fp4w(x[None], q4, s4, G)[0], 1, 1e-5, "fp4 R%d U%d" % (R, U))
+    finally:
+        lib.mila_cdna4_tune_matvec(0, 0, 0)
+
+
+@pytest.mark.parametrize("fmt", [0, 1, 2])
+def test_fp32_logits_within_1e3_relative(fmt):
+    """North-star bar: lm_head logits in fp32 within 1e-3 relative of the reference arithmetic."""
+    rng = np.random.default_rng(fmt)
+    K, N, G = 3840, 4096, 128
+    Wb = _weights(rng, N, K, "random")
+    x = orc.round_bf16(rng.uniform(-1, 1, K).astype(np.float32))
+    y = empty_f32(N)
+    xd = dev_u16(orc.to_bf16_bits(x))
+    if fmt == 0:
+        capi.call("matvec_f32out", y, xd, dev_u16(Wb), None, 0, K, N, 0)
+        exp = orc.linear_bf16w(x[None], Wb)[0]
+    elif fmt == 1:
+        q, s = orc.quantize_fp8_per_channel(Wb)
+        capi.call("matvec_f32out", y, xd, dev_u8(q), dev_f32(s), 1, K, N, 0)
+        exp = orc.linear_fp8w(x[None], q, s)[0]
+    else:
+        q, s = orc.quantize_fp4_per_group(Wb, G)
+        capi.call("matvec_f32out", y, xd, dev_u8(q), dev_f32(s), 2, K, N, G)
+        exp = orc.linear_fp4w(x[None], q, s, G)[0]
+    assert rel_err(host(y), exp) < 1e-5        # measured margin; the stated bar is 1e-3
+    assert rel_err(host(y), exp) < 1e-3
+
+
+@pytest.mark.parametrize("K,N", [(3840, 262144), (15360, 3840), (3840, 30720)])
+def test_matvec_full_size_exact_integer_property(K, N):
+    """BASELINE.json sizes (lm_head, fc_down, fc_gate_up): small-integer operands make every
+    partial sum exact in fp32, so the result must equal the exact integer dot product -- a
+    size-independent, bit-exact check of the indexing over the whole weight matrix."""
+    g = torch.Generator(device="cuda").manual_seed(K + N)
+    Wi = torch.randint(-2, 3, (N, K), device="cuda", generator=g, dtype=torch.int32)
+    xi = torch.randint(-1, 2, (K,), device="cuda", generator=g, dtype=torch.int32)
+    exact = (Wi.to(torch.float32) @ xi.to(torch.float32))          # |sum| <= 2*15360 < 2^24: exact
+    W = Wi.to(torch.bfloat16).view(torch.int16).contiguous()
+    x = xi.to(torch.bfloat16).view(torch.int16).contiguous()
+    y = empty_f32(N)
+    capi.call("matvec_f32out", y, x, W, None, 0, K, N, 0)
+    assert torch.equal(y, exact)
+    # fp8: the same integers are exactly representable in E4M3; per-channel scale 0.5 is exact too
+    W8 = Wi.to(torch.float32).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+    s = torch.full((N,), 0.5, device="cuda")
+    capi.call("matvec_f32out", y, x, W8, s, 1, K, N, 0)
+    assert torch.equal(y, exact * 0.5)
+    # fp4: nibbles for {-2,-1,0,1,2} are {0xC,0xA,0,2,4}; group scale 2.0
+    lut = torch.tensor([0xC, 0xA, 0x0, 0x2, 0x4], device="cuda", dtype=torch.uint8)
+    nib = lut[(Wi + 2).long()]
+    W4 = (nib[:, 0::2] | (nib[:, 1::2] << 4)).contiguous()
+    s4 = torch.full((N, K // 128), 2.0, device="cuda")
+    capi.call("matvec_f32out", y, x, W4, s4, 2, K, N, 128)
+    assert torch.equal(y, exact * 2.0)
+
+
+# ---- quantize-on-load: bit-exact ----------------------------------------------------------------------
+def _quant_inputs(rng, N, K):
+    W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    W[1] = 0.0                                   # all-zero channel -> scale 1
+    W[2, : K // 2] *= 1e-3                       # tiny values -> fp8 subnormals
+    W[3] *= 1e4                                  # large magnitudes
+    W[4, 5] = -0.0
+    W[5, :] = np.linspace(-1, 1, K)              # ties / breakpoints sweep
+    return orc.to_bf16_bits(W)
+
+
+@pytest.mark.parametrize("N,K", [(32, 64), (64, 3840), (16, 15360), (7, 4096)])
+def test_quantize_fp8_per_channel_bit_exact(N, K):
+    Wb = _quant_inputs(np.random.default_rng(N + K), N, K)
+    q, s = empty_u8(N, K), empty_f32(N)
+    capi.call("quantize_fp8_per_channel", q, s, dev_u16(Wb), N, K)
+    eq, es = orc.quantize_fp8_per_channel(Wb)
+    assert np.array_equal(host(s).view(np.uint32), es.view(np.uint32)), "scales differ"
+    assert np.array_equal(host(q), eq), "fp8 bytes differ"
+
+
+@pytest.mark.parametrize("N,K,G", [(32, 128, 128), (64, 3840, 128), (16, 15360, 128), (7, 4096, 64)])
+def test_quantize_fp4_per_group_bit_exact(N, K, G):
+    Wb = _quant_inputs(np.random.default_rng(N + K + G), N, K)
+    q, s = empty_u8(N, K // 2), empty_f32(N, K // G)
+    capi.call("quantize_fp4_per_group", q, s, dev_u16(Wb), N, K, G)
+    eq, es = orc.quantize_fp4_per_group(Wb, G)
+    assert np.array_equal(host(s).view(np.uint32), es.view(np.uint32)), "scales differ"
+    assert np.array_equal(host(q), eq), "packed nibbles differ"
+
+
+def test_quantize_every_bf16_value_fp8_and_fp4_codes():
+    """Exhaustive over all finite bf16 inputs in one row per scale regime: the encoders agree
+    with the oracle on every representable input (rounding ties, subnormals, saturation)."""
+    allb = np.arange(0x10000, dtype=np.uint32).astype(np.uint16)
+    f = orc.from_bf16_bits(allb)
+    keep = np.isfinite(f) & (np.abs(f) < 1e30)
+    vals = allb[keep]
+    K = 65536
+    row = np.zeros(K, np.uint16)
+    row[: vals.size] = vals
+    rows = []
+    for cap in (1e30, 448.0, 6.0, 1.0, 1e-3):
+        r = row.copy()
+        fr = orc.from_bf16_bits(r)
+        r[np.abs(fr) > cap] = 0
+        rows.append(r)
+    Wb = np.stack(rows)
+    N = Wb.shape[0]
+    q, s = empty_u8(N, K), empty_f32(N)
+    capi.call("quantize_fp8_per_channel", q, s, dev_u16(Wb), N, K)
+    eq, es = orc.quantize_fp8_per_channel(Wb)
+    assert np.array_equal(host(s).view(np.uint32), es.view(np.uint32))
+    assert np.array_equal(host(q), eq)
+    q4, s4 = empty_u8(N, K // 2), empty_f32(N, K // 128)
+    capi.call("quantize_fp4_per_group", q4, s4, dev_u16(Wb), N, K, 128)
+    eq4, es4 = orc.quantize_fp4_per_group(Wb, 128)
+    assert np.array_equal(host(s4).view(np.uint32), es4.view(np.uint32))
+    assert np.array_equal(host(q4), eq4)
+
+
+def test_quantize_then_matvec_reference_reconstruction_bar():
+    """Linear.Cuda.cpp:1046: stored FP8 weight * scale reconstructs w within 0.08|w| + 1e-3."""
+    N, K = 32, 64
+    Wb = _weights(np.random.default_rng(0), N, K, "closed_form")
+    q, s = empty_u8(N, K), empty_f32(N)
+    capi.call("quantize_fp8_per_channel", q, s, dev_u16(Wb), N, K)
+    rec = orc.E4M3_LUT[host(q)] * host(s)[:, None]
+    W = orc.from_bf16_bits(Wb)
+    assert np.all(np.abs(rec - W) <= 0.08 * np.abs(W) + 1e-3)
+
+
+# ---- prefill GEMM -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N", [(128, 64, 128), (256, 768, 384), (77, 3840, 200), (2, 64, 32), (300, 1024, 130),
+                                   (16, 4096, 256)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_gemm_bf16(M, K, N, bias):
+    rng = np.random.default_rng(M + K + N)
+    Wb = _weights(rng, N, K, "random")
+    X = orc.round_bf16(rng.uniform(-1, 1, (M, K)).astype(np.float32))
+    bb = orc.to_bf16_bits(rng.uniform(-0.1, 0.1, N).astype(np.float32)) if bias else None
+    Y = empty_u16(M, N)
+    capi.call("gemm_bf16", Y, dev_u16(orc.to_bf16_bits(X)), dev_u16(Wb), dev_u16(bb) if bias else None, M, K, N)
+    exp = orc.linear_bf16w(X, Wb, None)
+    if bias:   # reference prefill order: round the GEMM to bf16, then add bias (cuda_add_bias)
+        exp = orc.round_bf16(exp).astype(np.float64) + orc.from_bf16_bits(bb).astype(np.float64)
+    assert_bf16_close(bits(Y), exp, 1 if not bias else 2, _slack(X, orc.from_bf16_bits(Wb)), "gemm_bf16")
+
+
+@pytest.mark.parametrize("M,K,N", [(128, 64, 128), (200, 3840, 136), (33, 256, 64)])
+def test_gemm_fp8_and_fp4_weights_match_dequantize_then_gemm(M, K, N):
+    """2-phase reference semantics (CudaLinearOp.ixx:597-644, :716-764): weights rounded to bf16
+    after dequantization, then a bf16 GEMM with fp32 accumulation."""
+    rng = np.random.default_rng(M * K + N)
+    Wb = _weights(rng, N, K, "random")
+    X = orc.round_bf16(rng.uniform(-1, 1, (M, K)).astype(np.float32))
+    Xd = dev_u16(orc.to_bf16_bits(X))
+    Y = empty_u16(M, N)
+    q8, s8 = orc.quantize_fp8_per_channel(Wb)
+    capi.call("gemm_bf16_w8a16", Y, Xd, dev_u8(q8), dev_f32(s8), None, M, K, N)
+    W8 = orc.to_bf16_bits(orc.dequant_fp8(q8, s8))
+    assert_bf16_close(bits(Y), orc.linear_bf16w(X, W8), 1, _slack(X, orc.from_bf16_bits(W8)), "gemm w8a16")
+    G = 128 if K % 128 == 0 else 64
+    q4, s4 = orc.quantize_fp4_per_group(Wb, G)
+    capi.call("gemm_bf16_w4a16", Y, Xd, dev_u8(q4), dev_f32(s4), None, M, K, N, G)
+    W4 = orc.to_bf16_bits(orc.dequant_fp4(q4, s4, G))
+    assert_bf16_close(bits(Y), orc.linear_bf16w(X, W4), 1, _slack(X, orc.from_bf16_bits(W4)), "gemm w4a16")
+    # reference's own cross-path bar: prefill vs decode within 1e-1 * row absmax (Linear.Cuda.cpp:760-774)
+    y1 = empty_u16(N)
+    capi.call("matvec_bf16_qfp4", y1, Xd[0].contiguous(), dev_u8(q4), dev_f32(s4), None, K, N, G)
+    a = orc.from_bf16_bits(bits(Y)[0])
+    b = orc.from_bf16_bits(bits(y1))
+    assert np.abs(a - b).max() <= 1e-1 * np.abs(b).max()
+
+
+def test_gemm_identity_times_asymmetric_matrix_catches_transposed_tiles():
+    """A = I against an asymmetric B: any row/col swap in the MFMA output mapping shows up."""
+    M = K = 256
+    N = 192
+    X = np.eye(M, K, dtype=np.float32)
+    W = (np.arange(N)[:, None] * 3 + np.arange(K)[None, :] * 0.25).astype(np.float32) / 64.0
+    Wb = orc.to_bf16_bits(W)
+    Y = empty_u16(M, N)
+    capi.call("gemm_bf16", Y, dev_u16(orc.to_bf16_bits(X)), dev_u16(Wb), None, M, K, N)
+    assert np.array_equal(bits(Y), Wb.T)
+
+
+def test_gemm_full_prefill_shape_linearity_property():
+    """Config-3 shape (M=2048, K=3840, N=8192): GEMM(X) rows equal the decode matvec of each row
+    (spot rows), and integer operands give the exact integer product everywhere."""
+    M, K, N = 2048, 3840, 8192
+    g = torch.Generator(device="cuda").manual_seed(1)
+    Wi = torch.randint(-2, 3, (N, K), device="cuda", generator=g, dtype=torch.int32).to(torch.float32)
+    Xi = torch.randint(-1, 2, (M, K), device="cuda", generator=g, dtype=torch.int32).to(torch.float32)
+    exact = Xi @ Wi.T                                   # |.| <= 7680: exact in fp32, and every
+    W = Wi.to(torch.bfloat16).view(torch.int16).contiguous()      # integer <= 256*... may round in bf16
+    X = Xi.to(torch.bfloat16).view(torch.int16).contiguous()
+    Y = empty_u16(M, N)
+    capi.call("gemm_bf16", Y, X, W, None, M, K, N)
+    torch.cuda.synchronize()
+    assert torch.equal(Y.view(torch.bfloat16), exact.to(torch.bfloat16))
+
+
+# ---- error behaviour (reference: std::invalid_argument from the op constructors / build) ---------------
+def test_invalid_arguments_are_reported_not_launched():
+    y = empty_u16(8)
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("matvec_bf16", y, y, y, None, 12, 8)           # K % 8
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("matvec_bf16_qfp4", y, y, y, y, None, 128, 8, 32)   # group size
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("matvec_bf16", None, y, y, None, 8, 8)
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("quantize_fp4_per_group", y, y, y, 2, 100, 128)

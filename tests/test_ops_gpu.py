@@ -1,0 +1,191 @@
+"""GPU parity: normalisation, activations, RoPE, glue kernels against the CPU oracle via the C ABI.
+Reference scenarios and tolerances: Tests/Dnn/Components/{Normalization,Activations,Encodings,
+Embeddings,Connections}/**.Cuda.cpp (BF16 bar 5e-2 + 5e-2|y|; this build's bar: <= 1 bf16 ulp of the
+float64 oracle on identical bf16-rounded operands; integer/indexing outputs bit-exact)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+from gpu_util import (assert_bf16_close, bits, dev_f32, dev_i32, dev_u16, empty_f32, empty_u16, host)
+from mila_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return orc.round_bf16(np.asarray(x, dtype=np.float32))
+
+
+def _d(x):
+    return dev_u16(orc.to_bf16_bits(x))
+
+
+@pytest.mark.parametrize("outer,dim", [(6, 8), (5, 3840), (64, 256), (33, 512), (3, 1024), (2, 15360), (7, 24)])
+@pytest.mark.parametrize("mode", ["gemma", "bias", "unit_offset", "noweight"])
+def test_rmsnorm_rows(outer, dim, mode):
+    rng = np.random.default_rng(outer * dim)
+    X = _bf(rng.standard_normal((outer, dim)) * 3)
+    w = _bf(1 + 0.1 * rng.uniform(-1, 1, dim))
+    b = _bf(0.05 * rng.uniform(-1, 1, dim))
+    eps, off = (1e-6, 0.0) if mode == "gemma" else (1e-5, 1.0 if mode == "unit_offset" else 0.0)
+    use_w = mode != "noweight"
+    use_b = mode == "bias"
+    Y, rstd = empty_u16(outer, dim), empty_u16(outer)
+    capi.call("rmsnorm_bf16", Y, rstd, _d(X), _d(w) if use_w else None, _d(b) if use_b else None, outer, dim, 1,
+              eps, off)
+    exp, er = orc.rmsnorm(X, w if use_w else None, b if use_b else None, eps=eps, w_offset=off, return_rstd=True)
+    assert_bf16_close(bits(Y), exp, 1, 1e-30, "rmsnorm %s" % mode)
+    assert_bf16_close(bits(rstd), er, 1, 0, "rstd")
+
+
+def test_rmsnorm_strided_inner_axis():
+    rng = np.random.default_rng(5)
+    X = _bf(rng.standard_normal((3, 40, 6)))
+    w = _bf(1 + 0.1 * rng.uniform(-1, 1, 40))
+    Y = empty_u16(3, 40, 6)
+    capi.call("rmsnorm_bf16", Y, None, _d(X), _d(w), None, 3, 40, 6, 1e-5, 0.0)
+    assert_bf16_close(bits(Y), orc.rmsnorm(X, w, None, eps=1e-5, inner=6), 1, 0, "rmsnorm strided")
+
+
+@pytest.mark.parametrize("outer,dim", [(6, 8), (25, 768), (3, 1000)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_layernorm_bf16_and_fp32(outer, dim, bias):
+    rng = np.random.default_rng(dim)
+    X = _bf(rng.standard_normal((outer, dim)) * 2 + 0.25)
+    w = _bf(0.5 + 0.1 * rng.uniform(-1, 1, dim))
+    b = _bf(0.05 * rng.uniform(-1, 1, dim)) if bias else None
+    exp, em, er = orc.cpu_layernorm(X, w, b, 1e-5, return_stats=True)
+    Y, mean, rstd = empty_u16(outer, dim), empty_f32(outer), empty_f32(outer)
+    capi.call("layernorm_bf16", Y, mean, rstd, _d(X), _d(w), _d(b) if bias else None, outer, dim, 1e-5)
+    assert_bf16_close(bits(Y), exp, 1, 1e-6, "layernorm_bf16")
+    np.testing.assert_allclose(host(mean), em, atol=1e-5)
+    np.testing.assert_allclose(host(rstd), er, rtol=1e-5)
+    Yf = empty_f32(outer, dim)
+    capi.call("layernorm_fp32", Yf, mean, rstd, dev_f32(X), dev_f32(w), dev_f32(b) if bias else None, outer, dim, 1e-5)
+    np.testing.assert_allclose(host(Yf), exp, atol=1e-4, rtol=0)      # the reference's CPU-test bar
+
+
+@pytest.mark.parametrize("shape,axis", [((3, 4, 5), -1), ((3, 4, 5), 1), ((2, 1024), -1), ((8, 50257), -1)])
+def test_softmax(shape, axis):
+    rng = np.random.default_rng(len(shape) + shape[-1])
+    X = (rng.standard_normal(shape) * 4).astype(np.float32)
+    ax = axis % len(shape)
+    outer = int(np.prod(shape[:ax], dtype=np.int64))
+    inner = int(np.prod(shape[ax + 1:], dtype=np.int64))
+    Y = empty_f32(*shape)
+    capi.call("softmax_fp32", Y, dev_f32(X), outer, shape[ax], inner)
+    exp = orc.cpu_softmax(X, axis)
+    np.testing.assert_allclose(host(Y), exp, atol=2e-7, rtol=1e-5)
+    np.testing.assert_allclose(host(Y).astype(np.float64).sum(axis=ax), 1.0, atol=1e-5)   # Softmax.Cpu.cpp:161
+    Xb = _bf(X)
+    Yb = empty_u16(*shape)
+    capi.call("softmax_bf16", Yb, _d(Xb), outer, shape[ax], inner)
+    assert_bf16_close(bits(Yb), orc.cpu_softmax(Xb, axis), 1, 1e-30, "softmax_bf16")
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 3072 * 5, 100003])
+def test_gelu_residual_scale(n):
+    rng = np.random.default_rng(n)
+    X = _bf(rng.standard_normal(n) * 3)
+    Z = _bf(rng.standard_normal(n))
+    Y = empty_u16(n)
+    capi.call("gelu_bf16", Y, _d(X), C.c_int64(n))
+    assert_bf16_close(bits(Y), orc.cpu_gelu(X), 1, 1e-30, "gelu_bf16")
+    Yf = empty_f32(n)
+    capi.call("gelu_fp32", Yf, dev_f32(X), C.c_int64(n))
+    np.testing.assert_allclose(host(Yf), orc.cpu_gelu(X), atol=1e-6, rtol=1e-5)
+    capi.call("residual_bf16", Y, _d(X), _d(Z), C.c_int64(n))
+    assert np.array_equal(bits(Y), orc.to_bf16_bits(X + Z))                 # exact: one fp32 add, RNE
+    capi.call("residual_fp32", Yf, dev_f32(X), dev_f32(Z), C.c_int64(n))
+    assert np.array_equal(host(Yf), orc.cpu_residual(X, Z))
+    s = float(np.sqrt(np.float32(3840.0)))
+    capi.call("scale_bf16", Y, _d(X), C.c_int64(n), s)
+    assert np.array_equal(bits(Y), orc.to_bf16_bits(X * np.float32(s)))     # static_cast<T>(float(x)*s)
+
+
+@pytest.mark.parametrize("tokens,half", [(3, 8), (1, 15360), (5, 1024)])
+def test_geglu(tokens, half):
+    rng = np.random.default_rng(half)
+    X = _bf(rng.standard_normal((tokens, 2 * half)) * 2)
+    Y = empty_u16(tokens, half)
+    capi.call("geglu_bf16", Y, _d(X), tokens, half)
+    assert_bf16_close(bits(Y), orc.geglu(X), 1, 1e-30, "geglu")
+
+
+@pytest.mark.parametrize("HS,base,rot", [(256, 1e4, 0), (512, 1e6, 128), (64, 1e4, 0), (8 * 2, 1e4, 4 * 2)])
+def test_rope_cache_and_rotation(HS, base, rot):
+    max_seq, B, T, NH, NKV, off = 96, 2, 5, 4, 2, 40
+    cos, sin = empty_f32(max_seq, HS // 2), empty_f32(max_seq, HS // 2)
+    capi.call("rope_build_cache", cos, sin, max_seq, HS, float(base), rot)
+    ec, es = orc.rope_build_cache(max_seq, HS, base, rot)
+    # fp32 angle = pos * theta is shared; cosf/sinf differ by <= a few ulp between libms
+    np.testing.assert_allclose(host(cos), ec, atol=3e-6, rtol=0)
+    np.testing.assert_allclose(host(sin), es, atol=3e-6, rtol=0)
+    if 0 < rot < HS:
+        assert np.all(host(cos)[:, rot // 2:] == 1.0) and np.all(host(sin)[:, rot // 2:] == 0.0)
+    rng = np.random.default_rng(HS)
+    Q = _bf(rng.standard_normal((B, T, NH, HS)))
+    K = _bf(rng.standard_normal((B, T, NKV, HS)))
+    Qo, Ko = empty_u16(B, T, NH, HS), empty_u16(B, T, NKV, HS)
+    capi.call("rope_forward_bf16", Qo, Ko, _d(Q), _d(K), cos, sin, B, T, NH, NKV, HS, off, max_seq)
+    # rotate with the DEVICE cache values so only the rotation arithmetic is compared
+    assert_bf16_close(bits(Qo), orc.rope_rotate(Q, host(cos), host(sin), off), 1, 1e-30, "rope q")
+    assert_bf16_close(bits(Ko), orc.rope_rotate(K, host(cos), host(sin), off), 1, 1e-30, "rope k")
+    # and end-to-end against the oracle's cache at the reference's BF16 bar (Rope.Cuda.cpp:107-113)
+    e2e = orc.rope_rotate(Q, ec, es, off)
+    got = orc.from_bf16_bits(bits(Qo)).reshape(e2e.shape)
+    assert np.all(np.abs(got - e2e) <= 5e-2 + 5e-2 * np.abs(e2e))
+    # in place (the component rotates in place: Components/Encodings/Rope/Rope.ixx:107)
+    Qi = _d(Q)
+    capi.call("rope_forward_bf16", Qi, None, Qi, None, cos, sin, B, T, NH, NKV, HS, off, max_seq)
+    assert np.array_equal(bits(Qi), bits(Qo))
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("rope_forward_bf16", Qo, None, _d(Q), None, cos, sin, B, T, NH, NKV, HS, max_seq - 2, max_seq)
+
+
+def test_embedding_gather_lpe_split3():
+    rng = np.random.default_rng(3)
+    V, Cn, maxT = 50, 64, 12
+    table = _bf(rng.standard_normal((V, Cn)))
+    tok = np.array([3, 49, 0, 3, 17], dtype=np.int32)
+    flag = dev_i32(np.zeros(1))
+    Y = empty_u16(tok.size, Cn)
+    capi.call("embedding_gather_bf16", Y, dev_i32(tok), _d(table), tok.size, Cn, V, 0.0, flag)
+    assert np.array_equal(bits(Y), orc.to_bf16_bits(table[tok]))                       # gather: bit-exact
+    s = float(np.sqrt(np.float32(Cn)))
+    capi.call("embedding_gather_bf16", Y, dev_i32(tok), _d(table), tok.size, Cn, V, s, flag)
+    assert np.array_equal(bits(Y), orc.to_bf16_bits(orc.embedding_gather(tok, table, s)))
+    assert host(flag)[0] == 0
+    bad = np.array([3, V, 1], dtype=np.int32)
+    capi.call("embedding_gather_bf16", Y, dev_i32(bad), _d(table), 3, Cn, V, 0.0, flag)
+    assert host(flag)[0] == 2                                                             # 1 + offending index
+
+    wpe = _bf(rng.standard_normal((maxT, Cn)))
+    tk = np.array([[1, 5, 10], [0, 3, 3]], dtype=np.int32)
+    Yl = dev_u16(np.zeros((2, maxT, Cn), np.uint16))
+    flag = dev_i32(np.zeros(1))
+    capi.call("lpe_bf16", Yl, dev_i32(tk), _d(table), _d(wpe), 2, 3, Cn, maxT, V, flag)
+    exp = orc.cpu_lpe(tk, table, wpe, out_T=maxT)
+    assert np.array_equal(bits(Yl), orc.to_bf16_bits(exp))
+    assert host(flag)[0] == 0
+
+    X = _bf(rng.standard_normal((4, 16 + 8 + 24)))
+    a, b, c = empty_u16(4, 16), empty_u16(4, 8), empty_u16(4, 24)
+    capi.call("split3_bf16", a, b, c, _d(X), 4, 16, 8, 24)
+    Xb = orc.to_bf16_bits(X)
+    assert np.array_equal(bits(a), Xb[:, :16]) and np.array_equal(bits(b), Xb[:, 16:24]) and np.array_equal(bits(c), Xb[:, 24:])
+    # Gemma global layers: q | k only (no v projection)
+    capi.call("split3_bf16", a, b, None, _d(X[:, :24]), 4, 16, 8, 0)
+    assert np.array_equal(bits(a), Xb[:, :16]) and np.array_equal(bits(b), Xb[:, 16:24])
+
+
+def test_convert_roundtrip():
+    x = (np.random.default_rng(1).standard_normal(10001) * 100).astype(np.float32)
+    y = empty_u16(x.size)
+    capi.call("convert_f32_to_bf16", y, dev_f32(x), C.c_int64(x.size))
+    assert np.array_equal(bits(y), orc.to_bf16_bits(x))
+    z = empty_f32(x.size)
+    capi.call("convert_bf16_to_f32", z, y, C.c_int64(x.size))
+    assert np.array_equal(host(z), orc.round_bf16(x))
