@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gemma-4 12B decode tok/s (+ prefill TFLOP/s) on MI355X for the three weight
+policies of BASELINE.json (bf16 / PerChannelFp8 / PerGroupFp4), with the roofline fraction of the
+dominant kernel and the restated reference CPU backend timed beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--policies bf16,fp8,fp4] [--no-prefill]
+
+A "step" is one decode token of the whole model (embedding -> 48 blocks -> final norm -> lm_head, fp32
+logits) at context 2048 with every weight resident in HBM, replayed from one captured hipGraph.  The
+path does not shard: with --gpus N every rank runs an independent replica on its
+own GPU; there is no data-path collective.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+CONTEXT = 2048                # BASELINE.json configs[2..4]: B=1, T=2048
+
+
+def cpu_baseline(cfg):
+    """Reference CPU backend restated (oracle/mila_oracle.c: CpuLinearOp::forwardNaive, the path the
+    reference takes at batch 1) on a bounded sample of one decode token's Linear work:
+    one local layer + one global layer + 1/64 of the lm_head rows, FP32, single thread (the reference
+    default: MILA_ENABLE_OPENMP is OFF).  Extrapolated to a whole token by weight count."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import orc
+    rng = np.random.default_rng(0)
+    D, H, V = cfg["embedding_dim"], cfg["hidden_dim"], cfg["vocab_size"]
+
+    def shapes(g):
+        hd = cfg["global_head_dim"] if g else cfg["head_dim"]
+        nkv = cfg["num_global_kv_heads"] if g else cfg["num_kv_heads"]
+        qw = cfg["num_heads"] * hd
+        return [(D, qw + (1 if g else 2) * nkv * hd), (qw, D), (D, 2 * H), (H, D)]
+
+    def time_shapes(shs, frac=1.0):
+        total, macs = 0.0, 0
+        for K, N in shs:
+            n = max(1, int(N * frac))
+            W = rng.standard_normal((n, K)).astype(np.float32)
+            x = rng.standard_normal((1, K)).astype(np.float32)
+            t0 = time.perf_counter()
+            orc.cpu_linear(x, W, None)          # batch 1 -> forwardNaive (long double accumulation)
+            total += time.perf_counter() - t0
+            macs += n * K
+        return total, macs
+
+    t_loc, m_loc = time_shapes(shapes(False))
+    t_glb, m_glb = time_shapes(shapes(True))
+    t_head, m_head = time_shapes([(D, V)], 1.0 / 64)
+    n_glb = sum(1 for i in range(cfg["num_layers"]) if (i + 1) % cfg["sliding_window_pattern"] == 0)
+    n_loc = cfg["num_layers"] - n_glb
+    token_s = t_loc * n_loc + t_glb * n_glb + t_head * 64
+    return {"value": round(1.0 / token_s, 5), "unit": "tok/s", "cores": 1, "kind": "port",
+            "sample": "restated CpuLinearOp::forwardNaive (FP32, long double acc) on 1 local + 1 global layer's 4 Linear "
+                      "shapes + 1/64 of lm_head rows (%.2f GMAC, %.1f s), extrapolated by weight count to 48 layers + head; "
+                      "the reference has no CPU RMSNorm/RoPE/GQA/GeGLU ops, they are <1%% of the work and not timed"
+                      % ((m_loc + m_glb + m_head) / 1e9, t_loc + t_glb + t_head),
+            "GFLOPs": round(2 * (m_loc + m_glb + m_head) / (t_loc + t_glb + t_head) / 1e9, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--policies", default="bf16,fp8,fp4")
+    ap.add_argument("--mode", default="graph", choices=["graph", "fused", "reference"])
+    ap.add_argument("--no-prefill", action="store_true", help="skip the timed T=2048 prefill (KV cache left zero-filled)")
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from mila_amd import capi, host
+    capi.load()
+    capi.check(capi.load().mila_cdna4_set_device(local_rank))
+    cfg = dict(host.GEMMA4_12B)
+    policies = [p for p in a.policies.split(",") if p]
+    results = {}
+    for pol in policies:
+        m = host.Gemma(pol, cfg, max_seq=CONTEXT + a.steps + a.warmup + 8, max_prefill=1 if a.no_prefill else CONTEXT, seed=1234)
+        info = m.info(CONTEXT)
+        r = {"weight_GB": round(info["weight_bytes"] / 1e9, 3), "bytes_per_token_GB": round(info["decode_bytes_per_token"] / 1e9, 3)}
+        if not a.no_prefill:
+            ms = m.time_prefill(CONTEXT, 1)
+            # algorithmic FLOPs: Linear 2*params*T + head (last position) + attention 4*NH*HS*sum(keys)
+            lin = 2.0 * info["linear_params"] * CONTEXT + 2.0 * info["table_params"]
+            att = 0.0
+            for i in range(cfg["num_layers"]):
+                g = (i + 1) % cfg["sliding_window_pattern"] == 0
+                hd = cfg["global_head_dim"] if g else cfg["head_dim"]
+                w = 0 if g else cfg["window"]
+                keys = sum(min(t + 1, w) if w else t + 1 for t in range(CONTEXT))
+                att += 4.0 * cfg["num_heads"] * hd * keys
+            r["prefill_ms"] = round(ms, 3)
+            r["prefill_TFLOPs"] = round((lin + att) / ms / 1e9, 2)
+            r["prefill_tok_s"] = round(CONTEXT / ms * 1e3, 1)
+            r["prefill_mfma_frac"] = round((lin + att) / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = m.time_decode(CONTEXT, a.steps, a.warmup, a.mode)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            tt = torch.tensor([t["wall_ms_per_step"]], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # timing only: max over ranks
+            t["wall_ms_per_step"] = float(tt.item())
+        k = m.time_dominant_kernel(3)
+        r.update({"ms_per_step": round(t["wall_ms_per_step"], 4), "device_ms_per_step": round(t["device_ms_per_step"], 4),
+                  "tok_s": round(1e3 / t["wall_ms_per_step"], 2),
+                  "token_roofline_frac": round(info["decode_bytes_per_token"] / (t["wall_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                  "dominant_kernel": {"name": "matvec_kernel<fmt,R,U,PRO=2,GEGLU> (fc_gate_up)", "avg_us": round(k["avg_us"], 3),
+                                      "bytes": k["bytes"], "GBps": round(k["bytes"] / k["avg_us"] / 1e3, 1)}})
+        results[pol] = r
+        m.close()
+        del m
+
+    head = results[policies[0]]
+    out = {
+        "metric": "Gemma-4 12B decode tok/s (B=1, context 2048), 1xMI355X",
+        "value": round(head["tok_s"] * world, 2), "unit": "tok/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"bf16": "bf16", "fp8": "bf16 activations x fp8_e4m3 weights", "fp4": "bf16 activations x fp4_e2m1 weights"}[policies[0]],
+        "data": "synthetic (counter-based uniform weights, random-init architecture; KV cache filled by a T=2048 prefill)",
+        "config": {"workload": "Gemma-4 12B, weight policy %s, B=1, prefill T=2048 then decode at positions 2048.." % policies[0],
+                   "decode_mode": a.mode, "replicas": world, "parallelism": "replicas only (no collective)"},
+        "roofline": {"bound": "hbm", "achieved": head["dominant_kernel"]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(head["dominant_kernel"]["GBps"] / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "kernel": head["dominant_kernel"]["name"], "avg_us": head["dominant_kernel"]["avg_us"],
+                     "algorithmic_bytes_per_launch": head["dominant_kernel"]["bytes"],
+                     "whole_token_frac": head["token_roofline_frac"]},
+        "policies": results,
+    }
+    if rank == 0:
+        if not a.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -200,6 +200,11 @@ MILA_API int mila_cdna4_rope_forward_bf16(uint16_t* Qout, uint16_t* Kout, const 
 MILA_API int mila_cdna4_embedding_gather_bf16(uint16_t* Y, const int32_t* tokens, const uint16_t* table,
                                               int n_tok, int C, int vocab, float scale,
                                               int32_t* error_flag, mila_stream_t stream);
+/* FP8 tied embedding/lm_head table with one fp32 scale per vocab row
+ * (Embeddings/Kernels/TokenEmbedding.Fp8.cu:33-69): y = bf16(float(e4m3) * row_scale[tok]) [* scale] */
+MILA_API int mila_cdna4_embedding_gather_bf16_qfp8(uint16_t* Y, const int32_t* tokens, const uint8_t* table,
+                                                   const float* row_scales, int n_tok, int C, int vocab,
+                                                   float scale, int32_t* error_flag, mila_stream_t stream);
 MILA_API int mila_cdna4_lpe_bf16(uint16_t* Y, const int32_t* tokens, const uint16_t* wte,
                                  const uint16_t* wpe, int B, int T, int C, int out_stride_T, int vocab,
                                  int32_t* error_flag, mila_stream_t stream);
@@ -244,6 +249,24 @@ MILA_API int mila_cdna4_fused_qkv_post(uint16_t* q_out, uint16_t* Kc, uint16_t* 
                                        const uint16_t* kw, const uint16_t* vw, const float* cos_cache,
                                        const float* sin_cache, int NH, int NKV, int HS, int position,
                                        int capacity, float eps, mila_stream_t stream);
+
+
+/* Graph-replay forms: the decode position lives in DEVICE memory so that one captured hipGraph
+ * serves every step (the reference re-launches ~1100 kernels per token from the host,
+ * SPEC/Gemma4InferenceReview.md:71-84).  `max_len` fixes the split count at capture time; splits past
+ * the live band contribute (m=-inf, l=0) partials.  advance_position: *position_dev += 1. */
+MILA_API int mila_cdna4_attn_decode_bf16_devpos(uint16_t* Y, const uint16_t* Q, const uint16_t* Kc,
+                                                const uint16_t* Vc, void* scratch, size_t scratch_bytes,
+                                                int B, int NH, int NKV, int HS, int capacity,
+                                                const int32_t* position_dev, int max_len, int window,
+                                                float scale, mila_stream_t stream);
+MILA_API int mila_cdna4_fused_qkv_post_devpos(uint16_t* q_out, uint16_t* Kc, uint16_t* Vc, const uint16_t* q,
+                                              const uint16_t* k, const uint16_t* v_src, const uint16_t* qw,
+                                              const uint16_t* kw, const uint16_t* vw, const float* cos_cache,
+                                              const float* sin_cache, int NH, int NKV, int HS,
+                                              const int32_t* position_dev, int capacity, float eps,
+                                              mila_stream_t stream);
+MILA_API int mila_cdna4_advance_position(int32_t* position_dev, mila_stream_t stream);
 
 #ifdef __cplusplus
 }

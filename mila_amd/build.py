@@ -22,9 +22,11 @@ ARCH = "gfx950"
 
 KERNEL_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
                 "-Wall", "-Wno-unused-function"]
-HOST_FLAGS = ["--offload-arch=" + ARCH, "-O2", "-std=c++23", "-fPIC", "-fvisibility=hidden", "-Wall",
-              "-Wno-unused-function", "-I" + os.path.join(os.path.dirname(ROOT), "include"),
+# host mirror: plain C++23 (no device code), HIP runtime API only for graphs/events
+HOST_FLAGS = ["-O2", "-std=c++23", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+              "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(os.path.dirname(ROOT), "include"),
               "-I" + os.path.join(HOST, "include")]
+HOSTCXX = os.environ.get("HOSTCXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 
 def _newer(target, deps):
@@ -80,7 +82,7 @@ def build(force=False, verbose=False):
             obj = os.path.join(OBJDIR, "host_" + s[:-4] + ".o")
             hobjs.append(obj)
             if force or _newer(obj, [src] + hh):
-                hjobs.append([HIPCC, "-x", "hip"] + HOST_FLAGS + ["-c", src, "-o", obj])
+                hjobs.append([HOSTCXX] + HOST_FLAGS + ["-c", src, "-o", obj])
         if hjobs:
             with cf.ThreadPoolExecutor(max_workers=min(6, len(hjobs))) as ex:
                 for out in ex.map(_run, hjobs):
@@ -88,8 +90,8 @@ def build(force=False, verbose=False):
                         print(out)
         hlib = os.path.join(LIBDIR, "libmila_host.so")
         if hobjs and (force or hjobs or _newer(hlib, hobjs + [lib])):
-            _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", hlib] + hobjs +
-                 ["-L" + LIBDIR, "-lmila_cdna4", "-Wl,-rpath,$ORIGIN"])
+            _run([HOSTCXX, "-shared", "-fPIC", "-o", hlib] + hobjs +
+                 ["-L" + LIBDIR, "-lmila_cdna4", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN"])
     return lib
 
 

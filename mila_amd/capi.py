@@ -108,7 +108,8 @@ EXPORTED = [
     "rmsnorm_bf16", "layernorm_bf16", "layernorm_fp32", "softmax_fp32", "softmax_bf16",
     "gelu_bf16", "gelu_fp32", "geglu_bf16", "residual_bf16", "residual_fp32",
     "rope_build_cache", "rope_forward_bf16",
-    "embedding_gather_bf16", "lpe_bf16", "split3_bf16", "scale_bf16",
+    "embedding_gather_bf16", "embedding_gather_bf16_qfp8", "lpe_bf16", "split3_bf16", "scale_bf16",
     "convert_f32_to_bf16", "convert_bf16_to_f32",
     "fused_norm_matvec", "fused_qkv_post",
+    "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position",
 ]

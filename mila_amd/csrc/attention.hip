@@ -59,6 +59,7 @@ struct AttnParams
     int64_t q_row_stride, kv_b_stride, kv_h_stride, kv_r_stride;
     int Tq, NH, NKV, capacity, pos_offset, window, splits;
     float scale;
+    const int32_t* pos_dev;   // when set: position of query 0 is read from device memory (graph replay)
 };
 
 template <int EPL> struct RowVec;                        // EPL bf16 elements per lane
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
     const bool owner = lane < ACTIVE;
     const int split = blockIdx.x, kvh = blockIdx.y;
     const int bt = blockIdx.z, b = bt / p.Tq, t = bt % p.Tq;
-    const int pos = p.pos_offset + t;
+    const int pos = (p.pos_dev ? *p.pos_dev : p.pos_offset) + t;
     const int len = pos + 1;
     const int band_begin = (p.window > 0) ? max(0, len - p.window) : 0;
     const int band = len - band_begin;
@@ -373,11 +374,41 @@ int mila_cdna4_attn_decode_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t* 
     p.Tq = 1; p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.pos_offset = len - 1; p.window = window;
     p.splits = decode_splits(B, NKV, band);
     p.scale = scale;
+    p.pos_dev = nullptr;
     if (p.splits > 1)
     {
         const size_t need = (size_t)B * NH * p.splits * (HS + 2) * sizeof(float);
         if (!scratch || scratch_bytes < need)
             return set_error(MILA_E_SCRATCH_TOO_SMALL, "attn_decode_bf16: scratch %zu bytes < required %zu", scratch_bytes, need);
+    }
+    return dispatch_hs(HS, p, B, as_stream(stream));
+}
+
+int mila_cdna4_attn_decode_bf16_devpos(uint16_t* Y, const uint16_t* Q, const uint16_t* Kc, const uint16_t* Vc, void* scratch,
+                                       size_t scratch_bytes, int B, int NH, int NKV, int HS, int capacity,
+                                       const int32_t* position_dev, int max_len, int window, float scale,
+                                       mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && Q && Kc && Vc && position_dev, "attn_decode_bf16_devpos: null pointer");
+    MILA_REQUIRE(B > 0 && NH > 0 && NKV > 0 && NH % NKV == 0, "attn_decode_bf16_devpos: bad head counts (NH=%d NKV=%d)", NH, NKV);
+    MILA_REQUIRE(max_len > 0 && capacity > 0 && window >= 0, "attn_decode_bf16_devpos: bad sizes");
+    const int band = (window > 0 && window < max_len) ? window : max_len;
+    MILA_REQUIRE(band <= capacity, "attn_decode_bf16_devpos: live band %d exceeds the cache capacity %d", band, capacity);
+    AttnParams p;
+    p.Y = Y; p.Q = Q; p.K = Kc; p.V = Vc; p.scratch = reinterpret_cast<float*>(scratch);
+    p.q_row_stride = (int64_t)NH * HS;
+    p.kv_b_stride = (int64_t)NKV * capacity * HS;
+    p.kv_h_stride = (int64_t)capacity * HS;
+    p.kv_r_stride = HS;
+    p.Tq = 1; p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.pos_offset = 0; p.window = window;
+    p.splits = decode_splits(B, NKV, band);   // fixed at capture time from the largest band
+    p.scale = scale;
+    p.pos_dev = position_dev;
+    if (p.splits > 1)
+    {
+        const size_t need = (size_t)B * NH * p.splits * (HS + 2) * sizeof(float);
+        if (!scratch || scratch_bytes < need)
+            return set_error(MILA_E_SCRATCH_TOO_SMALL, "attn_decode_bf16_devpos: scratch %zu bytes < required %zu", scratch_bytes, need);
     }
     return dispatch_hs(HS, p, B, as_stream(stream));
 }
@@ -405,6 +436,7 @@ int mila_cdna4_attn_prefill_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t*
     p.Tq = chunk; p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.pos_offset = pos_offset; p.window = window;
     p.splits = 1;
     p.scale = scale;
+    p.pos_dev = nullptr;
     return dispatch_hs(HS, p, B, as_stream(stream));
 }
 
@@ -422,6 +454,7 @@ int mila_cdna4_mha_bf16(uint16_t* Y, const uint16_t* QKV, int B, int T, int C, i
     p.Tq = T; p.NH = NH; p.NKV = NH; p.capacity = T; p.pos_offset = 0; p.window = 0;
     p.splits = 1;
     p.scale = 1.0f / sqrtf((float)HS);
+    p.pos_dev = nullptr;
     return dispatch_hs(HS, p, B, as_stream(stream));
 }
 

@@ -148,6 +148,60 @@ __global__ __launch_bounds__(256) void embedding_gather_bf16_kernel(uint16_t* __
     }
 }
 
+// FP8 tied table (per-vocab-row scale): y = bf16(float(e4m3) * scale[row]), then the optional
+// embedding scale as a second bf16 rounding (OPS/Embeddings/Kernels/TokenEmbedding.Fp8.cu:33-69 +
+// TokenEmbedding.ixx:179-181)
+__global__ __launch_bounds__(256) void embedding_gather_bf16_qfp8_kernel(uint16_t* __restrict__ Y,
+                                                                         const int32_t* __restrict__ tokens,
+                                                                         const uint8_t* __restrict__ table,
+                                                                         const float* __restrict__ row_scales, int C,
+                                                                         int vocab, float scale, int32_t* error_flag)
+{
+    const int t = blockIdx.x;
+    const int tok = tokens[t];
+    if (tok < 0 || tok >= vocab)
+    {
+        if (threadIdx.x == 0 && error_flag) atomicExch(error_flag, 1 + t);
+        return;
+    }
+    const float rs = row_scales[tok];
+    const uint8_t* src = table + (size_t)tok * C;
+    uint16_t* dst = Y + (size_t)t * C;
+    for (int i = threadIdx.x; i < C / 8; i += 256)
+    {
+        const u32x2 raw = *reinterpret_cast<const u32x2*>(src + (size_t)i * 8);
+        u32x4 v;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+        {
+            const f32x2 a = fp8x2_to_f32x2(raw[d], false), b = fp8x2_to_f32x2(raw[d], true);
+            v[2 * d] = pack_bf16x2(a[0] * rs, a[1] * rs);
+            v[2 * d + 1] = pack_bf16x2(b[0] * rs, b[1] * rs);
+        }
+        if (scale != 0.0f) v = map8(v, [scale](float x) { return x * scale; });
+        st16(dst + (size_t)i * 8, v);
+    }
+}
+
+// counter-based synthetic data: element i of a tensor seeded `seed` is
+// bf16(offset + amp * (2u - 1)), u = top 24 bits of splitmix64(seed + i * golden) / 2^24.
+// Reproducible on the host (tests/synth.py) without shipping files.
+__device__ __forceinline__ float synth_uniform(uint64_t seed, uint64_t i)
+{
+    uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+__global__ __launch_bounds__(256) void fill_uniform_bf16_kernel(uint16_t* __restrict__ dst, int64_t n, uint64_t seed,
+                                                                float amp, float offset)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        dst[i] = f32_to_bf16_bits(__fadd_rn(offset, __fmul_rn(amp, __fadd_rn(__fmul_rn(2.0f, synth_uniform(seed, (uint64_t)i)), -1.0f))));  // no FMA contraction: host-reproducible
+}
+
 __global__ __launch_bounds__(256) void lpe_bf16_kernel(uint16_t* __restrict__ Y, const int32_t* __restrict__ tokens,
                                                        const uint16_t* __restrict__ wte,
                                                        const uint16_t* __restrict__ wpe, int T, int C,
@@ -321,6 +375,26 @@ int mila_cdna4_embedding_gather_bf16(uint16_t* Y, const int32_t* tokens, const u
     hipLaunchKernelGGL(embedding_gather_bf16_kernel, dim3(n_tok), dim3(256), 0, as_stream(stream), Y, tokens, table, C,
                        vocab, scale, error_flag);
     MILA_LAUNCH_CHECK("embedding_gather_bf16");
+}
+
+int mila_cdna4_embedding_gather_bf16_qfp8(uint16_t* Y, const int32_t* tokens, const uint8_t* table, const float* row_scales,
+                                          int n_tok, int C, int vocab, float scale, int32_t* error_flag, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && tokens && table && row_scales, "embedding_gather_bf16_qfp8: null pointer");
+    MILA_REQUIRE(n_tok > 0 && C > 0 && vocab > 0, "embedding_gather_bf16_qfp8: bad sizes");
+    MILA_REQUIRE(C % 8 == 0, "embedding_gather_bf16_qfp8: C=%d must be a multiple of 8", C);
+    hipLaunchKernelGGL(embedding_gather_bf16_qfp8_kernel, dim3(n_tok), dim3(256), 0, as_stream(stream), Y, tokens, table,
+                       row_scales, C, vocab, scale, error_flag);
+    MILA_LAUNCH_CHECK("embedding_gather_bf16_qfp8");
+}
+
+int mila_cdna4_fill_uniform_bf16(uint16_t* dst, int64_t n, uint64_t seed, float amp, float offset, mila_stream_t stream)
+{
+    MILA_REQUIRE(dst && n >= 0, "fill_uniform_bf16: bad arguments");
+    if (n == 0) return MILA_OK;
+    hipLaunchKernelGGL(fill_uniform_bf16_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), dst, n, seed, amp,
+                       offset);
+    MILA_LAUNCH_CHECK("fill_uniform_bf16");
 }
 
 int mila_cdna4_lpe_bf16(uint16_t* Y, const int32_t* tokens, const uint16_t* wte, const uint16_t* wpe, int B, int T,

@@ -22,11 +22,14 @@ struct QkvPostParams
     const uint16_t* qw;
     const uint16_t* kw;
     const uint16_t* vw;
-    const float* cos_row;   // cache row of this position
-    const float* sin_row;
-    int NH, NKV, HS, row, capacity;
+    const float* cos_cache;
+    const float* sin_cache;
+    const int32_t* pos_dev;   // when set, the position is read from device memory (graph replay)
+    int NH, NKV, HS, position, capacity;
     float eps;
 };
+
+__global__ void advance_position_kernel(int32_t* pos) { *pos += 1; }
 
 // one wave per head row; rows [0,NH) = q, [NH,NH+NKV) = k, [NH+NKV, NH+2NKV) = v
 __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostParams p)
@@ -35,6 +38,10 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostParams p)
     const int lane = threadIdx.x & 63;
     const int HS = p.HS, half = HS / 2, hv = half / 8;
     if (r >= p.NH + 2 * p.NKV) return;
+    const int position = p.pos_dev ? *p.pos_dev : p.position;
+    const int row = position % p.capacity;
+    const float* cos_row = p.cos_cache + (size_t)position * half;
+    const float* sin_row = p.sin_cache + (size_t)position * half;
     const uint16_t* src;
     const uint16_t* w;
     uint16_t* dst;
@@ -46,12 +53,12 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostParams p)
     else if (r < p.NH + p.NKV)
     {
         const int n = r - p.NH;
-        src = p.k + (size_t)n * HS; w = p.kw; dst = p.Kc + ((size_t)n * p.capacity + p.row) * HS; rotate = true;
+        src = p.k + (size_t)n * HS; w = p.kw; dst = p.Kc + ((size_t)n * p.capacity + row) * HS; rotate = true;
     }
     else
     {
         const int n = r - p.NH - p.NKV;
-        src = p.v_src + (size_t)n * HS; w = p.vw; dst = p.Vc + ((size_t)n * p.capacity + p.row) * HS; rotate = false;
+        src = p.v_src + (size_t)n * HS; w = p.vw; dst = p.Vc + ((size_t)n * p.capacity + row) * HS; rotate = false;
     }
     const float rstd = rms_rstd_wave(src, HS, p.eps);
     if (lane < hv)
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostParams p)
             lo = rms_apply8_now(xlo, rstd);
             hi = rms_apply8_now(xhi, rstd);
         }
-        if (rotate) rope_rotate8_vals(lo, hi, p.cos_row, p.sin_row, lane * 8);
+        if (rotate) rope_rotate8_vals(lo, hi, cos_row, sin_row, lane * 8);
         st16(dst + (size_t)lane * 8, lo);
         st16(dst + (size_t)(lane + hv) * 8, hi);
     }
@@ -88,11 +95,32 @@ int mila_cdna4_fused_qkv_post(uint16_t* q_out, uint16_t* Kc, uint16_t* Vc, const
     MILA_REQUIRE(q_out && Kc && Vc && q && k && v_src && qw && kw && cos_cache && sin_cache, "fused_qkv_post: null pointer");
     MILA_REQUIRE(NH > 0 && NKV > 0 && capacity > 0 && position >= 0, "fused_qkv_post: bad sizes");
     MILA_REQUIRE(HS % 16 == 0 && HS >= 16 && HS <= 1024, "fused_qkv_post: HS=%d must be a multiple of 16 in [16,1024]", HS);
-    QkvPostParams p{q_out, Kc, Vc, q, k, v_src, qw, kw, vw, cos_cache + (size_t)position * (HS / 2),
-                    sin_cache + (size_t)position * (HS / 2), NH, NKV, HS, position % capacity, capacity, eps};
+    QkvPostParams p{q_out, Kc, Vc, q, k, v_src, qw, kw, vw, cos_cache, sin_cache, nullptr, NH, NKV, HS, position, capacity, eps};
     const int rows = NH + 2 * NKV;
     hipLaunchKernelGGL(qkv_post_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, as_stream(stream), p);
     MILA_LAUNCH_CHECK("fused_qkv_post");
+}
+
+int mila_cdna4_fused_qkv_post_devpos(uint16_t* q_out, uint16_t* Kc, uint16_t* Vc, const uint16_t* q, const uint16_t* k,
+                                     const uint16_t* v_src, const uint16_t* qw, const uint16_t* kw, const uint16_t* vw,
+                                     const float* cos_cache, const float* sin_cache, int NH, int NKV, int HS,
+                                     const int32_t* position_dev, int capacity, float eps, mila_stream_t stream)
+{
+    MILA_REQUIRE(q_out && Kc && Vc && q && k && v_src && qw && kw && cos_cache && sin_cache && position_dev,
+                 "fused_qkv_post_devpos: null pointer");
+    MILA_REQUIRE(NH > 0 && NKV > 0 && capacity > 0, "fused_qkv_post_devpos: bad sizes");
+    MILA_REQUIRE(HS % 16 == 0 && HS >= 16 && HS <= 1024, "fused_qkv_post_devpos: HS=%d must be a multiple of 16 in [16,1024]", HS);
+    QkvPostParams p{q_out, Kc, Vc, q, k, v_src, qw, kw, vw, cos_cache, sin_cache, position_dev, NH, NKV, HS, 0, capacity, eps};
+    const int rows = NH + 2 * NKV;
+    hipLaunchKernelGGL(qkv_post_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, as_stream(stream), p);
+    MILA_LAUNCH_CHECK("fused_qkv_post_devpos");
+}
+
+int mila_cdna4_advance_position(int32_t* position_dev, mila_stream_t stream)
+{
+    MILA_REQUIRE(position_dev != nullptr, "advance_position: null pointer");
+    hipLaunchKernelGGL(advance_position_kernel, dim3(1), dim3(1), 0, as_stream(stream), position_dev);
+    MILA_LAUNCH_CHECK("advance_position");
 }
 
 }  // extern "C"

@@ -16,6 +16,9 @@ MILA_API int mila_cdna4_selftest_decode(float* out_fp8, float* out_fp4, mila_str
 /* streaming-copy ceiling: dst <- src with 16-byte accesses; used to report a measured HBM roof */
 MILA_API int mila_cdna4_stream_copy(void* dst, const void* src, size_t bytes, mila_stream_t stream);
 MILA_API int mila_cdna4_stream_read(float* sink, const void* src, size_t bytes, mila_stream_t stream);
+/* synthetic parameters: dst[i] = bf16(offset + amp * (2u - 1)), u from splitmix64(seed, i) */
+MILA_API int mila_cdna4_fill_uniform_bf16(uint16_t* dst, int64_t n, uint64_t seed, float amp, float offset,
+                                          mila_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,110 @@
+"""ctypes binding of libmila_host.so: the C++ host mirror's model runners (GemmaTransformer<TWeightQuant>
+on DeviceType::Rocm).  Used by bench.py and the model-level tests; loading fails loudly if the
+library is missing."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmila_host.so")
+POLICIES = {"bf16": 0, "fp8": 1, "fp4": 2}
+_lib = None
+
+
+class GemmaConfigC(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("vocab_size", "embedding_dim", "num_layers", "num_heads", "num_kv_heads",
+                                         "head_dim", "hidden_dim", "global_head_dim", "num_global_kv_heads", "window",
+                                         "sliding_window_pattern", "global_rotary_dim")]
+
+
+GEMMA4_12B = dict(vocab_size=262144, embedding_dim=3840, num_layers=48, num_heads=16, num_kv_heads=8, head_dim=256,
+                  hidden_dim=15360, global_head_dim=512, num_global_kv_heads=1, window=1024, sliding_window_pattern=6,
+                  global_rotary_dim=128)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        capi.load()      # libmila_cdna4 first (and torch's HIP runtime before both)
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run `python -m mila_amd.build`; there is no fallback path" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.mila_host_last_error.restype = C.c_char_p
+        _lib.mila_gemma_create.restype = C.c_void_p
+        _lib.mila_gemma_create.argtypes = [C.c_int, C.POINTER(GemmaConfigC), C.c_int64, C.c_int64, C.c_uint64]
+        _lib.mila_gemma_destroy.argtypes = [C.c_void_p]
+        _lib.mila_gemma_prefill.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        _lib.mila_gemma_decode.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int, C.c_void_p]
+        _lib.mila_gemma_time_decode.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _lib.mila_gemma_time_dominant_kernel.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _lib.mila_gemma_time_prefill.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        _lib.mila_gemma_info.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        text = load().mila_host_last_error().decode()
+        if rc == capi.MILA_E_INVALID_ARGUMENT:
+            raise ValueError(text)
+        raise RuntimeError(text)
+
+
+class Gemma:
+    """GemmaTransformer<policy> with synthetic weights on cuda:0."""
+
+    MODES = {"reference": 0, "fused": 1, "graph": 2}
+
+    def __init__(self, policy="bf16", config=None, max_seq=4096, max_prefill=1, seed=1234):
+        lib = load()
+        self.cfg = dict(GEMMA4_12B if config is None else config)
+        c = GemmaConfigC(**self.cfg)
+        self.vocab = self.cfg["vocab_size"]
+        self.h = lib.mila_gemma_create(POLICIES[policy], C.byref(c), max_seq, max_prefill, seed)
+        if not self.h:
+            raise RuntimeError("mila_gemma_create: " + lib.mila_host_last_error().decode())
+
+    def close(self):
+        if self.h:
+            load().mila_gemma_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prefill(self, tokens, position_offset=0):
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = np.empty(self.vocab, dtype=np.float32)
+        _check(load().mila_gemma_prefill(self.h, t.ctypes.data, t.size, position_offset, out.ctypes.data))
+        return out
+
+    def decode(self, token, position, mode="fused"):
+        out = np.empty(self.vocab, dtype=np.float32)
+        _check(load().mila_gemma_decode(self.h, int(token), int(position), self.MODES[mode], out.ctypes.data))
+        return out
+
+    def time_decode(self, start_position, steps, warmup, mode="graph"):
+        out = (C.c_double * 2)()
+        _check(load().mila_gemma_time_decode(self.h, start_position, steps, warmup, self.MODES[mode], out))
+        return {"wall_ms_per_step": out[0], "device_ms_per_step": out[1]}
+
+    def time_dominant_kernel(self, rounds=3):
+        out = (C.c_double * 2)()
+        _check(load().mila_gemma_time_dominant_kernel(self.h, rounds, out))
+        return {"avg_us": out[0], "bytes": out[1]}
+
+    def time_prefill(self, T, reps=1):
+        out = C.c_double()
+        _check(load().mila_gemma_time_prefill(self.h, T, reps, C.byref(out)))
+        return out.value
+
+    def info(self, context):
+        out = (C.c_double * 4)()
+        _check(load().mila_gemma_info(self.h, context, out))
+        return {"decode_bytes_per_token": out[0], "weight_bytes": out[1], "linear_params": out[2], "table_params": out[3]}

@@ -1,0 +1,544 @@
+// Gemma-4 decoder on the CDNA4 device: GemmaConfig, and GemmaTransformer<TWeightQuant> with
+//   * decode()/prefill() in the REFERENCE's per-component order (one C-ABI call per component
+//     forward, exactly the sequence of GemmaBlock::decode / ::prefill,
+//     /root/reference/Mila/Src/Dnn/Components/Transformers/Gemma/Gemma.Block.ixx:197-356, and
+//     GemmaTransformer::decode, Gemma.ixx:281-297), and
+//   * decodeFused(): the same arithmetic as 6 launches per layer, and
+//   * a hipGraph of the fused step with the position in device memory (one replay per token).
+// The three paths produce bit-identical logits (tests/test_gemma_host_gpu.py).
+//
+// Quirks kept from the reference (SURVEY.md Appendix A "Gemma block quirks"): sandwich norms; per-head
+// q/k/v norms; RoPE after q/k norm and never on V; global layers have no V projection, V =
+// v_norm(raw k_proj); residuals use the block input and res1; output scaled by a per-layer scalar;
+// embedding scaled by sqrt(D) with a second bf16 rounding; layer i is global iff (i+1) % 6 == 0;
+// tied table: bf16 for NoWeightQuant, per-row FP8 for quantized bodies (Gemma.ixx:143-147).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "Components.h"
+#include "../../../csrc/internal.h"
+
+namespace Mila::Dnn
+{
+    struct GemmaConfig
+    {
+        // defaults = Gemma-4 12B (Gemma.Config.ixx:796-821)
+        dim_t vocab_size = 262144, embedding_dim = 3840, num_layers = 48, num_heads = 16, num_kv_heads = 8, head_dim = 256,
+              hidden_dim = 15360, global_head_dim = 512, num_global_kv_heads = 1, window = 1024, sliding_window_pattern = 6,
+              global_rotary_dim = 128;
+        float rms_norm_eps = 1e-6f, rope_theta_local = 10000.0f, rope_theta_global = 1000000.0f, final_logit_softcapping = 30.0f;
+
+        bool isGlobalLayer( dim_t i ) const { return ( i + 1 ) % sliding_window_pattern == 0; }   // Gemma.Config.ixx:504-507
+        dim_t headDim( bool g ) const { return g ? global_head_dim : head_dim; }
+        dim_t numKvHeads( bool g ) const { return g ? num_global_kv_heads : num_kv_heads; }
+        dim_t qWidth( bool g ) const { return num_heads * headDim( g ); }
+        dim_t kvWidth( bool g ) const { return numKvHeads( g ) * headDim( g ); }
+        dim_t packedQkvWidth( bool g ) const { return qWidth( g ) + ( g ? 1 : 2 ) * kvWidth( g ); }   // K=V on global layers
+        dim_t windowFor( bool g ) const { return g ? 0 : window; }
+        float embeddingScale() const { return std::sqrt( static_cast<float>( embedding_dim ) ); }
+
+        void validate() const
+        {
+            if ( embedding_dim <= 0 || num_layers <= 0 || num_heads <= 0 || hidden_dim <= 0 || vocab_size <= 0 )
+                throw std::invalid_argument( "GemmaConfig: dimensions must be positive" );
+            if ( num_heads % num_kv_heads != 0 || num_heads % num_global_kv_heads != 0 )
+                throw std::invalid_argument( "GemmaConfig: num_heads must be a multiple of the KV head counts" );
+            if ( embedding_dim % 128 != 0 || hidden_dim % 128 != 0 || qWidth( false ) % 128 != 0 || qWidth( true ) % 128 != 0 )
+                throw std::invalid_argument( "GemmaConfig: feature widths must be multiples of 128 (FP4 group size)" );
+        }
+
+        /// weight parameters streamed per decode token (Linear body, tied table) -- SURVEY.md section 8d
+        dim_t linearParamsPerLayer( bool g ) const
+        {
+            return embedding_dim * packedQkvWidth( g ) + qWidth( g ) * embedding_dim + embedding_dim * 2 * hidden_dim + hidden_dim * embedding_dim;
+        }
+    };
+
+    inline void hipCheck( hipError_t e, const char* what )
+    {
+        if ( e != hipSuccess ) throw Compute::RocmException( std::string( what ) + ": " + hipGetErrorString( e ) );
+    }
+
+    template<WeightQuantPolicy TWeightQuant>
+    class GemmaTransformer
+    {
+    public:
+        static constexpr DeviceType kDevice = DeviceType::Rocm;
+        static constexpr TensorDataType kPrecision = TensorDataType::BF16;
+        using TensorType = Tensor<kPrecision, Compute::RocmDeviceMemoryResource>;
+        using TokenTensor = Tensor<TensorDataType::INT32, Compute::RocmDeviceMemoryResource>;
+        using LogitsTensor = Tensor<TensorDataType::FP32, Compute::RocmDeviceMemoryResource>;
+        using LinearType = Linear<kDevice, kPrecision, TWeightQuant>;
+        using TableQuantizationPolicy = std::conditional_t<TWeightQuant::kIsQuantized, Quant::Weight::PerChannelFp8<>, NoWeightQuant>;
+        using LmHeadLinearType = Linear<kDevice, kPrecision, TableQuantizationPolicy>;
+        using RmsNormType = RmsNorm<kDevice, kPrecision>;
+        using RopeOp = Compute::RocmRopeOp;
+        using GqaOp = Compute::RocmGqaOp<false>;   // 288 GB of HBM: unbounded caches on every layer (ring optional)
+        static constexpr int kFmt = Quant::Weight::abiWeightFormat<TWeightQuant>();
+        static constexpr int kTableFmt = Quant::Weight::abiWeightFormat<TableQuantizationPolicy>();
+
+        struct Layer
+        {
+            bool global{ false };
+            std::shared_ptr<RmsNormType> input_norm, q_norm, k_norm, v_norm, post_attn_norm, pre_ffn_norm, post_ffn_norm;
+            std::shared_ptr<LinearType> qkv_proj, o_proj, fc_gate_up, fc_down;
+            std::shared_ptr<RopeOp> rope;
+            std::shared_ptr<GqaOp> attn;
+            float layer_scalar{ 1.0f };
+        };
+
+        GemmaTransformer( const GemmaConfig& cfg, dim_t max_seq, dim_t max_prefill, DeviceId device = Compute::Device::Rocm( 0 ) )
+            : cfg_( cfg ), max_seq_( max_seq ), max_prefill_( std::max<dim_t>( max_prefill, 1 ) )
+        {
+            cfg_.validate();
+            if ( max_seq <= 0 ) throw std::invalid_argument( "GemmaTransformer: max_seq must be positive" );
+            owned_ctx_ = Compute::createExecutionContext( device );
+            ctx_ = Compute::cast_context<kDevice>( owned_ctx_.get() );
+            buildAll();
+        }
+
+        ~GemmaTransformer()
+        {
+            if ( graph_exec_ ) hipGraphExecDestroy( graph_exec_ );
+            if ( graph_ ) hipGraphDestroy( graph_ );
+        }
+
+        Compute::RocmExecutionContext* context() const noexcept { return ctx_; }
+        const GemmaConfig& config() const noexcept { return cfg_; }
+        std::vector<Layer>& layers() noexcept { return layers_; }
+
+        // ------------------------------------------------------------------------------------
+        // synthetic parameters: counter-based uniform values generated on the
+        // device; Linear weights U(-1/sqrt(K), 1/sqrt(K)); norm weights 1 + 0.1 U(-1,1); table U(-a,a)
+        // ------------------------------------------------------------------------------------
+        void initSynthetic( uint64_t seed )
+        {
+            const size_t max_elems = static_cast<size_t>( std::max( { cfg_.vocab_size * cfg_.embedding_dim, cfg_.embedding_dim * 2 * cfg_.hidden_dim } ) );
+            TensorType staging( ctx_->getDeviceId(), shape_t{ static_cast<dim_t>( max_elems ) } );
+            auto fillLinear = [&]( auto& lin, uint64_t s )
+            {
+                const dim_t N = lin.getConfig().getOutputFeatures(), K = lin.getConfig().getInputFeatures();
+                fill( staging.data(), N * K, s, 1.0f / std::sqrt( static_cast<float>( K ) ), 0.0f );
+                lin.loadWeightFromDevice( staging.data() );
+                ctx_->synchronize();
+            };
+            auto fillNorm = [&]( RmsNormType& n, uint64_t s ) { fill( n.getWeight()->data(), n.getConfig().dim(), s, 0.1f, 1.0f ); };
+            for ( size_t i = 0; i < layers_.size(); ++i )
+            {
+                auto& L = layers_[ i ];
+                const uint64_t b = seed * 1000003ull + i * 64ull;
+                fillLinear( *L.qkv_proj, b + 1 ); fillLinear( *L.o_proj, b + 2 ); fillLinear( *L.fc_gate_up, b + 3 ); fillLinear( *L.fc_down, b + 4 );
+                fillNorm( *L.input_norm, b + 5 ); fillNorm( *L.q_norm, b + 6 ); fillNorm( *L.k_norm, b + 7 );
+                fill( L.v_norm->getWeight()->data(), L.v_norm->getConfig().dim(), 0, 0.0f, 1.0f );   // unit weight (Gemma.Block.ixx:880-886)
+                fillNorm( *L.post_attn_norm, b + 8 ); fillNorm( *L.pre_ffn_norm, b + 9 ); fillNorm( *L.post_ffn_norm, b + 10 );
+                L.layer_scalar = 1.0f;
+            }
+            fillNorm( *final_norm_, seed * 1000003ull + 64ull * layers_.size() + 1 );
+            fillLinear( *lm_head_, seed * 1000003ull + 64ull * layers_.size() + 2 );   // the tied table
+            ctx_->synchronize();
+        }
+
+        // ------------------------------------------------------------------------------------
+        // reference-order decode: one component forward per line of GemmaBlock::decode
+        // ------------------------------------------------------------------------------------
+        LogitsTensor& decode( const TokenTensor& token, dim_t position )
+        {
+            checkPosition( position, 1 );
+            embed( token.data(), 1, *hidden_[ 0 ] );
+            TensorType* x = hidden_[ 0 ].get();
+            for ( auto& L : layers_ ) x = &blockDecode( L, *x, static_cast<int>( position ) );
+            auto& normed = final_norm_->forward( x->view( shape_t{ 1, 1, cfg_.embedding_dim } ) );
+            head( normed.data() );
+            return *logits_;
+        }
+
+        // ------------------------------------------------------------------------------------
+        // fused decode: embedding + 6 launches per layer + head
+        // ------------------------------------------------------------------------------------
+        LogitsTensor& decodeFused( const TokenTensor& token, dim_t position )
+        {
+            checkPosition( position, 1 );
+            enqueueFusedStep( token.data(), static_cast<int>( position ), nullptr );
+            return *logits_;
+        }
+
+        /// capture the fused step once; afterwards replayGraph() advances one token per call.
+        /// The token is read from `token` (device) and the position from an internal device counter.
+        void captureGraph( const TokenTensor& token, dim_t start_position )
+        {
+            setDevicePosition( start_position );
+            hipStream_t s = reinterpret_cast<hipStream_t>( ctx_->getStream() );
+            (void)ctx_->getScratch( attnScratchBytes() );   // grow before capture: no allocation inside
+            ctx_->synchronize();
+            hipCheck( hipStreamBeginCapture( s, hipStreamCaptureModeThreadLocal ), "hipStreamBeginCapture" );
+            try { enqueueFusedStep( token.data(), 0, pos_dev_->data() ); }
+            catch ( ... ) { hipGraph_t g; hipStreamEndCapture( s, &g ); throw; }
+            Compute::rocmCheck( mila_cdna4_advance_position( pos_dev_->data(), ctx_->getStream() ) );
+            hipCheck( hipStreamEndCapture( s, &graph_ ), "hipStreamEndCapture" );
+            hipCheck( hipGraphInstantiate( &graph_exec_, graph_, nullptr, nullptr, 0 ), "hipGraphInstantiate" );
+        }
+        void setDevicePosition( dim_t position )
+        {
+            checkPosition( position, 1 );
+            const int32_t p = static_cast<int32_t>( position );
+            Compute::rocmCheck( mila_cdna4_memcpy_h2d( pos_dev_->data(), &p, 4, ctx_->getStream() ) );
+            ctx_->synchronize();
+        }
+        void replayGraph()
+        {
+            if ( !graph_exec_ ) throw std::runtime_error( "GemmaTransformer::replayGraph: captureGraph() first" );
+            hipCheck( hipGraphLaunch( graph_exec_, reinterpret_cast<hipStream_t>( ctx_->getStream() ) ), "hipGraphLaunch" );
+        }
+        LogitsTensor& logits() { return *logits_; }
+
+        // ------------------------------------------------------------------------------------
+        // prefill: whole prompt as one chunk (288 GB: no 12 GB-card chunking);
+        // logits for the last position only (Gemma.ixx:269-276)
+        // ------------------------------------------------------------------------------------
+        LogitsTensor& prefill( const TokenTensor& tokens, dim_t T, dim_t position_offset = 0 )
+        {
+            if ( T <= 0 || T > max_prefill_ ) throw std::invalid_argument( "GemmaTransformer::prefill: chunk length out of range" );
+            checkPosition( position_offset, T );
+            const dim_t D = cfg_.embedding_dim;
+            embed( tokens.data(), static_cast<int>( T ), *pf_x_[ 0 ] );
+            TensorType* x = pf_x_[ 0 ].get();
+            int flip = 0;
+            for ( auto& L : layers_ )
+            {
+                TensorType* out = pf_x_[ 1 - flip ].get();
+                blockPrefill( L, *x, *out, static_cast<int>( T ), static_cast<int>( position_offset ) );
+                x = out;
+                flip = 1 - flip;
+            }
+            auto last = x->slice( static_cast<size_t>( ( T - 1 ) * D ), shape_t{ 1, 1, D } );
+            auto& normed = final_norm_->forward( last );
+            head( normed.data() );
+            return *logits_;
+        }
+
+        /// algorithmic bytes one decode token must read: weights + scales + norm weights + KV band
+        double decodeBytesPerToken( dim_t context ) const
+        {
+            double b = 0;
+            for ( auto& L : layers_ )
+            {
+                b += L.qkv_proj->getParameterBytes() + L.o_proj->getParameterBytes() + L.fc_gate_up->getParameterBytes() + L.fc_down->getParameterBytes();
+                const dim_t band = L.global ? context : std::min<dim_t>( context, cfg_.window );
+                b += 2.0 * band * cfg_.kvWidth( L.global ) * 2;
+                b += 2.0 * ( 4 * cfg_.embedding_dim + 2 * cfg_.headDim( L.global ) );
+            }
+            b += lm_head_->getParameterBytes();
+            return b;
+        }
+        double weightBytes() const
+        {
+            double b = lm_head_->getParameterBytes();
+            for ( auto& L : layers_ ) b += L.qkv_proj->getParameterBytes() + L.o_proj->getParameterBytes() + L.fc_gate_up->getParameterBytes() + L.fc_down->getParameterBytes();
+            return b;
+        }
+        LmHeadLinearType& lmHead() { return *lm_head_; }
+        RmsNormType& finalNorm() { return *final_norm_; }
+
+        /// launch only the dominant kernel (fc_gate_up fused matvec) of layer `i` -- used by the bench to
+        /// time that kernel with HIP events on the model stream
+        void launchGateUp( size_t i ) { fusedGateUp( layers_[ i ] ); }
+        double gateUpBytes( size_t i ) const { return static_cast<double>( layers_[ i ].fc_gate_up->getParameterBytes() ); }
+
+    private:
+        void fill( uint16_t* dst, dim_t n, uint64_t seed, float amp, float offset )
+        {
+            Compute::rocmCheck( mila_cdna4_fill_uniform_bf16( dst, n, seed, amp, offset, ctx_->getStream() ) );
+        }
+
+        template<typename C, typename... A> std::shared_ptr<C> make( const std::string& name, A&&... a )
+        {
+            auto c = std::make_shared<C>( name, std::forward<A>( a )... );
+            c->setExecutionContext( ctx_ );
+            return c;
+        }
+
+        void buildAll()
+        {
+            const dim_t D = cfg_.embedding_dim, P = max_prefill_;
+            const auto dev = ctx_->getDeviceId();
+            auto rms = [&]( dim_t dim ) { return RmsNormConfig( dim ).withEpsilon( cfg_.rms_norm_eps ).withBias( false ); };
+            layers_.resize( static_cast<size_t>( cfg_.num_layers ) );
+            for ( dim_t i = 0; i < cfg_.num_layers; ++i )
+            {
+                auto& L = layers_[ static_cast<size_t>( i ) ];
+                const std::string n = "gemma.layer_" + std::to_string( i );
+                const bool g = cfg_.isGlobalLayer( i );
+                L.global = g;
+                const dim_t HD = cfg_.headDim( g ), NKV = cfg_.numKvHeads( g ), NH = cfg_.num_heads;
+                L.input_norm = make<RmsNormType>( n + ".input_norm", rms( D ) ); L.input_norm->build( BuildContext( shape_t{ 1, P, D }, RuntimeMode::Inference ) );
+                L.q_norm = make<RmsNormType>( n + ".q_norm", rms( HD ) ); L.q_norm->build( BuildContext( shape_t{ 1, P * NH, HD }, RuntimeMode::Inference ) );
+                L.k_norm = make<RmsNormType>( n + ".k_norm", rms( HD ) ); L.k_norm->build( BuildContext( shape_t{ 1, P * NKV, HD }, RuntimeMode::Inference ) );
+                L.v_norm = make<RmsNormType>( n + ".v_norm", rms( HD ) ); L.v_norm->build( BuildContext( shape_t{ 1, P * NKV, HD }, RuntimeMode::Inference ) );
+                L.post_attn_norm = make<RmsNormType>( n + ".post_attn_norm", rms( D ) ); L.post_attn_norm->build( BuildContext( shape_t{ 1, P, D }, RuntimeMode::Inference ) );
+                L.pre_ffn_norm = make<RmsNormType>( n + ".pre_ffn_norm", rms( D ) ); L.pre_ffn_norm->build( BuildContext( shape_t{ 1, P, D }, RuntimeMode::Inference ) );
+                L.post_ffn_norm = make<RmsNormType>( n + ".post_ffn_norm", rms( D ) ); L.post_ffn_norm->build( BuildContext( shape_t{ 1, P, D }, RuntimeMode::Inference ) );
+                L.qkv_proj = make<LinearType>( n + ".qkv_proj", LinearConfig( D, cfg_.packedQkvWidth( g ) ).withBias( false ) );
+                L.qkv_proj->build( BuildContext( shape_t{ 1, P, D }, RuntimeMode::Inference ) );
+                L.o_proj = make<LinearType>( n + ".o_proj", LinearConfig( cfg_.qWidth( g ), D ).withBias( false ) );
+                L.o_proj->build( BuildContext( shape_t{ 1, P, cfg_.qWidth( g ) }, RuntimeMode::Inference ) );
+                L.fc_gate_up = make<LinearType>( n + ".fc_gate_up", LinearConfig( D, 2 * cfg_.hidden_dim ).withBias( false ) );
+                L.fc_gate_up->build( BuildContext( shape_t{ 1, P, D }, RuntimeMode::Inference ) );
+                L.fc_down = make<LinearType>( n + ".fc_down", LinearConfig( cfg_.hidden_dim, D ).withBias( false ) );
+                L.fc_down->build( BuildContext( shape_t{ 1, P, cfg_.hidden_dim }, RuntimeMode::Inference ) );
+                L.rope = std::make_shared<RopeOp>( ctx_, Compute::RopeOpConfig{ max_seq_, HD, NH, NKV, g ? cfg_.rope_theta_global : cfg_.rope_theta_local,
+                                                                               g ? cfg_.global_rotary_dim : 0 } );
+                L.rope->build( BuildContext( shape_t{ 1, P, cfg_.qWidth( g ) }, RuntimeMode::Inference ) );
+                L.attn = std::make_shared<GqaOp>( ctx_, Compute::GqaOpConfig{ NH, NKV, HD, cfg_.windowFor( g ), 1.0f } );   // scale 1.0: Gemma.Block.ixx:902-904
+                L.attn->initializeKvCache( 1, max_seq_, P );
+            }
+            final_norm_ = make<RmsNormType>( "gemma.final_norm", rms( D ) );
+            final_norm_->build( BuildContext( shape_t{ 1, 1, D }, RuntimeMode::Inference ) );
+            lm_head_ = make<LmHeadLinearType>( "gemma.lm_head", LinearConfig( D, cfg_.vocab_size ).withBias( false ) );
+            lm_head_->build( BuildContext( shape_t{ 1, 1, D }, RuntimeMode::Inference ) );
+
+            const dim_t maxq = std::max( cfg_.qWidth( false ), cfg_.qWidth( true ) ), maxkv = std::max( cfg_.kvWidth( false ), cfg_.kvWidth( true ) );
+            for ( int i = 0; i < 3; ++i ) hidden_[ i ] = std::make_unique<TensorType>( dev, shape_t{ 1, 1, D } );
+            for ( int i = 0; i < 2; ++i ) pf_x_[ i ] = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
+            q_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, maxq } );
+            k_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, maxkv } );
+            v_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, maxkv } );
+            attn_out_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, maxq } );
+            res1_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
+            res2_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
+            geglu_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, cfg_.hidden_dim } );
+            f_qkv_ = std::make_unique<TensorType>( dev, shape_t{ std::max( cfg_.packedQkvWidth( false ), cfg_.packedQkvWidth( true ) ) } );
+            f_q_ = std::make_unique<TensorType>( dev, shape_t{ maxq } );
+            f_o_ = std::make_unique<TensorType>( dev, shape_t{ D } );
+            f_down_ = std::make_unique<TensorType>( dev, shape_t{ D } );
+            f_act_ = std::make_unique<TensorType>( dev, shape_t{ cfg_.hidden_dim } );
+            logits_ = std::make_unique<LogitsTensor>( dev, shape_t{ 1, 1, cfg_.vocab_size } );
+            pos_dev_ = std::make_unique<TokenTensor>( dev, shape_t{ 1 } );
+            err_flag_ = std::make_unique<TokenTensor>( dev, shape_t{ 1 } );
+            Compute::rocmCheck( mila_cdna4_memset_zero( err_flag_->data(), 4, ctx_->getStream() ) );
+            ctx_->synchronize();
+        }
+
+        void checkPosition( dim_t position, dim_t n ) const
+        {
+            if ( position < 0 || position + n > max_seq_ ) throw std::invalid_argument( "GemmaTransformer: position beyond the built sequence length" );
+        }
+        size_t attnScratchBytes() const
+        {
+            return std::max( mila_cdna4_attn_decode_scratch_bytes( 1, (int)cfg_.num_heads, (int)cfg_.head_dim ),
+                             mila_cdna4_attn_decode_scratch_bytes( 1, (int)cfg_.num_heads, (int)cfg_.global_head_dim ) );
+        }
+
+        /// TokenEmbedding::forward: gather (bf16 table, or FP8 table x row scale) then scale(sqrt(D))
+        void embed( const int32_t* tokens_dev, int n, TensorType& out )
+        {
+            const int D = (int)cfg_.embedding_dim, V = (int)cfg_.vocab_size;
+            if constexpr ( kTableFmt == 0 )
+                Compute::rocmCheck( mila_cdna4_embedding_gather_bf16( out.data(), tokens_dev, static_cast<const uint16_t*>( lm_head_->getWeight().rawData() ), n, D, V,
+                                                                      cfg_.embeddingScale(), err_flag_->data(), ctx_->getStream() ) );
+            else
+                Compute::rocmCheck( mila_cdna4_embedding_gather_bf16_qfp8( out.data(), tokens_dev, static_cast<const uint8_t*>( lm_head_->getWeight().rawData() ),
+                                                                           lm_head_->getWeightScale()->data(), n, D, V, cfg_.embeddingScale(), err_flag_->data(),
+                                                                           ctx_->getStream() ) );
+        }
+
+        /// lm_head on the normalized last hidden state, fp32 logits (the 1e-3 bar is asserted on fp32)
+        void head( const uint16_t* normed )
+        {
+            const float* sc = nullptr;
+            if constexpr ( kTableFmt != 0 ) sc = lm_head_->getWeightScale()->data();
+            Compute::rocmCheck( mila_cdna4_matvec_f32out( logits_->data(), normed, lm_head_->getWeight().rawData(), sc, kTableFmt, (int)cfg_.embedding_dim,
+                                                          (int)cfg_.vocab_size, 0, ctx_->getStream() ) );
+        }
+
+        // ---- reference-order block (decode) --------------------------------------------------------
+        TensorType& blockDecode( Layer& L, TensorType& input, int position )
+        {
+            const bool g = L.global;
+            const dim_t NH = cfg_.num_heads, NKV = cfg_.numKvHeads( g ), HD = cfg_.headDim( g ), D = cfg_.embedding_dim;
+            mila_stream_t st = ctx_->getStream();
+            auto x3 = input.view( shape_t{ 1, 1, D } );
+            auto& normed = L.input_norm->forward( x3 );
+            auto& qkv = L.qkv_proj->forward( normed );
+            auto q = q_->view( shape_t{ 1, 1, NH * HD } );
+            auto k = k_->view( shape_t{ 1, 1, NKV * HD } );
+            auto v = v_->view( shape_t{ 1, 1, NKV * HD } );
+            Compute::rocmCheck( mila_cdna4_split3_bf16( q.data(), k.data(), g ? nullptr : v.data(), static_cast<const uint16_t*>( qkv.rawData() ), 1,
+                                                        (int)( NH * HD ), (int)( NKV * HD ), g ? 0 : (int)( NKV * HD ), st ) );
+            auto& q_normed = L.q_norm->forward( q.view( shape_t{ 1, NH, HD } ) );
+            auto& k_normed = L.k_norm->forward( k.view( shape_t{ 1, NKV, HD } ) );
+            auto q_roped = q_normed.view( shape_t{ 1, 1, NH * HD } );
+            auto k_roped = k_normed.view( shape_t{ 1, 1, NKV * HD } );
+            L.rope->decode( q_roped, k_roped, 1, position );
+            auto& v_normed = L.v_norm->forward( ( g ? k : v ).view( shape_t{ 1, NKV, HD } ) );   // global: V = v_norm(raw k_proj)
+            auto attn = attn_out_->view( shape_t{ 1, 1, NH * HD } );
+            L.attn->decode( q_roped, k_roped, v_normed.view( shape_t{ 1, 1, NKV * HD } ), attn, position );
+            auto& o = L.o_proj->forward( attn );
+            auto& o_normed = L.post_attn_norm->forward( o );
+            auto res1 = res1_->view( shape_t{ 1, 1, D } );
+            Compute::rocmCheck( mila_cdna4_residual_bf16( res1.data(), x3.data(), o_normed.data(), D, st ) );
+            auto& ffn_in = L.pre_ffn_norm->forward( res1 );
+            auto& gate_up = L.fc_gate_up->forward( ffn_in );
+            auto act = geglu_->view( shape_t{ 1, 1, cfg_.hidden_dim } );
+            Compute::rocmCheck( mila_cdna4_geglu_bf16( act.data(), gate_up.data(), 1, (int)cfg_.hidden_dim, st ) );
+            auto& ffn = L.fc_down->forward( act );
+            auto& ffn_normed = L.post_ffn_norm->forward( ffn );
+            auto res2 = res2_->view( shape_t{ 1, 1, D } );
+            Compute::rocmCheck( mila_cdna4_residual_bf16( res2.data(), res1.data(), ffn_normed.data(), D, st ) );
+            TensorType* out = ( &input == hidden_[ 0 ].get() ) ? hidden_[ 1 ].get() : hidden_[ 0 ].get();
+            Compute::rocmCheck( mila_cdna4_scale_bf16( out->data(), res2.data(), D, L.layer_scalar, st ) );
+            return *out;
+        }
+
+        // ---- reference-order block (prefill, T tokens) ------------------------------------------------
+        void blockPrefill( Layer& L, TensorType& input, TensorType& output, int T, int position_offset )
+        {
+            const bool g = L.global;
+            const dim_t NH = cfg_.num_heads, NKV = cfg_.numKvHeads( g ), HD = cfg_.headDim( g ), D = cfg_.embedding_dim;
+            mila_stream_t st = ctx_->getStream();
+            auto x3 = input.view( shape_t{ 1, T, D } );
+            auto& normed = L.input_norm->forward( x3 );
+            auto& qkv = L.qkv_proj->forward( normed );
+            auto q = q_->view( shape_t{ 1, T, NH * HD } );
+            auto k = k_->view( shape_t{ 1, T, NKV * HD } );
+            auto v = v_->view( shape_t{ 1, T, NKV * HD } );
+            Compute::rocmCheck( mila_cdna4_split3_bf16( q.data(), k.data(), g ? nullptr : v.data(), static_cast<const uint16_t*>( qkv.rawData() ), T,
+                                                        (int)( NH * HD ), (int)( NKV * HD ), g ? 0 : (int)( NKV * HD ), st ) );
+            auto& q_normed = L.q_norm->forward( q.view( shape_t{ 1, T * NH, HD } ) );
+            auto& k_normed = L.k_norm->forward( k.view( shape_t{ 1, T * NKV, HD } ) );
+            auto q_roped = q_normed.view( shape_t{ 1, T, NH * HD } );
+            auto k_roped = k_normed.view( shape_t{ 1, T, NKV * HD } );
+            L.rope->prefill( q_roped, k_roped, 1, T, position_offset );
+            auto& v_normed = L.v_norm->forward( ( g ? k : v ).view( shape_t{ 1, T * NKV, HD } ) );
+            auto attn = attn_out_->view( shape_t{ 1, T, NH * HD } );
+            L.attn->prefill( q_roped, k_roped, v_normed.view( shape_t{ 1, T, NKV * HD } ), attn, T, position_offset );
+            auto& o = L.o_proj->forward( attn );
+            auto& o_normed = L.post_attn_norm->forward( o );
+            auto res1 = res1_->view( shape_t{ 1, T, D } );
+            Compute::rocmCheck( mila_cdna4_residual_bf16( res1.data(), x3.data(), o_normed.data(), (int64_t)T * D, st ) );
+            auto& ffn_in = L.pre_ffn_norm->forward( res1 );
+            auto& gate_up = L.fc_gate_up->forward( ffn_in );
+            auto act = geglu_->view( shape_t{ 1, T, cfg_.hidden_dim } );
+            Compute::rocmCheck( mila_cdna4_geglu_bf16( act.data(), gate_up.data(), T, (int)cfg_.hidden_dim, st ) );
+            auto& ffn = L.fc_down->forward( act );
+            auto& ffn_normed = L.post_ffn_norm->forward( ffn );
+            auto res2 = res2_->view( shape_t{ 1, T, D } );
+            Compute::rocmCheck( mila_cdna4_residual_bf16( res2.data(), res1.data(), ffn_normed.data(), (int64_t)T * D, st ) );
+            Compute::rocmCheck( mila_cdna4_scale_bf16( output.data(), res2.data(), (int64_t)T * D, L.layer_scalar, st ) );
+        }
+
+        // ---- fused step ---------------------------------------------------------------------------------
+        mila_fused_matvec_args baseArgs( LinearType& lin, uint16_t* y, const uint16_t* x ) const
+        {
+            mila_fused_matvec_args a{};
+            a.y = y; a.x = x; a.W = lin.getWeight().rawData();
+            a.scales = nullptr;
+            if constexpr ( TWeightQuant::kIsQuantized ) a.scales = lin.getWeightScale()->data();
+            a.post_scale = 1.0f; a.eps = cfg_.rms_norm_eps; a.fmt = kFmt; a.K = (int)lin.getConfig().getInputFeatures();
+            a.N = (int)lin.getConfig().getOutputFeatures(); a.group = Quant::Weight::groupSizeOf<TWeightQuant>(); a.geglu = 0;
+            return a;
+        }
+        void plainMatvec( LinearType& lin, uint16_t* y, const uint16_t* x )
+        {
+            auto in = TensorType();   // route through the op so the launch is the same C-ABI call as Linear::forward
+            (void)in;
+            const int K = (int)lin.getConfig().getInputFeatures(), N = (int)lin.getConfig().getOutputFeatures();
+            mila_stream_t st = ctx_->getStream();
+            if constexpr ( kFmt == 0 ) Compute::rocmCheck( mila_cdna4_matvec_bf16( y, x, static_cast<const uint16_t*>( lin.getWeight().rawData() ), nullptr, K, N, st ) );
+            else if constexpr ( kFmt == 1 ) Compute::rocmCheck( mila_cdna4_matvec_bf16_qfp8( y, x, static_cast<const uint8_t*>( lin.getWeight().rawData() ), lin.getWeightScale()->data(), nullptr, K, N, st ) );
+            else Compute::rocmCheck( mila_cdna4_matvec_bf16_qfp4( y, x, static_cast<const uint8_t*>( lin.getWeight().rawData() ), lin.getWeightScale()->data(), nullptr, K, N,
+                                                                  Quant::Weight::groupSizeOf<TWeightQuant>(), st ) );
+        }
+        void fusedGateUp( Layer& L )
+        {
+            auto a = baseArgs( *L.fc_gate_up, f_act_->data(), f_o_->data() );
+            a.N = (int)cfg_.hidden_dim; a.geglu = 1;
+            a.norm_w = L.pre_ffn_norm->getWeight()->data(); a.post_w = L.post_attn_norm->getWeight()->data();
+            a.res = cur_hidden_; a.res_out = res1_->data();
+            Compute::rocmCheck( mila_cdna4_fused_norm_matvec( &a, ctx_->getStream() ) );
+        }
+
+        /// x_l (hidden) -> x_{l+1}.  The sandwich tail of layer l-1 (post_ffn_norm, residual, layer scalar)
+        /// is the prologue of layer l's qkv kernel; the tail of the last layer is the prologue of the head.
+        void enqueueFusedStep( const int32_t* token_dev, int position, const int32_t* pos_dev )
+        {
+            mila_stream_t st = ctx_->getStream();
+            embed( token_dev, 1, *hidden_[ 0 ] );
+            cur_hidden_ = hidden_[ 0 ]->data();
+            int next = 1;
+            const Layer* prev = nullptr;
+            for ( auto& L : layers_ )
+            {
+                const bool g = L.global;
+                const int NH = (int)cfg_.num_heads, NKV = (int)cfg_.numKvHeads( g ), HD = (int)cfg_.headDim( g );
+                // 1. [tail of previous layer] + input_norm + qkv projection
+                auto a = baseArgs( *L.qkv_proj, f_qkv_->data(), prev ? f_down_->data() : cur_hidden_ );
+                a.norm_w = L.input_norm->getWeight()->data();
+                if ( prev )
+                {
+                    a.post_w = prev->post_ffn_norm->getWeight()->data(); a.res = res1_->data(); a.res_out = hidden_[ next ]->data(); a.post_scale = prev->layer_scalar;
+                }
+                Compute::rocmCheck( mila_cdna4_fused_norm_matvec( &a, st ) );
+                if ( prev ) { cur_hidden_ = hidden_[ next ]->data(); next = ( next == 1 ) ? 2 : 1; }
+                // 2. q/k/v norms + RoPE + KV append.  qkv row = [q | k | v] (global: [q | k], V from raw k)
+                const uint16_t* qp = f_qkv_->data();
+                const uint16_t* kp = qp + (size_t)NH * HD;
+                const uint16_t* vp = g ? kp : kp + (size_t)NKV * HD;
+                if ( pos_dev )
+                    Compute::rocmCheck( mila_cdna4_fused_qkv_post_devpos( f_q_->data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
+                                                                          L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(), NH, NKV,
+                                                                          HD, pos_dev, (int)L.attn->cacheCapacity(), cfg_.rms_norm_eps, st ) );
+                else
+                    Compute::rocmCheck( mila_cdna4_fused_qkv_post( f_q_->data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
+                                                                   L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(), NH, NKV, HD,
+                                                                   position, (int)L.attn->cacheCapacity(), cfg_.rms_norm_eps, st ) );
+                // 3. flash-decode (+ combine)
+                const size_t need = attnScratchBytes();
+                void* scratch = ctx_->getScratch( need );
+                if ( pos_dev )
+                    Compute::rocmCheck( mila_cdna4_attn_decode_bf16_devpos( attn_out_->data(), f_q_->data(), L.attn->keyCache(), L.attn->valueCache(), scratch, need, 1, NH, NKV, HD,
+                                                                            (int)L.attn->cacheCapacity(), pos_dev, (int)max_seq_, (int)cfg_.windowFor( g ), L.attn->scale(), st ) );
+                else
+                    Compute::rocmCheck( mila_cdna4_attn_decode_bf16( attn_out_->data(), f_q_->data(), L.attn->keyCache(), L.attn->valueCache(), scratch, need, 1, NH, NKV, HD,
+                                                                     (int)L.attn->cacheCapacity(), position + 1, (int)cfg_.windowFor( g ), L.attn->scale(), st ) );
+                // 4. o_proj
+                plainMatvec( *L.o_proj, f_o_->data(), attn_out_->data() );
+                // 5. post_attn_norm + residual + pre_ffn_norm + gate_up + GeGLU
+                fusedGateUp( L );
+                // 6. fc_down
+                plainMatvec( *L.fc_down, f_down_->data(), f_act_->data() );
+                prev = &L;
+            }
+            // tail of the last layer + final norm + lm_head (fp32 logits)
+            {
+                TensorType* out = hidden_[ next ].get();
+                // the head kernel has no prologue variant with fp32 output: materialise x_L and the final norm
+                auto a_tail = mila_fused_matvec_args{};
+                (void)a_tail;
+                Compute::rocmCheck( mila_cdna4_rmsnorm_bf16( res2_->data(), nullptr, f_down_->data(), prev->post_ffn_norm->getWeight()->data(), nullptr, 1,
+                                                             (int)cfg_.embedding_dim, 1, cfg_.rms_norm_eps, 0.0f, st ) );
+                Compute::rocmCheck( mila_cdna4_residual_bf16( out->data(), res1_->data(), res2_->data(), cfg_.embedding_dim, st ) );
+                Compute::rocmCheck( mila_cdna4_scale_bf16( out->data(), out->data(), cfg_.embedding_dim, prev->layer_scalar, st ) );
+                auto& normed = final_norm_->forward( out->view( shape_t{ 1, 1, cfg_.embedding_dim } ) );
+                head( normed.data() );
+            }
+        }
+
+        GemmaConfig cfg_;
+        dim_t max_seq_, max_prefill_;
+        std::unique_ptr<IExecutionContext> owned_ctx_;
+        Compute::RocmExecutionContext* ctx_{ nullptr };
+        std::vector<Layer> layers_;
+        std::shared_ptr<RmsNormType> final_norm_;
+        std::shared_ptr<LmHeadLinearType> lm_head_;
+        std::unique_ptr<TensorType> hidden_[ 3 ], pf_x_[ 2 ], q_, k_, v_, attn_out_, res1_, res2_, geglu_, f_qkv_, f_q_, f_o_, f_down_, f_act_;
+        std::unique_ptr<LogitsTensor> logits_;
+        std::unique_ptr<TokenTensor> pos_dev_, err_flag_;
+        const uint16_t* cur_hidden_{ nullptr };
+        hipGraph_t graph_{ nullptr };
+        hipGraphExec_t graph_exec_{ nullptr };
+    };
+}

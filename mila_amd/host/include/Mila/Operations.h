@@ -1,0 +1,486 @@
+// Operation layer: OperationType, the OperationTraits primary template, and the CDNA4 (Rocm) op
+// classes it resolves to.  Mirrors /root/reference/Mila/Src/Dnn/Compute/Operations/
+// OperationTraits.Template.ixx:59-60,78-79,95-147, OperationType.ixx:29-49, OperationBase.ixx:21-175
+// and is the build's counterpart of Compute/Devices/Cuda/Operations/OperationTraits.Cuda.ixx.
+//
+// Contract kept from the reference: ops are constructed by the component as
+// std::make_shared<OpType>(IExecutionContext*, const Config&); they cache RAW pointers handed over by
+// setParameters()/setWeightScales() and never own parameters; build() validates shapes and throws;
+// forward() only enqueues work on the context's stream; scratch is fetched from the context on every
+// forward.  Every forward() ends in exactly one C-ABI call (include/mila_cdna4.h).
+#pragma once
+
+#include <cmath>
+
+#include "Core.h"
+#include "Quantization.h"
+
+namespace Mila::Dnn::Compute
+{
+    enum class OperationType
+    {
+        LinearOp, GroupedQueryAttentionOp, MultiHeadAttentionOp, RmsNormOp, LayerNormOp, SoftmaxOp, GeluOp,
+        GegluOp, SwigluOp, RopeOp, LpeOp, TokenEmbeddingOp, ResidualOp, SamplingOp,
+    };
+
+    /// primary stays undefined: a missing (Op, Device, Precision, Policy) row is a compile error
+    template<OperationType TOp, DeviceType TDeviceType, TensorDataType TPrecision, typename TPolicy = void>
+    struct OperationTraits;
+
+    template<OperationType TOp, DeviceType TDeviceType, TensorDataType TPrecision, typename TPolicy = void>
+    concept OperationSupported = requires { sizeof( OperationTraits<TOp, TDeviceType, TPrecision, TPolicy> ); };
+
+    template<typename TOp, typename TTensor>
+    concept UnaryOpConcept = requires( const TOp& op, const TTensor& in, TTensor& out ) { op.forward( in, out ); };
+
+    template<typename TOp, typename TTensor>
+    concept LinearOpConcept = requires( const TOp& op, const TTensor& in, TTensor& out ) { op.forward( in, out ); };
+
+    /// Operation<Dev,Prec> base (OperationBase.ixx:21-175): holds the typed context
+    template<DeviceType TDeviceType, TensorDataType TPrecision>
+    class Operation
+    {
+    public:
+        explicit Operation( IExecutionContext* ctx ) : context_( cast_context<TDeviceType>( ctx ) ) {}
+        virtual ~Operation() = default;
+        ExecutionContext<TDeviceType>* getExecutionContext() const noexcept { return context_; }
+    protected:
+        ExecutionContext<TDeviceType>* context_;
+    };
+
+    using RocmBf16Tensor = Tensor<TensorDataType::BF16, RocmDeviceMemoryResource>;
+
+    // ---------------------------------------------------------------------------------------
+    // Linear
+    // ---------------------------------------------------------------------------------------
+    struct LinearOpConfig
+    {
+        dim_t in_features{ 0 }, out_features{ 0 };
+        bool has_bias{ false };
+    };
+
+    /// counterpart of CudaLinearOp<Prec, TWeightQuant> (OPS/Linear/CudaLinearOp.ixx:107-1287)
+    template<TensorDataType TPrecision, Quant::Weight::WeightQuantPolicy TWeightQuant>
+    class RocmLinearOp : public Operation<DeviceType::Rocm, TPrecision>
+    {
+        static_assert( TPrecision == TensorDataType::BF16, "the CDNA4 Linear rows are BF16 activations" );
+    public:
+        using TensorType = RocmBf16Tensor;
+        static constexpr int kFmt = Quant::Weight::abiWeightFormat<TWeightQuant>();
+        static constexpr int kGroup = Quant::Weight::groupSizeOf<TWeightQuant>();
+
+        RocmLinearOp( IExecutionContext* ctx, const LinearOpConfig& cfg ) : Operation<DeviceType::Rocm, TPrecision>( ctx ), cfg_( cfg )
+        {
+            if ( cfg.in_features <= 0 || cfg.out_features <= 0 ) throw std::invalid_argument( "RocmLinearOp: feature counts must be positive" );
+            if constexpr ( kFmt == 2 )
+                if ( cfg.in_features % kGroup != 0 ) throw std::invalid_argument( "RocmLinearOp: in_features must be a multiple of the FP4 group size" );
+        }
+
+        /// caches raw pointers; never owns (OperationBase.ixx:52-64, CudaLinearOp.ixx:192-241)
+        void setParameters( ITensor* weight, ITensor* bias )
+        {
+            if ( !weight ) throw std::invalid_argument( "RocmLinearOp::setParameters: weight is required" );
+            if ( cfg_.has_bias && !bias ) throw std::invalid_argument( "RocmLinearOp::setParameters: bias is required by the config" );
+            weight_ = weight->rawData();
+            bias_ = bias ? static_cast<const uint16_t*>( bias->rawData() ) : nullptr;
+        }
+
+        void setWeightScales( ITensor* scales )
+        {
+            if constexpr ( !TWeightQuant::kIsQuantized ) throw std::logic_error( "RocmLinearOp::setWeightScales: policy is not quantized" );
+            if ( !scales ) throw std::invalid_argument( "RocmLinearOp::setWeightScales: null scales" );
+            scales_ = static_cast<const float*>( scales->rawData() );
+        }
+
+        void build( const BuildContext& ctx )
+        {
+            const auto& s = ctx.inputShape();
+            if ( s.back() != cfg_.in_features )
+                throw std::invalid_argument( "RocmLinearOp::build: input feature dimension " + std::to_string( s.back() ) +
+                                             " does not match in_features " + std::to_string( cfg_.in_features ) );
+            if ( !weight_ ) throw std::runtime_error( "RocmLinearOp::build: setParameters() must be called first" );
+            if ( TWeightQuant::kIsQuantized && !scales_ ) throw std::runtime_error( "RocmLinearOp::build: setWeightScales() must be called first" );
+            built_ = true;
+        }
+
+        /// M == 1 -> decode matvec; M > 1 -> MFMA GEMM (CudaLinearOp.ixx:535-827)
+        void forward( const TensorType& in, TensorType& out ) const
+        {
+            if ( !built_ ) throw std::runtime_error( "RocmLinearOp::forward: not built" );
+            const int K = narrowToKernelIndex( cfg_.in_features, "in_features" );
+            const int N = narrowToKernelIndex( cfg_.out_features, "out_features" );
+            const int M = narrowToKernelIndex( static_cast<dim_t>( in.size() ) / cfg_.in_features, "outer size" );
+            auto* y = static_cast<uint16_t*>( out.rawData() );
+            auto* x = static_cast<const uint16_t*>( in.rawData() );
+            mila_stream_t st = this->context_->getStream();
+            if ( M == 1 )
+            {
+                if constexpr ( kFmt == 0 ) rocmCheck( mila_cdna4_matvec_bf16( y, x, static_cast<const uint16_t*>( weight_ ), bias_, K, N, st ) );
+                else if constexpr ( kFmt == 1 ) rocmCheck( mila_cdna4_matvec_bf16_qfp8( y, x, static_cast<const uint8_t*>( weight_ ), scales_, bias_, K, N, st ) );
+                else rocmCheck( mila_cdna4_matvec_bf16_qfp4( y, x, static_cast<const uint8_t*>( weight_ ), scales_, bias_, K, N, kGroup, st ) );
+            }
+            else
+            {
+                if constexpr ( kFmt == 0 ) rocmCheck( mila_cdna4_gemm_bf16( y, x, static_cast<const uint16_t*>( weight_ ), bias_, M, K, N, st ) );
+                else if constexpr ( kFmt == 1 ) rocmCheck( mila_cdna4_gemm_bf16_w8a16( y, x, static_cast<const uint8_t*>( weight_ ), scales_, bias_, M, K, N, st ) );
+                else rocmCheck( mila_cdna4_gemm_bf16_w4a16( y, x, static_cast<const uint8_t*>( weight_ ), scales_, bias_, M, K, N, kGroup, st ) );
+            }
+        }
+
+        void backward( const TensorType&, const TensorType&, TensorType& ) const
+        {
+            throw std::logic_error( "RocmLinearOp::backward: the CDNA4 backend is inference-only (and the reference forbids backward on quantized weights)" );
+        }
+
+        /// quantize-on-load: bf16 source already on the device (CudaLinearOp.ixx:332-392)
+        void quantize( const uint16_t* src_bf16_device, ITensor& weight_out, ITensor& scales_out ) const
+        {
+            const int K = narrowToKernelIndex( cfg_.in_features, "in_features" );
+            const int N = narrowToKernelIndex( cfg_.out_features, "out_features" );
+            mila_stream_t st = this->context_->getStream();
+            if constexpr ( kFmt == 1 )
+                rocmCheck( mila_cdna4_quantize_fp8_per_channel( static_cast<uint8_t*>( weight_out.rawData() ), static_cast<float*>( scales_out.rawData() ), src_bf16_device, N, K, st ) );
+            else if constexpr ( kFmt == 2 )
+                rocmCheck( mila_cdna4_quantize_fp4_per_group( static_cast<uint8_t*>( weight_out.rawData() ), static_cast<float*>( scales_out.rawData() ), src_bf16_device, N, K, kGroup, st ) );
+            else
+                throw std::logic_error( "RocmLinearOp::quantize: NoWeightQuant has no quantize path" );
+        }
+
+        void onQuantizedWeightsLoaded() {}
+
+        const void* weightPtr() const noexcept { return weight_; }
+        const float* scalesPtr() const noexcept { return scales_; }
+        const LinearOpConfig& config() const noexcept { return cfg_; }
+
+    private:
+        LinearOpConfig cfg_;
+        const void* weight_{ nullptr };
+        const uint16_t* bias_{ nullptr };
+        const float* scales_{ nullptr };
+        bool built_{ false };
+    };
+
+    template<typename TPolicy>
+    struct OperationTraits<OperationType::LinearOp, DeviceType::Rocm, TensorDataType::BF16, TPolicy>
+    {
+        using type = RocmLinearOp<TensorDataType::BF16, TPolicy>;
+    };
+    // PerGroupInt4 has no row, like the quantize path of the reference (CudaLinearOp.ixx:385-391)
+    template<int G>
+    struct OperationTraits<OperationType::LinearOp, DeviceType::Rocm, TensorDataType::BF16, Quant::Weight::PerGroupInt4<G>>;
+
+    // ---------------------------------------------------------------------------------------
+    // RMSNorm / LayerNorm / Softmax / GELU / GeGLU / Residual
+    // ---------------------------------------------------------------------------------------
+    struct NormOpConfig
+    {
+        dim_t dim{ 0 };
+        float epsilon{ 1e-5f };
+        bool has_bias{ true };
+        float weight_offset{ 0.0f };   ///< RmsNormConfig unit_offset
+    };
+
+    class RocmRmsNormOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    {
+    public:
+        using TensorType = RocmBf16Tensor;
+        RocmRmsNormOp( IExecutionContext* ctx, const NormOpConfig& cfg ) : Operation( ctx ), cfg_( cfg )
+        {
+            if ( cfg.dim <= 0 ) throw std::invalid_argument( "RocmRmsNormOp: normalized dimension must be positive" );
+        }
+        void setParameters( ITensor* weight, ITensor* bias )
+        {
+            w_ = weight ? static_cast<const uint16_t*>( weight->rawData() ) : nullptr;
+            b_ = bias ? static_cast<const uint16_t*>( bias->rawData() ) : nullptr;
+        }
+        void build( const BuildContext& ctx )
+        {
+            if ( ctx.inputShape().back() != cfg_.dim ) throw std::invalid_argument( "RocmRmsNormOp::build: trailing dimension does not match the normalized shape" );
+            built_ = true;
+        }
+        void forward( const TensorType& in, TensorType& out ) const
+        {
+            if ( !built_ ) throw std::runtime_error( "RocmRmsNormOp::forward: not built" );
+            const int dim = narrowToKernelIndex( cfg_.dim, "dim" );
+            const int outer = narrowToKernelIndex( static_cast<dim_t>( in.size() ) / cfg_.dim, "outer" );
+            rocmCheck( mila_cdna4_rmsnorm_bf16( static_cast<uint16_t*>( out.rawData() ), nullptr, static_cast<const uint16_t*>( in.rawData() ), w_, b_,
+                                                outer, dim, 1, cfg_.epsilon, cfg_.weight_offset, context_->getStream() ) );
+        }
+        const uint16_t* weightPtr() const noexcept { return w_; }
+        float epsilon() const noexcept { return cfg_.epsilon; }
+    private:
+        NormOpConfig cfg_;
+        const uint16_t* w_{ nullptr };
+        const uint16_t* b_{ nullptr };
+        bool built_{ false };
+    };
+    template<> struct OperationTraits<OperationType::RmsNormOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmRmsNormOp; };
+
+    class RocmLayerNormOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    {
+    public:
+        using TensorType = RocmBf16Tensor;
+        RocmLayerNormOp( IExecutionContext* ctx, const NormOpConfig& cfg ) : Operation( ctx ), cfg_( cfg ) {}
+        void setParameters( ITensor* weight, ITensor* bias )
+        {
+            w_ = weight ? static_cast<const uint16_t*>( weight->rawData() ) : nullptr;
+            b_ = bias ? static_cast<const uint16_t*>( bias->rawData() ) : nullptr;
+        }
+        void build( const BuildContext& ) { built_ = true; }
+        void forward( const TensorType& in, TensorType& out ) const
+        {
+            if ( !built_ ) throw std::runtime_error( "RocmLayerNormOp::forward: operation must be built before forward()" );
+            const int dim = narrowToKernelIndex( cfg_.dim, "dim" );
+            const int outer = narrowToKernelIndex( static_cast<dim_t>( in.size() ) / cfg_.dim, "outer" );
+            rocmCheck( mila_cdna4_layernorm_bf16( static_cast<uint16_t*>( out.rawData() ), nullptr, nullptr, static_cast<const uint16_t*>( in.rawData() ),
+                                                  w_, b_, outer, dim, cfg_.epsilon, context_->getStream() ) );
+        }
+    private:
+        NormOpConfig cfg_;
+        const uint16_t* w_{ nullptr };
+        const uint16_t* b_{ nullptr };
+        bool built_{ false };
+    };
+    template<> struct OperationTraits<OperationType::LayerNormOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmLayerNormOp; };
+
+    class RocmGeluOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    {
+    public:
+        using TensorType = RocmBf16Tensor;
+        explicit RocmGeluOp( IExecutionContext* ctx ) : Operation( ctx ) {}
+        void forward( const TensorType& in, TensorType& out ) const
+        {
+            rocmCheck( mila_cdna4_gelu_bf16( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( in.rawData() ),
+                                             static_cast<int64_t>( in.size() ), context_->getStream() ) );
+        }
+    };
+    template<> struct OperationTraits<OperationType::GeluOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmGeluOp; };
+
+    /// Swiglu<..., Gelu> resolves to the GeGLU op (Gemma.Block.ixx:150)
+    class RocmGegluOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    {
+    public:
+        using TensorType = RocmBf16Tensor;
+        explicit RocmGegluOp( IExecutionContext* ctx ) : Operation( ctx ) {}
+        void forward( const TensorType& in, TensorType& out ) const
+        {
+            const dim_t two_h = in.shape().back();
+            if ( two_h % 2 != 0 ) throw std::invalid_argument( "RocmGegluOp::forward: the last dimension must be even ([gate | up])" );
+            const int half = narrowToKernelIndex( two_h / 2, "half" );
+            const int tokens = narrowToKernelIndex( static_cast<dim_t>( in.size() ) / two_h, "tokens" );
+            rocmCheck( mila_cdna4_geglu_bf16( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( in.rawData() ), tokens, half, context_->getStream() ) );
+        }
+    };
+    template<> struct OperationTraits<OperationType::GegluOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmGegluOp; };
+
+    class RocmResidualOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    {
+    public:
+        using TensorType = RocmBf16Tensor;
+        explicit RocmResidualOp( IExecutionContext* ctx ) : Operation( ctx ) {}
+        void forward( const TensorType& a, const TensorType& b, TensorType& out ) const
+        {
+            if ( a.size() != b.size() ) throw std::invalid_argument( "RocmResidualOp::forward: operand sizes differ" );
+            rocmCheck( mila_cdna4_residual_bf16( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( a.rawData() ),
+                                                 static_cast<const uint16_t*>( b.rawData() ), static_cast<int64_t>( a.size() ), context_->getStream() ) );
+        }
+    };
+    template<> struct OperationTraits<OperationType::ResidualOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmResidualOp; };
+
+    class RocmSoftmaxOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    {
+    public:
+        using TensorType = RocmBf16Tensor;
+        RocmSoftmaxOp( IExecutionContext* ctx, int axis ) : Operation( ctx ), axis_( axis ) {}
+        void forward( const TensorType& in, TensorType& out ) const
+        {
+            const auto& s = in.shape();
+            const int rank = static_cast<int>( s.size() );
+            const int ax = axis_ < 0 ? axis_ + rank : axis_;
+            if ( ax < 0 || ax >= rank ) throw std::invalid_argument( "RocmSoftmaxOp::forward: axis out of range" );
+            dim_t outer = 1, inner = 1;
+            for ( int i = 0; i < ax; ++i ) outer *= s[ i ];
+            for ( int i = ax + 1; i < rank; ++i ) inner *= s[ i ];
+            rocmCheck( mila_cdna4_softmax_bf16( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( in.rawData() ),
+                                                narrowToKernelIndex( outer, "outer" ), narrowToKernelIndex( s[ ax ], "dim" ),
+                                                narrowToKernelIndex( inner, "inner" ), context_->getStream() ) );
+        }
+    private:
+        int axis_;
+    };
+    template<> struct OperationTraits<OperationType::SoftmaxOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmSoftmaxOp; };
+
+    // ---------------------------------------------------------------------------------------
+    // RoPE (IPositionalPairedOp) -- cache built once per (max_seq, head_dim, base, rotary_dim)
+    // ---------------------------------------------------------------------------------------
+    struct RopeOpConfig
+    {
+        dim_t max_seq{ 0 }, head_dim{ 0 }, num_heads{ 0 }, num_kv_heads{ 0 };
+        float base{ 10000.0f };
+        dim_t rotary_dim{ 0 };
+    };
+
+    class RocmRopeOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    {
+    public:
+        using TensorType = RocmBf16Tensor;
+        using CacheTensor = Tensor<TensorDataType::FP32, RocmDeviceMemoryResource>;
+        RocmRopeOp( IExecutionContext* ctx, const RopeOpConfig& cfg ) : Operation( ctx ), cfg_( cfg )
+        {
+            if ( cfg.head_dim <= 0 || cfg.head_dim % 2 != 0 ) throw std::invalid_argument( "RocmRopeOp: head_dim must be positive and even" );
+            if ( cfg.max_seq <= 0 ) throw std::invalid_argument( "RocmRopeOp: max_seq must be positive" );
+        }
+        void build( const BuildContext& )
+        {
+            cos_ = std::make_unique<CacheTensor>( context_->getDeviceId(), shape_t{ cfg_.max_seq, cfg_.head_dim / 2 } );
+            sin_ = std::make_unique<CacheTensor>( context_->getDeviceId(), shape_t{ cfg_.max_seq, cfg_.head_dim / 2 } );
+            rocmCheck( mila_cdna4_rope_build_cache( cos_->data(), sin_->data(), narrowToKernelIndex( cfg_.max_seq, "max_seq" ),
+                                                    narrowToKernelIndex( cfg_.head_dim, "head_dim" ), cfg_.base,
+                                                    narrowToKernelIndex( cfg_.rotary_dim, "rotary_dim" ), context_->getStream() ) );
+            built_ = true;
+        }
+        /// rotate q [B,T,NH,HS] and k [B,T,NKV,HS] in place (Components/Encodings/Rope/Rope.ixx:107,160-200)
+        void prefill( TensorType& q, TensorType& k, int B, int T, int position_offset ) const
+        {
+            if ( !built_ ) throw std::runtime_error( "RocmRopeOp: not built" );
+            auto* qp = static_cast<uint16_t*>( q.rawData() );
+            auto* kp = static_cast<uint16_t*>( k.rawData() );
+            rocmCheck( mila_cdna4_rope_forward_bf16( qp, kp, qp, kp, cos_->data(), sin_->data(), B, T, narrowToKernelIndex( cfg_.num_heads, "NH" ),
+                                                     narrowToKernelIndex( cfg_.num_kv_heads, "NKV" ), narrowToKernelIndex( cfg_.head_dim, "HS" ),
+                                                     position_offset, narrowToKernelIndex( cfg_.max_seq, "max_seq" ), context_->getStream() ) );
+        }
+        void decode( TensorType& q, TensorType& k, int B, int position ) const { prefill( q, k, B, 1, position ); }
+        const float* cosCache() const noexcept { return cos_ ? cos_->data() : nullptr; }
+        const float* sinCache() const noexcept { return sin_ ? sin_->data() : nullptr; }
+    private:
+        RopeOpConfig cfg_;
+        std::unique_ptr<CacheTensor> cos_, sin_;
+        bool built_{ false };
+    };
+    template<> struct OperationTraits<OperationType::RopeOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmRopeOp; };
+
+    // ---------------------------------------------------------------------------------------
+    // Grouped-query attention over an op-owned KV cache (IKvInference)
+    // ---------------------------------------------------------------------------------------
+    struct GqaOpConfig
+    {
+        dim_t num_heads{ 0 }, num_kv_heads{ 0 }, head_dim{ 0 };
+        dim_t window{ 0 };               ///< 0 = global
+        float attention_scale{ 0.0f };   ///< <= 0 -> 1/sqrt(head_dim)  (GroupedQueryAttention.Config.ixx:190-200)
+    };
+
+    /// counterpart of CudaGqaOp<Prec, kBounded> (OPS/Attention/GQA/CudaGqaOp.ixx:97-985)
+    template<bool kBoundedRing>
+    class RocmGqaOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    {
+    public:
+        using TensorType = RocmBf16Tensor;
+        RocmGqaOp( IExecutionContext* ctx, const GqaOpConfig& cfg ) : Operation( ctx ), cfg_( cfg )
+        {
+            if ( cfg.num_heads <= 0 || cfg.num_kv_heads <= 0 || cfg.num_heads % cfg.num_kv_heads != 0 )
+                throw std::invalid_argument( "RocmGqaOp: num_heads must be a positive multiple of num_kv_heads" );
+            if ( cfg.head_dim <= 0 ) throw std::invalid_argument( "RocmGqaOp: head_dim must be positive" );
+            if ( kBoundedRing && cfg.window <= 0 ) throw std::invalid_argument( "RocmGqaOp: a bounded ring cache needs a sliding window" );
+        }
+
+        float scale() const noexcept { return cfg_.attention_scale > 0.0f ? cfg_.attention_scale : 1.0f / std::sqrt( static_cast<float>( cfg_.head_dim ) ); }
+
+        /// capacity rule of CudaGqaOp::resolveCacheCapacity (CudaGqaOp.ixx:552-574)
+        static dim_t resolveCacheCapacity( dim_t max_seq, dim_t window, dim_t prefill_chunk )
+        {
+            if constexpr ( kBoundedRing ) return std::min( max_seq, window + std::max<dim_t>( prefill_chunk, 1 ) - 1 );
+            else return max_seq;
+        }
+
+        void initializeKvCache( int batch, dim_t max_seq, dim_t prefill_chunk )
+        {
+            batch_ = batch;
+            capacity_ = resolveCacheCapacity( max_seq, cfg_.window, prefill_chunk );
+            const shape_t s{ batch, cfg_.num_kv_heads, capacity_, cfg_.head_dim };
+            k_cache_ = std::make_unique<TensorType>( context_->getDeviceId(), s );
+            v_cache_ = std::make_unique<TensorType>( context_->getDeviceId(), s );
+            length_ = 0;
+        }
+        void resetKvCache() noexcept { length_ = 0; }
+        void rewindKvCache( dim_t length )
+        {
+            if ( length < 0 || length > length_ ) throw std::invalid_argument( "RocmGqaOp::rewindKvCache: bad length" );
+            if ( kBoundedRing && length_ - length >= capacity_ ) throw std::runtime_error( "RocmGqaOp::rewindKvCache: evicted positions cannot be restored" );
+            length_ = length;
+        }
+        dim_t cacheLength() const noexcept { return length_; }
+        dim_t cacheCapacity() const noexcept { return capacity_; }
+
+        /// q [B,chunk,NH*HS], k/v [B,chunk,NKV*HS] at absolute positions [position, position+chunk)
+        void prefill( const TensorType& q, const TensorType& k, const TensorType& v, TensorType& out, int chunk, int position )
+        {
+            requireCache();
+            mila_stream_t st = context_->getStream();
+            const int NH = (int)cfg_.num_heads, NKV = (int)cfg_.num_kv_heads, HS = (int)cfg_.head_dim, cap = (int)capacity_;
+            rocmCheck( mila_cdna4_kv_write_bf16( k_cache_->data(), v_cache_->data(), q_cast( k ), q_cast( v ), batch_, chunk, NKV, HS, position, cap, st ) );
+            rocmCheck( mila_cdna4_attn_prefill_bf16( out.data(), q_cast( q ), k_cache_->data(), v_cache_->data(), batch_, chunk, NH, NKV, HS, cap,
+                                                     position, (int)cfg_.window, scale(), st ) );
+            length_ = position + chunk;
+        }
+
+        /// one token per sequence at absolute position `position`
+        void decode( const TensorType& q, const TensorType& k, const TensorType& v, TensorType& out, int position )
+        {
+            requireCache();
+            mila_stream_t st = context_->getStream();
+            const int NH = (int)cfg_.num_heads, NKV = (int)cfg_.num_kv_heads, HS = (int)cfg_.head_dim, cap = (int)capacity_;
+            rocmCheck( mila_cdna4_kv_write_bf16( k_cache_->data(), v_cache_->data(), q_cast( k ), q_cast( v ), batch_, 1, NKV, HS, position, cap, st ) );
+            attendDecode( q, out, position );
+        }
+
+        /// attention only (the fused q/k/v post-processing kernel has already appended K/V)
+        void attendDecode( const TensorType& q, TensorType& out, int position )
+        {
+            requireCache();
+            const int NH = (int)cfg_.num_heads, NKV = (int)cfg_.num_kv_heads, HS = (int)cfg_.head_dim, cap = (int)capacity_;
+            const size_t need = mila_cdna4_attn_decode_scratch_bytes( batch_, NH, HS );
+            void* scratch = context_->getScratch( need );   // fetched per forward, never cached
+            rocmCheck( mila_cdna4_attn_decode_bf16( out.data(), q_cast( q ), k_cache_->data(), v_cache_->data(), scratch, need, batch_, NH, NKV, HS, cap,
+                                                    position + 1, (int)cfg_.window, scale(), context_->getStream() ) );
+            length_ = position + 1;
+        }
+
+        uint16_t* keyCache() noexcept { return k_cache_ ? k_cache_->data() : nullptr; }
+        uint16_t* valueCache() noexcept { return v_cache_ ? v_cache_->data() : nullptr; }
+        const GqaOpConfig& config() const noexcept { return cfg_; }
+
+    private:
+        static const uint16_t* q_cast( const TensorType& t ) { return static_cast<const uint16_t*>( t.rawData() ); }
+        void requireCache() const { if ( !k_cache_ ) throw std::runtime_error( "RocmGqaOp: initializeKvCache() must be called first" ); }
+        GqaOpConfig cfg_;
+        std::unique_ptr<TensorType> k_cache_, v_cache_;
+        int batch_{ 1 };
+        dim_t capacity_{ 0 }, length_{ 0 };
+    };
+    template<typename TKvPolicy>
+    struct OperationTraits<OperationType::GroupedQueryAttentionOp, DeviceType::Rocm, TensorDataType::BF16, TKvPolicy>
+    {
+        using type = RocmGqaOp<TKvPolicy::kBoundedRing>;
+    };
+
+    /// GPT-2 attention on packed QKV (new BF16 row; the reference's CUDA MHA is FP32-only,
+    /// OPS/OperationTraits.Cuda.ixx:274-282)
+    class RocmMultiHeadAttentionOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    {
+    public:
+        using TensorType = RocmBf16Tensor;
+        RocmMultiHeadAttentionOp( IExecutionContext* ctx, dim_t model_dim, dim_t num_heads ) : Operation( ctx ), C_( model_dim ), NH_( num_heads )
+        {
+            if ( model_dim <= 0 || num_heads <= 0 || model_dim % num_heads != 0 ) throw std::invalid_argument( "RocmMultiHeadAttentionOp: model_dim must be a positive multiple of num_heads" );
+        }
+        void forward( const TensorType& qkv, TensorType& out ) const
+        {
+            const auto& s = qkv.shape();
+            if ( s.size() != 3 || s[ 2 ] != 3 * C_ ) throw std::invalid_argument( "RocmMultiHeadAttentionOp::forward: expected [B, T, 3C]" );
+            rocmCheck( mila_cdna4_mha_bf16( out.data(), static_cast<const uint16_t*>( qkv.rawData() ), (int)s[ 0 ], (int)s[ 1 ], (int)C_, (int)NH_, context_->getStream() ) );
+        }
+    private:
+        dim_t C_, NH_;
+    };
+    template<> struct OperationTraits<OperationType::MultiHeadAttentionOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmMultiHeadAttentionOp; };
+}

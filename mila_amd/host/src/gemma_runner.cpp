@@ -1,0 +1,265 @@
+// C entry points over the C++ host mirror for bench.py / tests (plain pointers and sizes only).
+// Instantiates GemmaTransformer<TWeightQuant> for the three weight policies of BASELINE.json
+// configs 3-5 and exposes build / prefill / decode / timing.
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <variant>
+
+#include "Mila/Gemma.h"
+
+using namespace Mila::Dnn;
+using Quant::Weight::NoWeightQuant;
+using Quant::Weight::PerChannelFp8;
+using Quant::Weight::PerGroupFp4;
+
+namespace
+{
+    thread_local std::string g_err;
+
+    struct Runner
+    {
+        std::variant<std::unique_ptr<GemmaTransformer<NoWeightQuant>>, std::unique_ptr<GemmaTransformer<PerChannelFp8<>>>,
+                     std::unique_ptr<GemmaTransformer<PerGroupFp4<128>>>> model;
+        std::unique_ptr<Tensor<TensorDataType::INT32, Compute::RocmDeviceMemoryResource>> tokens;
+        dim_t max_prefill{ 1 };
+        bool graph_captured{ false };
+    };
+
+    template<typename F> int guarded( F&& f )
+    {
+        try { f(); return 0; }
+        catch ( const std::invalid_argument& e ) { g_err = std::string( "invalid_argument: " ) + e.what(); return MILA_E_INVALID_ARGUMENT; }
+        catch ( const std::exception& e ) { g_err = e.what(); return MILA_E_RUNTIME; }
+    }
+}
+
+extern "C" {
+
+#define HOST_API __attribute__((visibility("default")))
+
+struct mila_gemma_config
+{
+    int64_t vocab_size, embedding_dim, num_layers, num_heads, num_kv_heads, head_dim, hidden_dim, global_head_dim,
+            num_global_kv_heads, window, sliding_window_pattern, global_rotary_dim;
+};
+
+HOST_API const char* mila_host_last_error( void ) { return g_err.c_str(); }
+
+/// policy: 0 NoWeightQuant (bf16), 1 PerChannelFp8<>, 2 PerGroupFp4<128>.  cfg == NULL -> Gemma-4 12B.
+HOST_API void* mila_gemma_create( int policy, const mila_gemma_config* c, int64_t max_seq, int64_t max_prefill, uint64_t seed )
+{
+    Runner* r = nullptr;
+    int rc = guarded( [&]
+    {
+        GemmaConfig cfg;
+        if ( c )
+        {
+            cfg.vocab_size = c->vocab_size; cfg.embedding_dim = c->embedding_dim; cfg.num_layers = c->num_layers; cfg.num_heads = c->num_heads;
+            cfg.num_kv_heads = c->num_kv_heads; cfg.head_dim = c->head_dim; cfg.hidden_dim = c->hidden_dim; cfg.global_head_dim = c->global_head_dim;
+            cfg.num_global_kv_heads = c->num_global_kv_heads; cfg.window = c->window; cfg.sliding_window_pattern = c->sliding_window_pattern;
+            cfg.global_rotary_dim = c->global_rotary_dim;
+        }
+        auto rr = std::make_unique<Runner>();
+        rr->max_prefill = max_prefill;
+        switch ( policy )
+        {
+            case 0: rr->model = std::make_unique<GemmaTransformer<NoWeightQuant>>( cfg, max_seq, max_prefill ); break;
+            case 1: rr->model = std::make_unique<GemmaTransformer<PerChannelFp8<>>>( cfg, max_seq, max_prefill ); break;
+            case 2: rr->model = std::make_unique<GemmaTransformer<PerGroupFp4<128>>>( cfg, max_seq, max_prefill ); break;
+            default: throw std::invalid_argument( "unknown weight policy" );
+        }
+        std::visit( [&]( auto& m )
+        {
+            m->initSynthetic( seed );
+            rr->tokens = std::make_unique<Tensor<TensorDataType::INT32, Compute::RocmDeviceMemoryResource>>(
+                m->context()->getDeviceId(), shape_t{ std::max<dim_t>( max_prefill, 1 ) } );
+        }, rr->model );
+        r = rr.release();
+    } );
+    return rc == 0 ? r : nullptr;
+}
+
+HOST_API void mila_gemma_destroy( void* h ) { delete static_cast<Runner*>( h ); }
+
+static void upload_tokens( Runner* r, const int32_t* host_tokens, int64_t n )
+{
+    std::visit( [&]( auto& m )
+    {
+        Compute::rocmCheck( mila_cdna4_memcpy_h2d( r->tokens->data(), host_tokens, static_cast<size_t>( n ) * 4, m->context()->getStream() ) );
+        m->context()->synchronize();
+    }, r->model );
+}
+
+static void download_logits( Runner* r, float* host_logits )
+{
+    if ( !host_logits ) return;
+    std::visit( [&]( auto& m )
+    {
+        auto& lg = m->logits();
+        Compute::rocmCheck( mila_cdna4_memcpy_d2h( host_logits, lg.data(), lg.sizeInBytes(), m->context()->getStream() ) );
+        m->context()->synchronize();
+    }, r->model );
+}
+
+HOST_API int mila_gemma_prefill( void* h, const int32_t* host_tokens, int64_t T, int64_t position_offset, float* host_logits )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&]
+    {
+        upload_tokens( r, host_tokens, T );
+        std::visit( [&]( auto& m ) { m->prefill( *r->tokens, T, position_offset ); m->context()->synchronize(); }, r->model );
+        download_logits( r, host_logits );
+    } );
+}
+
+/// mode: 0 reference-order (one launch per component), 1 fused schedule, 2 graph replay (position from device)
+HOST_API int mila_gemma_decode( void* h, int32_t token, int64_t position, int mode, float* host_logits )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&]
+    {
+        upload_tokens( r, &token, 1 );
+        std::visit( [&]( auto& m )
+        {
+            if ( mode == 0 ) m->decode( *r->tokens, position );
+            else if ( mode == 1 ) m->decodeFused( *r->tokens, position );
+            else
+            {
+                if ( !r->graph_captured ) { m->captureGraph( *r->tokens, position ); r->graph_captured = true; }
+                m->setDevicePosition( position );
+                m->replayGraph();
+            }
+            m->context()->synchronize();
+        }, r->model );
+        download_logits( r, host_logits );
+    } );
+}
+
+/// Timed decode: `warmup` untimed steps then `steps` timed ones from `start_position`, token ids
+/// cycling through a fixed pattern (the sampler is outside the measured path).
+/// out[0] = wall ms per step (host clock around the timed region, stream synchronised both sides)
+/// out[1] = device ms per step (HIP events on the model stream)
+HOST_API int mila_gemma_time_decode( void* h, int64_t start_position, int steps, int warmup, int mode, double* out )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&]
+    {
+        int32_t tok = 17;
+        upload_tokens( r, &tok, 1 );
+        std::visit( [&]( auto& m )
+        {
+            auto* ctx = m->context();
+            hipStream_t s = reinterpret_cast<hipStream_t>( ctx->getStream() );
+            if ( mode == 2 && !r->graph_captured ) { m->captureGraph( *r->tokens, start_position ); r->graph_captured = true; }
+            if ( mode == 2 ) m->setDevicePosition( start_position );
+            auto step = [&]( int64_t pos )
+            {
+                if ( mode == 0 ) m->decode( *r->tokens, pos );
+                else if ( mode == 1 ) m->decodeFused( *r->tokens, pos );
+                else m->replayGraph();
+            };
+            int64_t pos = start_position;
+            for ( int i = 0; i < warmup; ++i ) step( pos++ );
+            ctx->synchronize();
+            hipEvent_t e0, e1;
+            hipCheck( hipEventCreate( &e0 ), "hipEventCreate" );
+            hipCheck( hipEventCreate( &e1 ), "hipEventCreate" );
+            const auto t0 = std::chrono::steady_clock::now();
+            hipCheck( hipEventRecord( e0, s ), "hipEventRecord" );
+            for ( int i = 0; i < steps; ++i ) step( pos++ );
+            hipCheck( hipEventRecord( e1, s ), "hipEventRecord" );
+            ctx->synchronize();
+            const auto t1 = std::chrono::steady_clock::now();
+            float ms = 0;
+            hipCheck( hipEventElapsedTime( &ms, e0, e1 ), "hipEventElapsedTime" );
+            hipEventDestroy( e0 ); hipEventDestroy( e1 );
+            out[ 0 ] = std::chrono::duration<double, std::milli>( t1 - t0 ).count() / steps;
+            out[ 1 ] = static_cast<double>( ms ) / steps;
+        }, r->model );
+    } );
+}
+
+/// Average launch duration of the dominant kernel (fc_gate_up fused matvec) measured with HIP events on
+/// the model stream: `rounds` passes over all layers' weights (so no pass re-reads a cached matrix).
+/// out[0] = average microseconds per launch, out[1] = algorithmic bytes per launch
+HOST_API int mila_gemma_time_dominant_kernel( void* h, int rounds, double* out )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&]
+    {
+        std::visit( [&]( auto& m )
+        {
+            auto* ctx = m->context();
+            hipStream_t s = reinterpret_cast<hipStream_t>( ctx->getStream() );
+            const size_t L = m->layers().size();
+            for ( size_t i = 0; i < L; ++i ) m->launchGateUp( i );
+            ctx->synchronize();
+            hipEvent_t e0, e1;
+            hipCheck( hipEventCreate( &e0 ), "hipEventCreate" );
+            hipCheck( hipEventCreate( &e1 ), "hipEventCreate" );
+            hipCheck( hipEventRecord( e0, s ), "hipEventRecord" );
+            for ( int k = 0; k < rounds; ++k )
+                for ( size_t i = 0; i < L; ++i ) m->launchGateUp( i );
+            hipCheck( hipEventRecord( e1, s ), "hipEventRecord" );
+            ctx->synchronize();
+            float ms = 0;
+            hipCheck( hipEventElapsedTime( &ms, e0, e1 ), "hipEventElapsedTime" );
+            hipEventDestroy( e0 ); hipEventDestroy( e1 );
+            out[ 0 ] = static_cast<double>( ms ) * 1e3 / ( static_cast<double>( rounds ) * L );
+            out[ 1 ] = m->gateUpBytes( 0 );
+        }, r->model );
+    } );
+}
+
+HOST_API int mila_gemma_time_prefill( void* h, int64_t T, int reps, double* out_ms )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&]
+    {
+        std::vector<int32_t> toks( static_cast<size_t>( T ) );
+        for ( int64_t i = 0; i < T; ++i ) toks[ i ] = static_cast<int32_t>( ( i * 7919 + 13 ) % 1000 );
+        upload_tokens( r, toks.data(), T );
+        std::visit( [&]( auto& m )
+        {
+            auto* ctx = m->context();
+            hipStream_t s = reinterpret_cast<hipStream_t>( ctx->getStream() );
+            m->prefill( *r->tokens, T, 0 );
+            ctx->synchronize();
+            hipEvent_t e0, e1;
+            hipCheck( hipEventCreate( &e0 ), "hipEventCreate" );
+            hipCheck( hipEventCreate( &e1 ), "hipEventCreate" );
+            hipCheck( hipEventRecord( e0, s ), "hipEventRecord" );
+            for ( int i = 0; i < reps; ++i ) m->prefill( *r->tokens, T, 0 );
+            hipCheck( hipEventRecord( e1, s ), "hipEventRecord" );
+            ctx->synchronize();
+            float ms = 0;
+            hipCheck( hipEventElapsedTime( &ms, e0, e1 ), "hipEventElapsedTime" );
+            hipEventDestroy( e0 ); hipEventDestroy( e1 );
+            *out_ms = static_cast<double>( ms ) / reps;
+        }, r->model );
+    } );
+}
+
+/// model facts for the bench line: out[0] algorithmic bytes per decode token at `context`,
+/// out[1] weight bytes, out[2] Linear parameter count (body), out[3] table parameter count
+HOST_API int mila_gemma_info( void* h, int64_t context, double* out )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&]
+    {
+        std::visit( [&]( auto& m )
+        {
+            out[ 0 ] = m->decodeBytesPerToken( context );
+            out[ 1 ] = m->weightBytes();
+            double p = 0;
+            const auto& c = m->config();
+            for ( dim_t i = 0; i < c.num_layers; ++i ) p += static_cast<double>( c.linearParamsPerLayer( c.isGlobalLayer( i ) ) );
+            out[ 2 ] = p;
+            out[ 3 ] = static_cast<double>( c.vocab_size ) * c.embedding_dim;
+        }, r->model );
+    } );
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+"""Oracle composition of the Gemma-4 forward (decode + prefill) from the CPU oracle's ops, with every
+bf16 rounding the component chain performs.  Order restated from GemmaBlock::prefill / ::decode
+(/root/reference/Mila/Src/Dnn/Components/Transformers/Gemma/Gemma.Block.ixx:197-356) and
+GemmaTransformer::decode (Gemma.ixx:281-297).  TEST INFRASTRUCTURE ONLY.
+
+Block-level parity is "unpinned" in the reference tree (its Gemma tests assert shapes/finiteness only,
+SURVEY.md section 4); this composition is pinned op-by-op through the oracle's own pins."""
+import numpy as np
+
+import orc
+import synth
+
+
+def bf(x):
+    return orc.round_bf16(np.asarray(x, dtype=np.float32))
+
+
+class RefGemma:
+    def __init__(self, cfg, policy, seed):
+        self.c = dict(cfg)
+        self.policy = policy
+        c = self.c
+        D, H = c["embedding_dim"], c["hidden_dim"]
+        self.layers = []
+        for i in range(c["num_layers"]):
+            g = (i + 1) % c["sliding_window_pattern"] == 0
+            HD = c["global_head_dim"] if g else c["head_dim"]
+            NKV = c["num_global_kv_heads"] if g else c["num_kv_heads"]
+            NH = c["num_heads"]
+            qw, kvw = NH * HD, NKV * HD
+            packed = qw + (1 if g else 2) * kvw
+            b = seed * 1000003 + i * 64
+            L = dict(g=g, HD=HD, NKV=NKV, NH=NH,
+                     qkv=self._lin(b + 1, packed, D), o=self._lin(b + 2, D, qw), gu=self._lin(b + 3, 2 * H, D),
+                     down=self._lin(b + 4, D, H),
+                     input_norm=self._norm(b + 5, D), q_norm=self._norm(b + 6, HD), k_norm=self._norm(b + 7, HD),
+                     post_attn=self._norm(b + 8, D), pre_ffn=self._norm(b + 9, D), post_ffn=self._norm(b + 10, D),
+                     K=np.zeros((1, 0, NKV, HD), np.float32), V=np.zeros((1, 0, NKV, HD), np.float32))
+            self.layers.append(L)
+        nl = c["num_layers"]
+        self.final_norm = self._norm(seed * 1000003 + 64 * nl + 1, D)
+        tb = synth.fill_bf16(seed * 1000003 + 64 * nl + 2, c["vocab_size"] * D, 1.0 / np.sqrt(np.float32(D)), 0.0).reshape(c["vocab_size"], D)
+        if policy == "bf16":
+            self.table = ("bf16", tb)
+        else:
+            self.table = ("fp8",) + orc.quantize_fp8_per_channel(tb)
+        self.rope = {}
+
+    def _lin(self, seed, N, K):
+        wb = synth.fill_bf16(seed, N * K, 1.0 / np.sqrt(np.float32(K)), 0.0).reshape(N, K)
+        if self.policy == "bf16":
+            return ("bf16", wb)
+        if self.policy == "fp8":
+            return ("fp8",) + orc.quantize_fp8_per_channel(wb)
+        return ("fp4",) + orc.quantize_fp4_per_group(wb, 128)
+
+    @staticmethod
+    def _norm(seed, n):
+        return orc.from_bf16_bits(synth.fill_bf16(seed, n, 0.1, 1.0))
+
+    @staticmethod
+    def linear(x, W, round_out=True):
+        if W[0] == "bf16":
+            y = orc.linear_bf16w(x, W[1])
+        elif W[0] == "fp8":
+            y = orc.linear_fp8w(x, W[1], W[2])
+        else:
+            y = orc.linear_fp4w(x, W[1], W[2], 128)
+        return bf(y) if round_out else y
+
+    def rms(self, x, w):
+        return bf(orc.rmsnorm(x, w, None, eps=1e-6))
+
+    def embed(self, tokens):
+        D = self.c["embedding_dim"]
+        s = np.sqrt(np.float32(D))
+        if self.table[0] == "bf16":
+            rows = orc.from_bf16_bits(self.table[1][tokens])
+        else:
+            q, sc = self.table[1], self.table[2]
+            rows = bf(orc.E4M3_LUT[q[tokens]] * sc[tokens][:, None])
+        return bf(rows * s)
+
+    def _rope_cache(self, L, max_seq):
+        key = (L["HD"], L["g"])
+        if key not in self.rope:
+            c = self.c
+            self.rope[key] = orc.rope_build_cache(max_seq, L["HD"], 1e6 if L["g"] else 1e4, c["global_rotary_dim"] if L["g"] else 0)
+        return self.rope[key]
+
+    def block(self, x, L, pos, max_seq):
+        """x [T, D] (bf16-valued f32); positions pos..pos+T-1; appends to the layer's K/V history"""
+        T = x.shape[0]
+        NH, NKV, HD = L["NH"], L["NKV"], L["HD"]
+        qkv = self.linear(self.rms(x, L["input_norm"]), L["qkv"])
+        q = qkv[:, :NH * HD].reshape(T, NH, HD)
+        k = qkv[:, NH * HD:NH * HD + NKV * HD].reshape(T, NKV, HD)
+        v = k if L["g"] else qkv[:, NH * HD + NKV * HD:].reshape(T, NKV, HD)
+        qn = self.rms(q, L["q_norm"])
+        kn = self.rms(k, L["k_norm"])
+        cos, sin = self._rope_cache(L, max_seq)
+        qr = bf(orc.rope_rotate(qn[None], cos, sin, pos))[0]
+        kr = bf(orc.rope_rotate(kn[None], cos, sin, pos))[0]
+        vn = self.rms(v, np.ones(HD, np.float32))
+        L["K"] = np.concatenate([L["K"][:, :pos], kr[None]], axis=1)
+        L["V"] = np.concatenate([L["V"][:, :pos], vn[None]], axis=1)
+        window = 0 if L["g"] else self.c["window"]
+        attn = bf(orc.gqa_attention(qr[None], L["K"], L["V"], pos, window, 1.0))[0]
+        o = self.linear(attn, L["o"])
+        res1 = bf(x + self.rms(o, L["post_attn"]))
+        gu = self.linear(self.rms(res1, L["pre_ffn"]), L["gu"])
+        act = bf(orc.geglu(gu))
+        dn = self.linear(act, L["down"])
+        res2 = bf(res1 + self.rms(dn, L["post_ffn"]))
+        return bf(res2 * np.float32(1.0))
+
+    def forward(self, tokens, pos, max_seq):
+        x = self.embed(np.asarray(tokens, dtype=np.int64))
+        for L in self.layers:
+            x = self.block(x, L, pos, max_seq)
+        last = self.rms(x[-1:], self.final_norm)
+        return self.linear(last, self.table, round_out=False)[0]
