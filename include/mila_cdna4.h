@@ -238,6 +238,7 @@ typedef struct mila_fused_matvec_args {
     float post_scale;         /* layer scalar applied to r (1.0f = none)                      */
     float eps;
     int fmt, K, N, group, geglu;
+    int f32_out;              /* != 0: y is float[N] (lm_head logits); not combinable with geglu */
 } mila_fused_matvec_args;
 MILA_API int mila_cdna4_fused_norm_matvec(const mila_fused_matvec_args* host_args, mila_stream_t stream);
 

@@ -54,7 +54,7 @@ class fused_matvec_args(C.Structure):
     _fields_ = [("y", C.c_void_p), ("x", C.c_void_p), ("W", C.c_void_p), ("scales", C.c_void_p),
                 ("norm_w", C.c_void_p), ("post_w", C.c_void_p), ("res", C.c_void_p), ("res_out", C.c_void_p),
                 ("post_scale", C.c_float), ("eps", C.c_float), ("fmt", C.c_int), ("K", C.c_int),
-                ("N", C.c_int), ("group", C.c_int), ("geglu", C.c_int)]
+                ("N", C.c_int), ("group", C.c_int), ("geglu", C.c_int), ("f32_out", C.c_int)]
 
 
 def _ptr(t):

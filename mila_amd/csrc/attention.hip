@@ -86,20 +86,24 @@ __device__ __forceinline__ void load_row(uint32_t (&dst)[EPL / 2], const uint16_
     }
 }
 
-// HS = 64 * EPL (EPL in {2,4,8}) or HS = 64 handled as EPL = 2 on 32 active lanes (LANES = 32).
-template <int HS, int GS>
+// HS = 64 * EPL (EPL in {2,4,8}) or HS = 64 handled as EPL = 2 on 32 active lanes.
+// GH = query heads handled per workgroup (<= 4): grid.y = NKV * (GS / GH); the head groups of one
+// KV head re-read the same K/V rows from L2, which costs nothing next to the 4x cut in per-wave
+// VALU work and registers for MQA (GS = 16).
+template <int HS, int GH>
 __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
 {
     constexpr int EPL = (HS >= 128) ? HS / 64 : 2;
     constexpr int NPAIR = EPL / 2;
     constexpr int ACTIVE = HS / EPL;                       // lanes that own data (64, or 32 for HS = 64)
-    constexpr int HC = (GS < 4) ? GS : 4;                  // heads merged per LDS round
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* sm = reinterpret_cast<float*>(smem_raw);        // [4 waves][HC][HS + 2]
+    float* sm = reinterpret_cast<float*>(smem_raw);        // [4 waves][GH][HS + 2]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool owner = lane < ACTIVE;
-    const int split = blockIdx.x, kvh = blockIdx.y;
+    const int GS = p.NH / p.NKV, hgroups = GS / GH;
+    const int split = blockIdx.x, kvh = blockIdx.y / hgroups, hg = blockIdx.y % hgroups;
+    const int h0 = kvh * GS + hg * GH;                     // first query head of this workgroup
     const int bt = blockIdx.z, b = bt / p.Tq, t = bt % p.Tq;
     const int pos = (p.pos_dev ? *p.pos_dev : p.pos_offset) + t;
     const int len = pos + 1;
@@ -109,12 +113,12 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
     const int begin = band_begin + split * chunk;
     const int end = min(begin + chunk, len);
 
-    // q for the GS heads of this KV head, packed bf16 pairs
-    uint32_t q[GS][NPAIR];
+    // q for the GH heads, packed bf16 pairs
+    uint32_t q[GH][NPAIR];
 #pragma unroll
-    for (int g = 0; g < GS; ++g)
+    for (int g = 0; g < GH; ++g)
     {
-        const uint16_t* qp = p.Q + (size_t)bt * p.q_row_stride + (size_t)(kvh * GS + g) * HS + lane * EPL;
+        const uint16_t* qp = p.Q + (size_t)bt * p.q_row_stride + (size_t)(h0 + g) * HS + lane * EPL;
         if (owner) load_row<EPL>(q[g], qp);
         else
         {
@@ -122,9 +126,9 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
             for (int e = 0; e < NPAIR; ++e) q[g][e] = 0u;
         }
     }
-    float m[GS], l[GS], o[GS][EPL];
+    float m[GH], l[GH], o[GH][EPL];
 #pragma unroll
-    for (int g = 0; g < GS; ++g)
+    for (int g = 0; g < GH; ++g)
     {
         m[g] = -INFINITY;
         l[g] = 0.0f;
@@ -155,21 +159,37 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
 #pragma unroll
             for (int e = 0; e < NPAIR; ++e) { k0[e] = 0u; k1[e] = 0u; v0[e] = 0u; v1[e] = 0u; }
         }
+        float s0[GH], s1[GH];
 #pragma unroll
-        for (int g = 0; g < GS; ++g)
+        for (int g = 0; g < GH; ++g)
         {
-            float s0 = 0.0f, s1 = 0.0f;
+            s0[g] = 0.0f; s1[g] = 0.0f;
 #pragma unroll
             for (int e = 0; e < NPAIR; ++e)
             {
-                s0 = dot2_bf16(as_bf16x2(q[g][e]), as_bf16x2(k0[e]), s0);
-                s1 = dot2_bf16(as_bf16x2(q[g][e]), as_bf16x2(k1[e]), s1);
+                s0[g] = dot2_bf16(as_bf16x2(q[g][e]), as_bf16x2(k0[e]), s0[g]);
+                s1[g] = dot2_bf16(as_bf16x2(q[g][e]), as_bf16x2(k1[e]), s1[g]);
             }
-            s0 = wave_sum(s0) * p.scale;
-            s1 = has1 ? wave_sum(s1) * p.scale : -INFINITY;
-            const float mn = fmaxf(m[g], fmaxf(s0, s1));
+        }
+        // 2*GH independent butterflies, interleaved by the compiler
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+        {
+#pragma unroll
+            for (int g = 0; g < GH; ++g)
+            {
+                s0[g] += __shfl_xor(s0[g], off, 64);
+                s1[g] += __shfl_xor(s1[g], off, 64);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GH; ++g)
+        {
+            const float a0 = s0[g] * p.scale;
+            const float a1 = has1 ? s1[g] * p.scale : -INFINITY;
+            const float mn = fmaxf(m[g], fmaxf(a0, a1));
             const float alpha = __expf(m[g] - mn);           // m = -inf first time: exp(-inf) = 0
-            const float e0 = __expf(s0 - mn), e1 = __expf(s1 - mn);
+            const float e0 = __expf(a0 - mn), e1 = __expf(a1 - mn);
             l[g] = l[g] * alpha + e0 + e1;
             m[g] = mn;
 #pragma unroll
@@ -181,125 +201,120 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
         }
     }
 
-    // ---- merge the 4 waves through LDS, HC heads per round; wave w finalises head hc*HC + w ----
+    // ---- merge the 4 waves through LDS; wave w finalises head w (GH <= 4) ----
     constexpr int STR = HS + 2;
 #pragma unroll
-    for (int hc = 0; hc < GS / HC; ++hc)
+    for (int g = 0; g < GH; ++g)
     {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < HC; ++j)
+        float* dst = sm + ((size_t)wave * GH + g) * STR;
+        if (owner)
         {
-            const int g = hc * HC + j;
-            float* dst = sm + ((size_t)wave * HC + j) * STR;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) dst[lane * EPL + e] = o[g][e];
+        }
+        if (lane == 0) { dst[HS] = m[g]; dst[HS + 1] = l[g]; }
+    }
+    __syncthreads();
+    if (wave < GH)
+    {
+        const int g = wave;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, sm[((size_t)w * GH + g) * STR + HS]);
+        float L = 0.0f, acc[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+        {
+            const float* src = sm + ((size_t)w * GH + g) * STR;
+            const float mw = src[HS];
+            const float f = (mw == -INFINITY) ? 0.0f : __expf(mw - M);
+            L += src[HS + 1] * f;
             if (owner)
             {
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) dst[lane * EPL + e] = o[g][e];
+                for (int e = 0; e < EPL; ++e) acc[e] += src[lane * EPL + e] * f;
             }
-            if (lane == 0) { dst[HS] = m[g]; dst[HS + 1] = l[g]; }
         }
-        __syncthreads();
-        if (wave < HC)
+        const int h = h0 + g;
+        if (p.splits == 1)
         {
-            const int j = wave, g = hc * HC + j;
-            float M = -INFINITY;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) M = fmaxf(M, sm[((size_t)w * HC + j) * STR + HS]);
-            float L = 0.0f, acc[EPL];
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[e] = 0.0f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w)
+            const float inv = (L > 0.0f) ? 1.0f / L : 0.0f;
+            uint16_t* y = p.Y + ((size_t)bt * p.NH + h) * HS + lane * EPL;
+            if (owner)
             {
-                const float* src = sm + ((size_t)w * HC + j) * STR;
-                const float mw = src[HS];
-                const float f = (mw == -INFINITY) ? 0.0f : __expf(mw - M);
-                L += src[HS + 1] * f;
-                if (owner)
-                {
 #pragma unroll
-                    for (int e = 0; e < EPL; ++e) acc[e] += src[lane * EPL + e] * f;
-                }
+                for (int e = 0; e < EPL; e += 2)
+                    *reinterpret_cast<uint32_t*>(y + e) = pack_bf16x2(acc[e] * inv, acc[e + 1] * inv);
             }
-            const int h = kvh * GS + g;
-            if (p.splits == 1)
+        }
+        else
+        {
+            float* dst = p.scratch + (((size_t)bt * p.NH + h) * p.splits + split) * STR;
+            if (owner)
             {
-                const float inv = (L > 0.0f) ? 1.0f / L : 0.0f;
-                uint16_t* y = p.Y + ((size_t)bt * p.NH + h) * HS + lane * EPL;
-                if (owner)
-                {
 #pragma unroll
-                    for (int e = 0; e < EPL; e += 2)
-                        *reinterpret_cast<uint32_t*>(y + e) = pack_bf16x2(acc[e] * inv, acc[e + 1] * inv);
-                }
+                for (int e = 0; e < EPL; ++e) dst[lane * EPL + e] = acc[e];
             }
-            else
-            {
-                float* dst = p.scratch + (((size_t)bt * p.NH + h) * p.splits + split) * STR;
-                if (owner)
-                {
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) dst[lane * EPL + e] = acc[e];
-                }
-                if (lane == 0) { dst[HS] = M; dst[HS + 1] = L; }
-            }
+            if (lane == 0) { dst[HS] = M; dst[HS + 1] = L; }
         }
     }
 }
 
-// combine split partials: grid (NH, B*Tq), 64..256 threads over HS
-__global__ void attn_combine_kernel(uint16_t* __restrict__ Y, const float* __restrict__ scratch, int NH, int HS,
-                                    int splits)
+// combine split partials: grid (NH, B*Tq, HS/64), 64 threads -> 64 dims each
+__global__ __launch_bounds__(64) void attn_combine_kernel(uint16_t* __restrict__ Y, const float* __restrict__ scratch, int NH,
+                                                          int HS, int splits)
 {
     const int h = blockIdx.x, bt = blockIdx.y;
+    const int d = blockIdx.z * 64 + threadIdx.x;
     const int STR = HS + 2;
     const float* base = scratch + ((size_t)bt * NH + h) * splits * STR;
-    float M = -INFINITY;
-    for (int s = 0; s < splits; ++s) M = fmaxf(M, base[(size_t)s * STR + HS]);
-    for (int d = threadIdx.x; d < HS; d += blockDim.x)
+    // lane s holds split s's (m, l); splits <= 64
+    const int s = threadIdx.x;
+    const float ms = (s < splits) ? base[(size_t)s * STR + HS] : -INFINITY;
+    const float ls = (s < splits) ? base[(size_t)s * STR + HS + 1] : 0.0f;
+    const float M = wave_max(ms);
+    const float fs = (ms == -INFINITY) ? 0.0f : __expf(ms - M);
+    const float L = wave_sum(ls * fs);
+    float acc = 0.0f;
+    for (int i = 0; i < splits; ++i)
     {
-        float L = 0.0f, acc = 0.0f;
-        for (int s = 0; s < splits; ++s)
-        {
-            const float* src = base + (size_t)s * STR;
-            const float ms = src[HS];
-            const float f = (ms == -INFINITY) ? 0.0f : __expf(ms - M);
-            L += src[HS + 1] * f;
-            acc += src[d] * f;
-        }
-        Y[((size_t)bt * NH + h) * HS + d] = f32_to_bf16_bits(L > 0.0f ? acc / L : 0.0f);
+        const float f = __shfl(fs, i, 64);
+        acc += base[(size_t)i * STR + d] * f;
     }
+    Y[((size_t)bt * NH + h) * HS + d] = f32_to_bf16_bits(L > 0.0f ? acc / L : 0.0f);
 }
 
-template <int HS, int GS>
+template <int HS, int GH>
 static int launch_rowwise(const AttnParams& p, int B, hipStream_t s)
 {
-    constexpr int HC = (GS < 4) ? GS : 4;
-    const size_t lds = (size_t)4 * HC * (HS + 2) * sizeof(float);
-    hipLaunchKernelGGL((attn_rowwise_kernel<HS, GS>), dim3(p.splits, p.NKV, B * p.Tq), dim3(256), lds, s, p);
+    const int hgroups = (p.NH / p.NKV) / GH;
+    const size_t lds = (size_t)4 * GH * (HS + 2) * sizeof(float);
+    hipLaunchKernelGGL((attn_rowwise_kernel<HS, GH>), dim3(p.splits, p.NKV * hgroups, B * p.Tq), dim3(256), lds, s, p);
     int rc = check_hip(hipGetLastError(), "attn_rowwise");
     if (rc) return rc;
     if (p.splits > 1)
     {
-        hipLaunchKernelGGL(attn_combine_kernel, dim3(p.NH, B * p.Tq), dim3(HS >= 256 ? 256 : 64), 0, s, p.Y, p.scratch, p.NH,
-                           HS, p.splits);
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(p.NH, B * p.Tq, HS / 64), dim3(64), 0, s, p.Y, p.scratch, p.NH, HS,
+                           p.splits);
         rc = check_hip(hipGetLastError(), "attn_combine");
     }
     return rc;
 }
 
+static int heads_per_group(int GS) { return GS >= 4 ? 4 : GS; }
+
 template <int HS>
 static int dispatch_gs(const AttnParams& p, int B, hipStream_t s)
 {
-    switch (p.NH / p.NKV)
+    const int GS = p.NH / p.NKV;
+    switch (GS)
     {
         case 1: return launch_rowwise<HS, 1>(p, B, s);
         case 2: return launch_rowwise<HS, 2>(p, B, s);
-        case 4: return launch_rowwise<HS, 4>(p, B, s);
-        case 8: return launch_rowwise<HS, 8>(p, B, s);
-        case 16: return launch_rowwise<HS, 16>(p, B, s);
-        default: return set_error(MILA_E_UNSUPPORTED, "attention: group size %d (NH/NKV) must be 1,2,4,8 or 16", p.NH / p.NKV);
+        case 4: case 8: case 16: case 32: return launch_rowwise<HS, 4>(p, B, s);
+        default: return set_error(MILA_E_UNSUPPORTED, "attention: group size %d (NH/NKV) must be 1,2,4,8,16 or 32", GS);
     }
 }
 
@@ -315,12 +330,13 @@ static int dispatch_hs(int HS, const AttnParams& p, int B, hipStream_t s)
     }
 }
 
-static int decode_splits(int B, int NKV, int band)
+static int decode_splits(int B, int NH, int NKV, int band)
 {
-    // enough workgroups to cover the chip (~2 per CU), at least 32 positions per split
-    int cap = 512 / (NKV * B);
+    // ~256 workgroups (one per CU), at least 64 positions (16 per wave) per split
+    const int hgroups = (NH / NKV) / heads_per_group(NH / NKV);
+    int cap = 256 / (NKV * hgroups * B);
     if (cap < 1) cap = 1;
-    int s = (band + 31) / 32;
+    int s = (band + 63) / 64;
     if (s > cap) s = cap;
     if (s > kMaxSplits) s = kMaxSplits;
     if (s < 1) s = 1;
@@ -372,7 +388,7 @@ int mila_cdna4_attn_decode_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t* 
     p.kv_h_stride = (int64_t)capacity * HS;
     p.kv_r_stride = HS;
     p.Tq = 1; p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.pos_offset = len - 1; p.window = window;
-    p.splits = decode_splits(B, NKV, band);
+    p.splits = decode_splits(B, NH, NKV, band);
     p.scale = scale;
     p.pos_dev = nullptr;
     if (p.splits > 1)
@@ -401,7 +417,7 @@ int mila_cdna4_attn_decode_bf16_devpos(uint16_t* Y, const uint16_t* Q, const uin
     p.kv_h_stride = (int64_t)capacity * HS;
     p.kv_r_stride = HS;
     p.Tq = 1; p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.pos_offset = 0; p.window = window;
-    p.splits = decode_splits(B, NKV, band);   // fixed at capture time from the largest band
+    p.splits = decode_splits(B, NH, NKV, band);   // fixed at capture time from the largest band
     p.scale = scale;
     p.pos_dev = position_dev;
     if (p.splits > 1)

@@ -60,15 +60,20 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostParams p)
         const int n = r - p.NH - p.NKV;
         src = p.v_src + (size_t)n * HS; w = p.vw; dst = p.Vc + ((size_t)n * p.capacity + row) * HS; rotate = false;
     }
+    // apply-phase operands are requested first so their latency overlaps the reduction's
+    const bool act = lane < hv;
+    const int l2 = act ? lane : 0;
+    const u32x4 xlo = ld16(src + (size_t)l2 * 8), xhi = ld16(src + (size_t)(l2 + hv) * 8);
+    u32x4 wlo = u32x4{0u, 0u, 0u, 0u}, whi = wlo;
+    if (w) { wlo = ld16(w + (size_t)l2 * 8); whi = ld16(w + (size_t)(l2 + hv) * 8); }
     const float rstd = rms_rstd_wave(src, HS, p.eps);
-    if (lane < hv)
+    if (act)
     {
-        const u32x4 xlo = ld16(src + (size_t)lane * 8), xhi = ld16(src + (size_t)(lane + hv) * 8);
         u32x4 lo, hi;
         if (w)
         {
-            lo = rms_apply8(xlo, ld16(w + (size_t)lane * 8), rstd, 0.0f);
-            hi = rms_apply8(xhi, ld16(w + (size_t)(lane + hv) * 8), rstd, 0.0f);
+            lo = rms_apply8(xlo, wlo, rstd, 0.0f);
+            hi = rms_apply8(xhi, whi, rstd, 0.0f);
         }
         else
         {

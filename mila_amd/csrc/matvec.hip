@@ -80,6 +80,18 @@ struct MatvecParams
 
 // PRO: 0 = x as is; 1 = x <- rmsnorm(x; norm_w); 2 = sandwich tail (see mila_cdna4.h)
 // ROWS = R output columns per wave; with GEGLU each column reads two weight rows (n, N + n).
+//
+// The weight stream is software-pipelined per wave over the flattened (row-group, chunk-position)
+// space with two named register buffers: the loads of step i+1 are in flight while step i is
+// multiplied, and the FIRST step's loads are issued before the x staging / RMSNorm prologue, so the
+// prologue's latency chain (loads -> block reductions -> barriers) overlaps the first HBM round trip.
+template <int FMT, int U, int NR>
+struct WBuf
+{
+    u32x4 w[U][NR];
+    float sc[U][NR];
+};
+
 template <int FMT, int R, int U, int PRO, bool GEGLU, bool F32OUT>
 __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
 {
@@ -90,6 +102,46 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
     const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
     const int K = p.K, N = p.N;
     const int nx16 = K / 8;   // 16-byte units of x
+
+    constexpr int EPC = Fmt<FMT>::kElemsPerChunk;
+    constexpr int NR = GEGLU ? 2 * R : R;              // weight rows per wave step
+    const int nchunks = K / EPC;                       // 16-byte chunks per weight row
+    const size_t row_bytes = (size_t)nchunks * 16;
+    const int ngroups = (FMT == FMT_FP4) ? K / p.group : 0;
+    const int chunks_per_group = (FMT == FMT_FP4) ? p.group / EPC : 1;
+    const int total_waves = gridDim.x * 4;
+    const int n_rg = (N + R - 1) / R;
+
+    // issue the loads of one pipeline step: row-group rg, chunk positions c0 + 64u
+    auto issue = [&](WBuf<FMT, U, NR>& b, int rg, int c0) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+        {
+            const int col = rg * R + (GEGLU ? (j >> 1) : j);
+            const bool valid = col < N;
+            const int row = (GEGLU && (j & 1)) ? (N + col) : col;
+            const uint8_t* wrow = p.W + (size_t)(valid ? row : 0) * row_bytes;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                const int c = c0 + 64 * u;
+                if (valid && c < nchunks)
+                {
+                    b.w[u][j] = ld16_nt(wrow + (size_t)c * 16);
+                    if constexpr (FMT == FMT_FP4) b.sc[u][j] = p.scales[(size_t)row * ngroups + c / chunks_per_group];
+                }
+                else
+                {
+                    b.w[u][j] = u32x4{0u, 0u, 0u, 0u};
+                    if constexpr (FMT == FMT_FP4) b.sc[u][j] = 0.0f;
+                }
+            }
+        }
+    };
+
+    int rg = blockIdx.x * 4 + wib, c0 = lane;
+    WBuf<FMT, U, NR> ba, bb;
+    if (rg < n_rg) issue(ba, rg, c0);                  // PREFETCH: in flight during the prologue
 
     // ---- stage x into LDS (optionally through the fused RMSNorm prologue) ----
     if constexpr (PRO == 0)
@@ -130,82 +182,37 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
     }
     __syncthreads();
 
-    constexpr int EPC = Fmt<FMT>::kElemsPerChunk;
-    const int nchunks = K / EPC;                       // 16-byte chunks per weight row
-    const size_t row_bytes = (size_t)nchunks * 16;
-    const int ngroups = (FMT == FMT_FP4) ? K / p.group : 0;
-    const int chunks_per_group = (FMT == FMT_FP4) ? p.group / EPC : 1;
-    constexpr int NR = GEGLU ? 2 * R : R;              // weight rows per wave step
+    float acc[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) acc[j] = 0.0f;
 
-    const int total_waves = gridDim.x * 4;
-    const int n_rg = (N + R - 1) / R;
-    for (int rg = blockIdx.x * 4 + wib; rg < n_rg; rg += total_waves)
-    {
-        const int col0 = rg * R;
-        const uint8_t* wrow[NR];
-        const float* srow[NR];
-        bool valid[NR];
+    auto compute = [&](const WBuf<FMT, U, NR>& b, int c0_) {
 #pragma unroll
-        for (int j = 0; j < NR; ++j)
+        for (int u = 0; u < U; ++u)
         {
-            const int col = col0 + (GEGLU ? (j >> 1) : j);
-            valid[j] = col < N;
-            const int row = (GEGLU && (j & 1)) ? (N + col) : col;
-            wrow[j] = p.W + (size_t)(valid[j] ? row : 0) * row_bytes;
-            srow[j] = (FMT == FMT_FP4) ? p.scales + (size_t)(valid[j] ? row : 0) * ngroups : nullptr;
-        }
-        float acc[NR];
+            const int c = min(c0_ + 64 * u, nchunks - 1);
 #pragma unroll
-        for (int j = 0; j < NR; ++j) acc[j] = 0.0f;
-
-        for (int c0 = lane; c0 < nchunks; c0 += 64 * U)
-        {
-            u32x4 w[U][NR];
-            float sc[U][NR];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int j = 0; j < NR; ++j)
             {
-                const int c = c0 + 64 * u;
-                const bool in = c < nchunks;
-#pragma unroll
-                for (int j = 0; j < NR; ++j)
-                {
-                    if (in && valid[j])
-                    {
-                        w[u][j] = ld16_nt(wrow[j] + (size_t)c * 16);
-                        if constexpr (FMT == FMT_FP4) sc[u][j] = srow[j][c / chunks_per_group];
-                    }
-                    else
-                    {
-                        w[u][j] = u32x4{0u, 0u, 0u, 0u};
-                        if constexpr (FMT == FMT_FP4) sc[u][j] = 0.0f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-            {
-                const int c = min(c0 + 64 * u, nchunks - 1);
-#pragma unroll
-                for (int j = 0; j < NR; ++j)
-                {
-                    if constexpr (FMT == FMT_FP4)
-                        acc[j] = fmaf(sc[u][j], chunk_dot<FMT>(w[u][j], xs, c, 0.0f), acc[j]);
-                    else
-                        acc[j] = chunk_dot<FMT>(w[u][j], xs, c, acc[j]);
-                }
+                if constexpr (FMT == FMT_FP4)
+                    acc[j] = fmaf(b.sc[u][j], chunk_dot<FMT>(b.w[u][j], xs, c, 0.0f), acc[j]);
+                else
+                    acc[j] = chunk_dot<FMT>(b.w[u][j], xs, c, acc[j]);
             }
         }
+    };
+
+    auto finish = [&](int rg_) {
+        const int col0 = rg_ * R;
 #pragma unroll
         for (int j = 0; j < NR; ++j) acc[j] = wave_sum(acc[j]);
-
         if (lane == 0)
         {
 #pragma unroll
             for (int j = 0; j < NR; ++j)
             {
-                if (!valid[j]) continue;
                 const int col = col0 + (GEGLU ? (j >> 1) : j);
+                if (col >= N) continue;
                 const int row = (GEGLU && (j & 1)) ? (N + col) : col;
                 float v = acc[j];
                 if constexpr (FMT == FMT_FP8) v = p.scales[row] * v;
@@ -230,7 +237,31 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
                     reinterpret_cast<uint16_t*>(p.y)[col] = f32_to_bf16_bits(acc[r]);
             }
         }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[j] = 0.0f;
+    };
+
+    // one pipeline step: prefetch the next (rg, c0) into NXT, consume CUR
+#define MILA_MATVEC_STEP(CUR, NXT)                                   \
+    {                                                                \
+        int rgn = rg, c0n = c0 + 64 * U;                             \
+        if (c0n >= nchunks) { rgn = rg + total_waves; c0n = lane; }  \
+        if (rgn < n_rg) issue(NXT, rgn, c0n);                        \
+        compute(CUR, c0);                                            \
+        if (rgn != rg) finish(rg);                                   \
+        rg = rgn;                                                    \
+        c0 = c0n;                                                    \
+        if (rg >= n_rg) break;                                       \
     }
+    if (rg < n_rg)
+    {
+        for (;;)
+        {
+            MILA_MATVEC_STEP(ba, bb)
+            MILA_MATVEC_STEP(bb, ba)
+        }
+    }
+#undef MILA_MATVEC_STEP
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -241,7 +272,7 @@ static int launch(const MatvecParams& p, hipStream_t s)
 {
     const int n_rg = (p.N + R - 1) / R;
     const size_t lds = (size_t)p.K * 2;
-    int max_blocks = g_tune_blocks > 0 ? g_tune_blocks : kNumCU * 8;
+    int max_blocks = g_tune_blocks > 0 ? g_tune_blocks : kNumCU * 4;
     int blocks = (n_rg + 3) / 4;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
@@ -373,6 +404,9 @@ int mila_cdna4_fused_norm_matvec(const mila_fused_matvec_args* a, mila_stream_t 
     MatvecParams p{a->y, a->x, reinterpret_cast<const uint8_t*>(a->W), a->scales, nullptr, a->norm_w, a->post_w,
                    a->res, a->res_out, a->post_scale, a->eps, a->K, a->N, a->group};
     hipStream_t s = as_stream(stream);
+    MILA_REQUIRE(!(a->geglu && a->f32_out), "fused_norm_matvec: geglu and f32_out are exclusive");
+    if (a->f32_out)
+        return a->res ? dispatch_fmt<2, false, true>(a->fmt, p, s) : dispatch_fmt<1, false, true>(a->fmt, p, s);
     if (a->res)
         return a->geglu ? dispatch_fmt<2, true, false>(a->fmt, p, s) : dispatch_fmt<2, false, false>(a->fmt, p, s);
     return a->geglu ? dispatch_fmt<1, true, false>(a->fmt, p, s) : dispatch_fmt<1, false, false>(a->fmt, p, s);

@@ -103,8 +103,8 @@ namespace Mila::Dnn
 
         ~GemmaTransformer()
         {
-            if ( graph_exec_ ) hipGraphExecDestroy( graph_exec_ );
-            if ( graph_ ) hipGraphDestroy( graph_ );
+            if ( graph_exec_ ) (void)hipGraphExecDestroy( graph_exec_ );
+            if ( graph_ ) (void)hipGraphDestroy( graph_ );
         }
 
         Compute::RocmExecutionContext* context() const noexcept { return ctx_; }
@@ -176,7 +176,7 @@ namespace Mila::Dnn
             ctx_->synchronize();
             hipCheck( hipStreamBeginCapture( s, hipStreamCaptureModeThreadLocal ), "hipStreamBeginCapture" );
             try { enqueueFusedStep( token.data(), 0, pos_dev_->data() ); }
-            catch ( ... ) { hipGraph_t g; hipStreamEndCapture( s, &g ); throw; }
+            catch ( ... ) { hipGraph_t g; (void)hipStreamEndCapture( s, &g ); throw; }
             Compute::rocmCheck( mila_cdna4_advance_position( pos_dev_->data(), ctx_->getStream() ) );
             hipCheck( hipStreamEndCapture( s, &graph_ ), "hipStreamEndCapture" );
             hipCheck( hipGraphInstantiate( &graph_exec_, graph_, nullptr, nullptr, 0 ), "hipGraphInstantiate" );
@@ -512,18 +512,16 @@ namespace Mila::Dnn
                 plainMatvec( *L.fc_down, f_down_->data(), f_act_->data() );
                 prev = &L;
             }
-            // tail of the last layer + final norm + lm_head (fp32 logits)
+            // tail of the last layer + final norm + lm_head (fp32 logits) in one launch
             {
-                TensorType* out = hidden_[ next ].get();
-                // the head kernel has no prologue variant with fp32 output: materialise x_L and the final norm
-                auto a_tail = mila_fused_matvec_args{};
-                (void)a_tail;
-                Compute::rocmCheck( mila_cdna4_rmsnorm_bf16( res2_->data(), nullptr, f_down_->data(), prev->post_ffn_norm->getWeight()->data(), nullptr, 1,
-                                                             (int)cfg_.embedding_dim, 1, cfg_.rms_norm_eps, 0.0f, st ) );
-                Compute::rocmCheck( mila_cdna4_residual_bf16( out->data(), res1_->data(), res2_->data(), cfg_.embedding_dim, st ) );
-                Compute::rocmCheck( mila_cdna4_scale_bf16( out->data(), out->data(), cfg_.embedding_dim, prev->layer_scalar, st ) );
-                auto& normed = final_norm_->forward( out->view( shape_t{ 1, 1, cfg_.embedding_dim } ) );
-                head( normed.data() );
+                mila_fused_matvec_args a{};
+                a.y = reinterpret_cast<uint16_t*>( logits_->data() ); a.x = f_down_->data(); a.W = lm_head_->getWeight().rawData();
+                a.scales = nullptr;
+                if constexpr ( kTableFmt != 0 ) a.scales = lm_head_->getWeightScale()->data();
+                a.norm_w = final_norm_->getWeight()->data(); a.post_w = prev->post_ffn_norm->getWeight()->data();
+                a.res = res1_->data(); a.res_out = hidden_[ next ]->data(); a.post_scale = prev->layer_scalar; a.eps = cfg_.rms_norm_eps;
+                a.fmt = kTableFmt; a.K = (int)cfg_.embedding_dim; a.N = (int)cfg_.vocab_size; a.group = 0; a.geglu = 0; a.f32_out = 1;
+                Compute::rocmCheck( mila_cdna4_fused_norm_matvec( &a, st ) );
             }
         }
 

@@ -174,7 +174,7 @@ HOST_API int mila_gemma_time_decode( void* h, int64_t start_position, int steps,
             const auto t1 = std::chrono::steady_clock::now();
             float ms = 0;
             hipCheck( hipEventElapsedTime( &ms, e0, e1 ), "hipEventElapsedTime" );
-            hipEventDestroy( e0 ); hipEventDestroy( e1 );
+            (void)hipEventDestroy( e0 ); (void)hipEventDestroy( e1 );
             out[ 0 ] = std::chrono::duration<double, std::milli>( t1 - t0 ).count() / steps;
             out[ 1 ] = static_cast<double>( ms ) / steps;
         }, r->model );
@@ -206,7 +206,7 @@ HOST_API int mila_gemma_time_dominant_kernel( void* h, int rounds, double* out )
             ctx->synchronize();
             float ms = 0;
             hipCheck( hipEventElapsedTime( &ms, e0, e1 ), "hipEventElapsedTime" );
-            hipEventDestroy( e0 ); hipEventDestroy( e1 );
+            (void)hipEventDestroy( e0 ); (void)hipEventDestroy( e1 );
             out[ 0 ] = static_cast<double>( ms ) * 1e3 / ( static_cast<double>( rounds ) * L );
             out[ 1 ] = m->gateUpBytes( 0 );
         }, r->model );
@@ -236,7 +236,7 @@ HOST_API int mila_gemma_time_prefill( void* h, int64_t T, int reps, double* out_
             ctx->synchronize();
             float ms = 0;
             hipCheck( hipEventElapsedTime( &ms, e0, e1 ), "hipEventElapsedTime" );
-            hipEventDestroy( e0 ); hipEventDestroy( e1 );
+            (void)hipEventDestroy( e0 ); (void)hipEventDestroy( e1 );
             *out_ms = static_cast<double>( ms ) / reps;
         }, r->model );
     } );
