@@ -1,5 +1,5 @@
-// Attention over a (ring) KV cache: append, split-K flash-decode (+ combine), and the row-wise
-// prefill / MHA entry points.
+// Attention over a (ring) KV cache: append and split-K flash-decode (+ combine).  The MFMA
+// flash-prefill / MHA kernels live in attention_prefill.hip.
 //
 // Semantics restated from the reference:
 //   * cache [B, NKV, capacity, HS] bf16, row = abs_pos % capacity   (Gqa.Cache.Bf16.cu:86-130)
@@ -426,51 +426,6 @@ int mila_cdna4_attn_decode_bf16_devpos(uint16_t* Y, const uint16_t* Q, const uin
         if (!scratch || scratch_bytes < need)
             return set_error(MILA_E_SCRATCH_TOO_SMALL, "attn_decode_bf16_devpos: scratch %zu bytes < required %zu", scratch_bytes, need);
     }
-    return dispatch_hs(HS, p, B, as_stream(stream));
-}
-
-int mila_cdna4_attn_prefill_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t* Kc, const uint16_t* Vc, int B, int chunk,
-                                 int NH, int NKV, int HS, int capacity, int pos_offset, int window, float scale,
-                                 mila_stream_t stream)
-{
-    MILA_REQUIRE(Y && Q && Kc && Vc, "attn_prefill_bf16: null pointer");
-    MILA_REQUIRE(B > 0 && chunk > 0 && NH > 0 && NKV > 0 && NH % NKV == 0, "attn_prefill_bf16: bad sizes");
-    MILA_REQUIRE(pos_offset >= 0 && capacity > 0 && window >= 0, "attn_prefill_bf16: bad positions");
-    {
-        // every key a query of this chunk may see must still be resident in the ring
-        const int last = pos_offset + chunk - 1;
-        const int oldest_needed = (window > 0) ? max(0, pos_offset - window + 1) : 0;
-        MILA_REQUIRE(last - oldest_needed + 1 <= capacity,
-                     "attn_prefill_bf16: keys [%d,%d] do not fit the cache capacity %d", oldest_needed, last, capacity);
-    }
-    AttnParams p;
-    p.Y = Y; p.Q = Q; p.K = Kc; p.V = Vc; p.scratch = nullptr;
-    p.q_row_stride = (int64_t)NH * HS;
-    p.kv_b_stride = (int64_t)NKV * capacity * HS;
-    p.kv_h_stride = (int64_t)capacity * HS;
-    p.kv_r_stride = HS;
-    p.Tq = chunk; p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.pos_offset = pos_offset; p.window = window;
-    p.splits = 1;
-    p.scale = scale;
-    p.pos_dev = nullptr;
-    return dispatch_hs(HS, p, B, as_stream(stream));
-}
-
-int mila_cdna4_mha_bf16(uint16_t* Y, const uint16_t* QKV, int B, int T, int C, int NH, mila_stream_t stream)
-{
-    MILA_REQUIRE(Y && QKV, "mha_bf16: null pointer");
-    MILA_REQUIRE(B > 0 && T > 0 && C > 0 && NH > 0 && C % NH == 0, "mha_bf16: bad sizes (B=%d T=%d C=%d NH=%d)", B, T, C, NH);
-    const int HS = C / NH;
-    AttnParams p;
-    p.Y = Y; p.Q = QKV; p.K = QKV + C; p.V = QKV + 2 * C; p.scratch = nullptr;
-    p.q_row_stride = 3 * (int64_t)C;
-    p.kv_b_stride = (int64_t)T * 3 * C;
-    p.kv_h_stride = HS;
-    p.kv_r_stride = 3 * (int64_t)C;
-    p.Tq = T; p.NH = NH; p.NKV = NH; p.capacity = T; p.pos_offset = 0; p.window = 0;
-    p.splits = 1;
-    p.scale = 1.0f / sqrtf((float)HS);
-    p.pos_dev = nullptr;
     return dispatch_hs(HS, p, B, as_stream(stream));
 }
 

@@ -1,0 +1,317 @@
+// Flash-attention prefill on the matrix cores (causal, optional sliding window, GQA/MQA, ring cache),
+// also used for GPT-2's packed-QKV MHA.
+//
+// Replaces the reference's flash-prefill rungs (OPS/Attention/GQA/Kernels/Gqa.Flash.Wmma.cu:246,
+// Gqa.Flash.Fa2.cu:177 -- mma.sync m16n8k16 + ldmatrix, Br = Bc = 16) and its cuBLASLt
+// QK -> softmax -> AV pipeline (CudaGqaOp.ixx:673-794).  Mask / scale / head-map semantics as in
+// attention.hip.  fp32 scores and softmax state, P rounded to bf16 for the PV product exactly as the
+// reference's flash kernels do (SURVEY.md Appendix A "Intermediate precision").
+//
+// CDNA4 design (re-derived, not translated):
+//   * v_mfma_f32_16x16x32_bf16 for both products.  One wave owns 16 query rows of one head and
+//     keeps O^T (HS x 16, fp32) in HS/4 accumulator registers and its Q fragments (HS/8 VGPRs).
+//   * the products are computed TRANSPOSED: S^T = K Q^T puts a query row on a lane (col = lane & 15)
+//     and its keys in the lane's registers, so the row max / row sum are in-lane plus two xor
+//     shuffles (16, 32); the exponentiated scores ARE the B operand of O^T += V^T P^T with no lane
+//     movement (the PV contraction index is permuted consistently on both operands).
+//   * K / V tiles of 32 keys are staged global -> registers -> LDS (next tile's loads in flight during
+//     the current tile's math); K fragments are ds_read_b128 from an XOR-swizzled row-major image,
+//     V^T fragments come from the row-major V image through ds_read_b64_tr_b16 (hardware transpose),
+//     so V is stored exactly as it arrives from HBM.
+//   * a workgroup = 4 waves = (query heads sharing one KV head) x (16-row query sub-tiles): all four
+//     waves consume the same K/V tiles (GQA/MQA reuse in LDS); the heaviest (latest) query tiles are
+//     dispatched first.
+#include "common.h"
+
+namespace mila {
+
+struct FlashParams
+{
+    uint16_t* Y;              // [B*Tq, NH*HS]
+    const uint16_t* Q;        // row (b*Tq+t): Q + (b*Tq+t)*q_row_stride + h*HS
+    const uint16_t* K;        // K + b*kv_b_stride + kvh*kv_h_stride + row*kv_r_stride, row = pos % capacity
+    const uint16_t* V;
+    int64_t q_row_stride, kv_b_stride, kv_h_stride, kv_r_stride;
+    int Tq, NH, NKV, capacity, pos_offset, window;
+    float scale;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kKeysPerTile = 32;
+
+// LDS images: row-major [32 keys][HS] bf16, 16-byte chunk index XORed with a function of the row.
+// The same involution is applied on write and on both kinds of read.
+template <int HS>
+__device__ __forceinline__ int k_off(int row, int chunk)      // ds_read_b128 of 16 rows x same chunk
+{
+    constexpr int ROWB = HS * 2, NCH = ROWB / 16;
+    const int x = (NCH >= 16) ? (row & 15) : ((row >> 1) & (NCH - 1));
+    return row * ROWB + (((chunk & ~(NCH >= 16 ? 15 : NCH - 1)) | ((chunk ^ x) & (NCH >= 16 ? 15 : NCH - 1))) << 4);
+}
+template <int HS>
+__device__ __forceinline__ int v_off(int row, int chunk)      // ds_read_b64_tr_b16 blocks of 4 rows x 16 cols
+{
+    constexpr int ROWB = HS * 2, NCH = ROWB / 16;
+    const int f = (((row & 3) << 2) | ((row >> 2) & 3)) & (NCH >= 16 ? 15 : NCH - 1);
+    return row * ROWB + ((chunk ^ f) << 4);
+}
+
+// HB = heads per workgroup (1, 2 or 4); QB = 4 / HB query sub-tiles of 16 rows
+template <int HS, int HB>
+__global__ __launch_bounds__(256) void flash_prefill_kernel(const FlashParams p)
+{
+    constexpr int QB = 4 / HB;
+    constexpr int QROWS = 16 * QB;
+    constexpr int KSTEPS = HS / 32;          // MFMA k-steps of the QK^T product
+    constexpr int DT = HS / 16;              // 16-wide d tiles of O^T
+    constexpr int ROWB = HS * 2;
+    constexpr int TILE_BYTES = kKeysPerTile * ROWB;
+    constexpr int CH_PER_THREAD = (kKeysPerTile * (ROWB / 16)) / 256;   // 16-byte chunks each thread stages per tile
+    static_assert(CH_PER_THREAD >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [K tile | V tile]
+    unsigned char* ldsK = smem;
+    unsigned char* ldsV = smem + TILE_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int GS = p.NH / p.NKV;
+    const int qt = gridDim.x - 1 - blockIdx.x;                 // heaviest tiles first
+    const int hblk = blockIdx.y, b = blockIdx.z;
+    const int h = hblk * HB + (wave % HB);
+    const int kvh = (hblk * HB) / GS;                          // all HB heads share one KV head (HB | GS)
+    const int q0 = qt * QROWS;                                 // first query row (within the chunk) of this workgroup
+    const int wq0 = q0 + 16 * (wave / HB);                     // this wave's first row
+    const int my_row = wq0 + l15;                              // the query row on this lane
+    const bool row_valid = my_row < p.Tq;
+    const int my_pos = p.pos_offset + (row_valid ? my_row : p.Tq - 1);
+
+    // ---- Q fragments: B operand of S^T = K Q^T: lane holds Q[row l15][32 s + 8 g + j] ----
+    s16x8 qf[KSTEPS];
+    {
+        const uint16_t* qp = p.Q + ((size_t)b * p.Tq + (row_valid ? my_row : 0)) * p.q_row_stride + (size_t)h * HS + 8 * g;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+        {
+            const u32x4 v = row_valid ? ld16(qp + 32 * s) : u32x4{0u, 0u, 0u, 0u};
+            qf[s] = __builtin_bit_cast(s16x8, v);
+        }
+    }
+
+    f32x4 o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) o[d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    // key range needed by the workgroup (union over its rows)
+    const int pos_first = p.pos_offset + q0;
+    const int pos_last = p.pos_offset + min(q0 + QROWS, p.Tq) - 1;
+    const int kmin = (p.window > 0) ? max(0, pos_first - p.window + 1) : 0;
+    const int kt0 = kmin & ~(kKeysPerTile - 1);
+    const int ntiles = (pos_last - kt0) / kKeysPerTile + 1;
+
+    const uint16_t* kbase = p.K + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride;
+    const uint16_t* vbase = p.V + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride;
+
+    u32x4 kreg[CH_PER_THREAD], vreg[CH_PER_THREAD];
+    auto stage_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < CH_PER_THREAD; ++i)
+        {
+            const int c = tid + 256 * i;
+            const int row = c / (ROWB / 16), chunk = c % (ROWB / 16);
+            const int pos = kt + row;
+            if (pos <= pos_last)     // rows beyond the last key any row of this workgroup may see stay zero
+            {
+                const size_t off = (size_t)(pos % p.capacity) * p.kv_r_stride + chunk * 8;
+                kreg[i] = ld16(kbase + off);
+                vreg[i] = ld16(vbase + off);
+            }
+            else
+            {
+                kreg[i] = u32x4{0u, 0u, 0u, 0u};
+                vreg[i] = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < CH_PER_THREAD; ++i)
+        {
+            const int c = tid + 256 * i;
+            const int row = c / (ROWB / 16), chunk = c % (ROWB / 16);
+            *reinterpret_cast<u32x4*>(ldsK + k_off<HS>(row, chunk)) = kreg[i];
+            *reinterpret_cast<u32x4*>(ldsV + v_off<HS>(row, chunk)) = vreg[i];
+        }
+    };
+
+    stage_load(kt0);
+    for (int t = 0; t < ntiles; ++t)
+    {
+        const int kt = kt0 + t * kKeysPerTile;
+        __syncthreads();                     // previous tile fully consumed
+        stage_store();
+        __syncthreads();
+        if (t + 1 < ntiles) stage_load(kt + kKeysPerTile);   // in flight during this tile's math
+
+        // ---- S^T = K Q^T : two 16-key groups ----
+        f32x4 s0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+        {
+            // A operand: K[key l15 (+16)][32 s + 8 g .. +7] -> chunk 4 s + g
+            const s16x8 ka = *reinterpret_cast<const s16x8*>(ldsK + k_off<HS>(l15, 4 * s + g));
+            const s16x8 kb = *reinterpret_cast<const s16x8*>(ldsK + k_off<HS>(16 + l15, 4 * s + g));
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka), __builtin_bit_cast(bf16x8, qf[s]), s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb), __builtin_bit_cast(bf16x8, qf[s]), s1, 0, 0, 0);
+        }
+        // lane holds keys kt + 4 g + r (s0) and kt + 16 + 4 g + r (s1) of query row l15
+        float sv[8];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+        {
+            const int key = kt + ((r < 4) ? (4 * g + r) : (16 + 4 * g + (r - 4)));
+            const float raw = (r < 4) ? s0[r] : s1[r - 4];
+            const bool vis = row_valid && key <= my_pos && (p.window == 0 || key > my_pos - p.window);
+            sv[r] = vis ? raw * p.scale : -INFINITY;
+            mt = fmaxf(mt, sv[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float mn = fmaxf(m_run, mt);
+        const float msafe = (mn == -INFINITY) ? 0.0f : mn;      // row with nothing visible yet
+        const float alpha = __expf(m_run - msafe);              // m_run = -inf -> 0
+        float pe[8], rs = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+        {
+            pe[r] = __expf(sv[r] - msafe);
+            rs += pe[r];
+        }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = mn;
+        // B operand of O^T += V^T P^T: element j <-> key (j < 4 ? 4 g + j : 16 + 4 g + j - 4)
+        u32x4 pb;
+        pb[0] = pack_bf16x2(pe[0], pe[1]);
+        pb[1] = pack_bf16x2(pe[2], pe[3]);
+        pb[2] = pack_bf16x2(pe[4], pe[5]);
+        pb[3] = pack_bf16x2(pe[6], pe[7]);
+        const bf16x8 pfrag = __builtin_bit_cast(bf16x8, pb);
+        const bool rescale = __any(alpha != 1.0f);
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+        {
+            // A operand: V^T[dim 16 d + l15][keys as above] via the transposing read:
+            // lane 4 q + pp of a 16-lane group supplies row q, columns 4 pp .. 4 pp + 3 of the block
+            const int q4 = l15 >> 2, pp = l15 & 3;
+            const int col = 16 * d + 4 * pp;                   // first of 4 columns (8 bytes)
+            const int r_lo = 4 * g + q4, r_hi = 16 + 4 * g + q4;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(ldsV + v_off<HS>(r_lo, col >> 3) + ((col & 7) << 1)));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(ldsV + v_off<HS>(r_hi, col >> 3) + ((col & 7) << 1)));
+            s16x8 va;
+            va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3];
+            va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
+            if (rescale)
+            {
+                o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha;
+            }
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), pfrag, o[d], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: O^T[dim 16 d + 4 g + r][row l15] -> Y[row][h*HS + dim] ----
+    if (row_valid)
+    {
+        const float inv = (l_run > 0.0f) ? 1.0f / l_run : 0.0f;
+        uint16_t* y = p.Y + (((size_t)b * p.Tq + my_row) * p.NH + h) * HS + 4 * g;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+            *reinterpret_cast<u32x2*>(y + 16 * d) = u32x2{pack_bf16x2(o[d][0] * inv, o[d][1] * inv), pack_bf16x2(o[d][2] * inv, o[d][3] * inv)};
+    }
+}
+
+template <int HS, int HB>
+static int launch_flash(const FlashParams& p, int B, hipStream_t s)
+{
+    constexpr int QROWS = 16 * (4 / HB);
+    const size_t lds = (size_t)2 * kKeysPerTile * HS * 2;
+    const dim3 grid((p.Tq + QROWS - 1) / QROWS, p.NH / HB, B);
+    hipLaunchKernelGGL((flash_prefill_kernel<HS, HB>), grid, dim3(256), lds, s, p);
+    MILA_LAUNCH_CHECK("flash_prefill");
+}
+
+template <int HS>
+static int dispatch_hb(const FlashParams& p, int B, hipStream_t s)
+{
+    const int GS = p.NH / p.NKV;
+    if (GS % 4 == 0) return launch_flash<HS, 4>(p, B, s);
+    if (GS % 2 == 0) return launch_flash<HS, 2>(p, B, s);
+    return launch_flash<HS, 1>(p, B, s);
+}
+
+int flash_dispatch(int HS, const FlashParams& p, int B, hipStream_t s)
+{
+    switch (HS)
+    {
+        case 64: return dispatch_hb<64>(p, B, s);
+        case 128: return dispatch_hb<128>(p, B, s);
+        case 256: return dispatch_hb<256>(p, B, s);
+        case 512: return dispatch_hb<512>(p, B, s);
+        default: return set_error(MILA_E_UNSUPPORTED, "attention: head size %d must be 64, 128, 256 or 512", HS);
+    }
+}
+
+}  // namespace mila
+
+using namespace mila;
+
+extern "C" {
+
+int mila_cdna4_attn_prefill_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t* Kc, const uint16_t* Vc, int B, int chunk,
+                                 int NH, int NKV, int HS, int capacity, int pos_offset, int window, float scale,
+                                 mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && Q && Kc && Vc, "attn_prefill_bf16: null pointer");
+    MILA_REQUIRE(B > 0 && chunk > 0 && NH > 0 && NKV > 0 && NH % NKV == 0, "attn_prefill_bf16: bad sizes");
+    MILA_REQUIRE(pos_offset >= 0 && capacity > 0 && window >= 0, "attn_prefill_bf16: bad positions");
+    {
+        // every key a query of this chunk may see must still be resident in the ring
+        const int last = pos_offset + chunk - 1;
+        const int oldest_needed = (window > 0) ? max(0, pos_offset - window + 1) : 0;
+        MILA_REQUIRE(last - oldest_needed + 1 <= capacity,
+                     "attn_prefill_bf16: keys [%d,%d] do not fit the cache capacity %d", oldest_needed, last, capacity);
+    }
+    FlashParams p;
+    p.Y = Y; p.Q = Q; p.K = Kc; p.V = Vc;
+    p.q_row_stride = (int64_t)NH * HS;
+    p.kv_b_stride = (int64_t)NKV * capacity * HS;
+    p.kv_h_stride = (int64_t)capacity * HS;
+    p.kv_r_stride = HS;
+    p.Tq = chunk; p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.pos_offset = pos_offset; p.window = window;
+    p.scale = scale;
+    return flash_dispatch(HS, p, B, as_stream(stream));
+}
+
+int mila_cdna4_mha_bf16(uint16_t* Y, const uint16_t* QKV, int B, int T, int C, int NH, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && QKV, "mha_bf16: null pointer");
+    MILA_REQUIRE(B > 0 && T > 0 && C > 0 && NH > 0 && C % NH == 0, "mha_bf16: bad sizes (B=%d T=%d C=%d NH=%d)", B, T, C, NH);
+    const int HS = C / NH;
+    FlashParams p;
+    p.Y = Y; p.Q = QKV; p.K = QKV + C; p.V = QKV + 2 * C;
+    p.q_row_stride = 3 * (int64_t)C;
+    p.kv_b_stride = (int64_t)T * 3 * C;
+    p.kv_h_stride = HS;
+    p.kv_r_stride = 3 * (int64_t)C;
+    p.Tq = T; p.NH = NH; p.NKV = NH; p.capacity = T; p.pos_offset = 0; p.window = 0;
+    p.scale = 1.0f / sqrtf((float)HS);
+    return flash_dispatch(HS, p, B, as_stream(stream));
+}
+
+}  // extern "C"
