@@ -139,65 +139,94 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
     const uint16_t* kbase = p.K + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride + lane * EPL;
     const uint16_t* vbase = p.V + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride + lane * EPL;
 
-    for (int pp = begin + wave; pp < end; pp += 8)
-    {
-        // two positions per iteration: 4 row loads in flight per lane
-        const int p0 = pp, p1 = pp + 4;
-        const bool has1 = p1 < end;
-        uint32_t k0[NPAIR], v0[NPAIR], k1[NPAIR], v1[NPAIR];
-        const size_t r0 = (size_t)(p0 % p.capacity) * p.kv_r_stride;
-        const size_t r1 = (size_t)((has1 ? p1 : p0) % p.capacity) * p.kv_r_stride;
-        if (owner)
-        {
-            load_row<EPL>(k0, kbase + r0);
-            load_row<EPL>(k1, kbase + r1);
-            load_row<EPL>(v0, vbase + r0);
-            load_row<EPL>(v1, vbase + r1);
-        }
-        else
-        {
+    // A wave owns positions base, base + 4, ... of the split, PG at a time.  All K/V rows of a group are
+    // requested at once and the next group's rows are in flight while the current group is reduced, so a
+    // split of <= 4*PG positions per wave costs a single HBM round trip.
+    constexpr int PG = (HS >= 512) ? 4 : 8;
+    struct KVG { uint32_t k[PG][NPAIR], v[PG][NPAIR]; };
+    auto load_group = [&](KVG& gbuf, int base) {
 #pragma unroll
-            for (int e = 0; e < NPAIR; ++e) { k0[e] = 0u; k1[e] = 0u; v0[e] = 0u; v1[e] = 0u; }
-        }
-        float s0[GH], s1[GH];
-#pragma unroll
-        for (int g = 0; g < GH; ++g)
+        for (int j = 0; j < PG; ++j)
         {
-            s0[g] = 0.0f; s1[g] = 0.0f;
-#pragma unroll
-            for (int e = 0; e < NPAIR; ++e)
+            const int pos = base + 4 * j;
+            if (owner && pos < end)
             {
-                s0[g] = dot2_bf16(as_bf16x2(q[g][e]), as_bf16x2(k0[e]), s0[g]);
-                s1[g] = dot2_bf16(as_bf16x2(q[g][e]), as_bf16x2(k1[e]), s1[g]);
+                const size_t r = (size_t)(pos % p.capacity) * p.kv_r_stride;
+                load_row<EPL>(gbuf.k[j], kbase + r);
+                load_row<EPL>(gbuf.v[j], vbase + r);
+            }
+            else
+            {
+#pragma unroll
+                for (int e = 0; e < NPAIR; ++e) { gbuf.k[j][e] = 0u; gbuf.v[j][e] = 0u; }
             }
         }
-        // 2*GH independent butterflies, interleaved by the compiler
+    };
+    auto compute_group = [&](const KVG& gbuf, int base) {
+        float sc[PG][GH];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-        {
+        for (int j = 0; j < PG; ++j)
 #pragma unroll
             for (int g = 0; g < GH; ++g)
             {
-                s0[g] += __shfl_xor(s0[g], off, 64);
-                s1[g] += __shfl_xor(s1[g], off, 64);
+                float a = 0.0f;
+#pragma unroll
+                for (int e = 0; e < NPAIR; ++e) a = dot2_bf16(as_bf16x2(q[g][e]), as_bf16x2(gbuf.k[j][e]), a);
+                sc[j][g] = a;
             }
-        }
+#pragma unroll
+        for (int j = 0; j < PG; ++j)
+#pragma unroll
+            for (int g = 0; g < GH; ++g) sc[j][g] = wave_sum(sc[j][g]);
 #pragma unroll
         for (int g = 0; g < GH; ++g)
         {
-            const float a0 = s0[g] * p.scale;
-            const float a1 = has1 ? s1[g] * p.scale : -INFINITY;
-            const float mn = fmaxf(m[g], fmaxf(a0, a1));
-            const float alpha = __expf(m[g] - mn);           // m = -inf first time: exp(-inf) = 0
-            const float e0 = __expf(a0 - mn), e1 = __expf(a1 - mn);
-            l[g] = l[g] * alpha + e0 + e1;
+            float a[PG], mt = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < PG; ++j)
+            {
+                a[j] = (base + 4 * j < end) ? sc[j][g] * p.scale : -INFINITY;
+                mt = fmaxf(mt, a[j]);
+            }
+            const float mn = fmaxf(m[g], mt);
+            const float msafe = (mn == -INFINITY) ? 0.0f : mn;
+            const float alpha = __expf(m[g] - msafe);        // m = -inf first time: exp(-inf) = 0
+            float ex[PG], rs = 0.0f;
+#pragma unroll
+            for (int j = 0; j < PG; ++j) { ex[j] = __expf(a[j] - msafe); rs += ex[j]; }
+            l[g] = l[g] * alpha + rs;
             m[g] = mn;
 #pragma unroll
             for (int e = 0; e < NPAIR; ++e)
             {
-                o[g][2 * e] = o[g][2 * e] * alpha + e0 * bf16_lo(v0[e]) + e1 * bf16_lo(v1[e]);
-                o[g][2 * e + 1] = o[g][2 * e + 1] * alpha + e0 * bf16_hi(v0[e]) + e1 * bf16_hi(v1[e]);
+                float lo = o[g][2 * e] * alpha, hi = o[g][2 * e + 1] * alpha;
+#pragma unroll
+                for (int j = 0; j < PG; ++j)
+                {
+                    lo = fmaf(ex[j], bf16_lo(gbuf.v[j][e]), lo);
+                    hi = fmaf(ex[j], bf16_hi(gbuf.v[j][e]), hi);
+                }
+                o[g][2 * e] = lo;
+                o[g][2 * e + 1] = hi;
             }
+        }
+    };
+    {
+        int base = begin + wave;
+        KVG ga, gb;
+        if (base < end) load_group(ga, base);
+        for (;;)
+        {
+            if (base >= end) break;
+            int nb = base + 4 * PG;
+            if (nb < end) load_group(gb, nb);
+            compute_group(ga, base);
+            base = nb;
+            if (base >= end) break;
+            nb = base + 4 * PG;
+            if (nb < end) load_group(ga, nb);
+            compute_group(gb, base);
+            base = nb;
         }
     }
 
@@ -278,10 +307,11 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(uint16_t* __restrict__
     const float fs = (ms == -INFINITY) ? 0.0f : __expf(ms - M);
     const float L = wave_sum(ls * fs);
     float acc = 0.0f;
+#pragma unroll 8
     for (int i = 0; i < splits; ++i)
     {
-        const float f = __shfl(fs, i, 64);
-        acc += base[(size_t)i * STR + d] * f;
+        const float f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fs), i));
+        acc = fmaf(base[(size_t)i * STR + d], f, acc);
     }
     Y[((size_t)bt * NH + h) * HS + d] = f32_to_bf16_bits(L > 0.0f ? acc / L : 0.0f);
 }
@@ -332,11 +362,11 @@ static int dispatch_hs(int HS, const AttnParams& p, int B, hipStream_t s)
 
 static int decode_splits(int B, int NH, int NKV, int band)
 {
-    // ~256 workgroups (one per CU), at least 64 positions (16 per wave) per split
+    // ~256 workgroups (one per CU) of 32 positions (8 per wave: one or two load groups)
     const int hgroups = (NH / NKV) / heads_per_group(NH / NKV);
     int cap = 256 / (NKV * hgroups * B);
     if (cap < 1) cap = 1;
-    int s = (band + 63) / 64;
+    int s = (band + 31) / 32;
     if (s > cap) s = cap;
     if (s > kMaxSplits) s = kMaxSplits;
     if (s < 1) s = 1;

@@ -59,16 +59,56 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
 __device__ __forceinline__ float round_bf16(float f) { return bf16_bits_to_f32(f32_to_bf16_bits(f)); }
 
 // ---- wave / block reductions (64 lanes) -------------------------------------------------------
+// All-lanes butterfly without the LDS crossbar: four DPP steps inside a 16-lane row (quad_perm xor 1,
+// quad_perm xor 2, row_half_mirror, row_mirror -- every lane of a finished sub-group holds the same
+// partial, so a mirror is as good as an xor), then the gfx950 v_permlane16_swap / v_permlane32_swap
+// pair for the cross-row steps.  Addition is commutative, so every lane ends with identical bits.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v += dpp_f32<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);    // row_half_mirror
+    v += dpp_f32<0x140>(v);    // row_mirror
+    {
+        const uint32_t u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const uint32_t u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
     return v;
 }
 __device__ __forceinline__ float wave_max(float v)
 {
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x140>(v));
+    {
+        const uint32_t u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    {
+        const uint32_t u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    return v;
+}
+// reference implementation through the LDS crossbar (tests compare the two)
+__device__ __forceinline__ float wave_sum_shfl(float v)
+{
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 

@@ -257,6 +257,14 @@ __global__ void selftest_decode_kernel(float* out_fp8, float* out_fp4)
     }
 }
 
+__global__ void selftest_wave_reduce_kernel(float* out, const float* in)
+{
+    const float v = in[threadIdx.x];
+    out[threadIdx.x] = wave_sum(v);
+    out[64 + threadIdx.x] = wave_max(v);
+    out[128 + threadIdx.x] = wave_sum_shfl(v);
+}
+
 __global__ __launch_bounds__(256) void stream_copy_kernel(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int64_t nvec)
 {
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -414,6 +422,13 @@ int mila_cdna4_selftest_decode(float* out_fp8, float* out_fp4, mila_stream_t str
     MILA_REQUIRE(out_fp8 && out_fp4, "selftest_decode: null pointer");
     hipLaunchKernelGGL(selftest_decode_kernel, dim3(1), dim3(256), 0, as_stream(stream), out_fp8, out_fp4);
     MILA_LAUNCH_CHECK("selftest_decode");
+}
+
+int mila_cdna4_selftest_wave_reduce(float* out, const float* in, mila_stream_t stream)
+{
+    MILA_REQUIRE(out && in, "selftest_wave_reduce: null pointer");
+    hipLaunchKernelGGL(selftest_wave_reduce_kernel, dim3(1), dim3(64), 0, as_stream(stream), out, in);
+    MILA_LAUNCH_CHECK("selftest_wave_reduce");
 }
 
 int mila_cdna4_stream_copy(void* dst, const void* src, size_t bytes, mila_stream_t stream)

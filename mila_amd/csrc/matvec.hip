@@ -139,9 +139,17 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
         }
     };
 
+    // compute cursor (rg, c0) and issue cursor (rgi, c0i), the latter two pipeline steps ahead
     int rg = blockIdx.x * 4 + wib, c0 = lane;
+    int rgi = rg, c0i = c0;
+    auto advance = [&](int& r_, int& c_) {
+        c_ += 64 * U;
+        if (c_ >= nchunks) { r_ += total_waves; c_ = lane; }
+    };
     WBuf<FMT, U, NR> ba, bb;
-    if (rg < n_rg) issue(ba, rg, c0);                  // PREFETCH: in flight during the prologue
+    // PREFETCH: two steps in flight during the prologue
+    if (rgi < n_rg) { issue(ba, rgi, c0i); advance(rgi, c0i); }
+    if (rgi < n_rg) { issue(bb, rgi, c0i); advance(rgi, c0i); }
 
     // ---- stage x into LDS (optionally through the fused RMSNorm prologue) ----
     if constexpr (PRO == 0)
@@ -241,25 +249,21 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
         for (int j = 0; j < NR; ++j) acc[j] = 0.0f;
     };
 
-    // one pipeline step: prefetch the next (rg, c0) into NXT, consume CUR
-#define MILA_MATVEC_STEP(CUR, NXT)                                   \
+    // one pipeline step: consume BUF (compute cursor), then refill it from the issue cursor, which
+    // runs two steps ahead -> up to two steps (2 * U * NR 16-byte loads per lane) in flight
+#define MILA_MATVEC_STEP(BUF)                                        \
     {                                                                \
-        int rgn = rg, c0n = c0 + 64 * U;                             \
-        if (c0n >= nchunks) { rgn = rg + total_waves; c0n = lane; }  \
-        if (rgn < n_rg) issue(NXT, rgn, c0n);                        \
-        compute(CUR, c0);                                            \
-        if (rgn != rg) finish(rg);                                   \
-        rg = rgn;                                                    \
-        c0 = c0n;                                                    \
         if (rg >= n_rg) break;                                       \
+        compute(BUF, c0);                                            \
+        const int rg_prev = rg;                                      \
+        advance(rg, c0);                                             \
+        if (rgi < n_rg) { issue(BUF, rgi, c0i); advance(rgi, c0i); } \
+        if (rg != rg_prev) finish(rg_prev);                          \
     }
-    if (rg < n_rg)
+    for (;;)
     {
-        for (;;)
-        {
-            MILA_MATVEC_STEP(ba, bb)
-            MILA_MATVEC_STEP(bb, ba)
-        }
+        MILA_MATVEC_STEP(ba)
+        MILA_MATVEC_STEP(bb)
     }
 #undef MILA_MATVEC_STEP
 }

@@ -42,6 +42,14 @@ def load():
         _lib.mila_gemma_time_dominant_kernel.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _lib.mila_gemma_time_prefill.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         _lib.mila_gemma_info.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        _lib.mila_gpt_last_error.restype = C.c_char_p
+        _lib.mila_gpt_create.restype = C.c_void_p
+        _lib.mila_gpt_create.argtypes = [C.c_int64] * 7
+        _lib.mila_gpt_destroy.argtypes = [C.c_void_p]
+        _lib.mila_gpt_parameter_count.restype = C.c_int64
+        _lib.mila_gpt_parameter_count.argtypes = [C.c_void_p]
+        _lib.mila_gpt_load_parameter.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        _lib.mila_gpt_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -108,3 +116,40 @@ class Gemma:
         out = (C.c_double * 4)()
         _check(load().mila_gemma_info(self.h, context, out))
         return {"decode_bytes_per_token": out[0], "weight_bytes": out[1], "linear_params": out[2], "table_params": out[3]}
+
+
+class Gpt:
+    """GptTransformer (GPT-2) on cuda:0, BF16; parameters in the order of oracle orc_cpu_gpt2_forward."""
+
+    def __init__(self, vocab, max_seq, C_, L, NH, B, T):
+        lib = load()
+        self.shape = (B, T, vocab)
+        self.h = lib.mila_gpt_create(vocab, max_seq, C_, L, NH, B, T)
+        if not self.h:
+            raise (ValueError if b"invalid_argument" in lib.mila_gpt_last_error() else RuntimeError)(lib.mila_gpt_last_error().decode())
+
+    def load_parameters(self, params_bf16_bits):
+        lib = load()
+        assert len(params_bf16_bits) == lib.mila_gpt_parameter_count(self.h)
+        for i, p in enumerate(params_bf16_bits):
+            p = np.ascontiguousarray(p, dtype=np.uint16)
+            rc = lib.mila_gpt_load_parameter(self.h, i, p.ctypes.data, p.nbytes)
+            if rc:
+                raise ValueError(lib.mila_gpt_last_error().decode())
+
+    def forward(self, tokens):
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = np.empty(self.shape, dtype=np.uint16)
+        ms = C.c_double()
+        rc = load().mila_gpt_forward(self.h, t.ctypes.data, out.ctypes.data, C.byref(ms))
+        if rc < 0:
+            raise RuntimeError(load().mila_gpt_last_error().decode())
+        if rc > 0:
+            raise IndexError("token index outside vocabulary range (flat position %d)" % (rc - 1))
+        self.last_ms = ms.value
+        return out
+
+    def close(self):
+        if self.h:
+            load().mila_gpt_destroy(self.h)
+            self.h = None

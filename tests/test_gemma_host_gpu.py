@@ -54,6 +54,7 @@ def test_prefill_then_decode_matches_token_by_token_decode(policy):
     # matvec does not -- "changes numerics by design", reference bar 1e-1 * absmax (Linear.Cuda.cpp:760-774)
     bar = 1e-1 if policy == "fp4" else 3e-2
     assert np.abs(lp - ld).max() <= bar * np.abs(ld).max()
+    bar = 1e-1     # one more chaotic step on top of caches that differ in the last bf16 bit
     # continue decoding on top of the prefilled cache vs on top of the decoded cache
     l1 = a.decode(TOKENS[T], T, "fused")
     l2 = b.decode(TOKENS[T], T, "fused")

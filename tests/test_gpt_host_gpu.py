@@ -1,0 +1,62 @@
+"""GPT-2 (BASELINE.json configs 1-2) through the C++ host mirror vs the restated reference CPU backend
+(oracle orc_cpu_gpt2_forward = GptTransformer::forward over CpuLinearOp / CpuLayerNormOp / CpuAttentionOp /
+CpuGeluOp / CpuResidualOp / CpuEncoderOp), fed the identical bf16-rounded parameters.
+
+The GPU path keeps bf16 activations between ops, the CPU reference is FP32 end to end, so the bar is the
+reference's own BF16 bar (5e-2 + 5e-2|y|, Linear.Cuda.cpp:111-129) on the logits; argmax agreement is
+checked where the top-2 margin exceeds the bar."""
+import numpy as np
+import pytest
+
+import orc
+from mila_amd import host
+
+pytestmark = pytest.mark.gpu
+
+
+def make_params(rng, V, maxT, C_, L):
+    def t(*shape, scale=0.02, offset=0.0):
+        return orc.to_bf16_bits((rng.standard_normal(shape) * scale + offset).astype(np.float32))
+    ps = [t(V, C_, scale=0.05), t(maxT, C_, scale=0.02)]
+    for _ in range(L):
+        ps += [t(C_, scale=0.1, offset=1.0), t(C_, scale=0.05), t(3 * C_, C_, scale=C_ ** -0.5), t(3 * C_, scale=0.02),
+               t(C_, C_, scale=C_ ** -0.5), t(C_, scale=0.02), t(C_, scale=0.1, offset=1.0), t(C_, scale=0.05),
+               t(4 * C_, C_, scale=C_ ** -0.5), t(4 * C_, scale=0.02), t(C_, 4 * C_, scale=(4 * C_) ** -0.5), t(C_, scale=0.02)]
+    ps += [t(C_, scale=0.1, offset=1.0), t(C_, scale=0.05), t(V, C_, scale=C_ ** -0.5)]
+    return ps
+
+
+@pytest.mark.parametrize("V,maxT,C_,L,NH,B,T", [(512, 64, 128, 2, 2, 2, 24), (1000, 128, 768, 3, 12, 1, 64)])
+def test_gpt2_forward_matches_the_restated_cpu_backend(V, maxT, C_, L, NH, B, T):
+    rng = np.random.default_rng(C_ + T)
+    params = make_params(rng, V, maxT, C_, L)
+    tokens = rng.integers(0, V, (B, T)).astype(np.int32)
+    g = host.Gpt(V, maxT, C_, L, NH, B, T)
+    g.load_parameters(params)
+    got = orc.from_bf16_bits(g.forward(tokens))
+    exp = orc.cpu_gpt2_forward(tokens, [orc.from_bf16_bits(p) for p in params], C_, L, NH, V, maxT)
+    assert np.all(np.isfinite(got))
+    assert np.all(np.abs(got - exp) <= 5e-2 + 5e-2 * np.abs(exp)), np.abs(got - exp).max()
+    srt = np.sort(exp, axis=-1)
+    clear = (srt[..., -1] - srt[..., -2]) > 0.2
+    assert np.array_equal(got.argmax(-1)[clear], exp.argmax(-1)[clear])
+    with pytest.raises(IndexError):
+        bad = tokens.copy()
+        bad[0, 3] = V
+        g.forward(bad)
+    g.close()
+
+
+def test_gpt2_124m_full_width_single_block_row():
+    """config-2 widths (C=768, NH=12, V=50257) on a short sequence: every Linear/LayerNorm/MHA/LPE row at
+    its real size against the CPU reference (the full B=8, T=1024 forward is 2 TFLOP on the FP32 CPU path)."""
+    V, maxT, C_, L, NH, B, T = 50257, 1024, 768, 1, 12, 1, 16
+    rng = np.random.default_rng(1)
+    params = make_params(rng, V, maxT, C_, L)
+    tokens = rng.integers(0, V, (B, T)).astype(np.int32)
+    g = host.Gpt(V, maxT, C_, L, NH, B, T)
+    g.load_parameters(params)
+    got = orc.from_bf16_bits(g.forward(tokens))
+    exp = orc.cpu_gpt2_forward(tokens, [orc.from_bf16_bits(p) for p in params], C_, L, NH, V, maxT)
+    assert np.all(np.abs(got - exp) <= 5e-2 + 5e-2 * np.abs(exp)), np.abs(got - exp).max()
+    g.close()

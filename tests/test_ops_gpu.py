@@ -189,3 +189,20 @@ def test_convert_roundtrip():
     z = empty_f32(x.size)
     capi.call("convert_bf16_to_f32", z, y, C.c_int64(x.size))
     assert np.array_equal(host(z), orc.round_bf16(x))
+
+
+def test_dpp_wave_reductions_match_the_crossbar_butterfly():
+    """wave_sum / wave_max built from DPP + v_permlane16/32_swap: every lane gets the same bits; on
+    integer-valued inputs the sum is exact; on random inputs it equals the ds_bpermute butterfly up to
+    reassociation (both are pairwise trees)."""
+    rng = np.random.default_rng(0)
+    for trial in range(4):
+        x = rng.integers(-1000, 1000, 64).astype(np.float32) if trial < 2 else rng.standard_normal(64).astype(np.float32)
+        out = empty_f32(192)
+        capi.check(capi.load().mila_cdna4_selftest_wave_reduce(C.c_void_p(out.data_ptr()), C.c_void_p(dev_f32(x).data_ptr()), None))
+        o = host(out)
+        assert np.all(o[:64] == o[0]) and np.all(o[64:128] == x.max())
+        if trial < 2:
+            assert o[0] == x.astype(np.float64).sum() and np.all(o[128:] == o[0])
+        else:
+            assert abs(o[0] - x.astype(np.float64).sum()) < 1e-4 and abs(o[128] - o[0]) < 1e-4
