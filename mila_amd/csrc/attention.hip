@@ -411,6 +411,9 @@ int mila_cdna4_attn_decode_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t* 
     MILA_REQUIRE(window >= 0, "attn_decode_bf16: negative window");
     const int band = (window > 0 && window < len) ? window : len;
     MILA_REQUIRE(band <= capacity, "attn_decode_bf16: live band %d exceeds the cache capacity %d", band, capacity);
+    // the split count depends only on (window, capacity), never on the current length, so that eager
+    // launches and a graph captured once (the _devpos form) reduce in the same order: bit-identical
+    const int band_max = (window > 0 && window < capacity) ? window : capacity;
     AttnParams p;
     p.Y = Y; p.Q = Q; p.K = Kc; p.V = Vc; p.scratch = reinterpret_cast<float*>(scratch);
     p.q_row_stride = (int64_t)NH * HS;
@@ -418,7 +421,7 @@ int mila_cdna4_attn_decode_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t* 
     p.kv_h_stride = (int64_t)capacity * HS;
     p.kv_r_stride = HS;
     p.Tq = 1; p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.pos_offset = len - 1; p.window = window;
-    p.splits = decode_splits(B, NH, NKV, band);
+    p.splits = decode_splits(B, NH, NKV, band_max);
     p.scale = scale;
     p.pos_dev = nullptr;
     if (p.splits > 1)
@@ -440,6 +443,7 @@ int mila_cdna4_attn_decode_bf16_devpos(uint16_t* Y, const uint16_t* Q, const uin
     MILA_REQUIRE(max_len > 0 && capacity > 0 && window >= 0, "attn_decode_bf16_devpos: bad sizes");
     const int band = (window > 0 && window < max_len) ? window : max_len;
     MILA_REQUIRE(band <= capacity, "attn_decode_bf16_devpos: live band %d exceeds the cache capacity %d", band, capacity);
+    const int band_max = (window > 0 && window < capacity) ? window : capacity;   // same rule as the eager form
     AttnParams p;
     p.Y = Y; p.Q = Q; p.K = Kc; p.V = Vc; p.scratch = reinterpret_cast<float*>(scratch);
     p.q_row_stride = (int64_t)NH * HS;
@@ -447,7 +451,7 @@ int mila_cdna4_attn_decode_bf16_devpos(uint16_t* Y, const uint16_t* Q, const uin
     p.kv_h_stride = (int64_t)capacity * HS;
     p.kv_r_stride = HS;
     p.Tq = 1; p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.pos_offset = 0; p.window = window;
-    p.splits = decode_splits(B, NH, NKV, band);   // fixed at capture time from the largest band
+    p.splits = decode_splits(B, NH, NKV, band_max);
     p.scale = scale;
     p.pos_dev = position_dev;
     if (p.splits > 1)
