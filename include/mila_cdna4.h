@@ -269,6 +269,19 @@ MILA_API int mila_cdna4_fused_qkv_post_devpos(uint16_t* q_out, uint16_t* Kc, uin
                                               mila_stream_t stream);
 MILA_API int mila_cdna4_advance_position(int32_t* position_dev, mila_stream_t stream);
 
+/* One-launch decode attention for one token (B == 1): q/k/v per-head RMSNorm + RoPE + KV append (the
+ * work of fused_qkv_post) folded into the flash-decode kernel's prologue, where it overlaps the first
+ * K/V round trip.  q_raw [NH*HS], k_raw / v_raw [NKV*HS] are the raw projections (v_raw == k_raw on Gemma
+ * global layers).  position_dev != NULL selects the graph-replay form.  Bit-identical to
+ * fused_qkv_post + attn_decode_bf16. */
+MILA_API int mila_cdna4_fused_attn_decode_bf16(uint16_t* Y, uint16_t* Kc, uint16_t* Vc, const uint16_t* q_raw,
+                                               const uint16_t* k_raw, const uint16_t* v_raw, const uint16_t* qw,
+                                               const uint16_t* kw, const uint16_t* vw, const float* cos_cache,
+                                               const float* sin_cache, void* scratch, size_t scratch_bytes, int NH,
+                                               int NKV, int HS, int capacity, int position,
+                                               const int32_t* position_dev, int window, float scale, float eps,
+                                               mila_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

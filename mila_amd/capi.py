@@ -111,5 +111,5 @@ EXPORTED = [
     "embedding_gather_bf16", "embedding_gather_bf16_qfp8", "lpe_bf16", "split3_bf16", "scale_bf16",
     "convert_f32_to_bf16", "convert_bf16_to_f32",
     "fused_norm_matvec", "fused_qkv_post",
-    "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position",
+    "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position", "fused_attn_decode_bf16",
 ]

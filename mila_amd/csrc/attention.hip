@@ -19,6 +19,8 @@
 //   merged by a second tiny kernel (a kernel boundary is cheaper than an in-kernel agent-scope
 //   acquire on this chip, MI355X_MICROARCH "boundary" vs "barrier-xcd").
 #include "common.h"
+#include "rms_common.h"
+#include "rope_common.h"
 
 namespace mila {
 
@@ -48,24 +50,28 @@ __global__ __launch_bounds__(256) void kv_write_bf16_kernel(uint16_t* __restrict
     }
 }
 
-// ---- generic addressing so one kernel serves the cache layout and GPT-2's packed QKV -----------------
+// ---- decode attention ---------------------------------------------------------------------------------
 struct AttnParams
 {
-    uint16_t* Y;              // [B*Tq, NH*HS]
-    const uint16_t* Q;        // row (b*Tq+t): Q + (b*Tq+t)*q_row_stride + h*HS
-    const uint16_t* K;        // K + b*kv_b_stride + kvh*kv_h_stride + row*kv_r_stride
-    const uint16_t* V;
-    float* scratch;           // [B*Tq, NH, splits, HS+2] partials when splits > 1
-    int64_t q_row_stride, kv_b_stride, kv_h_stride, kv_r_stride;
-    int Tq, NH, NKV, capacity, pos_offset, window, splits;
+    uint16_t* Y;              // [B, NH*HS]
+    const uint16_t* Q;        // [B, NH*HS] post-norm/rope queries (unfused form), or NULL in the fused form
+    uint16_t* K;              // cache [B, NKV, capacity, HS]
+    uint16_t* V;
+    float* scratch;           // [B, NH, splits, HS+2] partials when splits > 1
+    int NH, NKV, capacity, position, window, splits;
     float scale;
-    const int32_t* pos_dev;   // when set: position of query 0 is read from device memory (graph replay)
+    const int32_t* pos_dev;   // when set: the position is read from device memory (graph replay)
+    // fused prologue (GemmaBlock::decode lines 315-337 folded in): raw projections + norm weights + RoPE cache
+    const uint16_t* q_raw;    // [NH*HS]  (B == 1)
+    const uint16_t* k_raw;    // [NKV*HS]
+    const uint16_t* v_raw;    // [NKV*HS] (== k_raw on Gemma global layers)
+    const uint16_t* qw;
+    const uint16_t* kw;
+    const uint16_t* vw;       // may be NULL (unit weight)
+    const float* cos_cache;
+    const float* sin_cache;
+    float eps;
 };
-
-template <int EPL> struct RowVec;                        // EPL bf16 elements per lane
-template <> struct RowVec<8> { typedef u32x4 type; };
-template <> struct RowVec<4> { typedef u32x2 type; };
-template <> struct RowVec<2> { typedef uint32_t type; };
 
 template <int EPL>
 __device__ __forceinline__ void load_row(uint32_t (&dst)[EPL / 2], const uint16_t* p)
@@ -86,72 +92,79 @@ __device__ __forceinline__ void load_row(uint32_t (&dst)[EPL / 2], const uint16_
     }
 }
 
-// HS = 64 * EPL (EPL in {2,4,8}) or HS = 64 handled as EPL = 2 on 32 active lanes.
-// GH = query heads handled per workgroup (<= 4): grid.y = NKV * (GS / GH); the head groups of one
-// KV head re-read the same K/V rows from L2, which costs nothing next to the 4x cut in per-wave
-// VALU work and registers for MQA (GS = 16).
-template <int HS, int GH>
-__global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
+constexpr int kDecodeWaves = 8;     // 512 threads per workgroup
+
+// norm (+ RoPE) of one head row by one wave, canonical helpers => bit-identical to the standalone
+// rmsnorm / rope kernels and to qkv_post_kernel.  dst_lds / dst_glb may be NULL.
+template <int HS>
+__device__ __forceinline__ void head_row_post(const uint16_t* __restrict__ src, const uint16_t* __restrict__ w, bool rotate,
+                                              const float* cos_row, const float* sin_row, float eps,
+                                              uint16_t* dst_lds, uint16_t* dst_glb)
 {
+    constexpr int hv = HS / 16;
+    const int lane = threadIdx.x & 63;
+    const bool act = lane < hv;
+    const int l2 = act ? lane : 0;
+    const u32x4 xlo = ld16(src + (size_t)l2 * 8), xhi = ld16(src + (size_t)(l2 + hv) * 8);
+    u32x4 wlo = u32x4{0u, 0u, 0u, 0u}, whi = wlo;
+    if (w) { wlo = ld16(w + (size_t)l2 * 8); whi = ld16(w + (size_t)(l2 + hv) * 8); }
+    const float rstd = rms_rstd_wave(src, HS, eps);
+    if (act)
+    {
+        u32x4 lo, hi;
+        if (w) { lo = rms_apply8(xlo, wlo, rstd, 0.0f); hi = rms_apply8(xhi, whi, rstd, 0.0f); }
+        else { lo = rms_apply8_now(xlo, rstd); hi = rms_apply8_now(xhi, rstd); }
+        if (rotate) rope_rotate8_vals(lo, hi, cos_row, sin_row, lane * 8);
+        if (dst_lds) { st16(dst_lds + (size_t)lane * 8, lo); st16(dst_lds + (size_t)(lane + hv) * 8, hi); }
+        if (dst_glb) { st16(dst_glb + (size_t)lane * 8, lo); st16(dst_glb + (size_t)(lane + hv) * 8, hi); }
+    }
+}
+
+// HS = 64 * EPL (EPL in {2,4,8}) or HS = 64 handled as EPL = 2 on 32 active lanes.
+// GH = query heads per workgroup; grid = (splits, NKV * GS/GH, B); 8 waves, wave w owns positions
+// begin + w + 8 j of the split.  FUSED: the q/k/v post-processing of the token is done in the prologue,
+// overlapped with the first K/V round trip; the new K/V row is appended to the cache by the split that owns it.
+template <int HS, int GH, bool FUSED>
+__global__ __launch_bounds__(kDecodeWaves * 64) void attn_decode_kernel(const AttnParams p)
+{
+    constexpr int NW = kDecodeWaves;
     constexpr int EPL = (HS >= 128) ? HS / 64 : 2;
     constexpr int NPAIR = EPL / 2;
     constexpr int ACTIVE = HS / EPL;                       // lanes that own data (64, or 32 for HS = 64)
+    constexpr int STR = HS + 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* sm = reinterpret_cast<float*>(smem_raw);        // [4 waves][GH][HS + 2]
+    float* sm = reinterpret_cast<float*>(smem_raw);        // [NW][GH][HS + 2]
+    uint16_t* qs = reinterpret_cast<uint16_t*>(smem_raw + (size_t)NW * GH * STR * sizeof(float));   // [GH][HS], then k_new, v_new
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool owner = lane < ACTIVE;
     const int GS = p.NH / p.NKV, hgroups = GS / GH;
     const int split = blockIdx.x, kvh = blockIdx.y / hgroups, hg = blockIdx.y % hgroups;
     const int h0 = kvh * GS + hg * GH;                     // first query head of this workgroup
-    const int bt = blockIdx.z, b = bt / p.Tq, t = bt % p.Tq;
-    const int pos = (p.pos_dev ? *p.pos_dev : p.pos_offset) + t;
+    const int b = blockIdx.z;
+    const int pos = p.pos_dev ? *p.pos_dev : p.position;
     const int len = pos + 1;
     const int band_begin = (p.window > 0) ? max(0, len - p.window) : 0;
     const int band = len - band_begin;
     const int chunk = (band + p.splits - 1) / p.splits;
     const int begin = band_begin + split * chunk;
     const int end = min(begin + chunk, len);
+    const bool owns_new = FUSED && pos >= begin && pos < end;   // this split appends (and consumes) the new K/V row
 
-    // q for the GH heads, packed bf16 pairs
-    uint32_t q[GH][NPAIR];
-#pragma unroll
-    for (int g = 0; g < GH; ++g)
-    {
-        const uint16_t* qp = p.Q + (size_t)bt * p.q_row_stride + (size_t)(h0 + g) * HS + lane * EPL;
-        if (owner) load_row<EPL>(q[g], qp);
-        else
-        {
-#pragma unroll
-            for (int e = 0; e < NPAIR; ++e) q[g][e] = 0u;
-        }
-    }
-    float m[GH], l[GH], o[GH][EPL];
-#pragma unroll
-    for (int g = 0; g < GH; ++g)
-    {
-        m[g] = -INFINITY;
-        l[g] = 0.0f;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) o[g][e] = 0.0f;
-    }
+    uint16_t* kbase = p.K + ((size_t)b * p.NKV + kvh) * p.capacity * HS;
+    uint16_t* vbase = p.V + ((size_t)b * p.NKV + kvh) * p.capacity * HS;
 
-    const uint16_t* kbase = p.K + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride + lane * EPL;
-    const uint16_t* vbase = p.V + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride + lane * EPL;
-
-    // A wave owns positions base, base + 4, ... of the split, PG at a time.  All K/V rows of a group are
-    // requested at once and the next group's rows are in flight while the current group is reduced, so a
-    // split of <= 4*PG positions per wave costs a single HBM round trip.
     constexpr int PG = (HS >= 512) ? 4 : 8;
     struct KVG { uint32_t k[PG][NPAIR], v[PG][NPAIR]; };
     auto load_group = [&](KVG& gbuf, int base) {
 #pragma unroll
         for (int j = 0; j < PG; ++j)
         {
-            const int pos = base + 4 * j;
-            if (owner && pos < end)
+            const int pp = base + NW * j;
+            // in the fused form row `pos` is not in the cache yet: it is patched in from LDS below
+            if (owner && pp < end && !(FUSED && pp == pos))
             {
-                const size_t r = (size_t)(pos % p.capacity) * p.kv_r_stride;
+                const size_t r = (size_t)(pp % p.capacity) * HS + lane * EPL;
                 load_row<EPL>(gbuf.k[j], kbase + r);
                 load_row<EPL>(gbuf.v[j], vbase + r);
             }
@@ -162,7 +175,83 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
             }
         }
     };
-    auto compute_group = [&](const KVG& gbuf, int base) {
+
+    int base = begin + wave;
+    KVG ga, gb;
+    if (base < end) load_group(ga, base);                  // in flight during the prologue
+
+    // ---- q (and the new K/V row) ----
+    uint32_t q[GH][NPAIR];
+    if constexpr (FUSED)
+    {
+        const int half = HS / 2;
+        const float* cos_row = p.cos_cache + (size_t)pos * half;
+        const float* sin_row = p.sin_cache + (size_t)pos * half;
+        const int nrows = GH + (owns_new ? 2 : 0);
+        for (int r = wave; r < nrows; r += NW)
+        {
+            if (r < GH)
+                head_row_post<HS>(p.q_raw + (size_t)(h0 + r) * HS, p.qw, true, cos_row, sin_row, p.eps, qs + (size_t)r * HS, nullptr);
+            else if (r == GH)
+                head_row_post<HS>(p.k_raw + (size_t)kvh * HS, p.kw, true, cos_row, sin_row, p.eps, qs + (size_t)GH * HS,
+                                  (hg == 0) ? kbase + (size_t)(pos % p.capacity) * HS : nullptr);
+            else
+                head_row_post<HS>(p.v_raw + (size_t)kvh * HS, p.vw, false, cos_row, sin_row, p.eps, qs + (size_t)(GH + 1) * HS,
+                                  (hg == 0) ? vbase + (size_t)(pos % p.capacity) * HS : nullptr);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < GH; ++g)
+        {
+            if (owner) load_row<EPL>(q[g], qs + (size_t)g * HS + lane * EPL);
+            else
+            {
+#pragma unroll
+                for (int e = 0; e < NPAIR; ++e) q[g][e] = 0u;
+            }
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int g = 0; g < GH; ++g)
+        {
+            const uint16_t* qp = p.Q + ((size_t)b * p.NH + (h0 + g)) * HS + lane * EPL;
+            if (owner) load_row<EPL>(q[g], qp);
+            else
+            {
+#pragma unroll
+                for (int e = 0; e < NPAIR; ++e) q[g][e] = 0u;
+            }
+        }
+    }
+
+    float m[GH], l[GH], o[GH][EPL];
+#pragma unroll
+    for (int g = 0; g < GH; ++g)
+    {
+        m[g] = -INFINITY;
+        l[g] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[g][e] = 0.0f;
+    }
+
+    auto patch_new = [&](KVG& gbuf, int base_) {           // put the LDS copy of row `pos` into its slot
+        if constexpr (FUSED)
+        {
+            if (owns_new)
+            {
+#pragma unroll
+                for (int j = 0; j < PG; ++j)
+                    if (base_ + NW * j == pos && owner)
+                    {
+                        load_row<EPL>(gbuf.k[j], qs + (size_t)GH * HS + lane * EPL);
+                        load_row<EPL>(gbuf.v[j], qs + (size_t)(GH + 1) * HS + lane * EPL);
+                    }
+            }
+        }
+    };
+    auto compute_group = [&](const KVG& gbuf, int base_) {
         float sc[PG][GH];
 #pragma unroll
         for (int j = 0; j < PG; ++j)
@@ -185,7 +274,7 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
 #pragma unroll
             for (int j = 0; j < PG; ++j)
             {
-                a[j] = (base + 4 * j < end) ? sc[j][g] * p.scale : -INFINITY;
+                a[j] = (base_ + NW * j < end) ? sc[j][g] * p.scale : -INFINITY;
                 mt = fmaxf(mt, a[j]);
             }
             const float mn = fmaxf(m[g], mt);
@@ -211,27 +300,23 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
             }
         }
     };
+    for (;;)
     {
-        int base = begin + wave;
-        KVG ga, gb;
-        if (base < end) load_group(ga, base);
-        for (;;)
-        {
-            if (base >= end) break;
-            int nb = base + 4 * PG;
-            if (nb < end) load_group(gb, nb);
-            compute_group(ga, base);
-            base = nb;
-            if (base >= end) break;
-            nb = base + 4 * PG;
-            if (nb < end) load_group(ga, nb);
-            compute_group(gb, base);
-            base = nb;
-        }
+        if (base >= end) break;
+        int nb = base + NW * PG;
+        if (nb < end) load_group(gb, nb);
+        patch_new(ga, base);
+        compute_group(ga, base);
+        base = nb;
+        if (base >= end) break;
+        nb = base + NW * PG;
+        if (nb < end) load_group(ga, nb);
+        patch_new(gb, base);
+        compute_group(gb, base);
+        base = nb;
     }
 
-    // ---- merge the 4 waves through LDS; wave w finalises head w (GH <= 4) ----
-    constexpr int STR = HS + 2;
+    // ---- merge the NW waves through LDS; wave w < GH finalises head w ----
 #pragma unroll
     for (int g = 0; g < GH; ++g)
     {
@@ -249,12 +334,12 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
         const int g = wave;
         float M = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) M = fmaxf(M, sm[((size_t)w * GH + g) * STR + HS]);
+        for (int w = 0; w < NW; ++w) M = fmaxf(M, sm[((size_t)w * GH + g) * STR + HS]);
         float L = 0.0f, acc[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
+        for (int w = 0; w < NW; ++w)
         {
             const float* src = sm + ((size_t)w * GH + g) * STR;
             const float mw = src[HS];
@@ -270,7 +355,7 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
         if (p.splits == 1)
         {
             const float inv = (L > 0.0f) ? 1.0f / L : 0.0f;
-            uint16_t* y = p.Y + ((size_t)bt * p.NH + h) * HS + lane * EPL;
+            uint16_t* y = p.Y + ((size_t)b * p.NH + h) * HS + lane * EPL;
             if (owner)
             {
 #pragma unroll
@@ -280,7 +365,7 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
         }
         else
         {
-            float* dst = p.scratch + (((size_t)bt * p.NH + h) * p.splits + split) * STR;
+            float* dst = p.scratch + (((size_t)b * p.NH + h) * p.splits + split) * STR;
             if (owner)
             {
 #pragma unroll
@@ -291,86 +376,119 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p)
     }
 }
 
-// combine split partials: grid (NH, B*Tq, HS/64), 64 threads -> 64 dims each
+// combine split partials: grid (NH, B, HS/64), 64 threads -> 64 dims each; splits <= 64.
+// Every thread reads all (m, l) pairs itself (broadcast loads) and all partial values of its dim in
+// unrolled batches, so the kernel is two dependent memory round trips long.
 __global__ __launch_bounds__(64) void attn_combine_kernel(uint16_t* __restrict__ Y, const float* __restrict__ scratch, int NH,
                                                           int HS, int splits)
 {
-    const int h = blockIdx.x, bt = blockIdx.y;
+    const int h = blockIdx.x, b = blockIdx.y;
     const int d = blockIdx.z * 64 + threadIdx.x;
     const int STR = HS + 2;
-    const float* base = scratch + ((size_t)bt * NH + h) * splits * STR;
-    // lane s holds split s's (m, l); splits <= 64
+    const float* base = scratch + ((size_t)b * NH + h) * splits * STR;
     const int s = threadIdx.x;
     const float ms = (s < splits) ? base[(size_t)s * STR + HS] : -INFINITY;
     const float ls = (s < splits) ? base[(size_t)s * STR + HS + 1] : 0.0f;
+    float acc = 0.0f;
+    // partial values are requested before the (m, l) reduction completes
+    float vals[8];
     const float M = wave_max(ms);
     const float fs = (ms == -INFINITY) ? 0.0f : __expf(ms - M);
     const float L = wave_sum(ls * fs);
-    float acc = 0.0f;
-#pragma unroll 8
-    for (int i = 0; i < splits; ++i)
+    for (int i0 = 0; i0 < splits; i0 += 8)
     {
-        const float f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fs), i));
-        acc = fmaf(base[(size_t)i * STR + d], f, acc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vals[u] = (i0 + u < splits) ? base[(size_t)(i0 + u) * STR + d] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+        {
+            const float f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fs), min(i0 + u, 63)));
+            acc = fmaf(vals[u], f, acc);
+        }
     }
-    Y[((size_t)bt * NH + h) * HS + d] = f32_to_bf16_bits(L > 0.0f ? acc / L : 0.0f);
+    Y[((size_t)b * NH + h) * HS + d] = f32_to_bf16_bits(L > 0.0f ? acc / L : 0.0f);
 }
 
-template <int HS, int GH>
-static int launch_rowwise(const AttnParams& p, int B, hipStream_t s)
+static int heads_per_group(int GS, int HS) { return HS >= 512 ? (GS >= 2 ? 2 : 1) : (GS >= 4 ? 4 : GS); }
+
+template <int HS, int GH, bool FUSED>
+static int launch_decode(const AttnParams& p, int B, hipStream_t s)
 {
     const int hgroups = (p.NH / p.NKV) / GH;
-    const size_t lds = (size_t)4 * GH * (HS + 2) * sizeof(float);
-    hipLaunchKernelGGL((attn_rowwise_kernel<HS, GH>), dim3(p.splits, p.NKV * hgroups, B * p.Tq), dim3(256), lds, s, p);
-    int rc = check_hip(hipGetLastError(), "attn_rowwise");
+    const size_t lds = (size_t)kDecodeWaves * GH * (HS + 2) * sizeof(float) + (size_t)(GH + 2) * HS * 2;
+    hipLaunchKernelGGL((attn_decode_kernel<HS, GH, FUSED>), dim3(p.splits, p.NKV * hgroups, B), dim3(kDecodeWaves * 64), lds, s, p);
+    int rc = check_hip(hipGetLastError(), "attn_decode");
     if (rc) return rc;
     if (p.splits > 1)
     {
-        hipLaunchKernelGGL(attn_combine_kernel, dim3(p.NH, B * p.Tq, HS / 64), dim3(64), 0, s, p.Y, p.scratch, p.NH, HS,
-                           p.splits);
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(p.NH, B, HS / 64), dim3(64), 0, s, p.Y, p.scratch, p.NH, HS, p.splits);
         rc = check_hip(hipGetLastError(), "attn_combine");
     }
     return rc;
 }
 
-static int heads_per_group(int GS) { return GS >= 4 ? 4 : GS; }
-
-template <int HS>
+template <int HS, bool FUSED>
 static int dispatch_gs(const AttnParams& p, int B, hipStream_t s)
 {
     const int GS = p.NH / p.NKV;
-    switch (GS)
+    if (GS != 1 && GS != 2 && GS != 4 && GS != 8 && GS != 16 && GS != 32)
+        return set_error(MILA_E_UNSUPPORTED, "attention: group size %d (NH/NKV) must be 1,2,4,8,16 or 32", GS);
+    switch (heads_per_group(GS, HS))
     {
-        case 1: return launch_rowwise<HS, 1>(p, B, s);
-        case 2: return launch_rowwise<HS, 2>(p, B, s);
-        case 4: case 8: case 16: case 32: return launch_rowwise<HS, 4>(p, B, s);
-        default: return set_error(MILA_E_UNSUPPORTED, "attention: group size %d (NH/NKV) must be 1,2,4,8,16 or 32", GS);
+        case 1: return launch_decode<HS, 1, FUSED>(p, B, s);
+        case 2: return launch_decode<HS, 2, FUSED>(p, B, s);
+        default: return launch_decode<HS, 4, FUSED>(p, B, s);
     }
 }
 
+template <bool FUSED>
 static int dispatch_hs(int HS, const AttnParams& p, int B, hipStream_t s)
 {
     switch (HS)
     {
-        case 64: return dispatch_gs<64>(p, B, s);
-        case 128: return dispatch_gs<128>(p, B, s);
-        case 256: return dispatch_gs<256>(p, B, s);
-        case 512: return dispatch_gs<512>(p, B, s);
+        case 64: return dispatch_gs<64, FUSED>(p, B, s);
+        case 128: return dispatch_gs<128, FUSED>(p, B, s);
+        case 256: return dispatch_gs<256, FUSED>(p, B, s);
+        case 512: return dispatch_gs<512, FUSED>(p, B, s);
         default: return set_error(MILA_E_UNSUPPORTED, "attention: head size %d must be 64, 128, 256 or 512", HS);
     }
 }
 
-static int decode_splits(int B, int NH, int NKV, int band)
+static int decode_splits(int B, int NH, int NKV, int HS, int band)
 {
-    // ~256 workgroups (one per CU) of 32 positions (8 per wave: one or two load groups)
-    const int hgroups = (NH / NKV) / heads_per_group(NH / NKV);
+    // ~256 workgroups of 8 waves, 64 positions (8 per wave) per split
+    const int GS = NH / NKV;
+    const int hgroups = GS / heads_per_group(GS, HS);
     int cap = 256 / (NKV * hgroups * B);
     if (cap < 1) cap = 1;
-    int s = (band + 31) / 32;
+    int s = (band + 63) / 64;
     if (s > cap) s = cap;
     if (s > kMaxSplits) s = kMaxSplits;
     if (s < 1) s = 1;
     return s;
+}
+
+static int run_decode(uint16_t* Y, const uint16_t* Q, uint16_t* Kc, uint16_t* Vc, void* scratch, size_t scratch_bytes, int B,
+                      int NH, int NKV, int HS, int capacity, int position, const int32_t* pos_dev, int window, float scale,
+                      const AttnParams* fused, const char* who, hipStream_t stream)
+{
+    AttnParams p{};
+    if (fused) p = *fused;
+    p.Y = Y; p.Q = Q; p.K = Kc; p.V = Vc; p.scratch = reinterpret_cast<float*>(scratch);
+    p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.position = position; p.window = window;
+    // the split count depends only on (window, capacity), never on the current length, so that eager
+    // launches and a graph captured once (the _devpos forms) reduce in the same order: bit-identical
+    const int band_max = (window > 0 && window < capacity) ? window : capacity;
+    p.splits = decode_splits(B, NH, NKV, HS, band_max);
+    p.scale = scale;
+    p.pos_dev = pos_dev;
+    if (p.splits > 1)
+    {
+        const size_t need = (size_t)B * NH * p.splits * (HS + 2) * sizeof(float);
+        if (!scratch || scratch_bytes < need)
+            return set_error(MILA_E_SCRATCH_TOO_SMALL, "%s: scratch %zu bytes < required %zu", who, scratch_bytes, need);
+    }
+    return fused ? dispatch_hs<true>(HS, p, B, stream) : dispatch_hs<false>(HS, p, B, stream);
 }
 
 }  // namespace mila
@@ -411,26 +529,8 @@ int mila_cdna4_attn_decode_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t* 
     MILA_REQUIRE(window >= 0, "attn_decode_bf16: negative window");
     const int band = (window > 0 && window < len) ? window : len;
     MILA_REQUIRE(band <= capacity, "attn_decode_bf16: live band %d exceeds the cache capacity %d", band, capacity);
-    // the split count depends only on (window, capacity), never on the current length, so that eager
-    // launches and a graph captured once (the _devpos form) reduce in the same order: bit-identical
-    const int band_max = (window > 0 && window < capacity) ? window : capacity;
-    AttnParams p;
-    p.Y = Y; p.Q = Q; p.K = Kc; p.V = Vc; p.scratch = reinterpret_cast<float*>(scratch);
-    p.q_row_stride = (int64_t)NH * HS;
-    p.kv_b_stride = (int64_t)NKV * capacity * HS;
-    p.kv_h_stride = (int64_t)capacity * HS;
-    p.kv_r_stride = HS;
-    p.Tq = 1; p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.pos_offset = len - 1; p.window = window;
-    p.splits = decode_splits(B, NH, NKV, band_max);
-    p.scale = scale;
-    p.pos_dev = nullptr;
-    if (p.splits > 1)
-    {
-        const size_t need = (size_t)B * NH * p.splits * (HS + 2) * sizeof(float);
-        if (!scratch || scratch_bytes < need)
-            return set_error(MILA_E_SCRATCH_TOO_SMALL, "attn_decode_bf16: scratch %zu bytes < required %zu", scratch_bytes, need);
-    }
-    return dispatch_hs(HS, p, B, as_stream(stream));
+    return run_decode(Y, Q, const_cast<uint16_t*>(Kc), const_cast<uint16_t*>(Vc), scratch, scratch_bytes, B, NH, NKV, HS, capacity,
+                      len - 1, nullptr, window, scale, nullptr, "attn_decode_bf16", as_stream(stream));
 }
 
 int mila_cdna4_attn_decode_bf16_devpos(uint16_t* Y, const uint16_t* Q, const uint16_t* Kc, const uint16_t* Vc, void* scratch,
@@ -443,24 +543,32 @@ int mila_cdna4_attn_decode_bf16_devpos(uint16_t* Y, const uint16_t* Q, const uin
     MILA_REQUIRE(max_len > 0 && capacity > 0 && window >= 0, "attn_decode_bf16_devpos: bad sizes");
     const int band = (window > 0 && window < max_len) ? window : max_len;
     MILA_REQUIRE(band <= capacity, "attn_decode_bf16_devpos: live band %d exceeds the cache capacity %d", band, capacity);
-    const int band_max = (window > 0 && window < capacity) ? window : capacity;   // same rule as the eager form
-    AttnParams p;
-    p.Y = Y; p.Q = Q; p.K = Kc; p.V = Vc; p.scratch = reinterpret_cast<float*>(scratch);
-    p.q_row_stride = (int64_t)NH * HS;
-    p.kv_b_stride = (int64_t)NKV * capacity * HS;
-    p.kv_h_stride = (int64_t)capacity * HS;
-    p.kv_r_stride = HS;
-    p.Tq = 1; p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.pos_offset = 0; p.window = window;
-    p.splits = decode_splits(B, NH, NKV, band_max);
-    p.scale = scale;
-    p.pos_dev = position_dev;
-    if (p.splits > 1)
+    return run_decode(Y, Q, const_cast<uint16_t*>(Kc), const_cast<uint16_t*>(Vc), scratch, scratch_bytes, B, NH, NKV, HS, capacity, 0,
+                      position_dev, window, scale, nullptr, "attn_decode_bf16_devpos", as_stream(stream));
+}
+
+// Fused decode attention for one token (B == 1): per-head q/k/v RMSNorm + RoPE + KV append + flash-decode.
+// position_dev != NULL selects the graph-replay form (position read from device memory).
+int mila_cdna4_fused_attn_decode_bf16(uint16_t* Y, uint16_t* Kc, uint16_t* Vc, const uint16_t* q_raw, const uint16_t* k_raw,
+                                      const uint16_t* v_raw, const uint16_t* qw, const uint16_t* kw, const uint16_t* vw,
+                                      const float* cos_cache, const float* sin_cache, void* scratch, size_t scratch_bytes,
+                                      int NH, int NKV, int HS, int capacity, int position, const int32_t* position_dev,
+                                      int window, float scale, float eps, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && Kc && Vc && q_raw && k_raw && v_raw && qw && kw && cos_cache && sin_cache, "fused_attn_decode_bf16: null pointer");
+    MILA_REQUIRE(NH > 0 && NKV > 0 && NH % NKV == 0, "fused_attn_decode_bf16: bad head counts (NH=%d NKV=%d)", NH, NKV);
+    MILA_REQUIRE(capacity > 0 && window >= 0 && (position_dev || position >= 0), "fused_attn_decode_bf16: bad sizes");
+    MILA_REQUIRE(HS % 16 == 0, "fused_attn_decode_bf16: HS=%d must be a multiple of 16", HS);
+    if (!position_dev)
     {
-        const size_t need = (size_t)B * NH * p.splits * (HS + 2) * sizeof(float);
-        if (!scratch || scratch_bytes < need)
-            return set_error(MILA_E_SCRATCH_TOO_SMALL, "attn_decode_bf16_devpos: scratch %zu bytes < required %zu", scratch_bytes, need);
+        const int len = position + 1, band = (window > 0 && window < len) ? window : len;
+        MILA_REQUIRE(band <= capacity, "fused_attn_decode_bf16: live band %d exceeds the cache capacity %d", band, capacity);
     }
-    return dispatch_hs(HS, p, B, as_stream(stream));
+    AttnParams f{};
+    f.q_raw = q_raw; f.k_raw = k_raw; f.v_raw = v_raw; f.qw = qw; f.kw = kw; f.vw = vw; f.cos_cache = cos_cache; f.sin_cache = sin_cache;
+    f.eps = eps;
+    return run_decode(Y, nullptr, Kc, Vc, scratch, scratch_bytes, 1, NH, NKV, HS, capacity, position, position_dev, window, scale, &f,
+                      "fused_attn_decode_bf16", as_stream(stream));
 }
 
 }  // extern "C"

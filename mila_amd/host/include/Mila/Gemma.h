@@ -483,27 +483,17 @@ namespace Mila::Dnn
                 }
                 Compute::rocmCheck( mila_cdna4_fused_norm_matvec( &a, st ) );
                 if ( prev ) { cur_hidden_ = hidden_[ next ]->data(); next = ( next == 1 ) ? 2 : 1; }
-                // 2. q/k/v norms + RoPE + KV append.  qkv row = [q | k | v] (global: [q | k], V from raw k)
+                // 2+3. q/k/v norms + RoPE + KV append + flash-decode in one launch (+ combine).
+                //        qkv row = [q | k | v] (global: [q | k], V from the raw k projection)
                 const uint16_t* qp = f_qkv_->data();
                 const uint16_t* kp = qp + (size_t)NH * HD;
                 const uint16_t* vp = g ? kp : kp + (size_t)NKV * HD;
-                if ( pos_dev )
-                    Compute::rocmCheck( mila_cdna4_fused_qkv_post_devpos( f_q_->data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
-                                                                          L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(), NH, NKV,
-                                                                          HD, pos_dev, (int)L.attn->cacheCapacity(), cfg_.rms_norm_eps, st ) );
-                else
-                    Compute::rocmCheck( mila_cdna4_fused_qkv_post( f_q_->data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
-                                                                   L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(), NH, NKV, HD,
-                                                                   position, (int)L.attn->cacheCapacity(), cfg_.rms_norm_eps, st ) );
-                // 3. flash-decode (+ combine)
                 const size_t need = attnScratchBytes();
                 void* scratch = ctx_->getScratch( need );
-                if ( pos_dev )
-                    Compute::rocmCheck( mila_cdna4_attn_decode_bf16_devpos( attn_out_->data(), f_q_->data(), L.attn->keyCache(), L.attn->valueCache(), scratch, need, 1, NH, NKV, HD,
-                                                                            (int)L.attn->cacheCapacity(), pos_dev, (int)max_seq_, (int)cfg_.windowFor( g ), L.attn->scale(), st ) );
-                else
-                    Compute::rocmCheck( mila_cdna4_attn_decode_bf16( attn_out_->data(), f_q_->data(), L.attn->keyCache(), L.attn->valueCache(), scratch, need, 1, NH, NKV, HD,
-                                                                     (int)L.attn->cacheCapacity(), position + 1, (int)cfg_.windowFor( g ), L.attn->scale(), st ) );
+                Compute::rocmCheck( mila_cdna4_fused_attn_decode_bf16( attn_out_->data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
+                                                                       L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(),
+                                                                       scratch, need, NH, NKV, HD, (int)L.attn->cacheCapacity(), position, pos_dev,
+                                                                       (int)cfg_.windowFor( g ), L.attn->scale(), cfg_.rms_norm_eps, st ) );
                 // 4. o_proj
                 plainMatvec( *L.o_proj, f_o_->data(), attn_out_->data() );
                 // 5. post_attn_norm + residual + pre_ffn_norm + gate_up + GeGLU

@@ -125,3 +125,41 @@ def test_qkv_post_equals_unfused_chain_and_oracle(NH, NKV, HS, rot, base, kv_sha
     from gpu_util import host
     qe = orc.rope_rotate(_bf(orc.rmsnorm(q, qw, None, eps=1e-6)).reshape(1, 1, NH, HS), host(cos), host(sin), pos)
     assert_bf16_close(bits(q1), qe, 1, 1e-30, "fused q vs oracle")
+
+
+@pytest.mark.parametrize("NH,NKV,HS,rot,base,window,kv_shared", [(16, 8, 256, 0, 1e4, 1024, False), (16, 1, 512, 128, 1e6, 0, True),
+                                                                 (4, 2, 64, 0, 1e4, 8, False)])
+@pytest.mark.parametrize("pos", [0, 5, 63, 64, 200, 1500])
+def test_fused_attn_decode_equals_qkv_post_plus_attn_decode(NH, NKV, HS, rot, base, window, kv_shared, pos):
+    """one launch (prologue: q/k/v norm + RoPE + KV append) vs the two-launch chain, bit for bit, including
+    the cache contents; positions at split boundaries and inside/outside the sliding window"""
+    rng = np.random.default_rng(HS + pos)
+    cap, max_seq = 2048, 2048
+    hist = min(pos, 1600)
+    Kc0 = torch.from_numpy(orc.to_bf16_bits(rng.uniform(-1, 1, (1, NKV, cap, HS)).astype(np.float32) * 0.5).view(np.int16)).cuda()
+    Vc0 = torch.from_numpy(orc.to_bf16_bits(rng.uniform(-1, 1, (1, NKV, cap, HS)).astype(np.float32)).view(np.int16)).cuda()
+    q = _bf(rng.standard_normal((NH, HS)))
+    k = _bf(rng.standard_normal((NKV, HS)))
+    v = k if kv_shared else _bf(rng.standard_normal((NKV, HS)))
+    qw, kw = _d(_bf(1 + 0.1 * rng.uniform(-1, 1, HS))), _d(_bf(1 + 0.1 * rng.uniform(-1, 1, HS)))
+    cos, sin = empty_f32(max_seq, HS // 2), empty_f32(max_seq, HS // 2)
+    capi.call("rope_build_cache", cos, sin, max_seq, HS, float(base), rot)
+    nbytes = capi.load().mila_cdna4_attn_decode_scratch_bytes(1, NH, HS)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    # chain
+    K0, V0, q0, y0 = Kc0.clone(), Vc0.clone(), empty_u16(NH, HS), empty_u16(NH * HS)
+    capi.call("fused_qkv_post", q0, K0, V0, _d(q), _d(k), _d(v), qw, kw, None, cos, sin, NH, NKV, HS, pos, cap, 1e-6)
+    capi.call("attn_decode_bf16", y0, q0, K0, V0, scratch, C.c_size_t(nbytes), 1, NH, NKV, HS, cap, pos + 1, window, 1.0)
+    # one launch
+    K1, V1, y1 = Kc0.clone(), Vc0.clone(), empty_u16(NH * HS)
+    capi.call("fused_attn_decode_bf16", y1, K1, V1, _d(q), _d(k), _d(v), qw, kw, None, cos, sin, scratch, C.c_size_t(nbytes), NH, NKV, HS,
+              cap, pos, None, window, 1.0, 1e-6)
+    assert np.array_equal(bits(K1), bits(K0)) and np.array_equal(bits(V1), bits(V0)), "cache rows differ"
+    assert np.array_equal(bits(y1), bits(y0)), "attention output differs"
+    # graph-replay form: position from device memory
+    K2, V2, y2 = Kc0.clone(), Vc0.clone(), empty_u16(NH * HS)
+    pd = torch.tensor([pos], dtype=torch.int32, device="cuda")
+    capi.call("fused_attn_decode_bf16", y2, K2, V2, _d(q), _d(k), _d(v), qw, kw, None, cos, sin, scratch, C.c_size_t(nbytes), NH, NKV, HS,
+              cap, 0, pd, window, 1.0, 1e-6)
+    assert np.array_equal(bits(y2), bits(y0)) and np.array_equal(bits(K2), bits(K0))
+    del hist
