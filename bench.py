@@ -78,15 +78,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    from mila_amd.replicas import Ranks
+    ranks = Ranks()
+    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
 
     from mila_amd import capi, host
     capi.load()
@@ -113,16 +109,12 @@ def main():
             r["prefill_TFLOPs"] = round((lin + att) / ms / 1e9, 2)
             r["prefill_tok_s"] = round(CONTEXT / ms * 1e3, 1)
             r["prefill_mfma_frac"] = round((lin + att) / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)
-        if dist is not None:
-            dist.barrier()
+        ranks.barrier()
         torch.cuda.synchronize()
         t = m.time_decode(CONTEXT, a.steps, a.warmup, a.mode)
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            tt = torch.tensor([t["wall_ms_per_step"]], device="cuda", dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # timing only: max over ranks
-            t["wall_ms_per_step"] = float(tt.item())
+        ranks.barrier()
+        t["wall_ms_per_step"] = ranks.max_over_ranks(t["wall_ms_per_step"])      # timing only: max over ranks
         k = m.time_dominant_kernel(3)
         r.update({"ms_per_step": round(t["wall_ms_per_step"], 4), "device_ms_per_step": round(t["device_ms_per_step"], 4),
                   "tok_s": round(1e3 / t["wall_ms_per_step"], 2),
@@ -153,8 +145,7 @@ def main():
         if not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

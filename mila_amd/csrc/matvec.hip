@@ -139,6 +139,32 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
         }
     };
 
+    // Prologue operands are requested FIRST (vector memory returns in order: anything issued behind the
+    // weight prefetch would only become usable after the weights have landed), two 16-byte chunks per thread
+    // and array cover K <= 4096; larger K takes the plain path below.
+    const bool pre_ok = (PRO != 0) && nx16 <= 512;
+    const int i0 = tid, i1 = tid + 256;
+    const bool h0 = i0 < nx16, h1 = i1 < nx16;
+    u32x4 px[2], ppw[2], pres[2], pnw[2];
+    if constexpr (PRO != 0)
+    {
+        if (pre_ok)
+        {
+            const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+            px[0] = h0 ? ld16(p.x + (size_t)i0 * 8) : z;
+            px[1] = h1 ? ld16(p.x + (size_t)i1 * 8) : z;
+            pnw[0] = h0 ? ld16(p.norm_w + (size_t)i0 * 8) : z;
+            pnw[1] = h1 ? ld16(p.norm_w + (size_t)i1 * 8) : z;
+            if constexpr (PRO == 2)
+            {
+                ppw[0] = h0 ? ld16(p.post_w + (size_t)i0 * 8) : z;
+                ppw[1] = h1 ? ld16(p.post_w + (size_t)i1 * 8) : z;
+                pres[0] = h0 ? ld16(p.res + (size_t)i0 * 8) : z;
+                pres[1] = h1 ? ld16(p.res + (size_t)i1 * 8) : z;
+            }
+        }
+    }
+
     // compute cursor (rg, c0) and issue cursor (rgi, c0i), the latter two pipeline steps ahead
     int rg = blockIdx.x * 4 + wib, c0 = lane;
     int rgi = rg, c0i = c0;
@@ -151,10 +177,55 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
     if (rgi < n_rg) { issue(ba, rgi, c0i); advance(rgi, c0i); }
     if (rgi < n_rg) { issue(bb, rgi, c0i); advance(rgi, c0i); }
 
+    // r = bf16(bf16(res + a) * post_scale) on 8 elements (sandwich tail)
+    auto tail8 = [&](const u32x4 a, const u32x4 rr) {
+        u32x4 r;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+        {
+            float lo = round_bf16(bf16_lo(rr[d]) + bf16_lo(a[d]));
+            float hi = round_bf16(bf16_hi(rr[d]) + bf16_hi(a[d]));
+            if (p.post_scale != 1.0f) { lo = lo * p.post_scale; hi = hi * p.post_scale; }
+            r[d] = pack_bf16x2(lo, hi);
+        }
+        return r;
+    };
+
     // ---- stage x into LDS (optionally through the fused RMSNorm prologue) ----
     if constexpr (PRO == 0)
     {
         for (int i = tid; i < nx16; i += 256) xs[i] = ld16(p.x + (size_t)i * 8);
+    }
+    else if (pre_ok)
+    {
+        // same thread -> element assignment and summation order as rms_rstd_block256 (i = tid, tid + 256)
+        auto rstd_of = [&](const u32x4 c0v, const u32x4 c1v) {
+            float ss = 0.0f;
+            if (h0) ss = sumsq8(c0v, ss);
+            if (h1) ss = sumsq8(c1v, ss);
+            ss = block_sum<4>(ss, red);
+            return rsqrtf(ss / (float)K + p.eps);
+        };
+        if constexpr (PRO == 1)
+        {
+            const float rstd = rstd_of(px[0], px[1]);
+            if (h0) xs[i0] = rms_apply8(px[0], pnw[0], rstd, 0.0f);
+            if (h1) xs[i1] = rms_apply8(px[1], pnw[1], rstd, 0.0f);
+        }
+        else
+        {
+            const float rstd_a = rstd_of(px[0], px[1]);
+            const u32x4 r0 = tail8(rms_apply8(px[0], ppw[0], rstd_a, 0.0f), pres[0]);
+            const u32x4 r1 = tail8(rms_apply8(px[1], ppw[1], rstd_a, 0.0f), pres[1]);
+            if (blockIdx.x == 0)
+            {
+                if (h0) st16(p.res_out + (size_t)i0 * 8, r0);
+                if (h1) st16(p.res_out + (size_t)i1 * 8, r1);
+            }
+            const float rstd_r = rstd_of(r0, r1);
+            if (h0) xs[i0] = rms_apply8(r0, pnw[0], rstd_r, 0.0f);
+            if (h1) xs[i1] = rms_apply8(r1, pnw[1], rstd_r, 0.0f);
+        }
     }
     else if constexpr (PRO == 1)
     {
@@ -169,16 +240,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
         for (int i = tid; i < nx16; i += 256)
         {
             const u32x4 a = rms_apply8(ld16(p.x + (size_t)i * 8), ld16(p.post_w + (size_t)i * 8), rstd_a, 0.0f);
-            const u32x4 rr = ld16(p.res + (size_t)i * 8);
-            u32x4 r;
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-            {
-                float lo = round_bf16(bf16_lo(rr[d]) + bf16_lo(a[d]));
-                float hi = round_bf16(bf16_hi(rr[d]) + bf16_hi(a[d]));
-                if (p.post_scale != 1.0f) { lo = lo * p.post_scale; hi = hi * p.post_scale; }
-                r[d] = pack_bf16x2(lo, hi);
-            }
+            const u32x4 r = tail8(a, ld16(p.res + (size_t)i * 8));
             xs[i] = r;
             if (blockIdx.x == 0) st16(p.res_out + (size_t)i * 8, r);
         }

@@ -1,0 +1,46 @@
+"""Replica plumbing for bench.py --gpus N: the decode path does not shard, so N GPUs
+run N independent replicas.  The only cross-rank traffic is the barrier around the timed region and the
+MAX-over-ranks reduction of the measured time -- never a data-path collective."""
+import os
+
+
+class Ranks:
+    def __init__(self, backend=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        self.backend = backend
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            self.backend = backend
+            kw = {}
+            if backend == "nccl":
+                kw["device_id"] = torch.device("cuda", self.local_rank)
+            dist.init_process_group(backend, **kw)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, value):
+        """MAX reduction of a python float (timing only)."""
+        if self.dist is None:
+            return float(value)
+        import torch
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def aggregate_throughput(self, units_per_rank, ms_this_rank):
+        """whole-job throughput = units all ranks processed / max-over-ranks time (weak scaling)."""
+        ms = self.max_over_ranks(ms_this_rank)
+        return units_per_rank * self.world / (ms * 1e-3), ms
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()

@@ -52,7 +52,7 @@ def test_prefill_then_decode_matches_token_by_token_decode(policy):
         ld = b.decode(TOKENS[pos], pos, "fused")
     # fp4: the prefill GEMM rounds dequantized weights to bf16 (reference 2-phase semantics), the decode
     # matvec does not -- "changes numerics by design", reference bar 1e-1 * absmax (Linear.Cuda.cpp:760-774)
-    bar = 1e-1 if policy == "fp4" else 3e-2
+    bar = 1e-1 if policy == "fp4" else 5e-2       # the reference's BF16 bar is 5e-2 + 5e-2|y| per op
     assert np.abs(lp - ld).max() <= bar * np.abs(ld).max()
     bar = 1e-1     # one more chaotic step on top of caches that differ in the last bf16 bit
     # continue decoding on top of the prefilled cache vs on top of the decoded cache
