@@ -67,6 +67,20 @@ def cpu_baseline(cfg):
             "GFLOPs": round(2 * (m_loc + m_glb + m_head) / (t_loc + t_glb + t_head) / 1e9, 3)}
 
 
+def measured_traffic(policy):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, produced by
+    tools/summarize_pmc.py with the gfx950 FETCH_SIZE correction); None when no pass exists for this policy."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % policy)
+    if not os.path.exists(path):
+        return None, None
+    fmt = {"bf16": 0, "fp8": 1, "fp4": 2}[policy]
+    want = "matvec_kernel<%d, 1, 2, 2, true, false>" % fmt
+    for k in json.load(open(path))["kernels"]:
+        if want in k["kernel"]:
+            return k["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,7 +149,8 @@ def main():
         "config": {"workload": "Gemma-4 12B, weight policy %s, B=1, prefill T=2048 then decode at positions 2048.." % policies[0],
                    "decode_mode": a.mode, "replicas": world, "parallelism": "replicas only (no collective)"},
         "roofline": {"bound": "hbm", "achieved": head["dominant_kernel"]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(head["dominant_kernel"]["GBps"] / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "frac": round(head["dominant_kernel"]["GBps"] / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(policies[0])[0],
+                     "traffic_source": measured_traffic(policies[0])[1],
                      "kernel": head["dominant_kernel"]["name"], "avg_us": head["dominant_kernel"]["avg_us"],
                      "algorithmic_bytes_per_launch": head["dominant_kernel"]["bytes"],
                      "whole_token_frac": head["token_roofline_frac"]},

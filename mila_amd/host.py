@@ -73,7 +73,8 @@ class Gemma:
         self.vocab = self.cfg["vocab_size"]
         self.h = lib.mila_gemma_create(POLICIES[policy], C.byref(c), max_seq, max_prefill, seed)
         if not self.h:
-            raise RuntimeError("mila_gemma_create: " + lib.mila_host_last_error().decode())
+            text = lib.mila_host_last_error().decode()
+            raise (ValueError if text.startswith("invalid_argument") else RuntimeError)("mila_gemma_create: " + text)
 
     def close(self):
         if self.h:

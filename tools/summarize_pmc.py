@@ -1,0 +1,37 @@
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as the TCC slots require) into the per-launch
+HBM traffic of each kernel, corrected as /opt/skills/guides/MI355X_MICROARCH.md section HBM prescribes for gfx950:
+    bytes = 2 * FETCH_SIZE * 1024   (FETCH_SIZE counts 128-B requests at 64 B for wide coalesced streams)
+          +     WRITE_SIZE * 1024
+usage: python tools/summarize_pmc.py <fetch_dir> <write_dir> <out.json> [label]"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_kernel(d, counter):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    g = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            g[(r["Kernel_Name"], r["Grid_Size"])].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in g.items()}
+
+
+def main():
+    fd, wd, out = sys.argv[1:4]
+    label = sys.argv[4] if len(sys.argv) > 4 else ""
+    fetch, write = per_kernel(fd, "FETCH_SIZE"), per_kernel(wd, "WRITE_SIZE")
+    res = []
+    for k, (fv, n) in sorted(fetch.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+        wv = write.get(k, (0.0, 0))[0]
+        res.append({"kernel": k[0], "grid_threads": int(k[1]), "launches": n, "FETCH_SIZE_KB_avg": round(fv, 2),
+                    "WRITE_SIZE_KB_avg": round(wv, 2), "hbm_bytes_per_launch": round(2 * fv * 1024 + wv * 1024)})
+    json.dump({"label": label, "correction": "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950, MI355X_MICROARCH.md HBM section)",
+               "kernels": res[:24]}, open(out, "w"), indent=1)
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    main()
