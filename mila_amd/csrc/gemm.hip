@@ -20,6 +20,7 @@
 // remapped so that the workgroups sharing an XCD (id % 8) walk neighbouring tiles and share
 // their W / X panels in that XCD's L2.
 #include "common.h"
+#include "internal.h"
 
 namespace mila {
 
@@ -263,6 +264,10 @@ static int launch_gemm(GemmParams p, hipStream_t s)
     MILA_LAUNCH_CHECK("gemm");
 }
 
+bool gemm256_applicable(int M, int K, int N);
+int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s);
+static int g_gemm_force128 = 0;
+
 static int validate_gemm(const char* who, const void* Y, const void* X, const void* W, int M, int K, int N)
 {
     MILA_REQUIRE(Y && X && W, "%s: null pointer", who);
@@ -277,11 +282,18 @@ using namespace mila;
 
 extern "C" {
 
+int mila_cdna4_tune_gemm(int force_128_tile)
+{
+    g_gemm_force128 = force_128_tile;
+    return MILA_OK;
+}
+
 int mila_cdna4_gemm_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N,
                          mila_stream_t stream)
 {
     int rc = validate_gemm("gemm_bf16", Y, X, W, M, K, N);
     if (rc) return rc;
+    if (!g_gemm_force128 && gemm256_applicable(M, K, N)) return launch_gemm256(Y, X, W, bias, M, K, N, as_stream(stream));
     GemmParams p{Y, X, reinterpret_cast<const uint8_t*>(W), nullptr, bias, M, K, N, 0, 0, 0};
     return launch_gemm<G_BF16>(p, as_stream(stream));
 }

@@ -1,0 +1,204 @@
+// bf16 GEMM, 256 x 256 x 64 tile, direct-to-LDS staging with a counted-vmcnt pipeline.
+//   Y[M,N] = X[M,K] * W[N,K]^T (+ bias), M % 256 == 0, N % 256 == 0, K % 64 == 0 (the Gemma prefill shapes);
+// other shapes and the quantized weight formats take gemm.hip's 128 x 128 register-staged kernel.
+//
+// Structure (re-derived from the MI355X guide's description of an 8-wave, 4-phase-per-K-tile schedule):
+//   * 512 threads = 8 waves as 2 (P = W rows, the MFMA "M" side) x 4 (Q = X rows, the MFMA "N" side); the
+//     product is computed transposed (A operand = W, B operand = X) so a lane's 4 accumulator registers are 4
+//     consecutive output columns n -> 8-byte stores.
+//   * LDS: 2 K-tile buffers x {W half 0, W half 1, X half 0, X half 1} x 16 KB = 128 KB.  A half-tile is
+//     128 rows x 64 bf16, written by 16 wave-level global_load_lds_dwordx4 (1 KiB each, lane-linear); the
+//     XOR swizzle (16-byte slot ^= (row >> 1) & 7) is applied to the SOURCE address and to the fragment read.
+//   * every wave's 128 x 64 output is 2 x 2 quadrants of 64 x 32 taken from (W half hA, X half hB), so phase
+//     (hA, hB) touches exactly two half-tiles; the quadrant order (0,0) (0,1) (1,1) (1,0) frees W0 after phase
+//     1, X1 after phase 2, W1 and X0 after phase 3, and each phase issues the refill of one freed slot two
+//     K-tiles ahead:   ph0: X0(t+1)  ph1: W1(t+1)  ph2: W0(t+2)  ph3: X1(t+2).
+//     Every half-tile is requested >= 4 phases before its first use; three half-tiles (6 wave-instructions)
+//     stay in flight across every barrier: s_waitcnt vmcnt(6) + one raw s_barrier per phase, never vmcnt(0) in
+//     the steady state.  A staged slot is read one phase after the wait + barrier that retires it.
+//   * fragments: ds_read_b128, 12 / 4 / 8 / 4 per phase (the W or X fragments of the previous phase are reused).
+#include "common.h"
+
+namespace mila {
+
+struct Gemm256Params
+{
+    uint16_t* Y;
+    const uint16_t* X;
+    const uint16_t* W;
+    const uint16_t* bias;
+    int M, K, N, tiles_m, tiles_n;
+};
+
+constexpr int kHalfBytes = 128 * 128;          // 128 rows x 64 bf16
+constexpr int kBufBytes = 4 * kHalfBytes;      // W0 W1 X0 X1
+
+__device__ __forceinline__ int half_off(bool isX, int half) { return (isX ? 2 * kHalfBytes : 0) + half * kHalfBytes; }
+
+__global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int xcd = id & 7, qd = nwg >> 3, rem = nwg & 7;
+    const int tile = ((xcd < rem) ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (id >> 3);
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int K = p.K, nk = K / 64;
+
+    // ---- staging: half-tile (isX, half) of K-tile kt into buffer kt & 1 ----
+    const int srow = lane >> 3, sslot = lane & 7;          // this lane's row within a 1 KiB chunk / 16-byte slot
+    auto stage = [&](int kt, bool isX, int half) {
+        const uint16_t* base = isX ? p.X + (size_t)(m0 + half * 128) * K : p.W + (size_t)(n0 + half * 128) * K;
+        unsigned char* dst_half = smem + (kt & 1) * kBufBytes + half_off(isX, half);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+        {
+            const int chunk = i * 8 + wave;                // 16 chunks of 8 rows
+            const int row = chunk * 8 + srow;              // row within the half-tile
+            const int kslot = sslot ^ ((row >> 1) & 7);    // swizzle on the source address
+            const uint16_t* src = base + (size_t)row * K + (size_t)kt * 64 + kslot * 8;
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(dst_half + chunk * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    s16x8 fa[4][2], fb[2][2];
+    auto load_a = [&](int kt, int hA) {
+        const unsigned char* hb = smem + (kt & 1) * kBufBytes + half_off(false, hA);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+        {
+            const int r = wr * 64 + pt * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                fa[pt][ks] = *reinterpret_cast<const s16x8*>(hb + r * 128 + (((ks * 4 + g) ^ ((r >> 1) & 7)) << 4));
+        }
+    };
+    auto load_b = [&](int kt, int hB) {
+        const unsigned char* hb = smem + (kt & 1) * kBufBytes + half_off(true, hB);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+        {
+            const int r = wc * 32 + qt * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                fb[qt][ks] = *reinterpret_cast<const s16x8*>(hb + r * 128 + (((ks * 4 + g) ^ ((r >> 1) & 7)) << 4));
+        }
+    };
+    auto mma = [&](int hA, int hB) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    acc[hA][hB][pt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fa[pt][ks]), __builtin_bit_cast(bf16x8, fb[qt][ks]), acc[hA][hB][pt][qt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // end of a phase: retire everything but the 3 youngest half-tiles, then let every wave see it
+    auto phase_end = [&](bool steady) {
+        if (steady) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // ---- prologue: K-tile 0 complete, W0 / X1 of K-tile 1 in flight ----
+    stage(0, false, 0); stage(0, true, 0); stage(0, true, 1); stage(0, false, 1);
+    if (nk > 1) { stage(1, false, 0); stage(1, true, 1); }
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int t = 0; t < nk; ++t)
+    {
+        const bool steady = t + 2 < nk;                    // the full issue sequence is still running
+        // ph0: quadrant (0,0)
+        if (t + 1 < nk) stage(t + 1, true, 0);
+        load_b(t, 0);
+        load_a(t, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 0);
+        phase_end(steady);
+        // ph1: quadrant (0,1)
+        if (t + 1 < nk) stage(t + 1, false, 1);
+        load_b(t, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 1);
+        phase_end(steady);
+        // ph2: quadrant (1,1)
+        if (t + 2 < nk) stage(t + 2, false, 0);
+        load_a(t, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 1);
+        phase_end(steady);
+        // ph3: quadrant (1,0)
+        if (t + 2 < nk) stage(t + 2, true, 1);
+        load_b(t, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 0);
+        phase_end(steady);
+    }
+
+    // ---- epilogue: D[p = 4 g + r][q = l15] -> Y[m0 + q][n0 + p] ----
+#pragma unroll
+    for (int hA = 0; hA < 2; ++hA)
+#pragma unroll
+        for (int hB = 0; hB < 2; ++hB)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                {
+                    const int n = n0 + hA * 128 + wr * 64 + pt * 16 + 4 * g;
+                    const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[hA][hB][pt][qt][e];
+                    if (p.bias)
+                    {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
+                    }
+                    *reinterpret_cast<u32x2*>(p.Y + (size_t)m * p.N + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                }
+}
+
+bool gemm256_applicable(int M, int K, int N) { return M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && (M / 256) * (N / 256) >= 200; }
+
+int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set)
+    {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               2 * kBufBytes), "hipFuncSetAttribute(gemm256)");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, N / 256};
+    hipLaunchKernelGGL(gemm256_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), 2 * kBufBytes, s, p);
+    MILA_LAUNCH_CHECK("gemm256");
+}
+
+}  // namespace mila

@@ -9,6 +9,8 @@ extern "C" {
 /* override the matvec launch heuristics (0 = default): rows per wave, chunk positions in flight,
  * maximum workgroups */
 MILA_API int mila_cdna4_tune_matvec(int R, int U, int max_blocks);
+/* 1 = always use the 128 x 128 register-staged GEMM (A/B against the 256 x 256 direct-to-LDS kernel) */
+MILA_API int mila_cdna4_tune_gemm(int force_128_tile);
 /* decode all 256 byte values with the hardware converts used by the kernels:
  * out_fp8[256] floats; out_fp4[512] floats (byte b -> [2b] low nibble, [2b+1] high nibble),
  * each for the 4 byte positions of a dword: out_fp4 has 4*512 floats, out_fp8 4*256. */

@@ -322,3 +322,39 @@ def test_invalid_arguments_are_reported_not_launched():
         capi.call("matvec_bf16", None, y, y, None, 8, 8)
     with pytest.raises(capi.InvalidArgument):
         capi.call("quantize_fp4_per_group", y, y, y, 2, 100, 128)
+
+
+@pytest.mark.parametrize("M,K,N,bias", [(2048, 128, 8192, False), (512, 3840, 30720, True), (256, 64, 51200, False)])
+def test_gemm_256_tile_kernel_agrees_with_the_128_tile_kernel(M, K, N, bias):
+    """shapes with >= 200 tiles of 256 x 256 take the direct-to-LDS 8-wave kernel; same products, fp32
+    accumulation in a different order -> equal to the register-staged kernel within 1 bf16 ulp, and to the
+    float64 oracle on sampled rows"""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    X = (torch.rand((M, K), device="cuda", generator=g) * 2 - 1).to(torch.bfloat16)
+    W = ((torch.rand((N, K), device="cuda", generator=g) * 2 - 1) / K ** 0.5).to(torch.bfloat16)
+    b = ((torch.rand((N,), device="cuda", generator=g) - 0.5) * 0.2).to(torch.bfloat16) if bias else None
+    Xi, Wi = X.view(torch.int16), W.view(torch.int16)
+    bi = b.view(torch.int16) if bias else None
+    lib = capi.load()
+    Y256, Y128 = empty_u16(M, N), empty_u16(M, N)
+    capi.call("gemm_bf16", Y256, Xi, Wi, bi, M, K, N)
+    try:
+        lib.mila_cdna4_tune_gemm(1)
+        capi.call("gemm_bf16", Y128, Xi, Wi, bi, M, K, N)
+    finally:
+        lib.mila_cdna4_tune_gemm(0)
+    a = bits(Y256).astype(np.int32)
+    c = bits(Y128).astype(np.int32)
+    oa = np.where(a & 0x8000, -(a & 0x7fff), a)
+    oc = np.where(c & 0x8000, -(c & 0x7fff), c)
+    fa, fc = orc.from_bf16_bits(bits(Y256)), orc.from_bf16_bits(bits(Y128))
+    ok = (np.abs(oa - oc) <= 1) | (np.abs(fa - fc) <= 2e-3)
+    assert ok.all(), int((~ok).sum())
+    rows = [0, 1, 127, 128, 255, M - 1, M // 2 + 3]
+    Xh = orc.from_bf16_bits(X[rows].view(torch.int16).cpu().numpy().view(np.uint16))
+    Wb = W.view(torch.int16).cpu().numpy().view(np.uint16)
+    exp = orc.linear_bf16w(Xh, Wb, None)
+    if bias:
+        bb = b.view(torch.int16).cpu().numpy().view(np.uint16)
+        exp = orc.round_bf16(exp).astype(np.float64) + orc.from_bf16_bits(bb).astype(np.float64)
+    assert_bf16_close(bits(Y256)[rows], exp, 2 if bias else 1, 2e-3, "gemm256 vs oracle")
