@@ -184,7 +184,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 }
 }
 
-bool gemm256_applicable(int M, int K, int N) { return M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && (M / 256) * (N / 256) >= 200; }
+// one 512-thread workgroup per CU: worth it only when the tile count fills whole rounds of 256 CUs
+bool gemm256_applicable(int M, int K, int N)
+{
+    if (M % 256 != 0 || N % 256 != 0 || K % 64 != 0) return false;
+    const int tiles = (M / 256) * (N / 256);
+    const int rounds = (tiles + kNumCU - 1) / kNumCU;
+    return tiles >= 200 && tiles >= 0.85 * rounds * kNumCU;
+}
 
 int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
 {

@@ -112,8 +112,10 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
     const int total_waves = gridDim.x * 4;
     const int n_rg = (N + R - 1) / R;
 
-    // issue the loads of one pipeline step: row-group rg, chunk positions c0 + 64u
-    auto issue = [&](WBuf<FMT, U, NR>& b, int rg, int c0) {
+    // issue the loads of one pipeline step: row-group rg, chunk positions cb + lane + 64u
+    // (cb is the wave-uniform chunk base: every lane of a wave walks the same (rg, cb) sequence)
+    auto issue = [&](WBuf<FMT, U, NR>& b, int rg, int cb) {
+        const int c0 = cb + lane;
 #pragma unroll
         for (int j = 0; j < NR; ++j)
         {
@@ -166,11 +168,11 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
     }
 
     // compute cursor (rg, c0) and issue cursor (rgi, c0i), the latter two pipeline steps ahead
-    int rg = blockIdx.x * 4 + wib, c0 = lane;
+    int rg = blockIdx.x * 4 + wib, c0 = 0;
     int rgi = rg, c0i = c0;
     auto advance = [&](int& r_, int& c_) {
         c_ += 64 * U;
-        if (c_ >= nchunks) { r_ += total_waves; c_ = lane; }
+        if (c_ >= nchunks) { r_ += total_waves; c_ = 0; }
     };
     WBuf<FMT, U, NR> ba, bb;
     // PREFETCH: two steps in flight during the prologue
@@ -256,11 +258,11 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
 #pragma unroll
     for (int j = 0; j < NR; ++j) acc[j] = 0.0f;
 
-    auto compute = [&](const WBuf<FMT, U, NR>& b, int c0_) {
+    auto compute = [&](const WBuf<FMT, U, NR>& b, int cb_) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
         {
-            const int c = min(c0_ + 64 * u, nchunks - 1);
+            const int c = min(cb_ + lane + 64 * u, nchunks - 1);
 #pragma unroll
             for (int j = 0; j < NR; ++j)
             {
