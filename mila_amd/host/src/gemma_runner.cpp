@@ -108,6 +108,7 @@ HOST_API int mila_gemma_prefill( void* h, const int32_t* host_tokens, int64_t T,
     auto* r = static_cast<Runner*>( h );
     return guarded( [&]
     {
+        if ( T <= 0 || T > r->max_prefill ) throw std::invalid_argument( "GemmaTransformer::prefill: chunk length out of range" );
         upload_tokens( r, host_tokens, T );
         std::visit( [&]( auto& m ) { m->prefill( *r->tokens, T, position_offset ); m->context()->synchronize(); }, r->model );
         download_logits( r, host_logits );
