@@ -106,6 +106,18 @@ MILA_API int mila_cdna4_gemm_bf16_w4a16(uint16_t* Y, const uint16_t* X, const ui
                                         const float* scales, const uint16_t* bias, int M, int K,
                                         int N, int group, mila_stream_t stream);
 
+/* 2-phase forms for quantized weights (the reference's own structure, Linear/CudaLinearOp.ixx:597-644, :716-764:
+ * dequantize to a bf16 scratch, then the bf16 GEMM).  Chosen automatically when the 256 x 256 LDS-DMA GEMM
+ * applies to (M,K,N) -- gemm_staging_bytes() says how much scratch that needs (0 = the register-dequantizing kernel is
+ * used and no scratch is touched).  Same arithmetic as the fused forms: w = bf16(decode(q) * scale), fp32 accumulate. */
+MILA_API size_t mila_cdna4_gemm_staging_bytes(int M, int K, int N);
+MILA_API int mila_cdna4_gemm_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W, const float* scales,
+                                               const uint16_t* bias, int M, int K, int N, void* scratch,
+                                               size_t scratch_bytes, mila_stream_t stream);
+MILA_API int mila_cdna4_gemm_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed,
+                                               const float* scales, const uint16_t* bias, int M, int K, int N,
+                                               int group, void* scratch, size_t scratch_bytes, mila_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Linear -- quantize-on-load.  Integer outputs are bit-exact with the reference kernels.
  * replaces cuda_quantize_fp8_per_channel (Linear/Kernels/Quantization/CudaFp8WeightQuantization.cu:

@@ -268,6 +268,57 @@ bool gemm256_applicable(int M, int K, int N);
 int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s);
 static int g_gemm_force128 = 0;
 
+// ---- 2-phase staging (the reference's own prefill structure for quantized weights,
+// OPS/Linear/CudaLinearOp.ixx:597-644, :716-764): dequantize the whole matrix to bf16 scratch, then the bf16 GEMM.
+// Used when the 256 x 256 direct-to-LDS kernel applies: it reads its tiles with LDS-DMA and cannot dequantize.
+// w = bf16(float(e4m3) * scale[n])   (Fp8Prefill/CudaFp8Prefill.cu:64-84)
+__global__ __launch_bounds__(256) void dequant_fp8_kernel(uint16_t* __restrict__ out, const uint8_t* __restrict__ W,
+                                                          const float* __restrict__ scales, int64_t total_vec, int vec_per_row)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += stride)
+    {
+        const float sc = scales[i / vec_per_row];
+        const u32x4 w = ld16_nt(W + i * 16);
+        u32x4 lo, hi;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+        {
+            const f32x2 a = fp8x2_to_f32x2(w[d], false), b = fp8x2_to_f32x2(w[d], true);
+            lo[2 * d] = pack_bf16x2(a[0] * sc, a[1] * sc);
+            lo[2 * d + 1] = pack_bf16x2(b[0] * sc, b[1] * sc);
+            const f32x2 c = fp8x2_to_f32x2(w[d + 2], false), e = fp8x2_to_f32x2(w[d + 2], true);
+            hi[2 * d] = pack_bf16x2(c[0] * sc, c[1] * sc);
+            hi[2 * d + 1] = pack_bf16x2(e[0] * sc, e[1] * sc);
+        }
+        st16(out + i * 16, lo);
+        st16(out + i * 16 + 8, hi);
+    }
+}
+// w = bf16(lut[nibble] * scale[n, k / G])   (W4A16Gemm/CudaW4A16Gemm.cu:210-235); one 16-byte load = 32 elements
+__global__ __launch_bounds__(256) void dequant_fp4_kernel(uint16_t* __restrict__ out, const uint8_t* __restrict__ W,
+                                                          const float* __restrict__ scales, int64_t total_vec, int vec_per_group)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += stride)
+    {
+        const float sc = scales[i / vec_per_group];        // scales are [N, K/G] row-major == flat group index
+        const u32x4 w = ld16_nt(W + i * 16);
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+        {
+            const bf16x2 v0 = fp4x2_to_bf16x2<0>(w[d]), v1 = fp4x2_to_bf16x2<1>(w[d]), v2 = fp4x2_to_bf16x2<2>(w[d]),
+                         v3 = fp4x2_to_bf16x2<3>(w[d]);
+            u32x4 o;
+            o[0] = pack_bf16x2((float)v0[0] * sc, (float)v0[1] * sc);
+            o[1] = pack_bf16x2((float)v1[0] * sc, (float)v1[1] * sc);
+            o[2] = pack_bf16x2((float)v2[0] * sc, (float)v2[1] * sc);
+            o[3] = pack_bf16x2((float)v3[0] * sc, (float)v3[1] * sc);
+            st16(out + i * 32 + d * 8, o);
+        }
+    }
+}
+
 static int validate_gemm(const char* who, const void* Y, const void* X, const void* W, int M, int K, int N)
 {
     MILA_REQUIRE(Y && X && W, "%s: null pointer", who);
@@ -318,6 +369,50 @@ int mila_cdna4_gemm_bf16_w4a16(uint16_t* Y, const uint16_t* X, const uint8_t* W_
     MILA_REQUIRE(K % group == 0, "gemm_bf16_w4a16: K=%d must be a multiple of the group size %d", K, group);
     GemmParams p{Y, X, W_packed, scales, bias, M, K, N, group, 0, 0};
     return launch_gemm<G_FP4>(p, as_stream(stream));
+}
+
+size_t mila_cdna4_gemm_staging_bytes(int M, int K, int N)
+{
+    return (!g_gemm_force128 && gemm256_applicable(M, K, N)) ? (size_t)N * K * 2 : 0;
+}
+
+int mila_cdna4_gemm_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W, const float* scales, const uint16_t* bias,
+                                      int M, int K, int N, void* scratch, size_t scratch_bytes, mila_stream_t stream)
+{
+    const size_t need = mila_cdna4_gemm_staging_bytes(M, K, N);
+    if (need == 0) return mila_cdna4_gemm_bf16_w8a16(Y, X, W, scales, bias, M, K, N, stream);
+    int rc = validate_gemm("gemm_bf16_w8a16_staged", Y, X, W, M, K, N);
+    if (rc) return rc;
+    MILA_REQUIRE(scales != nullptr, "gemm_bf16_w8a16_staged: per-channel scales are required");
+    if (!scratch || scratch_bytes < need)
+        return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_bf16_w8a16_staged: scratch %zu bytes < required %zu", scratch_bytes, need);
+    const int64_t total_vec = (int64_t)N * K / 16;
+    hipLaunchKernelGGL(dequant_fp8_kernel, dim3(2048), dim3(256), 0, as_stream(stream), reinterpret_cast<uint16_t*>(scratch), W, scales,
+                       total_vec, K / 16);
+    rc = check_hip(hipGetLastError(), "dequant_fp8");
+    if (rc) return rc;
+    return launch_gemm256(Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream));
+}
+
+int mila_cdna4_gemm_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed, const float* scales,
+                                      const uint16_t* bias, int M, int K, int N, int group, void* scratch, size_t scratch_bytes,
+                                      mila_stream_t stream)
+{
+    const size_t need = mila_cdna4_gemm_staging_bytes(M, K, N);
+    if (need == 0) return mila_cdna4_gemm_bf16_w4a16(Y, X, W_packed, scales, bias, M, K, N, group, stream);
+    int rc = validate_gemm("gemm_bf16_w4a16_staged", Y, X, W_packed, M, K, N);
+    if (rc) return rc;
+    MILA_REQUIRE(scales != nullptr, "gemm_bf16_w4a16_staged: per-group scales are required");
+    MILA_REQUIRE(group == 64 || group == 128, "gemm_bf16_w4a16_staged: group size must be 64 or 128 (got %d)", group);
+    MILA_REQUIRE(K % group == 0, "gemm_bf16_w4a16_staged: K=%d must be a multiple of the group size %d", K, group);
+    if (!scratch || scratch_bytes < need)
+        return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_bf16_w4a16_staged: scratch %zu bytes < required %zu", scratch_bytes, need);
+    const int64_t total_vec = (int64_t)N * K / 32;
+    hipLaunchKernelGGL(dequant_fp4_kernel, dim3(2048), dim3(256), 0, as_stream(stream), reinterpret_cast<uint16_t*>(scratch), W_packed,
+                       scales, total_vec, group / 32);
+    rc = check_hip(hipGetLastError(), "dequant_fp4");
+    if (rc) return rc;
+    return launch_gemm256(Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream));
 }
 
 }  // extern "C"

@@ -122,8 +122,15 @@ namespace Mila::Dnn::Compute
             else
             {
                 if constexpr ( kFmt == 0 ) rocmCheck( mila_cdna4_gemm_bf16( y, x, static_cast<const uint16_t*>( weight_ ), bias_, M, K, N, st ) );
-                else if constexpr ( kFmt == 1 ) rocmCheck( mila_cdna4_gemm_bf16_w8a16( y, x, static_cast<const uint8_t*>( weight_ ), scales_, bias_, M, K, N, st ) );
-                else rocmCheck( mila_cdna4_gemm_bf16_w4a16( y, x, static_cast<const uint8_t*>( weight_ ), scales_, bias_, M, K, N, kGroup, st ) );
+                else
+                {
+                    // 2-phase staging through context scratch when the LDS-DMA GEMM applies; scratch is fetched per
+                    // forward and never cached (reference rule, CudaLinearOp.ixx:603-614)
+                    const size_t need = mila_cdna4_gemm_staging_bytes( M, K, N );
+                    void* scratch = need ? this->context_->getScratch( need ) : nullptr;
+                    if constexpr ( kFmt == 1 ) rocmCheck( mila_cdna4_gemm_bf16_w8a16_staged( y, x, static_cast<const uint8_t*>( weight_ ), scales_, bias_, M, K, N, scratch, need, st ) );
+                    else rocmCheck( mila_cdna4_gemm_bf16_w4a16_staged( y, x, static_cast<const uint8_t*>( weight_ ), scales_, bias_, M, K, N, kGroup, scratch, need, st ) );
+                }
             }
         }
 

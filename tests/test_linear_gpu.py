@@ -358,3 +358,38 @@ def test_gemm_256_tile_kernel_agrees_with_the_128_tile_kernel(M, K, N, bias):
         bb = b.view(torch.int16).cpu().numpy().view(np.uint16)
         exp = orc.round_bf16(exp).astype(np.float64) + orc.from_bf16_bits(bb).astype(np.float64)
     assert_bf16_close(bits(Y256)[rows], exp, 2 if bias else 1, 2e-3, "gemm256 vs oracle")
+
+
+@pytest.mark.parametrize("M,K,N", [(2048, 128, 8192), (512, 256, 30720)])
+def test_staged_quantized_gemm_equals_register_dequantizing_gemm(M, K, N):
+    """2-phase (dequantize to scratch + LDS-DMA GEMM) vs the fused 128-tile kernel: both multiply the same
+    bf16-rounded weights; within 1 bf16 ulp of each other (summation order differs)"""
+    rng = np.random.default_rng(N)
+    Wb = _weights(rng, N, K, "random")
+    X = orc.round_bf16(rng.uniform(-1, 1, (M, K)).astype(np.float32))
+    Xd = dev_u16(orc.to_bf16_bits(X))
+    need = capi.load().mila_cdna4_gemm_staging_bytes(M, K, N)
+    assert need == N * K * 2
+    scratch = torch.empty(need, dtype=torch.uint8, device="cuda")
+    for fmt in (1, 2):
+        if fmt == 1:
+            q, s = orc.quantize_fp8_per_channel(Wb)
+            Wdq = orc.to_bf16_bits(orc.dequant_fp8(q, s))
+        else:
+            q, s = orc.quantize_fp4_per_group(Wb, 128)
+            Wdq = orc.to_bf16_bits(orc.dequant_fp4(q, s, 128))
+        Ys, Yf = empty_u16(M, N), empty_u16(M, N)
+        if fmt == 1:
+            capi.call("gemm_bf16_w8a16_staged", Ys, Xd, dev_u8(q), dev_f32(s), None, M, K, N, scratch, C.c_size_t(need))
+            capi.call("gemm_bf16_w8a16", Yf, Xd, dev_u8(q), dev_f32(s), None, M, K, N)
+        else:
+            capi.call("gemm_bf16_w4a16_staged", Ys, Xd, dev_u8(q), dev_f32(s), None, M, K, N, 128, scratch, C.c_size_t(need))
+            capi.call("gemm_bf16_w4a16", Yf, Xd, dev_u8(q), dev_f32(s), None, M, K, N, 128)
+        # the staged weights are exactly the oracle's dequantized, bf16-rounded weights
+        assert np.array_equal(scratch.view(torch.int16).cpu().numpy().view(np.uint16).reshape(N, K), Wdq)
+        fa, fb = orc.from_bf16_bits(bits(Ys)), orc.from_bf16_bits(bits(Yf))
+        assert np.abs(fa - fb).max() <= 2 ** -7 * max(1.0, np.abs(fb).max())
+        rows = [0, 200, M - 1]
+        assert_bf16_close(bits(Ys)[rows], orc.linear_bf16w(X[rows], Wdq), 1, 2e-3, "staged gemm vs oracle")
+    with pytest.raises(capi.MilaError):
+        capi.call("gemm_bf16_w8a16_staged", Ys, Xd, dev_u8(q), dev_f32(s[:, 0].copy() if s.ndim > 1 else s), None, M, K, N, scratch, C.c_size_t(16))
