@@ -228,6 +228,17 @@ MILA_API int mila_cdna4_convert_f32_to_bf16(uint16_t* Y, const float* X, int64_t
 MILA_API int mila_cdna4_convert_bf16_to_f32(float* Y, const uint16_t* X, int64_t n, mila_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Greedy device sampler: token_out[0] = argmax(logits), ties to the lowest index.
+ * replaces Sampling/Kernels/Sampling.cuh: cuda_sample_argmax_fp32 / _bf16 (Sampling.cu:23-75).  The token stays on
+ * the device and feeds the next step's embedding gather (the reference's "decode-ahead", Models/GemmaModel.ixx:497-537).
+ * ------------------------------------------------------------------------------------------- */
+MILA_API size_t mila_cdna4_sample_scratch_bytes(void);
+MILA_API int mila_cdna4_sample_argmax_fp32(const float* logits, int32_t* token_out, int vocab, void* scratch,
+                                           size_t scratch_bytes, mila_stream_t stream);
+MILA_API int mila_cdna4_sample_argmax_bf16(const uint16_t* logits, int32_t* token_out, int vocab, void* scratch,
+                                           size_t scratch_bytes, mila_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused decode-step kernels (GemmaBlock::decode,
  * Components/Transformers/Gemma/Gemma.Block.ixx:287-356, as a fused schedule).  Each computes
  * exactly what the listed chain of unfused ops computes, including every intermediate bf16 rounding,

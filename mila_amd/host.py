@@ -42,6 +42,7 @@ def load():
         _lib.mila_gemma_time_dominant_kernel.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _lib.mila_gemma_time_prefill.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         _lib.mila_gemma_info.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        _lib.mila_gemma_generate.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         _lib.mila_gpt_last_error.restype = C.c_char_p
         _lib.mila_gpt_create.restype = C.c_void_p
         _lib.mila_gpt_create.argtypes = [C.c_int64] * 7
@@ -96,6 +97,12 @@ class Gemma:
     def decode(self, token, position, mode="fused"):
         out = np.empty(self.vocab, dtype=np.float32)
         _check(load().mila_gemma_decode(self.h, int(token), int(position), self.MODES[mode], out.ctypes.data))
+        return out
+
+    def generate(self, first_token, start_position, n_tokens, mode="graph"):
+        """greedy autoregressive generation with the device sampler; returns the sampled token ids"""
+        out = np.empty(n_tokens, dtype=np.int32)
+        _check(load().mila_gemma_generate(self.h, int(first_token), int(start_position), int(n_tokens), self.MODES[mode], out.ctypes.data))
         return out
 
     def time_decode(self, start_position, steps, warmup, mode="graph"):

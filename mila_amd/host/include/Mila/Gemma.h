@@ -175,12 +175,19 @@ namespace Mila::Dnn
             (void)ctx_->getScratch( attnScratchBytes() );   // grow before capture: no allocation inside
             ctx_->synchronize();
             hipCheck( hipStreamBeginCapture( s, hipStreamCaptureModeThreadLocal ), "hipStreamBeginCapture" );
-            try { enqueueFusedStep( token.data(), 0, pos_dev_->data() ); }
+            try
+            {
+                enqueueFusedStep( token.data(), 0, pos_dev_->data() );
+                if ( sample_in_graph_ ) sampleGreedy( const_cast<TokenTensor&>( token ) );   // feeds the next replay
+            }
             catch ( ... ) { hipGraph_t g; (void)hipStreamEndCapture( s, &g ); throw; }
             Compute::rocmCheck( mila_cdna4_advance_position( pos_dev_->data(), ctx_->getStream() ) );
             hipCheck( hipStreamEndCapture( s, &graph_ ), "hipStreamEndCapture" );
             hipCheck( hipGraphInstantiate( &graph_exec_, graph_, nullptr, nullptr, 0 ), "hipGraphInstantiate" );
         }
+        /// when set before captureGraph(), every replay ends with the greedy sampler writing the next token
+        /// into the token buffer the graph reads from: a closed autoregressive loop with no host round trip
+        void setSampleInGraph( bool on ) { sample_in_graph_ = on; }
         void setDevicePosition( dim_t position )
         {
             checkPosition( position, 1 );
@@ -194,6 +201,14 @@ namespace Mila::Dnn
             hipCheck( hipGraphLaunch( graph_exec_, reinterpret_cast<hipStream_t>( ctx_->getStream() ) ), "hipGraphLaunch" );
         }
         LogitsTensor& logits() { return *logits_; }
+
+        /// greedy device sampler: token <- argmax(logits); the token never leaves the device
+        /// (GemmaModel::enqueueSampleNext, Models/GemmaModel.ixx:568)
+        void sampleGreedy( TokenTensor& token_out )
+        {
+            Compute::rocmCheck( mila_cdna4_sample_argmax_fp32( logits_->data(), token_out.data(), (int)cfg_.vocab_size, sample_scratch_->data(),
+                                                               sample_scratch_->sizeInBytes(), ctx_->getStream() ) );
+        }
 
         // ------------------------------------------------------------------------------------
         // prefill: whole prompt as one chunk (288 GB: no 12 GB-card chunking);
@@ -317,6 +332,7 @@ namespace Mila::Dnn
             f_act_ = std::make_unique<TensorType>( dev, shape_t{ cfg_.hidden_dim } );
             logits_ = std::make_unique<LogitsTensor>( dev, shape_t{ 1, 1, cfg_.vocab_size } );
             pos_dev_ = std::make_unique<TokenTensor>( dev, shape_t{ 1 } );
+            sample_scratch_ = std::make_unique<LogitsTensor>( dev, shape_t{ static_cast<dim_t>( mila_cdna4_sample_scratch_bytes() / 4 ) } );
             err_flag_ = std::make_unique<TokenTensor>( dev, shape_t{ 1 } );
             Compute::rocmCheck( mila_cdna4_memset_zero( err_flag_->data(), 4, ctx_->getStream() ) );
             ctx_->synchronize();
@@ -525,6 +541,8 @@ namespace Mila::Dnn
         std::unique_ptr<TensorType> hidden_[ 3 ], pf_x_[ 2 ], q_, k_, v_, attn_out_, res1_, res2_, geglu_, f_qkv_, f_q_, f_o_, f_down_, f_act_;
         std::unique_ptr<LogitsTensor> logits_;
         std::unique_ptr<TokenTensor> pos_dev_, err_flag_;
+        std::unique_ptr<LogitsTensor> sample_scratch_;
+        bool sample_in_graph_{ false };
         const uint16_t* cur_hidden_{ nullptr };
         hipGraph_t graph_{ nullptr };
         hipGraphExec_t graph_exec_{ nullptr };

@@ -153,12 +153,14 @@ HOST_API int mila_gemma_time_decode( void* h, int64_t start_position, int steps,
         {
             auto* ctx = m->context();
             hipStream_t s = reinterpret_cast<hipStream_t>( ctx->getStream() );
+            // every step ends with the greedy device sampler writing the next token: a real autoregressive loop
+            m->setSampleInGraph( true );
             if ( mode == 2 && !r->graph_captured ) { m->captureGraph( *r->tokens, start_position ); r->graph_captured = true; }
             if ( mode == 2 ) m->setDevicePosition( start_position );
             auto step = [&]( int64_t pos )
             {
-                if ( mode == 0 ) m->decode( *r->tokens, pos );
-                else if ( mode == 1 ) m->decodeFused( *r->tokens, pos );
+                if ( mode == 0 ) { m->decode( *r->tokens, pos ); m->sampleGreedy( *r->tokens ); }
+                else if ( mode == 1 ) { m->decodeFused( *r->tokens, pos ); m->sampleGreedy( *r->tokens ); }
                 else m->replayGraph();
             };
             int64_t pos = start_position;
@@ -239,6 +241,33 @@ HOST_API int mila_gemma_time_prefill( void* h, int64_t T, int reps, double* out_
             hipCheck( hipEventElapsedTime( &ms, e0, e1 ), "hipEventElapsedTime" );
             (void)hipEventDestroy( e0 ); (void)hipEventDestroy( e1 );
             *out_ms = static_cast<double>( ms ) / reps;
+        }, r->model );
+    } );
+}
+
+/// greedy generation: feeds `first_token` at `start_position`, then n_tokens - 1 more steps, each consuming the
+/// token the device sampler produced; returns the sampled ids (host) -- mode as in mila_gemma_decode
+HOST_API int mila_gemma_generate( void* h, int32_t first_token, int64_t start_position, int n_tokens, int mode, int32_t* host_out )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&]
+    {
+        upload_tokens( r, &first_token, 1 );
+        std::visit( [&]( auto& m )
+        {
+            auto* ctx = m->context();
+            m->setSampleInGraph( true );
+            if ( mode == 2 && !r->graph_captured ) { m->captureGraph( *r->tokens, start_position ); r->graph_captured = true; }
+            if ( mode == 2 ) m->setDevicePosition( start_position );
+            for ( int i = 0; i < n_tokens; ++i )
+            {
+                const int64_t pos = start_position + i;
+                if ( mode == 0 ) { m->decode( *r->tokens, pos ); m->sampleGreedy( *r->tokens ); }
+                else if ( mode == 1 ) { m->decodeFused( *r->tokens, pos ); m->sampleGreedy( *r->tokens ); }
+                else m->replayGraph();
+                Compute::rocmCheck( mila_cdna4_memcpy_d2h( host_out + i, r->tokens->data(), 4, ctx->getStream() ) );
+                ctx->synchronize();
+            }
         }, r->model );
     } );
 }

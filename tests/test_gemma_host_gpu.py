@@ -76,3 +76,22 @@ def test_host_mirror_error_behaviour():
     with pytest.raises(ValueError):
         g.prefill(list(range(5)))                                         # chunk longer than max_prefill
     g.close()
+
+
+@pytest.mark.parametrize("policy", ["bf16", "fp4"])
+def test_greedy_generation_is_identical_across_paths_and_follows_the_logits(policy):
+    """closed autoregressive loop (device sampler feeds the next embedding gather): reference-order, fused and
+    graph replay produce the same token ids; each id is the argmax of that step's logits"""
+    ids = {}
+    for mode in ("reference", "fused", "graph"):
+        g = host.Gemma(policy, SMALL, max_seq=MAX_SEQ, max_prefill=1, seed=11)
+        ids[mode] = g.generate(5, 0, 20, mode)
+        g.close()
+    assert np.array_equal(ids["reference"], ids["fused"]) and np.array_equal(ids["reference"], ids["graph"])
+    g = host.Gemma(policy, SMALL, max_seq=MAX_SEQ, max_prefill=1, seed=11)
+    tok = 5
+    for pos in range(6):
+        nxt = int(np.argmax(g.decode(tok, pos, "fused")))
+        assert nxt == int(ids["fused"][pos])
+        tok = nxt
+    g.close()

@@ -206,3 +206,21 @@ def test_dpp_wave_reductions_match_the_crossbar_butterfly():
             assert o[0] == x.astype(np.float64).sum() and np.all(o[128:] == o[0])
         else:
             assert abs(o[0] - x.astype(np.float64).sum()) < 1e-4 and abs(o[128] - o[0]) < 1e-4
+
+
+@pytest.mark.parametrize("V", [1, 7, 1000, 50257, 262144])
+def test_greedy_sampler_argmax_ties_to_lowest_index(V):
+    """integer output => bit-exact; reference semantics: OPS/Sampling/Kernels/Sampling.cu:23-75"""
+    import torch
+    rng = np.random.default_rng(V)
+    x = rng.standard_normal(V).astype(np.float32)
+    if V > 10:
+        x[[V // 3, V // 2, V - 1]] = x.max() + 1.0        # three-way tie: the lowest index must win
+    nb = capi.load().mila_cdna4_sample_scratch_bytes()
+    scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    tok = dev_i32(np.array([-1]))
+    capi.call("sample_argmax_fp32", dev_f32(x), tok, V, scratch, C.c_size_t(nb))
+    assert int(host(tok)[0]) == int(np.argmax(x))
+    xb = orc.to_bf16_bits(x)
+    capi.call("sample_argmax_bf16", dev_u16(xb), tok, V, scratch, C.c_size_t(nb))
+    assert int(host(tok)[0]) == int(np.argmax(orc.from_bf16_bits(xb)))
