@@ -80,11 +80,19 @@ struct MatvecParams
 
 // PRO: 0 = x as is; 1 = x <- rmsnorm(x; norm_w); 2 = sandwich tail (see mila_cdna4.h)
 // ROWS = R output columns per wave; with GEGLU each column reads two weight rows (n, N + n).
+// XC   = 16-byte x chunks each thread preloads (256 * 8 * XC >= K): 2 covers K <= 4096, 8 covers K <= 16384.
 //
-// The weight stream is software-pipelined per wave over the flattened (row-group, chunk-position)
-// space with two named register buffers: the loads of step i+1 are in flight while step i is
-// multiplied, and the FIRST step's loads are issued before the x staging / RMSNorm prologue, so the
-// prologue's latency chain (loads -> block reductions -> barriers) overlaps the first HBM round trip.
+// The kernel is written so that the compiler's own s_waitcnt accounting stays COUNTED (vmcnt(n), n > 0):
+//   * there is no load under divergent control flow -- out-of-range rows / chunk positions are clamped to a
+//     valid address (x is zero-padded in LDS up to the last chunk position, so a clamped chunk contributes 0)
+//     and per-row scalars (fp8 channel scale, bias) come through the scalar cache (s_load, lgkmcnt);
+//   * x and the prologue operands are requested FIRST, into registers (vector memory returns in order:
+//     anything issued behind the weight prefetch only becomes usable after the weights have landed), then
+//     two pipeline steps of weights; the prologue's latency chain (reductions, barriers) runs under that
+//     first HBM round trip;
+//   * the weight stream is software-pipelined per wave over the flattened (row-group, chunk-position) space
+//     with two named register buffers and a straight-line steady-state loop: consume step t, refill the same
+//     buffer with step t + 2; the last <= 3 steps are peeled so the loop body needs no validity test.
 template <int FMT, int U, int NR>
 struct WBuf
 {
@@ -92,92 +100,84 @@ struct WBuf
     float sc[U][NR];
 };
 
-template <int FMT, int R, int U, int PRO, bool GEGLU, bool F32OUT>
+// uniform 32-bit load through the scalar cache (read-only data: scales, bias)
+__device__ __forceinline__ uint32_t sload32(const void* p_uniform)
+{
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p_uniform) : "memory");
+    return v;
+}
+
+template <int FMT, int R, int U, int PRO, bool GEGLU, bool F32OUT, int XC>
 __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
     __shared__ float red[8];
 
-    const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = p.K, N = p.N;
     const int nx16 = K / 8;   // 16-byte units of x
 
     constexpr int EPC = Fmt<FMT>::kElemsPerChunk;
+    constexpr int XPC = EPC / 8;                       // 16-byte x units per weight chunk
     constexpr int NR = GEGLU ? 2 * R : R;              // weight rows per wave step
     const int nchunks = K / EPC;                       // 16-byte chunks per weight row
     const size_t row_bytes = (size_t)nchunks * 16;
+    const int S = (nchunks + 64 * U - 1) / (64 * U);   // pipeline steps per row-group
+    const int nx16_pad = S * 64 * U * XPC;             // x units covered by the chunk positions of S steps
     const int ngroups = (FMT == FMT_FP4) ? K / p.group : 0;
-    const int chunks_per_group = (FMT == FMT_FP4) ? p.group / EPC : 1;
+    const int cpg_shift = (FMT == FMT_FP4) ? (p.group == 128 ? 2 : 1) : 0;   // chunks per group = group / 32
     const int total_waves = gridDim.x * 4;
     const int n_rg = (N + R - 1) / R;
+    const int wave_g = blockIdx.x * 4 + wib;
+    const int nrg_w = wave_g < n_rg ? (n_rg - 1 - wave_g) / total_waves + 1 : 0;
+    const int T = nrg_w * S;                           // pipeline steps of this wave
 
-    // issue the loads of one pipeline step: row-group rg, chunk positions cb + lane + 64u
-    // (cb is the wave-uniform chunk base: every lane of a wave walks the same (rg, cb) sequence)
-    auto issue = [&](WBuf<FMT, U, NR>& b, int rg, int cb) {
-        const int c0 = cb + lane;
+    // ---- x / prologue operands first ----
+    u32x4 px[XC], pnw[PRO != 0 ? XC : 1], ppw[PRO == 2 ? XC : 1], pres[PRO == 2 ? XC : 1];
 #pragma unroll
-        for (int j = 0; j < NR; ++j)
-        {
-            const int col = rg * R + (GEGLU ? (j >> 1) : j);
-            const bool valid = col < N;
-            const int row = (GEGLU && (j & 1)) ? (N + col) : col;
-            const uint8_t* wrow = p.W + (size_t)(valid ? row : 0) * row_bytes;
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-            {
-                const int c = c0 + 64 * u;
-                if (valid && c < nchunks)
-                {
-                    b.w[u][j] = ld16_nt(wrow + (size_t)c * 16);
-                    if constexpr (FMT == FMT_FP4) b.sc[u][j] = p.scales[(size_t)row * ngroups + c / chunks_per_group];
-                }
-                else
-                {
-                    b.w[u][j] = u32x4{0u, 0u, 0u, 0u};
-                    if constexpr (FMT == FMT_FP4) b.sc[u][j] = 0.0f;
-                }
-            }
-        }
-    };
-
-    // Prologue operands are requested FIRST (vector memory returns in order: anything issued behind the
-    // weight prefetch would only become usable after the weights have landed), two 16-byte chunks per thread
-    // and array cover K <= 4096; larger K takes the plain path below.
-    const bool pre_ok = (PRO != 0) && nx16 <= 512;
-    const int i0 = tid, i1 = tid + 256;
-    const bool h0 = i0 < nx16, h1 = i1 < nx16;
-    u32x4 px[2], ppw[2], pres[2], pnw[2];
-    if constexpr (PRO != 0)
+    for (int k = 0; k < XC; ++k)
     {
-        if (pre_ok)
+        const size_t e = (size_t)min(tid + 256 * k, nx16 - 1) * 8;
+        px[k] = ld16(p.x + e);
+        if constexpr (PRO != 0) pnw[k] = ld16(p.norm_w + e);
+        if constexpr (PRO == 2)
         {
-            const u32x4 z = u32x4{0u, 0u, 0u, 0u};
-            px[0] = h0 ? ld16(p.x + (size_t)i0 * 8) : z;
-            px[1] = h1 ? ld16(p.x + (size_t)i1 * 8) : z;
-            pnw[0] = h0 ? ld16(p.norm_w + (size_t)i0 * 8) : z;
-            pnw[1] = h1 ? ld16(p.norm_w + (size_t)i1 * 8) : z;
-            if constexpr (PRO == 2)
-            {
-                ppw[0] = h0 ? ld16(p.post_w + (size_t)i0 * 8) : z;
-                ppw[1] = h1 ? ld16(p.post_w + (size_t)i1 * 8) : z;
-                pres[0] = h0 ? ld16(p.res + (size_t)i0 * 8) : z;
-                pres[1] = h1 ? ld16(p.res + (size_t)i1 * 8) : z;
-            }
+            ppw[k] = ld16(p.post_w + e);
+            pres[k] = ld16(p.res + e);
         }
     }
 
-    // compute cursor (rg, c0) and issue cursor (rgi, c0i), the latter two pipeline steps ahead
-    int rg = blockIdx.x * 4 + wib, c0 = 0;
-    int rgi = rg, c0i = c0;
-    auto advance = [&](int& r_, int& c_) {
-        c_ += 64 * U;
-        if (c_ >= nchunks) { r_ += total_waves; c_ = 0; }
+    // issue the loads of one pipeline step: row-group rg, step s (chunk positions 64 U s + lane + 64 u)
+    auto issue = [&](WBuf<FMT, U, NR>& b, int rg, int s) {
+        const int c0 = s * (64 * U) + lane;
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+        {
+            const int col = min(rg * R + (GEGLU ? (j >> 1) : j), N - 1);
+            const int row = (GEGLU && (j & 1)) ? (N + col) : col;
+            const uint8_t* wrow = p.W + (size_t)row * row_bytes;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                const int c = min(c0 + 64 * u, nchunks - 1);
+                b.w[u][j] = ld16_nt(wrow + (size_t)c * 16);
+                if constexpr (FMT == FMT_FP4) b.sc[u][j] = p.scales[(size_t)row * ngroups + (c >> cpg_shift)];
+            }
+        }
+    };
+    // wave-uniform cursors over (row-group, step): `ci` issues, two steps ahead of `cc`, which computes
+    int ci_rg = wave_g, ci_s = 0, cc_rg = wave_g, cc_s = 0;
+    auto advance = [&](int& rg_, int& s_) {
+        const bool wrap = (s_ + 1 == S);
+        s_ = wrap ? 0 : s_ + 1;
+        rg_ = wrap ? rg_ + total_waves : rg_;
     };
     WBuf<FMT, U, NR> ba, bb;
-    // PREFETCH: two steps in flight during the prologue
-    if (rgi < n_rg) { issue(ba, rgi, c0i); advance(rgi, c0i); }
-    if (rgi < n_rg) { issue(bb, rgi, c0i); advance(rgi, c0i); }
+    issue(ba, ci_rg, ci_s); advance(ci_rg, ci_s);
+    issue(bb, ci_rg, ci_s); advance(ci_rg, ci_s);
 
     // r = bf16(bf16(res + a) * post_scale) on 8 elements (sandwich tail)
     auto tail8 = [&](const u32x4 a, const u32x4 rr) {
@@ -193,64 +193,52 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
         return r;
     };
 
-    // ---- stage x into LDS (optionally through the fused RMSNorm prologue) ----
+    // ---- stage x into LDS (optionally through the fused RMSNorm prologue), zero-pad the tail ----
+    for (int i = nx16 + tid; i < nx16_pad; i += 256) xs[i] = u32x4{0u, 0u, 0u, 0u};
     if constexpr (PRO == 0)
     {
-        for (int i = tid; i < nx16; i += 256) xs[i] = ld16(p.x + (size_t)i * 8);
+#pragma unroll
+        for (int k = 0; k < XC; ++k)
+            if (tid + 256 * k < nx16) xs[tid + 256 * k] = px[k];
     }
-    else if (pre_ok)
+    else
     {
-        // same thread -> element assignment and summation order as rms_rstd_block256 (i = tid, tid + 256)
-        auto rstd_of = [&](const u32x4 c0v, const u32x4 c1v) {
+        // same thread -> element assignment and summation order as rms_rstd_block256 (i = tid, tid + 256, ..)
+        auto rstd_of = [&](const u32x4* v) {
             float ss = 0.0f;
-            if (h0) ss = sumsq8(c0v, ss);
-            if (h1) ss = sumsq8(c1v, ss);
+#pragma unroll
+            for (int k = 0; k < XC; ++k)
+            {
+                const float t = sumsq8(v[k], ss);
+                ss = (tid + 256 * k < nx16) ? t : ss;
+            }
             ss = block_sum<4>(ss, red);
             return rsqrtf(ss / (float)K + p.eps);
         };
         if constexpr (PRO == 1)
         {
-            const float rstd = rstd_of(px[0], px[1]);
-            if (h0) xs[i0] = rms_apply8(px[0], pnw[0], rstd, 0.0f);
-            if (h1) xs[i1] = rms_apply8(px[1], pnw[1], rstd, 0.0f);
+            const float rstd = rstd_of(px);
+#pragma unroll
+            for (int k = 0; k < XC; ++k)
+                if (tid + 256 * k < nx16) xs[tid + 256 * k] = rms_apply8(px[k], pnw[k], rstd, 0.0f);
         }
         else
         {
-            const float rstd_a = rstd_of(px[0], px[1]);
-            const u32x4 r0 = tail8(rms_apply8(px[0], ppw[0], rstd_a, 0.0f), pres[0]);
-            const u32x4 r1 = tail8(rms_apply8(px[1], ppw[1], rstd_a, 0.0f), pres[1]);
+            const float rstd_a = rstd_of(px);
+            u32x4 r[XC];
+#pragma unroll
+            for (int k = 0; k < XC; ++k) r[k] = tail8(rms_apply8(px[k], ppw[k], rstd_a, 0.0f), pres[k]);
             if (blockIdx.x == 0)
             {
-                if (h0) st16(p.res_out + (size_t)i0 * 8, r0);
-                if (h1) st16(p.res_out + (size_t)i1 * 8, r1);
+#pragma unroll
+                for (int k = 0; k < XC; ++k)
+                    if (tid + 256 * k < nx16) st16(p.res_out + (size_t)(tid + 256 * k) * 8, r[k]);
             }
-            const float rstd_r = rstd_of(r0, r1);
-            if (h0) xs[i0] = rms_apply8(r0, pnw[0], rstd_r, 0.0f);
-            if (h1) xs[i1] = rms_apply8(r1, pnw[1], rstd_r, 0.0f);
+            const float rstd_r = rstd_of(r);
+#pragma unroll
+            for (int k = 0; k < XC; ++k)
+                if (tid + 256 * k < nx16) xs[tid + 256 * k] = rms_apply8(r[k], pnw[k], rstd_r, 0.0f);
         }
-    }
-    else if constexpr (PRO == 1)
-    {
-        const float rstd = rms_rstd_block256(p.x, K, p.eps, red);
-        for (int i = tid; i < nx16; i += 256)
-            xs[i] = rms_apply8(ld16(p.x + (size_t)i * 8), ld16(p.norm_w + (size_t)i * 8), rstd, 0.0f);
-    }
-    else
-    {
-        // a = bf16(rmsnorm(x; post_w)); r = bf16(res + a); r = bf16(r * post_scale)
-        const float rstd_a = rms_rstd_block256(p.x, K, p.eps, red);
-        for (int i = tid; i < nx16; i += 256)
-        {
-            const u32x4 a = rms_apply8(ld16(p.x + (size_t)i * 8), ld16(p.post_w + (size_t)i * 8), rstd_a, 0.0f);
-            const u32x4 r = tail8(a, ld16(p.res + (size_t)i * 8));
-            xs[i] = r;
-            if (blockIdx.x == 0) st16(p.res_out + (size_t)i * 8, r);
-        }
-        __syncthreads();
-        // x' = bf16(rmsnorm(r; norm_w)) computed from the LDS copy of r
-        const float rstd_r = rms_rstd_block256_lds(xs, K, p.eps, red);
-        for (int i = tid; i < nx16; i += 256)
-            xs[i] = rms_apply8(xs[i], ld16(p.norm_w + (size_t)i * 8), rstd_r, 0.0f);
     }
     __syncthreads();
 
@@ -258,11 +246,11 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
 #pragma unroll
     for (int j = 0; j < NR; ++j) acc[j] = 0.0f;
 
-    auto compute = [&](const WBuf<FMT, U, NR>& b, int cb_) {
+    auto compute = [&](const WBuf<FMT, U, NR>& b, int s) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
         {
-            const int c = min(cb_ + lane + 64 * u, nchunks - 1);
+            const int c = s * (64 * U) + lane + 64 * u;    // < S * 64 * U: inside the zero-padded x
 #pragma unroll
             for (int j = 0; j < NR; ++j)
             {
@@ -278,19 +266,22 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
         const int col0 = rg_ * R;
 #pragma unroll
         for (int j = 0; j < NR; ++j) acc[j] = wave_sum(acc[j]);
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+        {
+            const int col = min(col0 + (GEGLU ? (j >> 1) : j), N - 1);
+            const int row = (GEGLU && (j & 1)) ? (N + col) : col;
+            float v = acc[j];
+            if constexpr (FMT == FMT_FP8) v = __builtin_bit_cast(float, sload32(p.scales + row)) * v;
+            if (p.bias)
+            {
+                const uint32_t pair = sload32(reinterpret_cast<const uint32_t*>(p.bias) + (row >> 1));
+                v += bf16_bits_to_f32((uint16_t)((row & 1) ? (pair >> 16) : (pair & 0xffffu)));
+            }
+            acc[j] = v;
+        }
         if (lane == 0)
         {
-#pragma unroll
-            for (int j = 0; j < NR; ++j)
-            {
-                const int col = col0 + (GEGLU ? (j >> 1) : j);
-                if (col >= N) continue;
-                const int row = (GEGLU && (j & 1)) ? (N + col) : col;
-                float v = acc[j];
-                if constexpr (FMT == FMT_FP8) v = p.scales[row] * v;
-                if (p.bias) v += bf16_bits_to_f32(p.bias[row]);
-                acc[j] = v;
-            }
 #pragma unroll
             for (int r = 0; r < R; ++r)
             {
@@ -313,39 +304,61 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
         for (int j = 0; j < NR; ++j) acc[j] = 0.0f;
     };
 
-    // one pipeline step: consume BUF (compute cursor), then refill it from the issue cursor, which
-    // runs two steps ahead -> up to two steps (2 * U * NR 16-byte loads per lane) in flight
-#define MILA_MATVEC_STEP(BUF)                                        \
-    {                                                                \
-        if (rg >= n_rg) break;                                       \
-        compute(BUF, c0);                                            \
-        const int rg_prev = rg;                                      \
-        advance(rg, c0);                                             \
-        if (rgi < n_rg) { issue(BUF, rgi, c0i); advance(rgi, c0i); } \
-        if (rg != rg_prev) finish(rg_prev);                          \
-    }
-    for (;;)
+    // consume one step from BUF; at the end of a row-group reduce and store it
+    auto consume = [&](const WBuf<FMT, U, NR>& b) {
+        compute(b, cc_s);
+        const int rg_prev = cc_rg;
+        advance(cc_rg, cc_s);
+        if (cc_rg != rg_prev) finish(rg_prev);
+    };
+
+    int t = 0;
+    for (; t + 4 <= T; t += 2)      // steps t + 2 and t + 3 exist: refill unconditionally
     {
-        MILA_MATVEC_STEP(ba)
-        MILA_MATVEC_STEP(bb)
+        consume(ba);
+        issue(ba, ci_rg, ci_s); advance(ci_rg, ci_s);
+        consume(bb);
+        issue(bb, ci_rg, ci_s); advance(ci_rg, ci_s);
     }
-#undef MILA_MATVEC_STEP
+    const int rem = T - t;          // 0 (idle wave), 1, 2 or 3
+    if (rem >= 1)
+    {
+        consume(ba);
+        if (rem == 3) issue(ba, ci_rg, ci_s);
+    }
+    if (rem >= 2) consume(bb);
+    if (rem == 3) consume(ba);
 }
 
 // ---- host side ------------------------------------------------------------------------------
 static int g_tune_R = 0, g_tune_U = 0, g_tune_blocks = 0;
 
-template <int FMT, int R, int U, int PRO, bool GEGLU, bool F32OUT>
-static int launch(const MatvecParams& p, hipStream_t s)
+template <int FMT, int R, int U, int PRO, bool GEGLU, bool F32OUT, int XC>
+static int launch_xc(const MatvecParams& p, hipStream_t s)
 {
     const int n_rg = (p.N + R - 1) / R;
-    const size_t lds = (size_t)p.K * 2;
+    constexpr int EPC = Fmt<FMT>::kElemsPerChunk;
+    const int nchunks = p.K / EPC;
+    const int S = (nchunks + 64 * U - 1) / (64 * U);
+    const size_t lds = (size_t)S * 64 * U * EPC * 2;
+    MILA_REQUIRE(lds <= 65536, "matvec: K=%d needs %zu bytes of LDS for x (limit 65536)", p.K, lds);
     int max_blocks = g_tune_blocks > 0 ? g_tune_blocks : kNumCU * 4;
     int blocks = (n_rg + 3) / 4;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((matvec_kernel<FMT, R, U, PRO, GEGLU, F32OUT>), dim3(blocks), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((matvec_kernel<FMT, R, U, PRO, GEGLU, F32OUT, XC>), dim3(blocks), dim3(256), lds, s, p);
     MILA_LAUNCH_CHECK("matvec");
+}
+
+template <int FMT, int R, int U, int PRO, bool GEGLU, bool F32OUT>
+static int launch(const MatvecParams& p, hipStream_t s)
+{
+    if (p.K <= 4096) return launch_xc<FMT, R, U, PRO, GEGLU, F32OUT, 2>(p, s);
+    if constexpr (PRO == 0)
+    {
+        if (p.K <= 16384) return launch_xc<FMT, R, U, PRO, GEGLU, F32OUT, 8>(p, s);
+    }
+    return set_error(MILA_E_INVALID_ARGUMENT, "matvec: K=%d exceeds the register-staged x limit (%d)", p.K, PRO == 0 ? 16384 : 4096);
 }
 
 template <int FMT, int PRO, bool GEGLU, bool F32OUT>
@@ -362,13 +375,8 @@ static int dispatch_RU(const MatvecParams& p, hipStream_t s)
     if (R == 1 && U == 2) return launch<FMT, 1, 2, PRO, GEGLU, F32OUT>(p, s);
     if (R == 1) return launch<FMT, 1, 4, PRO, GEGLU, F32OUT>(p, s);
     if (R == 2 && U == 1) return launch<FMT, 2, 1, PRO, GEGLU, F32OUT>(p, s);
-    if (R == 2 && U == 2) return launch<FMT, 2, 2, PRO, GEGLU, F32OUT>(p, s);
-    if (R == 2) return launch<FMT, 2, 4, PRO, GEGLU, F32OUT>(p, s);
-    if constexpr (!GEGLU)
-    {
-        if (U == 1) return launch<FMT, 4, 1, PRO, GEGLU, F32OUT>(p, s);
-        return launch<FMT, 4, 2, PRO, GEGLU, F32OUT>(p, s);
-    }
+    if (R == 2) return launch<FMT, 2, 2, PRO, GEGLU, F32OUT>(p, s);
+    if constexpr (!GEGLU) return launch<FMT, 4, 2, PRO, GEGLU, F32OUT>(p, s);
     return launch<FMT, 2, 2, PRO, GEGLU, F32OUT>(p, s);
 }
 
@@ -377,7 +385,7 @@ static int validate(const char* who, const void* y, const void* x, const void* W
 {
     MILA_REQUIRE(y && x && W, "%s: null pointer (y=%p x=%p W=%p)", who, y, x, W);
     MILA_REQUIRE(K > 0 && N > 0, "%s: K and N must be positive (K=%d N=%d)", who, K, N);
-    MILA_REQUIRE(K <= 32768, "%s: K=%d exceeds the 64 KB LDS staging limit (32768)", who, K);
+    MILA_REQUIRE(K <= 16384, "%s: K=%d exceeds the register-staged x limit (16384)", who, K);
     if (fmt == FMT_BF16) MILA_REQUIRE(K % 8 == 0, "%s: K=%d must be a multiple of 8 for bf16 weights", who, K);
     if (fmt == FMT_FP8)
     {
