@@ -5,8 +5,8 @@
 // per-channel, scale after the reduction) and :271-508 (fp4 per-group) -- re-derived for CDNA4:
 //   * HBM-bound: every weight byte is read exactly once with 16-byte non-temporal loads
 //     (1 KiB per wave-instruction), R rows x U chunk positions in flight per lane;
-//   * x (<= 64 KB) is staged once per workgroup in LDS and re-read with ds_read_b128, so the
-//     vector L1 only ever sees the weight stream;
+//   * x is staged once per workgroup (one 16-wave workgroup per CU) in LDS and re-read with ds_read_b128,
+//     so the vector L1 only ever sees the weight stream;
 //   * one wave owns R whole rows (no cross-wave reduction, no barrier in the streaming loop);
 //     the 64-lane reduction is a xor butterfly;
 //   * fp8 / fp4 are expanded to bf16 pairs by the gfx950 v_cvt_scalef32_pk_bf16_{fp8,fp4}
@@ -80,7 +80,9 @@ struct MatvecParams
 
 // PRO: 0 = x as is; 1 = x <- rmsnorm(x; norm_w); 2 = sandwich tail (see mila_cdna4.h)
 // ROWS = R output columns per wave; with GEGLU each column reads two weight rows (n, N + n).
-// XC   = 16-byte x chunks each thread preloads (256 * 8 * XC >= K): 2 covers K <= 4096, 8 covers K <= 16384.
+// XC   = 16-byte x chunks each thread preloads (1024 * 8 * XC >= K): 1 covers K <= 8192, 2 covers K <= 16384.
+// One 1024-thread workgroup (16 waves) per CU: x is staged (and the prologue computed) once per CU, so the
+// L2 -> LDS staging traffic is 256 * 2K bytes whatever the weight format.
 //
 // The kernel is written so that the compiler's own s_waitcnt accounting stays COUNTED (vmcnt(n), n > 0):
 //   * there is no load under divergent control flow -- out-of-range rows / chunk positions are clamped to a
@@ -93,6 +95,8 @@ struct MatvecParams
 //   * the weight stream is software-pipelined per wave over the flattened (row-group, chunk-position) space
 //     with two named register buffers and a straight-line steady-state loop: consume step t, refill the same
 //     buffer with step t + 2; the last <= 3 steps are peeled so the loop body needs no validity test.
+constexpr int kMatvecWaves = 16;   // 1024 threads
+
 template <int FMT, int U, int NR>
 struct WBuf
 {
@@ -109,11 +113,11 @@ __device__ __forceinline__ uint32_t sload32(const void* p_uniform)
 }
 
 template <int FMT, int R, int U, int PRO, bool GEGLU, bool F32OUT, int XC>
-__global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
+__global__ __launch_bounds__(1024) void matvec_kernel(const MatvecParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);
-    __shared__ float red[8];
+    __shared__ float red_a[16 * XC], red_b[16 * XC];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,9 +133,9 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
     const int nx16_pad = S * 64 * U * XPC;             // x units covered by the chunk positions of S steps
     const int ngroups = (FMT == FMT_FP4) ? K / p.group : 0;
     const int cpg_shift = (FMT == FMT_FP4) ? (p.group == 128 ? 2 : 1) : 0;   // chunks per group = group / 32
-    const int total_waves = gridDim.x * 4;
+    const int total_waves = gridDim.x * kMatvecWaves;
     const int n_rg = (N + R - 1) / R;
-    const int wave_g = blockIdx.x * 4 + wib;
+    const int wave_g = blockIdx.x * kMatvecWaves + wib;
     const int nrg_w = wave_g < n_rg ? (n_rg - 1 - wave_g) / total_waves + 1 : 0;
     const int T = nrg_w * S;                           // pipeline steps of this wave
 
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
 #pragma unroll
     for (int k = 0; k < XC; ++k)
     {
-        const size_t e = (size_t)min(tid + 256 * k, nx16 - 1) * 8;
+        const size_t e = (size_t)min(tid + 1024 * k, nx16 - 1) * 8;
         px[k] = ld16(p.x + e);
         if constexpr (PRO != 0) pnw[k] = ld16(p.norm_w + e);
         if constexpr (PRO == 2)
@@ -194,37 +198,40 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
     };
 
     // ---- stage x into LDS (optionally through the fused RMSNorm prologue), zero-pad the tail ----
-    for (int i = nx16 + tid; i < nx16_pad; i += 256) xs[i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = nx16 + tid; i < nx16_pad; i += 1024) xs[i] = u32x4{0u, 0u, 0u, 0u};
     if constexpr (PRO == 0)
     {
 #pragma unroll
         for (int k = 0; k < XC; ++k)
-            if (tid + 256 * k < nx16) xs[tid + 256 * k] = px[k];
+            if (tid + 1024 * k < nx16) xs[tid + 1024 * k] = px[k];
     }
     else
     {
-        // same thread -> element assignment and summation order as rms_rstd_block256 (i = tid, tid + 256, ..)
-        auto rstd_of = [&](const u32x4* v) {
-            float ss = 0.0f;
+        // the canonical order of rms_rstd_block (rms_common.h): chunk tid + 1024 k belongs to group wib + 16 k
+        const int G = (nx16 + 63) / 64;
+        auto rstd_of = [&](const u32x4* v, float* red) {
 #pragma unroll
             for (int k = 0; k < XC; ++k)
             {
-                const float t = sumsq8(v[k], ss);
-                ss = (tid + 256 * k < nx16) ? t : ss;
+                float s = (tid + 1024 * k < nx16) ? sumsq8(v[k], 0.0f) : 0.0f;
+                s = wave_sum(s);
+                if (lane == 0) red[wib + kMatvecWaves * k] = s;
             }
-            ss = block_sum<4>(ss, red);
-            return rsqrtf(ss / (float)K + p.eps);
+            __syncthreads();
+            float t = 0.0f;
+            for (int g = 0; g < G; ++g) t += red[g];
+            return rsqrtf(t / (float)K + p.eps);
         };
         if constexpr (PRO == 1)
         {
-            const float rstd = rstd_of(px);
+            const float rstd = rstd_of(px, red_a);
 #pragma unroll
             for (int k = 0; k < XC; ++k)
-                if (tid + 256 * k < nx16) xs[tid + 256 * k] = rms_apply8(px[k], pnw[k], rstd, 0.0f);
+                if (tid + 1024 * k < nx16) xs[tid + 1024 * k] = rms_apply8(px[k], pnw[k], rstd, 0.0f);
         }
         else
         {
-            const float rstd_a = rstd_of(px);
+            const float rstd_a = rstd_of(px, red_a);
             u32x4 r[XC];
 #pragma unroll
             for (int k = 0; k < XC; ++k) r[k] = tail8(rms_apply8(px[k], ppw[k], rstd_a, 0.0f), pres[k]);
@@ -232,12 +239,12 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
             {
 #pragma unroll
                 for (int k = 0; k < XC; ++k)
-                    if (tid + 256 * k < nx16) st16(p.res_out + (size_t)(tid + 256 * k) * 8, r[k]);
+                    if (tid + 1024 * k < nx16) st16(p.res_out + (size_t)(tid + 1024 * k) * 8, r[k]);
             }
-            const float rstd_r = rstd_of(r);
+            const float rstd_r = rstd_of(r, red_b);
 #pragma unroll
             for (int k = 0; k < XC; ++k)
-                if (tid + 256 * k < nx16) xs[tid + 256 * k] = rms_apply8(r[k], pnw[k], rstd_r, 0.0f);
+                if (tid + 1024 * k < nx16) xs[tid + 1024 * k] = rms_apply8(r[k], pnw[k], rstd_r, 0.0f);
         }
     }
     __syncthreads();
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const MatvecParams p)
 static int g_tune_R = 0, g_tune_U = 0, g_tune_blocks = 0;
 
 template <int FMT, int R, int U, int PRO, bool GEGLU, bool F32OUT, int XC>
-static int launch_xc(const MatvecParams& p, hipStream_t s)
+static int launch_xc(const MatvecParams& p, int max_blocks, hipStream_t s)
 {
     const int n_rg = (p.N + R - 1) / R;
     constexpr int EPC = Fmt<FMT>::kElemsPerChunk;
@@ -342,42 +349,47 @@ static int launch_xc(const MatvecParams& p, hipStream_t s)
     const int S = (nchunks + 64 * U - 1) / (64 * U);
     const size_t lds = (size_t)S * 64 * U * EPC * 2;
     MILA_REQUIRE(lds <= 65536, "matvec: K=%d needs %zu bytes of LDS for x (limit 65536)", p.K, lds);
-    int max_blocks = g_tune_blocks > 0 ? g_tune_blocks : kNumCU * 4;
-    int blocks = (n_rg + 3) / 4;
+    int blocks = (n_rg + kMatvecWaves - 1) / kMatvecWaves;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((matvec_kernel<FMT, R, U, PRO, GEGLU, F32OUT, XC>), dim3(blocks), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((matvec_kernel<FMT, R, U, PRO, GEGLU, F32OUT, XC>), dim3(blocks), dim3(64 * kMatvecWaves), lds, s, p);
     MILA_LAUNCH_CHECK("matvec");
 }
 
 template <int FMT, int R, int U, int PRO, bool GEGLU, bool F32OUT>
-static int launch(const MatvecParams& p, hipStream_t s)
+static int launch(const MatvecParams& p, int max_blocks, hipStream_t s)
 {
-    if (p.K <= 4096) return launch_xc<FMT, R, U, PRO, GEGLU, F32OUT, 2>(p, s);
-    if constexpr (PRO == 0)
-    {
-        if (p.K <= 16384) return launch_xc<FMT, R, U, PRO, GEGLU, F32OUT, 8>(p, s);
-    }
-    return set_error(MILA_E_INVALID_ARGUMENT, "matvec: K=%d exceeds the register-staged x limit (%d)", p.K, PRO == 0 ? 16384 : 4096);
+    if (p.K <= 8192) return launch_xc<FMT, R, U, PRO, GEGLU, F32OUT, 1>(p, max_blocks, s);
+    if (p.K <= 16384) return launch_xc<FMT, R, U, PRO, GEGLU, F32OUT, 2>(p, max_blocks, s);
+    return set_error(MILA_E_INVALID_ARGUMENT, "matvec: K=%d exceeds the register-staged x limit (16384)", p.K);
 }
 
 template <int FMT, int PRO, bool GEGLU, bool F32OUT>
 static int dispatch_RU(const MatvecParams& p, hipStream_t s)
 {
-    // rows in flight per wave: enough waves to fill 256 CUs first, then more rows per wave so the
-    // x re-reads from LDS amortise.  (tuned on MI355X)
-    int R = g_tune_R, U = g_tune_U;
+    // Launch shape (measured on MI355X with tools/bench_matvec.py): weight rows per wave step
+    // `rows_per_step` and chunk positions per step U by weight format and matrix height.  Small matrices want
+    // the most waves (1 row each) and, for bf16, the deepest per-wave stream; tall ones amortise the LDS x
+    // reads over more rows and take two workgroups per CU so the hardware balances the tail.
     const int rows = GEGLU ? 2 * p.N : p.N;
-    if (R == 0) R = GEGLU ? 1 : (rows >= 32768 ? 4 : (rows >= 8192 ? 2 : 1));
+    const bool tall = rows >= 16384, huge = rows >= 100000;
+    int rows_per_step, U;
+    if (FMT == FMT_BF16) { rows_per_step = tall ? 4 : 1; U = tall ? 2 : 4; }
+    else if (FMT == FMT_FP8) { rows_per_step = huge ? 4 : (tall ? 2 : 1); U = 2; }
+    else { rows_per_step = tall ? 2 : 1; U = huge ? 2 : 1; }
+    int R = GEGLU ? (rows_per_step >= 2 ? rows_per_step / 2 : 1) : rows_per_step;
+    int max_blocks = tall ? 2 * kNumCU : kNumCU;
+    if (g_tune_R > 0) R = g_tune_R;
+    if (g_tune_U > 0) U = g_tune_U;
+    if (g_tune_blocks > 0) max_blocks = g_tune_blocks;
     if (GEGLU && R > 2) R = 2;
-    if (U == 0) U = 2;
-    if (R == 1 && U == 1) return launch<FMT, 1, 1, PRO, GEGLU, F32OUT>(p, s);
-    if (R == 1 && U == 2) return launch<FMT, 1, 2, PRO, GEGLU, F32OUT>(p, s);
-    if (R == 1) return launch<FMT, 1, 4, PRO, GEGLU, F32OUT>(p, s);
-    if (R == 2 && U == 1) return launch<FMT, 2, 1, PRO, GEGLU, F32OUT>(p, s);
-    if (R == 2) return launch<FMT, 2, 2, PRO, GEGLU, F32OUT>(p, s);
-    if constexpr (!GEGLU) return launch<FMT, 4, 2, PRO, GEGLU, F32OUT>(p, s);
-    return launch<FMT, 2, 2, PRO, GEGLU, F32OUT>(p, s);
+    if (R == 1 && U == 1) return launch<FMT, 1, 1, PRO, GEGLU, F32OUT>(p, max_blocks, s);
+    if (R == 1 && U == 2) return launch<FMT, 1, 2, PRO, GEGLU, F32OUT>(p, max_blocks, s);
+    if (R == 1) return launch<FMT, 1, 4, PRO, GEGLU, F32OUT>(p, max_blocks, s);
+    if (R == 2 && U == 1) return launch<FMT, 2, 1, PRO, GEGLU, F32OUT>(p, max_blocks, s);
+    if (R == 2) return launch<FMT, 2, 2, PRO, GEGLU, F32OUT>(p, max_blocks, s);
+    if constexpr (!GEGLU) return launch<FMT, 4, 2, PRO, GEGLU, F32OUT>(p, max_blocks, s);
+    return launch<FMT, 2, 2, PRO, GEGLU, F32OUT>(p, max_blocks, s);
 }
 
 static int validate(const char* who, const void* y, const void* x, const void* W, const float* scales,

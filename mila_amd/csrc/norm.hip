@@ -11,17 +11,19 @@
 namespace mila {
 
 // ---- RMSNorm ----------------------------------------------------------------------------------
+constexpr int kRmsBlockMaxGroups = 256;   // rows up to 131072 elements through the workgroup-per-row kernel
+
 __global__ __launch_bounds__(256) void rmsnorm_block_kernel(uint16_t* __restrict__ Y, uint16_t* __restrict__ rstd_out,
                                                             const uint16_t* __restrict__ X,
                                                             const uint16_t* __restrict__ w,
                                                             const uint16_t* __restrict__ b, int dim, float eps,
                                                             float w_offset)
 {
-    __shared__ float red[4];
+    __shared__ float red[kRmsBlockMaxGroups];
     const size_t row = blockIdx.x;
     const uint16_t* x = X + row * dim;
     uint16_t* y = Y + row * dim;
-    const float rstd = rms_rstd_block256(x, dim, eps, red);
+    const float rstd = rms_rstd_block<4>(x, dim, eps, red);
     if (threadIdx.x == 0 && rstd_out) rstd_out[row] = f32_to_bf16_bits(rstd);
     for (int i = threadIdx.x; i < dim / 8; i += 256)
     {
@@ -166,7 +168,7 @@ int mila_cdna4_rmsnorm_bf16(uint16_t* Y, uint16_t* rstd, const uint16_t* X, cons
     hipStream_t s = as_stream(stream);
     if (inner == 1 && dim % 8 == 0)
     {
-        if (dim > 1024)
+        if (dim > 1024 && dim <= kRmsBlockMaxGroups * 512)
             hipLaunchKernelGGL(rmsnorm_block_kernel, dim3(outer), dim3(256), 0, s, Y, rstd, X, w, b, dim, eps, w_offset);
         else
             hipLaunchKernelGGL(rmsnorm_wave_kernel, dim3(ceil_div(outer, 4)), dim3(256), 0, s, Y, rstd, X, w, b, outer,

@@ -21,21 +21,27 @@ __device__ __forceinline__ float sumsq8(const u32x4 v, float acc)
     return acc;
 }
 
-// 256-thread workgroup, row contiguous in global memory, dim % 8 == 0.  `red`: >= 4 floats of LDS.
-__device__ __forceinline__ float rms_rstd_block256(const uint16_t* __restrict__ x, int dim, float eps, float* red)
+// Canonical sum of squares of a row handled by a whole workgroup (dim > 1024), independent of the workgroup
+// size: every 16-byte chunk (8 elements) is summed with an fma chain starting from 0; each group of 64
+// consecutive chunks is reduced by the wave butterfly; the group partials are added in ascending group order.
+// `red`: LDS, >= ceil(dim / 512) floats.  NW = waves in the workgroup.  Ends with the partials visible to
+// every thread (one barrier); the caller must not overwrite `red` before all waves have read it.
+template <int NW>
+__device__ __forceinline__ float rms_rstd_block(const uint16_t* __restrict__ x, int dim, float eps, float* red)
 {
-    float ss = 0.0f;
-    for (int i = threadIdx.x; i < dim / 8; i += 256) ss = sumsq8(ld16(x + (size_t)i * 8), ss);
-    ss = block_sum<4>(ss, red);
-    return rsqrtf(ss / (float)dim + eps);
-}
-// same, row already in LDS (16-byte units)
-__device__ __forceinline__ float rms_rstd_block256_lds(const u32x4* xs, int dim, float eps, float* red)
-{
-    float ss = 0.0f;
-    for (int i = threadIdx.x; i < dim / 8; i += 256) ss = sumsq8(xs[i], ss);
-    ss = block_sum<4>(ss, red);
-    return rsqrtf(ss / (float)dim + eps);
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int nx16 = dim / 8, G = (nx16 + 63) / 64;
+    for (int g = wib; g < G; g += NW)
+    {
+        const int c = 64 * g + lane;
+        float s = c < nx16 ? sumsq8(ld16(x + (size_t)c * 8), 0.0f) : 0.0f;
+        s = wave_sum(s);
+        if (lane == 0) red[g] = s;
+    }
+    __syncthreads();
+    float t = 0.0f;
+    for (int g = 0; g < G; ++g) t += red[g];
+    return rsqrtf(t / (float)dim + eps);
 }
 // one wave per row (dim <= 1024 rows: per-head q/k/v norms)
 __device__ __forceinline__ float rms_rstd_wave(const uint16_t* __restrict__ x, int dim, float eps)
