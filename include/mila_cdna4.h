@@ -265,6 +265,44 @@ typedef struct mila_fused_matvec_args {
 } mila_fused_matvec_args;
 MILA_API int mila_cdna4_fused_norm_matvec(const mila_fused_matvec_args* host_args, mila_stream_t stream);
 
+/* Decode chain: the four Linears between two attention calls of a Gemma decode step in ONE launch
+ * (Gemma.Block.ixx:287-356 from o_proj to the end of the block, plus the next block's input norm + qkv_proj,
+ * Gemma.Block.ixx:287-300, or the final norm + tied lm_head, Gemma.ixx forward tail):
+ *   phase 0  a  = o_proj(attn)
+ *   phase 1  r1 = bf16(res + bf16(rmsnorm(a; post_attn_w)));  h = GeGLU(fc_gate_up(rmsnorm(r1; pre_ffn_w)))
+ *   phase 2  d  = fc_down(h)
+ *   phase 3  r2 = bf16(bf16(r1 + bf16(rmsnorm(d; post_ffn_w))) * layer_scalar);  y = next(rmsnorm(r2; next_norm_w))
+ * `next` is a qkv_proj in the layer's weight format (y: bf16[N_next]) or, with f32_out, the lm_head table in
+ * `next_fmt` (y: float[N_next]).  r2 is written to res_out.  Results are bit-identical to the sequence
+ * matvec + fused_norm_matvec(geglu) + matvec + fused_norm_matvec.  One workgroup per CU; the phases hand their
+ * vectors over through `scratch` (decode_chain_scratch_bytes(D, F), zero its header ONCE with decode_chain_init;
+ * consecutive launches that share a scratch must be stream-ordered).  A launch whose workgroups cannot all be
+ * resident gives up after a bounded wait and sets the error word read by decode_chain_status (0 = healthy). */
+typedef struct mila_decode_chain_args {
+    const uint16_t* attn;         /* [K_attn] attention output                                        */
+    const uint16_t* res;          /* [D] residual stream entering the post-attention tail             */
+    uint16_t* res_out;            /* [D] r2                                                           */
+    void* y;                      /* [N_next] bf16, or float when f32_out                             */
+    const void* W_o;       const float* s_o;         /* [D, K_attn]                                   */
+    const void* W_gate_up; const float* s_gate_up;   /* [2F, D] rows [gate | up]                      */
+    const void* W_down;    const float* s_down;      /* [D, F]                                        */
+    const void* W_next;    const float* s_next;      /* [N_next, D]                                   */
+    const uint16_t* post_attn_w;  /* [D] */
+    const uint16_t* pre_ffn_w;    /* [D] */
+    const uint16_t* post_ffn_w;   /* [D] */
+    const uint16_t* next_norm_w;  /* [D] next layer's input norm, or the final norm                   */
+    float layer_scalar, eps;
+    int fmt, group;               /* format of o_proj / fc_gate_up / fc_down (0 bf16, 1 fp8, 2 fp4)   */
+    int next_fmt, next_group;     /* format of W_next                                                 */
+    int f32_out;
+    int D, F, K_attn, N_next;
+    void* scratch; size_t scratch_bytes;
+} mila_decode_chain_args;
+MILA_API size_t mila_cdna4_decode_chain_scratch_bytes(int D, int F);
+MILA_API int mila_cdna4_decode_chain_init(void* scratch, size_t scratch_bytes, mila_stream_t stream);
+MILA_API int mila_cdna4_decode_chain_status(const void* scratch, int32_t* error_out, mila_stream_t stream);
+MILA_API int mila_cdna4_decode_chain(const mila_decode_chain_args* host_args, mila_stream_t stream);
+
 /* q/k(/v) per-head RMSNorm + RoPE + KV-cache append for one decode token, in one launch:
  *   q <- rope(rmsnorm(q; qw)), k' = rope(rmsnorm(k; kw)), v' = rmsnorm(v_src; vw or ones),
  *   cache[pos % capacity] <- (k', v').  v_src == k (raw) on Gemma global layers. */

@@ -49,6 +49,7 @@ def load():
     _lib.mila_cdna4_attn_decode_scratch_bytes.restype = C.c_size_t
     _lib.mila_cdna4_gemm_staging_bytes.restype = C.c_size_t
     _lib.mila_cdna4_sample_scratch_bytes.restype = C.c_size_t
+    _lib.mila_cdna4_decode_chain_scratch_bytes.restype = C.c_size_t
     return _lib
 
 
@@ -57,6 +58,17 @@ class fused_matvec_args(C.Structure):
                 ("norm_w", C.c_void_p), ("post_w", C.c_void_p), ("res", C.c_void_p), ("res_out", C.c_void_p),
                 ("post_scale", C.c_float), ("eps", C.c_float), ("fmt", C.c_int), ("K", C.c_int),
                 ("N", C.c_int), ("group", C.c_int), ("geglu", C.c_int), ("f32_out", C.c_int)]
+
+
+class decode_chain_args(C.Structure):
+    _fields_ = [("attn", C.c_void_p), ("res", C.c_void_p), ("res_out", C.c_void_p), ("y", C.c_void_p),
+                ("W_o", C.c_void_p), ("s_o", C.c_void_p), ("W_gate_up", C.c_void_p), ("s_gate_up", C.c_void_p),
+                ("W_down", C.c_void_p), ("s_down", C.c_void_p), ("W_next", C.c_void_p), ("s_next", C.c_void_p),
+                ("post_attn_w", C.c_void_p), ("pre_ffn_w", C.c_void_p), ("post_ffn_w", C.c_void_p),
+                ("next_norm_w", C.c_void_p), ("layer_scalar", C.c_float), ("eps", C.c_float),
+                ("fmt", C.c_int), ("group", C.c_int), ("next_fmt", C.c_int), ("next_group", C.c_int),
+                ("f32_out", C.c_int), ("D", C.c_int), ("F", C.c_int), ("K_attn", C.c_int), ("N_next", C.c_int),
+                ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t)]
 
 
 def _ptr(t):
@@ -115,4 +127,5 @@ EXPORTED = [
     "sample_scratch_bytes", "sample_argmax_fp32", "sample_argmax_bf16",
     "fused_norm_matvec", "fused_qkv_post",
     "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position", "fused_attn_decode_bf16",
+    "decode_chain_scratch_bytes", "decode_chain_init", "decode_chain_status", "decode_chain",
 ]

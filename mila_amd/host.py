@@ -43,6 +43,8 @@ def load():
         _lib.mila_gemma_time_prefill.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         _lib.mila_gemma_info.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         _lib.mila_gemma_generate.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        _lib.mila_gemma_set_chain.argtypes = [C.c_void_p, C.c_int]
+        _lib.mila_gemma_uses_chain.argtypes = [C.c_void_p]
         _lib.mila_gpt_last_error.restype = C.c_char_p
         _lib.mila_gpt_create.restype = C.c_void_p
         _lib.mila_gpt_create.argtypes = [C.c_int64] * 7
@@ -87,6 +89,15 @@ class Gemma:
             self.close()
         except Exception:
             pass
+
+    def set_chain(self, on):
+        """fused / graph decode with the four Linears between two attention calls as ONE launch (default when the
+        configuration fits) or one launch per Linear; the two give identical bits.  Before the first graph decode."""
+        _check(load().mila_gemma_set_chain(self.h, int(bool(on))))
+
+    @property
+    def uses_chain(self):
+        return bool(load().mila_gemma_uses_chain(self.h))
 
     def prefill(self, tokens, position_offset=0):
         t = np.ascontiguousarray(tokens, dtype=np.int32)

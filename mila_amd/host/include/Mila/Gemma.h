@@ -262,6 +262,23 @@ namespace Mila::Dnn
         /// time that kernel with HIP events on the model stream
         void launchGateUp( size_t i ) { fusedGateUp( layers_[ i ] ); }
         double gateUpBytes( size_t i ) const { return static_cast<double>( layers_[ i ].fc_gate_up->getParameterBytes() ); }
+        /// the dominant decode kernel of the active schedule: the chain launch of layer i (not the last layer), or the
+        /// fc_gate_up fused matvec when the chain is off
+        void launchDominant( size_t i )
+        {
+            if ( use_chain_ && layers_.size() > 1 ) { const size_t l = i % ( layers_.size() - 1 ); launchChain( l, hidden_[ 0 ]->data(), hidden_[ 1 ]->data() ); }
+            else fusedGateUp( layers_[ i % layers_.size() ] );
+        }
+        double dominantBytes( size_t i ) const
+        {
+            if ( use_chain_ && layers_.size() > 1 )
+            {
+                const size_t l = i % ( layers_.size() - 1 );
+                return static_cast<double>( layers_[ l ].o_proj->getParameterBytes() + layers_[ l ].fc_gate_up->getParameterBytes() +
+                                            layers_[ l ].fc_down->getParameterBytes() + layers_[ l + 1 ].qkv_proj->getParameterBytes() );
+            }
+            return gateUpBytes( i % layers_.size() );
+        }
 
     private:
         void fill( uint16_t* dst, dim_t n, uint64_t seed, float amp, float offset )
@@ -335,6 +352,15 @@ namespace Mila::Dnn
             sample_scratch_ = std::make_unique<LogitsTensor>( dev, shape_t{ static_cast<dim_t>( mila_cdna4_sample_scratch_bytes() / 4 ) } );
             err_flag_ = std::make_unique<TokenTensor>( dev, shape_t{ 1 } );
             Compute::rocmCheck( mila_cdna4_memset_zero( err_flag_->data(), 4, ctx_->getStream() ) );
+            if ( chainApplicable() )
+            {
+                const size_t nb = mila_cdna4_decode_chain_scratch_bytes( (int)cfg_.embedding_dim, (int)cfg_.hidden_dim );
+                chain_scratch_ = std::make_unique<LogitsTensor>( dev, shape_t{ static_cast<dim_t>( ( nb + 3 ) / 4 ) } );
+                Compute::rocmCheck( mila_cdna4_decode_chain_init( chain_scratch_->data(), chain_scratch_->sizeInBytes(), ctx_->getStream() ) );
+                // opt-in (setUseChain): measured on MI355X the in-launch hand-offs cost MORE than the kernel boundaries
+                // they replace (Gemma-4 12B decode 222 -> 200 tok/s bf16, 410 -> 313 fp4)
+                use_chain_ = false;
+            }
             ctx_->synchronize();
         }
 
@@ -481,6 +507,7 @@ namespace Mila::Dnn
         /// is the prologue of layer l's qkv kernel; the tail of the last layer is the prologue of the head.
         void enqueueFusedStep( const int32_t* token_dev, int position, const int32_t* pos_dev )
         {
+            if ( use_chain_ ) { enqueueChainStep( token_dev, position, pos_dev ); return; }
             mila_stream_t st = ctx_->getStream();
             embed( token_dev, 1, *hidden_[ 0 ] );
             cur_hidden_ = hidden_[ 0 ]->data();
@@ -531,6 +558,110 @@ namespace Mila::Dnn
             }
         }
 
+        /// q/k/v norms + RoPE + KV append + flash-decode in one launch (+ combine) for layer L; qkv row = [q | k | v]
+        /// (global: [q | k], V from the raw k projection)
+        void fusedAttention( Layer& L, int position, const int32_t* pos_dev )
+        {
+            const bool g = L.global;
+            const int NH = (int)cfg_.num_heads, NKV = (int)cfg_.numKvHeads( g ), HD = (int)cfg_.headDim( g );
+            const uint16_t* qp = f_qkv_->data();
+            const uint16_t* kp = qp + (size_t)NH * HD;
+            const uint16_t* vp = g ? kp : kp + (size_t)NKV * HD;
+            const size_t need = attnScratchBytes();
+            void* scratch = ctx_->getScratch( need );
+            Compute::rocmCheck( mila_cdna4_fused_attn_decode_bf16( attn_out_->data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
+                                                                   L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(),
+                                                                   scratch, need, NH, NKV, HD, (int)L.attn->cacheCapacity(), position, pos_dev,
+                                                                   (int)cfg_.windowFor( g ), L.attn->scale(), cfg_.rms_norm_eps, ctx_->getStream() ) );
+        }
+
+        /// The same step with the four Linears between two attention calls in one launch (mila_cdna4_decode_chain):
+        /// per layer 3 launches (attention, combine, chain) instead of 6; bit-identical to enqueueFusedStep.
+        /// Opt-in: see the note in buildAll().
+        void enqueueChainStep( const int32_t* token_dev, int position, const int32_t* pos_dev )
+        {
+            mila_stream_t st = ctx_->getStream();
+            embed( token_dev, 1, *hidden_[ 0 ] );
+            cur_hidden_ = hidden_[ 0 ]->data();
+            int next = 1;
+            {   // layer 0: input_norm + qkv projection
+                auto a = baseArgs( *layers_[ 0 ].qkv_proj, f_qkv_->data(), cur_hidden_ );
+                a.norm_w = layers_[ 0 ].input_norm->getWeight()->data();
+                Compute::rocmCheck( mila_cdna4_fused_norm_matvec( &a, st ) );
+            }
+            for ( size_t i = 0; i < layers_.size(); ++i )
+            {
+                fusedAttention( layers_[ i ], position, pos_dev );
+                launchChain( i, cur_hidden_, hidden_[ next ]->data() );
+                cur_hidden_ = hidden_[ next ]->data(); next = ( next == 1 ) ? 2 : 1;
+            }
+        }
+
+        /// chain launch of layer i: attention output + residual stream `res` -> next layer's packed qkv (or the logits)
+        /// and the new residual stream `res_out`
+        void launchChain( size_t i, const uint16_t* res, uint16_t* res_out )
+        {
+            auto& L = layers_[ i ];
+            const bool last = ( i + 1 == layers_.size() );
+            mila_decode_chain_args c{};
+            c.attn = attn_out_->data(); c.res = res; c.res_out = res_out;
+            auto scales = []( auto& lin ) -> const float* { if constexpr ( TWeightQuant::kIsQuantized ) return lin.getWeightScale()->data(); else return nullptr; };
+            c.W_o = L.o_proj->getWeight().rawData(); c.s_o = scales( *L.o_proj );
+            c.W_gate_up = L.fc_gate_up->getWeight().rawData(); c.s_gate_up = scales( *L.fc_gate_up );
+            c.W_down = L.fc_down->getWeight().rawData(); c.s_down = scales( *L.fc_down );
+            c.post_attn_w = L.post_attn_norm->getWeight()->data(); c.pre_ffn_w = L.pre_ffn_norm->getWeight()->data();
+            c.post_ffn_w = L.post_ffn_norm->getWeight()->data();
+            c.layer_scalar = L.layer_scalar; c.eps = cfg_.rms_norm_eps;
+            c.fmt = kFmt; c.group = Quant::Weight::groupSizeOf<TWeightQuant>();
+            c.D = (int)cfg_.embedding_dim; c.F = (int)cfg_.hidden_dim; c.K_attn = (int)L.o_proj->getConfig().getInputFeatures();
+            if ( last )
+            {
+                c.y = logits_->data(); c.W_next = lm_head_->getWeight().rawData(); c.s_next = nullptr;
+                if constexpr ( kTableFmt != 0 ) c.s_next = lm_head_->getWeightScale()->data();
+                c.next_norm_w = final_norm_->getWeight()->data(); c.next_fmt = kTableFmt; c.next_group = 0; c.f32_out = 1;
+                c.N_next = (int)cfg_.vocab_size;
+            }
+            else
+            {
+                auto& Nx = layers_[ i + 1 ];
+                c.y = f_qkv_->data(); c.W_next = Nx.qkv_proj->getWeight().rawData(); c.s_next = scales( *Nx.qkv_proj );
+                c.next_norm_w = Nx.input_norm->getWeight()->data(); c.next_fmt = kFmt; c.next_group = c.group; c.f32_out = 0;
+                c.N_next = (int)Nx.qkv_proj->getConfig().getOutputFeatures();
+            }
+            c.scratch = chain_scratch_->data(); c.scratch_bytes = chain_scratch_->sizeInBytes();
+            Compute::rocmCheck( mila_cdna4_decode_chain( &c, ctx_->getStream() ) );
+        }
+
+    public:
+        /// whether the decode chain kernel serves this configuration (D, attention width <= 8192, F <= 16384, ...)
+        bool chainApplicable() const
+        {
+            const dim_t D = cfg_.embedding_dim, F = cfg_.hidden_dim;
+            const dim_t ka = cfg_.num_heads * std::max( cfg_.headDim( false ), cfg_.headDim( true ) );
+            const dim_t g = TWeightQuant::kIsQuantized ? std::max<dim_t>( 32, Quant::Weight::groupSizeOf<TWeightQuant>() ) : 32;
+            bool ok = D <= 8192 && ka <= 8192 && F <= 16384 && D % g == 0 && F % g == 0;
+            for ( dim_t i = 0; i < cfg_.num_layers; ++i ) ok = ok && ( cfg_.num_heads * cfg_.headDim( cfg_.isGlobalLayer( i ) ) ) % g == 0;
+            return ok && kTableFmt != 2;
+        }
+        bool usesChain() const { return use_chain_; }
+        /// choose between the one-launch chain and one launch per Linear for the fused / graph decode paths
+        /// (before captureGraph); the two produce identical bits
+        void setUseChain( bool on )
+        {
+            if ( on && !chainApplicable() ) throw std::invalid_argument( "GemmaTransformer::setUseChain: configuration outside the chain kernel's limits" );
+            if ( graph_exec_ ) throw std::runtime_error( "GemmaTransformer::setUseChain: the graph is already captured" );
+            use_chain_ = on;
+        }
+        /// after a synchronisation point: throws if a hand-off wait inside a chain launch gave up
+        void checkChainStatus()
+        {
+            if ( !chain_scratch_ ) return;
+            int32_t e = 0;
+            Compute::rocmCheck( mila_cdna4_decode_chain_status( chain_scratch_->data(), &e, ctx_->getStream() ) );
+            if ( e != 0 ) throw std::runtime_error( "GemmaTransformer: a decode-chain hand-off wait gave up (phase " + std::to_string( e ) + "): not all workgroups were resident" );
+        }
+
+    private:
         GemmaConfig cfg_;
         dim_t max_seq_, max_prefill_;
         std::unique_ptr<IExecutionContext> owned_ctx_;
@@ -543,6 +674,8 @@ namespace Mila::Dnn
         std::unique_ptr<TokenTensor> pos_dev_, err_flag_;
         std::unique_ptr<LogitsTensor> sample_scratch_;
         bool sample_in_graph_{ false };
+        bool use_chain_{ false };
+        std::unique_ptr<LogitsTensor> chain_scratch_;
         const uint16_t* cur_hidden_{ nullptr };
         hipGraph_t graph_{ nullptr };
         hipGraphExec_t graph_exec_{ nullptr };

@@ -115,6 +115,22 @@ HOST_API int mila_gemma_prefill( void* h, const int32_t* host_tokens, int64_t T,
     } );
 }
 
+/// on != 0: the fused / graph decode paths run the four Linears between two attention calls as one chain launch
+/// (default when the configuration fits); 0: one launch per Linear.  Call before the first graph-mode decode.
+HOST_API int mila_gemma_set_chain( void* h, int on )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&] { std::visit( [&]( auto& m ) { m->setUseChain( on != 0 ); }, r->model ); } );
+}
+/// 1 if the chain launch is in use, 0 if not
+HOST_API int mila_gemma_uses_chain( void* h )
+{
+    auto* r = static_cast<Runner*>( h );
+    int u = 0;
+    std::visit( [&]( auto& m ) { u = m->usesChain() ? 1 : 0; }, r->model );
+    return u;
+}
+
 /// mode: 0 reference-order (one launch per component), 1 fused schedule, 2 graph replay (position from device)
 HOST_API int mila_gemma_decode( void* h, int32_t token, int64_t position, int mode, float* host_logits )
 {
@@ -133,6 +149,7 @@ HOST_API int mila_gemma_decode( void* h, int32_t token, int64_t position, int mo
                 m->replayGraph();
             }
             m->context()->synchronize();
+            if ( mode != 0 ) m->checkChainStatus();
         }, r->model );
         download_logits( r, host_logits );
     } );
@@ -180,6 +197,7 @@ HOST_API int mila_gemma_time_decode( void* h, int64_t start_position, int steps,
             (void)hipEventDestroy( e0 ); (void)hipEventDestroy( e1 );
             out[ 0 ] = std::chrono::duration<double, std::milli>( t1 - t0 ).count() / steps;
             out[ 1 ] = static_cast<double>( ms ) / steps;
+            if ( mode != 0 ) m->checkChainStatus();
         }, r->model );
     } );
 }
@@ -197,21 +215,24 @@ HOST_API int mila_gemma_time_dominant_kernel( void* h, int rounds, double* out )
             auto* ctx = m->context();
             hipStream_t s = reinterpret_cast<hipStream_t>( ctx->getStream() );
             const size_t L = m->layers().size();
-            for ( size_t i = 0; i < L; ++i ) m->launchGateUp( i );
+            for ( size_t i = 0; i < L; ++i ) m->launchDominant( i );
             ctx->synchronize();
             hipEvent_t e0, e1;
             hipCheck( hipEventCreate( &e0 ), "hipEventCreate" );
             hipCheck( hipEventCreate( &e1 ), "hipEventCreate" );
             hipCheck( hipEventRecord( e0, s ), "hipEventRecord" );
             for ( int k = 0; k < rounds; ++k )
-                for ( size_t i = 0; i < L; ++i ) m->launchGateUp( i );
+                for ( size_t i = 0; i < L; ++i ) m->launchDominant( i );
             hipCheck( hipEventRecord( e1, s ), "hipEventRecord" );
             ctx->synchronize();
             float ms = 0;
             hipCheck( hipEventElapsedTime( &ms, e0, e1 ), "hipEventElapsedTime" );
             (void)hipEventDestroy( e0 ); (void)hipEventDestroy( e1 );
             out[ 0 ] = static_cast<double>( ms ) * 1e3 / ( static_cast<double>( rounds ) * L );
-            out[ 1 ] = m->gateUpBytes( 0 );
+            double bytes = 0;
+            for ( size_t i = 0; i < L; ++i ) bytes += m->dominantBytes( i );
+            out[ 1 ] = bytes / static_cast<double>( L );
+            m->checkChainStatus();
         }, r->model );
     } );
 }

@@ -163,3 +163,75 @@ def test_fused_attn_decode_equals_qkv_post_plus_attn_decode(NH, NKV, HS, rot, ba
               cap, 0, pd, window, 1.0, 1e-6)
     assert np.array_equal(bits(y2), bits(y0)) and np.array_equal(bits(K2), bits(K0))
     del hist
+
+
+def _chain_args(**kw):
+    a = capi.decode_chain_args()
+    for k, v in kw.items():
+        if hasattr(v, "data_ptr"):
+            v = v.data_ptr()
+        setattr(a, k, v)
+    return a
+
+
+@pytest.mark.parametrize("fmt,head_fmt", [(0, None), (1, None), (2, None), (0, 0), (1, 1), (2, 1)])
+def test_decode_chain_equals_the_four_launch_sequence(fmt, head_fmt):
+    """o_proj -> tail -> gate_up + GeGLU -> down -> tail -> next qkv_proj / lm_head in ONE launch
+    (Gemma.Block.ixx:287-356) is bit-identical to matvec + fused_norm_matvec(geglu) + matvec + fused_norm_matvec,
+    launch after launch on the same scratch (the arrival counter / epoch words carry over)."""
+    rng = np.random.default_rng(100 + fmt * 7 + (head_fmt or 0))
+    D, F, KA = 1024, 2304, 512
+    NN = 1040 if head_fmt is None else 4099
+    nfmt = fmt if head_fmt is None else head_fmt
+    Wo, so, _ = _weights(rng, D, KA, fmt)
+    Wg, sg, _ = _weights(rng, 2 * F, D, fmt)
+    Wd, sd, _ = _weights(rng, D, F, fmt)
+    Wn, sn, _ = _weights(rng, NN, D, nfmt)
+    nws = [_d(_bf(1 + 0.1 * rng.uniform(-1, 1, D))) for _ in range(4)]    # post_attn, pre_ffn, post_ffn, next_norm
+    lib, stream = capi.load(), C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nbytes = lib.mila_cdna4_decode_chain_scratch_bytes(D, F)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    capi.call("decode_chain_init", scratch, C.c_size_t(nbytes))
+    z = 0
+    for it in range(3):
+        attn = _d(_bf(rng.standard_normal(KA)))
+        res = _d(_bf(rng.standard_normal(D)))
+        # --- four launches ---
+        a0, h0, d0 = empty_u16(D), empty_u16(F), empty_u16(D)
+        r1, r2 = empty_u16(D), empty_u16(D)
+        _matvec(fmt, a0, attn, Wo, so, KA, D)
+        fa = _args(y=h0, x=a0, W=Wg, scales=sg if sg is not None else z, norm_w=nws[1], post_w=nws[0], res=res, res_out=r1,
+                   post_scale=1.0, eps=1e-6, fmt=fmt, K=D, N=F, group=128, geglu=1)
+        capi.check(lib.mila_cdna4_fused_norm_matvec(C.byref(fa), stream))
+        _matvec(fmt, d0, h0, Wd, sd, F, D)
+        y0 = empty_f32(NN) if head_fmt is not None else empty_u16(NN)
+        fb = _args(y=y0, x=d0, W=Wn, scales=sn if sn is not None else z, norm_w=nws[3], post_w=nws[2], res=r1, res_out=r2,
+                   post_scale=0.75, eps=1e-6, fmt=nfmt, K=D, N=NN, group=128, geglu=0, f32_out=int(head_fmt is not None))
+        capi.check(lib.mila_cdna4_fused_norm_matvec(C.byref(fb), stream))
+        # --- one launch ---
+        y1 = empty_f32(NN) if head_fmt is not None else empty_u16(NN)
+        r2c = empty_u16(D)
+        ca = _chain_args(attn=attn, res=res, res_out=r2c, y=y1, W_o=Wo, s_o=so if so is not None else z, W_gate_up=Wg,
+                         s_gate_up=sg if sg is not None else z, W_down=Wd, s_down=sd if sd is not None else z, W_next=Wn,
+                         s_next=sn if sn is not None else z, post_attn_w=nws[0], pre_ffn_w=nws[1], post_ffn_w=nws[2],
+                         next_norm_w=nws[3], layer_scalar=0.75, eps=1e-6, fmt=fmt, group=128, next_fmt=nfmt, next_group=128,
+                         f32_out=int(head_fmt is not None), D=D, F=F, K_attn=KA, N_next=NN, scratch=scratch,
+                         scratch_bytes=nbytes)
+        capi.check(lib.mila_cdna4_decode_chain(C.byref(ca), stream))
+        err = C.c_int32(-1)
+        capi.check(lib.mila_cdna4_decode_chain_status(C.c_void_p(scratch.data_ptr()), C.byref(err), stream))
+        assert err.value == 0, "a hand-off wait gave up (code %d)" % err.value
+        assert np.array_equal(bits(r2), bits(r2c)), "residual stream differs (launch %d)" % it
+        if head_fmt is not None:
+            assert np.array_equal(y0.cpu().numpy().view(np.uint32), y1.cpu().numpy().view(np.uint32)), "logits differ (launch %d)" % it
+        else:
+            assert np.array_equal(bits(y0), bits(y1)), "qkv differs (launch %d)" % it
+
+
+def test_decode_chain_rejects_bad_arguments():
+    lib, stream = capi.load(), C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    a = _chain_args(D=1024, F=2304, K_attn=512, N_next=8, fmt=0, next_fmt=0)
+    with pytest.raises(capi.InvalidArgument):
+        capi.check(lib.mila_cdna4_decode_chain(C.byref(a), stream))
+    with pytest.raises(capi.InvalidArgument):
+        capi.check(lib.mila_cdna4_decode_chain(None, stream))

@@ -22,12 +22,16 @@ MAX_SEQ = 64
 @pytest.mark.parametrize("policy", ["bf16", "fp8", "fp4"])
 def test_three_decode_paths_are_bit_identical_and_match_the_oracle(policy):
     ref = RefGemma(SMALL, policy, seed=7)
-    models = {m: host.Gemma(policy, SMALL, max_seq=MAX_SEQ, max_prefill=1, seed=7) for m in ("reference", "fused", "graph")}
+    models = {m: host.Gemma(policy, SMALL, max_seq=MAX_SEQ, max_prefill=1, seed=7) for m in ("reference", "fused", "graph", "chain", "chain-graph")}
+    assert not models["fused"].uses_chain and not models["graph"].uses_chain      # one launch per Linear is the default
+    models["chain"].set_chain(True)                                               # opt-in: one chain launch per layer
+    models["chain-graph"].set_chain(True)
+    mode_of = {"chain": "fused", "chain-graph": "graph"}
     worst, errs = 0.0, []
     for pos, tok in enumerate(TOKENS):
-        out = {m: g.decode(tok, pos, m) for m, g in models.items()}
-        assert np.array_equal(out["reference"].view(np.uint32), out["fused"].view(np.uint32)), "fused != reference-order at %d" % pos
-        assert np.array_equal(out["reference"].view(np.uint32), out["graph"].view(np.uint32)), "graph != reference-order at %d" % pos
+        out = {m: g.decode(tok, pos, mode_of.get(m, m)) for m, g in models.items()}
+        for m in ("fused", "graph", "chain", "chain-graph"):
+            assert np.array_equal(out["reference"].view(np.uint32), out[m].view(np.uint32)), "%s != reference-order at %d" % (m, pos)
         exp = ref.forward([tok], pos, MAX_SEQ)
         assert np.all(np.isfinite(out["fused"]))
         err = np.abs(out["fused"] - exp).max() / np.abs(exp).max()
