@@ -106,6 +106,21 @@ MILA_API int mila_cdna4_gemm_bf16_w4a16(uint16_t* Y, const uint16_t* X, const ui
                                         const float* scales, const uint16_t* bias, int M, int K,
                                         int N, int group, mila_stream_t stream);
 
+/* Linear + GeGLU in ONE kernel for the prefill fc_gate_up (Components/Transformers/Gemma/Gemma.Block.ixx:343-348: the
+ * Linear writes [M, 2F] = [gate | up], the GeGLU kernel reads it back): Y[M, F] = bf16(gelu_tanh(bf16(gate)) * bf16(up)),
+ * gate = X W[0:F]^T, up = X W[F:2F]^T.  A tile pairs 128 gate rows with the matching 128 up rows; results are
+ * bit-identical to gemm_bf16 + geglu_bf16.  gemm_geglu_applicable() != 0 says the fused kernel serves (M, K, F); the
+ * _staged forms dequantize the whole [2F, K] weight to `scratch` (2 * F * K * 2 bytes) first. */
+MILA_API int mila_cdna4_gemm_geglu_applicable(int M, int K, int F);
+MILA_API int mila_cdna4_gemm_geglu_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F,
+                                        mila_stream_t stream);
+MILA_API int mila_cdna4_gemm_geglu_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W,
+                                                     const float* scales, int M, int K, int F, void* scratch,
+                                                     size_t scratch_bytes, mila_stream_t stream);
+MILA_API int mila_cdna4_gemm_geglu_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed,
+                                                     const float* scales, int M, int K, int F, int group,
+                                                     void* scratch, size_t scratch_bytes, mila_stream_t stream);
+
 /* 2-phase forms for quantized weights (the reference's own structure, Linear/CudaLinearOp.ixx:597-644, :716-764:
  * dequantize to a bf16 scratch, then the bf16 GEMM).  Chosen automatically when the 256 x 256 LDS-DMA GEMM
  * applies to (M,K,N) -- gemm_staging_bytes() says how much scratch that needs (0 = the register-dequantizing kernel is

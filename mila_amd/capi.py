@@ -117,6 +117,7 @@ EXPORTED = [
     "memcpy_h2d", "memcpy_d2h", "memcpy_d2d", "memset_zero",
     "matvec_bf16", "matvec_bf16_qfp8", "matvec_bf16_qfp4", "matvec_f32out",
     "gemm_bf16", "gemm_bf16_w8a16", "gemm_bf16_w4a16", "gemm_staging_bytes", "gemm_bf16_w8a16_staged", "gemm_bf16_w4a16_staged",
+    "gemm_geglu_applicable", "gemm_geglu_bf16", "gemm_geglu_bf16_w8a16_staged", "gemm_geglu_bf16_w4a16_staged",
     "quantize_fp8_per_channel", "quantize_fp4_per_group",
     "kv_write_bf16", "attn_decode_scratch_bytes", "attn_decode_bf16", "attn_prefill_bf16", "mha_bf16",
     "rmsnorm_bf16", "layernorm_bf16", "layernorm_fp32", "softmax_fp32", "softmax_bf16",

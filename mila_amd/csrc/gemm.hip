@@ -266,6 +266,8 @@ static int launch_gemm(GemmParams p, hipStream_t s)
 
 bool gemm256_applicable(int M, int K, int N);
 int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s);
+bool gemm256_geglu_applicable(int M, int K, int F);
+int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s);
 static int g_gemm_force128 = 0;
 
 // ---- 2-phase staging (the reference's own prefill structure for quantized weights,
@@ -413,6 +415,58 @@ int mila_cdna4_gemm_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, const uint
     rc = check_hip(hipGetLastError(), "dequant_fp4");
     if (rc) return rc;
     return launch_gemm256(Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream));
+}
+
+/* ---- Linear + GeGLU in one kernel (prefill fc_gate_up): Y[M, F] = GeGLU(X W^T), W = [gate | up] rows ---- */
+int mila_cdna4_gemm_geglu_applicable(int M, int K, int F)
+{
+    return (M > 0 && K > 0 && F > 0 && !g_gemm_force128 && gemm256_geglu_applicable(M, K, F)) ? 1 : 0;
+}
+
+int mila_cdna4_gemm_geglu_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, mila_stream_t stream)
+{
+    int rc = validate_gemm("gemm_geglu_bf16", Y, X, W, M, K, F);
+    if (rc) return rc;
+    MILA_REQUIRE(gemm256_geglu_applicable(M, K, F), "gemm_geglu_bf16: shape (M=%d, K=%d, F=%d) is outside the fused kernel (ask gemm_geglu_applicable)", M, K, F);
+    return launch_gemm256_geglu(Y, X, W, M, K, F, as_stream(stream));
+}
+
+int mila_cdna4_gemm_geglu_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W, const float* scales, int M, int K, int F,
+                                            void* scratch, size_t scratch_bytes, mila_stream_t stream)
+{
+    int rc = validate_gemm("gemm_geglu_bf16_w8a16_staged", Y, X, W, M, K, F);
+    if (rc) return rc;
+    MILA_REQUIRE(gemm256_geglu_applicable(M, K, F), "gemm_geglu_bf16_w8a16_staged: shape (M=%d, K=%d, F=%d) is outside the fused kernel", M, K, F);
+    MILA_REQUIRE(scales != nullptr, "gemm_geglu_bf16_w8a16_staged: per-channel scales are required");
+    const size_t need = (size_t)2 * F * K * 2;
+    if (!scratch || scratch_bytes < need)
+        return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_geglu_bf16_w8a16_staged: scratch %zu bytes < required %zu", scratch_bytes, need);
+    const int64_t total_vec = (int64_t)2 * F * K / 16;
+    hipLaunchKernelGGL(dequant_fp8_kernel, dim3(2048), dim3(256), 0, as_stream(stream), reinterpret_cast<uint16_t*>(scratch), W, scales,
+                       total_vec, K / 16);
+    rc = check_hip(hipGetLastError(), "dequant_fp8");
+    if (rc) return rc;
+    return launch_gemm256_geglu(Y, X, reinterpret_cast<const uint16_t*>(scratch), M, K, F, as_stream(stream));
+}
+
+int mila_cdna4_gemm_geglu_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed, const float* scales, int M, int K,
+                                            int F, int group, void* scratch, size_t scratch_bytes, mila_stream_t stream)
+{
+    int rc = validate_gemm("gemm_geglu_bf16_w4a16_staged", Y, X, W_packed, M, K, F);
+    if (rc) return rc;
+    MILA_REQUIRE(gemm256_geglu_applicable(M, K, F), "gemm_geglu_bf16_w4a16_staged: shape (M=%d, K=%d, F=%d) is outside the fused kernel", M, K, F);
+    MILA_REQUIRE(scales != nullptr, "gemm_geglu_bf16_w4a16_staged: per-group scales are required");
+    MILA_REQUIRE(group == 64 || group == 128, "gemm_geglu_bf16_w4a16_staged: group size must be 64 or 128 (got %d)", group);
+    MILA_REQUIRE(K % group == 0, "gemm_geglu_bf16_w4a16_staged: K=%d must be a multiple of the group size %d", K, group);
+    const size_t need = (size_t)2 * F * K * 2;
+    if (!scratch || scratch_bytes < need)
+        return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_geglu_bf16_w4a16_staged: scratch %zu bytes < required %zu", scratch_bytes, need);
+    const int64_t total_vec = (int64_t)2 * F * K / 32;
+    hipLaunchKernelGGL(dequant_fp4_kernel, dim3(2048), dim3(256), 0, as_stream(stream), reinterpret_cast<uint16_t*>(scratch), W_packed,
+                       scales, total_vec, group / 32);
+    rc = check_hip(hipGetLastError(), "dequant_fp4");
+    if (rc) return rc;
+    return launch_gemm256_geglu(Y, X, reinterpret_cast<const uint16_t*>(scratch), M, K, F, as_stream(stream));
 }
 
 }  // extern "C"

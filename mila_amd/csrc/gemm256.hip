@@ -27,7 +27,7 @@ struct Gemm256Params
     const uint16_t* X;
     const uint16_t* W;
     const uint16_t* bias;
-    int M, K, N, tiles_m, tiles_n;
+    int M, K, N, tiles_m, tiles_n;     // GEGLU: N = F output columns, W has 2 F rows [gate | up]
 };
 
 constexpr int kHalfBytes = 128 * 128;          // 128 rows x 64 bf16
@@ -35,6 +35,10 @@ constexpr int kBufBytes = 4 * kHalfBytes;      // W0 W1 X0 X1
 
 __device__ __forceinline__ int half_off(bool isX, int half) { return (isX ? 2 * kHalfBytes : 0) + half * kHalfBytes; }
 
+// GEGLU: the tile's two W half-tiles are 128 gate rows (n0 ..) and the matching 128 up rows (F + n0 ..), so a lane's
+// accumulators acc[0][..] / acc[1][..] hold gate and up of the SAME outputs and the epilogue writes
+// bf16(gelu_tanh(bf16(gate)) * bf16(up)) -- the Linear + GeGLU pair of Gemma.Block.ixx:343-348 without the [M, 2F] round trip.
+template <bool GEGLU>
 __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -43,7 +47,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     const int xcd = id & 7, qd = nwg >> 3, rem = nwg & 7;
     const int tile = ((xcd < rem) ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (id >> 3);
     const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-    const int m0 = tm * 256, n0 = tn * 256;
+    const int m0 = tm * 256, n0 = tn * (GEGLU ? 128 : 256);
+    const int wrow1 = GEGLU ? p.N + n0 : n0 + 128;      // first W row of half-tile 1
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     // ---- staging: half-tile (isX, half) of K-tile kt into buffer kt & 1 ----
     const int srow = lane >> 3, sslot = lane & 7;          // this lane's row within a 1 KiB chunk / 16-byte slot
     auto stage = [&](int kt, bool isX, int half) {
-        const uint16_t* base = isX ? p.X + (size_t)(m0 + half * 128) * K : p.W + (size_t)(n0 + half * 128) * K;
+        const uint16_t* base = isX ? p.X + (size_t)(m0 + half * 128) * K : p.W + (size_t)(half ? wrow1 : n0) * K;
         unsigned char* dst_half = smem + (kt & 1) * kBufBytes + half_off(isX, half);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -161,8 +166,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     }
 
     // ---- epilogue: D[p = 4 g + r][q = l15] -> Y[m0 + q][n0 + p] ----
-#pragma unroll
-    for (int hA = 0; hA < 2; ++hA)
+    if constexpr (GEGLU)
+    {
 #pragma unroll
         for (int hB = 0; hB < 2; ++hB)
 #pragma unroll
@@ -170,18 +175,39 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
                 {
-                    const int n = n0 + hA * 128 + wr * 64 + pt * 16 + 4 * g;
+                    const int n = n0 + wr * 64 + pt * 16 + 4 * g;
                     const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[hA][hB][pt][qt][e];
-                    if (p.bias)
-                    {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = gelu_tanh(round_bf16(acc[0][hB][pt][qt][e])) * round_bf16(acc[1][hB][pt][qt][e]);
                     *reinterpret_cast<u32x2*>(p.Y + (size_t)m * p.N + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 }
+    }
+    else
+    {
+#pragma unroll
+        for (int hA = 0; hA < 2; ++hA)
+#pragma unroll
+            for (int hB = 0; hB < 2; ++hB)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                    {
+                        const int n = n0 + hA * 128 + wr * 64 + pt * 16 + 4 * g;
+                        const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[hA][hB][pt][qt][e];
+                        if (p.bias)
+                        {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
+                        }
+                        *reinterpret_cast<u32x2*>(p.Y + (size_t)m * p.N + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    }
+    }
 }
 
 // one 512-thread workgroup per CU: worth it only when the tile count fills whole rounds of 256 CUs
@@ -193,19 +219,39 @@ bool gemm256_applicable(int M, int K, int N)
     return tiles >= 200 && tiles >= 0.85 * rounds * kNumCU;
 }
 
-int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
+template <bool GEGLU>
+static int launch_gemm256_t(const Gemm256Params& p, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set)
     {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                2 * kBufBytes), "hipFuncSetAttribute(gemm256)");
         if (rc) return rc;
         attr_set = true;
     }
-    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, N / 256};
-    hipLaunchKernelGGL(gemm256_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), 2 * kBufBytes, s, p);
+    hipLaunchKernelGGL(gemm256_kernel<GEGLU>, dim3(p.tiles_m * p.tiles_n), dim3(512), 2 * kBufBytes, s, p);
     MILA_LAUNCH_CHECK("gemm256");
+}
+
+int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
+{
+    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, N / 256};
+    return launch_gemm256_t<false>(p, s);
+}
+
+// Y[M, F] = GeGLU(X W^T), W = [gate rows 0 .. F-1 | up rows F .. 2F-1]
+bool gemm256_geglu_applicable(int M, int K, int F)
+{
+    if (M % 256 != 0 || F % 128 != 0 || K % 64 != 0) return false;
+    const int tiles = (M / 256) * (F / 128);
+    const int rounds = (tiles + kNumCU - 1) / kNumCU;
+    return tiles >= 200 && tiles >= 0.85 * rounds * kNumCU;
+}
+int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s)
+{
+    Gemm256Params p{Y, X, W, nullptr, M, K, F, M / 256, F / 128};
+    return launch_gemm256_t<true>(p, s);
 }
 
 }  // namespace mila

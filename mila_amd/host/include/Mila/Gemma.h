@@ -462,9 +462,31 @@ namespace Mila::Dnn
             auto res1 = res1_->view( shape_t{ 1, T, D } );
             Compute::rocmCheck( mila_cdna4_residual_bf16( res1.data(), x3.data(), o_normed.data(), (int64_t)T * D, st ) );
             auto& ffn_in = L.pre_ffn_norm->forward( res1 );
-            auto& gate_up = L.fc_gate_up->forward( ffn_in );
             auto act = geglu_->view( shape_t{ 1, T, cfg_.hidden_dim } );
-            Compute::rocmCheck( mila_cdna4_geglu_bf16( act.data(), gate_up.data(), T, (int)cfg_.hidden_dim, st ) );
+            if ( mila_cdna4_gemm_geglu_applicable( T, (int)D, (int)cfg_.hidden_dim ) )
+            {
+                // Linear + GeGLU in one kernel: the [T, 2F] gate|up intermediate never reaches memory (bit-identical to the pair)
+                const int F = (int)cfg_.hidden_dim;
+                const void* W = L.fc_gate_up->getWeight().rawData();
+                if constexpr ( kFmt == 0 )
+                    Compute::rocmCheck( mila_cdna4_gemm_geglu_bf16( act.data(), ffn_in.data(), static_cast<const uint16_t*>( W ), T, (int)D, F, st ) );
+                else
+                {
+                    const size_t need = (size_t)2 * F * D * 2;
+                    void* scratch = ctx_->getScratch( need );
+                    if constexpr ( kFmt == 1 )
+                        Compute::rocmCheck( mila_cdna4_gemm_geglu_bf16_w8a16_staged( act.data(), ffn_in.data(), static_cast<const uint8_t*>( W ), L.fc_gate_up->getWeightScale()->data(),
+                                                                                     T, (int)D, F, scratch, need, st ) );
+                    else
+                        Compute::rocmCheck( mila_cdna4_gemm_geglu_bf16_w4a16_staged( act.data(), ffn_in.data(), static_cast<const uint8_t*>( W ), L.fc_gate_up->getWeightScale()->data(),
+                                                                                     T, (int)D, F, Quant::Weight::groupSizeOf<TWeightQuant>(), scratch, need, st ) );
+                }
+            }
+            else
+            {
+                auto& gate_up = L.fc_gate_up->forward( ffn_in );
+                Compute::rocmCheck( mila_cdna4_geglu_bf16( act.data(), gate_up.data(), T, (int)cfg_.hidden_dim, st ) );
+            }
             auto& ffn = L.fc_down->forward( act );
             auto& ffn_normed = L.post_ffn_norm->forward( ffn );
             auto res2 = res2_->view( shape_t{ 1, T, D } );

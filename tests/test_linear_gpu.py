@@ -393,3 +393,45 @@ def test_staged_quantized_gemm_equals_register_dequantizing_gemm(M, K, N):
         assert_bf16_close(bits(Ys)[rows], orc.linear_bf16w(X[rows], Wdq), 1, 2e-3, "staged gemm vs oracle")
     with pytest.raises(capi.MilaError):
         capi.call("gemm_bf16_w8a16_staged", Ys, Xd, dev_u8(q), dev_f32(s[:, 0].copy() if s.ndim > 1 else s), None, M, K, N, scratch, C.c_size_t(16))
+
+
+@pytest.mark.parametrize("M,K,F", [(512, 256, 15360), (2048, 128, 3584)])
+def test_gemm_with_geglu_epilogue_is_bit_identical_to_gemm_then_geglu(M, K, F):
+    """prefill fc_gate_up + GeGLU in one kernel (Gemma.Block.ixx:343-348): a tile pairs 128 gate rows with the matching
+    128 up rows, so the [M, 2F] intermediate never reaches memory; the K loop of every output is unchanged -> same bits as
+    gemm_bf16 (256-tile kernel) followed by geglu_bf16, for bf16 weights and for the two staged quantized formats"""
+    lib = capi.load()
+    assert lib.mila_cdna4_gemm_geglu_applicable(M, K, F) == 1
+    assert lib.mila_cdna4_gemm_geglu_applicable(M, K, F + 64) == 0 and lib.mila_cdna4_gemm_geglu_applicable(100, K, F) == 0
+    rng = np.random.default_rng(F)
+    Wb = _weights(rng, 2 * F, K, "random")
+    X = orc.round_bf16(rng.uniform(-2, 2, (M, K)).astype(np.float32))
+    Xd = dev_u16(orc.to_bf16_bits(X))
+    need = 2 * F * K * 2
+    scratch = torch.empty(need, dtype=torch.uint8, device="cuda")
+    for fmt in (0, 1, 2):
+        GU, Y0, Y1 = empty_u16(M, 2 * F), empty_u16(M, F), empty_u16(M, F)
+        if fmt == 0:
+            Wd = dev_u16(Wb)
+            capi.call("gemm_bf16", GU, Xd, Wd, None, M, K, 2 * F)
+            capi.call("gemm_geglu_bf16", Y1, Xd, Wd, M, K, F)
+            Wdq = Wb
+        elif fmt == 1:
+            q, s = orc.quantize_fp8_per_channel(Wb)
+            capi.call("gemm_bf16_w8a16_staged", GU, Xd, dev_u8(q), dev_f32(s), None, M, K, 2 * F, scratch, C.c_size_t(need))
+            capi.call("gemm_geglu_bf16_w8a16_staged", Y1, Xd, dev_u8(q), dev_f32(s), M, K, F, scratch, C.c_size_t(need))
+            Wdq = orc.to_bf16_bits(orc.dequant_fp8(q, s))
+        else:
+            q, s = orc.quantize_fp4_per_group(Wb, 128)
+            capi.call("gemm_bf16_w4a16_staged", GU, Xd, dev_u8(q), dev_f32(s), None, M, K, 2 * F, 128, scratch, C.c_size_t(need))
+            capi.call("gemm_geglu_bf16_w4a16_staged", Y1, Xd, dev_u8(q), dev_f32(s), M, K, F, 128, scratch, C.c_size_t(need))
+            Wdq = orc.to_bf16_bits(orc.dequant_fp4(q, s, 128))
+        capi.call("geglu_bf16", Y0, GU, M, F)
+        assert np.array_equal(bits(Y0), bits(Y1)), "fmt %d: fused GeGLU epilogue differs from gemm + geglu" % fmt
+        rows = [0, 129, M - 1]
+        gu = orc.round_bf16(orc.linear_bf16w(X[rows], Wdq).astype(np.float32)).astype(np.float64)
+        g_, u_ = gu[:, :F], gu[:, F:]
+        exp = 0.5 * g_ * (1 + np.tanh(0.7978845608028654 * (g_ + 0.044715 * g_ ** 3))) * u_
+        assert_bf16_close(bits(Y1)[rows], exp, 2, 2e-3, "gemm+geglu vs oracle fmt %d" % fmt)
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("gemm_geglu_bf16", Y1, Xd, dev_u16(Wb), M, K, F + 64)
