@@ -266,9 +266,24 @@ static int launch_gemm(GemmParams p, hipStream_t s)
 
 bool gemm256_applicable(int M, int K, int N);
 int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s);
+bool gemm256x128_applicable(int M, int K, int N);
+int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s);
 bool gemm256_geglu_applicable(int M, int K, int F);
 int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s);
 static int g_gemm_force128 = 0;
+
+// which direct-to-LDS kernel serves a bf16-weight GEMM of this shape: 2 = 256 x 256, 1 = 256 x 128, 0 = none (128 x 128 register-staged)
+static int glds_kernel_for(int M, int K, int N)
+{
+    if (g_gemm_force128) return 0;
+    if (gemm256_applicable(M, K, N)) return 2;
+    if (gemm256x128_applicable(M, K, N)) return 1;
+    return 0;
+}
+static int launch_glds(int which, uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
+{
+    return which == 2 ? launch_gemm256(Y, X, W, bias, M, K, N, s) : launch_gemm256x128(Y, X, W, bias, M, K, N, s);
+}
 
 // ---- 2-phase staging (the reference's own prefill structure for quantized weights,
 // OPS/Linear/CudaLinearOp.ixx:597-644, :716-764): dequantize the whole matrix to bf16 scratch, then the bf16 GEMM.
@@ -346,7 +361,7 @@ int mila_cdna4_gemm_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, cons
 {
     int rc = validate_gemm("gemm_bf16", Y, X, W, M, K, N);
     if (rc) return rc;
-    if (!g_gemm_force128 && gemm256_applicable(M, K, N)) return launch_gemm256(Y, X, W, bias, M, K, N, as_stream(stream));
+    if (const int which = glds_kernel_for(M, K, N)) return launch_glds(which, Y, X, W, bias, M, K, N, as_stream(stream));
     GemmParams p{Y, X, reinterpret_cast<const uint8_t*>(W), nullptr, bias, M, K, N, 0, 0, 0};
     return launch_gemm<G_BF16>(p, as_stream(stream));
 }
@@ -375,7 +390,7 @@ int mila_cdna4_gemm_bf16_w4a16(uint16_t* Y, const uint16_t* X, const uint8_t* W_
 
 size_t mila_cdna4_gemm_staging_bytes(int M, int K, int N)
 {
-    return (!g_gemm_force128 && gemm256_applicable(M, K, N)) ? (size_t)N * K * 2 : 0;
+    return glds_kernel_for(M, K, N) ? (size_t)N * K * 2 : 0;
 }
 
 int mila_cdna4_gemm_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W, const float* scales, const uint16_t* bias,
@@ -393,7 +408,7 @@ int mila_cdna4_gemm_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, const uint
                        total_vec, K / 16);
     rc = check_hip(hipGetLastError(), "dequant_fp8");
     if (rc) return rc;
-    return launch_gemm256(Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream));
+    return launch_glds(glds_kernel_for(M, K, N), Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream));
 }
 
 int mila_cdna4_gemm_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed, const float* scales,
@@ -414,7 +429,7 @@ int mila_cdna4_gemm_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, const uint
                        scales, total_vec, group / 32);
     rc = check_hip(hipGetLastError(), "dequant_fp4");
     if (rc) return rc;
-    return launch_gemm256(Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream));
+    return launch_glds(glds_kernel_for(M, K, N), Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream));
 }
 
 /* ---- Linear + GeGLU in one kernel (prefill fc_gate_up): Y[M, F] = GeGLU(X W^T), W = [gate | up] rows ---- */

@@ -210,6 +210,159 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     }
 }
 
+// ---- 256 (M) x 128 (N) x 64 tile: shapes whose N leaves the 256 x 256 grid half empty (Gemma o_proj / fc_down, N = 3840:
+// 8 x 15 = 120 tiles) get 8 x 30 = 240 tiles, one per CU.  Same 8 waves (2 over the 128 W rows x 4 over 32 X rows of each
+// X half), same swizzled half-tiles and fragment reads; the K pipeline is a 3-stage ring of {W, X0, X1} half-tiles
+// (3 x 48 KB): K-tile t + 2 is requested at the top of K-tile t, ONE s_waitcnt vmcnt(6) + barrier per K-tile retires
+// K-tile t + 1 while t + 2 stays in flight.
+constexpr int kStage3Bytes = 3 * kHalfBytes;   // W, X0, X1
+
+__global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int xcd = id & 7, qd = nwg >> 3, rem = nwg & 7;
+    const int tile = ((xcd < rem) ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (id >> 3);
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int m0 = tm * 256, n0 = tn * 128;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int K = p.K, nk = K / 64;
+
+    const int srow = lane >> 3, sslot = lane & 7;
+    // which: 0 = W rows n0 .., 1 = X rows m0 .., 2 = X rows m0 + 128 ..
+    auto stage = [&](int kt, int which) {
+        const uint16_t* base = which == 0 ? p.W + (size_t)n0 * K : p.X + (size_t)(m0 + (which - 1) * 128) * K;
+        unsigned char* dst_half = smem + (kt % 3) * kStage3Bytes + which * kHalfBytes;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+        {
+            const int chunk = i * 8 + wave;
+            const int row = chunk * 8 + srow;
+            const int kslot = sslot ^ ((row >> 1) & 7);
+            const uint16_t* src = base + (size_t)row * K + (size_t)kt * 64 + kslot * 8;
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(dst_half + chunk * 1024), 16, 0, 0);
+        }
+    };
+    auto stage_all = [&](int kt) { stage(kt, 0); stage(kt, 1); stage(kt, 2); };
+
+    f32x4 acc[2][4][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) acc[b][c][d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    s16x8 fa[4][2], fb[2][2];
+    auto load_a = [&](int kt) {
+        const unsigned char* hb = smem + (kt % 3) * kStage3Bytes;
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+        {
+            const int r = wr * 64 + pt * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                fa[pt][ks] = *reinterpret_cast<const s16x8*>(hb + r * 128 + (((ks * 4 + g) ^ ((r >> 1) & 7)) << 4));
+        }
+    };
+    auto load_b = [&](int kt, int hB) {
+        const unsigned char* hb = smem + (kt % 3) * kStage3Bytes + (1 + hB) * kHalfBytes;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+        {
+            const int r = wc * 32 + qt * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                fb[qt][ks] = *reinterpret_cast<const s16x8*>(hb + r * 128 + (((ks * 4 + g) ^ ((r >> 1) & 7)) << 4));
+        }
+    };
+    auto mma = [&](int hB) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    acc[hB][pt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fa[pt][ks]), __builtin_bit_cast(bf16x8, fb[qt][ks]), acc[hB][pt][qt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    stage_all(0);
+    if (nk > 1) stage_all(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int t = 0; t < nk; ++t)
+    {
+        const bool more = t + 2 < nk;
+        if (more) stage_all(t + 2);
+        load_a(t);
+        load_b(t, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0);
+        load_b(t, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1);
+        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+#pragma unroll
+    for (int hB = 0; hB < 2; ++hB)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+            {
+                const int n = n0 + wr * 64 + pt * 16 + 4 * g;
+                const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[hB][pt][qt][e];
+                if (p.bias)
+                {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
+                }
+                *reinterpret_cast<u32x2*>(p.Y + (size_t)m * p.N + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+}
+
+// taken when the 256 x 256 grid does not apply and the 256 x 128 grid fills most of one round of CUs (or several)
+bool gemm256x128_applicable(int M, int K, int N)
+{
+    if (M % 256 != 0 || N % 128 != 0 || K % 64 != 0) return false;
+    const int tiles = (M / 256) * (N / 128);
+    const int rounds = (tiles + kNumCU - 1) / kNumCU;
+    return tiles >= 200 && tiles >= 0.70 * rounds * kNumCU;
+}
+
+int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set)
+    {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               3 * kStage3Bytes), "hipFuncSetAttribute(gemm256x128)");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, N / 128};
+    hipLaunchKernelGGL(gemm256x128_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), 3 * kStage3Bytes, s, p);
+    MILA_LAUNCH_CHECK("gemm256x128");
+}
+
 // one 512-thread workgroup per CU: worth it only when the tile count fills whole rounds of 256 CUs
 bool gemm256_applicable(int M, int K, int N)
 {

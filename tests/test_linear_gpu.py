@@ -324,7 +324,7 @@ def test_invalid_arguments_are_reported_not_launched():
         capi.call("quantize_fp4_per_group", y, y, y, 2, 100, 128)
 
 
-@pytest.mark.parametrize("M,K,N,bias", [(2048, 128, 8192, False), (512, 3840, 30720, True), (256, 64, 51200, False)])
+@pytest.mark.parametrize("M,K,N,bias", [(2048, 128, 8192, False), (512, 3840, 30720, True), (256, 64, 51200, False), (2048, 192, 3840, True), (2048, 64, 3840, False), (512, 320, 14848, False)])
 def test_gemm_256_tile_kernel_agrees_with_the_128_tile_kernel(M, K, N, bias):
     """shapes with >= 200 tiles of 256 x 256 take the direct-to-LDS 8-wave kernel; same products, fp32
     accumulation in a different order -> equal to the register-staged kernel within 1 bf16 ulp, and to the
@@ -360,7 +360,7 @@ def test_gemm_256_tile_kernel_agrees_with_the_128_tile_kernel(M, K, N, bias):
     assert_bf16_close(bits(Y256)[rows], exp, 2 if bias else 1, 2e-3, "gemm256 vs oracle")
 
 
-@pytest.mark.parametrize("M,K,N", [(2048, 128, 8192), (512, 256, 30720)])
+@pytest.mark.parametrize("M,K,N", [(2048, 128, 8192), (512, 256, 30720), (2048, 128, 3840)])
 def test_staged_quantized_gemm_equals_register_dequantizing_gemm(M, K, N):
     """2-phase (dequantize to scratch + LDS-DMA GEMM) vs the fused 128-tile kernel: both multiply the same
     bf16-rounded weights; within 1 bf16 ulp of each other (summation order differs)"""
