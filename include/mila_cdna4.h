@@ -328,6 +328,21 @@ MILA_API int mila_cdna4_fused_qkv_post(uint16_t* q_out, uint16_t* Kc, uint16_t* 
                                        int capacity, float eps, mila_stream_t stream);
 
 
+/* Prefill forms of the two glue fusions above, T rows per launch (B == 1), bit-identical to the unfused launches:
+ *   fused_qkv_post_prefill: for token t < T at position pos_offset + t, q/k/v_src rows at + t * src_row_stride elements
+ *     (the packed qkv_proj output: no split3 copy), q_out[t] <- rope(rmsnorm(q)), cache row <- (rope(rmsnorm(k)), rmsnorm(v_src))
+ *     -- replaces split3 + q_norm + k_norm + v_norm + rope.prefill + kv_write (Gemma.Block.ixx:215-262);
+ *   fused_tail_norm_bf16: R = bf16(bf16(RES + bf16(rmsnorm(A; post_w))) * post_scale), XN = rmsnorm(R; next_w) (XN / next_w
+ *     may both be NULL) -- replaces RmsNorm + Residual (+ scale) + RmsNorm (Gemma.Block.ixx:339-356, :287-289); 1024 < dim <= 8192. */
+MILA_API int mila_cdna4_fused_qkv_post_prefill(uint16_t* q_out, uint16_t* Kc, uint16_t* Vc, const uint16_t* q,
+                                               const uint16_t* k, const uint16_t* v_src, int64_t src_row_stride,
+                                               const uint16_t* qw, const uint16_t* kw, const uint16_t* vw,
+                                               const float* cos_cache, const float* sin_cache, int T, int NH, int NKV,
+                                               int HS, int pos_offset, int capacity, float eps, mila_stream_t stream);
+MILA_API int mila_cdna4_fused_tail_norm_bf16(uint16_t* R, uint16_t* XN, const uint16_t* A, const uint16_t* RES,
+                                             const uint16_t* post_w, const uint16_t* next_w, int rows, int dim,
+                                             float post_scale, float eps, mila_stream_t stream);
+
 /* Graph-replay forms: the decode position lives in DEVICE memory so that one captured hipGraph
  * serves every step (the reference re-launches ~1100 kernels per token from the host,
  * SPEC/Gemma4InferenceReview.md:71-84).  `max_len` fixes the split count at capture time; splits past

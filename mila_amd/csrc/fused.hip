@@ -27,6 +27,8 @@ struct QkvPostParams
     const int32_t* pos_dev;   // when set, the position is read from device memory (graph replay)
     int NH, NKV, HS, position, capacity;
     float eps;
+    // prefill form: token t = blockIdx.y at position + t reads its q/k/v at + t * src_row_stride and writes q_out at + t * NH * HS
+    int64_t src_row_stride;
 };
 
 __global__ void advance_position_kernel(int32_t* pos) { *pos += 1; }
@@ -38,8 +40,10 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostParams p)
     const int lane = threadIdx.x & 63;
     const int HS = p.HS, half = HS / 2, hv = half / 8;
     if (r >= p.NH + 2 * p.NKV) return;
-    const int position = p.pos_dev ? *p.pos_dev : p.position;
+    const int t = blockIdx.y;
+    const int position = (p.pos_dev ? *p.pos_dev : p.position) + t;
     const int row = position % p.capacity;
+    const size_t src_t = (size_t)t * p.src_row_stride;
     const float* cos_row = p.cos_cache + (size_t)position * half;
     const float* sin_row = p.sin_cache + (size_t)position * half;
     const uint16_t* src;
@@ -48,17 +52,17 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostParams p)
     bool rotate;
     if (r < p.NH)
     {
-        src = p.q + (size_t)r * HS; w = p.qw; dst = p.q_out + (size_t)r * HS; rotate = true;
+        src = p.q + src_t + (size_t)r * HS; w = p.qw; dst = p.q_out + ((size_t)t * p.NH + r) * HS; rotate = true;
     }
     else if (r < p.NH + p.NKV)
     {
         const int n = r - p.NH;
-        src = p.k + (size_t)n * HS; w = p.kw; dst = p.Kc + ((size_t)n * p.capacity + row) * HS; rotate = true;
+        src = p.k + src_t + (size_t)n * HS; w = p.kw; dst = p.Kc + ((size_t)n * p.capacity + row) * HS; rotate = true;
     }
     else
     {
         const int n = r - p.NH - p.NKV;
-        src = p.v_src + (size_t)n * HS; w = p.vw; dst = p.Vc + ((size_t)n * p.capacity + row) * HS; rotate = false;
+        src = p.v_src + src_t + (size_t)n * HS; w = p.vw; dst = p.Vc + ((size_t)n * p.capacity + row) * HS; rotate = false;
     }
     // apply-phase operands are requested first so their latency overlaps the reduction's
     const bool act = lane < hv;
@@ -100,10 +104,26 @@ int mila_cdna4_fused_qkv_post(uint16_t* q_out, uint16_t* Kc, uint16_t* Vc, const
     MILA_REQUIRE(q_out && Kc && Vc && q && k && v_src && qw && kw && cos_cache && sin_cache, "fused_qkv_post: null pointer");
     MILA_REQUIRE(NH > 0 && NKV > 0 && capacity > 0 && position >= 0, "fused_qkv_post: bad sizes");
     MILA_REQUIRE(HS % 16 == 0 && HS >= 16 && HS <= 1024, "fused_qkv_post: HS=%d must be a multiple of 16 in [16,1024]", HS);
-    QkvPostParams p{q_out, Kc, Vc, q, k, v_src, qw, kw, vw, cos_cache, sin_cache, nullptr, NH, NKV, HS, position, capacity, eps};
+    QkvPostParams p{q_out, Kc, Vc, q, k, v_src, qw, kw, vw, cos_cache, sin_cache, nullptr, NH, NKV, HS, position, capacity, eps, 0};
     const int rows = NH + 2 * NKV;
     hipLaunchKernelGGL(qkv_post_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, as_stream(stream), p);
     MILA_LAUNCH_CHECK("fused_qkv_post");
+}
+
+int mila_cdna4_fused_qkv_post_prefill(uint16_t* q_out, uint16_t* Kc, uint16_t* Vc, const uint16_t* q, const uint16_t* k,
+                                      const uint16_t* v_src, int64_t src_row_stride, const uint16_t* qw, const uint16_t* kw,
+                                      const uint16_t* vw, const float* cos_cache, const float* sin_cache, int T, int NH, int NKV,
+                                      int HS, int pos_offset, int capacity, float eps, mila_stream_t stream)
+{
+    MILA_REQUIRE(q_out && Kc && Vc && q && k && v_src && qw && kw && cos_cache && sin_cache, "fused_qkv_post_prefill: null pointer");
+    MILA_REQUIRE(T > 0 && T <= 65535 && NH > 0 && NKV > 0 && capacity > 0 && pos_offset >= 0, "fused_qkv_post_prefill: bad sizes");
+    MILA_REQUIRE(T <= capacity, "fused_qkv_post_prefill: %d tokens do not fit the cache capacity %d", T, capacity);
+    MILA_REQUIRE(HS % 16 == 0 && HS >= 16 && HS <= 1024, "fused_qkv_post_prefill: HS=%d must be a multiple of 16 in [16,1024]", HS);
+    MILA_REQUIRE(src_row_stride % 8 == 0 && src_row_stride >= (int64_t)HS, "fused_qkv_post_prefill: row stride %lld must be a multiple of 8", (long long)src_row_stride);
+    QkvPostParams p{q_out, Kc, Vc, q, k, v_src, qw, kw, vw, cos_cache, sin_cache, nullptr, NH, NKV, HS, pos_offset, capacity, eps, src_row_stride};
+    const int rows = NH + 2 * NKV;
+    hipLaunchKernelGGL(qkv_post_kernel, dim3(ceil_div(rows, 4), T), dim3(256), 0, as_stream(stream), p);
+    MILA_LAUNCH_CHECK("fused_qkv_post_prefill");
 }
 
 int mila_cdna4_fused_qkv_post_devpos(uint16_t* q_out, uint16_t* Kc, uint16_t* Vc, const uint16_t* q, const uint16_t* k,
@@ -115,7 +135,7 @@ int mila_cdna4_fused_qkv_post_devpos(uint16_t* q_out, uint16_t* Kc, uint16_t* Vc
                  "fused_qkv_post_devpos: null pointer");
     MILA_REQUIRE(NH > 0 && NKV > 0 && capacity > 0, "fused_qkv_post_devpos: bad sizes");
     MILA_REQUIRE(HS % 16 == 0 && HS >= 16 && HS <= 1024, "fused_qkv_post_devpos: HS=%d must be a multiple of 16 in [16,1024]", HS);
-    QkvPostParams p{q_out, Kc, Vc, q, k, v_src, qw, kw, vw, cos_cache, sin_cache, position_dev, NH, NKV, HS, 0, capacity, eps};
+    QkvPostParams p{q_out, Kc, Vc, q, k, v_src, qw, kw, vw, cos_cache, sin_cache, position_dev, NH, NKV, HS, 0, capacity, eps, 0};
     const int rows = NH + 2 * NKV;
     hipLaunchKernelGGL(qkv_post_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, as_stream(stream), p);
     MILA_LAUNCH_CHECK("fused_qkv_post_devpos");

@@ -201,20 +201,6 @@ __device__ __forceinline__ void matvec_body(const MatvecParams& p, u32x4* xs, fl
             px[k] = handoff_load8(reinterpret_cast<const uint32_t*>(p.x), min(tid + 1024 * k, nx16 - 1));
     }
 
-    // r = bf16(bf16(res + a) * post_scale) on 8 elements (sandwich tail)
-    auto tail8 = [&](const u32x4 a, const u32x4 rr) {
-        u32x4 r;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-        {
-            float lo = round_bf16(bf16_lo(rr[d]) + bf16_lo(a[d]));
-            float hi = round_bf16(bf16_hi(rr[d]) + bf16_hi(a[d]));
-            if (p.post_scale != 1.0f) { lo = lo * p.post_scale; hi = hi * p.post_scale; }
-            r[d] = pack_bf16x2(lo, hi);
-        }
-        return r;
-    };
-
     // ---- stage x into LDS (optionally through the fused RMSNorm prologue), zero-pad the tail ----
     for (int i = nx16 + tid; i < nx16_pad; i += 1024) xs[i] = u32x4{0u, 0u, 0u, 0u};
     if constexpr (PRO == 0)
@@ -251,7 +237,7 @@ __device__ __forceinline__ void matvec_body(const MatvecParams& p, u32x4* xs, fl
         {
             const float rstd_a = rstd_of(px, red_a);
 #pragma unroll
-            for (int k = 0; k < XC; ++k) rkeep[k] = tail8(rms_apply8(px[k], ppw[k], rstd_a, 0.0f), pres[k]);
+            for (int k = 0; k < XC; ++k) rkeep[k] = sandwich_tail8(rms_apply8(px[k], ppw[k], rstd_a, 0.0f), pres[k], p.post_scale);
             if (block == 0 && p.res_out != nullptr)
             {
 #pragma unroll

@@ -36,6 +36,73 @@ __global__ __launch_bounds__(256) void rmsnorm_block_kernel(uint16_t* __restrict
     }
 }
 
+// Sandwich tail over T rows (prefill form of the decode matvec prologue): per row
+//   r  = bf16(bf16(res + bf16(rmsnorm(a; post_w))) * post_scale)          -> R
+//   xn = bf16(rmsnorm(r; next_w))                                         -> XN (when next_w != NULL)
+// replaces RmsNorm + Residual (+ scale) + RmsNorm of Gemma.Block.ixx:339-356 / :287-289; same canonical reductions
+// (rms_rstd_block) and element functions, so the outputs carry the same bits as the unfused launches.
+// One workgroup per row, dim <= 8 * 256 * kTailChunks.
+constexpr int kTailChunks = 4;
+__global__ __launch_bounds__(256) void tail_norm_kernel(uint16_t* __restrict__ R, uint16_t* __restrict__ XN,
+                                                        const uint16_t* __restrict__ A, const uint16_t* __restrict__ RES,
+                                                        const uint16_t* __restrict__ post_w, const uint16_t* __restrict__ next_w,
+                                                        int dim, float post_scale, float eps)
+{
+    __shared__ float red_a[kRmsBlockMaxGroups], red_b[kRmsBlockMaxGroups];
+    const size_t row = blockIdx.x;
+    const uint16_t* a = A + row * dim;
+    const uint16_t* res = RES + row * dim;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int nx16 = dim / 8, G = (nx16 + 63) / 64;
+    // chunk c = 64 g + lane of group g = wib + 4 k: the assignment rms_rstd_block<4> uses
+    u32x4 av[kTailChunks], rv[kTailChunks];
+#pragma unroll
+    for (int k = 0; k < kTailChunks; ++k)
+    {
+        const int c = 64 * (wib + 4 * k) + lane;
+        av[k] = ld16(a + (size_t)min(c, nx16 - 1) * 8);
+    }
+    {
+#pragma unroll
+        for (int k = 0; k < kTailChunks; ++k)
+        {
+            const int g = wib + 4 * k, c = 64 * g + lane;
+            float s = c < nx16 ? sumsq8(av[k], 0.0f) : 0.0f;
+            s = wave_sum(s);
+            if (lane == 0 && g < G) red_a[g] = s;
+        }
+        __syncthreads();
+    }
+    float t = 0.0f;
+    for (int g = 0; g < G; ++g) t += red_a[g];
+    const float rstd_a = rsqrtf(t / (float)dim + eps);
+#pragma unroll
+    for (int k = 0; k < kTailChunks; ++k)
+    {
+        const int g = wib + 4 * k, c = 64 * g + lane;
+        const size_t e = (size_t)min(c, nx16 - 1) * 8;
+        rv[k] = sandwich_tail8(rms_apply8(av[k], ld16(post_w + e), rstd_a, 0.0f), ld16(res + e), post_scale);
+        if (c < nx16) st16(R + row * dim + e, rv[k]);
+        if (next_w != nullptr)
+        {
+            float s = c < nx16 ? sumsq8(rv[k], 0.0f) : 0.0f;
+            s = wave_sum(s);
+            if (lane == 0 && g < G) red_b[g] = s;
+        }
+    }
+    if (next_w == nullptr) return;
+    __syncthreads();
+    float t2 = 0.0f;
+    for (int g = 0; g < G; ++g) t2 += red_b[g];
+    const float rstd_r = rsqrtf(t2 / (float)dim + eps);
+#pragma unroll
+    for (int k = 0; k < kTailChunks; ++k)
+    {
+        const int c = 64 * (wib + 4 * k) + lane;
+        if (c < nx16) st16(XN + row * dim + (size_t)c * 8, rms_apply8(rv[k], ld16(next_w + (size_t)c * 8), rstd_r, 0.0f));
+    }
+}
+
 // wave per row, 4 rows per workgroup
 __global__ __launch_bounds__(256) void rmsnorm_wave_kernel(uint16_t* __restrict__ Y, uint16_t* __restrict__ rstd_out,
                                                            const uint16_t* __restrict__ X,
@@ -182,6 +249,17 @@ int mila_cdna4_rmsnorm_bf16(uint16_t* Y, uint16_t* rstd, const uint16_t* X, cons
                            (int)slices, dim, inner, eps, w_offset);
     }
     MILA_LAUNCH_CHECK("rmsnorm_bf16");
+}
+
+int mila_cdna4_fused_tail_norm_bf16(uint16_t* R, uint16_t* XN, const uint16_t* A, const uint16_t* RES, const uint16_t* post_w,
+                                    const uint16_t* next_w, int rows, int dim, float post_scale, float eps, mila_stream_t stream)
+{
+    MILA_REQUIRE(R && A && RES && post_w, "fused_tail_norm_bf16: null pointer");
+    MILA_REQUIRE((XN == nullptr) == (next_w == nullptr), "fused_tail_norm_bf16: XN and next_w go together");
+    MILA_REQUIRE(rows > 0 && dim > 0, "fused_tail_norm_bf16: rows/dim must be positive (%d,%d)", rows, dim);
+    MILA_REQUIRE(dim % 8 == 0 && dim > 1024 && dim <= 8 * 256 * kTailChunks, "fused_tail_norm_bf16: dim=%d must be a multiple of 8 in (1024, %d]", dim, 8 * 256 * kTailChunks);
+    hipLaunchKernelGGL(tail_norm_kernel, dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps);
+    MILA_LAUNCH_CHECK("fused_tail_norm_bf16");
 }
 
 int mila_cdna4_layernorm_bf16(uint16_t* Y, float* mean, float* rstd, const uint16_t* X, const uint16_t* w,

@@ -76,6 +76,22 @@ __device__ __forceinline__ u32x4 rms_apply8_bias(const u32x4 x, const u32x4 w, c
                            rms_apply1(bf16_hi(x[d]), bf16_hi(w[d]), rstd, w_offset, bf16_hi(b[d])));
     return y;
 }
+// sandwich tail on 8 elements: r = bf16(bf16(res + a) * post_scale), the residual add and the layer scalar of
+// Gemma.Block.ixx:339-356 as two roundings (Residual op, then the scale op); post_scale == 1 skips the second
+__device__ __forceinline__ u32x4 sandwich_tail8(const u32x4 a, const u32x4 rr, float post_scale)
+{
+    u32x4 r;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+    {
+        float lo = round_bf16(bf16_lo(rr[d]) + bf16_lo(a[d]));
+        float hi = round_bf16(bf16_hi(rr[d]) + bf16_hi(a[d]));
+        if (post_scale != 1.0f) { lo = lo * post_scale; hi = hi * post_scale; }
+        r[d] = pack_bf16x2(lo, hi);
+    }
+    return r;
+}
+
 // no weight tensor: w == 1 (the reference kernel's `weight ? ... : 1.0f`)
 __device__ __forceinline__ u32x4 rms_apply8_now(const u32x4 x, float rstd)
 {

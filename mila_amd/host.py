@@ -45,6 +45,7 @@ def load():
         _lib.mila_gemma_generate.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         _lib.mila_gemma_set_chain.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_uses_chain.argtypes = [C.c_void_p]
+        _lib.mila_gemma_set_fused_prefill.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gpt_last_error.restype = C.c_char_p
         _lib.mila_gpt_create.restype = C.c_void_p
         _lib.mila_gpt_create.argtypes = [C.c_int64] * 7
@@ -94,6 +95,10 @@ class Gemma:
         """fused / graph decode with the four Linears between two attention calls as ONE launch (default when the
         configuration fits) or one launch per Linear; the two give identical bits.  Before the first graph decode."""
         _check(load().mila_gemma_set_chain(self.h, int(bool(on))))
+
+    def set_fused_prefill(self, on):
+        """prefill with the fused glue kernels (default, when 1024 < D <= 8192) or one launch per reference op; same bits"""
+        _check(load().mila_gemma_set_fused_prefill(self.h, int(bool(on))))
 
     @property
     def uses_chain(self):

@@ -222,10 +222,12 @@ namespace Mila::Dnn
             embed( tokens.data(), static_cast<int>( T ), *pf_x_[ 0 ] );
             TensorType* x = pf_x_[ 0 ].get();
             int flip = 0;
-            for ( auto& L : layers_ )
+            const bool fused = fused_prefill_ && fusedPrefillApplicable();
+            for ( size_t i = 0; i < layers_.size(); ++i )
             {
                 TensorType* out = pf_x_[ 1 - flip ].get();
-                blockPrefill( L, *x, *out, static_cast<int>( T ), static_cast<int>( position_offset ) );
+                if ( fused ) blockPrefillFused( layers_[ i ], *x, i > 0, *out, i + 1 < layers_.size() ? &layers_[ i + 1 ] : nullptr, static_cast<int>( T ), static_cast<int>( position_offset ) );
+                else blockPrefill( layers_[ i ], *x, *out, static_cast<int>( T ), static_cast<int>( position_offset ) );
                 x = out;
                 flip = 1 - flip;
             }
@@ -341,6 +343,8 @@ namespace Mila::Dnn
             attn_out_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, maxq } );
             res1_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
             res2_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
+            pf_norm_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
+            pf_norm2_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
             geglu_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, cfg_.hidden_dim } );
             f_qkv_ = std::make_unique<TensorType>( dev, shape_t{ std::max( cfg_.packedQkvWidth( false ), cfg_.packedQkvWidth( true ) ) } );
             f_q_ = std::make_unique<TensorType>( dev, shape_t{ maxq } );
@@ -436,6 +440,37 @@ namespace Mila::Dnn
         }
 
         // ---- reference-order block (prefill, T tokens) ------------------------------------------------
+        /// act[T, F] = GeGLU(fc_gate_up(ffn_in)): one kernel when the fused GEMM serves the shape, else Linear + GeGLU
+        void gateUpGeglu( Layer& L, TensorType& ffn_in, TensorType& act, int T )
+        {
+            const dim_t D = cfg_.embedding_dim;
+            mila_stream_t st = ctx_->getStream();
+            if ( mila_cdna4_gemm_geglu_applicable( T, (int)D, (int)cfg_.hidden_dim ) )
+            {
+                // Linear + GeGLU in one kernel: the [T, 2F] gate|up intermediate never reaches memory (bit-identical to the pair)
+                const int F = (int)cfg_.hidden_dim;
+                const void* W = L.fc_gate_up->getWeight().rawData();
+                if constexpr ( kFmt == 0 )
+                    Compute::rocmCheck( mila_cdna4_gemm_geglu_bf16( act.data(), ffn_in.data(), static_cast<const uint16_t*>( W ), T, (int)D, F, st ) );
+                else
+                {
+                    const size_t need = (size_t)2 * F * D * 2;
+                    void* scratch = ctx_->getScratch( need );
+                    if constexpr ( kFmt == 1 )
+                        Compute::rocmCheck( mila_cdna4_gemm_geglu_bf16_w8a16_staged( act.data(), ffn_in.data(), static_cast<const uint8_t*>( W ), L.fc_gate_up->getWeightScale()->data(),
+                                                                                     T, (int)D, F, scratch, need, st ) );
+                    else
+                        Compute::rocmCheck( mila_cdna4_gemm_geglu_bf16_w4a16_staged( act.data(), ffn_in.data(), static_cast<const uint8_t*>( W ), L.fc_gate_up->getWeightScale()->data(),
+                                                                                     T, (int)D, F, Quant::Weight::groupSizeOf<TWeightQuant>(), scratch, need, st ) );
+                }
+            }
+            else
+            {
+                auto& gate_up = L.fc_gate_up->forward( ffn_in );
+                Compute::rocmCheck( mila_cdna4_geglu_bf16( act.data(), gate_up.data(), T, (int)cfg_.hidden_dim, st ) );
+            }
+        }
+
         void blockPrefill( Layer& L, TensorType& input, TensorType& output, int T, int position_offset )
         {
             const bool g = L.global;
@@ -463,30 +498,7 @@ namespace Mila::Dnn
             Compute::rocmCheck( mila_cdna4_residual_bf16( res1.data(), x3.data(), o_normed.data(), (int64_t)T * D, st ) );
             auto& ffn_in = L.pre_ffn_norm->forward( res1 );
             auto act = geglu_->view( shape_t{ 1, T, cfg_.hidden_dim } );
-            if ( mila_cdna4_gemm_geglu_applicable( T, (int)D, (int)cfg_.hidden_dim ) )
-            {
-                // Linear + GeGLU in one kernel: the [T, 2F] gate|up intermediate never reaches memory (bit-identical to the pair)
-                const int F = (int)cfg_.hidden_dim;
-                const void* W = L.fc_gate_up->getWeight().rawData();
-                if constexpr ( kFmt == 0 )
-                    Compute::rocmCheck( mila_cdna4_gemm_geglu_bf16( act.data(), ffn_in.data(), static_cast<const uint16_t*>( W ), T, (int)D, F, st ) );
-                else
-                {
-                    const size_t need = (size_t)2 * F * D * 2;
-                    void* scratch = ctx_->getScratch( need );
-                    if constexpr ( kFmt == 1 )
-                        Compute::rocmCheck( mila_cdna4_gemm_geglu_bf16_w8a16_staged( act.data(), ffn_in.data(), static_cast<const uint8_t*>( W ), L.fc_gate_up->getWeightScale()->data(),
-                                                                                     T, (int)D, F, scratch, need, st ) );
-                    else
-                        Compute::rocmCheck( mila_cdna4_gemm_geglu_bf16_w4a16_staged( act.data(), ffn_in.data(), static_cast<const uint8_t*>( W ), L.fc_gate_up->getWeightScale()->data(),
-                                                                                     T, (int)D, F, Quant::Weight::groupSizeOf<TWeightQuant>(), scratch, need, st ) );
-                }
-            }
-            else
-            {
-                auto& gate_up = L.fc_gate_up->forward( ffn_in );
-                Compute::rocmCheck( mila_cdna4_geglu_bf16( act.data(), gate_up.data(), T, (int)cfg_.hidden_dim, st ) );
-            }
+            gateUpGeglu( L, ffn_in, act, T );
             auto& ffn = L.fc_down->forward( act );
             auto& ffn_normed = L.post_ffn_norm->forward( ffn );
             auto res2 = res2_->view( shape_t{ 1, T, D } );
@@ -494,6 +506,49 @@ namespace Mila::Dnn
             Compute::rocmCheck( mila_cdna4_scale_bf16( output.data(), res2.data(), (int64_t)T * D, L.layer_scalar, st ) );
         }
 
+        /// GemmaBlock::forward with the glue fused (bit-identical to blockPrefill): the packed qkv rows go straight through
+        /// q/k/v norm + RoPE into q and the KV cache (no split3 / kv_write), and each sandwich tail (RmsNorm + Residual
+        /// (+ layer scalar) + the next RmsNorm) is one launch.  `have_normed`: the previous block's tail already wrote
+        /// input_norm(input) into pf_norm_; `nextL`: the block whose input_norm the second tail applies.
+        void blockPrefillFused( Layer& L, TensorType& input, bool have_normed, TensorType& output, Layer* nextL, int T, int position_offset )
+        {
+            const bool g = L.global;
+            const dim_t NH = cfg_.num_heads, NKV = cfg_.numKvHeads( g ), HD = cfg_.headDim( g ), D = cfg_.embedding_dim;
+            mila_stream_t st = ctx_->getStream();
+            auto x3 = input.view( shape_t{ 1, T, D } );
+            auto normed_view = pf_norm_->view( shape_t{ 1, T, D } );
+            TensorType* normed = &normed_view;
+            if ( !have_normed ) normed = &L.input_norm->forward( x3 );
+            auto& qkv = L.qkv_proj->forward( *normed );
+            auto q = q_->view( shape_t{ 1, T, NH * HD } );
+            const uint16_t* qp = static_cast<const uint16_t*>( qkv.rawData() );
+            const uint16_t* kp = qp + (size_t)( NH * HD );
+            const uint16_t* vp = g ? kp : kp + (size_t)( NKV * HD );
+            Compute::rocmCheck( mila_cdna4_fused_qkv_post_prefill( q.data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, (int64_t)cfg_.packedQkvWidth( g ),
+                                                                   L.q_norm->getWeight()->data(), L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(),
+                                                                   L.rope->cosCache(), L.rope->sinCache(), T, (int)NH, (int)NKV, (int)HD, position_offset,
+                                                                   (int)L.attn->cacheCapacity(), cfg_.rms_norm_eps, st ) );
+            auto attn = attn_out_->view( shape_t{ 1, T, NH * HD } );
+            L.attn->prefillFromCache( q, attn, T, position_offset );
+            auto& o = L.o_proj->forward( attn );
+            auto res1 = res1_->view( shape_t{ 1, T, D } );
+            auto ffn_in = pf_norm2_->view( shape_t{ 1, T, D } );
+            Compute::rocmCheck( mila_cdna4_fused_tail_norm_bf16( res1.data(), ffn_in.data(), o.data(), x3.data(), L.post_attn_norm->getWeight()->data(),
+                                                                 L.pre_ffn_norm->getWeight()->data(), T, (int)D, 1.0f, cfg_.rms_norm_eps, st ) );
+            auto act = geglu_->view( shape_t{ 1, T, cfg_.hidden_dim } );
+            gateUpGeglu( L, ffn_in, act, T );
+            auto& ffn = L.fc_down->forward( act );
+            Compute::rocmCheck( mila_cdna4_fused_tail_norm_bf16( output.data(), nextL ? pf_norm_->data() : nullptr, ffn.data(), res1.data(), L.post_ffn_norm->getWeight()->data(),
+                                                                 nextL ? nextL->input_norm->getWeight()->data() : nullptr, T, (int)D, L.layer_scalar, cfg_.rms_norm_eps, st ) );
+        }
+
+    public:
+        /// the fused prefill glue serves 1024 < D <= 8192 (workgroup-per-row canonical RMS reduction)
+        bool fusedPrefillApplicable() const { return cfg_.embedding_dim > 1024 && cfg_.embedding_dim <= 8192 && cfg_.embedding_dim % 8 == 0; }
+        /// on (default): prefill runs the fused glue when the configuration fits; off: one launch per reference op.  Same bits.
+        void setFusedPrefill( bool on ) { fused_prefill_ = on; }
+
+    private:
         // ---- fused step ---------------------------------------------------------------------------------
         mila_fused_matvec_args baseArgs( LinearType& lin, uint16_t* y, const uint16_t* x ) const
         {
@@ -697,6 +752,8 @@ namespace Mila::Dnn
         std::unique_ptr<LogitsTensor> sample_scratch_;
         bool sample_in_graph_{ false };
         bool use_chain_{ false };
+        bool fused_prefill_{ true };
+        std::unique_ptr<TensorType> pf_norm_, pf_norm2_;
         std::unique_ptr<LogitsTensor> chain_scratch_;
         const uint16_t* cur_hidden_{ nullptr };
         hipGraph_t graph_{ nullptr };

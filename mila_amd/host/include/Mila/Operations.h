@@ -430,6 +430,17 @@ namespace Mila::Dnn::Compute
             length_ = position + chunk;
         }
 
+        /// the chunk's K/V rows are already in the cache (written by the fused q/k/v post-processing kernel):
+        /// attention only.  q [B,chunk,NH*HS] at absolute positions [position, position+chunk)
+        void prefillFromCache( const TensorType& q, TensorType& out, int chunk, int position )
+        {
+            requireCache();
+            const int NH = (int)cfg_.num_heads, NKV = (int)cfg_.num_kv_heads, HS = (int)cfg_.head_dim, cap = (int)capacity_;
+            rocmCheck( mila_cdna4_attn_prefill_bf16( out.data(), q_cast( q ), k_cache_->data(), v_cache_->data(), batch_, chunk, NH, NKV, HS, cap,
+                                                     position, (int)cfg_.window, scale(), context_->getStream() ) );
+            length_ = position + chunk;
+        }
+
         /// one token per sequence at absolute position `position`
         void decode( const TensorType& q, const TensorType& k, const TensorType& v, TensorType& out, int position )
         {

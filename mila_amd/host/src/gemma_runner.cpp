@@ -122,6 +122,12 @@ HOST_API int mila_gemma_set_chain( void* h, int on )
     auto* r = static_cast<Runner*>( h );
     return guarded( [&] { std::visit( [&]( auto& m ) { m->setUseChain( on != 0 ); }, r->model ); } );
 }
+/// on != 0 (default): prefill runs the fused glue kernels when the configuration fits; 0: one launch per reference op
+HOST_API int mila_gemma_set_fused_prefill( void* h, int on )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&] { std::visit( [&]( auto& m ) { m->setFusedPrefill( on != 0 ); }, r->model ); } );
+}
 /// 1 if the chain launch is in use, 0 if not
 HOST_API int mila_gemma_uses_chain( void* h )
 {

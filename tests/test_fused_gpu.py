@@ -235,3 +235,64 @@ def test_decode_chain_rejects_bad_arguments():
         capi.check(lib.mila_cdna4_decode_chain(C.byref(a), stream))
     with pytest.raises(capi.InvalidArgument):
         capi.check(lib.mila_cdna4_decode_chain(None, stream))
+
+
+@pytest.mark.parametrize("NH,NKV,HS,rot,base,kv_shared", [(16, 8, 256, 0, 1e4, False), (16, 1, 512, 128, 1e6, True), (4, 2, 64, 0, 1e4, False)])
+def test_qkv_post_prefill_equals_split_norm_rope_kvwrite(NH, NKV, HS, rot, base, kv_shared):
+    """T packed qkv rows -> q (normed, roped) + KV cache rows in one launch == split3 + q_norm + k_norm + v_norm +
+    rope.prefill + kv_write (Gemma.Block.ixx:215-262), bit for bit, ring wrap-around included"""
+    rng = np.random.default_rng(HS + NKV)
+    T, cap, pos0, max_seq = 37, 48, 30, 128          # positions 30..66 wrap the 48-row ring
+    qd, kd = NH * HS, NKV * HS
+    width = qd + kd + (0 if kv_shared else kd)
+    packed = _bf(rng.standard_normal((T, width)))
+    qw, kw, vw = (_bf(1 + 0.1 * rng.uniform(-1, 1, HS)) for _ in range(3))
+    cos, sin = empty_f32(max_seq, HS // 2), empty_f32(max_seq, HS // 2)
+    capi.call("rope_build_cache", cos, sin, max_seq, HS, float(base), rot)
+    P = _d(packed)
+    # unfused chain
+    q0, k0, v0 = empty_u16(T, qd), empty_u16(T, kd), empty_u16(T, kd)
+    capi.call("split3_bf16", q0, k0, None if kv_shared else v0, P, T, qd, kd, 0 if kv_shared else kd)
+    qn, kn, vn = empty_u16(T, qd), empty_u16(T, kd), empty_u16(T, kd)
+    capi.call("rmsnorm_bf16", qn, None, q0, _d(qw), None, T * NH, HS, 1, 1e-6, 0.0)
+    capi.call("rmsnorm_bf16", kn, None, k0, _d(kw), None, T * NKV, HS, 1, 1e-6, 0.0)
+    capi.call("rmsnorm_bf16", vn, None, k0 if kv_shared else v0, _d(vw), None, T * NKV, HS, 1, 1e-6, 0.0)
+    capi.call("rope_forward_bf16", qn, kn, qn, kn, cos, sin, 1, T, NH, NKV, HS, pos0, max_seq)
+    K0 = torch.zeros((1, NKV, cap, HS), dtype=torch.int16, device="cuda")
+    V0 = torch.zeros_like(K0)
+    capi.call("kv_write_bf16", K0, V0, kn, vn, 1, T, NKV, HS, pos0, cap)
+    # fused: pointers into the packed rows
+    K1, V1, q1 = torch.zeros_like(K0), torch.zeros_like(K0), empty_u16(T, qd)
+    base_ptr = P.data_ptr()
+    kptr = C.c_void_p(base_ptr + 2 * qd)
+    vptr = kptr if kv_shared else C.c_void_p(base_ptr + 2 * (qd + kd))
+    capi.call("fused_qkv_post_prefill", q1, K1, V1, P, kptr, vptr, C.c_int64(width), _d(qw), _d(kw), _d(vw), cos, sin, T, NH, NKV, HS, pos0, cap, 1e-6)
+    assert np.array_equal(bits(q1), bits(qn)), "q differs"
+    assert np.array_equal(bits(K1), bits(K0)), "K cache differs"
+    assert np.array_equal(bits(V1), bits(V0)), "V cache differs"
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("fused_qkv_post_prefill", q1, K1, V1, P, kptr, vptr, C.c_int64(width), _d(qw), _d(kw), _d(vw), cos, sin, cap + 1, NH, NKV, HS, pos0, cap, 1e-6)
+
+
+@pytest.mark.parametrize("D", [3840, 2056])
+@pytest.mark.parametrize("post_scale,with_next", [(1.0, True), (0.75, True), (0.75, False)])
+def test_tail_norm_equals_rmsnorm_residual_scale_rmsnorm(D, post_scale, with_next):
+    """the prefill sandwich tail over T rows in one launch == RmsNorm + Residual (+ scale) + RmsNorm (Gemma.Block.ixx:339-356)"""
+    rng = np.random.default_rng(D)
+    T = 19
+    a = _d(_bf(rng.standard_normal((T, D)) * 3))
+    res = _d(_bf(rng.standard_normal((T, D))))
+    pw, nw = _d(_bf(1 + 0.1 * rng.uniform(-1, 1, D))), _d(_bf(1 + 0.1 * rng.uniform(-1, 1, D)))
+    an, r0, x0 = empty_u16(T, D), empty_u16(T, D), empty_u16(T, D)
+    capi.call("rmsnorm_bf16", an, None, a, pw, None, T, D, 1, 1e-6, 0.0)
+    capi.call("residual_bf16", r0, res, an, C.c_int64(T * D))
+    if post_scale != 1.0:
+        capi.call("scale_bf16", r0, r0, C.c_int64(T * D), post_scale)
+    capi.call("rmsnorm_bf16", x0, None, r0, nw, None, T, D, 1, 1e-6, 0.0)
+    r1, x1 = empty_u16(T, D), empty_u16(T, D)
+    capi.call("fused_tail_norm_bf16", r1, x1 if with_next else None, a, res, pw, nw if with_next else None, T, D, post_scale, 1e-6)
+    assert np.array_equal(bits(r0), bits(r1)), "residual stream differs"
+    if with_next:
+        assert np.array_equal(bits(x0), bits(x1)), "normed output differs"
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("fused_tail_norm_bf16", r1, None, a, res, pw, None, T, 512, post_scale, 1e-6)

@@ -99,3 +99,23 @@ def test_greedy_generation_is_identical_across_paths_and_follows_the_logits(poli
         assert nxt == int(ids["fused"][pos])
         tok = nxt
     g.close()
+
+
+MEDIUM = dict(vocab_size=2048, embedding_dim=1280, num_layers=6, num_heads=4, num_kv_heads=2, head_dim=64, hidden_dim=2560,
+              global_head_dim=128, num_global_kv_heads=1, window=8, sliding_window_pattern=6, global_rotary_dim=32)
+
+
+@pytest.mark.parametrize("policy", ["bf16", "fp4"])
+def test_fused_prefill_glue_gives_the_same_logits_and_cache_as_one_launch_per_op(policy):
+    """prefill with the fused glue (packed-qkv post-processing straight into the cache, one-launch sandwich tails) vs one
+    launch per reference op: identical logits, and identical KV caches as seen by the next decode step"""
+    toks = [(7 * i + 3) % 2048 for i in range(24)]
+    a = host.Gemma(policy, MEDIUM, max_seq=MAX_SEQ, max_prefill=32, seed=5)
+    b = host.Gemma(policy, MEDIUM, max_seq=MAX_SEQ, max_prefill=32, seed=5)
+    b.set_fused_prefill(False)
+    la, lb = a.prefill(toks), b.prefill(toks)
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    da, db = a.decode(11, len(toks), "fused"), b.decode(11, len(toks), "fused")
+    assert np.array_equal(da.view(np.uint32), db.view(np.uint32))
+    a.close()
+    b.close()
