@@ -253,6 +253,20 @@ MILA_API int mila_cdna4_sample_argmax_fp32(const float* logits, int32_t* token_o
 MILA_API int mila_cdna4_sample_argmax_bf16(const uint16_t* logits, int32_t* token_out, int vocab, void* scratch,
                                            size_t scratch_bytes, mila_stream_t stream);
 
+/* Stochastic sampler: x = (softcap > 0 ? softcap * tanh(l / softcap) : l) / temperature;
+ * top-k (0 = off) keeps the values strictly above the (k+1)-th largest; top-p (>= 1 = off) keeps the smallest set of
+ * highest-probability survivors whose mass exceeds top_p * total; token = first index, in token order, with
+ * probability > 0 and cumulative >= r * total (vocab - 1 otherwise); r in [0, 1] is drawn by the caller.
+ * replaces Sampling/Kernels/Sampling.cuh: cuda_sample_stochastic_fp32 / _bf16 (Sampling.cu:655-714; semantics of the
+ * single-block kernel :760-905).  temperature <= 0 is the greedy sampler above.  Deterministic for fixed arguments. */
+MILA_API size_t mila_cdna4_sample_stochastic_scratch_bytes(int vocab);
+MILA_API int mila_cdna4_sample_stochastic_fp32(const float* logits, int32_t* token_out, int vocab, float softcap,
+                                               float temperature, int top_k, float top_p, float r, void* scratch,
+                                               size_t scratch_bytes, mila_stream_t stream);
+MILA_API int mila_cdna4_sample_stochastic_bf16(const uint16_t* logits, int32_t* token_out, int vocab, float softcap,
+                                               float temperature, int top_k, float top_p, float r, void* scratch,
+                                               size_t scratch_bytes, mila_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused decode-step kernels (GemmaBlock::decode,
  * Components/Transformers/Gemma/Gemma.Block.ixx:287-356, as a fused schedule).  Each computes

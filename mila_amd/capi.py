@@ -49,6 +49,7 @@ def load():
     _lib.mila_cdna4_attn_decode_scratch_bytes.restype = C.c_size_t
     _lib.mila_cdna4_gemm_staging_bytes.restype = C.c_size_t
     _lib.mila_cdna4_sample_scratch_bytes.restype = C.c_size_t
+    _lib.mila_cdna4_sample_stochastic_scratch_bytes.restype = C.c_size_t
     _lib.mila_cdna4_decode_chain_scratch_bytes.restype = C.c_size_t
     return _lib
 
@@ -126,6 +127,7 @@ EXPORTED = [
     "embedding_gather_bf16", "embedding_gather_bf16_qfp8", "lpe_bf16", "split3_bf16", "scale_bf16",
     "convert_f32_to_bf16", "convert_bf16_to_f32",
     "sample_scratch_bytes", "sample_argmax_fp32", "sample_argmax_bf16",
+    "sample_stochastic_scratch_bytes", "sample_stochastic_fp32", "sample_stochastic_bf16",
     "fused_norm_matvec", "fused_qkv_post", "fused_qkv_post_prefill", "fused_tail_norm_bf16",
     "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position", "fused_attn_decode_bf16",
     "decode_chain_scratch_bytes", "decode_chain_init", "decode_chain_status", "decode_chain",

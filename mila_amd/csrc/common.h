@@ -86,6 +86,13 @@ __device__ __forceinline__ float wave_sum(float v)
     }
     return v;
 }
+// integer 64-lane sum (all lanes get the result)
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+    return v;
+}
 __device__ __forceinline__ float wave_max(float v)
 {
     v = fmaxf(v, dpp_f32<0xB1>(v));

@@ -43,6 +43,7 @@ def load():
         _lib.mila_gemma_time_prefill.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         _lib.mila_gemma_info.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         _lib.mila_gemma_generate.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        _lib.mila_gemma_generate_sampled.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_uint32, C.c_void_p]
         _lib.mila_gemma_set_chain.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_uses_chain.argtypes = [C.c_void_p]
         _lib.mila_gemma_set_fused_prefill.argtypes = [C.c_void_p, C.c_int]
@@ -119,6 +120,13 @@ class Gemma:
         """greedy autoregressive generation with the device sampler; returns the sampled token ids"""
         out = np.empty(n_tokens, dtype=np.int32)
         _check(load().mila_gemma_generate(self.h, int(first_token), int(start_position), int(n_tokens), self.MODES[mode], out.ctypes.data))
+        return out
+
+    def generate_sampled(self, first_token, start_position, n_tokens, temperature=1.0, top_k=0, top_p=1.0, seed=0, mode="fused"):
+        """multinomial generation (softcap + temperature + top-k + top-p on the device, uniform draws from a host mt19937)"""
+        out = np.empty(n_tokens, dtype=np.int32)
+        _check(load().mila_gemma_generate_sampled(self.h, int(first_token), int(start_position), int(n_tokens), self.MODES[mode], float(temperature),
+                                                  int(top_k), float(top_p), int(seed), out.ctypes.data))
         return out
 
     def time_decode(self, start_position, steps, warmup, mode="graph"):

@@ -210,6 +210,20 @@ namespace Mila::Dnn
                                                                sample_scratch_->sizeInBytes(), ctx_->getStream() ) );
         }
 
+        /// SamplingParams (Components/Transformers/SamplingParams.ixx): temperature <= 0 is greedy; top_k 0 / top_p >= 1 disable
+        /// the truncations.  The uniform r in [0, 1) is drawn by the caller, as in the reference (host RNG, GemmaModel.ixx:568).
+        struct SamplingParams { float temperature = 1.0f; int top_k = 0; float top_p = 1.0f; };
+        /// token <- a draw from softmax(softcap(logits) / temperature) restricted by top-k / top-p; the Gemma final logit
+        /// softcap (cfg.final_logit_softcapping) is applied here, at the sampler (Gemma.ixx:30-32)
+        void sampleStochastic( TokenTensor& token_out, const SamplingParams& sp, float r )
+        {
+            if ( sp.temperature <= 0.0f ) { sampleGreedy( token_out ); return; }
+            const size_t need = mila_cdna4_sample_stochastic_scratch_bytes( (int)cfg_.vocab_size );
+            void* scratch = ctx_->getScratch( need );
+            Compute::rocmCheck( mila_cdna4_sample_stochastic_fp32( logits_->data(), token_out.data(), (int)cfg_.vocab_size, cfg_.final_logit_softcapping, sp.temperature,
+                                                                   sp.top_k, sp.top_p, r, scratch, need, ctx_->getStream() ) );
+        }
+
         // ------------------------------------------------------------------------------------
         // prefill: whole prompt as one chunk (288 GB: no 12 GB-card chunking);
         // logits for the last position only (Gemma.ixx:269-276)

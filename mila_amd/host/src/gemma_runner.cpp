@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cstring>
 #include <memory>
+#include <random>
 #include <string>
 #include <variant>
 
@@ -292,6 +293,35 @@ HOST_API int mila_gemma_generate( void* h, int32_t first_token, int64_t start_po
                 if ( mode == 0 ) { m->decode( *r->tokens, pos ); m->sampleGreedy( *r->tokens ); }
                 else if ( mode == 1 ) { m->decodeFused( *r->tokens, pos ); m->sampleGreedy( *r->tokens ); }
                 else m->replayGraph();
+                Compute::rocmCheck( mila_cdna4_memcpy_d2h( host_out + i, r->tokens->data(), 4, ctx->getStream() ) );
+                ctx->synchronize();
+            }
+        }, r->model );
+    } );
+}
+
+/// Stochastic generation: like mila_gemma_generate (mode 0 or 1) with the multinomial device sampler; the per-step uniform
+/// comes from a host mt19937( seed ) as in the reference's generate loop.  temperature <= 0 degenerates to greedy.
+HOST_API int mila_gemma_generate_sampled( void* h, int32_t first_token, int64_t start_position, int n_tokens, int mode, float temperature, int top_k,
+                                          float top_p, uint32_t seed, int32_t* host_out )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&]
+    {
+        if ( mode != 0 && mode != 1 ) throw std::invalid_argument( "generate_sampled: mode must be 0 (reference order) or 1 (fused)" );
+        upload_tokens( r, &first_token, 1 );
+        std::mt19937 rng( seed );
+        std::uniform_real_distribution<float> uni( 0.0f, 1.0f );
+        std::visit( [&]( auto& m )
+        {
+            auto* ctx = m->context();
+            typename std::remove_reference_t<decltype( *m )>::SamplingParams sp;
+            sp.temperature = temperature; sp.top_k = top_k; sp.top_p = top_p;
+            for ( int i = 0; i < n_tokens; ++i )
+            {
+                const int64_t pos = start_position + i;
+                if ( mode == 0 ) m->decode( *r->tokens, pos ); else m->decodeFused( *r->tokens, pos );
+                m->sampleStochastic( *r->tokens, sp, uni( rng ) );
                 Compute::rocmCheck( mila_cdna4_memcpy_d2h( host_out + i, r->tokens->data(), 4, ctx->getStream() ) );
                 ctx->synchronize();
             }

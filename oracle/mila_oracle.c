@@ -9,6 +9,7 @@
  */
 #include "mila_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -781,3 +782,107 @@ void orc_split3(float* a, float* b, float* c, const float* X, int64_t rows, int6
 
 /* OPS/Sampling/Kernels/Sampling.cuh:46-57: cap * tanh(x / cap). */
 float orc_softcap(float x, float cap) { return cap * tanhf(x / cap); }
+
+/* ---- stochastic sampler ------------------------------------------------------------------------
+ * Restates the truncation semantics of the reference's single-block multinomial kernel
+ * (OPS/Sampling/Kernels/Sampling.cu:760-905) in closed form instead of its 40-step bisections:
+ *   x_i   = (softcap > 0 ? softcap * tanhf(l_i / softcap) : l_i) / temperature            (:773-781, fp32)
+ *   top-k : the bisection converges to hi = the smallest float with count(x >= hi) <= k, i.e. the survivors are
+ *           the values STRICTLY greater than the (k+1)-th largest value (exactly k of them when the k-th and
+ *           (k+1)-th differ; a tie across the boundary drops the whole tie)                (:803-829)
+ *   e_i   = survivors: expf(x_i - max), others 0; total = sum                              (:831-841)
+ *   top-p : lo converges to the largest probability p with mass(e >= p) > top_p * total: the nucleus is
+ *           the smallest prefix of the probability-sorted survivors (ties grouped) whose mass exceeds the target
+ *           (:843-880); total is recomputed over the nucleus
+ *   draw  : the first index i, in token-index order, with e_i > 0 and cumulative >= r * total; vocab-1 otherwise (:882-903)
+ * Sums are accumulated in double.  margins[0..2] (optional) report how far the three decisions are from flipping:
+ *   [0] (a_k - a_{k+1}) / max(|a_k|, 1e-30)   [1] distance of the nucleus prefix masses to the target / total
+ *   [2] distance of r * total to the nearest cumulative boundary of the chosen token / total.      Returns the token. */
+typedef struct { float v; int i; } orc_vi;
+static int orc_cmp_desc(const void* a, const void* b)
+{
+    const float x = ((const orc_vi*)a)->v, y = ((const orc_vi*)b)->v;
+    if (x > y) return -1;
+    if (x < y) return 1;
+    return ((const orc_vi*)a)->i - ((const orc_vi*)b)->i;
+}
+int orc_sample_stochastic(const float* logits, int vocab, float softcap, float temperature, int top_k, float top_p, float r,
+                          double* margins)
+{
+    float* x = (float*)malloc(sizeof(float) * (size_t)vocab);
+    float* e = (float*)malloc(sizeof(float) * (size_t)vocab);
+    orc_vi* srt = (orc_vi*)malloc(sizeof(orc_vi) * (size_t)vocab);
+    double m0 = 1e30, m1 = 1e30, m2 = 1e30;
+    float mx = -FLT_MAX;
+    for (int i = 0; i < vocab; ++i)
+    {
+        float v = logits[i];
+        if (softcap > 0.0f) v = softcap * tanhf(v / softcap);
+        v = v / temperature;
+        x[i] = v;
+        if (v > mx) mx = v;
+        srt[i].v = v; srt[i].i = i;
+    }
+    float kthr = -FLT_MAX;    /* survivors: x > kthr (or all) */
+    int use_k = top_k > 0 && top_k < vocab;
+    if (use_k)
+    {
+        qsort(srt, (size_t)vocab, sizeof(orc_vi), orc_cmp_desc);
+        kthr = srt[top_k].v;                       /* (k+1)-th largest */
+        const double ak = srt[top_k - 1].v;
+        m0 = (ak - (double)kthr) / fmax(fabs(ak), 1e-30);
+    }
+    double total = 0.0;
+    for (int i = 0; i < vocab; ++i)
+    {
+        e[i] = (!use_k || x[i] > kthr) ? expf(x[i] - mx) : 0.0f;
+        total += e[i];
+    }
+    if (top_p < 1.0f)
+    {
+        for (int i = 0; i < vocab; ++i) { srt[i].v = e[i]; srt[i].i = i; }
+        qsort(srt, (size_t)vocab, sizeof(orc_vi), orc_cmp_desc);
+        const double target = (double)top_p * total;
+        double mass = 0.0;
+        float pthr = 0.0f;
+        int j = 0;
+        while (j < vocab && srt[j].v > 0.0f)
+        {
+            int g = j;
+            const double before = mass;
+            while (g < vocab && srt[g].v == srt[j].v) { mass += srt[g].v; ++g; }   /* a tie group enters as a whole */
+            if (mass > target)
+            {
+                pthr = srt[j].v;
+                m1 = fmin(fabs(mass - target), fabs(target - before)) / total;
+                break;
+            }
+            j = g;
+        }
+        double t2 = 0.0;
+        for (int i = 0; i < vocab; ++i)
+        {
+            if (e[i] < pthr) e[i] = 0.0f;
+            t2 += e[i];
+        }
+        total = t2;
+    }
+    const double target = (double)r * total;
+    double cum = 0.0;
+    int result = vocab - 1;
+    for (int i = 0; i < vocab; ++i)
+    {
+        const double before = cum;
+        cum += e[i];
+        if (e[i] > 0.0f && cum >= target)
+        {
+            result = i;
+            m2 = fmin(fabs(cum - target), fabs(target - before)) / total;
+            break;
+        }
+    }
+    if (margins) { margins[0] = m0; margins[1] = m1; margins[2] = m2; }
+    free(x); free(e); free(srt);
+    return result;
+}
+

@@ -126,6 +126,8 @@ int  orc_embedding_gather(float* Y, const int32_t* tokens, const float* table, i
 void orc_split3(float* a, float* b, float* c, const float* X, int64_t rows, int64_t na,
                 int64_t nb, int64_t nc);
 float orc_softcap(float x, float cap);
+int orc_sample_stochastic(const float* logits, int vocab, float softcap, float temperature, int top_k, float top_p, float r,
+                          double* margins);
 
 #ifdef __cplusplus
 }

@@ -368,6 +368,18 @@ def embedding_gather(tokens, table, scale=0.0):
     return Y
 
 
+lib.orc_sample_stochastic.restype = C.c_int
+lib.orc_sample_stochastic.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]
+
+
+def sample_stochastic(logits, softcap, temperature, top_k, top_p, r):
+    """(token, margins[3]) of the reference's multinomial sampler semantics (oracle/mila_oracle.c orc_sample_stochastic)"""
+    lg = np.ascontiguousarray(logits, dtype=np.float32)
+    m = np.zeros(3, dtype=np.float64)
+    tok = lib.orc_sample_stochastic(lg.ctypes.data, lg.size, softcap, temperature, top_k, top_p, r, m.ctypes.data)
+    return tok, m
+
+
 def softcap(x, cap=30.0):
     return np.array([lib.orc_softcap(float(v), cap) for v in np.asarray(x).reshape(-1)],
                     dtype=np.float32).reshape(np.asarray(x).shape)

@@ -119,3 +119,28 @@ def test_fused_prefill_glue_gives_the_same_logits_and_cache_as_one_launch_per_op
     assert np.array_equal(da.view(np.uint32), db.view(np.uint32))
     a.close()
     b.close()
+
+
+def test_sampled_generation_degenerates_to_greedy_and_is_reproducible():
+    """top_k = 1 and temperature <= 0 both reproduce the greedy continuation; a fixed seed reproduces a sampled one; and a
+    sampled continuation only ever picks tokens inside the top-k set of the logits it was drawn from"""
+    g = host.Gemma("bf16", SMALL, max_seq=MAX_SEQ, max_prefill=1, seed=11)
+    greedy = g.generate(5, 0, 10, "fused")
+    g.close()
+    for kw in (dict(temperature=1.0, top_k=1), dict(temperature=0.0)):
+        g = host.Gemma("bf16", SMALL, max_seq=MAX_SEQ, max_prefill=1, seed=11)
+        assert np.array_equal(g.generate_sampled(5, 0, 10, seed=3, **kw), greedy), kw
+        g.close()
+    outs = []
+    for _ in range(2):
+        g = host.Gemma("bf16", SMALL, max_seq=MAX_SEQ, max_prefill=1, seed=11)
+        outs.append(g.generate_sampled(5, 0, 10, temperature=0.9, top_k=8, top_p=0.95, seed=7))
+        g.close()
+    assert np.array_equal(outs[0], outs[1])
+    g = host.Gemma("bf16", SMALL, max_seq=MAX_SEQ, max_prefill=1, seed=11)
+    tok = 5
+    for pos, nxt in enumerate(outs[0]):
+        logits = g.decode(int(tok), pos, "fused")
+        assert int(nxt) in np.argsort(-logits)[:8], "position %d: sampled token outside the top-8" % pos
+        tok = nxt
+    g.close()

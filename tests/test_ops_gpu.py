@@ -224,3 +224,74 @@ def test_greedy_sampler_argmax_ties_to_lowest_index(V):
     xb = orc.to_bf16_bits(x)
     capi.call("sample_argmax_bf16", dev_u16(xb), tok, V, scratch, C.c_size_t(nb))
     assert int(host(tok)[0]) == int(np.argmax(orc.from_bf16_bits(xb)))
+
+
+def _sample_gpu(logits, softcap, t, k, p, r, bf16=False):
+    import torch
+    V = logits.size
+    nb = capi.load().mila_cdna4_sample_stochastic_scratch_bytes(V)
+    scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    tok = dev_i32(np.array([-1]))
+    if bf16:
+        capi.call("sample_stochastic_bf16", dev_u16(orc.to_bf16_bits(logits)), tok, V, float(softcap), float(t), int(k), float(p), float(r), scratch, C.c_size_t(nb))
+    else:
+        capi.call("sample_stochastic_fp32", dev_f32(logits), tok, V, float(softcap), float(t), int(k), float(p), float(r), scratch, C.c_size_t(nb))
+    return int(host(tok)[0])
+
+
+def test_stochastic_sampler_reference_scenarios():
+    """the reference's own expectations (Tests/Dnn/Samplers/Sampling.Cuda.cpp:152-262, :387-401) through the C ABI"""
+    f = lambda v: np.array(v, dtype=np.float32)
+    assert _sample_gpu(f([8, 2, 3, 4, 5, 6, 7, 1]), 0, 1.0, 1, 1.0, 0.99) == 0
+    assert _sample_gpu(f([1, 2, 3, 4, 5, 6, 7, 8]), 0, 1.0, 0, 1.0, 0.0) == 0
+    assert _sample_gpu(f([1, 2, 3, 4, 5, 6, 7, 8]), 0, 1.0, 0, 1.0, 0.999999) == 7
+    for i in range(20):
+        assert _sample_gpu(f([1, 2, 3, 4, 5, 6, 70, 80]), 0, 1.0, 2, 1.0, i / 20.0) in (6, 7)
+        assert _sample_gpu(f([0, 0, 0, 0, 0, 0, 0, 20]), 0, 1.0, 0, 0.5, i / 20.0) == 7
+    V = 262144
+    assert _sample_gpu(np.zeros(V, dtype=np.float32), 0, 1.0, 0, 1.0, 0.0) == 0
+    assert _sample_gpu(np.zeros(V, dtype=np.float32), 0, 1.0, 0, 1.0, 0.999999) == V - 1
+    assert all(_sample_gpu(f([5, 3, 3, 1]), 0, 1.0, 2, 1.0, r) == 0 for r in (0.0, 0.5, 0.99))     # tie across the top-k boundary
+    assert [_sample_gpu(f([1000, 990]), 30.0, 1.0, 0, 1.0, r) for r in (0.25, 0.75)] == [0, 1]     # softcap before temperature
+    assert [_sample_gpu(f([1000, 990]), 0.0, 1.0, 0, 1.0, r) for r in (0.25, 0.75)] == [0, 0]
+    with pytest.raises(capi.InvalidArgument):
+        _sample_gpu(f([1, 2]), 0, 0.0, 0, 1.0, 0.5)                                                 # temperature <= 0: use the greedy entry
+
+
+@pytest.mark.parametrize("V,softcap,t,k,p", [(262144, 30.0, 0.8, 64, 0.95), (262144, 30.0, 0.7, 0, 0.9), (262144, 0.0, 1.0, 40, 1.0),
+                                             (262144, 30.0, 1.3, 0, 1.0), (50257, 0.0, 0.9, 200, 0.8), (1000, 30.0, 0.5, 5, 0.99)])
+def test_stochastic_sampler_matches_the_oracle(V, softcap, t, k, p):
+    """integer output: same token as the restated reference semantics for every draw whose top-k cut and CDF bracket are not
+    within float rounding of flipping (a nucleus-boundary flip moves the total by one boundary token's probability, far
+    below the 2e-3 bracket margin asked for here); deterministic across repeated launches"""
+    rng = np.random.default_rng(V + k)
+    lg = (rng.standard_normal(V) * 4.0).astype(np.float32)
+    lg[rng.integers(0, V, 8)] += 9.0                      # a few strong candidates, like real logits
+    checked = 0
+    full = (k == 0 and p >= 1.0)
+    if full:
+        # untruncated multinomial over the whole vocabulary: every token's probability is ~1e-5, no draw is "decisive";
+        # the reference's own check (Sampling.Cuda.cpp:307-362): the chosen token's CDF bracket contains r * total within a slack
+        x = lg.astype(np.float32)
+        if softcap > 0:
+            x = np.float32(softcap) * np.tanh(x / np.float32(softcap))
+        x = (x / np.float32(t)).astype(np.float64)
+        e = np.exp(x - x.max())
+        cum = np.cumsum(e)
+        total, slack = cum[-1], 1e-4 * cum[-1]
+    for r in [0.0, 0.999999] + [(i + 0.5) / 23.0 for i in range(23)]:
+        tok, m = orc.sample_stochastic(lg, softcap, t, k, p, r)
+        got = _sample_gpu(lg, softcap, t, k, p, r)
+        assert got == _sample_gpu(lg, softcap, t, k, p, r), "not deterministic"
+        if full:
+            target = r * total
+            assert cum[got] >= target - slack and cum[got] - e[got] <= target + slack, "r=%g: token %d outside its CDF bracket" % (r, got)
+            checked += 1
+        elif m[0] > 1e-6 and m[2] > 2e-3:
+            assert got == tok, "r=%g: %d != %d (margins %s)" % (r, got, tok, m)
+            checked += 1
+    assert checked >= 8, "too few decisive draws (%d)" % checked
+    lb = orc.from_bf16_bits(orc.to_bf16_bits(lg))
+    tok, m = orc.sample_stochastic(lb, softcap, t, k, p, 0.41)
+    if m[0] > 1e-6 and m[2] > 2e-3:
+        assert _sample_gpu(lb, softcap, t, k, p, 0.41, bf16=True) == tok

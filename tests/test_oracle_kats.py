@@ -390,3 +390,31 @@ def test_bf16_rne():
     xs = np.random.default_rng(9).standard_normal(50000).astype(np.float32) * 1e3
     ref = torch.from_numpy(xs).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
     assert np.array_equal(orc.to_bf16_bits(xs), ref)
+
+
+def test_stochastic_sampler_reference_scenarios():
+    """the restated multinomial sampler reproduces every closed-form expectation of the reference's own tests
+    (Tests/Dnn/Samplers/Sampling.Cuda.cpp:152-262, :387-401)"""
+    f = lambda v: np.array(v, dtype=np.float32)
+    s = lambda lg, **kw: orc.sample_stochastic(lg, kw.get("softcap", 0.0), kw.get("t", 1.0), kw.get("k", 0), kw.get("p", 1.0), kw["r"])[0]
+    assert s(f([8, 2, 3, 4, 5, 6, 7, 1]), k=1, r=0.99) == 0                       # TopK1_PicksArgmax
+    assert s(f([1, 2, 3, 4, 5, 6, 7, 8]), r=0.0) == 0                             # FullMultinomial_BoundaryR
+    assert s(f([1, 2, 3, 4, 5, 6, 7, 8]), r=0.999999) == 7
+    assert s(f([1, 5, 2, 8, 3, 6, 4, 7]), t=0.8, r=0.42) == s(f([1, 5, 2, 8, 3, 6, 4, 7]), t=0.8, r=0.42)
+    for i in range(20):
+        assert s(f([1, 2, 3, 4, 5, 6, 70, 80]), k=2, r=i / 20.0) in (6, 7)        # TopK_RestrictsSupport
+        assert s(f([0, 0, 0, 0, 0, 0, 0, 20]), p=0.5, r=i / 20.0) == 7            # TopP_RestrictsSupport
+    V = 262144                                                                    # Pipeline_BoundaryR_AtGemmaVocab (uniform logits)
+    assert s(np.zeros(V, dtype=np.float32), r=0.0) == 0
+    assert s(np.zeros(V, dtype=np.float32), r=0.999999) == V - 1
+    # closed form: probabilities .4 .3 .2 .1
+    lg = np.log(np.array([0.4, 0.3, 0.2, 0.1])).astype(np.float32)
+    assert [s(lg, r=r) for r in (0.1, 0.45, 0.75, 0.95)] == [0, 1, 2, 3]
+    assert [s(lg, p=0.65, r=r) for r in (0.1, 0.5, 0.6, 0.99)] == [0, 0, 1, 1]     # nucleus {0, 1}: .7 > .65
+    assert [s(lg, k=2, r=r) for r in (0.1, 0.5, 0.6, 0.99)] == [0, 0, 1, 1]
+    # a tie across the top-k boundary drops the whole tie (the reference's bisection excludes the (k+1)-th value)
+    assert all(s(f([5, 3, 3, 1]), k=2, r=r) == 0 for r in (0.0, 0.5, 0.99))
+    # softcap is applied before the temperature: 30 * tanh(1000 / 30) == 30 * tanh(990 / 30) -> a coin flip; without it
+    # token 1 has probability e^-10
+    assert [s(f([1000, 990]), softcap=30.0, r=r) for r in (0.25, 0.75)] == [0, 1]
+    assert [s(f([1000, 990]), r=r) for r in (0.25, 0.75)] == [0, 0]
