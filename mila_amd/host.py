@@ -17,7 +17,7 @@ _lib = None
 class GemmaConfigC(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("vocab_size", "embedding_dim", "num_layers", "num_heads", "num_kv_heads",
                                          "head_dim", "hidden_dim", "global_head_dim", "num_global_kv_heads", "window",
-                                         "sliding_window_pattern", "global_rotary_dim")]
+                                         "sliding_window_pattern", "global_rotary_dim", "bounded_local_kv")]
 
 
 GEMMA4_12B = dict(vocab_size=262144, embedding_dim=3840, num_layers=48, num_heads=16, num_kv_heads=8, head_dim=256,
@@ -74,6 +74,7 @@ class Gemma:
     def __init__(self, policy="bf16", config=None, max_seq=4096, max_prefill=1, seed=1234):
         lib = load()
         self.cfg = dict(GEMMA4_12B if config is None else config)
+        self.cfg.setdefault("bounded_local_kv", 0)      # 1: SlidingWindowKvCache on the sliding-window layers
         c = GemmaConfigC(**self.cfg)
         self.vocab = self.cfg["vocab_size"]
         self.h = lib.mila_gemma_create(POLICIES[policy], C.byref(c), max_seq, max_prefill, seed)

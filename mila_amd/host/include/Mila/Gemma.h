@@ -31,6 +31,7 @@ namespace Mila::Dnn
               hidden_dim = 15360, global_head_dim = 512, num_global_kv_heads = 1, window = 1024, sliding_window_pattern = 6,
               global_rotary_dim = 128;
         float rms_norm_eps = 1e-6f, rope_theta_local = 10000.0f, rope_theta_global = 1000000.0f, final_logit_softcapping = 30.0f;
+        bool bounded_local_kv = false;   ///< SlidingWindowKvCache on the sliding-window layers (ring of window + chunk - 1 rows)
 
         bool isGlobalLayer( dim_t i ) const { return ( i + 1 ) % sliding_window_pattern == 0; }   // Gemma.Config.ixx:504-507
         dim_t headDim( bool g ) const { return g ? global_head_dim : head_dim; }
@@ -77,7 +78,7 @@ namespace Mila::Dnn
         using LmHeadLinearType = Linear<kDevice, kPrecision, TableQuantizationPolicy>;
         using RmsNormType = RmsNorm<kDevice, kPrecision>;
         using RopeOp = Compute::RocmRopeOp;
-        using GqaOp = Compute::RocmGqaOp<false>;   // 288 GB of HBM: unbounded caches on every layer (ring optional)
+        using GqaOp = Compute::RocmGqaOpBase;      // local layers: RocmGqaOp<cfg.bounded_local_kv>; global layers: RocmGqaOp<false>
         static constexpr int kFmt = Quant::Weight::abiWeightFormat<TWeightQuant>();
         static constexpr int kTableFmt = Quant::Weight::abiWeightFormat<TableQuantizationPolicy>();
 
@@ -340,7 +341,11 @@ namespace Mila::Dnn
                 L.rope = std::make_shared<RopeOp>( ctx_, Compute::RopeOpConfig{ max_seq_, HD, NH, NKV, g ? cfg_.rope_theta_global : cfg_.rope_theta_local,
                                                                                g ? cfg_.global_rotary_dim : 0 } );
                 L.rope->build( BuildContext( shape_t{ 1, P, cfg_.qWidth( g ) }, RuntimeMode::Inference ) );
-                L.attn = std::make_shared<GqaOp>( ctx_, Compute::GqaOpConfig{ NH, NKV, HD, cfg_.windowFor( g ), 1.0f } );   // scale 1.0: Gemma.Block.ixx:902-904
+                const Compute::GqaOpConfig acfg{ NH, NKV, HD, cfg_.windowFor( g ), 1.0f };   // scale 1.0: Gemma.Block.ixx:902-904
+                // KV policy (Quantization/KvCache policies; CudaGqaOp.ixx:552-574): 288 GB of HBM makes unbounded caches the default;
+                // SlidingWindowKvCache bounds the sliding-window layers to window + prefill_chunk - 1 rows, global layers stay unbounded
+                if ( cfg_.bounded_local_kv && !g ) L.attn = std::make_shared<Compute::RocmGqaOp<Quant::KvCache::SlidingWindowKvCache::kBoundedRing>>( ctx_, acfg );
+                else L.attn = std::make_shared<Compute::RocmGqaOp<Quant::KvCache::NoKvCompression::kBoundedRing>>( ctx_, acfg );
                 L.attn->initializeKvCache( 1, max_seq_, P );
             }
             final_norm_ = make<RmsNormType>( "gemma.final_norm", rms( D ) );

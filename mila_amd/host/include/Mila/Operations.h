@@ -376,27 +376,30 @@ namespace Mila::Dnn::Compute
         float attention_scale{ 0.0f };   ///< <= 0 -> 1/sqrt(head_dim)  (GroupedQueryAttention.Config.ixx:190-200)
     };
 
-    /// counterpart of CudaGqaOp<Prec, kBounded> (OPS/Attention/GQA/CudaGqaOp.ixx:97-985)
-    template<bool kBoundedRing>
-    class RocmGqaOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    /// Shared body of the two KV-cache policies of CudaGqaOp<Prec, kBounded> (OPS/Attention/GQA/CudaGqaOp.ixx:97-985): the
+    /// policy only changes the cache capacity rule and what rewind may restore, so a model can hold bounded (sliding-window)
+    /// and unbounded (global) layers behind one pointer type.
+    class RocmGqaOpBase : public Operation<DeviceType::Rocm, TensorDataType::BF16>
     {
     public:
         using TensorType = RocmBf16Tensor;
-        RocmGqaOp( IExecutionContext* ctx, const GqaOpConfig& cfg ) : Operation( ctx ), cfg_( cfg )
+        RocmGqaOpBase( IExecutionContext* ctx, const GqaOpConfig& cfg, bool bounded_ring ) : Operation( ctx ), cfg_( cfg ), kBoundedRing( bounded_ring )
         {
             if ( cfg.num_heads <= 0 || cfg.num_kv_heads <= 0 || cfg.num_heads % cfg.num_kv_heads != 0 )
                 throw std::invalid_argument( "RocmGqaOp: num_heads must be a positive multiple of num_kv_heads" );
             if ( cfg.head_dim <= 0 ) throw std::invalid_argument( "RocmGqaOp: head_dim must be positive" );
             if ( kBoundedRing && cfg.window <= 0 ) throw std::invalid_argument( "RocmGqaOp: a bounded ring cache needs a sliding window" );
         }
+        virtual ~RocmGqaOpBase() = default;
+        bool boundedRing() const noexcept { return kBoundedRing; }
 
         float scale() const noexcept { return cfg_.attention_scale > 0.0f ? cfg_.attention_scale : 1.0f / std::sqrt( static_cast<float>( cfg_.head_dim ) ); }
 
         /// capacity rule of CudaGqaOp::resolveCacheCapacity (CudaGqaOp.ixx:552-574)
-        static dim_t resolveCacheCapacity( dim_t max_seq, dim_t window, dim_t prefill_chunk )
+        dim_t resolveCacheCapacity( dim_t max_seq, dim_t window, dim_t prefill_chunk ) const
         {
-            if constexpr ( kBoundedRing ) return std::min( max_seq, window + std::max<dim_t>( prefill_chunk, 1 ) - 1 );
-            else return max_seq;
+            if ( kBoundedRing ) return std::min( max_seq, window + std::max<dim_t>( prefill_chunk, 1 ) - 1 );
+            return max_seq;
         }
 
         void initializeKvCache( int batch, dim_t max_seq, dim_t prefill_chunk )
@@ -471,9 +474,17 @@ namespace Mila::Dnn::Compute
         static const uint16_t* q_cast( const TensorType& t ) { return static_cast<const uint16_t*>( t.rawData() ); }
         void requireCache() const { if ( !k_cache_ ) throw std::runtime_error( "RocmGqaOp: initializeKvCache() must be called first" ); }
         GqaOpConfig cfg_;
+        const bool kBoundedRing;
         std::unique_ptr<TensorType> k_cache_, v_cache_;
         int batch_{ 1 };
         dim_t capacity_{ 0 }, length_{ 0 };
+    };
+    /// counterpart of CudaGqaOp<Prec, kBounded>: the KV policy as a compile-time axis, as in the reference
+    template<bool kBoundedRingPolicy>
+    class RocmGqaOp : public RocmGqaOpBase
+    {
+    public:
+        RocmGqaOp( IExecutionContext* ctx, const GqaOpConfig& cfg ) : RocmGqaOpBase( ctx, cfg, kBoundedRingPolicy ) {}
     };
     template<typename TKvPolicy>
     struct OperationTraits<OperationType::GroupedQueryAttentionOp, DeviceType::Rocm, TensorDataType::BF16, TKvPolicy>

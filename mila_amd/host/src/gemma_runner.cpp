@@ -44,6 +44,7 @@ struct mila_gemma_config
 {
     int64_t vocab_size, embedding_dim, num_layers, num_heads, num_kv_heads, head_dim, hidden_dim, global_head_dim,
             num_global_kv_heads, window, sliding_window_pattern, global_rotary_dim;
+    int64_t bounded_local_kv;   ///< != 0: SlidingWindowKvCache (ring of window + chunk - 1 rows) on the sliding-window layers
 };
 
 HOST_API const char* mila_host_last_error( void ) { return g_err.c_str(); }
@@ -61,6 +62,7 @@ HOST_API void* mila_gemma_create( int policy, const mila_gemma_config* c, int64_
             cfg.num_kv_heads = c->num_kv_heads; cfg.head_dim = c->head_dim; cfg.hidden_dim = c->hidden_dim; cfg.global_head_dim = c->global_head_dim;
             cfg.num_global_kv_heads = c->num_global_kv_heads; cfg.window = c->window; cfg.sliding_window_pattern = c->sliding_window_pattern;
             cfg.global_rotary_dim = c->global_rotary_dim;
+            cfg.bounded_local_kv = c->bounded_local_kv != 0;
         }
         auto rr = std::make_unique<Runner>();
         rr->max_prefill = max_prefill;

@@ -144,3 +144,21 @@ def test_sampled_generation_degenerates_to_greedy_and_is_reproducible():
         assert int(nxt) in np.argsort(-logits)[:8], "position %d: sampled token outside the top-8" % pos
         tok = nxt
     g.close()
+
+
+@pytest.mark.parametrize("policy", ["bf16", "fp8"])
+def test_bounded_ring_kv_policy_matches_the_unbounded_cache(policy):
+    """SlidingWindowKvCache (CudaGqaOp.ixx:552-574: the sliding-window layers keep window + chunk - 1 rows, global layers stay
+    unbounded) must not change a single logit bit: prefill a chunk, then decode far past the ring's capacity"""
+    toks = [(11 * i + 2) % 1024 for i in range(12)]
+    a = host.Gemma(policy, SMALL, max_seq=MAX_SEQ, max_prefill=16, seed=9)
+    b = host.Gemma(policy, dict(SMALL, bounded_local_kv=1), max_seq=MAX_SEQ, max_prefill=16, seed=9)     # ring of 8 + 16 - 1 = 23 rows
+    assert np.array_equal(a.prefill(toks).view(np.uint32), b.prefill(toks).view(np.uint32))
+    tok = 3
+    for pos in range(len(toks), 60):
+        mode = "fused" if pos % 2 else "reference"
+        la, lb = a.decode(tok, pos, mode), b.decode(tok, pos, mode)
+        assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), "position %d (%s)" % (pos, mode)
+        tok = int(np.argmax(la))
+    a.close()
+    b.close()
