@@ -12,6 +12,9 @@
 //   * fp8 / fp4 are expanded to bf16 pairs by the gfx950 v_cvt_scalef32_pk_bf16_{fp8,fp4}
 //     converts (scale operand 1.0 => exact) and multiplied with v_dot2_f32_bf16, fp32 accumulate;
 //     the fp4 group scale is folded with one FMA per 32-element chunk.
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 #include "internal.h"
 #include "rms_common.h"
@@ -71,6 +74,25 @@ static int launch(const MatvecParams& p, int max_blocks, hipStream_t s)
     return set_error(MILA_E_INVALID_ARGUMENT, "matvec: K=%d exceeds the register-staged x limit (16384)", p.K);
 }
 
+struct ShapeOverrides
+{
+    struct E { bool set = false; int rows = 1, U = 2, blocks = kNumCU; } e[3][3];
+};
+static ShapeOverrides parse_shape_overrides()
+{
+    ShapeOverrides o;
+    const char* env = getenv("MILA_MATVEC_SHAPE");
+    if (!env) return o;
+    int f, t, r, u, b, n = 0;
+    while (*env && sscanf(env, "f%dt%d=%d,%d,%d%n", &f, &t, &r, &u, &b, &n) == 5)
+    {
+        if (f >= 0 && f < 3 && t >= 0 && t < 3 && r >= 1 && u >= 1 && b >= 1) { o.e[f][t].set = true; o.e[f][t].rows = r; o.e[f][t].U = u; o.e[f][t].blocks = b; }
+        env += n;
+        if (*env == ';') ++env;
+    }
+    return o;
+}
+
 template <int FMT, int PRO, bool GEGLU, bool F32OUT>
 static int dispatch_RU(const MatvecParams& p, hipStream_t s)
 {
@@ -81,11 +103,19 @@ static int dispatch_RU(const MatvecParams& p, hipStream_t s)
     const int rows = GEGLU ? 2 * p.N : p.N;
     const bool tall = rows >= 16384, huge = rows >= 100000;
     int rows_per_step, U;
-    if (FMT == FMT_BF16) { rows_per_step = tall ? 4 : 1; U = tall ? 2 : 4; }
+    if (FMT == FMT_BF16) { rows_per_step = huge ? 4 : (tall ? 2 : 1); U = tall ? 2 : 4; }
     else if (FMT == FMT_FP8) { rows_per_step = huge ? 4 : (tall ? 2 : 1); U = 2; }
     else { rows_per_step = tall ? 2 : 1; U = huge ? 2 : 1; }
+    // two workgroups per CU (dynamic tail balance) pay for the bf16 matrices and for the lm_head; the quantized
+    // tall matrices (fc_gate_up) are faster with one resident workgroup per CU (in-situ sweep, tools/tune_shapes.sh)
+    int max_blocks = (huge || (tall && FMT == FMT_BF16)) ? 2 * kNumCU : kNumCU;
+    {
+        // tuning hook (tools/, never set by the product path): MILA_MATVEC_SHAPE="f<fmt>t<0 short|1 tall|2 huge>=rows,U,blocks;..."
+        static const ShapeOverrides ov = parse_shape_overrides();
+        const ShapeOverrides::E& e = ov.e[FMT][huge ? 2 : (tall ? 1 : 0)];
+        if (e.set) { rows_per_step = e.rows; U = e.U; max_blocks = e.blocks; }
+    }
     int R = GEGLU ? (rows_per_step >= 2 ? rows_per_step / 2 : 1) : rows_per_step;
-    int max_blocks = tall ? 2 * kNumCU : kNumCU;
     if (g_tune_R > 0) R = g_tune_R;
     if (g_tune_U > 0) U = g_tune_U;
     if (g_tune_blocks > 0) max_blocks = g_tune_blocks;
