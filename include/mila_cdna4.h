@@ -294,6 +294,24 @@ typedef struct mila_fused_matvec_args {
 } mila_fused_matvec_args;
 MILA_API int mila_cdna4_fused_norm_matvec(const mila_fused_matvec_args* host_args, mila_stream_t stream);
 
+/* Flash-decode with the split combine moved into the consumer: fused_attn_decode_partials_bf16 is fused_attn_decode_bf16
+ * without its second launch -- it leaves the per-split partials (float [NH, splits, HS + 4]: O | m | l | pad) in `scratch`;
+ * matvec_attn_combine is the o_proj Linear (Gemma.Block.ixx: o_proj after the attention op) whose x is combined from those
+ * partials in its prologue, element for element the arithmetic of the combine launch, so
+ *   fused_attn_decode_partials + matvec_attn_combine  ==  fused_attn_decode + matvec_bf16[_qfp8|_qfp4]   bit for bit,
+ * one launch fewer.  Every workgroup re-reads all partials from L2, so callers use it while NH * splits * (HS + 4) * 4 bytes
+ * stays small (Gemma sliding-window layers: 266 KB); attn_decode_split_count() gives `splits` for a (window, capacity). */
+MILA_API int mila_cdna4_attn_decode_split_count(int B, int NH, int NKV, int HS, int capacity, int window);
+MILA_API int mila_cdna4_fused_attn_decode_partials_bf16(uint16_t* Kc, uint16_t* Vc, const uint16_t* q_raw,
+                                                        const uint16_t* k_raw, const uint16_t* v_raw,
+                                                        const uint16_t* qw, const uint16_t* kw, const uint16_t* vw,
+                                                        const float* cos_cache, const float* sin_cache, void* scratch,
+                                                        size_t scratch_bytes, int NH, int NKV, int HS, int capacity,
+                                                        int position, const int32_t* position_dev, int window,
+                                                        float scale, float eps, mila_stream_t stream);
+MILA_API int mila_cdna4_matvec_attn_combine(uint16_t* y, const void* partials, int splits, int NH, int HS, const void* W,
+                                            const float* scales, int fmt, int N, int group, mila_stream_t stream);
+
 /* Decode chain: the four Linears between two attention calls of a Gemma decode step in ONE launch
  * (Gemma.Block.ixx:287-356 from o_proj to the end of the block, plus the next block's input norm + qkv_proj,
  * Gemma.Block.ixx:287-300, or the final norm + tied lm_head, Gemma.ixx forward tail):

@@ -57,7 +57,8 @@ struct AttnParams
     const uint16_t* Q;        // [B, NH*HS] post-norm/rope queries (unfused form), or NULL in the fused form
     uint16_t* K;              // cache [B, NKV, capacity, HS]
     uint16_t* V;
-    float* scratch;           // [B, NH, splits, HS+2] partials when splits > 1
+    float* scratch;           // [B, NH, splits, HS+4] partials when splits > 1: O (HS) | m | l | pad (rows stay 16-byte aligned)
+    int no_combine;           // leave the partials for the consumer (matvec_attn_combine) instead of launching the combine
     int NH, NKV, capacity, position, window, splits;
     float scale;
     const int32_t* pos_dev;   // when set: the position is read from device memory (graph replay)
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(kDecodeWaves * 64) void attn_decode_kernel(const At
         }
         else
         {
-            float* dst = p.scratch + (((size_t)b * p.NH + h) * p.splits + split) * STR;
+            float* dst = p.scratch + (((size_t)b * p.NH + h) * p.splits + split) * (HS + 4);
             if (owner)
             {
 #pragma unroll
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(uint16_t* __restrict__
 {
     const int h = blockIdx.x, b = blockIdx.y;
     const int d = blockIdx.z * 64 + threadIdx.x;
-    const int STR = HS + 2;
+    const int STR = HS + 4;
     const float* base = scratch + ((size_t)b * NH + h) * splits * STR;
     const int s = threadIdx.x;
     const float ms = (s < splits) ? base[(size_t)s * STR + HS] : -INFINITY;
@@ -419,7 +420,7 @@ static int launch_decode(const AttnParams& p, int B, hipStream_t s)
     hipLaunchKernelGGL((attn_decode_kernel<HS, GH, FUSED>), dim3(p.splits, p.NKV * hgroups, B), dim3(kDecodeWaves * 64), lds, s, p);
     int rc = check_hip(hipGetLastError(), "attn_decode");
     if (rc) return rc;
-    if (p.splits > 1)
+    if (p.splits > 1 && !p.no_combine)
     {
         hipLaunchKernelGGL(attn_combine_kernel, dim3(p.NH, B, HS / 64), dim3(64), 0, s, p.Y, p.scratch, p.NH, HS, p.splits);
         rc = check_hip(hipGetLastError(), "attn_combine");
@@ -484,7 +485,7 @@ static int run_decode(uint16_t* Y, const uint16_t* Q, uint16_t* Kc, uint16_t* Vc
     p.pos_dev = pos_dev;
     if (p.splits > 1)
     {
-        const size_t need = (size_t)B * NH * p.splits * (HS + 2) * sizeof(float);
+        const size_t need = (size_t)B * NH * p.splits * (HS + 4) * sizeof(float);
         if (!scratch || scratch_bytes < need)
             return set_error(MILA_E_SCRATCH_TOO_SMALL, "%s: scratch %zu bytes < required %zu", who, scratch_bytes, need);
     }
@@ -516,7 +517,7 @@ int mila_cdna4_kv_write_bf16(uint16_t* Kc, uint16_t* Vc, const uint16_t* k, cons
 size_t mila_cdna4_attn_decode_scratch_bytes(int B, int NH, int HS)
 {
     if (B <= 0 || NH <= 0 || HS <= 0) return 0;
-    return (size_t)B * NH * kMaxSplits * (HS + 2) * sizeof(float);
+    return (size_t)B * NH * kMaxSplits * (HS + 4) * sizeof(float);
 }
 
 int mila_cdna4_attn_decode_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t* Kc, const uint16_t* Vc, void* scratch,
@@ -569,6 +570,38 @@ int mila_cdna4_fused_attn_decode_bf16(uint16_t* Y, uint16_t* Kc, uint16_t* Vc, c
     f.eps = eps;
     return run_decode(Y, nullptr, Kc, Vc, scratch, scratch_bytes, 1, NH, NKV, HS, capacity, position, position_dev, window, scale, &f,
                       "fused_attn_decode_bf16", as_stream(stream));
+}
+
+int mila_cdna4_attn_decode_split_count(int B, int NH, int NKV, int HS, int capacity, int window)
+{
+    if (B <= 0 || NH <= 0 || NKV <= 0 || NH % NKV != 0 || capacity <= 0 || window < 0) return 0;
+    const int band_max = (window > 0 && window < capacity) ? window : capacity;
+    return decode_splits(B, NH, NKV, HS, band_max);
+}
+
+int mila_cdna4_fused_attn_decode_partials_bf16(uint16_t* Kc, uint16_t* Vc, const uint16_t* q_raw, const uint16_t* k_raw,
+                                               const uint16_t* v_raw, const uint16_t* qw, const uint16_t* kw, const uint16_t* vw,
+                                               const float* cos_cache, const float* sin_cache, void* scratch, size_t scratch_bytes,
+                                               int NH, int NKV, int HS, int capacity, int position, const int32_t* position_dev,
+                                               int window, float scale, float eps, mila_stream_t stream)
+{
+    MILA_REQUIRE(Kc && Vc && q_raw && k_raw && v_raw && qw && kw && cos_cache && sin_cache, "fused_attn_decode_partials_bf16: null pointer");
+    MILA_REQUIRE(NH > 0 && NKV > 0 && NH % NKV == 0, "fused_attn_decode_partials_bf16: bad head counts (NH=%d NKV=%d)", NH, NKV);
+    MILA_REQUIRE(capacity > 0 && window >= 0 && (position_dev || position >= 0), "fused_attn_decode_partials_bf16: bad sizes");
+    MILA_REQUIRE(HS % 16 == 0, "fused_attn_decode_partials_bf16: HS=%d must be a multiple of 16", HS);
+    MILA_REQUIRE(mila_cdna4_attn_decode_split_count(1, NH, NKV, HS, capacity, window) > 1,
+                 "fused_attn_decode_partials_bf16: this (window, capacity) runs unsplit; use fused_attn_decode_bf16");
+    if (!position_dev)
+    {
+        const int len = position + 1, band = (window > 0 && window < len) ? window : len;
+        MILA_REQUIRE(band <= capacity, "fused_attn_decode_partials_bf16: live band %d exceeds the cache capacity %d", band, capacity);
+    }
+    AttnParams f{};
+    f.q_raw = q_raw; f.k_raw = k_raw; f.v_raw = v_raw; f.qw = qw; f.kw = kw; f.vw = vw; f.cos_cache = cos_cache; f.sin_cache = sin_cache;
+    f.eps = eps;
+    f.no_combine = 1;
+    return run_decode(nullptr, nullptr, Kc, Vc, scratch, scratch_bytes, 1, NH, NKV, HS, capacity, position, position_dev, window, scale, &f,
+                      "fused_attn_decode_partials_bf16", as_stream(stream));
 }
 
 }  // extern "C"

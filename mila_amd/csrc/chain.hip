@@ -216,10 +216,10 @@ int mila_cdna4_decode_chain(const mila_decode_chain_args* a, mila_stream_t strea
     uint32_t* h2 = h1 + F;
     ChainParams c;
     // {y, x, W, scales, bias, norm_w, post_w, res, res_out, post_scale, eps, K, N, group}
-    c.ph[0] = MatvecParams{h0, a->attn, static_cast<const uint8_t*>(a->W_o), a->s_o, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, a->eps, a->K_attn, D, a->group};
-    c.ph[1] = MatvecParams{h1, reinterpret_cast<const uint16_t*>(h0), static_cast<const uint8_t*>(a->W_gate_up), a->s_gate_up, nullptr, a->pre_ffn_w, a->post_attn_w, a->res, nullptr, 1.0f, a->eps, D, F, a->group};
-    c.ph[2] = MatvecParams{h2, reinterpret_cast<const uint16_t*>(h1), static_cast<const uint8_t*>(a->W_down), a->s_down, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, a->eps, F, D, a->group};
-    c.ph[3] = MatvecParams{a->y, reinterpret_cast<const uint16_t*>(h2), static_cast<const uint8_t*>(a->W_next), a->s_next, nullptr, a->next_norm_w, a->post_ffn_w, nullptr, a->res_out, a->layer_scalar, a->eps, D, a->N_next, a->next_group};
+    c.ph[0] = MatvecParams{h0, a->attn, static_cast<const uint8_t*>(a->W_o), a->s_o, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, a->eps, a->K_attn, D, a->group, 0, 0};
+    c.ph[1] = MatvecParams{h1, reinterpret_cast<const uint16_t*>(h0), static_cast<const uint8_t*>(a->W_gate_up), a->s_gate_up, nullptr, a->pre_ffn_w, a->post_attn_w, a->res, nullptr, 1.0f, a->eps, D, F, a->group, 0, 0};
+    c.ph[2] = MatvecParams{h2, reinterpret_cast<const uint16_t*>(h1), static_cast<const uint8_t*>(a->W_down), a->s_down, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, a->eps, F, D, a->group, 0, 0};
+    c.ph[3] = MatvecParams{a->y, reinterpret_cast<const uint16_t*>(h2), static_cast<const uint8_t*>(a->W_next), a->s_next, nullptr, a->next_norm_w, a->post_ffn_w, nullptr, a->res_out, a->layer_scalar, a->eps, D, a->N_next, a->next_group, 0, 0};
     c.counter = reinterpret_cast<unsigned long long*>(sc);
     c.epoch = reinterpret_cast<unsigned long long*>(sc + 8);
     c.error = reinterpret_cast<uint32_t*>(sc + 16);

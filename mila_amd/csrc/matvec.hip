@@ -37,13 +37,13 @@ namespace mila {
 //     buffer with step t + 2; the last <= 3 steps are peeled so the loop body needs no validity test.
 // One 1024-thread workgroup (16 waves) per CU: x is staged (and the prologue computed) once per CU, so the
 // L2 -> LDS staging traffic is 256 * 2K bytes whatever the weight format.
-template <int FMT, int R, int U, int PRO, bool GEGLU, bool F32OUT, int XC>
+template <int FMT, int R, int U, int PRO, bool GEGLU, bool F32OUT, int XC, int XSRC = X_PLAIN>
 __global__ __launch_bounds__(1024) void matvec_kernel(const MatvecParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ float red_a[16 * XC], red_b[16 * XC];
     u32x4 rkeep[XC];
-    matvec_body<FMT, R, U, PRO, GEGLU, F32OUT ? Y_F32 : Y_BF16, XC, X_PLAIN, RES_MEM>(
+    matvec_body<FMT, R, U, PRO, GEGLU, F32OUT ? Y_F32 : Y_BF16, XC, XSRC, RES_MEM>(
         p, reinterpret_cast<u32x4*>(smem_raw), red_a, red_b, (int)blockIdx.x, (int)gridDim.x, rkeep, NoWait{});
 }
 
@@ -129,6 +129,31 @@ static int dispatch_RU(const MatvecParams& p, hipStream_t s)
     return launch<FMT, 2, 2, PRO, GEGLU, F32OUT>(p, max_blocks, s);
 }
 
+// o_proj with the attention combine as its prologue: the short-matrix launch shape of the format, x chunks per thread 1
+template <int FMT, int U, int XSRC>
+static int launch_combine_t(const MatvecParams& p, hipStream_t s)
+{
+    constexpr int EPC = Fmt<FMT>::kElemsPerChunk;
+    const int nchunks = p.K / EPC;
+    const int S = (nchunks + 64 * U - 1) / (64 * U);
+    const size_t lds = (size_t)S * 64 * U * EPC * 2;
+    MILA_REQUIRE(lds <= 65536, "matvec_attn_combine: K=%d needs %zu bytes of LDS for x (limit 65536)", p.K, lds);
+    int blocks = (p.N + kMatvecWaves - 1) / kMatvecWaves;
+    if (blocks > kNumCU) blocks = kNumCU;
+    hipLaunchKernelGGL((matvec_kernel<FMT, 1, U, 0, false, false, 1, XSRC>), dim3(blocks), dim3(64 * kMatvecWaves), lds, s, p);
+    MILA_LAUNCH_CHECK("matvec_attn_combine");
+}
+template <int XSRC>
+static int launch_combine(int fmt, const MatvecParams& p, hipStream_t s)
+{
+    switch (fmt)
+    {
+        case FMT_BF16: return launch_combine_t<FMT_BF16, 4, XSRC>(p, s);
+        case FMT_FP8: return launch_combine_t<FMT_FP8, 2, XSRC>(p, s);
+        default: return launch_combine_t<FMT_FP4, 1, XSRC>(p, s);
+    }
+}
+
 static int validate(const char* who, const void* y, const void* x, const void* W, const float* scales,
                     int fmt, int K, int N, int group)
 {
@@ -181,7 +206,7 @@ int mila_cdna4_matvec_bf16(uint16_t* y, const uint16_t* x, const uint16_t* W, co
 {
     int rc = validate("matvec_bf16", y, x, W, nullptr, FMT_BF16, K, N, 0);
     if (rc) return rc;
-    MatvecParams p{y, x, reinterpret_cast<const uint8_t*>(W), nullptr, bias, nullptr, nullptr, nullptr, nullptr, 1.0f, 0.0f, K, N, 0};
+    MatvecParams p{y, x, reinterpret_cast<const uint8_t*>(W), nullptr, bias, nullptr, nullptr, nullptr, nullptr, 1.0f, 0.0f, K, N, 0, 0, 0};
     return dispatch_fmt<0, false, false>(FMT_BF16, p, as_stream(stream));
 }
 
@@ -190,7 +215,7 @@ int mila_cdna4_matvec_bf16_qfp8(uint16_t* y, const uint16_t* x, const uint8_t* W
 {
     int rc = validate("matvec_bf16_qfp8", y, x, W, scales, FMT_FP8, K, N, 0);
     if (rc) return rc;
-    MatvecParams p{y, x, W, scales, bias, nullptr, nullptr, nullptr, nullptr, 1.0f, 0.0f, K, N, 0};
+    MatvecParams p{y, x, W, scales, bias, nullptr, nullptr, nullptr, nullptr, 1.0f, 0.0f, K, N, 0, 0, 0};
     return dispatch_fmt<0, false, false>(FMT_FP8, p, as_stream(stream));
 }
 
@@ -199,7 +224,7 @@ int mila_cdna4_matvec_bf16_qfp4(uint16_t* y, const uint16_t* x, const uint8_t* W
 {
     int rc = validate("matvec_bf16_qfp4", y, x, W_packed, scales, FMT_FP4, K, N, group);
     if (rc) return rc;
-    MatvecParams p{y, x, W_packed, scales, bias, nullptr, nullptr, nullptr, nullptr, 1.0f, 0.0f, K, N, group};
+    MatvecParams p{y, x, W_packed, scales, bias, nullptr, nullptr, nullptr, nullptr, 1.0f, 0.0f, K, N, group, 0, 0};
     return dispatch_fmt<0, false, false>(FMT_FP4, p, as_stream(stream));
 }
 
@@ -208,8 +233,23 @@ int mila_cdna4_matvec_f32out(float* y, const uint16_t* x, const void* W, const f
 {
     int rc = validate("matvec_f32out", y, x, W, scales, fmt, K, N, group);
     if (rc) return rc;
-    MatvecParams p{y, x, reinterpret_cast<const uint8_t*>(W), scales, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, 0.0f, K, N, group};
+    MatvecParams p{y, x, reinterpret_cast<const uint8_t*>(W), scales, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, 0.0f, K, N, group, 0, 0};
     return dispatch_fmt<0, false, true>(fmt, p, as_stream(stream));
+}
+
+int mila_cdna4_matvec_attn_combine(uint16_t* y, const void* partials, int splits, int NH, int HS, const void* W, const float* scales,
+                                   int fmt, int N, int group, mila_stream_t stream)
+{
+    MILA_REQUIRE(partials != nullptr, "matvec_attn_combine: null partials");
+    MILA_REQUIRE(HS == 256 || HS == 512, "matvec_attn_combine: head size %d must be 256 or 512 (a wave's 64 chunks span 2 or 1 heads)", HS);
+    MILA_REQUIRE(NH > 0 && splits > 1 && splits <= 64, "matvec_attn_combine: need NH > 0 and 1 < splits <= 64 (NH=%d splits=%d)", NH, splits);
+    const int K = NH * HS;
+    MILA_REQUIRE(K <= 8192, "matvec_attn_combine: NH * HS = %d exceeds 8192", K);
+    int rc = validate("matvec_attn_combine", y, partials, W, scales, fmt, K, N, group);
+    if (rc) return rc;
+    MatvecParams p{y, reinterpret_cast<const uint16_t*>(partials), reinterpret_cast<const uint8_t*>(W), scales, nullptr, nullptr, nullptr, nullptr,
+                   nullptr, 1.0f, 0.0f, K, N, group, splits, NH};
+    return HS == 512 ? launch_combine<X_COMBINE_1>(fmt, p, as_stream(stream)) : launch_combine<X_COMBINE_2>(fmt, p, as_stream(stream));
 }
 
 int mila_cdna4_fused_norm_matvec(const mila_fused_matvec_args* a, mila_stream_t stream)
@@ -227,7 +267,7 @@ int mila_cdna4_fused_norm_matvec(const mila_fused_matvec_args* a, mila_stream_t 
         MILA_REQUIRE(a->res_out != a->res && a->res_out != a->x, "fused_norm_matvec: res_out must not alias res or x");
     }
     MatvecParams p{a->y, a->x, reinterpret_cast<const uint8_t*>(a->W), a->scales, nullptr, a->norm_w, a->post_w,
-                   a->res, a->res_out, a->post_scale, a->eps, a->K, a->N, a->group};
+                   a->res, a->res_out, a->post_scale, a->eps, a->K, a->N, a->group, 0, 0};
     hipStream_t s = as_stream(stream);
     MILA_REQUIRE(!(a->geglu && a->f32_out), "fused_norm_matvec: geglu and f32_out are exclusive");
     if (a->f32_out)

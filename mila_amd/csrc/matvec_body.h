@@ -64,6 +64,7 @@ struct MatvecParams
     uint16_t* res_out;
     float post_scale, eps;
     int K, N, group;
+    int comb_splits, comb_heads;   // X_COMBINE: x = combine of the decode-attention split partials [heads, splits, HS + 4] at p.x
 };
 
 constexpr int kMatvecWaves = 16;   // 1024 threads
@@ -115,7 +116,7 @@ __device__ __forceinline__ u32x4 handoff_load8(const uint32_t* v, int c)
 struct NoWait { __device__ __forceinline__ void operator()() const {} };
 
 enum { Y_BF16 = 0, Y_F32 = 1, Y_HANDOFF = 2 };     // where a phase writes its outputs
-enum { X_PLAIN = 0, X_HANDOFF = 1 };               // where a phase reads x (p.x reinterpreted for hand-off)
+enum { X_PLAIN = 0, X_HANDOFF = 1, X_COMBINE_1 = 2, X_COMBINE_2 = 3 };   // where x comes from (p.x reinterpreted); COMBINE_n: n heads per wave
 enum { RES_MEM = 0, RES_REG = 1 };                 // residual operand of the sandwich tail
 
 // PRO: 0 = x as is; 1 = x <- rmsnorm(x; norm_w); 2 = sandwich tail (see mila_cdna4.h)
@@ -191,6 +192,74 @@ __device__ __forceinline__ void matvec_body(const MatvecParams& p, u32x4* xs, fl
     WBuf<FMT, U, NR> ba, bb;
     issue(ba, ci_rg, ci_s); advance(ci_rg, ci_s);
     issue(bb, ci_rg, ci_s); advance(ci_rg, ci_s);
+
+    // ---- x = attention output combined from the flash-decode split partials (attn_combine_kernel's arithmetic, element for
+    //      element: M = max m_s, f_s = exp(m_s - M), L = sum l_s f_s (64-lane butterflies with lane = split), acc = fma chain over
+    //      the splits in order, y = bf16(acc / L)); a wave's 64 chunks span HPW = 512 / HS heads.  Runs under the weight prefetch.
+    if constexpr (XSRC == X_COMBINE_1 || XSRC == X_COMBINE_2)
+    {
+        constexpr int HPW = (XSRC == X_COMBINE_1) ? 1 : 2;
+        const float* part = reinterpret_cast<const float*>(p.x);
+        const int splits = p.comb_splits, HS = 512 / HPW, STR = HS + 4;
+#pragma unroll
+        for (int k = 0; k < XC; ++k)
+        {
+            const int c = tid + 1024 * k;
+            const int h0 = ((c & ~63) * 8) / HS;                       // first head of this wave's 64 chunks
+            const int myj = (HPW == 1) ? 0 : (lane >> 5);              // this lane's head within the wave
+            float fs[HPW], Lh[HPW];
+#pragma unroll
+            for (int j = 0; j < HPW; ++j)
+            {
+                const int h = min(h0 + j, p.comb_heads - 1);
+                const float* hb = part + (size_t)h * splits * STR;
+                const float ms = (lane < splits) ? hb[(size_t)lane * STR + HS] : -INFINITY;
+                const float ls = (lane < splits) ? hb[(size_t)lane * STR + HS + 1] : 0.0f;
+                const float M = wave_max(ms);
+                fs[j] = (ms == -INFINITY) ? 0.0f : __expf(ms - M);
+                Lh[j] = wave_sum(ls * fs[j]);
+            }
+            const int h = min(h0 + myj, p.comb_heads - 1);
+            const float* vb = part + (size_t)h * splits * STR + (size_t)((c * 8) % HS);
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+            for (int s0 = 0; s0 < splits; s0 += 8)
+            {
+                f32x4 va[8], vb2[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                {
+                    const float* src = vb + (size_t)min(s0 + u, splits - 1) * STR;
+                    va[u] = *reinterpret_cast<const f32x4*>(src);
+                    vb2[u] = *reinterpret_cast<const f32x4*>(src + 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                {
+                    const int si = min(s0 + u, 63);
+                    float f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fs[0]), si));
+                    if constexpr (HPW == 2)
+                    {
+                        const float f1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fs[1]), si));
+                        f = myj ? f1 : f;
+                    }
+                    if (s0 + u >= splits) f = 0.0f;                     // past the last split: fma(x, 0, acc) leaves acc as it is
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                    {
+                        acc[e] = fmaf(va[u][e], f, acc[e]);
+                        acc[4 + e] = fmaf(vb2[u][e], f, acc[4 + e]);
+                    }
+                }
+            }
+            float L = Lh[0];
+            if constexpr (HPW == 2) L = myj ? Lh[1] : Lh[0];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                px[k][d] = pack_bf16x2(L > 0.0f ? acc[2 * d] / L : 0.0f, L > 0.0f ? acc[2 * d + 1] / L : 0.0f);
+        }
+    }
 
     // ---- the previous phase's outputs become readable here (chain); no-op for the plain kernel ----
     wait();

@@ -629,12 +629,28 @@ namespace Mila::Dnn
                 const uint16_t* vp = g ? kp : kp + (size_t)NKV * HD;
                 const size_t need = attnScratchBytes();
                 void* scratch = ctx_->getScratch( need );
-                Compute::rocmCheck( mila_cdna4_fused_attn_decode_bf16( attn_out_->data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
-                                                                       L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(),
-                                                                       scratch, need, NH, NKV, HD, (int)L.attn->cacheCapacity(), position, pos_dev,
-                                                                       (int)cfg_.windowFor( g ), L.attn->scale(), cfg_.rms_norm_eps, st ) );
-                // 4. o_proj
-                plainMatvec( *L.o_proj, f_o_->data(), attn_out_->data() );
+                const int splits = combineSplits( L );
+                if ( splits > 1 )
+                {
+                    // small partial set (sliding-window layers): no combine launch, o_proj combines the splits in its prologue
+                    Compute::rocmCheck( mila_cdna4_fused_attn_decode_partials_bf16( L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
+                                                                                    L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(),
+                                                                                    scratch, need, NH, NKV, HD, (int)L.attn->cacheCapacity(), position, pos_dev,
+                                                                                    (int)cfg_.windowFor( g ), L.attn->scale(), cfg_.rms_norm_eps, st ) );
+                    const float* sc = nullptr;
+                    if constexpr ( TWeightQuant::kIsQuantized ) sc = L.o_proj->getWeightScale()->data();
+                    Compute::rocmCheck( mila_cdna4_matvec_attn_combine( f_o_->data(), scratch, splits, NH, HD, L.o_proj->getWeight().rawData(), sc, kFmt,
+                                                                        (int)cfg_.embedding_dim, Quant::Weight::groupSizeOf<TWeightQuant>(), st ) );
+                }
+                else
+                {
+                    Compute::rocmCheck( mila_cdna4_fused_attn_decode_bf16( attn_out_->data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
+                                                                           L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(),
+                                                                           scratch, need, NH, NKV, HD, (int)L.attn->cacheCapacity(), position, pos_dev,
+                                                                           (int)cfg_.windowFor( g ), L.attn->scale(), cfg_.rms_norm_eps, st ) );
+                    // 4. o_proj
+                    plainMatvec( *L.o_proj, f_o_->data(), attn_out_->data() );
+                }
                 // 5. post_attn_norm + residual + pre_ffn_norm + gate_up + GeGLU
                 fusedGateUp( L );
                 // 6. fc_down
@@ -728,7 +744,27 @@ namespace Mila::Dnn
             Compute::rocmCheck( mila_cdna4_decode_chain( &c, ctx_->getStream() ) );
         }
 
+        /// split count when layer L's attention combine is folded into its o_proj (0 = keep the combine launch): the partial set
+        /// every o_proj workgroup re-reads must stay small, and a wave's 64 x-chunks must span whole heads (HS 256 / 512)
+        int combineSplits( Layer& L ) const
+        {
+            if ( !combine_in_oproj_ ) return 0;
+            const bool g = L.global;
+            const int NH = (int)cfg_.num_heads, NKV = (int)cfg_.numKvHeads( g ), HD = (int)cfg_.headDim( g );
+            if ( ( HD != 256 && HD != 512 ) || NH * HD > 8192 ) return 0;
+            const int splits = mila_cdna4_attn_decode_split_count( 1, NH, NKV, HD, (int)L.attn->cacheCapacity(), (int)cfg_.windowFor( g ) );
+            if ( splits <= 1 || (size_t)NH * splits * ( HD + 4 ) * 4 > ( 512u << 10 ) ) return 0;
+            return splits;
+        }
+
     public:
+        /// fold the flash-decode combine into o_proj's prologue where the partial set is small (opt-in: every o_proj workgroup
+        /// re-reading the partials from L2 costs more than the combine launch it removes; same bits)
+        void setCombineInOProj( bool on )
+        {
+            if ( graph_exec_ ) throw std::runtime_error( "GemmaTransformer::setCombineInOProj: the graph is already captured" );
+            combine_in_oproj_ = on;
+        }
         /// whether the decode chain kernel serves this configuration (D, attention width <= 8192, F <= 16384, ...)
         bool chainApplicable() const
         {
@@ -771,6 +807,7 @@ namespace Mila::Dnn
         std::unique_ptr<LogitsTensor> sample_scratch_;
         bool sample_in_graph_{ false };
         bool use_chain_{ false };
+        bool combine_in_oproj_{ false };   // measured slower on MI355X (bf16 222 -> 217, fp4 415 -> 396 tok/s): opt-in, DESIGN.md section 5
         bool fused_prefill_{ true };
         std::unique_ptr<TensorType> pf_norm_, pf_norm2_;
         std::unique_ptr<LogitsTensor> chain_scratch_;

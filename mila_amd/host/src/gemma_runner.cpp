@@ -131,6 +131,12 @@ HOST_API int mila_gemma_set_fused_prefill( void* h, int on )
     auto* r = static_cast<Runner*>( h );
     return guarded( [&] { std::visit( [&]( auto& m ) { m->setFusedPrefill( on != 0 ); }, r->model ); } );
 }
+/// on != 0 (default): layers with a small split-partial set run the attention combine inside o_proj's prologue
+HOST_API int mila_gemma_set_combine_in_oproj( void* h, int on )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&] { std::visit( [&]( auto& m ) { m->setCombineInOProj( on != 0 ); }, r->model ); } );
+}
 /// 1 if the chain launch is in use, 0 if not
 HOST_API int mila_gemma_uses_chain( void* h )
 {

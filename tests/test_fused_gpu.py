@@ -296,3 +296,42 @@ def test_tail_norm_equals_rmsnorm_residual_scale_rmsnorm(D, post_scale, with_nex
         assert np.array_equal(bits(x0), bits(x1)), "normed output differs"
     with pytest.raises(capi.InvalidArgument):
         capi.call("fused_tail_norm_bf16", r1, None, a, res, pw, None, T, 512, post_scale, 1e-6)
+
+
+@pytest.mark.parametrize("NH,NKV,HS,rot,base,window,kv_shared,cap", [(16, 8, 256, 0, 1e4, 1024, False, 2048), (16, 1, 512, 128, 1e6, 0, True, 512),
+                                                                     (4, 2, 256, 0, 1e4, 128, False, 256)])
+@pytest.mark.parametrize("fmt", [0, 1, 2])
+@pytest.mark.parametrize("pos", [3, 200, 1500])
+def test_attention_partials_plus_combining_o_proj_equals_attention_plus_o_proj(NH, NKV, HS, rot, base, window, kv_shared, cap, fmt, pos):
+    """flash-decode without its combine launch + an o_proj whose prologue combines the split partials == the two-launch
+    attention + the plain o_proj Linear, bit for bit (cache rows too)"""
+    pos = min(pos, cap - 1)
+    rng = np.random.default_rng(HS + NKV + pos + fmt)
+    max_seq, D = 2048, 520
+    lib = capi.load()
+    splits = lib.mila_cdna4_attn_decode_split_count(1, NH, NKV, HS, cap, window)
+    assert splits > 1
+    Kc0 = torch.from_numpy(orc.to_bf16_bits(rng.uniform(-1, 1, (1, NKV, cap, HS)).astype(np.float32) * 0.5).view(np.int16)).cuda()
+    Vc0 = torch.from_numpy(orc.to_bf16_bits(rng.uniform(-1, 1, (1, NKV, cap, HS)).astype(np.float32)).view(np.int16)).cuda()
+    q = _bf(rng.standard_normal((NH, HS)))
+    k = _bf(rng.standard_normal((NKV, HS)))
+    v = k if kv_shared else _bf(rng.standard_normal((NKV, HS)))
+    qw, kw = _d(_bf(1 + 0.1 * rng.uniform(-1, 1, HS))), _d(_bf(1 + 0.1 * rng.uniform(-1, 1, HS)))
+    cos, sin = empty_f32(max_seq, HS // 2), empty_f32(max_seq, HS // 2)
+    capi.call("rope_build_cache", cos, sin, max_seq, HS, float(base), rot)
+    nbytes = lib.mila_cdna4_attn_decode_scratch_bytes(1, NH, HS)
+    scratch = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    W, s, _ = _weights(rng, D, NH * HS, fmt)
+    # two launches + plain Linear
+    K0, V0, a0, y0 = Kc0.clone(), Vc0.clone(), empty_u16(NH * HS), empty_u16(D)
+    capi.call("fused_attn_decode_bf16", a0, K0, V0, _d(q), _d(k), _d(v), qw, kw, None, cos, sin, scratch, C.c_size_t(nbytes), NH, NKV, HS,
+              cap, pos, None, window, 1.0, 1e-6)
+    _matvec(fmt, y0, a0, W, s, NH * HS, D)
+    # partials + combining Linear
+    K1, V1, y1 = Kc0.clone(), Vc0.clone(), empty_u16(D)
+    scratch.zero_()
+    capi.call("fused_attn_decode_partials_bf16", K1, V1, _d(q), _d(k), _d(v), qw, kw, None, cos, sin, scratch, C.c_size_t(nbytes), NH, NKV, HS,
+              cap, pos, None, window, 1.0, 1e-6)
+    capi.call("matvec_attn_combine", y1, scratch, splits, NH, HS, W, s, fmt, D, 128)
+    assert np.array_equal(bits(K1), bits(K0)) and np.array_equal(bits(V1), bits(V0)), "cache rows differ"
+    assert np.array_equal(bits(y1), bits(y0)), "o_proj output differs"

@@ -162,3 +162,29 @@ def test_bounded_ring_kv_policy_matches_the_unbounded_cache(policy):
         tok = int(np.argmax(la))
     a.close()
     b.close()
+
+
+SPLIT = dict(vocab_size=1024, embedding_dim=1280, num_layers=6, num_heads=4, num_kv_heads=2, head_dim=256, hidden_dim=2560,
+             global_head_dim=512, num_global_kv_heads=1, window=128, sliding_window_pattern=6, global_rotary_dim=128)
+
+
+@pytest.mark.parametrize("policy", ["bf16", "fp4"])
+def test_combine_in_o_proj_gives_the_reference_order_bits(policy):
+    """a configuration whose decode attention really splits (window 128 -> 2 splits, global 256-row cache -> 4): with the
+    combine folded into o_proj (opt-in) the fused and graph paths must still equal the one-launch-per-component path"""
+    models = {m: host.Gemma(policy, SPLIT, max_seq=256, max_prefill=1, seed=21) for m in ("reference", "fused", "graph", "folded", "folded-graph")}
+    models["folded"].set_combine_in_oproj(True)
+    models["folded-graph"].set_combine_in_oproj(True)
+    mode_of = {"folded": "fused", "folded-graph": "graph"}
+    tok = 9
+    for pos in range(0, 140, 1):
+        step = {m: g.decode(tok, pos, mode_of.get(m, m)) for m, g in models.items()} if pos in (0, 1, 63, 64, 127, 128, 139) else None
+        if step is None:
+            for m, g in models.items():
+                g.decode(tok, pos, "fused" if m == "reference" else mode_of.get(m, m))      # advance every cache cheaply
+        else:
+            for m in ("fused", "graph", "folded", "folded-graph"):
+                assert np.array_equal(step["reference"].view(np.uint32), step[m].view(np.uint32)), "%s != reference-order at %d" % (m, pos)
+        tok = (tok * 7 + pos) % 1024
+    for g in models.values():
+        g.close()
