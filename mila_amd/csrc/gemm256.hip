@@ -306,12 +306,8 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
         if (more) stage_all(t + 2);
         load_a(t);
         load_b(t, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
         mma(0);
         load_b(t, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
         mma(1);
         if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
