@@ -74,9 +74,10 @@ def measured_traffic(policy):
     if not os.path.exists(path):
         return None, None
     fmt = {"bf16": 0, "fp8": 1, "fp4": 2}[policy]
-    want = "matvec_kernel<%d, 1, 2, 2, true, false>" % fmt
+    import re
+    want = re.compile(r"matvec_kernel<%d, \d+, \d+, 2, true, false" % fmt)      # <FMT, R, U, PRO=2, GEGLU, !F32OUT, ...>: fc_gate_up
     for k in json.load(open(path))["kernels"]:
-        if want in k["kernel"]:
+        if want.search(k["kernel"]):
             return k["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
     return None, None
 

@@ -121,6 +121,36 @@ MILA_API int mila_cdna4_gemm_geglu_bf16_w4a16_staged(uint16_t* Y, const uint16_t
                                                      const float* scales, int M, int K, int F, int group,
                                                      void* scratch, size_t scratch_bytes, mila_stream_t stream);
 
+/* W4A8 prefill: the reference's DEFAULT prefill for the fp4 policy (Linear/CudaLinearOp.ixx:646-715, kUseFp8ActivationPrefillPath):
+ *   sB   = max(max(group scales), 1e-12) * 6 / 448                       (fp4_weight_fp8_scale; once, at load: CudaW4A16Gemm.cu:244-294)
+ *   W8   = e4m3( lut(nibble) * (group scale * (1 / sB)) )                 (upcast_fp4_to_fp8: CudaW4A16Gemm.cu:300-323)
+ *   s_m  = max(absmax(x_m), 1e-12) / 448,  X8 = e4m3( x * (1 / s_m) )     (quantize_fp8_per_token: Fp8Prefill/CudaFp8Prefill.cu:108-160)
+ *   y    = bf16( float(bf16(sB * sum_k X8 W8)) * s_m + bias )             (fp8 x fp8 GEMM + cuda_fp8_apply_per_token_scales, :191-211)
+ * The contraction runs on v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3, unit block scales, fp32 accumulate) in the two LDS-DMA
+ * GEMM kernels; integer outputs (W8, X8) are bit-exact, y is within 1 bf16 ulp of the restated reference.  gemm_fp8_applicable()
+ * says whether a shape has an fp8 kernel (K % 128 == 0 and a full 256 x 256 or 256 x 128 grid); gemm_bf16_w4a8 runs the three
+ * steps with scratch = [W8 | X8 | s_m] of gemm_w4a8_scratch_bytes(M, K, N) bytes. */
+MILA_API int mila_cdna4_fp4_weight_fp8_scale(float* out_scale, const float* group_scales, int64_t num_scales,
+                                             mila_stream_t stream);
+MILA_API int mila_cdna4_upcast_fp4_to_fp8(uint8_t* out, const uint8_t* W_packed, const float* scales,
+                                          const float* weight_fp8_scale, int N, int K, int group, mila_stream_t stream);
+MILA_API int mila_cdna4_quantize_fp8_per_token(uint8_t* dst, float* token_scales, const uint16_t* X, int M, int K,
+                                               mila_stream_t stream);
+MILA_API int mila_cdna4_gemm_fp8_applicable(int M, int K, int N);
+MILA_API int mila_cdna4_gemm_fp8_scaled(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* token_scales,
+                                        const float* weight_scale, const uint16_t* bias, int M, int K, int N,
+                                        mila_stream_t stream);
+MILA_API size_t mila_cdna4_gemm_w4a8_scratch_bytes(int M, int K, int N);
+MILA_API int mila_cdna4_gemm_bf16_w4a8(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed, const float* scales,
+                                       const float* weight_fp8_scale, const uint16_t* bias, int M, int K, int N,
+                                       int group, void* scratch, size_t scratch_bytes, mila_stream_t stream);
+/* the same with the GeGLU epilogue (W_packed = [gate | up] rows, Y[M, F]): bit-identical to gemm_bf16_w4a8 + geglu_bf16;
+ * scratch = gemm_w4a8_scratch_bytes(M, K, 2 F) */
+MILA_API int mila_cdna4_gemm_geglu_w4a8_applicable(int M, int K, int F);
+MILA_API int mila_cdna4_gemm_geglu_bf16_w4a8(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed, const float* scales,
+                                             const float* weight_fp8_scale, int M, int K, int F, int group,
+                                             void* scratch, size_t scratch_bytes, mila_stream_t stream);
+
 /* 2-phase forms for quantized weights (the reference's own structure, Linear/CudaLinearOp.ixx:597-644, :716-764:
  * dequantize to a bf16 scratch, then the bf16 GEMM).  Chosen automatically when the 256 x 256 LDS-DMA GEMM
  * applies to (M,K,N) -- gemm_staging_bytes() says how much scratch that needs (0 = the register-dequantizing kernel is

@@ -257,6 +257,35 @@ __global__ void selftest_decode_kernel(float* out_fp8, float* out_fp4)
     }
 }
 
+// one v_mfma_scale_f32_16x16x128_f8f6f4 (fp8 e4m3 x fp8 e4m3, unit scales): C[16,16] = A[16,128] B[16,128]^T with the operand
+// layout the fp8 GEMM assumes: lane l holds row l & 15, bytes k = 32 (l >> 4) .. + 31 (mode 0) or the two-half layout
+// k = 16 (l >> 4) + j, 64 + 16 (l >> 4) + j (mode 1).  tests/test_linear_gpu.py checks which one the hardware implements.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__global__ void selftest_mfma_fp8_kernel(float* C, const uint8_t* A, const uint8_t* B, int mode)
+{
+    const int lane = threadIdx.x & 63, row = lane & 15, kg = lane >> 4;
+    i32x8 a, b;
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+    {
+        uint32_t wa = 0, wb = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            const int byte = 4 * d + j;
+            const int k = (mode == 0) ? 32 * kg + byte : (byte < 16 ? 16 * kg + byte : 64 + 16 * kg + (byte - 16));
+            wa |= (uint32_t)A[row * 128 + k] << (8 * j);
+            wb |= (uint32_t)B[row * 128 + k] << (8 * j);
+        }
+        a[d] = (int)wa;
+        b[d] = (int)wb;
+    }
+    f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[(4 * kg + r) * 16 + row] = c[r];      // D[i = 4 (l >> 4) + r][j = l & 15]
+}
+
 __global__ void selftest_wave_reduce_kernel(float* out, const float* in)
 {
     const float v = in[threadIdx.x];
@@ -422,6 +451,13 @@ int mila_cdna4_selftest_decode(float* out_fp8, float* out_fp4, mila_stream_t str
     MILA_REQUIRE(out_fp8 && out_fp4, "selftest_decode: null pointer");
     hipLaunchKernelGGL(selftest_decode_kernel, dim3(1), dim3(256), 0, as_stream(stream), out_fp8, out_fp4);
     MILA_LAUNCH_CHECK("selftest_decode");
+}
+
+int mila_cdna4_selftest_mfma_fp8(float* C, const uint8_t* A, const uint8_t* B, int mode, mila_stream_t stream)
+{
+    MILA_REQUIRE(C && A && B, "selftest_mfma_fp8: null pointer");
+    hipLaunchKernelGGL(selftest_mfma_fp8_kernel, dim3(1), dim3(64), 0, as_stream(stream), C, A, B, mode);
+    MILA_LAUNCH_CHECK("selftest_mfma_fp8");
 }
 
 int mila_cdna4_selftest_wave_reduce(float* out, const float* in, mila_stream_t stream)

@@ -28,7 +28,12 @@ struct Gemm256Params
     const uint16_t* W;
     const uint16_t* bias;
     int M, K, N, tiles_m, tiles_n;     // GEGLU: N = F output columns, W has 2 F rows [gate | up]
+    // FP8 mode (W4A8 / W8A8 prefill): X and W are e4m3 bytes [M, K] / [N, K]; y = bf16(float(bf16(acc * *w_scale)) * x_scales[m] + bias)
+    const float* x_scales;   // [M] per-token activation scales
+    const float* w_scale;    // device scalar: per-tensor weight scale
 };
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+enum { G_PLAIN = 0, G_GEGLU = 1, G_FP8 = 2, G_FP8_GEGLU = 3 };
 
 constexpr int kHalfBytes = 128 * 128;          // 128 rows x 64 bf16
 constexpr int kBufBytes = 4 * kHalfBytes;      // W0 W1 X0 X1
@@ -38,9 +43,17 @@ __device__ __forceinline__ int half_off(bool isX, int half) { return (isX ? 2 * 
 // GEGLU: the tile's two W half-tiles are 128 gate rows (n0 ..) and the matching 128 up rows (F + n0 ..), so a lane's
 // accumulators acc[0][..] / acc[1][..] hold gate and up of the SAME outputs and the epilogue writes
 // bf16(gelu_tanh(bf16(gate)) * bf16(up)) -- the Linear + GeGLU pair of Gemma.Block.ixx:343-348 without the [M, 2F] round trip.
-template <bool GEGLU>
+// MODE G_FP8: the same tile geometry in BYTES (a half-tile is 128 rows x 128 B = 128 e4m3 of K), one
+// v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) per 16 x 16 sub-tile and K-tile instead of two 16x16x32 bf16 MFMAs
+// over half the K: twice the FLOPs per LDS byte and per barrier.  Lane l supplies row l & 15 and the 32 bytes
+// k = 32 (l >> 4) .. + 31 of both operands (selftest_mfma_fp8 pins that layout).
+template <int MODE>
 __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 {
+    constexpr bool GEGLU = (MODE == G_GEGLU || MODE == G_FP8_GEGLU);
+    constexpr bool FP8 = (MODE == G_FP8 || MODE == G_FP8_GEGLU);
+    constexpr int ES = FP8 ? 1 : 2;            // bytes per element
+    constexpr int KT = 128 / ES;               // elements of K per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int nwg = gridDim.x, id = blockIdx.x;
@@ -54,12 +67,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, g = lane >> 4;
-    const int K = p.K, nk = K / 64;
+    const int K = p.K, nk = K / KT;
+    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(p.X);
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
 
     // ---- staging: half-tile (isX, half) of K-tile kt into buffer kt & 1 ----
     const int srow = lane >> 3, sslot = lane & 7;          // this lane's row within a 1 KiB chunk / 16-byte slot
     auto stage = [&](int kt, bool isX, int half) {
-        const uint16_t* base = isX ? p.X + (size_t)(m0 + half * 128) * K : p.W + (size_t)(half ? wrow1 : n0) * K;
+        const unsigned char* base = isX ? Xb + (size_t)(m0 + half * 128) * K * ES : Wb + (size_t)(half ? wrow1 : n0) * K * ES;
         unsigned char* dst_half = smem + (kt & 1) * kBufBytes + half_off(isX, half);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -67,7 +82,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
             const int chunk = i * 8 + wave;                // 16 chunks of 8 rows
             const int row = chunk * 8 + srow;              // row within the half-tile
             const int kslot = sslot ^ ((row >> 1) & 7);    // swizzle on the source address
-            const uint16_t* src = base + (size_t)row * K + (size_t)kt * 64 + kslot * 8;
+            const unsigned char* src = base + (size_t)row * K * ES + (size_t)kt * 128 + kslot * 16;
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(dst_half + chunk * 1024), 16, 0, 0);
         }
     };
@@ -82,7 +97,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 #pragma unroll
                 for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
+    // fragment registers: bf16 = [ks] halves of 16 B (k slots 4 ks + g); fp8 = the two 16-B slots 2 g, 2 g + 1 of one 32-byte operand
     s16x8 fa[4][2], fb[2][2];
+    auto frag_slot = [&](int ks) { return FP8 ? (2 * g + ks) : (ks * 4 + g); };
     auto load_a = [&](int kt, int hA) {
         const unsigned char* hb = smem + (kt & 1) * kBufBytes + half_off(false, hA);
 #pragma unroll
@@ -91,7 +108,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
             const int r = wr * 64 + pt * 16 + l15;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                fa[pt][ks] = *reinterpret_cast<const s16x8*>(hb + r * 128 + (((ks * 4 + g) ^ ((r >> 1) & 7)) << 4));
+                fa[pt][ks] = *reinterpret_cast<const s16x8*>(hb + r * 128 + ((frag_slot(ks) ^ ((r >> 1) & 7)) << 4));
         }
     };
     auto load_b = [&](int kt, int hB) {
@@ -102,19 +119,35 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
             const int r = wc * 32 + qt * 16 + l15;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                fb[qt][ks] = *reinterpret_cast<const s16x8*>(hb + r * 128 + (((ks * 4 + g) ^ ((r >> 1) & 7)) << 4));
+                fb[qt][ks] = *reinterpret_cast<const s16x8*>(hb + r * 128 + ((frag_slot(ks) ^ ((r >> 1) & 7)) << 4));
         }
     };
     auto mma = [&](int hA, int hB) {
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        if constexpr (FP8)
+        {
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
-                    acc[hA][hB][pt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, fa[pt][ks]), __builtin_bit_cast(bf16x8, fb[qt][ks]), acc[hA][hB][pt][qt], 0, 0, 0);
+                {
+                    struct Pair { s16x8 lo, hi; };
+                    const i32x8 a8 = __builtin_bit_cast(i32x8, (Pair{fa[pt][0], fa[pt][1]}));
+                    const i32x8 b8 = __builtin_bit_cast(i32x8, (Pair{fb[qt][0], fb[qt][1]}));
+                    acc[hA][hB][pt][qt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[hA][hB][pt][qt], 0, 0, 0, 127, 0, 127);
+                }
+        }
+        else
+        {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                        acc[hA][hB][pt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fa[pt][ks]), __builtin_bit_cast(bf16x8, fb[qt][ks]), acc[hA][hB][pt][qt], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     // end of a phase: retire everything but the 3 youngest half-tiles, then let every wave see it
@@ -178,9 +211,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                     const int n = n0 + wr * 64 + pt * 16 + 4 * g;
                     const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
                     float v[4];
+                    if constexpr (FP8)
+                    {
+                        // gate / up as the W4A8 Linear stores them (bf16(float(bf16(acc * sB)) * s_m)), then the GeGLU kernel's product
+                        const float ws = *p.w_scale, ts = p.x_scales[m];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = gelu_tanh(round_bf16(acc[0][hB][pt][qt][e])) * round_bf16(acc[1][hB][pt][qt][e]);
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = gelu_tanh(round_bf16(round_bf16(acc[0][hB][pt][qt][e] * ws) * ts)) * round_bf16(round_bf16(acc[1][hB][pt][qt][e] * ws) * ts);
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = gelu_tanh(round_bf16(acc[0][hB][pt][qt][e])) * round_bf16(acc[1][hB][pt][qt][e]);
+                    }
                     *reinterpret_cast<u32x2*>(p.Y + (size_t)m * p.N + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 }
     }
@@ -200,7 +244,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = acc[hA][hB][pt][qt][e];
-                        if (p.bias)
+                        if constexpr (FP8)
+                        {
+                            // the reference's two steps: the GEMM stores bf16(acc * weight scale), the per-token pass rescales (+ bias)
+                            const float ws = *p.w_scale, ts = p.x_scales[m];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                            {
+                                v[e] = round_bf16(v[e] * ws) * ts;
+                                if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
+                            }
+                        }
+                        else if (p.bias)
                         {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
@@ -217,9 +272,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 // K-tile t + 1 while t + 2 stays in flight.
 constexpr int kStage3Bytes = 3 * kHalfBytes;   // W, X0, X1
 
+template <bool FP8>
 __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ES = FP8 ? 1 : 2;
+    constexpr int KT = 128 / ES;
 
     const int nwg = gridDim.x, id = blockIdx.x;
     const int xcd = id & 7, qd = nwg >> 3, rem = nwg & 7;
@@ -231,12 +289,14 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, g = lane >> 4;
-    const int K = p.K, nk = K / 64;
+    const int K = p.K, nk = K / KT;
+    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(p.X);
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
 
     const int srow = lane >> 3, sslot = lane & 7;
     // which: 0 = W rows n0 .., 1 = X rows m0 .., 2 = X rows m0 + 128 ..
     auto stage = [&](int kt, int which) {
-        const uint16_t* base = which == 0 ? p.W + (size_t)n0 * K : p.X + (size_t)(m0 + (which - 1) * 128) * K;
+        const unsigned char* base = which == 0 ? Wb + (size_t)n0 * K * ES : Xb + (size_t)(m0 + (which - 1) * 128) * K * ES;
         unsigned char* dst_half = smem + (kt % 3) * kStage3Bytes + which * kHalfBytes;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -244,7 +304,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             const int chunk = i * 8 + wave;
             const int row = chunk * 8 + srow;
             const int kslot = sslot ^ ((row >> 1) & 7);
-            const uint16_t* src = base + (size_t)row * K + (size_t)kt * 64 + kslot * 8;
+            const unsigned char* src = base + (size_t)row * K * ES + (size_t)kt * 128 + kslot * 16;
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(dst_half + chunk * 1024), 16, 0, 0);
         }
     };
@@ -259,6 +319,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             for (int d = 0; d < 2; ++d) acc[b][c][d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     s16x8 fa[4][2], fb[2][2];
+    auto frag_slot = [&](int ks) { return FP8 ? (2 * g + ks) : (ks * 4 + g); };
     auto load_a = [&](int kt) {
         const unsigned char* hb = smem + (kt % 3) * kStage3Bytes;
 #pragma unroll
@@ -267,7 +328,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             const int r = wr * 64 + pt * 16 + l15;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                fa[pt][ks] = *reinterpret_cast<const s16x8*>(hb + r * 128 + (((ks * 4 + g) ^ ((r >> 1) & 7)) << 4));
+                fa[pt][ks] = *reinterpret_cast<const s16x8*>(hb + r * 128 + ((frag_slot(ks) ^ ((r >> 1) & 7)) << 4));
         }
     };
     auto load_b = [&](int kt, int hB) {
@@ -278,19 +339,35 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             const int r = wc * 32 + qt * 16 + l15;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                fb[qt][ks] = *reinterpret_cast<const s16x8*>(hb + r * 128 + (((ks * 4 + g) ^ ((r >> 1) & 7)) << 4));
+                fb[qt][ks] = *reinterpret_cast<const s16x8*>(hb + r * 128 + ((frag_slot(ks) ^ ((r >> 1) & 7)) << 4));
         }
     };
     auto mma = [&](int hB) {
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        if constexpr (FP8)
+        {
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
-                    acc[hB][pt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, fa[pt][ks]), __builtin_bit_cast(bf16x8, fb[qt][ks]), acc[hB][pt][qt], 0, 0, 0);
+                {
+                    struct Pair { s16x8 lo, hi; };
+                    const i32x8 a8 = __builtin_bit_cast(i32x8, (Pair{fa[pt][0], fa[pt][1]}));
+                    const i32x8 b8 = __builtin_bit_cast(i32x8, (Pair{fb[qt][0], fb[qt][1]}));
+                    acc[hB][pt][qt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[hB][pt][qt], 0, 0, 0, 127, 0, 127);
+                }
+        }
+        else
+        {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                        acc[hB][pt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fa[pt][ks]), __builtin_bit_cast(bf16x8, fb[qt][ks]), acc[hB][pt][qt], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -326,7 +403,17 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[hB][pt][qt][e];
-                if (p.bias)
+                if constexpr (FP8)
+                {
+                    const float ws = *p.w_scale, ts = p.x_scales[m];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                    {
+                        v[e] = round_bf16(v[e] * ws) * ts;
+                        if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
+                    }
+                }
+                else if (p.bias)
                 {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
@@ -344,19 +431,24 @@ bool gemm256x128_applicable(int M, int K, int N)
     return tiles >= 200 && tiles >= 0.70 * rounds * kNumCU;
 }
 
-int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
+template <bool FP8>
+static int launch_gemm256x128_t(const Gemm256Params& p, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set)
     {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel<FP8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                3 * kStage3Bytes), "hipFuncSetAttribute(gemm256x128)");
         if (rc) return rc;
         attr_set = true;
     }
-    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, N / 128};
-    hipLaunchKernelGGL(gemm256x128_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), 3 * kStage3Bytes, s, p);
+    hipLaunchKernelGGL(gemm256x128_kernel<FP8>, dim3(p.tiles_m * p.tiles_n), dim3(512), 3 * kStage3Bytes, s, p);
     MILA_LAUNCH_CHECK("gemm256x128");
+}
+int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
+{
+    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, N / 128, nullptr, nullptr};
+    return launch_gemm256x128_t<false>(p, s);
 }
 
 // one 512-thread workgroup per CU: worth it only when the tile count fills whole rounds of 256 CUs
@@ -368,25 +460,25 @@ bool gemm256_applicable(int M, int K, int N)
     return tiles >= 200 && tiles >= 0.85 * rounds * kNumCU;
 }
 
-template <bool GEGLU>
+template <int MODE>
 static int launch_gemm256_t(const Gemm256Params& p, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set)
     {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                2 * kBufBytes), "hipFuncSetAttribute(gemm256)");
         if (rc) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm256_kernel<GEGLU>, dim3(p.tiles_m * p.tiles_n), dim3(512), 2 * kBufBytes, s, p);
+    hipLaunchKernelGGL(gemm256_kernel<MODE>, dim3(p.tiles_m * p.tiles_n), dim3(512), 2 * kBufBytes, s, p);
     MILA_LAUNCH_CHECK("gemm256");
 }
 
 int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
 {
-    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, N / 256};
-    return launch_gemm256_t<false>(p, s);
+    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, N / 256, nullptr, nullptr};
+    return launch_gemm256_t<G_PLAIN>(p, s);
 }
 
 // Y[M, F] = GeGLU(X W^T), W = [gate rows 0 .. F-1 | up rows F .. 2F-1]
@@ -399,8 +491,34 @@ bool gemm256_geglu_applicable(int M, int K, int F)
 }
 int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s)
 {
-    Gemm256Params p{Y, X, W, nullptr, M, K, F, M / 256, F / 128};
-    return launch_gemm256_t<true>(p, s);
+    Gemm256Params p{Y, X, W, nullptr, M, K, F, M / 256, F / 128, nullptr, nullptr};
+    return launch_gemm256_t<G_GEGLU>(p, s);
+}
+
+// fp8 x fp8 (e4m3 bytes, K % 128 == 0): 2 = the 256 x 256 kernel, 1 = 256 x 128, 0 = no LDS-DMA kernel for this shape
+int gemm_fp8_kernel_for(int M, int K, int N)
+{
+    if (K % 128 != 0) return 0;
+    if (gemm256_applicable(M, K, N)) return 2;
+    if (gemm256x128_applicable(M, K, N)) return 1;
+    return 0;
+}
+// Y[M, F] = GeGLU of the W4A8 Linear over W8 = [gate rows | up rows] (2F x K e4m3)
+int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
+                          hipStream_t s)
+{
+    Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, M, K, F, M / 256, F / 128, x_scales, w_scale};
+    return launch_gemm256_t<G_FP8_GEGLU>(p, s);
+}
+int launch_gemm_fp8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
+                    int M, int K, int N, hipStream_t s)
+{
+    const int which = gemm_fp8_kernel_for(M, K, N);
+    Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), bias, M, K, N, M / 256,
+                    which == 2 ? N / 256 : N / 128, x_scales, w_scale};
+    if (which == 2) return launch_gemm256_t<G_FP8>(p, s);
+    if (which == 1) return launch_gemm256x128_t<true>(p, s);
+    return set_error(MILA_E_UNSUPPORTED, "gemm_fp8: no fp8 MFMA kernel for M=%d K=%d N=%d", M, K, N);
 }
 
 }  // namespace mila

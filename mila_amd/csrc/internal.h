@@ -17,6 +17,7 @@ MILA_API int mila_cdna4_tune_gemm(int force_128_tile);
 MILA_API int mila_cdna4_selftest_decode(float* out_fp8, float* out_fp4, mila_stream_t stream);
 /* out[0..63] = wave_sum(in[lane]), out[64..127] = wave_max, out[128..191] = the ds_bpermute butterfly */
 MILA_API int mila_cdna4_selftest_wave_reduce(float* out, const float* in, mila_stream_t stream);
+MILA_API int mila_cdna4_selftest_mfma_fp8(float* C, const uint8_t* A, const uint8_t* B, int mode, mila_stream_t stream);
 /* streaming-copy ceiling: dst <- src with 16-byte accesses; used to report a measured HBM roof */
 MILA_API int mila_cdna4_stream_copy(void* dst, const void* src, size_t bytes, mila_stream_t stream);
 MILA_API int mila_cdna4_stream_read(float* sink, const void* src, size_t bytes, mila_stream_t stream);

@@ -110,6 +110,98 @@ __global__ __launch_bounds__(256) void quantize_fp4_per_group_kernel(uint8_t* __
     (void)K;
 }
 
+// ---- W4A8 prefill staging (the reference's default fp4-policy prefill, CudaLinearOp.ixx:646-715) ----------------------
+// weight_fp8_scale = max(max(group scale), 1e-12) * (6 / 448)          (CudaW4A16Gemm.cu:244-294; exact max, any order)
+__global__ __launch_bounds__(1024) void fp4_weight_fp8_scale_kernel(float* __restrict__ out, const float* __restrict__ scales, int64_t n)
+{
+    __shared__ float red[16];
+    float m = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, scales[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+        out[0] = fmaxf(m, 1e-12f) * (6.0f / 448.0f);
+    }
+}
+
+// packed fp4 -> e4m3: out[2b], out[2b+1] = e4m3(lut(nibble) * (group scale * (1 / weight_fp8_scale)))  (CudaW4A16Gemm.cu:300-323)
+// one workgroup per output channel, one thread per 8 packed bytes (16 outputs = one 16-byte store): no index division
+__global__ __launch_bounds__(256) void upcast_fp4_to_fp8_kernel(uint8_t* __restrict__ out, const uint8_t* __restrict__ packed,
+                                                                const float* __restrict__ scales, const float* __restrict__ w_scale,
+                                                                int K, int group_shift)
+{
+    const float inv_ws = 1.0f / w_scale[0];
+    const size_t row = blockIdx.x;
+    const int vec_per_row = K >> 4;
+    const uint8_t* prow = packed + row * (size_t)(K >> 1);
+    const float* srow = scales + row * (size_t)(K >> group_shift);
+    uint8_t* orow = out + row * (size_t)K;
+    for (int v = threadIdx.x; v < vec_per_row; v += 256)
+    {
+        const int k0 = v << 4;
+        const float sc = srow[k0 >> group_shift] * inv_ws;
+        const u32x2 pk = *reinterpret_cast<const u32x2*>(prow + (k0 >> 1));
+        u32x4 o;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+        {
+            const uint32_t word = (w < 2) ? pk[0] : pk[1];
+            const uint32_t bytes2 = (word >> (16 * (w & 1))) & 0xffffu;       // two packed bytes = four elements
+            uint32_t r = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+            {
+                const uint32_t nib = (bytes2 >> (4 * e)) & 0xfu;
+                r |= f32_to_e4m3_rne_sat(fp4_decode_sw(nib) * sc) << (8 * e);
+            }
+            o[w] = r;
+        }
+        *reinterpret_cast<u32x4*>(orow + k0) = o;
+    }
+}
+
+// per-token activation quantization: scale = max(absmax(row), 1e-12) / 448, q = e4m3(x * (1 / scale))  (CudaFp8Prefill.cu:108-160)
+__global__ __launch_bounds__(256) void quantize_fp8_per_token_kernel(uint8_t* __restrict__ dst, float* __restrict__ scales,
+                                                                     const uint16_t* __restrict__ src, int K)
+{
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    const uint16_t* s = src + row * K;
+    uint8_t* d = dst + row * K;
+    const int nvec = K / 8;
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < nvec; i += 256)
+    {
+        const u32x4 v = ld16(s + (size_t)i * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(fabsf(bf16_lo(v[e])), fabsf(bf16_hi(v[e]))));
+    }
+    m = block_max<4>(m, red);
+    const float scale = fmaxf(m, 1e-12f) / 448.0f;
+    if (threadIdx.x == 0) scales[row] = scale;
+    const float inv = 1.0f / scale;
+    for (int i = threadIdx.x; i < nvec; i += 256)
+    {
+        const u32x4 v = ld16(s + (size_t)i * 8);
+        u32x2 o;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            o[h] = f32_to_e4m3_rne_sat(bf16_lo(v[2 * h]) * inv) | (f32_to_e4m3_rne_sat(bf16_hi(v[2 * h]) * inv) << 8) |
+                   (f32_to_e4m3_rne_sat(bf16_lo(v[2 * h + 1]) * inv) << 16) | (f32_to_e4m3_rne_sat(bf16_hi(v[2 * h + 1]) * inv) << 24);
+        *reinterpret_cast<u32x2*>(d + (size_t)i * 8) = o;
+    }
+}
+
+int gemm_fp8_kernel_for(int M, int K, int N);
+int launch_gemm_fp8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
+                    int M, int K, int N, hipStream_t s);
+bool gemm256_geglu_applicable(int M, int K, int F);
+int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
+                          hipStream_t s);
+
 }  // namespace mila
 
 using namespace mila;
@@ -143,6 +235,84 @@ int mila_cdna4_quantize_fp4_per_group(uint8_t* dst_packed, float* scales, const 
         hipLaunchKernelGGL(quantize_fp4_per_group_kernel<64>, dim3(blocks), dim3(256), 0, as_stream(stream),
                            dst_packed, scales, src_bf16, K, pairs);
     MILA_LAUNCH_CHECK("quantize_fp4_per_group");
+}
+
+int mila_cdna4_fp4_weight_fp8_scale(float* out_scale, const float* group_scales, int64_t num_scales, mila_stream_t stream)
+{
+    MILA_REQUIRE(out_scale && group_scales && num_scales > 0, "fp4_weight_fp8_scale: bad arguments");
+    hipLaunchKernelGGL(fp4_weight_fp8_scale_kernel, dim3(1), dim3(1024), 0, as_stream(stream), out_scale, group_scales, num_scales);
+    MILA_LAUNCH_CHECK("fp4_weight_fp8_scale");
+}
+
+int mila_cdna4_upcast_fp4_to_fp8(uint8_t* out, const uint8_t* packed, const float* scales, const float* weight_fp8_scale, int N, int K,
+                                 int group, mila_stream_t stream)
+{
+    MILA_REQUIRE(out && packed && scales && weight_fp8_scale, "upcast_fp4_to_fp8: null pointer");
+    MILA_REQUIRE(N > 0 && K > 0 && (group == 64 || group == 128) && K % group == 0 && K % 16 == 0, "upcast_fp4_to_fp8: bad sizes (N=%d K=%d group=%d)", N, K, group);
+    hipLaunchKernelGGL(upcast_fp4_to_fp8_kernel, dim3(N), dim3(256), 0, as_stream(stream), out, packed, scales, weight_fp8_scale, K, group == 128 ? 7 : 6);
+    MILA_LAUNCH_CHECK("upcast_fp4_to_fp8");
+}
+
+int mila_cdna4_quantize_fp8_per_token(uint8_t* dst, float* scales, const uint16_t* src, int M, int K, mila_stream_t stream)
+{
+    MILA_REQUIRE(dst && scales && src, "quantize_fp8_per_token: null pointer");
+    MILA_REQUIRE(M > 0 && K > 0 && K % 8 == 0, "quantize_fp8_per_token: bad sizes (M=%d K=%d)", M, K);
+    hipLaunchKernelGGL(quantize_fp8_per_token_kernel, dim3(M), dim3(256), 0, as_stream(stream), dst, scales, src, K);
+    MILA_LAUNCH_CHECK("quantize_fp8_per_token");
+}
+
+int mila_cdna4_gemm_fp8_applicable(int M, int K, int N) { return (M > 0 && K > 0 && N > 0 && gemm_fp8_kernel_for(M, K, N) != 0) ? 1 : 0; }
+
+int mila_cdna4_gemm_fp8_scaled(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* weight_scale,
+                               const uint16_t* bias, int M, int K, int N, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X8 && W8 && x_scales && weight_scale, "gemm_fp8_scaled: null pointer");
+    MILA_REQUIRE(mila_cdna4_gemm_fp8_applicable(M, K, N), "gemm_fp8_scaled: shape (M=%d, K=%d, N=%d) has no fp8 MFMA kernel (ask gemm_fp8_applicable)", M, K, N);
+    return launch_gemm_fp8(Y, X8, W8, x_scales, weight_scale, bias, M, K, N, as_stream(stream));
+}
+
+size_t mila_cdna4_gemm_w4a8_scratch_bytes(int M, int K, int N)
+{
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    const size_t w = ((size_t)N * K + 15) & ~(size_t)15, x = ((size_t)M * K + 15) & ~(size_t)15;
+    return w + x + (size_t)M * 4;
+}
+
+int mila_cdna4_gemm_bf16_w4a8(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed, const float* scales, const float* weight_fp8_scale,
+                              const uint16_t* bias, int M, int K, int N, int group, void* scratch, size_t scratch_bytes, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X && W_packed && scales && weight_fp8_scale, "gemm_bf16_w4a8: null pointer");
+    MILA_REQUIRE(mila_cdna4_gemm_fp8_applicable(M, K, N), "gemm_bf16_w4a8: shape (M=%d, K=%d, N=%d) has no fp8 MFMA kernel (ask gemm_fp8_applicable)", M, K, N);
+    const size_t need = mila_cdna4_gemm_w4a8_scratch_bytes(M, K, N);
+    if (!scratch || scratch_bytes < need) return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_bf16_w4a8: scratch %zu bytes < required %zu", scratch_bytes, need);
+    uint8_t* w8 = static_cast<uint8_t*>(scratch);
+    uint8_t* x8 = w8 + (((size_t)N * K + 15) & ~(size_t)15);
+    float* ts = reinterpret_cast<float*>(x8 + (((size_t)M * K + 15) & ~(size_t)15));
+    int rc = mila_cdna4_upcast_fp4_to_fp8(w8, W_packed, scales, weight_fp8_scale, N, K, group, stream);
+    if (rc) return rc;
+    rc = mila_cdna4_quantize_fp8_per_token(x8, ts, X, M, K, stream);
+    if (rc) return rc;
+    return launch_gemm_fp8(Y, x8, w8, ts, weight_fp8_scale, bias, M, K, N, as_stream(stream));
+}
+
+int mila_cdna4_gemm_geglu_w4a8_applicable(int M, int K, int F) { return (M > 0 && K > 0 && F > 0 && K % 128 == 0 && gemm256_geglu_applicable(M, K, F)) ? 1 : 0; }
+
+int mila_cdna4_gemm_geglu_bf16_w4a8(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed, const float* scales, const float* weight_fp8_scale,
+                                    int M, int K, int F, int group, void* scratch, size_t scratch_bytes, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X && W_packed && scales && weight_fp8_scale, "gemm_geglu_bf16_w4a8: null pointer");
+    MILA_REQUIRE(mila_cdna4_gemm_geglu_w4a8_applicable(M, K, F), "gemm_geglu_bf16_w4a8: shape (M=%d, K=%d, F=%d) is outside the fused kernel", M, K, F);
+    const int N = 2 * F;
+    const size_t need = mila_cdna4_gemm_w4a8_scratch_bytes(M, K, N);
+    if (!scratch || scratch_bytes < need) return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_geglu_bf16_w4a8: scratch %zu bytes < required %zu", scratch_bytes, need);
+    uint8_t* w8 = static_cast<uint8_t*>(scratch);
+    uint8_t* x8 = w8 + (((size_t)N * K + 15) & ~(size_t)15);
+    float* ts = reinterpret_cast<float*>(x8 + (((size_t)M * K + 15) & ~(size_t)15));
+    int rc = mila_cdna4_upcast_fp4_to_fp8(w8, W_packed, scales, weight_fp8_scale, N, K, group, stream);
+    if (rc) return rc;
+    rc = mila_cdna4_quantize_fp8_per_token(x8, ts, X, M, K, stream);
+    if (rc) return rc;
+    return launch_gemm_fp8_geglu(Y, x8, w8, ts, weight_fp8_scale, M, K, F, as_stream(stream));
 }
 
 }  // extern "C"

@@ -46,6 +46,7 @@ def load():
         _lib.mila_gemma_generate_sampled.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_uint32, C.c_void_p]
         _lib.mila_gemma_set_chain.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_uses_chain.argtypes = [C.c_void_p]
+        _lib.mila_gemma_set_fp8_activation_prefill.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_set_combine_in_oproj.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_set_fused_prefill.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gpt_last_error.restype = C.c_char_p
@@ -103,6 +104,10 @@ class Gemma:
         """fused / graph decode: fold the flash-decode combine into o_proj's prologue on layers with a small partial set
         (opt-in: measured slower than the combine launch it removes) or keep the combine launch; identical bits"""
         _check(load().mila_gemma_set_combine_in_oproj(self.h, int(bool(on))))
+
+    def set_fp8_activation_prefill(self, on):
+        """fp4 policy: W4A8 prefill on the fp8 matrix cores (default, the reference's default) or the exact-weight bf16 fallback"""
+        _check(load().mila_gemma_set_fp8_activation_prefill(self.h, int(bool(on))))
 
     def set_fused_prefill(self, on):
         """prefill with the fused glue kernels (default, when 1024 < D <= 8192) or one launch per reference op; same bits"""

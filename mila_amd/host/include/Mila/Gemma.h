@@ -464,7 +464,23 @@ namespace Mila::Dnn
         {
             const dim_t D = cfg_.embedding_dim;
             mila_stream_t st = ctx_->getStream();
-            if ( mila_cdna4_gemm_geglu_applicable( T, (int)D, (int)cfg_.hidden_dim ) )
+            bool w4a8 = false;
+            if constexpr ( kFmt == 2 )
+                w4a8 = L.fc_gate_up->getOperation().fp8ActivationPrefill() && mila_cdna4_gemm_fp8_applicable( T, (int)D, 2 * (int)cfg_.hidden_dim );
+            if constexpr ( kFmt == 2 )
+            {
+                if ( w4a8 && mila_cdna4_gemm_geglu_w4a8_applicable( T, (int)D, (int)cfg_.hidden_dim ) && L.fc_gate_up->getOperation().weightFp8Scale() )
+                {
+                    const int F = (int)cfg_.hidden_dim;
+                    const size_t need = mila_cdna4_gemm_w4a8_scratch_bytes( T, (int)D, 2 * F );
+                    void* scratch = ctx_->getScratch( need );
+                    Compute::rocmCheck( mila_cdna4_gemm_geglu_bf16_w4a8( act.data(), ffn_in.data(), static_cast<const uint8_t*>( L.fc_gate_up->getWeight().rawData() ),
+                                                                         L.fc_gate_up->getWeightScale()->data(), L.fc_gate_up->getOperation().weightFp8Scale(), T, (int)D, F,
+                                                                         Quant::Weight::groupSizeOf<TWeightQuant>(), scratch, need, st ) );
+                    return;
+                }
+            }
+            if ( !w4a8 && mila_cdna4_gemm_geglu_applicable( T, (int)D, (int)cfg_.hidden_dim ) )
             {
                 // Linear + GeGLU in one kernel: the [T, 2F] gate|up intermediate never reaches memory (bit-identical to the pair)
                 const int F = (int)cfg_.hidden_dim;
@@ -566,6 +582,17 @@ namespace Mila::Dnn
         bool fusedPrefillApplicable() const { return cfg_.embedding_dim > 1024 && cfg_.embedding_dim <= 8192 && cfg_.embedding_dim % 8 == 0; }
         /// on (default): prefill runs the fused glue when the configuration fits; off: one launch per reference op.  Same bits.
         void setFusedPrefill( bool on ) { fused_prefill_ = on; }
+        /// fp4 policy: W4A8 prefill (fp4 -> e4m3 weights, per-token e4m3 activations, fp8 MFMA; the reference's default) on every
+        /// layer Linear, or the exact-weight fallback (dequantize -> bf16 MFMA).  No effect on the other policies.
+        void setFp8ActivationPrefill( bool on )
+        {
+            if constexpr ( kFmt == 2 )
+                for ( auto& L : layers_ )
+                {
+                    L.qkv_proj->getOperation().setFp8ActivationPrefill( on ); L.o_proj->getOperation().setFp8ActivationPrefill( on );
+                    L.fc_gate_up->getOperation().setFp8ActivationPrefill( on ); L.fc_down->getOperation().setFp8ActivationPrefill( on );
+                }
+        }
 
     private:
         // ---- fused step ---------------------------------------------------------------------------------

@@ -126,6 +126,18 @@ namespace Mila::Dnn::Compute
                 {
                     // 2-phase staging through context scratch when the LDS-DMA GEMM applies; scratch is fetched per
                     // forward and never cached (reference rule, CudaLinearOp.ixx:603-614)
+                    if constexpr ( kFmt == 2 )
+                    {
+                        // W4A8: fp4 -> e4m3 weight staging + per-token e4m3 activations + fp8 x fp8 MFMA GEMM, the reference's default
+                        // prefill for this policy (kUseFp8ActivationPrefillPath, CudaLinearOp.ixx:646-715), when an fp8 kernel serves the shape
+                        if ( use_fp8_activation_prefill_ && weight_fp8_scale_ && mila_cdna4_gemm_fp8_applicable( M, K, N ) )
+                        {
+                            const size_t need8 = mila_cdna4_gemm_w4a8_scratch_bytes( M, K, N );
+                            void* scratch8 = this->context_->getScratch( need8 );
+                            rocmCheck( mila_cdna4_gemm_bf16_w4a8( y, x, static_cast<const uint8_t*>( weight_ ), scales_, weight_fp8_scale_->data(), bias_, M, K, N, kGroup, scratch8, need8, st ) );
+                            return;
+                        }
+                    }
                     const size_t need = mila_cdna4_gemm_staging_bytes( M, K, N );
                     void* scratch = need ? this->context_->getScratch( need ) : nullptr;
                     if constexpr ( kFmt == 1 ) rocmCheck( mila_cdna4_gemm_bf16_w8a16_staged( y, x, static_cast<const uint8_t*>( weight_ ), scales_, bias_, M, K, N, scratch, need, st ) );
@@ -153,7 +165,21 @@ namespace Mila::Dnn::Compute
                 throw std::logic_error( "RocmLinearOp::quantize: NoWeightQuant has no quantize path" );
         }
 
-        void onQuantizedWeightsLoaded() {}
+        /// fp4 policy: (re)compute the per-tensor e4m3 weight scale the W4A8 prefill needs (an op-owned device scalar, like
+        /// CudaLinearOp's weight_fp8_scale_, CudaLinearOp.ixx:311-330, :1118-1129)
+        void onQuantizedWeightsLoaded()
+        {
+            if constexpr ( kFmt == 2 )
+            {
+                if ( !scales_ ) return;
+                if ( !weight_fp8_scale_ ) weight_fp8_scale_ = std::make_unique<Tensor<TensorDataType::FP32, RocmDeviceMemoryResource>>( this->context_->getDeviceId(), shape_t{ 1 } );
+                rocmCheck( mila_cdna4_fp4_weight_fp8_scale( weight_fp8_scale_->data(), scales_, (int64_t)cfg_.out_features * ( cfg_.in_features / kGroup ), this->context_->getStream() ) );
+            }
+        }
+        /// fp4 policy: W4A8 prefill (default on, as in the reference) or the dequantize -> bf16 GEMM fallback
+        void setFp8ActivationPrefill( bool on ) noexcept { use_fp8_activation_prefill_ = on; }
+        bool fp8ActivationPrefill() const noexcept { return use_fp8_activation_prefill_; }
+        const float* weightFp8Scale() const noexcept { return weight_fp8_scale_ ? weight_fp8_scale_->data() : nullptr; }
 
         const void* weightPtr() const noexcept { return weight_; }
         const float* scalesPtr() const noexcept { return scales_; }
@@ -165,6 +191,8 @@ namespace Mila::Dnn::Compute
         const uint16_t* bias_{ nullptr };
         const float* scales_{ nullptr };
         bool built_{ false };
+        bool use_fp8_activation_prefill_{ true };
+        std::unique_ptr<Tensor<TensorDataType::FP32, RocmDeviceMemoryResource>> weight_fp8_scale_;
     };
 
     template<typename TPolicy>

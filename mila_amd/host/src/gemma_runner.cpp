@@ -137,6 +137,12 @@ HOST_API int mila_gemma_set_combine_in_oproj( void* h, int on )
     auto* r = static_cast<Runner*>( h );
     return guarded( [&] { std::visit( [&]( auto& m ) { m->setCombineInOProj( on != 0 ); }, r->model ); } );
 }
+/// fp4 policy: on != 0 (default, as in the reference) = W4A8 prefill on the fp8 matrix cores; 0 = dequantize -> bf16 GEMM
+HOST_API int mila_gemma_set_fp8_activation_prefill( void* h, int on )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&] { std::visit( [&]( auto& m ) { m->setFp8ActivationPrefill( on != 0 ); }, r->model ); } );
+}
 /// 1 if the chain launch is in use, 0 if not
 HOST_API int mila_gemma_uses_chain( void* h )
 {

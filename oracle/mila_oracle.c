@@ -559,6 +559,23 @@ void orc_dequant_fp4(float* W, const uint8_t* packed, const float* scales, int64
         }
 }
 
+/* CudaW4A16Gemm.cu:300-323 (W4A8 prefill staging): out[2b], out[2b+1] = e4m3(lut(nibble) * (group_scale * (1 / sB))), FP32 steps. */
+void orc_upcast_fp4_to_fp8(uint8_t* out, const uint8_t* packed, const float* scales, float weight_fp8_scale, int64_t N, int64_t K,
+                           int group)
+{
+    const int64_t ng = K / group;
+    const float inv = 1.0f / weight_fp8_scale;
+    for (int64_t n = 0; n < N; ++n)
+        for (int64_t b = 0; b < K / 2; ++b)
+        {
+            const uint8_t byte = packed[n * (K / 2) + b];
+            volatile float sc = scales[n * ng + (2 * b) / group] * inv;
+            volatile float lo = orc_e2m1_to_f32((uint8_t)(byte & 0xf)) * sc, hi = orc_e2m1_to_f32((uint8_t)(byte >> 4)) * sc;
+            out[n * K + 2 * b] = orc_f32_to_e4m3(lo);
+            out[n * K + 2 * b + 1] = orc_f32_to_e4m3(hi);
+        }
+}
+
 /* ===========================================================================================
  * Linear on bf16 activations (decode matvec + prefill GEMM share one mathematical definition)
  * ========================================================================================= */

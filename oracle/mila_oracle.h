@@ -85,6 +85,8 @@ void orc_quantize_fp8_per_channel(uint8_t* dst, float* scales, const uint16_t* s
 void orc_quantize_fp4_per_group(uint8_t* dst_packed, float* scales, const uint16_t* src_bf16,
                                 int64_t N, int64_t K, int group);
 float orc_fp8_weight_scale_from_groups(const float* group_scales, int64_t n);  /* sB */
+void orc_upcast_fp4_to_fp8(uint8_t* out, const uint8_t* packed, const float* scales, float weight_fp8_scale, int64_t N, int64_t K,
+                           int group);
 void orc_dequant_fp8(float* W, const uint8_t* q, const float* scales, int64_t N, int64_t K);
 void orc_dequant_fp4(float* W, const uint8_t* packed, const float* scales, int64_t N,
                      int64_t K, int group);

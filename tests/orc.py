@@ -305,6 +305,15 @@ def linear_fp4w(X, q, s, group=128, bias_bits=None):
     return Y
 
 
+def upcast_fp4_to_fp8(packed, scales, weight_fp8_scale, group):
+    """e4m3 codes of the W4A8 weight staging (CudaW4A16Gemm.cu:300-323)"""
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    N, K = packed.shape[0], packed.shape[1] * 2
+    out = np.empty((N, K), dtype=np.uint8)
+    lib.orc_upcast_fp4_to_fp8(_p(out, u8p), _p(packed, u8p), _p(_f(scales), f32p), C.c_float(weight_fp8_scale), i64(N), i64(K), C.c_int(group))
+    return out
+
+
 def quantize_act_fp8_per_token(X):
     X = _f(X)
     K = X.shape[-1]

@@ -435,3 +435,92 @@ def test_gemm_with_geglu_epilogue_is_bit_identical_to_gemm_then_geglu(M, K, F):
         assert_bf16_close(bits(Y1)[rows], exp, 2, 2e-3, "gemm+geglu vs oracle fmt %d" % fmt)
     with pytest.raises(capi.InvalidArgument):
         capi.call("gemm_geglu_bf16", Y1, Xd, dev_u16(Wb), M, K, F + 64)
+
+
+def test_scaled_fp8_mfma_operand_layout():
+    """v_mfma_scale_f32_16x16x128_f8f6f4 with e4m3 operands and unit block scales computes C = A B^T exactly for small integers,
+    with the lane layout the fp8 GEMM assumes (row = lane & 15, 32 bytes of k per lane)"""
+    lib = capi.load()
+    rng = np.random.default_rng(3)
+    vals = np.array([-3, -2, -1.5, -1, -0.5, 0, 0.5, 1, 1.5, 2, 3, 4], dtype=np.float32)
+    A, B = rng.choice(vals, (16, 128)), rng.choice(vals, (16, 128))
+    q = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(torch.float8_e4m3fn).view(torch.uint8).cuda()
+    Ad, Bd, Cd = q(A), q(B), torch.zeros(256, dtype=torch.float32, device="cuda")
+    capi.check(lib.mila_cdna4_selftest_mfma_fp8(C.c_void_p(Cd.data_ptr()), C.c_void_p(Ad.data_ptr()), C.c_void_p(Bd.data_ptr()), 0,
+                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert np.array_equal(Cd.cpu().numpy().reshape(16, 16), (A.astype(np.float64) @ B.astype(np.float64).T).astype(np.float32))
+
+
+@pytest.mark.parametrize("M,K,N,bias", [(2048, 256, 8192, False), (512, 384, 30720, True), (2048, 128, 3840, True), (2048, 1280, 3840, False)])
+def test_w4a8_prefill_matches_the_restated_reference(M, K, N, bias):
+    """the fp4 policy's default prefill (CudaLinearOp.ixx:646-715): weight scale, fp4 -> e4m3 staging and per-token activation
+    quantization are integer outputs -> bit-exact; the fp8 x fp8 MFMA GEMM with the two-step scaling epilogue -> within 2 bf16 ulp
+    of the restated reference (fp32 accumulation order is the only freedom), for the 256x256 and the 256x128 kernels"""
+    lib = capi.load()
+    assert lib.mila_cdna4_gemm_fp8_applicable(M, K, N) == 1 and lib.mila_cdna4_gemm_fp8_applicable(M, K + 64, N) == 0
+    rng = np.random.default_rng(N + K)
+    Wb = _weights(rng, N, K, "random")
+    q4, s4 = orc.quantize_fp4_per_group(Wb, 128)
+    X = orc.round_bf16((rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32))
+    X[7] = 0.0                                                              # an all-zero token: the 1e-12 guard
+    bb = orc.to_bf16_bits(rng.uniform(-0.1, 0.1, N).astype(np.float32)) if bias else None
+    # 1. per-tensor weight scale
+    ws_d = empty_f32(1)
+    capi.call("fp4_weight_fp8_scale", ws_d, dev_f32(s4), C.c_int64(s4.size))
+    ws = orc.fp8_weight_scale_from_groups(s4)
+    assert np.float32(host(ws_d)[0]) == np.float32(ws)
+    # 2. weight staging
+    W8 = torch.empty((N, K), dtype=torch.uint8, device="cuda")
+    capi.call("upcast_fp4_to_fp8", W8, dev_u8(q4), dev_f32(s4), ws_d, N, K, 128)
+    w8_exp = orc.upcast_fp4_to_fp8(q4, s4, ws, 128)
+    assert np.array_equal(W8.cpu().numpy(), w8_exp)
+    # 3. activation quantization
+    X8, ts_d = torch.empty((M, K), dtype=torch.uint8, device="cuda"), empty_f32(M)
+    capi.call("quantize_fp8_per_token", X8, ts_d, dev_u16(orc.to_bf16_bits(X)), M, K)
+    x8_exp, ts_exp = orc.quantize_act_fp8_per_token(X)
+    assert np.array_equal(host(ts_d), ts_exp) and np.array_equal(X8.cpu().numpy(), x8_exp)
+    # 4. GEMM + epilogue, stand-alone and through the one-call form
+    rows = [0, 7, 129, M - 1]
+    raw = orc.linear_fp8a_fp8w(x8_exp[rows], np.ones(len(rows), dtype=np.float32), w8_exp, None, ws, None)       # sB * acc
+    exp = orc.round_bf16(raw.astype(np.float32)).astype(np.float64) * ts_exp[rows].astype(np.float64)[:, None]
+    if bias:
+        exp = exp + orc.from_bf16_bits(bb).astype(np.float64)
+    Y = empty_u16(M, N)
+    capi.call("gemm_fp8_scaled", Y, X8, W8, ts_d, ws_d, dev_u16(bb) if bias else None, M, K, N)
+    # two roundings in the reference (GEMM output, then the rescaled + biased result): an fp32 accumulation-order difference that
+    # flips the first one moves the final value by up to 2 ulp; outputs that are the difference of large partial sums get 1e-3 of
+    # the output range
+    assert_bf16_close(bits(Y)[rows], exp, 2, 1e-3 * float(np.abs(exp).max()), "fp8 GEMM vs restated reference")
+    need = lib.mila_cdna4_gemm_w4a8_scratch_bytes(M, K, N)
+    scratch = torch.empty(need, dtype=torch.uint8, device="cuda")
+    Y2 = empty_u16(M, N)
+    capi.call("gemm_bf16_w4a8", Y2, dev_u16(orc.to_bf16_bits(X)), dev_u8(q4), dev_f32(s4), ws_d, dev_u16(bb) if bias else None, M, K, N, 128,
+              scratch, C.c_size_t(need))
+    assert np.array_equal(bits(Y2), bits(Y))
+    # the W4A8 result stays close to the exact-weight (W4A16) Linear: the reference's own bar for this path is 1e-1 relative
+    ref16 = orc.linear_fp4w(X[rows], q4, s4, 128)
+    if bias:
+        ref16 = ref16 + orc.from_bf16_bits(bb).astype(np.float64)
+    got = orc.from_bf16_bits(bits(Y)[rows]).astype(np.float64)
+    assert np.abs(got - ref16).max() <= 1e-1 * max(1.0, np.abs(ref16).max())
+    with pytest.raises(capi.MilaError):
+        capi.call("gemm_bf16_w4a8", Y2, dev_u16(orc.to_bf16_bits(X)), dev_u8(q4), dev_f32(s4), ws_d, None, M, K, N, 128, scratch, C.c_size_t(64))
+
+
+def test_w4a8_gemm_with_geglu_epilogue_is_bit_identical_to_w4a8_gemm_then_geglu():
+    M, K, F = 512, 256, 15360
+    lib = capi.load()
+    assert lib.mila_cdna4_gemm_geglu_w4a8_applicable(M, K, F) == 1
+    rng = np.random.default_rng(5)
+    Wb = _weights(rng, 2 * F, K, "random")
+    q4, s4 = orc.quantize_fp4_per_group(Wb, 128)
+    X = dev_u16(orc.to_bf16_bits(orc.round_bf16(rng.uniform(-2, 2, (M, K)).astype(np.float32))))
+    ws = empty_f32(1)
+    capi.call("fp4_weight_fp8_scale", ws, dev_f32(s4), C.c_int64(s4.size))
+    need = lib.mila_cdna4_gemm_w4a8_scratch_bytes(M, K, 2 * F)
+    scratch = torch.empty(need, dtype=torch.uint8, device="cuda")
+    GU, Y0, Y1 = empty_u16(M, 2 * F), empty_u16(M, F), empty_u16(M, F)
+    capi.call("gemm_bf16_w4a8", GU, X, dev_u8(q4), dev_f32(s4), ws, None, M, K, 2 * F, 128, scratch, C.c_size_t(need))
+    capi.call("geglu_bf16", Y0, GU, M, F)
+    capi.call("gemm_geglu_bf16_w4a8", Y1, X, dev_u8(q4), dev_f32(s4), ws, M, K, F, 128, scratch, C.c_size_t(need))
+    assert np.array_equal(bits(Y0), bits(Y1))
