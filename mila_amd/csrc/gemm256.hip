@@ -272,7 +272,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 // K-tile t + 1 while t + 2 stays in flight.
 constexpr int kStage3Bytes = 3 * kHalfBytes;   // W, X0, X1
 
-template <bool FP8>
+// GEGLU: the tile's 128 W rows are, per wave half wr, 32 gate rows then the matching 32 up rows (64 output columns per tile:
+// n0 = 64 tn), so a lane's sub-tiles pt = 0,1 / 2,3 hold gate / up of the same outputs.
+template <bool FP8, bool GEGLU>
 __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     const int xcd = id & 7, qd = nwg >> 3, rem = nwg & 7;
     const int tile = ((xcd < rem) ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (id >> 3);
     const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-    const int m0 = tm * 256, n0 = tn * 128;
+    const int m0 = tm * 256, n0 = tn * (GEGLU ? 64 : 128);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     const int srow = lane >> 3, sslot = lane & 7;
     // which: 0 = W rows n0 .., 1 = X rows m0 .., 2 = X rows m0 + 128 ..
     auto stage = [&](int kt, int which) {
-        const unsigned char* base = which == 0 ? Wb + (size_t)n0 * K * ES : Xb + (size_t)(m0 + (which - 1) * 128) * K * ES;
+        const unsigned char* base = which == 0 ? Wb : Xb + (size_t)(m0 + (which - 1) * 128) * K * ES;
         unsigned char* dst_half = smem + (kt % 3) * kStage3Bytes + which * kHalfBytes;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -304,7 +306,13 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             const int chunk = i * 8 + wave;
             const int row = chunk * 8 + srow;
             const int kslot = sslot ^ ((row >> 1) & 7);
-            const unsigned char* src = base + (size_t)row * K * ES + (size_t)kt * 128 + kslot * 16;
+            int grow = row;                                   // global row of `base`
+            if (which == 0)
+            {
+                if constexpr (GEGLU) { const int q = row & 63; grow = (q < 32 ? 0 : p.N - 32) + n0 + (row >> 6) * 32 + q; }   // N = F: up rows start at F
+                else grow = n0 + row;
+            }
+            const unsigned char* src = base + (size_t)grow * K * ES + (size_t)kt * 128 + kslot * 16;
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(dst_half + chunk * 1024), 16, 0, 0);
         }
     };
@@ -391,6 +399,34 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
         __builtin_amdgcn_s_barrier();
     }
 
+    if constexpr (GEGLU)
+    {
+#pragma unroll
+        for (int hB = 0; hB < 2; ++hB)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                {
+                    const int n = n0 + wr * 32 + pt * 16 + 4 * g;
+                    const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                    float v[4];
+                    if constexpr (FP8)
+                    {
+                        const float ws = *p.w_scale, ts = p.x_scales[m];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = gelu_tanh(round_bf16(round_bf16(acc[hB][pt][qt][e] * ws) * ts)) * round_bf16(round_bf16(acc[hB][pt + 2][qt][e] * ws) * ts);
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(round_bf16(acc[hB][pt][qt][e])) * round_bf16(acc[hB][pt + 2][qt][e]);
+                    }
+                    *reinterpret_cast<u32x2*>(p.Y + (size_t)m * p.N + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                }
+        return;
+    }
 #pragma unroll
     for (int hB = 0; hB < 2; ++hB)
 #pragma unroll
@@ -431,18 +467,18 @@ bool gemm256x128_applicable(int M, int K, int N)
     return tiles >= 200 && tiles >= 0.70 * rounds * kNumCU;
 }
 
-template <bool FP8>
+template <bool FP8, bool GEGLU = false>
 static int launch_gemm256x128_t(const Gemm256Params& p, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set)
     {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel<FP8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel<FP8, GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                3 * kStage3Bytes), "hipFuncSetAttribute(gemm256x128)");
         if (rc) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm256x128_kernel<FP8>, dim3(p.tiles_m * p.tiles_n), dim3(512), 3 * kStage3Bytes, s, p);
+    hipLaunchKernelGGL((gemm256x128_kernel<FP8, GEGLU>), dim3(p.tiles_m * p.tiles_n), dim3(512), 3 * kStage3Bytes, s, p);
     MILA_LAUNCH_CHECK("gemm256x128");
 }
 int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
@@ -498,15 +534,22 @@ int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int 
 // fp8 x fp8 (e4m3 bytes, K % 128 == 0): 2 = the 256 x 256 kernel, 1 = 256 x 128, 0 = no LDS-DMA kernel for this shape
 int gemm_fp8_kernel_for(int M, int K, int N)
 {
+    // at the fp8 rate the 4-barrier-per-K-tile 256 x 256 schedule is barrier-bound (1.36 PFLOP/s on fc_gate_up); the 3-stage
+    // 256 x 128 ring (one barrier per K-tile) reaches 1.8-1.9, so it is preferred wherever its grid fills the chip
     if (K % 128 != 0) return 0;
-    if (gemm256_applicable(M, K, N)) return 2;
     if (gemm256x128_applicable(M, K, N)) return 1;
+    if (gemm256_applicable(M, K, N)) return 2;
     return 0;
 }
 // Y[M, F] = GeGLU of the W4A8 Linear over W8 = [gate rows | up rows] (2F x K e4m3)
 int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
                           hipStream_t s)
 {
+    if (M % 256 == 0 && F % 64 == 0 && gemm256x128_applicable(M, K, 2 * F))
+    {
+        Gemm256Params q{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, M, K, F, M / 256, F / 64, x_scales, w_scale};
+        return launch_gemm256x128_t<true, true>(q, s);
+    }
     Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, M, K, F, M / 256, F / 128, x_scales, w_scale};
     return launch_gemm256_t<G_FP8_GEGLU>(p, s);
 }
