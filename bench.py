@@ -27,7 +27,7 @@ CONTEXT = 2048                # BASELINE.json configs[2..4]: B=1, T=2048
 def cpu_baseline(cfg):
     """Reference CPU backend restated (oracle/mila_oracle.c: CpuLinearOp::forwardNaive, the path the
     reference takes at batch 1) on a bounded sample of one decode token's Linear work:
-    one local layer + one global layer + 1/64 of the lm_head rows, FP32, single thread (the reference
+    30 passes over a local layer + 6 over a global layer + 1/4 of the lm_head rows, FP32, single thread (the reference
     default: MILA_ENABLE_OPENMP is OFF).  Extrapolated to a whole token by weight count."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
@@ -41,29 +41,34 @@ def cpu_baseline(cfg):
         qw = cfg["num_heads"] * hd
         return [(D, qw + (1 if g else 2) * nkv * hd), (qw, D), (D, 2 * H), (H, D)]
 
-    def time_shapes(shs, frac=1.0):
+    def time_shapes(shs, frac=1.0, reps=1):
         total, macs = 0.0, 0
         for K, N in shs:
             n = max(1, int(N * frac))
-            W = rng.standard_normal((n, K)).astype(np.float32)
-            x = rng.standard_normal((1, K)).astype(np.float32)
-            t0 = time.perf_counter()
-            orc.cpu_linear(x, W, None)          # batch 1 -> forwardNaive (long double accumulation)
-            total += time.perf_counter() - t0
-            macs += n * K
+            W = rng.standard_normal((n, K), dtype=np.float32)       # 30-470 MB: far beyond the CPU caches, every pass streams it from DRAM
+            x = rng.standard_normal((1, K), dtype=np.float32)
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                orc.cpu_linear(x, W, None)          # batch 1 -> forwardNaive (long double accumulation)
+                total += time.perf_counter() - t0
+                macs += n * K
         return total, macs
 
-    t_loc, m_loc = time_shapes(shapes(False))
-    t_glb, m_glb = time_shapes(shapes(True))
-    t_head, m_head = time_shapes([(D, V)], 1.0 / 64)
+    # a bounded sample of one token (about 10-15 s on one core): 30 passes over a local layer's four Linear shapes, 6 over a global
+    # layer's (the model's 5 : 1 mix) and 1/4 of the lm_head rows
+    REPS_LOC, REPS_GLB, HEAD_FRAC = 30, 6, 1.0 / 4
+    t_loc, m_loc = time_shapes(shapes(False), reps=REPS_LOC)
+    t_glb, m_glb = time_shapes(shapes(True), reps=REPS_GLB)
+    t_head, m_head = time_shapes([(D, V)], HEAD_FRAC)
     n_glb = sum(1 for i in range(cfg["num_layers"]) if (i + 1) % cfg["sliding_window_pattern"] == 0)
     n_loc = cfg["num_layers"] - n_glb
-    token_s = t_loc * n_loc + t_glb * n_glb + t_head * 64
+    token_s = t_loc / REPS_LOC * n_loc + t_glb / REPS_GLB * n_glb + t_head / HEAD_FRAC
     return {"value": round(1.0 / token_s, 5), "unit": "tok/s", "cores": 1, "kind": "port",
-            "sample": "restated CpuLinearOp::forwardNaive (FP32, long double acc) on 1 local + 1 global layer's 4 Linear "
-                      "shapes + 1/64 of lm_head rows (%.2f GMAC, %.1f s), extrapolated by weight count to 48 layers + head; "
-                      "the reference has no CPU RMSNorm/RoPE/GQA/GeGLU ops, they are <1%% of the work and not timed"
-                      % ((m_loc + m_glb + m_head) / 1e9, t_loc + t_glb + t_head),
+            "sample": "restated CpuLinearOp::forwardNaive (FP32, long double acc; the reference's batch-1 path, single thread as "
+                      "MILA_ENABLE_OPENMP is OFF by default) on %d passes over a local + %d over a global layer's Linear shapes + 1/%d of the lm_head rows "
+                      "(%.2f GMAC, %.1f s), extrapolated by weight count to 48 layers + head; the reference has no CPU "
+                      "RMSNorm/RoPE/GQA/GeGLU ops, they are <1%% of the work and not timed"
+                      % (REPS_LOC, REPS_GLB, round(1 / HEAD_FRAC), (m_loc + m_glb + m_head) / 1e9, t_loc + t_glb + t_head),
             "GFLOPs": round(2 * (m_loc + m_glb + m_head) / (t_loc + t_glb + t_head) / 1e9, 3)}
 
 

@@ -3,10 +3,11 @@ usage: python tools/step_breakdown.py <rocprof_out_dir> [...]"""
 import collections
 import csv
 import glob
+import os
 import sys
 
 for d in sys.argv[1:]:
-    f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
+    f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     starts = [i for i, r in enumerate(rows) if "embedding_gather" in r["Kernel_Name"]]
     seg = rows[starts[-2]:starts[-1]]

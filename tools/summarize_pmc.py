@@ -6,12 +6,13 @@ usage: python tools/summarize_pmc.py <fetch_dir> <write_dir> <out.json> [label]"
 import collections
 import csv
 import glob
+import os
 import json
 import sys
 
 
 def per_kernel(d, counter):
-    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    f = max(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
     g = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:

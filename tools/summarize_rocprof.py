@@ -3,13 +3,14 @@ usage: python tools/summarize_rocprof.py <rocprof_out_dir> <out.md> [title]"""
 import collections
 import csv
 import glob
+import os
 import sys
 
 
 def main():
     d, out = sys.argv[1], sys.argv[2]
     title = sys.argv[3] if len(sys.argv) > 3 else d
-    trace = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
+    trace = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
     rows = list(csv.DictReader(open(trace)))
     g = collections.defaultdict(list)
     for r in rows:
