@@ -60,3 +60,38 @@ def test_gpt2_124m_full_width_single_block_row():
     exp = orc.cpu_gpt2_forward(tokens, [orc.from_bf16_bits(p) for p in params], C_, L, NH, V, maxT)
     assert np.all(np.abs(got - exp) <= 5e-2 + 5e-2 * np.abs(exp)), np.abs(got - exp).max()
     g.close()
+
+
+def test_gpt2_124m_config2_full_size_properties():
+    """BASELINE.json config 2 at its full size (GPT-2 124M, B=8, T=1024: 2.2 TFLOP, beyond the FP32 CPU oracle's reach), checked
+    through size-independent properties of a causal transformer, bit for bit:
+      * a batch row's logits do not depend on its slot or on the other rows (rows 0 and 5 carry the same tokens);
+      * causality: changing tokens at positions >= 512 leaves every logit of positions < 512 untouched;
+      * the first 64 positions of row 0 equal a B=1, T=64 forward of the same tokens up to the reference's BF16 bar (a different
+        GEMM tile grid), and that short forward matches the restated CPU backend."""
+    V, maxT, C_, L, NH, B, T = 50257, 1024, 768, 12, 12, 8, 1024
+    rng = np.random.default_rng(124)
+    params = make_params(rng, V, maxT, C_, L)
+    tokens = rng.integers(0, V, (B, T)).astype(np.int32)
+    tokens[5] = tokens[0]
+    g = host.Gpt(V, maxT, C_, L, NH, B, T)
+    g.load_parameters(params)
+    a = g.forward(tokens)
+    print("GPT-2 124M B=8 T=1024 forward: %.2f ms" % g.last_ms)
+    assert a.shape == (B, T, V)
+    assert np.array_equal(a[0], a[5]), "identical rows in different slots differ"
+    tokens2 = tokens.copy()
+    tokens2[:, 512:] = rng.integers(0, V, (B, T - 512))
+    b = g.forward(tokens2)
+    assert np.array_equal(a[:, :512], b[:, :512]), "a later token changed an earlier position"
+    assert not np.array_equal(a[:, 512:], b[:, 512:])
+    f = orc.from_bf16_bits(a[0, :64])
+    assert np.all(np.isfinite(f))
+    g.close()
+    s = host.Gpt(V, maxT, C_, L, NH, 1, 64)
+    s.load_parameters(params)
+    short = orc.from_bf16_bits(s.forward(tokens[:1, :64]))[0]
+    s.close()
+    assert np.all(np.abs(f - short) <= 5e-2 + 5e-2 * np.abs(short)), np.abs(f - short).max()
+    exp = orc.cpu_gpt2_forward(tokens[:1, :64], [orc.from_bf16_bits(p) for p in params], C_, L, NH, V, maxT)[0]
+    assert np.all(np.abs(short - exp) <= 5e-2 + 5e-2 * np.abs(exp)), np.abs(short - exp).max()
