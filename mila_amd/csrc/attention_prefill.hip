@@ -21,6 +21,8 @@
 //   * a workgroup = 4 waves = (query heads sharing one KV head) x (16-row query sub-tiles): all four
 //     waves consume the same K/V tiles (GQA/MQA reuse in LDS); the heaviest (latest) query tiles are
 //     dispatched first.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mila {
@@ -59,7 +61,220 @@ __device__ __forceinline__ int v_off(int row, int chunk)      // ds_read_b64_tr_
 
 // HB = heads per workgroup (1, 2 or 4); QB = 4 / HB query sub-tiles of 16 rows
 template <int HS, int HB>
-__global__ __launch_bounds__(256) void flash_prefill_kernel(const FlashParams p)
+__global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams p)
+{
+    constexpr bool DEEP = true;              // two staging register sets (HS = 512 runs flash_prefill_kernel_s1)
+    constexpr int QB = 4 / HB;
+    constexpr int QROWS = 16 * QB;
+    constexpr int KSTEPS = HS / 32;          // MFMA k-steps of the QK^T product
+    constexpr int DT = HS / 16;              // 16-wide d tiles of O^T
+    constexpr int ROWB = HS * 2;
+    constexpr int TILE_BYTES = kKeysPerTile * ROWB;
+    constexpr int CH_PER_THREAD = (kKeysPerTile * (ROWB / 16)) / 256;   // 16-byte chunks each thread stages per tile
+    static_assert(CH_PER_THREAD >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [K tile | V tile]
+    unsigned char* ldsK = smem;
+    unsigned char* ldsV = smem + TILE_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int GS = p.NH / p.NKV;
+    const int qt = gridDim.x - 1 - blockIdx.x;                 // heaviest tiles first
+    const int hblk = blockIdx.y, b = blockIdx.z;
+    const int h = hblk * HB + (wave % HB);
+    const int kvh = (hblk * HB) / GS;                          // all HB heads share one KV head (HB | GS)
+    const int q0 = qt * QROWS;                                 // first query row (within the chunk) of this workgroup
+    const int wq0 = q0 + 16 * (wave / HB);                     // this wave's first row
+    const int my_row = wq0 + l15;                              // the query row on this lane
+    const bool row_valid = my_row < p.Tq;
+    const int my_pos = p.pos_offset + (row_valid ? my_row : p.Tq - 1);
+
+    // ---- Q fragments: B operand of S^T = K Q^T: lane holds Q[row l15][32 s + 8 g + j] ----
+    s16x8 qf[KSTEPS];
+    {
+        const uint16_t* qp = p.Q + ((size_t)b * p.Tq + (row_valid ? my_row : 0)) * p.q_row_stride + (size_t)h * HS + 8 * g;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+        {
+            const u32x4 v = row_valid ? ld16(qp + 32 * s) : u32x4{0u, 0u, 0u, 0u};
+            qf[s] = __builtin_bit_cast(s16x8, v);
+        }
+    }
+
+    f32x4 o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) o[d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    // key range needed by the workgroup (union over its rows)
+    const int pos_first = p.pos_offset + q0;
+    const int pos_last = p.pos_offset + min(q0 + QROWS, p.Tq) - 1;
+    const int kmin = (p.window > 0) ? max(0, pos_first - p.window + 1) : 0;
+    const int kt0 = kmin & ~(kKeysPerTile - 1);
+    const int ntiles = (pos_last - kt0) / kKeysPerTile + 1;
+
+    const uint16_t* kbase = p.K + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride;
+    const uint16_t* vbase = p.V + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride;
+
+    // K/V tiles travel global -> registers -> LDS with TWO register sets: the loads of tile t + 2 are issued while tile t is
+    // being multiplied, so a whole tile of math covers the L2 round trip (with one set the wait at the next stage_store cost
+    // 30 % of the kernel).  Loads are branch-free (rows past the workgroup's last key are clamped to it: their scores are masked and
+    // the clamped V row is a real, finite row), so the compiler keeps the other set's loads in flight across the wait.
+    struct StageRegs { u32x4 k[CH_PER_THREAD], v[CH_PER_THREAD]; };
+    const int kt_last = kt0 + (ntiles - 1) * kKeysPerTile;
+    auto stage_load = [&](StageRegs& r, int kt) {
+        if constexpr (DEEP) kt = min(kt, kt_last);
+#pragma unroll
+        for (int i = 0; i < CH_PER_THREAD; ++i)
+        {
+            const int c = tid + 256 * i;
+            const int row = c / (ROWB / 16), chunk = c % (ROWB / 16);
+            if constexpr (DEEP)
+            {
+                const int pos = min(kt + row, pos_last);
+                const size_t off = (size_t)(pos % p.capacity) * p.kv_r_stride + chunk * 8;
+                r.k[i] = ld16(kbase + off);
+                r.v[i] = ld16(vbase + off);
+            }
+            else
+            {
+                // HS = 512: every register counts; the guarded form keeps the loads late and the pressure at 244
+                const int pos = kt + row;
+                if (pos <= pos_last)     // rows beyond the last key any row of this workgroup may see stay zero
+                {
+                    const size_t off = (size_t)(pos % p.capacity) * p.kv_r_stride + chunk * 8;
+                    r.k[i] = ld16(kbase + off);
+                    r.v[i] = ld16(vbase + off);
+                }
+                else
+                {
+                    r.k[i] = u32x4{0u, 0u, 0u, 0u};
+                    r.v[i] = u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+        }
+    };
+    auto stage_store = [&](const StageRegs& r) {
+#pragma unroll
+        for (int i = 0; i < CH_PER_THREAD; ++i)
+        {
+            const int c = tid + 256 * i;
+            const int row = c / (ROWB / 16), chunk = c % (ROWB / 16);
+            *reinterpret_cast<u32x4*>(ldsK + k_off<HS>(row, chunk)) = r.k[i];
+            *reinterpret_cast<u32x4*>(ldsV + v_off<HS>(row, chunk)) = r.v[i];
+        }
+    };
+
+    StageRegs ra, rb;
+    stage_load(ra, kt0);
+    if constexpr (DEEP) stage_load(rb, kt0 + kKeysPerTile);
+    auto tile = [&](int t, StageRegs& regs) {
+        const int kt = kt0 + t * kKeysPerTile;
+        __syncthreads();                     // previous tile fully consumed
+        stage_store(regs);
+        __syncthreads();
+        // DEEP: two tiles ahead, in flight during this tile's and the next one's math; else the next tile
+        if (DEEP || t + 1 < ntiles) stage_load(regs, kt + (DEEP ? 2 : 1) * kKeysPerTile);
+
+        // ---- S^T = K Q^T : two 16-key groups ----
+        f32x4 s0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+        {
+            // A operand: K[key l15 (+16)][32 s + 8 g .. +7] -> chunk 4 s + g
+            const s16x8 ka = *reinterpret_cast<const s16x8*>(ldsK + k_off<HS>(l15, 4 * s + g));
+            const s16x8 kb = *reinterpret_cast<const s16x8*>(ldsK + k_off<HS>(16 + l15, 4 * s + g));
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka), __builtin_bit_cast(bf16x8, qf[s]), s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb), __builtin_bit_cast(bf16x8, qf[s]), s1, 0, 0, 0);
+        }
+        // lane holds keys kt + 4 g + r (s0) and kt + 16 + 4 g + r (s1) of query row l15
+        float sv[8];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+        {
+            const int key = kt + ((r < 4) ? (4 * g + r) : (16 + 4 * g + (r - 4)));
+            const float raw = (r < 4) ? s0[r] : s1[r - 4];
+            const bool vis = row_valid && key <= my_pos && (p.window == 0 || key > my_pos - p.window);
+            sv[r] = vis ? raw * p.scale : -INFINITY;
+            mt = fmaxf(mt, sv[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float mn = fmaxf(m_run, mt);
+        const float msafe = (mn == -INFINITY) ? 0.0f : mn;      // row with nothing visible yet
+        const float alpha = __expf(m_run - msafe);              // m_run = -inf -> 0
+        float pe[8], rs = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+        {
+            pe[r] = __expf(sv[r] - msafe);
+            rs += pe[r];
+        }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = mn;
+        // B operand of O^T += V^T P^T: element j <-> key (j < 4 ? 4 g + j : 16 + 4 g + j - 4)
+        u32x4 pb;
+        pb[0] = pack_bf16x2(pe[0], pe[1]);
+        pb[1] = pack_bf16x2(pe[2], pe[3]);
+        pb[2] = pack_bf16x2(pe[4], pe[5]);
+        pb[3] = pack_bf16x2(pe[6], pe[7]);
+        const bf16x8 pfrag = __builtin_bit_cast(bf16x8, pb);
+        const bool rescale = __any(alpha != 1.0f);
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+        {
+            // A operand: V^T[dim 16 d + l15][keys as above] via the transposing read:
+            // lane 4 q + pp of a 16-lane group supplies row q, columns 4 pp .. 4 pp + 3 of the block
+            const int q4 = l15 >> 2, pp = l15 & 3;
+            const int col = 16 * d + 4 * pp;                   // first of 4 columns (8 bytes)
+            const int r_lo = 4 * g + q4, r_hi = 16 + 4 * g + q4;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(ldsV + v_off<HS>(r_lo, col >> 3) + ((col & 7) << 1)));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(ldsV + v_off<HS>(r_hi, col >> 3) + ((col & 7) << 1)));
+            s16x8 va;
+            va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3];
+            va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
+            if (rescale)
+            {
+                o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha;
+            }
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), pfrag, o[d], 0, 0, 0);
+        }
+    };
+    if constexpr (DEEP)
+    {
+        for (int t = 0; t < ntiles; t += 2)
+        {
+            tile(t, ra);
+            if (t + 1 < ntiles) tile(t + 1, rb);
+        }
+    }
+    else
+    {
+        for (int t = 0; t < ntiles; ++t) tile(t, ra);
+    }
+
+    // ---- epilogue: O^T[dim 16 d + 4 g + r][row l15] -> Y[row][h*HS + dim] ----
+    if (row_valid)
+    {
+        const float inv = (l_run > 0.0f) ? 1.0f / l_run : 0.0f;
+        uint16_t* y = p.Y + (((size_t)b * p.Tq + my_row) * p.NH + h) * HS + 4 * g;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+            *reinterpret_cast<u32x2*>(y + 16 * d) = u32x2{pack_bf16x2(o[d][0] * inv, o[d][1] * inv), pack_bf16x2(o[d][2] * inv, o[d][3] * inv)};
+    }
+}
+
+// Single-staging form (one register set, next tile's loads in flight during the current tile's math): HS = 512, where the
+// accumulators (128 VGPRs) and Q fragments (64) leave no room for a second staging set.
+// HB = heads per workgroup (1, 2 or 4); QB = 4 / HB query sub-tiles of 16 rows
+template <int HS, int HB>
+__global__ __launch_bounds__(256) void flash_prefill_kernel_s1(const FlashParams p)
 {
     constexpr int QB = 4 / HB;
     constexpr int QROWS = 16 * QB;
@@ -242,7 +457,8 @@ static int launch_flash(const FlashParams& p, int B, hipStream_t s)
     constexpr int QROWS = 16 * (4 / HB);
     const size_t lds = (size_t)2 * kKeysPerTile * HS * 2;
     const dim3 grid((p.Tq + QROWS - 1) / QROWS, p.NH / HB, B);
-    hipLaunchKernelGGL((flash_prefill_kernel<HS, HB>), grid, dim3(256), lds, s, p);
+    if constexpr (HS >= 512) hipLaunchKernelGGL((flash_prefill_kernel_s1<HS, HB>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((flash_prefill_kernel<HS, HB>), grid, dim3(256), lds, s, p);
     MILA_LAUNCH_CHECK("flash_prefill");
 }
 

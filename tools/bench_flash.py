@@ -1,0 +1,25 @@
+"""Time the flash prefill kernel on the Gemma-4 12B attention shapes (T = 2048).  MILA_FLASH_DBG skips parts of the kernel
+(1 softmax, 2 PV, 4 QK, 8 staging; results are then meaningless) to see where the time goes."""
+import json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mila_amd import capi
+T = 2048
+for name, NH, NKV, HS, window in (("local", 16, 8, 256, 1024), ("global", 16, 1, 512, 0)):
+    q = (torch.randn((T, NH * HS), device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)
+    K = (torch.randn((1, NKV, T, HS), device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)
+    V = torch.randn((1, NKV, T, HS), device="cuda").to(torch.bfloat16).view(torch.int16)
+    Y = torch.empty((T, NH * HS), dtype=torch.int16, device="cuda")
+    call = lambda: capi.call("attn_prefill_bf16", Y, q, K, V, 1, T, NH, NKV, HS, T, 0, window, 1.0)
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    keys = sum(min(t + 1, window) if window else t + 1 for t in range(T))
+    print(json.dumps({"shape": name, "dbg": os.environ.get("MILA_FLASH_DBG", "0"), "us": round(us, 1), "TFLOPs": round(4.0 * NH * HS * keys / us / 1e6, 1)}), flush=True)
