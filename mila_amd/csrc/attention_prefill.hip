@@ -200,8 +200,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
             sv[r] = vis ? raw * p.scale : -INFINITY;
             mt = fmaxf(mt, sv[r]);
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        mt = quad_rows_max(mt);                                 // the row's other keys sit on lanes l ^ 16, l ^ 32, l ^ 48
         const float mn = fmaxf(m_run, mt);
         const float msafe = (mn == -INFINITY) ? 0.0f : mn;      // row with nothing visible yet
         const float alpha = __expf(m_run - msafe);              // m_run = -inf -> 0
@@ -212,8 +211,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
             pe[r] = __expf(sv[r] - msafe);
             rs += pe[r];
         }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
+        rs = quad_rows_sum(rs);
         l_run = l_run * alpha + rs;
         m_run = mn;
         // B operand of O^T += V^T P^T: element j <-> key (j < 4 ? 4 g + j : 16 + 4 g + j - 4)
@@ -393,8 +391,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel_s1(const FlashParams
             sv[r] = vis ? raw * p.scale : -INFINITY;
             mt = fmaxf(mt, sv[r]);
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        mt = quad_rows_max(mt);                                 // the row's other keys sit on lanes l ^ 16, l ^ 32, l ^ 48
         const float mn = fmaxf(m_run, mt);
         const float msafe = (mn == -INFINITY) ? 0.0f : mn;      // row with nothing visible yet
         const float alpha = __expf(m_run - msafe);              // m_run = -inf -> 0
@@ -405,8 +402,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel_s1(const FlashParams
             pe[r] = __expf(sv[r] - msafe);
             rs += pe[r];
         }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
+        rs = quad_rows_sum(rs);
         l_run = l_run * alpha + rs;
         m_run = mn;
         // B operand of O^T += V^T P^T: element j <-> key (j < 4 ? 4 g + j : 16 + 4 g + j - 4)

@@ -86,6 +86,36 @@ __device__ __forceinline__ float wave_sum(float v)
     }
     return v;
 }
+// reductions over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} only (the last two butterfly steps above): the MFMA layouts put
+// one matrix row on those four lanes
+__device__ __forceinline__ float quad_rows_max(float v)
+{
+    {
+        const uint32_t u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    {
+        const uint32_t u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    return v;
+}
+__device__ __forceinline__ float quad_rows_sum(float v)
+{
+    {
+        const uint32_t u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const uint32_t u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    return v;
+}
 // integer 64-lane sum (all lanes get the result)
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
