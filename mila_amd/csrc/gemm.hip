@@ -284,6 +284,18 @@ static int launch_glds(int which, uint16_t* Y, const uint16_t* X, const uint16_t
 {
     return which == 2 ? launch_gemm256(Y, X, W, bias, M, K, N, s) : launch_gemm256x128(Y, X, W, bias, M, K, N, s);
 }
+// Ragged prompt lengths: the LDS-DMA kernels take M % 256 == 0, so the first floor(M / 256) * 256 rows go to them and the
+// remaining < 256 rows to the register-staged 128-tile kernel (rows are independent; no padding, nothing read past the tensors).
+// Returns the number of leading rows the LDS-DMA kernel serves (0 = none) and which kernel.
+static int glds_rows_for(int M, int K, int N, int* which)
+{
+    *which = glds_kernel_for(M, K, N);
+    if (*which) return M;
+    const int main_rows = M - M % 256;
+    if (main_rows >= 512 && (*which = glds_kernel_for(main_rows, K, N)) != 0) return main_rows;
+    return 0;
+}
+static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s);
 
 // ---- 2-phase staging (the reference's own prefill structure for quantized weights,
 // OPS/Linear/CudaLinearOp.ixx:597-644, :716-764): dequantize the whole matrix to bf16 scratch, then the bf16 GEMM.
@@ -344,6 +356,20 @@ static int validate_gemm(const char* who, const void* Y, const void* X, const vo
     return MILA_OK;
 }
 
+// bf16-weight GEMM over M rows: LDS-DMA kernel on the leading multiple of 256 rows when one applies, 128-tile kernel on the rest
+static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
+{
+    int which;
+    const int main_rows = glds_rows_for(M, K, N, &which);
+    if (main_rows > 0)
+    {
+        int rc = launch_glds(which, Y, X, W, bias, main_rows, K, N, s);
+        if (rc || main_rows == M) return rc;
+    }
+    GemmParams p{Y + (size_t)main_rows * N, X + (size_t)main_rows * K, reinterpret_cast<const uint8_t*>(W), nullptr, bias, M - main_rows, K, N, 0, 0, 0};
+    return launch_gemm<G_BF16>(p, s);
+}
+
 }  // namespace mila
 
 using namespace mila;
@@ -361,9 +387,7 @@ int mila_cdna4_gemm_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, cons
 {
     int rc = validate_gemm("gemm_bf16", Y, X, W, M, K, N);
     if (rc) return rc;
-    if (const int which = glds_kernel_for(M, K, N)) return launch_glds(which, Y, X, W, bias, M, K, N, as_stream(stream));
-    GemmParams p{Y, X, reinterpret_cast<const uint8_t*>(W), nullptr, bias, M, K, N, 0, 0, 0};
-    return launch_gemm<G_BF16>(p, as_stream(stream));
+    return launch_bf16_rows(Y, X, W, bias, M, K, N, as_stream(stream));
 }
 
 int mila_cdna4_gemm_bf16_w8a16(uint16_t* Y, const uint16_t* X, const uint8_t* W, const float* scales,
@@ -390,7 +414,8 @@ int mila_cdna4_gemm_bf16_w4a16(uint16_t* Y, const uint16_t* X, const uint8_t* W_
 
 size_t mila_cdna4_gemm_staging_bytes(int M, int K, int N)
 {
-    return glds_kernel_for(M, K, N) ? (size_t)N * K * 2 : 0;
+    int which;
+    return glds_rows_for(M, K, N, &which) ? (size_t)N * K * 2 : 0;
 }
 
 int mila_cdna4_gemm_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W, const float* scales, const uint16_t* bias,
@@ -408,7 +433,7 @@ int mila_cdna4_gemm_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, const uint
                        total_vec, K / 16);
     rc = check_hip(hipGetLastError(), "dequant_fp8");
     if (rc) return rc;
-    return launch_glds(glds_kernel_for(M, K, N), Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream));
+    return launch_bf16_rows(Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream));
 }
 
 int mila_cdna4_gemm_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed, const float* scales,
@@ -429,7 +454,7 @@ int mila_cdna4_gemm_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, const uint
                        scales, total_vec, group / 32);
     rc = check_hip(hipGetLastError(), "dequant_fp4");
     if (rc) return rc;
-    return launch_glds(glds_kernel_for(M, K, N), Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream));
+    return launch_bf16_rows(Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream));
 }
 
 /* ---- Linear + GeGLU in one kernel (prefill fc_gate_up): Y[M, F] = GeGLU(X W^T), W = [gate | up] rows ---- */

@@ -524,3 +524,29 @@ def test_w4a8_gemm_with_geglu_epilogue_is_bit_identical_to_w4a8_gemm_then_geglu(
     capi.call("geglu_bf16", Y0, GU, M, F)
     capi.call("gemm_geglu_bf16_w4a8", Y1, X, dev_u8(q4), dev_f32(s4), ws, M, K, F, 128, scratch, C.c_size_t(need))
     assert np.array_equal(bits(Y0), bits(Y1))
+
+
+@pytest.mark.parametrize("M", [2048 + 77, 1024 + 255, 768 + 1])
+def test_ragged_prompt_lengths_split_between_the_lds_dma_and_the_128_tile_kernels(M):
+    """M % 256 != 0: the leading multiple of 256 rows runs the LDS-DMA kernel, the tail the 128-tile kernel; every row against
+    the float64 oracle, bf16 and (staged) fp4 weights, with bias"""
+    K, N = 192, 8192
+    rng = np.random.default_rng(M)
+    Wb = _weights(rng, N, K, "random")
+    X = orc.round_bf16(rng.uniform(-1, 1, (M, K)).astype(np.float32))
+    bb = orc.to_bf16_bits(rng.uniform(-0.1, 0.1, N).astype(np.float32))
+    Xd = dev_u16(orc.to_bf16_bits(X))
+    Y = empty_u16(M, N)
+    capi.call("gemm_bf16", Y, Xd, dev_u16(Wb), dev_u16(bb), M, K, N)
+    rows = [0, 255, 256, M - M % 256 - 1, M - M % 256, M - 1]
+    exp = orc.round_bf16(orc.linear_bf16w(X[rows], Wb, None)).astype(np.float64) + orc.from_bf16_bits(bb).astype(np.float64)
+    assert_bf16_close(bits(Y)[rows], exp, 2, 2e-3, "ragged gemm_bf16")
+    need = capi.load().mila_cdna4_gemm_staging_bytes(M, K, N)
+    assert need == (N * K * 2 if M >= 1024 else 0)                         # 768 leading rows are 96 tiles: too few for an LDS-DMA grid
+    if need == 0:
+        return
+    q4, s4 = orc.quantize_fp4_per_group(Wb, 64)
+    scratch = torch.empty(need, dtype=torch.uint8, device="cuda")
+    capi.call("gemm_bf16_w4a16_staged", Y, Xd, dev_u8(q4), dev_f32(s4), None, M, K, N, 64, scratch, C.c_size_t(need))
+    Wdq = orc.to_bf16_bits(orc.dequant_fp4(q4, s4, 64))                   # the staged path multiplies the bf16-rounded dequantized weights
+    assert_bf16_close(bits(Y)[rows], orc.linear_bf16w(X[rows], Wdq), 1, 2e-3, "ragged staged fp4 gemm")
