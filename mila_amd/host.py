@@ -34,7 +34,7 @@ def load():
         _lib = C.CDLL(LIB_PATH)
         _lib.mila_host_last_error.restype = C.c_char_p
         _lib.mila_gemma_create.restype = C.c_void_p
-        _lib.mila_gemma_create.argtypes = [C.c_int, C.POINTER(GemmaConfigC), C.c_int64, C.c_int64, C.c_uint64]
+        _lib.mila_gemma_create.argtypes = [C.c_int, C.POINTER(GemmaConfigC), C.c_int64, C.c_int64, C.c_uint64, C.c_int]
         _lib.mila_gemma_destroy.argtypes = [C.c_void_p]
         _lib.mila_gemma_prefill.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         _lib.mila_gemma_decode.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int, C.c_void_p]
@@ -73,13 +73,18 @@ class Gemma:
 
     MODES = {"reference": 0, "fused": 1, "graph": 2}
 
-    def __init__(self, policy="bf16", config=None, max_seq=4096, max_prefill=1, seed=1234):
+    def __init__(self, policy="bf16", config=None, max_seq=4096, max_prefill=1, seed=1234, device=None):
+        """device: HIP device ordinal; default = this process's LOCAL_RANK (one replica per GPU under torch.distributed.run)"""
         lib = load()
+        if device is None:
+            from .replicas import local_device
+            device = local_device()
+        self.device = device
         self.cfg = dict(GEMMA4_12B if config is None else config)
         self.cfg.setdefault("bounded_local_kv", 0)      # 1: SlidingWindowKvCache on the sliding-window layers
         c = GemmaConfigC(**self.cfg)
         self.vocab = self.cfg["vocab_size"]
-        self.h = lib.mila_gemma_create(POLICIES[policy], C.byref(c), max_seq, max_prefill, seed)
+        self.h = lib.mila_gemma_create(POLICIES[policy], C.byref(c), max_seq, max_prefill, seed, device)
         if not self.h:
             text = lib.mila_host_last_error().decode()
             raise (ValueError if text.startswith("invalid_argument") else RuntimeError)("mila_gemma_create: " + text)

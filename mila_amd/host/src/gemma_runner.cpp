@@ -50,7 +50,8 @@ struct mila_gemma_config
 HOST_API const char* mila_host_last_error( void ) { return g_err.c_str(); }
 
 /// policy: 0 NoWeightQuant (bf16), 1 PerChannelFp8<>, 2 PerGroupFp4<128>.  cfg == NULL -> Gemma-4 12B.
-HOST_API void* mila_gemma_create( int policy, const mila_gemma_config* c, int64_t max_seq, int64_t max_prefill, uint64_t seed )
+/// device: HIP device ordinal of this replica (one process per GPU: the launcher's LOCAL_RANK)
+HOST_API void* mila_gemma_create( int policy, const mila_gemma_config* c, int64_t max_seq, int64_t max_prefill, uint64_t seed, int device )
 {
     Runner* r = nullptr;
     int rc = guarded( [&]
@@ -68,9 +69,9 @@ HOST_API void* mila_gemma_create( int policy, const mila_gemma_config* c, int64_
         rr->max_prefill = max_prefill;
         switch ( policy )
         {
-            case 0: rr->model = std::make_unique<GemmaTransformer<NoWeightQuant>>( cfg, max_seq, max_prefill ); break;
-            case 1: rr->model = std::make_unique<GemmaTransformer<PerChannelFp8<>>>( cfg, max_seq, max_prefill ); break;
-            case 2: rr->model = std::make_unique<GemmaTransformer<PerGroupFp4<128>>>( cfg, max_seq, max_prefill ); break;
+            case 0: rr->model = std::make_unique<GemmaTransformer<NoWeightQuant>>( cfg, max_seq, max_prefill, Compute::Device::Rocm( device ) ); break;
+            case 1: rr->model = std::make_unique<GemmaTransformer<PerChannelFp8<>>>( cfg, max_seq, max_prefill, Compute::Device::Rocm( device ) ); break;
+            case 2: rr->model = std::make_unique<GemmaTransformer<PerGroupFp4<128>>>( cfg, max_seq, max_prefill, Compute::Device::Rocm( device ) ); break;
             default: throw std::invalid_argument( "unknown weight policy" );
         }
         std::visit( [&]( auto& m )

@@ -4,6 +4,11 @@ MAX-over-ranks reduction of the measured time -- never a data-path collective.""
 import os
 
 
+def local_device():
+    """HIP device ordinal of this replica: one process per GPU, the launcher's LOCAL_RANK (0 when run alone)."""
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
 class Ranks:
     def __init__(self, backend=None):
         self.rank = int(os.environ.get("RANK", "0"))

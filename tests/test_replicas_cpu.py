@@ -29,3 +29,16 @@ def test_single_rank_needs_no_process_group():
     assert r.world == 1 and r.dist is None
     v, ms = r.aggregate_throughput(10, 5.0)
     assert v == 10 / 5e-3 and ms == 5.0
+
+
+def test_each_replica_builds_its_model_on_its_own_gpu(monkeypatch):
+    """bench.py --gpus N is one process per GPU: the model runner must be created on the launcher's LOCAL_RANK device, not on
+    device 0 (host.Gemma's default), or all replicas would share one card"""
+    import inspect
+    from mila_amd import host, replicas
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    assert replicas.local_device() == 0
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert replicas.local_device() == 5
+    src = inspect.getsource(host.Gemma.__init__)
+    assert "local_device()" in src and "mila_gemma_create(POLICIES[policy], C.byref(c), max_seq, max_prefill, seed, device)" in src
