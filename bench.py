@@ -163,7 +163,7 @@ def main():
         "policies": results,
     }
     if rank == 0:
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:        # the CPU baseline belongs to the single-GPU line only
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     ranks.close()
