@@ -145,6 +145,24 @@ def main():
         m.close()
         del m
 
+    # measured streaming ceiling beside the 8 TB/s spec: a read-only pass over 2 GiB with 16-byte loads
+    import ctypes as C
+    n = 2 << 30
+    src = torch.empty(n, dtype=torch.uint8, device="cuda")
+    sink = torch.zeros(4096, dtype=torch.float32, device="cuda")
+    lib = capi.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        capi.check(lib.mila_cdna4_stream_read(C.c_void_p(sink.data_ptr()), C.c_void_p(src.data_ptr()), C.c_size_t(n), st))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        capi.check(lib.mila_cdna4_stream_read(C.c_void_p(sink.data_ptr()), C.c_void_p(src.data_ptr()), C.c_size_t(n), st))
+    e1.record()
+    torch.cuda.synchronize()
+    stream_read_gbps = round(5 * n / e0.elapsed_time(e1) / 1e6, 1)
+    del src
+
     head = results[policies[0]]
     out = {
         "metric": "Gemma-4 12B decode tok/s (B=1, context 2048), 1xMI355X",
@@ -159,7 +177,9 @@ def main():
                      "traffic_source": measured_traffic(policies[0])[1],
                      "kernel": head["dominant_kernel"]["name"], "avg_us": head["dominant_kernel"]["avg_us"],
                      "algorithmic_bytes_per_launch": head["dominant_kernel"]["bytes"],
-                     "whole_token_frac": head["token_roofline_frac"]},
+                     "whole_token_frac": head["token_roofline_frac"],
+                     "measured_stream_read_GBps": stream_read_gbps,
+                     "frac_of_measured_stream_read": round(head["dominant_kernel"]["GBps"] / stream_read_gbps, 4)},
         "policies": results,
     }
     if rank == 0:
