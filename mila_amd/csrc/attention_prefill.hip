@@ -36,6 +36,7 @@ struct FlashParams
     int64_t q_row_stride, kv_b_stride, kv_h_stride, kv_r_stride;
     int Tq, NH, NKV, capacity, pos_offset, window;
     float scale;
+    int n_qtiles, n_hblk;    // set by the launcher: query tiles and head blocks (grid.x = n_qtiles * n_hblk)
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -80,8 +81,14 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int GS = p.NH / p.NKV;
-    const int qt = gridDim.x - 1 - blockIdx.x;                 // heaviest tiles first
-    const int hblk = blockIdx.y, b = blockIdx.z;
+    // Causal work per query tile grows with its index.  Two workgroups are resident per CU and the hardware deals workgroup ids
+    // round-robin over the CUs, so ids c and c + 256 end up sharing a CU: even rounds of 256 ids take tiles from the heavy end of
+    // the (tile, head-block) list, odd rounds from the light end -- every CU gets a heavy and a light workgroup instead of two heavy ones.
+    const int n_items = p.n_qtiles * p.n_hblk;
+    const int bid = blockIdx.x, round = bid / kNumCU, k = (round >> 1) * kNumCU + bid % kNumCU;
+    const int item = (round & 1) ? n_items - 1 - k : k;         // index in the heavy -> light order
+    const int qt = p.n_qtiles - 1 - item / p.n_hblk;
+    const int hblk = item % p.n_hblk, b = blockIdx.z;
     const int h = hblk * HB + (wave % HB);
     const int kvh = (hblk * HB) / GS;                          // all HB heads share one KV head (HB | GS)
     const int q0 = qt * QROWS;                                 // first query row (within the chunk) of this workgroup
@@ -290,8 +297,14 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel_s1(const FlashParams
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int GS = p.NH / p.NKV;
-    const int qt = gridDim.x - 1 - blockIdx.x;                 // heaviest tiles first
-    const int hblk = blockIdx.y, b = blockIdx.z;
+    // Causal work per query tile grows with its index.  Two workgroups are resident per CU and the hardware deals workgroup ids
+    // round-robin over the CUs, so ids c and c + 256 end up sharing a CU: even rounds of 256 ids take tiles from the heavy end of
+    // the (tile, head-block) list, odd rounds from the light end -- every CU gets a heavy and a light workgroup instead of two heavy ones.
+    const int n_items = p.n_qtiles * p.n_hblk;
+    const int bid = blockIdx.x, round = bid / kNumCU, k = (round >> 1) * kNumCU + bid % kNumCU;
+    const int item = (round & 1) ? n_items - 1 - k : k;         // index in the heavy -> light order
+    const int qt = p.n_qtiles - 1 - item / p.n_hblk;
+    const int hblk = item % p.n_hblk, b = blockIdx.z;
     const int h = hblk * HB + (wave % HB);
     const int kvh = (hblk * HB) / GS;                          // all HB heads share one KV head (HB | GS)
     const int q0 = qt * QROWS;                                 // first query row (within the chunk) of this workgroup
@@ -452,9 +465,12 @@ static int launch_flash(const FlashParams& p, int B, hipStream_t s)
 {
     constexpr int QROWS = 16 * (4 / HB);
     const size_t lds = (size_t)2 * kKeysPerTile * HS * 2;
-    const dim3 grid((p.Tq + QROWS - 1) / QROWS, p.NH / HB, B);
-    if constexpr (HS >= 512) hipLaunchKernelGGL((flash_prefill_kernel_s1<HS, HB>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((flash_prefill_kernel<HS, HB>), grid, dim3(256), lds, s, p);
+    FlashParams q = p;
+    q.n_qtiles = (p.Tq + QROWS - 1) / QROWS;
+    q.n_hblk = p.NH / HB;
+    const dim3 grid(q.n_qtiles * q.n_hblk, 1, B);
+    if constexpr (HS >= 512) hipLaunchKernelGGL((flash_prefill_kernel_s1<HS, HB>), grid, dim3(256), lds, s, q);
+    else hipLaunchKernelGGL((flash_prefill_kernel<HS, HB>), grid, dim3(256), lds, s, q);
     MILA_LAUNCH_CHECK("flash_prefill");
 }
 
