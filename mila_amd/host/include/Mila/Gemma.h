@@ -283,6 +283,7 @@ namespace Mila::Dnn
         /// fc_gate_up fused matvec when the chain is off
         void launchDominant( size_t i )
         {
+            if ( !cur_hidden_ ) cur_hidden_ = hidden_[ 0 ]->data();   // no fused step has run yet (reference-order timing)
             if ( use_chain_ && layers_.size() > 1 ) { const size_t l = i % ( layers_.size() - 1 ); launchChain( l, hidden_[ 0 ]->data(), hidden_[ 1 ]->data() ); }
             else fusedGateUp( layers_[ i % layers_.size() ] );
         }
