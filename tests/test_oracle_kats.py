@@ -116,6 +116,20 @@ def test_activation_restatement_is_bit_identical_to_reference_header():
     assert np.array_equal(y, exp)
 
 
+def test_activation_restatement_matches_the_committed_reference_vectors():
+    """tests/golden/activation_reference.json holds the reference header's own outputs (made by make_activation_golden.py from
+    oracle/_ref): the pin travels to boxes without /root/reference; float32 bit patterns, compared bit for bit"""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "activation_reference.json")))
+    xs = np.array(g["x"], dtype=np.uint32).view(np.float32)
+    assert xs.size > 600
+    for x, ge, si in zip(xs, g["gelu_tanh"], g["silu"]):
+        assert int(np.float32(orc.lib.orc_gelu_tanh(float(x))).view(np.uint32)) == ge, x
+        assert int(np.float32(orc.lib.orc_silu(float(x))).view(np.uint32)) == si, x
+    assert np.array_equal(orc.cpu_gelu(xs).view(np.uint32), np.array(g["gelu_tanh"], dtype=np.uint32))
+
+
 # ---- LayerNorm (Normalization/LayerNorm/LayerNorm.Cpu.cpp:210-255, tol 1e-4) ------------------------
 @pytest.mark.parametrize("bias", [True, False])
 def test_cpu_layernorm_reference_scenario(bias):
