@@ -302,13 +302,16 @@ static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, c
 // Used when the 256 x 256 direct-to-LDS kernel applies: it reads its tiles with LDS-DMA and cannot dequantize.
 // w = bf16(float(e4m3) * scale[n])   (Fp8Prefill/CudaFp8Prefill.cu:64-84)
 __global__ __launch_bounds__(256) void dequant_fp8_kernel(uint16_t* __restrict__ out, const uint8_t* __restrict__ W,
-                                                          const float* __restrict__ scales, int64_t total_vec, int vec_per_row)
+                                                          const float* __restrict__ scales, int vec_per_row)
 {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += stride)
+    // one workgroup per output channel (no index division): 16 weights per thread and pass
+    const size_t row = blockIdx.x;
+    const float sc = scales[row];
+    const uint8_t* wrow = W + row * (size_t)vec_per_row * 16;
+    uint16_t* orow = out + row * (size_t)vec_per_row * 16;
+    for (int i = threadIdx.x; i < vec_per_row; i += 256)
     {
-        const float sc = scales[i / vec_per_row];
-        const u32x4 w = ld16_nt(W + i * 16);
+        const u32x4 w = ld16_nt(wrow + (size_t)i * 16);
         u32x4 lo, hi;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -320,19 +323,23 @@ __global__ __launch_bounds__(256) void dequant_fp8_kernel(uint16_t* __restrict__
             hi[2 * d] = pack_bf16x2(c[0] * sc, c[1] * sc);
             hi[2 * d + 1] = pack_bf16x2(e[0] * sc, e[1] * sc);
         }
-        st16(out + i * 16, lo);
-        st16(out + i * 16 + 8, hi);
+        st16(orow + (size_t)i * 16, lo);
+        st16(orow + (size_t)i * 16 + 8, hi);
     }
 }
 // w = bf16(lut[nibble] * scale[n, k / G])   (W4A16Gemm/CudaW4A16Gemm.cu:210-235); one 16-byte load = 32 elements
 __global__ __launch_bounds__(256) void dequant_fp4_kernel(uint16_t* __restrict__ out, const uint8_t* __restrict__ W,
-                                                          const float* __restrict__ scales, int64_t total_vec, int vec_per_group)
+                                                          const float* __restrict__ scales, int vec_per_row, int vec_per_group_shift)
 {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += stride)
+    // one workgroup per output channel; one 16-byte load = 32 elements; group index = vec >> shift (G / 32 = 2 or 4 vectors per group)
+    const size_t row = blockIdx.x;
+    const uint8_t* wrow = W + row * (size_t)vec_per_row * 16;
+    const float* srow = scales + row * (size_t)(vec_per_row >> vec_per_group_shift);
+    uint16_t* orow = out + row * (size_t)vec_per_row * 32;
+    for (int i = threadIdx.x; i < vec_per_row; i += 256)
     {
-        const float sc = scales[i / vec_per_group];        // scales are [N, K/G] row-major == flat group index
-        const u32x4 w = ld16_nt(W + i * 16);
+        const float sc = srow[i >> vec_per_group_shift];
+        const u32x4 w = ld16_nt(wrow + (size_t)i * 16);
 #pragma unroll
         for (int d = 0; d < 4; ++d)
         {
@@ -343,9 +350,17 @@ __global__ __launch_bounds__(256) void dequant_fp4_kernel(uint16_t* __restrict__
             o[1] = pack_bf16x2((float)v1[0] * sc, (float)v1[1] * sc);
             o[2] = pack_bf16x2((float)v2[0] * sc, (float)v2[1] * sc);
             o[3] = pack_bf16x2((float)v3[0] * sc, (float)v3[1] * sc);
-            st16(out + i * 32 + d * 8, o);
+            st16(orow + (size_t)i * 32 + d * 8, o);
         }
     }
+}
+
+// dequantize a whole [N, K] weight to bf16 (the staging pass of the 2-phase prefill)
+static int launch_dequant(int fmt, uint16_t* out, const uint8_t* W, const float* scales, int N, int K, int group, hipStream_t s)
+{
+    if (fmt == 1) hipLaunchKernelGGL(dequant_fp8_kernel, dim3(N), dim3(256), 0, s, out, W, scales, K / 16);
+    else hipLaunchKernelGGL(dequant_fp4_kernel, dim3(N), dim3(256), 0, s, out, W, scales, K / 32, group == 128 ? 2 : 1);
+    return check_hip(hipGetLastError(), fmt == 1 ? "dequant_fp8" : "dequant_fp4");
 }
 
 static int validate_gemm(const char* who, const void* Y, const void* X, const void* W, int M, int K, int N)
@@ -428,10 +443,7 @@ int mila_cdna4_gemm_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, const uint
     MILA_REQUIRE(scales != nullptr, "gemm_bf16_w8a16_staged: per-channel scales are required");
     if (!scratch || scratch_bytes < need)
         return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_bf16_w8a16_staged: scratch %zu bytes < required %zu", scratch_bytes, need);
-    const int64_t total_vec = (int64_t)N * K / 16;
-    hipLaunchKernelGGL(dequant_fp8_kernel, dim3(2048), dim3(256), 0, as_stream(stream), reinterpret_cast<uint16_t*>(scratch), W, scales,
-                       total_vec, K / 16);
-    rc = check_hip(hipGetLastError(), "dequant_fp8");
+    rc = launch_dequant(1, reinterpret_cast<uint16_t*>(scratch), W, scales, N, K, 0, as_stream(stream));
     if (rc) return rc;
     return launch_bf16_rows(Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream));
 }
@@ -449,10 +461,7 @@ int mila_cdna4_gemm_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, const uint
     MILA_REQUIRE(K % group == 0, "gemm_bf16_w4a16_staged: K=%d must be a multiple of the group size %d", K, group);
     if (!scratch || scratch_bytes < need)
         return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_bf16_w4a16_staged: scratch %zu bytes < required %zu", scratch_bytes, need);
-    const int64_t total_vec = (int64_t)N * K / 32;
-    hipLaunchKernelGGL(dequant_fp4_kernel, dim3(2048), dim3(256), 0, as_stream(stream), reinterpret_cast<uint16_t*>(scratch), W_packed,
-                       scales, total_vec, group / 32);
-    rc = check_hip(hipGetLastError(), "dequant_fp4");
+    rc = launch_dequant(2, reinterpret_cast<uint16_t*>(scratch), W_packed, scales, N, K, group, as_stream(stream));
     if (rc) return rc;
     return launch_bf16_rows(Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream));
 }
@@ -481,10 +490,7 @@ int mila_cdna4_gemm_geglu_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, cons
     const size_t need = (size_t)2 * F * K * 2;
     if (!scratch || scratch_bytes < need)
         return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_geglu_bf16_w8a16_staged: scratch %zu bytes < required %zu", scratch_bytes, need);
-    const int64_t total_vec = (int64_t)2 * F * K / 16;
-    hipLaunchKernelGGL(dequant_fp8_kernel, dim3(2048), dim3(256), 0, as_stream(stream), reinterpret_cast<uint16_t*>(scratch), W, scales,
-                       total_vec, K / 16);
-    rc = check_hip(hipGetLastError(), "dequant_fp8");
+    rc = launch_dequant(1, reinterpret_cast<uint16_t*>(scratch), W, scales, 2 * F, K, 0, as_stream(stream));
     if (rc) return rc;
     return launch_gemm256_geglu(Y, X, reinterpret_cast<const uint16_t*>(scratch), M, K, F, as_stream(stream));
 }
@@ -501,10 +507,7 @@ int mila_cdna4_gemm_geglu_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, cons
     const size_t need = (size_t)2 * F * K * 2;
     if (!scratch || scratch_bytes < need)
         return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_geglu_bf16_w4a16_staged: scratch %zu bytes < required %zu", scratch_bytes, need);
-    const int64_t total_vec = (int64_t)2 * F * K / 32;
-    hipLaunchKernelGGL(dequant_fp4_kernel, dim3(2048), dim3(256), 0, as_stream(stream), reinterpret_cast<uint16_t*>(scratch), W_packed,
-                       scales, total_vec, group / 32);
-    rc = check_hip(hipGetLastError(), "dequant_fp4");
+    rc = launch_dequant(2, reinterpret_cast<uint16_t*>(scratch), W_packed, scales, 2 * F, K, group, as_stream(stream));
     if (rc) return rc;
     return launch_gemm256_geglu(Y, X, reinterpret_cast<const uint16_t*>(scratch), M, K, F, as_stream(stream));
 }
