@@ -188,3 +188,22 @@ def test_combine_in_o_proj_gives_the_reference_order_bits(policy):
         tok = (tok * 7 + pos) % 1024
     for g in models.values():
         g.close()
+
+
+@pytest.mark.parametrize("cfg_name", ["SMALL", "MEDIUM"])
+def test_chunked_prefill_equals_single_chunk_prefill(cfg_name):
+    """a prompt fed as two chunks (the second at position_offset = 16) leaves the same KV caches and produces the same logits as
+    one chunk: every row's arithmetic is independent of the chunk it arrives in (reference-order glue for SMALL, fused glue for MEDIUM)"""
+    cfg = {"SMALL": SMALL, "MEDIUM": MEDIUM}[cfg_name]
+    V = cfg["vocab_size"]
+    toks = [(17 * i + 4) % V for i in range(24)]
+    a = host.Gemma("bf16", cfg, max_seq=MAX_SEQ, max_prefill=32, seed=13)
+    b = host.Gemma("bf16", cfg, max_seq=MAX_SEQ, max_prefill=32, seed=13)
+    la = a.prefill(toks)
+    b.prefill(toks[:16])
+    lb = b.prefill(toks[16:], position_offset=16)
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), "last-position logits differ"
+    da, db = a.decode(3, 24, "fused"), b.decode(3, 24, "fused")
+    assert np.array_equal(da.view(np.uint32), db.view(np.uint32)), "the caches differ"
+    a.close()
+    b.close()
