@@ -33,13 +33,36 @@ struct QkvPostParams
 
 __global__ void advance_position_kernel(int32_t* pos) { *pos += 1; }
 
-// one wave per head row; rows [0,NH) = q, [NH,NH+NKV) = k, [NH+NKV, NH+2NKV) = v
+// sum over the hv = HS / 16 lanes of a lane group (hv a power of two <= 32): the first log2(hv) steps of wave_sum's butterfly
+__device__ __forceinline__ float group_tree_sum(float v, int hv)
+{
+    if (hv >= 2) v += dpp_f32<0xB1>(v);     // quad_perm [1,0,3,2]
+    if (hv >= 4) v += dpp_f32<0x4E>(v);     // quad_perm [2,3,0,1]
+    if (hv >= 8) v += dpp_f32<0x141>(v);    // row_half_mirror
+    if (hv >= 16) v += dpp_f32<0x140>(v);   // row_mirror
+    if (hv >= 32)
+    {
+        const uint32_t u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    return v;
+}
+
+// Head rows [0,NH) = q, [NH,NH+NKV) = k, [NH+NKV, NH+2NKV) = v of token blockIdx.y.  HS <= 512: a row is handled by the hv = HS / 16
+// lanes that also apply the result (lane g holds the rotation pair of chunks g and g + hv), 64 / hv rows per wave, every lane busy.
+// The sum of squares is tree(lo chunks) + tree(hi chunks) over those hv lanes -- exactly what rms_rstd_wave's 64-lane butterfly
+// computes for a row of 2 hv chunks (its remaining steps add zeros), so the bits match the standalone RMSNorm kernel.
 __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostParams p)
 {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
     const int HS = p.HS, half = HS / 2, hv = half / 8;
-    if (r >= p.NH + 2 * p.NKV) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rpw = (hv <= 32) ? 64 / hv : 1;                       // rows per wave
+    const int grp = (hv <= 32) ? lane / hv : 0, gl = (hv <= 32) ? lane % hv : lane;
+    const int r = (blockIdx.x * 4 + wave) * rpw + grp;
+    const int nrows = p.NH + 2 * p.NKV;
+    const bool valid = r < nrows;
+    const int rr = valid ? r : nrows - 1;
     const int t = blockIdx.y;
     const int position = (p.pos_dev ? *p.pos_dev : p.position) + t;
     const int row = position % p.capacity;
@@ -50,44 +73,57 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostParams p)
     const uint16_t* w;
     uint16_t* dst;
     bool rotate;
-    if (r < p.NH)
+    if (rr < p.NH)
     {
-        src = p.q + src_t + (size_t)r * HS; w = p.qw; dst = p.q_out + ((size_t)t * p.NH + r) * HS; rotate = true;
+        src = p.q + src_t + (size_t)rr * HS; w = p.qw; dst = p.q_out + ((size_t)t * p.NH + rr) * HS; rotate = true;
     }
-    else if (r < p.NH + p.NKV)
+    else if (rr < p.NH + p.NKV)
     {
-        const int n = r - p.NH;
+        const int n = rr - p.NH;
         src = p.k + src_t + (size_t)n * HS; w = p.kw; dst = p.Kc + ((size_t)n * p.capacity + row) * HS; rotate = true;
     }
     else
     {
-        const int n = r - p.NH - p.NKV;
+        const int n = rr - p.NH - p.NKV;
         src = p.v_src + src_t + (size_t)n * HS; w = p.vw; dst = p.Vc + ((size_t)n * p.capacity + row) * HS; rotate = false;
     }
-    // apply-phase operands are requested first so their latency overlaps the reduction's
-    const bool act = lane < hv;
-    const int l2 = act ? lane : 0;
-    const u32x4 xlo = ld16(src + (size_t)l2 * 8), xhi = ld16(src + (size_t)(l2 + hv) * 8);
-    u32x4 wlo = u32x4{0u, 0u, 0u, 0u}, whi = wlo;
-    if (w) { wlo = ld16(w + (size_t)l2 * 8); whi = ld16(w + (size_t)(l2 + hv) * 8); }
-    const float rstd = rms_rstd_wave(src, HS, p.eps);
-    if (act)
+    float rstd;
+    u32x4 xlo, xhi;
+    if (hv <= 32)
     {
-        u32x4 lo, hi;
-        if (w)
-        {
-            lo = rms_apply8(xlo, wlo, rstd, 0.0f);
-            hi = rms_apply8(xhi, whi, rstd, 0.0f);
-        }
-        else
-        {
-            lo = rms_apply8_now(xlo, rstd);
-            hi = rms_apply8_now(xhi, rstd);
-        }
-        if (rotate) rope_rotate8_vals(lo, hi, cos_row, sin_row, lane * 8);
-        st16(dst + (size_t)lane * 8, lo);
-        st16(dst + (size_t)(lane + hv) * 8, hi);
+        xlo = ld16(src + (size_t)gl * 8);
+        xhi = ld16(src + (size_t)(gl + hv) * 8);
+        const float ss = group_tree_sum(sumsq8(xlo, 0.0f), hv) + group_tree_sum(sumsq8(xhi, 0.0f), hv);
+        rstd = rsqrtf(ss / (float)HS + p.eps);
     }
+    else
+    {
+        // HS = 1024: one row per wave, two chained chunks per lane (rms_rstd_wave's own order)
+        xlo = ld16(src + (size_t)gl * 8);
+        xhi = ld16(src + (size_t)(gl + hv) * 8);
+        rstd = rms_rstd_wave(src, HS, p.eps);
+    }
+    if (!valid) return;
+    u32x4 lo, hi;
+    if (w)
+    {
+        lo = rms_apply8(xlo, ld16(w + (size_t)gl * 8), rstd, 0.0f);
+        hi = rms_apply8(xhi, ld16(w + (size_t)(gl + hv) * 8), rstd, 0.0f);
+    }
+    else
+    {
+        lo = rms_apply8_now(xlo, rstd);
+        hi = rms_apply8_now(xhi, rstd);
+    }
+    if (rotate) rope_rotate8_vals(lo, hi, cos_row, sin_row, gl * 8);
+    st16(dst + (size_t)gl * 8, lo);
+    st16(dst + (size_t)(gl + hv) * 8, hi);
+}
+
+static int qkv_post_rows_per_wave(int HS)
+{
+    const int hv = HS / 16;
+    return hv <= 32 ? 64 / hv : 1;
 }
 
 }  // namespace mila
@@ -103,10 +139,10 @@ int mila_cdna4_fused_qkv_post(uint16_t* q_out, uint16_t* Kc, uint16_t* Vc, const
 {
     MILA_REQUIRE(q_out && Kc && Vc && q && k && v_src && qw && kw && cos_cache && sin_cache, "fused_qkv_post: null pointer");
     MILA_REQUIRE(NH > 0 && NKV > 0 && capacity > 0 && position >= 0, "fused_qkv_post: bad sizes");
-    MILA_REQUIRE(HS % 16 == 0 && HS >= 16 && HS <= 1024, "fused_qkv_post: HS=%d must be a multiple of 16 in [16,1024]", HS);
+    MILA_REQUIRE(HS >= 16 && HS <= 1024 && (HS & (HS - 1)) == 0, "fused_qkv_post: HS=%d must be a power of two in [16,1024]", HS);
     QkvPostParams p{q_out, Kc, Vc, q, k, v_src, qw, kw, vw, cos_cache, sin_cache, nullptr, NH, NKV, HS, position, capacity, eps, 0};
     const int rows = NH + 2 * NKV;
-    hipLaunchKernelGGL(qkv_post_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, as_stream(stream), p);
+    hipLaunchKernelGGL(qkv_post_kernel, dim3(ceil_div(rows, 4 * qkv_post_rows_per_wave(HS))), dim3(256), 0, as_stream(stream), p);
     MILA_LAUNCH_CHECK("fused_qkv_post");
 }
 
@@ -118,11 +154,11 @@ int mila_cdna4_fused_qkv_post_prefill(uint16_t* q_out, uint16_t* Kc, uint16_t* V
     MILA_REQUIRE(q_out && Kc && Vc && q && k && v_src && qw && kw && cos_cache && sin_cache, "fused_qkv_post_prefill: null pointer");
     MILA_REQUIRE(T > 0 && T <= 65535 && NH > 0 && NKV > 0 && capacity > 0 && pos_offset >= 0, "fused_qkv_post_prefill: bad sizes");
     MILA_REQUIRE(T <= capacity, "fused_qkv_post_prefill: %d tokens do not fit the cache capacity %d", T, capacity);
-    MILA_REQUIRE(HS % 16 == 0 && HS >= 16 && HS <= 1024, "fused_qkv_post_prefill: HS=%d must be a multiple of 16 in [16,1024]", HS);
+    MILA_REQUIRE(HS >= 16 && HS <= 1024 && (HS & (HS - 1)) == 0, "fused_qkv_post_prefill: HS=%d must be a power of two in [16,1024]", HS);
     MILA_REQUIRE(src_row_stride % 8 == 0 && src_row_stride >= (int64_t)HS, "fused_qkv_post_prefill: row stride %lld must be a multiple of 8", (long long)src_row_stride);
     QkvPostParams p{q_out, Kc, Vc, q, k, v_src, qw, kw, vw, cos_cache, sin_cache, nullptr, NH, NKV, HS, pos_offset, capacity, eps, src_row_stride};
     const int rows = NH + 2 * NKV;
-    hipLaunchKernelGGL(qkv_post_kernel, dim3(ceil_div(rows, 4), T), dim3(256), 0, as_stream(stream), p);
+    hipLaunchKernelGGL(qkv_post_kernel, dim3(ceil_div(rows, 4 * qkv_post_rows_per_wave(HS)), T), dim3(256), 0, as_stream(stream), p);
     MILA_LAUNCH_CHECK("fused_qkv_post_prefill");
 }
 
@@ -134,10 +170,10 @@ int mila_cdna4_fused_qkv_post_devpos(uint16_t* q_out, uint16_t* Kc, uint16_t* Vc
     MILA_REQUIRE(q_out && Kc && Vc && q && k && v_src && qw && kw && cos_cache && sin_cache && position_dev,
                  "fused_qkv_post_devpos: null pointer");
     MILA_REQUIRE(NH > 0 && NKV > 0 && capacity > 0, "fused_qkv_post_devpos: bad sizes");
-    MILA_REQUIRE(HS % 16 == 0 && HS >= 16 && HS <= 1024, "fused_qkv_post_devpos: HS=%d must be a multiple of 16 in [16,1024]", HS);
+    MILA_REQUIRE(HS >= 16 && HS <= 1024 && (HS & (HS - 1)) == 0, "fused_qkv_post_devpos: HS=%d must be a power of two in [16,1024]", HS);
     QkvPostParams p{q_out, Kc, Vc, q, k, v_src, qw, kw, vw, cos_cache, sin_cache, position_dev, NH, NKV, HS, 0, capacity, eps, 0};
     const int rows = NH + 2 * NKV;
-    hipLaunchKernelGGL(qkv_post_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, as_stream(stream), p);
+    hipLaunchKernelGGL(qkv_post_kernel, dim3(ceil_div(rows, 4 * qkv_post_rows_per_wave(HS))), dim3(256), 0, as_stream(stream), p);
     MILA_LAUNCH_CHECK("fused_qkv_post_devpos");
 }
 
