@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--mode", default="graph", choices=["graph", "fused", "reference"])
     ap.add_argument("--no-prefill", action="store_true", help="skip the timed T=2048 prefill (KV cache left zero-filled)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--onepass", type=int, default=None, help="1/0: split decode attention in one launch / with a combine launch (default: the model's)")
+    ap.add_argument("--prefetch-mb", type=float, default=None, help="side-stream Infinity-Cache prefetch cap per Linear in MB (0 = off; default: the model's)")
+    ap.add_argument("--prefetch-wgs", type=int, default=64)
     a = ap.parse_args()
 
     import torch
@@ -112,6 +115,10 @@ def main():
     results = {}
     for pol in policies:
         m = host.Gemma(pol, cfg, max_seq=CONTEXT + a.steps + a.warmup + 8, max_prefill=1 if a.no_prefill else CONTEXT, seed=1234)
+        if a.onepass is not None:
+            m.set_onepass_attention(a.onepass)
+        if a.prefetch_mb is not None:
+            m.set_prefetch_ahead(int(a.prefetch_mb * 1e6), a.prefetch_wgs)
         info = m.info(CONTEXT)
         r = {"weight_GB": round(info["weight_bytes"] / 1e9, 3), "bytes_per_token_GB": round(info["decode_bytes_per_token"] / 1e9, 3)}
         if not a.no_prefill:

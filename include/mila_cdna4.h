@@ -435,6 +435,24 @@ MILA_API int mila_cdna4_fused_attn_decode_bf16(uint16_t* Y, uint16_t* Kc, uint16
                                                const int32_t* position_dev, int window, float scale, float eps,
                                                mila_stream_t stream);
 
+/* The same in ONE launch on layers whose live band is split over workgroups: the combine launch of the reference's split-K decode
+ * (the fixup kernel, Gqa.Decode.Bf16.cu:297-351) becomes the tail of the workgroup whose partials arrive last.
+ * tickets: uint32 [mila_cdna4_attn_decode_ticket_count(1, NH)], zeroed once by the caller (memset_zero) and owned by ONE
+ * stream at a time; every call leaves it zero again.  Bit-identical to fused_attn_decode_bf16. */
+MILA_API size_t mila_cdna4_attn_decode_ticket_count(int B, int NH);
+MILA_API int mila_cdna4_fused_attn_decode_onepass_bf16(uint16_t* Y, uint16_t* Kc, uint16_t* Vc, const uint16_t* q_raw,
+                                                       const uint16_t* k_raw, const uint16_t* v_raw, const uint16_t* qw,
+                                                       const uint16_t* kw, const uint16_t* vw, const float* cos_cache,
+                                                       const float* sin_cache, void* scratch, size_t scratch_bytes,
+                                                       uint32_t* tickets, size_t ticket_count, int NH, int NKV, int HS,
+                                                       int capacity, int position, const int32_t* position_dev, int window,
+                                                       float scale, float eps, mila_stream_t stream);
+
+/* Warm the 256 MiB Infinity Cache with a byte range a later kernel will stream (the next Linear's weights), from a side stream
+ * while the current kernel runs; reads one dword per 128-byte line in address order, writes nothing (sink: any 4 writable bytes,
+ * never written in practice).  No reference counterpart (a 12 GB card has no memory-side cache to warm); results are unaffected. */
+MILA_API int mila_cdna4_prefetch_l3(const void* src, size_t bytes, int workgroups, float* sink, mila_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,8 @@ struct AttnParams
     uint16_t* V;
     float* scratch;           // [B, NH, splits, HS+4] partials when splits > 1: O (HS) | m | l | pad (rows stay 16-byte aligned)
     int no_combine;           // leave the partials for the consumer (matvec_attn_combine) instead of launching the combine
+    uint32_t* tickets;        // one-pass form: arrival counters [B, NKV * head-groups], zero between launches; the workgroup whose
+                              // partials arrive last combines its head-group's splits itself, so there is no combine launch
     int NH, NKV, capacity, position, window, splits;
     float scale;
     const int32_t* pos_dev;   // when set: the position is read from device memory (graph replay)
@@ -119,6 +121,47 @@ __device__ __forceinline__ void head_row_post(const uint16_t* __restrict__ src, 
         if (dst_lds) { st16(dst_lds + (size_t)lane * 8, lo); st16(dst_lds + (size_t)(lane + hv) * 8, hi); }
         if (dst_glb) { st16(dst_glb + (size_t)lane * 8, lo); st16(dst_glb + (size_t)(lane + hv) * 8, hi); }
     }
+}
+
+// Combine of one head's split partials for output dim d by the lane that owns it: the arithmetic of attn_combine_kernel, shared by
+// the standalone kernel (plain loads behind a kernel boundary) and the one-pass tail of attn_decode_kernel (SC1 = agent-coherent
+// loads of partials other workgroups wrote through inside the same launch).  Lane s of the wave holds split s's (m, l).
+template <bool SC1>
+__device__ __forceinline__ float partial_ld(const float* p)
+{
+    if constexpr (SC1)
+        return __hip_atomic_load((const __attribute__((address_space(1))) float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        return *p;
+}
+template <bool SC1>
+__device__ __forceinline__ uint16_t combine_dim(const float* __restrict__ base, int HS, int splits, int d)
+{
+    const int STR = HS + 4;
+    const int s = threadIdx.x & 63;
+    const float ms = (s < splits) ? partial_ld<SC1>(base + (size_t)s * STR + HS) : -INFINITY;
+    const float ls = (s < splits) ? partial_ld<SC1>(base + (size_t)s * STR + HS + 1) : 0.0f;
+    float acc = 0.0f;
+    float vals[8];
+    const float M = wave_max(ms);
+    const float fs = (ms == -INFINITY) ? 0.0f : __expf(ms - M);
+    const float L = wave_sum(ls * fs);
+    for (int i0 = 0; i0 < splits; i0 += 8)
+    {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vals[u] = (i0 + u < splits) ? partial_ld<SC1>(base + (size_t)(i0 + u) * STR + d) : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+        {
+            const float f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fs), min(i0 + u, 63)));
+            acc = fmaf(vals[u], f, acc);
+        }
+    }
+    return f32_to_bf16_bits(L > 0.0f ? acc / L : 0.0f);
+}
+__device__ __forceinline__ void partial_st_sc1(float* p, float v)
+{
+    __hip_atomic_store((__attribute__((address_space(1))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // HS = 64 * EPL (EPL in {2,4,8}) or HS = 64 handled as EPL = 2 on 32 active lanes.
@@ -364,7 +407,7 @@ __global__ __launch_bounds__(kDecodeWaves * 64) void attn_decode_kernel(const At
                     *reinterpret_cast<uint32_t*>(y + e) = pack_bf16x2(acc[e] * inv, acc[e + 1] * inv);
             }
         }
-        else
+        else if (p.tickets == nullptr)
         {
             float* dst = p.scratch + (((size_t)b * p.NH + h) * p.splits + split) * (HS + 4);
             if (owner)
@@ -373,6 +416,45 @@ __global__ __launch_bounds__(kDecodeWaves * 64) void attn_decode_kernel(const At
                 for (int e = 0; e < EPL; ++e) dst[lane * EPL + e] = acc[e];
             }
             if (lane == 0) { dst[HS] = M; dst[HS + 1] = L; }
+        }
+        else
+        {
+            // one-pass form: write-through (sc1) stores, drained by this wave before the workgroup's arrival is counted
+            float* dst = p.scratch + (((size_t)b * p.NH + h) * p.splits + split) * (HS + 4);
+            if (owner)
+            {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) partial_st_sc1(dst + lane * EPL + e, acc[e]);
+            }
+            if (lane == 0) { partial_st_sc1(dst + HS, M); partial_st_sc1(dst + HS + 1, L); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    if (p.splits > 1 && p.tickets != nullptr)
+    {
+        // Arrival ticket per (batch row, head-group): MI355X_MICROARCH.md hand-off table, row 1 (sc1 payload stores drained by
+        // every storing wave, a workgroup barrier, ONE lane's agent-scope atomic add; the workgroup whose add came last reads
+        // with sc1 loads, its other waves behind a barrier the adding wave joins).  The last arriver re-arms the counter.
+        __shared__ int s_last;
+        __syncthreads();
+        uint32_t* tk = p.tickets + (size_t)b * gridDim.y + blockIdx.y;
+        if (threadIdx.x == 0)
+        {
+            const uint32_t t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == (uint32_t)(p.splits - 1));
+            if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = last;
+        }
+        __syncthreads();
+        if (s_last)
+        {
+            for (int idx = threadIdx.x; idx < GH * HS; idx += NW * 64)
+            {
+                const int g = idx / HS, d = idx % HS;       // a wave's 64 dims lie in one head (HS % 64 == 0)
+                const int h = h0 + g;
+                const float* base = p.scratch + ((size_t)b * p.NH + h) * p.splits * (HS + 4);
+                p.Y[((size_t)b * p.NH + h) * HS + d] = combine_dim<true>(base, HS, p.splits, d);
+            }
         }
     }
 }
@@ -385,29 +467,8 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(uint16_t* __restrict__
 {
     const int h = blockIdx.x, b = blockIdx.y;
     const int d = blockIdx.z * 64 + threadIdx.x;
-    const int STR = HS + 4;
-    const float* base = scratch + ((size_t)b * NH + h) * splits * STR;
-    const int s = threadIdx.x;
-    const float ms = (s < splits) ? base[(size_t)s * STR + HS] : -INFINITY;
-    const float ls = (s < splits) ? base[(size_t)s * STR + HS + 1] : 0.0f;
-    float acc = 0.0f;
-    // partial values are requested before the (m, l) reduction completes
-    float vals[8];
-    const float M = wave_max(ms);
-    const float fs = (ms == -INFINITY) ? 0.0f : __expf(ms - M);
-    const float L = wave_sum(ls * fs);
-    for (int i0 = 0; i0 < splits; i0 += 8)
-    {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) vals[u] = (i0 + u < splits) ? base[(size_t)(i0 + u) * STR + d] : 0.0f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-        {
-            const float f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fs), min(i0 + u, 63)));
-            acc = fmaf(vals[u], f, acc);
-        }
-    }
-    Y[((size_t)b * NH + h) * HS + d] = f32_to_bf16_bits(L > 0.0f ? acc / L : 0.0f);
+    const float* base = scratch + ((size_t)b * NH + h) * splits * (HS + 4);
+    Y[((size_t)b * NH + h) * HS + d] = combine_dim<false>(base, HS, splits, d);
 }
 
 static int heads_per_group(int GS, int HS) { return HS >= 512 ? (GS >= 2 ? 2 : 1) : (GS >= 4 ? 4 : GS); }
@@ -420,7 +481,7 @@ static int launch_decode(const AttnParams& p, int B, hipStream_t s)
     hipLaunchKernelGGL((attn_decode_kernel<HS, GH, FUSED>), dim3(p.splits, p.NKV * hgroups, B), dim3(kDecodeWaves * 64), lds, s, p);
     int rc = check_hip(hipGetLastError(), "attn_decode");
     if (rc) return rc;
-    if (p.splits > 1 && !p.no_combine)
+    if (p.splits > 1 && !p.no_combine && !p.tickets)
     {
         hipLaunchKernelGGL(attn_combine_kernel, dim3(p.NH, B, HS / 64), dim3(64), 0, s, p.Y, p.scratch, p.NH, HS, p.splits);
         rc = check_hip(hipGetLastError(), "attn_combine");
@@ -602,6 +663,40 @@ int mila_cdna4_fused_attn_decode_partials_bf16(uint16_t* Kc, uint16_t* Vc, const
     f.no_combine = 1;
     return run_decode(nullptr, nullptr, Kc, Vc, scratch, scratch_bytes, 1, NH, NKV, HS, capacity, position, position_dev, window, scale, &f,
                       "fused_attn_decode_partials_bf16", as_stream(stream));
+}
+
+size_t mila_cdna4_attn_decode_ticket_count(int B, int NH)
+{
+    if (B <= 0 || NH <= 0) return 0;
+    return (size_t)B * NH;     // one counter per (batch row, head-group); head-groups <= NH
+}
+
+// fused_attn_decode_bf16 without the combine launch: the workgroup whose split partials arrive last (an arrival ticket per
+// head-group in `tickets`: uint32 [ticket_count], zero before the first call, re-armed by every call) merges its head-group's
+// splits in the same launch, with the combine kernel's arithmetic => bit-identical to fused_attn_decode_bf16.
+int mila_cdna4_fused_attn_decode_onepass_bf16(uint16_t* Y, uint16_t* Kc, uint16_t* Vc, const uint16_t* q_raw, const uint16_t* k_raw,
+                                              const uint16_t* v_raw, const uint16_t* qw, const uint16_t* kw, const uint16_t* vw,
+                                              const float* cos_cache, const float* sin_cache, void* scratch, size_t scratch_bytes,
+                                              uint32_t* tickets, size_t ticket_count, int NH, int NKV, int HS, int capacity, int position,
+                                              const int32_t* position_dev, int window, float scale, float eps, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && Kc && Vc && q_raw && k_raw && v_raw && qw && kw && cos_cache && sin_cache && tickets, "fused_attn_decode_onepass_bf16: null pointer");
+    MILA_REQUIRE(NH > 0 && NKV > 0 && NH % NKV == 0, "fused_attn_decode_onepass_bf16: bad head counts (NH=%d NKV=%d)", NH, NKV);
+    MILA_REQUIRE(capacity > 0 && window >= 0 && (position_dev || position >= 0), "fused_attn_decode_onepass_bf16: bad sizes");
+    MILA_REQUIRE(HS % 16 == 0, "fused_attn_decode_onepass_bf16: HS=%d must be a multiple of 16", HS);
+    MILA_REQUIRE(ticket_count >= mila_cdna4_attn_decode_ticket_count(1, NH), "fused_attn_decode_onepass_bf16: %zu tickets < required %zu",
+                 ticket_count, mila_cdna4_attn_decode_ticket_count(1, NH));
+    if (!position_dev)
+    {
+        const int len = position + 1, band = (window > 0 && window < len) ? window : len;
+        MILA_REQUIRE(band <= capacity, "fused_attn_decode_onepass_bf16: live band %d exceeds the cache capacity %d", band, capacity);
+    }
+    AttnParams f{};
+    f.q_raw = q_raw; f.k_raw = k_raw; f.v_raw = v_raw; f.qw = qw; f.kw = kw; f.vw = vw; f.cos_cache = cos_cache; f.sin_cache = sin_cache;
+    f.eps = eps;
+    f.tickets = tickets;
+    return run_decode(Y, nullptr, Kc, Vc, scratch, scratch_bytes, 1, NH, NKV, HS, capacity, position, position_dev, window, scale, &f,
+                      "fused_attn_decode_onepass_bf16", as_stream(stream));
 }
 
 }  // extern "C"

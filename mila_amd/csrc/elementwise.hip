@@ -318,6 +318,27 @@ __global__ __launch_bounds__(256) void stream_read_kernel(float* __restrict__ si
     if (acc == 0x12345679u) sink[0] = 1.0f;   // never true in practice; keeps the loads alive
 }
 
+
+// Warm the 256 MiB Infinity Cache with a byte range a LATER kernel will stream (the decode step's next weight matrices), from a
+// side stream while the current kernel runs: one dword per 128-byte line (the line is what moves), default cache policy, lines
+// walked in address order by the whole grid, which is the order the matvec kernels consume their rows in.  Nothing is written.
+__global__ __launch_bounds__(256) void prefetch_l3_kernel(float* __restrict__ sink, const uint8_t* __restrict__ src, int64_t nlines)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    uint32_t acc = 0;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 7 * stride < nlines; i += 8 * stride)
+    {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint32_t*>(src + (i + u * stride) * 128);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= v[u];
+    }
+    for (; i < nlines; i += stride) acc ^= *reinterpret_cast<const uint32_t*>(src + i * 128);
+    if (acc == 0x12345679u && sink != nullptr) sink[0] = 1.0f;   // keeps the loads alive; sink is never written in practice
+}
+
 }  // namespace mila
 
 using namespace mila;
@@ -481,6 +502,15 @@ int mila_cdna4_stream_read(float* sink, const void* src, size_t bytes, mila_stre
     hipLaunchKernelGGL(stream_read_kernel, dim3(2048), dim3(256), 0, as_stream(stream), sink, (const u32x4*)src,
                        (int64_t)(bytes / 16));
     MILA_LAUNCH_CHECK("stream_read");
+}
+
+int mila_cdna4_prefetch_l3(const void* src, size_t bytes, int workgroups, float* sink, mila_stream_t stream)
+{
+    MILA_REQUIRE(src && sink && workgroups > 0 && workgroups <= 4096, "prefetch_l3: bad arguments");
+    const int64_t nlines = (int64_t)(bytes / 128);
+    if (nlines == 0) return 0;
+    hipLaunchKernelGGL(prefetch_l3_kernel, dim3(workgroups), dim3(256), 0, as_stream(stream), sink, (const uint8_t*)src, nlines);
+    MILA_LAUNCH_CHECK("prefetch_l3");
 }
 
 }  // extern "C"

@@ -49,6 +49,8 @@ def load():
         _lib.mila_gemma_set_fp8_activation_prefill.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_set_combine_in_oproj.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_set_fused_prefill.argtypes = [C.c_void_p, C.c_int]
+        _lib.mila_gemma_set_onepass_attention.argtypes = [C.c_void_p, C.c_int]
+        _lib.mila_gemma_set_prefetch_ahead.argtypes = [C.c_void_p, C.c_int64, C.c_int]
         _lib.mila_gpt_last_error.restype = C.c_char_p
         _lib.mila_gpt_create.restype = C.c_void_p
         _lib.mila_gpt_create.argtypes = [C.c_int64] * 7
@@ -109,6 +111,16 @@ class Gemma:
         """fused / graph decode: fold the flash-decode combine into o_proj's prologue on layers with a small partial set
         (opt-in: measured slower than the combine launch it removes) or keep the combine launch; identical bits"""
         _check(load().mila_gemma_set_combine_in_oproj(self.h, int(bool(on))))
+
+    def set_onepass_attention(self, on):
+        """fused / graph decode: split decode attention in ONE launch (the workgroup whose partials arrive last merges its
+        head-group's splits) instead of attention + combine launches; identical bits"""
+        _check(load().mila_gemma_set_onepass_attention(self.h, int(bool(on))))
+
+    def set_prefetch_ahead(self, cap_bytes, workgroups=64):
+        """fused / graph decode: a side stream warms the Infinity Cache with the first cap_bytes of the next Linear's weights
+        while the current kernel runs (0 = off); results unaffected"""
+        _check(load().mila_gemma_set_prefetch_ahead(self.h, int(cap_bytes), int(workgroups)))
 
     def set_fp8_activation_prefill(self, on):
         """fp4 policy: W4A8 prefill on the fp8 matrix cores (default, the reference's default) or the exact-weight bf16 fallback"""

@@ -106,6 +106,9 @@ namespace Mila::Dnn
         {
             if ( graph_exec_ ) (void)hipGraphExecDestroy( graph_exec_ );
             if ( graph_ ) (void)hipGraphDestroy( graph_ );
+            if ( fork_ev_ ) (void)hipEventDestroy( fork_ev_ );
+            if ( join_ev_ ) (void)hipEventDestroy( join_ev_ );
+            if ( side_ ) (void)hipStreamDestroy( side_ );
         }
 
         Compute::RocmExecutionContext* context() const noexcept { return ctx_; }
@@ -376,6 +379,9 @@ namespace Mila::Dnn
             sample_scratch_ = std::make_unique<LogitsTensor>( dev, shape_t{ static_cast<dim_t>( mila_cdna4_sample_scratch_bytes() / 4 ) } );
             err_flag_ = std::make_unique<TokenTensor>( dev, shape_t{ 1 } );
             Compute::rocmCheck( mila_cdna4_memset_zero( err_flag_->data(), 4, ctx_->getStream() ) );
+            tickets_ = std::make_unique<TokenTensor>( dev, shape_t{ static_cast<dim_t>( mila_cdna4_attn_decode_ticket_count( 1, (int)cfg_.num_heads ) ) } );
+            Compute::rocmCheck( mila_cdna4_memset_zero( tickets_->data(), tickets_->sizeInBytes(), ctx_->getStream() ) );
+            pf_sink_ = std::make_unique<LogitsTensor>( dev, shape_t{ 4 } );
             if ( chainApplicable() )
             {
                 const size_t nb = mila_cdna4_decode_chain_scratch_bytes( (int)cfg_.embedding_dim, (int)cfg_.hidden_dim );
@@ -672,16 +678,31 @@ namespace Mila::Dnn
                 }
                 else
                 {
-                    Compute::rocmCheck( mila_cdna4_fused_attn_decode_bf16( attn_out_->data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
-                                                                           L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(),
-                                                                           scratch, need, NH, NKV, HD, (int)L.attn->cacheCapacity(), position, pos_dev,
-                                                                           (int)cfg_.windowFor( g ), L.attn->scale(), cfg_.rms_norm_eps, st ) );
+                    prefetchLinear( *L.o_proj ); prefetchLinear( *L.fc_gate_up, true );   // beside the latency-bound attention launches
+                    if ( onepass_attn_ )
+                        Compute::rocmCheck( mila_cdna4_fused_attn_decode_onepass_bf16( attn_out_->data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp,
+                                                                                       L.q_norm->getWeight()->data(), L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(),
+                                                                                       L.rope->cosCache(), L.rope->sinCache(), scratch, need,
+                                                                                       reinterpret_cast<uint32_t*>( tickets_->data() ), (size_t)tickets_->size(), NH, NKV, HD,
+                                                                                       (int)L.attn->cacheCapacity(), position, pos_dev, (int)cfg_.windowFor( g ), L.attn->scale(),
+                                                                                       cfg_.rms_norm_eps, st ) );
+                    else
+                        Compute::rocmCheck( mila_cdna4_fused_attn_decode_bf16( attn_out_->data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
+                                                                               L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(),
+                                                                               scratch, need, NH, NKV, HD, (int)L.attn->cacheCapacity(), position, pos_dev,
+                                                                               (int)cfg_.windowFor( g ), L.attn->scale(), cfg_.rms_norm_eps, st ) );
                     // 4. o_proj
                     plainMatvec( *L.o_proj, f_o_->data(), attn_out_->data() );
                 }
                 // 5. post_attn_norm + residual + pre_ffn_norm + gate_up + GeGLU
+                prefetchLinear( *L.fc_down );
                 fusedGateUp( L );
                 // 6. fc_down
+                {
+                    const size_t li = static_cast<size_t>( &L - layers_.data() );
+                    if ( li + 1 < layers_.size() ) prefetchLinear( *layers_[ li + 1 ].qkv_proj );
+                    else prefetchLinear( *lm_head_ );
+                }
                 plainMatvec( *L.fc_down, f_down_->data(), f_act_->data() );
                 prev = &L;
             }
@@ -696,6 +717,7 @@ namespace Mila::Dnn
                 a.fmt = kTableFmt; a.K = (int)cfg_.embedding_dim; a.N = (int)cfg_.vocab_size; a.group = 0; a.geglu = 0; a.f32_out = 1;
                 Compute::rocmCheck( mila_cdna4_fused_norm_matvec( &a, st ) );
             }
+            joinSide();
         }
 
         /// q/k/v norms + RoPE + KV append + flash-decode in one launch (+ combine) for layer L; qkv row = [q | k | v]
@@ -793,6 +815,73 @@ namespace Mila::Dnn
             if ( graph_exec_ ) throw std::runtime_error( "GemmaTransformer::setCombineInOProj: the graph is already captured" );
             combine_in_oproj_ = on;
         }
+        /// split decode attention in ONE launch (the workgroup whose partials arrive last merges its head-group's splits) instead of
+        /// attention + combine launches; same bits
+        void setOnepassAttention( bool on )
+        {
+            if ( graph_exec_ ) throw std::runtime_error( "GemmaTransformer::setOnepassAttention: the graph is already captured" );
+            onepass_attn_ = on;
+        }
+        /// cap_bytes > 0: while one decode kernel runs, a side stream pulls the first cap_bytes of the NEXT Linear's weights into the
+        /// 256 MiB Infinity Cache (mila_cdna4_prefetch_l3), so that the memory system works through kernel ramps, tails and the
+        /// latency-bound attention launches; 0 = off.  Results are unaffected (the prefetch only reads).
+        void setPrefetchAhead( size_t cap_bytes, int workgroups = 64 )
+        {
+            if ( graph_exec_ ) throw std::runtime_error( "GemmaTransformer::setPrefetchAhead: the graph is already captured" );
+            if ( workgroups < 1 || workgroups > 4096 ) throw std::invalid_argument( "GemmaTransformer::setPrefetchAhead: workgroups out of range" );
+            if ( cap_bytes > 0 && !side_ )
+            {
+                hipCheck( hipStreamCreateWithFlags( &side_, hipStreamNonBlocking ), "hipStreamCreate" );
+                hipCheck( hipEventCreateWithFlags( &fork_ev_, hipEventDisableTiming ), "hipEventCreate" );
+                hipCheck( hipEventCreateWithFlags( &join_ev_, hipEventDisableTiming ), "hipEventCreate" );
+            }
+            prefetch_cap_ = cap_bytes;
+            prefetch_wgs_ = workgroups;
+        }
+
+    private:
+        /// enqueue (side stream) a prefetch of the first min(bytes, cap) bytes at p, ordered after everything enqueued on the main
+        /// stream so far -- i.e. it runs beside the main-stream kernel enqueued next
+        void prefetchAhead( const void* p, size_t bytes, bool fork = true )
+        {
+            if ( prefetch_cap_ == 0 || p == nullptr || bytes == 0 ) return;
+            hipStream_t main = reinterpret_cast<hipStream_t>( ctx_->getStream() );
+            if ( fork )
+            {
+                hipCheck( hipEventRecord( fork_ev_, main ), "hipEventRecord" );
+                hipCheck( hipStreamWaitEvent( side_, fork_ev_, 0 ), "hipStreamWaitEvent" );
+            }
+            Compute::rocmCheck( mila_cdna4_prefetch_l3( p, std::min( bytes, prefetch_cap_ ), prefetch_wgs_, pf_sink_->data(), reinterpret_cast<mila_stream_t>( side_ ) ) );
+            side_dirty_ = true;
+        }
+        template<typename Lin> void prefetchLinear( Lin& lin, bool geglu = false )
+        {
+            if ( prefetch_cap_ == 0 ) return;
+            const uint8_t* w = static_cast<const uint8_t*>( lin.getWeight().rawData() );
+            const size_t wb = lin.getWeight().sizeInBytes();
+            if ( geglu && wb > prefetch_cap_ )
+            {
+                // the fused gate_up kernel reads gate row n and up row F + n together: warm the head of both halves
+                const size_t cap = prefetch_cap_;
+                prefetch_cap_ = cap / 2;
+                prefetchAhead( w, wb / 2 ); prefetchAhead( w + wb / 2, wb / 2, false );
+                prefetch_cap_ = cap;
+            }
+            else prefetchAhead( w, wb );
+            if constexpr ( Lin::kIsQuantized )
+                if ( lin.getWeightScale() && lin.getWeightScale()->sizeInBytes() > ( 1u << 20 ) ) prefetchAhead( lin.getWeightScale()->data(), lin.getWeightScale()->sizeInBytes(), false );
+        }
+        /// the side stream rejoins the main stream (end of a step; required before hipStreamEndCapture)
+        void joinSide()
+        {
+            if ( !side_dirty_ ) return;
+            hipStream_t main = reinterpret_cast<hipStream_t>( ctx_->getStream() );
+            hipCheck( hipEventRecord( join_ev_, side_ ), "hipEventRecord" );
+            hipCheck( hipStreamWaitEvent( main, join_ev_, 0 ), "hipStreamWaitEvent" );
+            side_dirty_ = false;
+        }
+
+    public:
         /// whether the decode chain kernel serves this configuration (D, attention width <= 8192, F <= 16384, ...)
         bool chainApplicable() const
         {
@@ -837,6 +926,14 @@ namespace Mila::Dnn
         bool use_chain_{ false };
         bool combine_in_oproj_{ false };   // measured slower on MI355X (bf16 222 -> 217, fp4 415 -> 396 tok/s): opt-in, DESIGN.md section 5
         bool fused_prefill_{ true };
+        bool onepass_attn_{ false };       // split decode attention without the combine launch (last-arriver merge in the same launch)
+        size_t prefetch_cap_{ 0 };         // > 0: side-stream Infinity-Cache prefetch of the next Linear's weights, at most this many bytes each
+        int prefetch_wgs_{ 64 };
+        bool side_dirty_{ false };
+        hipStream_t side_{ nullptr };
+        hipEvent_t fork_ev_{ nullptr }, join_ev_{ nullptr };
+        std::unique_ptr<TokenTensor> tickets_;
+        std::unique_ptr<LogitsTensor> pf_sink_;
         std::unique_ptr<TensorType> pf_norm_, pf_norm2_;
         std::unique_ptr<LogitsTensor> chain_scratch_;
         const uint16_t* cur_hidden_{ nullptr };

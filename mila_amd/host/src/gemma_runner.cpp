@@ -138,6 +138,19 @@ HOST_API int mila_gemma_set_combine_in_oproj( void* h, int on )
     auto* r = static_cast<Runner*>( h );
     return guarded( [&] { std::visit( [&]( auto& m ) { m->setCombineInOProj( on != 0 ); }, r->model ); } );
 }
+/// on != 0: split decode attention runs in ONE launch (last-arriver merge) instead of attention + combine; same bits
+HOST_API int mila_gemma_set_onepass_attention( void* h, int on )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&] { std::visit( [&]( auto& m ) { m->setOnepassAttention( on != 0 ); }, r->model ); } );
+}
+/// cap_bytes > 0: side-stream Infinity-Cache prefetch of the next Linear's weights (at most cap_bytes each) beside the running
+/// decode kernel; 0 = off.  Call before the first graph-mode decode.
+HOST_API int mila_gemma_set_prefetch_ahead( void* h, int64_t cap_bytes, int workgroups )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&] { std::visit( [&]( auto& m ) { m->setPrefetchAhead( cap_bytes > 0 ? (size_t)cap_bytes : 0, workgroups ); }, r->model ); } );
+}
 /// fp4 policy: on != 0 (default, as in the reference) = W4A8 prefill on the fp8 matrix cores; 0 = dequantize -> bf16 GEMM
 HOST_API int mila_gemma_set_fp8_activation_prefill( void* h, int on )
 {

@@ -335,3 +335,79 @@ def test_attention_partials_plus_combining_o_proj_equals_attention_plus_o_proj(N
     capi.call("matvec_attn_combine", y1, scratch, splits, NH, HS, W, s, fmt, D, 128)
     assert np.array_equal(bits(K1), bits(K0)) and np.array_equal(bits(V1), bits(V0)), "cache rows differ"
     assert np.array_equal(bits(y1), bits(y0)), "o_proj output differs"
+
+
+@pytest.mark.parametrize("NH,NKV,HS,rot,base,window,kv_shared,cap", [(16, 8, 256, 0, 1e4, 1024, False, 2048), (16, 1, 512, 128, 1e6, 0, True, 2048),
+                                                                     (4, 2, 64, 0, 1e4, 128, False, 256), (8, 8, 128, 0, 1e4, 0, False, 512)])
+@pytest.mark.parametrize("pos", [3, 200, 1500])
+def test_onepass_attention_equals_attention_plus_combine(NH, NKV, HS, rot, base, window, kv_shared, cap, pos):
+    """split flash-decode whose last-arriving workgroup merges its head-group's partials in the same launch == attention + combine
+    launches, bit for bit, call after call on the SAME scratch with changing queries (a stale partial from the previous call, or
+    a ticket left armed, would show), while another stream keeps the memory system busy"""
+    pos = min(pos, cap - 1)
+    rng = np.random.default_rng(7 * HS + NKV + pos)
+    max_seq = 2048
+    lib = capi.load()
+    splits = lib.mila_cdna4_attn_decode_split_count(1, NH, NKV, HS, cap, window)
+    assert splits > 1
+    Kc0 = torch.from_numpy(orc.to_bf16_bits(rng.uniform(-1, 1, (1, NKV, cap, HS)).astype(np.float32) * 0.5).view(np.int16)).cuda()
+    Vc0 = torch.from_numpy(orc.to_bf16_bits(rng.uniform(-1, 1, (1, NKV, cap, HS)).astype(np.float32)).view(np.int16)).cuda()
+    qw, kw = _d(_bf(1 + 0.1 * rng.uniform(-1, 1, HS))), _d(_bf(1 + 0.1 * rng.uniform(-1, 1, HS)))
+    cos, sin = empty_f32(max_seq, HS // 2), empty_f32(max_seq, HS // 2)
+    capi.call("rope_build_cache", cos, sin, max_seq, HS, float(base), rot)
+    nbytes = lib.mila_cdna4_attn_decode_scratch_bytes(1, NH, HS)
+    scratch0 = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    scratch1 = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    nt = lib.mila_cdna4_attn_decode_ticket_count(1, NH)
+    assert nt >= NH
+    tickets = torch.zeros(nt, dtype=torch.int32, device="cuda")
+    reps = 24
+    qs = [_d(_bf(rng.standard_normal((NH, HS)))) for _ in range(reps)]
+    ks = [_d(_bf(rng.standard_normal((NKV, HS)))) for _ in range(reps)]
+    vs = ks if kv_shared else [_d(_bf(rng.standard_normal((NKV, HS)))) for _ in range(reps)]
+    y0 = [empty_u16(NH * HS) for _ in range(reps)]
+    y1 = [empty_u16(NH * HS) for _ in range(reps)]
+    K0, V0, K1, V1 = Kc0.clone(), Vc0.clone(), Kc0.clone(), Vc0.clone()
+    for i in range(reps):
+        capi.call("fused_attn_decode_bf16", y0[i], K0, V0, qs[i], ks[i], vs[i], qw, kw, None, cos, sin, scratch0, C.c_size_t(nbytes), NH, NKV, HS,
+                  cap, pos, None, window, 1.0, 1e-6)
+    torch.cuda.synchronize()
+    # background load on a second stream while the one-pass launches run back to back
+    side = torch.cuda.Stream()
+    big = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    big2 = torch.empty_like(big)
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            big2.copy_(big)
+    for i in range(reps):
+        capi.call("fused_attn_decode_onepass_bf16", y1[i], K1, V1, qs[i], ks[i], vs[i], qw, kw, None, cos, sin, scratch1, C.c_size_t(nbytes),
+                  tickets, C.c_size_t(nt), NH, NKV, HS, cap, pos, None, window, 1.0, 1e-6)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(K1), bits(K0)) and np.array_equal(bits(V1), bits(V0)), "cache rows differ"
+    for i in range(reps):
+        assert np.array_equal(bits(y1[i]), bits(y0[i])), "one-pass output differs at call %d" % i
+    assert int(tickets.abs().sum().item()) == 0, "a ticket was left armed"
+    # graph-replay form
+    pd = torch.tensor([pos], dtype=torch.int32, device="cuda")
+    y2 = empty_u16(NH * HS)
+    capi.call("fused_attn_decode_onepass_bf16", y2, K1, V1, qs[-1], ks[-1], vs[-1], qw, kw, None, cos, sin, scratch1, C.c_size_t(nbytes),
+              tickets, C.c_size_t(nt), NH, NKV, HS, cap, 0, pd, window, 1.0, 1e-6)
+    assert np.array_equal(bits(y2), bits(y0[-1]))
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("fused_attn_decode_onepass_bf16", y2, K1, V1, qs[0], ks[0], vs[0], qw, kw, None, cos, sin, scratch1, C.c_size_t(nbytes),
+                  tickets, C.c_size_t(1), NH, NKV, HS, cap, pos, None, window, 1.0, 1e-6)
+
+
+def test_prefetch_l3_reads_only():
+    """the Infinity-Cache prefetch touches every 128-byte line of a range and writes nothing"""
+    n = 3 * (1 << 20) + 128 * 5
+    src = torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda")
+    keep = src.clone()
+    sink = torch.zeros(4, dtype=torch.float32, device="cuda")
+    for wgs in (1, 64, 300):
+        capi.call("prefetch_l3", src, C.c_size_t(n), wgs, sink)
+    capi.call("prefetch_l3", src, C.c_size_t(0), 64, sink)
+    torch.cuda.synchronize()
+    assert torch.equal(src, keep) and float(sink.abs().sum()) == 0.0
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("prefetch_l3", src, C.c_size_t(n), 0, sink)

@@ -190,6 +190,29 @@ def test_combine_in_o_proj_gives_the_reference_order_bits(policy):
         g.close()
 
 
+@pytest.mark.parametrize("policy", ["bf16", "fp8", "fp4"])
+def test_onepass_attention_and_prefetch_ahead_give_the_reference_order_bits(policy):
+    """the split configuration again: decode attention in one launch (last-arriver merge) and the side-stream Infinity-Cache
+    prefetch of the next Linear's weights (its own graph branch) change no bit of the logits, eager or replayed"""
+    models = {m: host.Gemma(policy, SPLIT, max_seq=256, max_prefill=1, seed=21) for m in ("reference", "onepass", "onepass-graph", "prefetch", "both-graph")}
+    models["onepass"].set_onepass_attention(True)
+    models["onepass-graph"].set_onepass_attention(True)
+    models["prefetch"].set_prefetch_ahead(1 << 20, 8)
+    models["both-graph"].set_onepass_attention(True)
+    models["both-graph"].set_prefetch_ahead(4 << 20)
+    mode_of = {"onepass": "fused", "onepass-graph": "graph", "prefetch": "fused", "both-graph": "graph"}
+    tok = 9
+    for pos in range(0, 140, 1):
+        check = pos in (0, 1, 63, 64, 65, 127, 128, 139)
+        step = {m: g.decode(tok, pos, mode_of.get(m, m) if (check or m != "reference") else "fused") for m, g in models.items()}
+        if check:
+            for m in mode_of:
+                assert np.array_equal(step["reference"].view(np.uint32), step[m].view(np.uint32)), "%s != reference-order at %d" % (m, pos)
+        tok = (tok * 7 + pos) % 1024
+    for g in models.values():
+        g.close()
+
+
 @pytest.mark.parametrize("cfg_name", ["SMALL", "MEDIUM"])
 def test_chunked_prefill_equals_single_chunk_prefill(cfg_name):
     """a prompt fed as two chunks (the second at position_offset = 16) leaves the same KV caches and produces the same logits as

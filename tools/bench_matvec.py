@@ -24,9 +24,11 @@ def bytes_per_call(fmt, K, N):
     return N * K // 2 + N * (K // 128) * 4
 
 
-def run(fmt, K, N, R, U, iters, lib, max_blocks=0):
+def run(fmt, K, N, R, U, iters, lib, max_blocks=0, hot=False):
     wbytes = bytes_per_call(fmt, K, N)
     nbuf = max(2, min(64, (1 << 30) // wbytes + 1))
+    if hot:   # the same matrix every launch: served from the 256 MiB Infinity Cache when it fits
+        nbuf = 1
     if fmt == 0:
         Ws = [torch.randint(-30000, 30000, (N, K), dtype=torch.int16, device="cuda") for _ in range(nbuf)]
         Ss = [None] * nbuf
@@ -55,18 +57,18 @@ def run(fmt, K, N, R, U, iters, lib, max_blocks=0):
     # capture one pass over all buffers in a graph: device-side timing, no host launch gaps
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        for i in range(nbuf):
+        for i in range(max(nbuf, 8)):
             call(i)
     g.replay()
     torch.cuda.synchronize()
-    reps = max(1, iters // nbuf)
+    reps = max(1, iters // max(nbuf, 8))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
         g.replay()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / (reps * nbuf)
+    us = e0.elapsed_time(e1) * 1e3 / (reps * max(nbuf, 8))
     return us, wbytes / us / 1e3   # GB/s
 
 
@@ -74,6 +76,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--hot", action="store_true", help="also time each shape re-reading ONE matrix (Infinity-Cache resident)")
+    ap.add_argument("--no-ceilings", action="store_true")
     a = ap.parse_args()
     lib = capi.load()
     # ceilings
@@ -81,7 +85,7 @@ def main():
     src = torch.empty(n, dtype=torch.uint8, device="cuda").random_(0, 255)
     dst = torch.empty_like(src)
     sink = torch.zeros(4, device="cuda")
-    for name in ("stream_copy", "stream_read"):
+    for name in (() if a.no_ceilings else ("stream_copy", "stream_read")):
         for _ in range(3):
             if name == "stream_copy":
                 capi.call(name, dst, src, C.c_size_t(n))
@@ -109,6 +113,10 @@ def main():
                 print(json.dumps({"kernel": "matvec", "fmt": ["bf16", "fp8", "fp4"][fmt], "shape": name, "K": K, "N": N,
                                   "R": R, "U": U, "max_blocks": MB, "us": round(us, 2), "GBps": round(gbps, 1),
                                   "frac_of_8TBps": round(gbps / 8000, 3)}), flush=True)
+                if a.hot:
+                    us, gbps = run(fmt, K, N, R, U, a.iters if N < 100000 else 30, lib, MB, hot=True)
+                    print(json.dumps({"kernel": "matvec_hot", "fmt": ["bf16", "fp8", "fp4"][fmt], "shape": name, "K": K, "N": N,
+                                      "R": R, "U": U, "us": round(us, 2), "GBps": round(gbps, 1)}), flush=True)
     lib.mila_cdna4_tune_matvec(0, 0, 0)
 
 
