@@ -4,7 +4,11 @@ bf16 rounding the component chain performs.  Order restated from GemmaBlock::pre
 GemmaTransformer::decode (Gemma.ixx:281-297).  TEST INFRASTRUCTURE ONLY.
 
 Block-level parity is "unpinned" in the reference tree (its Gemma tests assert shapes/finiteness only,
-SURVEY.md section 4); this composition is pinned op-by-op through the oracle's own pins."""
+SURVEY.md section 4); this composition is pinned op-by-op through the oracle's own pins, and as a WHOLE by
+tests/golden/gemma4_hf_logits.npz: with exact=True (no intermediate bf16 rounding) it must reproduce the
+FP32 logits of the transformers Gemma4ForCausalLM -- the implementation the reference validates its own
+checkpoints against (Tools/Converters/Gemma/gemma_4_BF16/hf_gemma_greedy_validation.py) -- on the same
+synthetic weights (tests/golden/make_gemma4_hf_golden.py, tests/test_oracle_kats.py)."""
 import numpy as np
 
 import orc
@@ -16,9 +20,10 @@ def bf(x):
 
 
 class RefGemma:
-    def __init__(self, cfg, policy, seed):
+    def __init__(self, cfg, policy, seed, exact=False):
         self.c = dict(cfg)
         self.policy = policy
+        self.exact = exact          # True: keep every intermediate in FP32 (the wiring check against the HF FP32 forward)
         c = self.c
         D, H = c["embedding_dim"], c["hidden_dim"]
         self.layers = []
@@ -58,18 +63,20 @@ class RefGemma:
     def _norm(seed, n):
         return orc.from_bf16_bits(synth.fill_bf16(seed, n, 0.1, 1.0))
 
-    @staticmethod
-    def linear(x, W, round_out=True):
+    def r(self, x):
+        return np.asarray(x, dtype=np.float32) if self.exact else bf(x)
+
+    def linear(self, x, W, round_out=True):
         if W[0] == "bf16":
             y = orc.linear_bf16w(x, W[1])
         elif W[0] == "fp8":
             y = orc.linear_fp8w(x, W[1], W[2])
         else:
             y = orc.linear_fp4w(x, W[1], W[2], 128)
-        return bf(y) if round_out else y
+        return self.r(y) if round_out else y
 
     def rms(self, x, w):
-        return bf(orc.rmsnorm(x, w, None, eps=1e-6))
+        return self.r(orc.rmsnorm(x, w, None, eps=1e-6))
 
     def embed(self, tokens):
         D = self.c["embedding_dim"]
@@ -78,8 +85,8 @@ class RefGemma:
             rows = orc.from_bf16_bits(self.table[1][tokens])
         else:
             q, sc = self.table[1], self.table[2]
-            rows = bf(orc.E4M3_LUT[q[tokens]] * sc[tokens][:, None])
-        return bf(rows * s)
+            rows = self.r(orc.E4M3_LUT[q[tokens]] * sc[tokens][:, None])
+        return self.r(rows * s)
 
     def _rope_cache(self, L, max_seq):
         key = (L["HD"], L["g"])
@@ -99,20 +106,20 @@ class RefGemma:
         qn = self.rms(q, L["q_norm"])
         kn = self.rms(k, L["k_norm"])
         cos, sin = self._rope_cache(L, max_seq)
-        qr = bf(orc.rope_rotate(qn[None], cos, sin, pos))[0]
-        kr = bf(orc.rope_rotate(kn[None], cos, sin, pos))[0]
+        qr = self.r(orc.rope_rotate(qn[None], cos, sin, pos))[0]
+        kr = self.r(orc.rope_rotate(kn[None], cos, sin, pos))[0]
         vn = self.rms(v, np.ones(HD, np.float32))
         L["K"] = np.concatenate([L["K"][:, :pos], kr[None]], axis=1)
         L["V"] = np.concatenate([L["V"][:, :pos], vn[None]], axis=1)
         window = 0 if L["g"] else self.c["window"]
-        attn = bf(orc.gqa_attention(qr[None], L["K"], L["V"], pos, window, 1.0))[0]
+        attn = self.r(orc.gqa_attention(qr[None], L["K"], L["V"], pos, window, 1.0))[0]
         o = self.linear(attn, L["o"])
-        res1 = bf(x + self.rms(o, L["post_attn"]))
+        res1 = self.r(x + self.rms(o, L["post_attn"]))
         gu = self.linear(self.rms(res1, L["pre_ffn"]), L["gu"])
-        act = bf(orc.geglu(gu))
+        act = self.r(orc.geglu(gu))
         dn = self.linear(act, L["down"])
-        res2 = bf(res1 + self.rms(dn, L["post_ffn"]))
-        return bf(res2 * np.float32(1.0))
+        res2 = self.r(res1 + self.rms(dn, L["post_ffn"]))
+        return self.r(res2 * np.float32(1.0))
 
     def forward(self, tokens, pos, max_seq):
         x = self.embed(np.asarray(tokens, dtype=np.int64))
