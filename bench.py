@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--onepass", type=int, default=None, help="1/0: split decode attention in one launch / with a combine launch (default: the model's)")
     ap.add_argument("--prefetch-mb", type=float, default=None, help="side-stream Infinity-Cache prefetch cap per Linear in MB (0 = off; default: the model's)")
     ap.add_argument("--prefetch-wgs", type=int, default=64)
+    ap.add_argument("--warm", default=None, help="blocks_a,cap_a_MB,blocks_b,cap_b_MB: warm-ahead workgroups of the attention / combine launches")
     a = ap.parse_args()
 
     import torch
@@ -119,6 +120,9 @@ def main():
             m.set_onepass_attention(a.onepass)
         if a.prefetch_mb is not None:
             m.set_prefetch_ahead(int(a.prefetch_mb * 1e6), a.prefetch_wgs)
+        if a.warm is not None:
+            wa, ca, wb, cb = [float(v) for v in a.warm.split(",")]
+            m.set_warm_ahead(int(wa), int(ca * 1e6), int(wb), int(cb * 1e6))
         info = m.info(CONTEXT)
         r = {"weight_GB": round(info["weight_bytes"] / 1e9, 3), "bytes_per_token_GB": round(info["decode_bytes_per_token"] / 1e9, 3)}
         if not a.no_prefill:

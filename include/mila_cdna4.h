@@ -453,6 +453,27 @@ MILA_API int mila_cdna4_fused_attn_decode_onepass_bf16(uint16_t* Y, uint16_t* Kc
  * never written in practice).  No reference counterpart (a 12 GB card has no memory-side cache to warm); results are unaffected. */
 MILA_API int mila_cdna4_prefetch_l3(const void* src, size_t bytes, int workgroups, float* sink, mila_stream_t stream);
 
+/* fused_attn_decode_bf16 from an argument block (tickets != NULL: the one-pass form), with optional WARM RANGES: warm_a_blocks
+ * extra workgroups per grid row of the attention launch and warm_b_blocks extra block planes of the combine launch touch one dword
+ * per 128-byte line of warm_a / warm_b (weights a later Linear of the step will stream), so the 256 MiB Infinity Cache fills
+ * while these latency-bound launches leave HBM idle.  The warm blocks only read; the attention result is bit-identical. */
+typedef struct mila_fused_attn_args {
+    uint16_t* Y; uint16_t* Kc; uint16_t* Vc;
+    const uint16_t* q_raw; const uint16_t* k_raw; const uint16_t* v_raw;
+    const uint16_t* qw; const uint16_t* kw; const uint16_t* vw;
+    const float* cos_cache; const float* sin_cache;
+    void* scratch; size_t scratch_bytes;
+    uint32_t* tickets; size_t ticket_count;         /* NULL / 0: attention + combine launches */
+    const void* warm_a; size_t warm_a_bytes; int warm_a_blocks;
+    const void* warm_b; size_t warm_b_bytes; int warm_b_blocks;
+    size_t warm_b_pair_offset;                      /* != 0: warm_b is the head of TWO streams this many bytes apart (gate | up), warm_b_bytes in all */
+    int NH, NKV, HS, capacity, position;
+    const int32_t* position_dev;
+    int window;
+    float scale, eps;
+} mila_fused_attn_args;
+MILA_API int mila_cdna4_fused_attn_decode_ex(const mila_fused_attn_args* host_args, mila_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,10 @@ struct AttnParams
     uint16_t* V;
     float* scratch;           // [B, NH, splits, HS+4] partials when splits > 1: O (HS) | m | l | pad (rows stay 16-byte aligned)
     int no_combine;           // leave the partials for the consumer (matvec_attn_combine) instead of launching the combine
+    // warm ranges: extra workgroups of the attention launch (warm_a) and of the combine launch (warm_b) touch one dword per 128-byte
+    // line of weights a LATER kernel streams, so the Infinity Cache fills while these latency-bound launches leave HBM idle
+    const uint8_t* warm_a; int64_t warm_a_lines; int warm_a_blocks;   // blocks per grid row (blockIdx.x >= splits)
+    const uint8_t* warm_b; int64_t warm_b_lines; int warm_b_blocks; int64_t warm_b_pair;
     uint32_t* tickets;        // one-pass form: arrival counters [B, NKV * head-groups], zero between launches; the workgroup whose
                               // partials arrive last combines its head-group's splits itself, so there is no combine launch
     int NH, NKV, capacity, position, window, splits;
@@ -164,6 +168,27 @@ __device__ __forceinline__ void partial_st_sc1(float* p, float v)
     __hip_atomic_store((__attribute__((address_space(1))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// one dword per 128-byte line of [base, base + 128 nlines), lines strided over `nthreads` threads; nothing is written
+// pair != 0: the range is the head of TWO streams `pair` bytes apart (the gate and up halves the fused gate_up kernel reads in
+// lockstep): line i is line i / 2 of stream i % 2
+__device__ __forceinline__ void warm_lines(const uint8_t* __restrict__ base, int64_t nlines, int64_t tid, int64_t nthreads, float* never,
+                                           int64_t pair = 0)
+{
+    uint32_t acc = 0;
+    int64_t i = tid;
+    auto at = [&](int64_t l) { return pair ? base + (l & 1) * pair + (l >> 1) * 128 : base + l * 128; };
+    for (; i + 7 * nthreads < nlines; i += 8 * nthreads)
+    {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint32_t*>(at(i + u * nthreads));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= v[u];
+    }
+    for (; i < nlines; i += nthreads) acc ^= *reinterpret_cast<const uint32_t*>(at(i));
+    if (acc == 0x12345679u && never != nullptr) never[0] = 1.0f;   // keeps the loads alive; never true in practice
+}
+
 // HS = 64 * EPL (EPL in {2,4,8}) or HS = 64 handled as EPL = 2 on 32 active lanes.
 // GH = query heads per workgroup; grid = (splits, NKV * GS/GH, B); 8 waves, wave w owns positions
 // begin + w + 8 j of the split.  FUSED: the q/k/v post-processing of the token is done in the prologue,
@@ -183,6 +208,13 @@ __global__ __launch_bounds__(kDecodeWaves * 64) void attn_decode_kernel(const At
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool owner = lane < ACTIVE;
     const int GS = p.NH / p.NKV, hgroups = GS / GH;
+    if ((int)blockIdx.x >= p.splits)                        // a warm block (block-uniform): no barrier is shared with the others
+    {
+        const int64_t wb = ((int64_t)(blockIdx.x - p.splits) * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
+        warm_lines(p.warm_a, p.warm_a_lines, wb * (NW * 64) + threadIdx.x, (int64_t)p.warm_a_blocks * gridDim.y * gridDim.z * (NW * 64),
+                   p.scratch);
+        return;
+    }
     const int split = blockIdx.x, kvh = blockIdx.y / hgroups, hg = blockIdx.y % hgroups;
     const int h0 = kvh * GS + hg * GH;                     // first query head of this workgroup
     const int b = blockIdx.z;
@@ -463,9 +495,15 @@ __global__ __launch_bounds__(kDecodeWaves * 64) void attn_decode_kernel(const At
 // Every thread reads all (m, l) pairs itself (broadcast loads) and all partial values of its dim in
 // unrolled batches, so the kernel is two dependent memory round trips long.
 __global__ __launch_bounds__(64) void attn_combine_kernel(uint16_t* __restrict__ Y, const float* __restrict__ scratch, int NH,
-                                                          int HS, int splits)
+                                                          int HS, int splits, const uint8_t* __restrict__ warm, int64_t warm_lines_n, int64_t warm_pair)
 {
     const int h = blockIdx.x, b = blockIdx.y;
+    if ((int)blockIdx.z >= HS / 64)                         // warm blocks (see AttnParams::warm_b)
+    {
+        const int64_t wb = ((int64_t)(blockIdx.z - HS / 64) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        warm_lines(warm, warm_lines_n, wb * 64 + threadIdx.x, (int64_t)(gridDim.z - HS / 64) * gridDim.y * gridDim.x * 64, nullptr, warm_pair);
+        return;
+    }
     const int d = blockIdx.z * 64 + threadIdx.x;
     const float* base = scratch + ((size_t)b * NH + h) * splits * (HS + 4);
     Y[((size_t)b * NH + h) * HS + d] = combine_dim<false>(base, HS, splits, d);
@@ -478,12 +516,15 @@ static int launch_decode(const AttnParams& p, int B, hipStream_t s)
 {
     const int hgroups = (p.NH / p.NKV) / GH;
     const size_t lds = (size_t)kDecodeWaves * GH * (HS + 2) * sizeof(float) + (size_t)(GH + 2) * HS * 2;
-    hipLaunchKernelGGL((attn_decode_kernel<HS, GH, FUSED>), dim3(p.splits, p.NKV * hgroups, B), dim3(kDecodeWaves * 64), lds, s, p);
+    const int wa = (p.warm_a && p.warm_a_lines > 0) ? p.warm_a_blocks : 0;
+    hipLaunchKernelGGL((attn_decode_kernel<HS, GH, FUSED>), dim3(p.splits + wa, p.NKV * hgroups, B), dim3(kDecodeWaves * 64), lds, s, p);
     int rc = check_hip(hipGetLastError(), "attn_decode");
     if (rc) return rc;
     if (p.splits > 1 && !p.no_combine && !p.tickets)
     {
-        hipLaunchKernelGGL(attn_combine_kernel, dim3(p.NH, B, HS / 64), dim3(64), 0, s, p.Y, p.scratch, p.NH, HS, p.splits);
+        const int wbk = (p.warm_b && p.warm_b_lines > 0) ? p.warm_b_blocks : 0;
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(p.NH, B, HS / 64 + wbk), dim3(64), 0, s, p.Y, p.scratch, p.NH, HS, p.splits, p.warm_b,
+                           p.warm_b_lines, p.warm_b_pair);
         rc = check_hip(hipGetLastError(), "attn_combine");
     }
     return rc;
@@ -697,6 +738,33 @@ int mila_cdna4_fused_attn_decode_onepass_bf16(uint16_t* Y, uint16_t* Kc, uint16_
     f.tickets = tickets;
     return run_decode(Y, nullptr, Kc, Vc, scratch, scratch_bytes, 1, NH, NKV, HS, capacity, position, position_dev, window, scale, &f,
                       "fused_attn_decode_onepass_bf16", as_stream(stream));
+}
+
+// fused_attn_decode_bf16 (or, with tickets, fused_attn_decode_onepass_bf16) from an argument block, with optional warm ranges
+int mila_cdna4_fused_attn_decode_ex(const mila_fused_attn_args* a, mila_stream_t stream)
+{
+    MILA_REQUIRE(a != nullptr, "fused_attn_decode_ex: null arguments");
+    MILA_REQUIRE(a->Y && a->Kc && a->Vc && a->q_raw && a->k_raw && a->v_raw && a->qw && a->kw && a->cos_cache && a->sin_cache, "fused_attn_decode_ex: null pointer");
+    MILA_REQUIRE(a->NH > 0 && a->NKV > 0 && a->NH % a->NKV == 0, "fused_attn_decode_ex: bad head counts (NH=%d NKV=%d)", a->NH, a->NKV);
+    MILA_REQUIRE(a->capacity > 0 && a->window >= 0 && (a->position_dev || a->position >= 0), "fused_attn_decode_ex: bad sizes");
+    MILA_REQUIRE(a->HS % 16 == 0, "fused_attn_decode_ex: HS=%d must be a multiple of 16", a->HS);
+    MILA_REQUIRE(a->warm_a_blocks >= 0 && a->warm_a_blocks <= 64 && a->warm_b_blocks >= 0 && a->warm_b_blocks <= 64, "fused_attn_decode_ex: warm block counts must be in [0, 64]");
+    if (a->tickets)
+        MILA_REQUIRE(a->ticket_count >= mila_cdna4_attn_decode_ticket_count(1, a->NH), "fused_attn_decode_ex: %zu tickets < required %zu",
+                     a->ticket_count, mila_cdna4_attn_decode_ticket_count(1, a->NH));
+    if (!a->position_dev)
+    {
+        const int len = a->position + 1, band = (a->window > 0 && a->window < len) ? a->window : len;
+        MILA_REQUIRE(band <= a->capacity, "fused_attn_decode_ex: live band %d exceeds the cache capacity %d", band, a->capacity);
+    }
+    AttnParams f{};
+    f.q_raw = a->q_raw; f.k_raw = a->k_raw; f.v_raw = a->v_raw; f.qw = a->qw; f.kw = a->kw; f.vw = a->vw; f.cos_cache = a->cos_cache; f.sin_cache = a->sin_cache;
+    f.eps = a->eps;
+    f.tickets = a->tickets;
+    if (a->warm_a && a->warm_a_bytes >= 128 && a->warm_a_blocks > 0) { f.warm_a = (const uint8_t*)a->warm_a; f.warm_a_lines = (int64_t)(a->warm_a_bytes / 128); f.warm_a_blocks = a->warm_a_blocks; }
+    if (a->warm_b && a->warm_b_bytes >= 128 && a->warm_b_blocks > 0) { f.warm_b = (const uint8_t*)a->warm_b; f.warm_b_lines = (int64_t)(a->warm_b_bytes / 128); f.warm_b_blocks = a->warm_b_blocks; f.warm_b_pair = (int64_t)a->warm_b_pair_offset; }
+    return run_decode(a->Y, nullptr, a->Kc, a->Vc, a->scratch, a->scratch_bytes, 1, a->NH, a->NKV, a->HS, a->capacity, a->position, a->position_dev, a->window,
+                      a->scale, &f, "fused_attn_decode_ex", as_stream(stream));
 }
 
 }  // extern "C"

@@ -50,6 +50,7 @@ def load():
         _lib.mila_gemma_set_combine_in_oproj.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_set_fused_prefill.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_set_onepass_attention.argtypes = [C.c_void_p, C.c_int]
+        _lib.mila_gemma_set_warm_ahead.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64]
         _lib.mila_gemma_set_prefetch_ahead.argtypes = [C.c_void_p, C.c_int64, C.c_int]
         _lib.mila_gpt_last_error.restype = C.c_char_p
         _lib.mila_gpt_create.restype = C.c_void_p
@@ -116,6 +117,11 @@ class Gemma:
         """fused / graph decode: split decode attention in ONE launch (the workgroup whose partials arrive last merges its
         head-group's splits) instead of attention + combine launches; identical bits"""
         _check(load().mila_gemma_set_onepass_attention(self.h, int(bool(on))))
+
+    def set_warm_ahead(self, blocks_a, cap_a, blocks_b, cap_b):
+        """fused / graph decode: extra workgroups of the attention (a) and combine (b) launches touch the lines of o_proj (cap_a
+        bytes) and of the heads of fc_gate_up's halves (cap_b bytes), so those Linears start from the Infinity Cache; same bits"""
+        _check(load().mila_gemma_set_warm_ahead(self.h, int(blocks_a), int(cap_a), int(blocks_b), int(cap_b)))
 
     def set_prefetch_ahead(self, cap_bytes, workgroups=64):
         """fused / graph decode: a side stream warms the Infinity Cache with the first cap_bytes of the next Linear's weights

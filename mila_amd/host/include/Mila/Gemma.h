@@ -679,7 +679,23 @@ namespace Mila::Dnn
                 else
                 {
                     prefetchLinear( *L.o_proj ); prefetchLinear( *L.fc_gate_up, true );   // beside the latency-bound attention launches
-                    if ( onepass_attn_ )
+                    if ( warm_a_blocks_ > 0 || warm_b_blocks_ > 0 )
+                    {
+                        mila_fused_attn_args a{};
+                        a.Y = attn_out_->data(); a.Kc = L.attn->keyCache(); a.Vc = L.attn->valueCache(); a.q_raw = qp; a.k_raw = kp; a.v_raw = vp;
+                        a.qw = L.q_norm->getWeight()->data(); a.kw = L.k_norm->getWeight()->data(); a.vw = L.v_norm->getWeight()->data();
+                        a.cos_cache = L.rope->cosCache(); a.sin_cache = L.rope->sinCache(); a.scratch = scratch; a.scratch_bytes = need;
+                        if ( onepass_attn_ ) { a.tickets = reinterpret_cast<uint32_t*>( tickets_->data() ); a.ticket_count = (size_t)tickets_->size(); }
+                        // the attention launch warms o_proj, the combine launch the heads of fc_gate_up's gate and up halves
+                        a.warm_a = L.o_proj->getWeight().rawData(); a.warm_a_bytes = std::min( L.o_proj->getWeight().sizeInBytes(), warm_a_cap_ ); a.warm_a_blocks = warm_a_blocks_;
+                        const size_t gub = L.fc_gate_up->getWeight().sizeInBytes();
+                        a.warm_b = L.fc_gate_up->getWeight().rawData(); a.warm_b_bytes = std::min( gub, warm_b_cap_ ) / 256 * 256; a.warm_b_blocks = warm_b_blocks_;
+                        a.warm_b_pair_offset = gub / 2;
+                        a.NH = NH; a.NKV = NKV; a.HS = HD; a.capacity = (int)L.attn->cacheCapacity(); a.position = position; a.position_dev = pos_dev;
+                        a.window = (int)cfg_.windowFor( g ); a.scale = L.attn->scale(); a.eps = cfg_.rms_norm_eps;
+                        Compute::rocmCheck( mila_cdna4_fused_attn_decode_ex( &a, st ) );
+                    }
+                    else if ( onepass_attn_ )
                         Compute::rocmCheck( mila_cdna4_fused_attn_decode_onepass_bf16( attn_out_->data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp,
                                                                                        L.q_norm->getWeight()->data(), L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(),
                                                                                        L.rope->cosCache(), L.rope->sinCache(), scratch, need,
@@ -822,6 +838,14 @@ namespace Mila::Dnn
             if ( graph_exec_ ) throw std::runtime_error( "GemmaTransformer::setOnepassAttention: the graph is already captured" );
             onepass_attn_ = on;
         }
+        /// extra workgroups of the latency-bound attention (a) and combine (b) launches touch the lines of o_proj (up to cap_a bytes)
+        /// and of the heads of fc_gate_up's two halves (cap_b bytes in all): the following Linears start from the Infinity Cache
+        void setWarmAhead( int blocks_a, size_t cap_a, int blocks_b, size_t cap_b )
+        {
+            if ( graph_exec_ ) throw std::runtime_error( "GemmaTransformer::setWarmAhead: the graph is already captured" );
+            if ( blocks_a < 0 || blocks_a > 64 || blocks_b < 0 || blocks_b > 64 ) throw std::invalid_argument( "GemmaTransformer::setWarmAhead: block counts must be in [0, 64]" );
+            warm_a_blocks_ = blocks_a; warm_a_cap_ = cap_a; warm_b_blocks_ = blocks_b; warm_b_cap_ = cap_b;
+        }
         /// cap_bytes > 0: while one decode kernel runs, a side stream pulls the first cap_bytes of the NEXT Linear's weights into the
         /// 256 MiB Infinity Cache (mila_cdna4_prefetch_l3), so that the memory system works through kernel ramps, tails and the
         /// latency-bound attention launches; 0 = off.  Results are unaffected (the prefetch only reads).
@@ -926,6 +950,8 @@ namespace Mila::Dnn
         bool use_chain_{ false };
         bool combine_in_oproj_{ false };   // measured slower on MI355X (bf16 222 -> 217, fp4 415 -> 396 tok/s): opt-in, DESIGN.md section 5
         bool fused_prefill_{ true };
+        int warm_a_blocks_{ 0 }, warm_b_blocks_{ 0 };       // extra workgroups of the attention / combine launches that warm the Infinity Cache
+        size_t warm_a_cap_{ 0 }, warm_b_cap_{ 0 };
         bool onepass_attn_{ false };       // split decode attention without the combine launch (last-arriver merge in the same launch)
         size_t prefetch_cap_{ 0 };         // > 0: side-stream Infinity-Cache prefetch of the next Linear's weights, at most this many bytes each
         int prefetch_wgs_{ 64 };

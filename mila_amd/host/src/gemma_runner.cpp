@@ -144,6 +144,12 @@ HOST_API int mila_gemma_set_onepass_attention( void* h, int on )
     auto* r = static_cast<Runner*>( h );
     return guarded( [&] { std::visit( [&]( auto& m ) { m->setOnepassAttention( on != 0 ); }, r->model ); } );
 }
+/// extra workgroups of the attention / combine launches warm the Infinity Cache with o_proj / the head of fc_gate_up (0 blocks = off)
+HOST_API int mila_gemma_set_warm_ahead( void* h, int blocks_a, int64_t cap_a, int blocks_b, int64_t cap_b )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&] { std::visit( [&]( auto& m ) { m->setWarmAhead( blocks_a, (size_t)std::max<int64_t>( cap_a, 0 ), blocks_b, (size_t)std::max<int64_t>( cap_b, 0 ) ); }, r->model ); } );
+}
 /// cap_bytes > 0: side-stream Infinity-Cache prefetch of the next Linear's weights (at most cap_bytes each) beside the running
 /// decode kernel; 0 = off.  Call before the first graph-mode decode.
 HOST_API int mila_gemma_set_prefetch_ahead( void* h, int64_t cap_bytes, int workgroups )

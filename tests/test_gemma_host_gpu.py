@@ -227,7 +227,12 @@ def test_onepass_attention_and_prefetch_ahead_give_the_reference_order_bits(poli
     models["prefetch"].set_prefetch_ahead(1 << 20, 8)
     models["both-graph"].set_onepass_attention(True)
     models["both-graph"].set_prefetch_ahead(4 << 20)
-    mode_of = {"onepass": "fused", "onepass-graph": "graph", "prefetch": "fused", "both-graph": "graph"}
+    models["warm-graph"] = host.Gemma(policy, SPLIT, max_seq=256, max_prefill=1, seed=21)
+    models["warm-graph"].set_warm_ahead(4, 1 << 20, 3, 3 << 20)        # warm blocks inside the attention and combine launches
+    models["warm-onepass"] = host.Gemma(policy, SPLIT, max_seq=256, max_prefill=1, seed=21)
+    models["warm-onepass"].set_warm_ahead(2, 64 << 20, 0, 0)
+    models["warm-onepass"].set_onepass_attention(True)
+    mode_of = {"onepass": "fused", "onepass-graph": "graph", "prefetch": "fused", "both-graph": "graph", "warm-graph": "graph", "warm-onepass": "fused"}
     tok = 9
     for pos in range(0, 140, 1):
         check = pos in (0, 1, 63, 64, 65, 127, 128, 139)
