@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--onepass", type=int, default=None, help="1/0: split decode attention in one launch / with a combine launch (default: the model's)")
     ap.add_argument("--prefetch-mb", type=float, default=None, help="side-stream Infinity-Cache prefetch cap per Linear in MB (0 = off; default: the model's)")
     ap.add_argument("--prefetch-wgs", type=int, default=64)
+    ap.add_argument("--gemm-schedule", type=int, default=None, help="tuning hook: 0 lockstep, 1 ping-pong (4 phases), 3 ping-pong (2 phases, default)")
     ap.add_argument("--warm", default=None, help="blocks_a,cap_a_MB,blocks_b,cap_b_MB: warm-ahead workgroups of the attention / combine launches")
     a = ap.parse_args()
 
@@ -111,6 +112,8 @@ def main():
     from mila_amd import capi, host
     capi.load()
     capi.check(capi.load().mila_cdna4_set_device(local_rank))
+    if a.gemm_schedule is not None:
+        capi.load().mila_cdna4_tune_gemm_schedule(a.gemm_schedule)
     cfg = dict(host.GEMMA4_12B)
     policies = [p for p in a.policies.split(",") if p]
     results = {}

@@ -143,22 +143,29 @@ __device__ __forceinline__ uint16_t combine_dim(const float* __restrict__ base, 
 {
     const int STR = HS + 4;
     const int s = threadIdx.x & 63;
+    // every load of the first 16 splits is requested before anything is reduced: ONE memory round trip for splits <= 16
+    float vals[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) vals[u] = (u < splits) ? partial_ld<SC1>(base + (size_t)u * STR + d) : 0.0f;
     const float ms = (s < splits) ? partial_ld<SC1>(base + (size_t)s * STR + HS) : -INFINITY;
     const float ls = (s < splits) ? partial_ld<SC1>(base + (size_t)s * STR + HS + 1) : 0.0f;
     float acc = 0.0f;
-    float vals[8];
     const float M = wave_max(ms);
     const float fs = (ms == -INFINITY) ? 0.0f : __expf(ms - M);
     const float L = wave_sum(ls * fs);
-    for (int i0 = 0; i0 < splits; i0 += 8)
+    const int n8 = (splits + 7) & ~7;                      // the fma chain runs over whole batches of 8 (zeros past the last split)
+    for (int i0 = 0; i0 < n8; i0 += 16)
     {
+        if (i0 > 0)
+        {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) vals[u] = (i0 + u < splits) ? partial_ld<SC1>(base + (size_t)(i0 + u) * STR + d) : 0.0f;
+            for (int u = 0; u < 16; ++u) vals[u] = (i0 + u < splits) ? partial_ld<SC1>(base + (size_t)(i0 + u) * STR + d) : 0.0f;
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
         {
             const float f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fs), min(i0 + u, 63)));
-            acc = fmaf(vals[u], f, acc);
+            if (i0 + u < n8) acc = fmaf(vals[u], f, acc);
         }
     }
     return f32_to_bf16_bits(L > 0.0f ? acc / L : 0.0f);
@@ -472,7 +479,9 @@ __global__ __launch_bounds__(kDecodeWaves * 64) void attn_decode_kernel(const At
         uint32_t* tk = p.tickets + (size_t)b * gridDim.y + blockIdx.y;
         if (threadIdx.x == 0)
         {
-            const uint32_t t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // acquire-release at agent scope on top of the drained write-through stores and the sc1 loads: the hand-off then
+            // holds by the memory model too, not only by the measured behaviour of the sc1 forms (this path is not the fast one)
+            const uint32_t t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (t == (uint32_t)(p.splits - 1));
             if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = last;

@@ -271,11 +271,13 @@ int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const 
 bool gemm256_geglu_applicable(int M, int K, int F);
 int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s);
 static int g_gemm_force128 = 0;
+extern int g_gemm_pingpong;     // gemm256.hip
 
 // which direct-to-LDS kernel serves a bf16-weight GEMM of this shape: 2 = 256 x 256, 1 = 256 x 128, 0 = none (128 x 128 register-staged)
 static int glds_kernel_for(int M, int K, int N)
 {
     if (g_gemm_force128) return 0;
+    if (g_gemm_pingpong == 2 && gemm256x128_applicable(M, K, N)) return 1;      // tuning: the 256 x 128 ring wherever it applies
     if (gemm256_applicable(M, K, N)) return 2;
     if (gemm256x128_applicable(M, K, N)) return 1;
     return 0;
@@ -394,6 +396,12 @@ extern "C" {
 int mila_cdna4_tune_gemm(int force_128_tile)
 {
     g_gemm_force128 = force_128_tile;
+    return MILA_OK;
+}
+
+int mila_cdna4_tune_gemm_schedule(int pingpong)
+{
+    g_gemm_pingpong = pingpong;
     return MILA_OK;
 }
 

@@ -47,7 +47,35 @@ __device__ __forceinline__ int half_off(bool isX, int half) { return (isX ? 2 * 
 // v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) per 16 x 16 sub-tile and K-tile instead of two 16x16x32 bf16 MFMAs
 // over half the K: twice the FLOPs per LDS byte and per barrier.  Lane l supplies row l & 15 and the 32 bytes
 // k = 32 (l >> 4) .. + 31 of both operands (selftest_mfma_fp8 pins that layout).
-template <int MODE>
+// tile index -> (tm, tn) in GROUPED order: groups of up to 8 row-blocks, tm fastest inside a group.  After the XCD remap the 32
+// workgroups an XCD runs together are then 8 row-blocks x 4 column-blocks (12 distinct operand blocks per K-step through its L2
+// instead of 1 + 32), and across the launch every XCD streams 1/8 of W instead of all of it.
+__device__ __forceinline__ void grouped_tile(int tile, int tiles_m, int tiles_n, int& tm, int& tn)
+{
+    constexpr int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int grp = tile / per_group, in = tile - grp * per_group;
+    const int gm = min(GM, tiles_m - grp * GM);
+    tm = grp * GM + in % gm;
+    tn = in / gm;
+}
+
+// PP (ping-pong): waves 4-7 run one barrier behind waves 0-3 and every phase has TWO barriers, [stage + fragment reads + waits] | A |
+// [16 MFMAs] | B |, so that while one wave of a SIMD multiplies, the other one reads its fragments and issues the staging: LDS
+// reads (28 ds_read_b128 per wave and K-tile, as many LDS cycles per CU as a SIMD has MFMA cycles) leave the critical path.
+// Hazards under the stagger (phases p of both groups; group 1's phase p runs half a phase later):
+//   RAW  a half-tile staged in phase ps is waited for by every wave at the end of its reads of phase ps + 3 (vmcnt(6)) and
+//        read from phase ps + 4 on -- behind barrier B(ps + 3) of group 0 = A(ps + 3) of group 1, which all eight waves reach
+//        only after that wait;
+//   WAR  a slot is restaged >= 2 phases after its last read, except X0 (read in ph3, restaged in ph0 of the next K-tile): every
+//        wave retires its own fragment reads (lgkmcnt(0)) BEFORE barrier A of the reading phase, and group 0's ph0 staging is
+//        issued behind its barrier B(ph3) = group 1's A(ph3).
+//
+// PP == 2: the same stagger with TWO phases per K-tile (32 MFMAs per slot, half the barriers, 24 fragment reads per K-tile: the
+// fragments of both X halves stay live).  Phase A(t): stage W1(t+1); read W0, X0, X1 of t; quadrants (0,0) (0,1).
+// Phase B(t): stage W0, X0, X1 of t+2; read W1 of t; quadrants (1,0) (1,1).  vmcnt(8) = the stages of the two youngest phases stay
+// in flight; every slot is restaged one phase after its last read (lgkmcnt(0) before barrier A) and read one phase after its wait.
+template <int MODE, int PP>
 __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 {
     constexpr bool GEGLU = (MODE == G_GEGLU || MODE == G_FP8_GEGLU);
@@ -59,7 +87,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     const int nwg = gridDim.x, id = blockIdx.x;
     const int xcd = id & 7, qd = nwg >> 3, rem = nwg & 7;
     const int tile = ((xcd < rem) ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (id >> 3);
-    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    int tm, tn;
+    grouped_tile(tile, p.tiles_m, p.tiles_n, tm, tn);
     const int m0 = tm * 256, n0 = tn * (GEGLU ? 128 : 256);
     const int wrow1 = GEGLU ? p.N + n0 : n0 + 128;      // first W row of half-tile 1
 
@@ -98,7 +127,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     // fragment registers: bf16 = [ks] halves of 16 B (k slots 4 ks + g); fp8 = the two 16-B slots 2 g, 2 g + 1 of one 32-byte operand
-    s16x8 fa[4][2], fb[2][2];
+    s16x8 fa[4][2], fb[2][2], fb1[PP == 2 ? 2 : 1][2];
     auto frag_slot = [&](int ks) { return FP8 ? (2 * g + ks) : (ks * 4 + g); };
     auto load_a = [&](int kt, int hA) {
         const unsigned char* hb = smem + (kt & 1) * kBufBytes + half_off(false, hA);
@@ -119,10 +148,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
             const int r = wc * 32 + qt * 16 + l15;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                fb[qt][ks] = *reinterpret_cast<const s16x8*>(hb + r * 128 + ((frag_slot(ks) ^ ((r >> 1) & 7)) << 4));
+            {
+                const s16x8 v = *reinterpret_cast<const s16x8*>(hb + r * 128 + ((frag_slot(ks) ^ ((r >> 1) & 7)) << 4));
+                if (PP == 2 && hB == 1) fb1[PP == 2 ? qt : 0][ks] = v;
+                else fb[qt][ks] = v;
+            }
         }
     };
     auto mma = [&](int hA, int hB) {
+        s16x8 (&fbx)[2][2] = *((PP == 2 && hB == 1) ? reinterpret_cast<s16x8 (*)[2][2]>(&fb1) : &fb);
         __builtin_amdgcn_s_setprio(1);
         if constexpr (FP8)
         {
@@ -133,7 +167,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 {
                     struct Pair { s16x8 lo, hi; };
                     const i32x8 a8 = __builtin_bit_cast(i32x8, (Pair{fa[pt][0], fa[pt][1]}));
-                    const i32x8 b8 = __builtin_bit_cast(i32x8, (Pair{fb[qt][0], fb[qt][1]}));
+                    const i32x8 b8 = __builtin_bit_cast(i32x8, (Pair{fbx[qt][0], fbx[qt][1]}));
                     acc[hA][hB][pt][qt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[hA][hB][pt][qt], 0, 0, 0, 127, 0, 127);
                 }
         }
@@ -146,7 +180,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 #pragma unroll
                     for (int qt = 0; qt < 2; ++qt)
                         acc[hA][hB][pt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, fa[pt][ks]), __builtin_bit_cast(bf16x8, fb[qt][ks]), acc[hA][hB][pt][qt], 0, 0, 0);
+                            __builtin_bit_cast(bf16x8, fa[pt][ks]), __builtin_bit_cast(bf16x8, fbx[qt][ks]), acc[hA][hB][pt][qt], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -157,45 +191,127 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
         __builtin_amdgcn_s_barrier();
     };
 
-    // ---- prologue: K-tile 0 complete, W0 / X1 of K-tile 1 in flight ----
+    // ---- prologue: K-tile 0 complete, W0 / X1 of K-tile 1 in flight (PP == 2: W0 / X0 / X1 of K-tile 1) ----
     stage(0, false, 0); stage(0, true, 0); stage(0, true, 1); stage(0, false, 1);
-    if (nk > 1) { stage(1, false, 0); stage(1, true, 1); }
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (nk > 1) { stage(1, false, 0); if constexpr (PP == 2) stage(1, true, 0); stage(1, true, 1); }
+    if (nk > 1) { if constexpr (PP == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    for (int t = 0; t < nk; ++t)
+    if constexpr (PP == 2)
     {
-        const bool steady = t + 2 < nk;                    // the full issue sequence is still running
-        // ph0: quadrant (0,0)
-        if (t + 1 < nk) stage(t + 1, true, 0);
-        load_b(t, 0);
-        load_a(t, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0, 0);
-        phase_end(steady);
-        // ph1: quadrant (0,1)
-        if (t + 1 < nk) stage(t + 1, false, 1);
-        load_b(t, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0, 1);
-        phase_end(steady);
-        // ph2: quadrant (1,1)
-        if (t + 2 < nk) stage(t + 2, false, 0);
-        load_a(t, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1, 1);
-        phase_end(steady);
-        // ph3: quadrant (1,0)
-        if (t + 2 < nk) stage(t + 2, true, 1);
-        load_b(t, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1, 0);
-        phase_end(steady);
+        auto reads_end = [&](bool steady) {
+            if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mma_end = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nk; ++t)
+        {
+            const bool steady = t + 2 < nk;
+            // phase A: quadrants (0,0) (0,1)
+            if (t + 1 < nk) stage(t + 1, false, 1);
+            load_a(t, 0);
+            load_b(t, 0);
+            load_b(t, 1);
+            reads_end(steady);
+            mma(0, 0);
+            mma(0, 1);
+            mma_end();
+            // phase B: quadrants (1,0) (1,1)
+            if (t + 2 < nk) { stage(t + 2, false, 0); stage(t + 2, true, 0); stage(t + 2, true, 1); }
+            load_a(t, 1);
+            reads_end(steady);
+            mma(1, 0);
+            mma(1, 1);
+            mma_end();
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+    }
+    else if constexpr (PP == 1)
+    {
+        // reads of a phase end with both waits (own staging share of phase p - 3, own fragment reads), then barrier A
+        auto reads_end = [&](bool steady) {
+            if (steady) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mma_end = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        if (wr == 1) __builtin_amdgcn_s_barrier();          // the stagger: group 1 starts one barrier late ...
+        for (int t = 0; t < nk; ++t)
+        {
+            const bool steady = t + 2 < nk;
+            if (t + 1 < nk) stage(t + 1, true, 0);          // ph0: quadrant (0,0)
+            load_b(t, 0);
+            load_a(t, 0);
+            reads_end(steady);
+            mma(0, 0);
+            mma_end();
+            if (t + 1 < nk) stage(t + 1, false, 1);         // ph1: quadrant (0,1)
+            load_b(t, 1);
+            reads_end(steady);
+            mma(0, 1);
+            mma_end();
+            if (t + 2 < nk) stage(t + 2, false, 0);         // ph2: quadrant (1,1)
+            load_a(t, 1);
+            reads_end(steady);
+            mma(1, 1);
+            mma_end();
+            if (t + 2 < nk) stage(t + 2, true, 1);          // ph3: quadrant (1,0)
+            load_b(t, 0);
+            reads_end(steady);
+            mma(1, 0);
+            mma_end();
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();          // ... and group 0 waits one barrier at the end: equal counts
+    }
+    else
+    {
+    for (int t = 0; t < nk; ++t)
+        {
+            const bool steady = t + 2 < nk;                    // the full issue sequence is still running
+            // ph0: quadrant (0,0)
+            if (t + 1 < nk) stage(t + 1, true, 0);
+            load_b(t, 0);
+            load_a(t, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0, 0);
+            phase_end(steady);
+            // ph1: quadrant (0,1)
+            if (t + 1 < nk) stage(t + 1, false, 1);
+            load_b(t, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0, 1);
+            phase_end(steady);
+            // ph2: quadrant (1,1)
+            if (t + 2 < nk) stage(t + 2, false, 0);
+            load_a(t, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1, 1);
+            phase_end(steady);
+            // ph3: quadrant (1,0)
+            if (t + 2 < nk) stage(t + 2, true, 1);
+            load_b(t, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1, 0);
+            phase_end(steady);
+        }
+
     }
 
     // ---- epilogue: D[p = 4 g + r][q = l15] -> Y[m0 + q][n0 + p] ----
@@ -274,7 +390,11 @@ constexpr int kStage3Bytes = 3 * kHalfBytes;   // W, X0, X1
 
 // GEGLU: the tile's 128 W rows are, per wave half wr, 32 gate rows then the matching 32 up rows (64 output columns per tile:
 // n0 = 64 tn), so a lane's sub-tiles pt = 0,1 / 2,3 hold gate / up of the same outputs.
-template <bool FP8, bool GEGLU>
+// PP: the same stagger as gemm256_kernel<.., PP>: [stage K-tile t + 2, all 16 fragment reads of K-tile t, waits] | A | [32 MFMAs] | B |,
+// waves 4-7 one barrier behind waves 0-3.  RAW: K-tile t + 1 is waited for (vmcnt(6)) at the end of the reads of phase t and read in
+// phase t + 1; WAR: ring slot (t + 2) % 3 held K-tile t - 1, whose reads every wave retired before barrier A(t - 1), and group 0
+// restages it behind B(t - 1) = group 1's A(t - 1).
+template <bool FP8, bool GEGLU, bool PP>
 __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -284,7 +404,8 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     const int nwg = gridDim.x, id = blockIdx.x;
     const int xcd = id & 7, qd = nwg >> 3, rem = nwg & 7;
     const int tile = ((xcd < rem) ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (id >> 3);
-    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    int tm, tn;
+    grouped_tile(tile, p.tiles_m, p.tiles_n, tm, tn);
     const int m0 = tm * 256, n0 = tn * (GEGLU ? 64 : 128);
 
     const int lane = threadIdx.x & 63;
@@ -326,7 +447,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
 #pragma unroll
             for (int d = 0; d < 2; ++d) acc[b][c][d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    s16x8 fa[4][2], fb[2][2];
+    s16x8 fa[4][2], fb[2][2], fb1[PP ? 2 : 1][2];          // PP keeps the fragments of both X halves live
     auto frag_slot = [&](int ks) { return FP8 ? (2 * g + ks) : (ks * 4 + g); };
     auto load_a = [&](int kt) {
         const unsigned char* hb = smem + (kt % 3) * kStage3Bytes;
@@ -347,10 +468,15 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             const int r = wc * 32 + qt * 16 + l15;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                fb[qt][ks] = *reinterpret_cast<const s16x8*>(hb + r * 128 + ((frag_slot(ks) ^ ((r >> 1) & 7)) << 4));
+            {
+                const s16x8 v = *reinterpret_cast<const s16x8*>(hb + r * 128 + ((frag_slot(ks) ^ ((r >> 1) & 7)) << 4));
+                if (PP && hB == 1) fb1[PP ? qt : 0][ks] = v;
+                else fb[qt][ks] = v;
+            }
         }
     };
     auto mma = [&](int hB) {
+        s16x8 (&fbx)[2][2] = *((PP && hB == 1) ? reinterpret_cast<s16x8 (*)[2][2]>(&fb1) : &fb);
         __builtin_amdgcn_s_setprio(1);
         if constexpr (FP8)
         {
@@ -361,7 +487,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                 {
                     struct Pair { s16x8 lo, hi; };
                     const i32x8 a8 = __builtin_bit_cast(i32x8, (Pair{fa[pt][0], fa[pt][1]}));
-                    const i32x8 b8 = __builtin_bit_cast(i32x8, (Pair{fb[qt][0], fb[qt][1]}));
+                    const i32x8 b8 = __builtin_bit_cast(i32x8, (Pair{fbx[qt][0], fbx[qt][1]}));
                     acc[hB][pt][qt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[hB][pt][qt], 0, 0, 0, 127, 0, 127);
                 }
         }
@@ -374,7 +500,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
 #pragma unroll
                     for (int qt = 0; qt < 2; ++qt)
                         acc[hB][pt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, fa[pt][ks]), __builtin_bit_cast(bf16x8, fb[qt][ks]), acc[hB][pt][qt], 0, 0, 0);
+                            __builtin_bit_cast(bf16x8, fa[pt][ks]), __builtin_bit_cast(bf16x8, fbx[qt][ks]), acc[hB][pt][qt], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -385,18 +511,43 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    for (int t = 0; t < nk; ++t)
+    if constexpr (PP)
     {
-        const bool more = t + 2 < nk;
-        if (more) stage_all(t + 2);
-        load_a(t);
-        load_b(t, 0);
-        mma(0);
-        load_b(t, 1);
-        mma(1);
-        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nk; ++t)
+        {
+            const bool more = t + 2 < nk;
+            if (more) stage_all(t + 2);
+            load_a(t);
+            load_b(t, 0);
+            load_b(t, 1);
+            if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0);
+            mma(1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+    }
+    else
+    {
+        for (int t = 0; t < nk; ++t)
+        {
+            const bool more = t + 2 < nk;
+            if (more) stage_all(t + 2);
+            load_a(t);
+            load_b(t, 0);
+            mma(0);
+            load_b(t, 1);
+            mma(1);
+            if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     }
 
     if constexpr (GEGLU)
@@ -467,19 +618,26 @@ bool gemm256x128_applicable(int M, int K, int N)
     return tiles >= 200 && tiles >= 0.70 * rounds * kNumCU;
 }
 
-template <bool FP8, bool GEGLU = false>
-static int launch_gemm256x128_t(const Gemm256Params& p, hipStream_t s)
+extern int g_gemm_pingpong;
+
+template <bool FP8, bool GEGLU, bool PP>
+static int launch_gemm256x128_tt(const Gemm256Params& p, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set)
     {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel<FP8, GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel<FP8, GEGLU, PP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                3 * kStage3Bytes), "hipFuncSetAttribute(gemm256x128)");
         if (rc) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256x128_kernel<FP8, GEGLU>), dim3(p.tiles_m * p.tiles_n), dim3(512), 3 * kStage3Bytes, s, p);
+    hipLaunchKernelGGL((gemm256x128_kernel<FP8, GEGLU, PP>), dim3(p.tiles_m * p.tiles_n), dim3(512), 3 * kStage3Bytes, s, p);
     MILA_LAUNCH_CHECK("gemm256x128");
+}
+template <bool FP8, bool GEGLU = false>
+static int launch_gemm256x128_t(const Gemm256Params& p, hipStream_t s)
+{
+    return g_gemm_pingpong ? launch_gemm256x128_tt<FP8, GEGLU, true>(p, s) : launch_gemm256x128_tt<FP8, GEGLU, false>(p, s);
 }
 int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
 {
@@ -496,19 +654,29 @@ bool gemm256_applicable(int M, int K, int N)
     return tiles >= 200 && tiles >= 0.85 * rounds * kNumCU;
 }
 
-template <int MODE>
-static int launch_gemm256_t(const Gemm256Params& p, hipStream_t s)
+int g_gemm_pingpong = 4;      // tuning hook (mila_cdna4_tune_gemm_schedule): 0 = all eight waves in lockstep; 1 = staggered (ping-pong), four phases per
+                              // K-tile in the 256 x 256 kernel; 2 = 1 + prefer the 256 x 128 ring; 3 = staggered, two phases per K-tile in the
+                              // 256 x 256 kernel; 4 (default) = 3 + fp8 x fp8 shapes take the 256 x 256 kernel wherever it applies
+
+template <int MODE, int PP>
+static int launch_gemm256_tt(const Gemm256Params& p, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set)
     {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<MODE, PP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                2 * kBufBytes), "hipFuncSetAttribute(gemm256)");
         if (rc) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm256_kernel<MODE>, dim3(p.tiles_m * p.tiles_n), dim3(512), 2 * kBufBytes, s, p);
+    hipLaunchKernelGGL((gemm256_kernel<MODE, PP>), dim3(p.tiles_m * p.tiles_n), dim3(512), 2 * kBufBytes, s, p);
     MILA_LAUNCH_CHECK("gemm256");
+}
+template <int MODE>
+static int launch_gemm256_t(const Gemm256Params& p, hipStream_t s)
+{
+    if (g_gemm_pingpong >= 3) return launch_gemm256_tt<MODE, 2>(p, s);
+    return g_gemm_pingpong ? launch_gemm256_tt<MODE, 1>(p, s) : launch_gemm256_tt<MODE, 0>(p, s);
 }
 
 int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
@@ -537,6 +705,7 @@ int gemm_fp8_kernel_for(int M, int K, int N)
     // at the fp8 rate the 4-barrier-per-K-tile 256 x 256 schedule is barrier-bound (1.36 PFLOP/s on fc_gate_up); the 3-stage
     // 256 x 128 ring (one barrier per K-tile) reaches 1.8-1.9, so it is preferred wherever its grid fills the chip
     if (K % 128 != 0) return 0;
+    if (g_gemm_pingpong == 4 && gemm256_applicable(M, K, N)) return 2;       // tuning: the two-phase 256 x 256 schedule for fp8 too
     if (gemm256x128_applicable(M, K, N)) return 1;
     if (gemm256_applicable(M, K, N)) return 2;
     return 0;
@@ -545,7 +714,7 @@ int gemm_fp8_kernel_for(int M, int K, int N)
 int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
                           hipStream_t s)
 {
-    if (M % 256 == 0 && F % 64 == 0 && gemm256x128_applicable(M, K, 2 * F))
+    if (M % 256 == 0 && F % 64 == 0 && gemm256x128_applicable(M, K, 2 * F) && !(g_gemm_pingpong == 4 && gemm256_geglu_applicable(M, K, F)))
     {
         Gemm256Params q{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, M, K, F, M / 256, F / 64, x_scales, w_scale};
         return launch_gemm256x128_t<true, true>(q, s);

@@ -11,6 +11,8 @@ extern "C" {
 MILA_API int mila_cdna4_tune_matvec(int R, int U, int max_blocks);
 /* 1 = always use the 128 x 128 register-staged GEMM (A/B against the 256 x 256 direct-to-LDS kernel) */
 MILA_API int mila_cdna4_tune_gemm(int force_128_tile);
+/* 1 (default) = the staggered two-barrier (ping-pong) schedule of the LDS-DMA GEMMs, 0 = all eight waves in lockstep */
+MILA_API int mila_cdna4_tune_gemm_schedule(int pingpong);
 /* decode all 256 byte values with the hardware converts used by the kernels:
  * out_fp8[256] floats; out_fp4[512] floats (byte b -> [2b] low nibble, [2b+1] high nibble),
  * each for the 4 byte positions of a dword: out_fp4 has 4*512 floats, out_fp8 4*256. */

@@ -127,39 +127,47 @@ __global__ __launch_bounds__(1024) void fp4_weight_fp8_scale_kernel(float* __res
     }
 }
 
+// four finite f32 -> four OCP e4m3 bytes with the hardware convert (v_cvt_pk_fp8_f32: RNE), saturating to +-448 first as
+// f32_to_e4m3_rne_sat does (|v| >= 464 -> 0x7e); inputs here are products of finite weights and scales, never NaN
+__device__ __forceinline__ uint32_t f32x4_to_e4m3x4_hw(float a, float b, float c, float d)
+{
+    a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f); b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+    c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f); d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+    return (uint32_t)r;
+}
+
 // packed fp4 -> e4m3: out[2b], out[2b+1] = e4m3(lut(nibble) * (group scale * (1 / weight_fp8_scale)))  (CudaW4A16Gemm.cu:300-323)
-// one workgroup per output channel, one thread per 8 packed bytes (16 outputs = one 16-byte store): no index division
+// One thread per 16 packed bytes (32 outputs = two 16-byte stores), grid-stride over the whole matrix.  The nibbles are decoded by
+// v_cvt_scalef32_pk_f32_fp4 (scale 1.0: exact), multiplied in f32 and encoded by v_cvt_pk_fp8_f32: 1.5 VALU operations per
+// element where the bit-arithmetic encoder needed ~25 (the kernel was VALU-bound at 2 TB/s); same bytes (tests/test_linear_gpu.py).
 __global__ __launch_bounds__(256) void upcast_fp4_to_fp8_kernel(uint8_t* __restrict__ out, const uint8_t* __restrict__ packed,
                                                                 const float* __restrict__ scales, const float* __restrict__ w_scale,
-                                                                int K, int group_shift)
+                                                                int K, int group_shift, int64_t nvec)
 {
     const float inv_ws = 1.0f / w_scale[0];
-    const size_t row = blockIdx.x;
-    const int vec_per_row = K >> 4;
-    const uint8_t* prow = packed + row * (size_t)(K >> 1);
-    const float* srow = scales + row * (size_t)(K >> group_shift);
-    uint8_t* orow = out + row * (size_t)K;
-    for (int v = threadIdx.x; v < vec_per_row; v += 256)
+    const int vec_per_row = K >> 5;                        // 32 elements per vector
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride)
     {
-        const int k0 = v << 4;
-        const float sc = srow[k0 >> group_shift] * inv_ws;
-        const u32x2 pk = *reinterpret_cast<const u32x2*>(prow + (k0 >> 1));
-        u32x4 o;
+        const int64_t row = v / vec_per_row;
+        const int k0 = (int)(v - row * vec_per_row) << 5;
+        // a 32-element vector never straddles a group (group >= 64)
+        const float sc = scales[row * (int64_t)(K >> group_shift) + (k0 >> group_shift)] * inv_ws;
+        const u32x4 pk = *reinterpret_cast<const u32x4*>(packed + v * 16);
+        u32x4 o[2];
 #pragma unroll
         for (int w = 0; w < 4; ++w)
         {
-            const uint32_t word = (w < 2) ? pk[0] : pk[1];
-            const uint32_t bytes2 = (word >> (16 * (w & 1))) & 0xffffu;       // two packed bytes = four elements
-            uint32_t r = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-            {
-                const uint32_t nib = (bytes2 >> (4 * e)) & 0xfu;
-                r |= f32_to_e4m3_rne_sat(fp4_decode_sw(nib) * sc) << (8 * e);
-            }
-            o[w] = r;
+            const f32x2 e01 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(pk[w], 1.0f, 0), e23 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(pk[w], 1.0f, 1);
+            const f32x2 e45 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(pk[w], 1.0f, 2), e67 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(pk[w], 1.0f, 3);
+            o[w >> 1][2 * (w & 1)] = f32x4_to_e4m3x4_hw(e01[0] * sc, e01[1] * sc, e23[0] * sc, e23[1] * sc);
+            o[w >> 1][2 * (w & 1) + 1] = f32x4_to_e4m3x4_hw(e45[0] * sc, e45[1] * sc, e67[0] * sc, e67[1] * sc);
         }
-        *reinterpret_cast<u32x4*>(orow + k0) = o;
+        uint8_t* dst = out + v * 32;
+        *reinterpret_cast<u32x4*>(dst) = o[0];
+        *reinterpret_cast<u32x4*>(dst + 16) = o[1];
     }
 }
 
@@ -186,11 +194,15 @@ __global__ __launch_bounds__(256) void quantize_fp8_per_token_kernel(uint8_t* __
     for (int i = threadIdx.x; i < nvec; i += 256)
     {
         const u32x4 v = ld16(s + (size_t)i * 8);
+        // |x * inv| <= 448 (1 + 2^-23): the hardware convert (RNE) needs no clamp here, and a NaN stays a NaN (0x7f)
         u32x2 o;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-            o[h] = f32_to_e4m3_rne_sat(bf16_lo(v[2 * h]) * inv) | (f32_to_e4m3_rne_sat(bf16_hi(v[2 * h]) * inv) << 8) |
-                   (f32_to_e4m3_rne_sat(bf16_lo(v[2 * h + 1]) * inv) << 16) | (f32_to_e4m3_rne_sat(bf16_hi(v[2 * h + 1]) * inv) << 24);
+        {
+            int r = __builtin_amdgcn_cvt_pk_fp8_f32(bf16_lo(v[2 * h]) * inv, bf16_hi(v[2 * h]) * inv, 0, false);
+            r = __builtin_amdgcn_cvt_pk_fp8_f32(bf16_lo(v[2 * h + 1]) * inv, bf16_hi(v[2 * h + 1]) * inv, r, true);
+            o[h] = (uint32_t)r;
+        }
         *reinterpret_cast<u32x2*>(d + (size_t)i * 8) = o;
     }
 }
@@ -248,8 +260,11 @@ int mila_cdna4_upcast_fp4_to_fp8(uint8_t* out, const uint8_t* packed, const floa
                                  int group, mila_stream_t stream)
 {
     MILA_REQUIRE(out && packed && scales && weight_fp8_scale, "upcast_fp4_to_fp8: null pointer");
-    MILA_REQUIRE(N > 0 && K > 0 && (group == 64 || group == 128) && K % group == 0 && K % 16 == 0, "upcast_fp4_to_fp8: bad sizes (N=%d K=%d group=%d)", N, K, group);
-    hipLaunchKernelGGL(upcast_fp4_to_fp8_kernel, dim3(N), dim3(256), 0, as_stream(stream), out, packed, scales, weight_fp8_scale, K, group == 128 ? 7 : 6);
+    MILA_REQUIRE(N > 0 && K > 0 && (group == 64 || group == 128) && K % group == 0 && K % 32 == 0, "upcast_fp4_to_fp8: bad sizes (N=%d K=%d group=%d)", N, K, group);
+    const int64_t nvec = (int64_t)N * (K >> 5);
+    const int blocks = (int)std::min<int64_t>((nvec + 255) / 256, 4096);
+    hipLaunchKernelGGL(upcast_fp4_to_fp8_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), out, packed, scales, weight_fp8_scale, K, group == 128 ? 7 : 6,
+                       nvec);
     MILA_LAUNCH_CHECK("upcast_fp4_to_fp8");
 }
 
