@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--onepass", type=int, default=None, help="1/0: split decode attention in one launch / with a combine launch (default: the model's)")
     ap.add_argument("--prefetch-mb", type=float, default=None, help="side-stream Infinity-Cache prefetch cap per Linear in MB (0 = off; default: the model's)")
     ap.add_argument("--prefetch-wgs", type=int, default=64)
+    ap.add_argument("--resident", type=int, default=None, help="1/0: resident prefill staging for the quantized policies (default: the model's = 1)")
     ap.add_argument("--gemm-schedule", type=int, default=None, help="tuning hook: 0 lockstep, 1 ping-pong (4 phases), 3 ping-pong (2 phases, default)")
     ap.add_argument("--warm", default=None, help="blocks_a,cap_a_MB,blocks_b,cap_b_MB: warm-ahead workgroups of the attention / combine launches")
     a = ap.parse_args()
@@ -119,6 +120,8 @@ def main():
     results = {}
     for pol in policies:
         m = host.Gemma(pol, cfg, max_seq=CONTEXT + a.steps + a.warmup + 8, max_prefill=1 if a.no_prefill else CONTEXT, seed=1234)
+        if a.resident is not None:
+            m.set_resident_prefill_weights(a.resident)
         if a.onepass is not None:
             m.set_onepass_attention(a.onepass)
         if a.prefetch_mb is not None:

@@ -151,6 +151,17 @@ MILA_API int mila_cdna4_gemm_geglu_bf16_w4a8(uint16_t* Y, const uint16_t* X, con
                                              const float* weight_fp8_scale, int M, int K, int F, int group,
                                              void* scratch, size_t scratch_bytes, mila_stream_t stream);
 
+/* Resident prefill weights (288 GB of HBM: the staging passes need not be repeated every forward as on the reference's 12 GB card).
+ * dequantize_to_bf16 is the staging pass of the 2-phase prefill as an entry point of its own (cuda_fp8_dequantize_to_bf16,
+ * Fp8Prefill/CudaFp8Prefill.cu:64-84; cuda_fp4_dequantize_to_bf16, W4A16Gemm/CudaW4A16Gemm.cu:210-235): out [N, K] bf16, the values
+ * gemm_bf16_w8a16_staged / _w4a16_staged put in their scratch, so gemm_bf16 on `out` equals the staged call bit for bit.
+ * gemm_geglu_fp8_scaled is gemm_geglu_bf16_w4a8 on operands staged by the caller (upcast_fp4_to_fp8 once at load,
+ * quantize_fp8_per_token per forward). */
+MILA_API int mila_cdna4_dequantize_to_bf16(uint16_t* out, const void* W, const float* scales, int fmt, int N, int K, int group,
+                                           mila_stream_t stream);
+MILA_API int mila_cdna4_gemm_geglu_fp8_scaled(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* token_scales,
+                                              const float* weight_scale, int M, int K, int F, mila_stream_t stream);
+
 /* 2-phase forms for quantized weights (the reference's own structure, Linear/CudaLinearOp.ixx:597-644, :716-764:
  * dequantize to a bf16 scratch, then the bf16 GEMM).  Chosen automatically when the 256 x 256 LDS-DMA GEMM
  * applies to (M,K,N) -- gemm_staging_bytes() says how much scratch that needs (0 = the register-dequantizing kernel is

@@ -136,5 +136,5 @@ EXPORTED = [
     "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position", "fused_attn_decode_bf16",
     "attn_decode_split_count", "fused_attn_decode_partials_bf16", "matvec_attn_combine",
     "decode_chain_scratch_bytes", "decode_chain_init", "decode_chain_status", "decode_chain",
-    "attn_decode_ticket_count", "fused_attn_decode_onepass_bf16", "prefetch_l3", "fused_attn_decode_ex",
+    "attn_decode_ticket_count", "fused_attn_decode_onepass_bf16", "prefetch_l3", "fused_attn_decode_ex", "dequantize_to_bf16", "gemm_geglu_fp8_scaled",
 ]

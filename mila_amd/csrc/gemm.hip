@@ -435,6 +435,15 @@ int mila_cdna4_gemm_bf16_w4a16(uint16_t* Y, const uint16_t* X, const uint8_t* W_
     return launch_gemm<G_FP4>(p, as_stream(stream));
 }
 
+int mila_cdna4_dequantize_to_bf16(uint16_t* out, const void* W, const float* scales, int fmt, int N, int K, int group, mila_stream_t stream)
+{
+    MILA_REQUIRE(out && W && scales, "dequantize_to_bf16: null pointer");
+    MILA_REQUIRE(fmt == 1 || fmt == 2, "dequantize_to_bf16: fmt must be 1 (fp8 per channel) or 2 (fp4 per group), got %d", fmt);
+    MILA_REQUIRE(N > 0 && K > 0 && K % 32 == 0, "dequantize_to_bf16: bad sizes (N=%d K=%d)", N, K);
+    if (fmt == 2) MILA_REQUIRE((group == 64 || group == 128) && K % group == 0, "dequantize_to_bf16: bad group size %d for K=%d", group, K);
+    return launch_dequant(fmt, out, static_cast<const uint8_t*>(W), scales, N, K, group, as_stream(stream));
+}
+
 size_t mila_cdna4_gemm_staging_bytes(int M, int K, int N)
 {
     int which;

@@ -312,6 +312,14 @@ int mila_cdna4_gemm_bf16_w4a8(uint16_t* Y, const uint16_t* X, const uint8_t* W_p
 
 int mila_cdna4_gemm_geglu_w4a8_applicable(int M, int K, int F) { return (M > 0 && K > 0 && F > 0 && K % 128 == 0 && gemm256_geglu_applicable(M, K, F)) ? 1 : 0; }
 
+int mila_cdna4_gemm_geglu_fp8_scaled(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* weight_scale, int M, int K, int F,
+                                     mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X8 && W8 && x_scales && weight_scale, "gemm_geglu_fp8_scaled: null pointer");
+    MILA_REQUIRE(mila_cdna4_gemm_geglu_w4a8_applicable(M, K, F), "gemm_geglu_fp8_scaled: shape (M=%d, K=%d, F=%d) is outside the fused kernel", M, K, F);
+    return launch_gemm_fp8_geglu(Y, X8, W8, x_scales, weight_scale, M, K, F, as_stream(stream));
+}
+
 int mila_cdna4_gemm_geglu_bf16_w4a8(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed, const float* scales, const float* weight_fp8_scale,
                                     int M, int K, int F, int group, void* scratch, size_t scratch_bytes, mila_stream_t stream)
 {

@@ -50,6 +50,7 @@ def load():
         _lib.mila_gemma_set_combine_in_oproj.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_set_fused_prefill.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_set_onepass_attention.argtypes = [C.c_void_p, C.c_int]
+        _lib.mila_gemma_set_resident_prefill_weights.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_set_warm_ahead.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64]
         _lib.mila_gemma_set_prefetch_ahead.argtypes = [C.c_void_p, C.c_int64, C.c_int]
         _lib.mila_gpt_last_error.restype = C.c_char_p
@@ -112,6 +113,11 @@ class Gemma:
         """fused / graph decode: fold the flash-decode combine into o_proj's prologue on layers with a small partial set
         (opt-in: measured slower than the combine launch it removes) or keep the combine launch; identical bits"""
         _check(load().mila_gemma_set_combine_in_oproj(self.h, int(bool(on))))
+
+    def set_resident_prefill_weights(self, on):
+        """quantized policies: keep the prefill staging of every layer Linear (fp8 -> bf16, fp4 -> e4m3) resident in HBM (default)
+        or re-stage it into scratch on every forward as the reference does; identical bits"""
+        _check(load().mila_gemma_set_resident_prefill_weights(self.h, int(bool(on))))
 
     def set_onepass_attention(self, on):
         """fused / graph decode: split decode attention in ONE launch (the workgroup whose partials arrive last merges its

@@ -476,6 +476,17 @@ namespace Mila::Dnn
                 w4a8 = L.fc_gate_up->getOperation().fp8ActivationPrefill() && mila_cdna4_gemm_fp8_applicable( T, (int)D, 2 * (int)cfg_.hidden_dim );
             if constexpr ( kFmt == 2 )
             {
+                if ( w4a8 && mila_cdna4_gemm_geglu_w4a8_applicable( T, (int)D, (int)cfg_.hidden_dim ) && L.fc_gate_up->getOperation().weightFp8Scale() &&
+                     L.fc_gate_up->getOperation().residentE4m3() )
+                {
+                    // resident e4m3 weights (staged once at load): only the activations are quantized per forward
+                    auto& op = L.fc_gate_up->getOperation();
+                    uint8_t* x8; float* ts;
+                    op.activationScratch( T, (int)D, x8, ts );
+                    Compute::rocmCheck( mila_cdna4_quantize_fp8_per_token( x8, ts, ffn_in.data(), T, (int)D, st ) );
+                    Compute::rocmCheck( mila_cdna4_gemm_geglu_fp8_scaled( act.data(), x8, op.residentE4m3(), ts, op.weightFp8Scale(), T, (int)D, (int)cfg_.hidden_dim, st ) );
+                    return;
+                }
                 if ( w4a8 && mila_cdna4_gemm_geglu_w4a8_applicable( T, (int)D, (int)cfg_.hidden_dim ) && L.fc_gate_up->getOperation().weightFp8Scale() )
                 {
                     const int F = (int)cfg_.hidden_dim;
@@ -494,6 +505,8 @@ namespace Mila::Dnn
                 const void* W = L.fc_gate_up->getWeight().rawData();
                 if constexpr ( kFmt == 0 )
                     Compute::rocmCheck( mila_cdna4_gemm_geglu_bf16( act.data(), ffn_in.data(), static_cast<const uint16_t*>( W ), T, (int)D, F, st ) );
+                else if ( kFmt == 1 && L.fc_gate_up->getOperation().residentBf16() )
+                    Compute::rocmCheck( mila_cdna4_gemm_geglu_bf16( act.data(), ffn_in.data(), L.fc_gate_up->getOperation().residentBf16(), T, (int)D, F, st ) );
                 else
                 {
                     const size_t need = (size_t)2 * F * D * 2;
@@ -830,6 +843,14 @@ namespace Mila::Dnn
         {
             if ( graph_exec_ ) throw std::runtime_error( "GemmaTransformer::setCombineInOProj: the graph is already captured" );
             combine_in_oproj_ = on;
+        }
+        /// quantized policies: keep the prefill staging (fp8 -> bf16, fp4 -> e4m3) of every layer Linear resident (default on: +2 / +1
+        /// bytes per weight of the 288 GB) or re-stage into scratch on every forward as the reference does; same bits
+        void setResidentPrefillWeights( bool on )
+        {
+            for ( auto& L : layers_ )
+                for ( auto* lin : { L.qkv_proj.get(), L.o_proj.get(), L.fc_gate_up.get(), L.fc_down.get() } ) lin->getOperation().setResidentPrefillWeights( on );
+            ctx_->synchronize();
         }
         /// split decode attention in ONE launch (the workgroup whose partials arrive last merges its head-group's splits) instead of
         /// attention + combine launches; same bits

@@ -124,12 +124,29 @@ namespace Mila::Dnn::Compute
                 if constexpr ( kFmt == 0 ) rocmCheck( mila_cdna4_gemm_bf16( y, x, static_cast<const uint16_t*>( weight_ ), bias_, M, K, N, st ) );
                 else
                 {
+                    // resident prefill weights: the staging pass was run once, at load (same values => same bits as the staged call)
+                    if constexpr ( kFmt == 1 )
+                    {
+                        if ( resident_bf16_ && mila_cdna4_gemm_staging_bytes( M, K, N ) != 0 )
+                        {
+                            rocmCheck( mila_cdna4_gemm_bf16( y, x, resident_bf16_->data(), bias_, M, K, N, st ) );
+                            return;
+                        }
+                    }
                     // 2-phase staging through context scratch when the LDS-DMA GEMM applies; scratch is fetched per
                     // forward and never cached (reference rule, CudaLinearOp.ixx:603-614)
                     if constexpr ( kFmt == 2 )
                     {
                         // W4A8: fp4 -> e4m3 weight staging + per-token e4m3 activations + fp8 x fp8 MFMA GEMM, the reference's default
                         // prefill for this policy (kUseFp8ActivationPrefillPath, CudaLinearOp.ixx:646-715), when an fp8 kernel serves the shape
+                        if ( use_fp8_activation_prefill_ && weight_fp8_scale_ && resident_e4m3_ && mila_cdna4_gemm_fp8_applicable( M, K, N ) )
+                        {
+                            uint8_t* x8; float* ts;
+                            activationScratch( M, K, x8, ts );
+                            rocmCheck( mila_cdna4_quantize_fp8_per_token( x8, ts, x, M, K, st ) );
+                            rocmCheck( mila_cdna4_gemm_fp8_scaled( y, x8, resident_e4m3_->data(), ts, weight_fp8_scale_->data(), bias_, M, K, N, st ) );
+                            return;
+                        }
                         if ( use_fp8_activation_prefill_ && weight_fp8_scale_ && mila_cdna4_gemm_fp8_applicable( M, K, N ) )
                         {
                             const size_t need8 = mila_cdna4_gemm_w4a8_scratch_bytes( M, K, N );
@@ -175,6 +192,27 @@ namespace Mila::Dnn::Compute
                 if ( !weight_fp8_scale_ ) weight_fp8_scale_ = std::make_unique<Tensor<TensorDataType::FP32, RocmDeviceMemoryResource>>( this->context_->getDeviceId(), shape_t{ 1 } );
                 rocmCheck( mila_cdna4_fp4_weight_fp8_scale( weight_fp8_scale_->data(), scales_, (int64_t)cfg_.out_features * ( cfg_.in_features / kGroup ), this->context_->getStream() ) );
             }
+            refreshResident();
+        }
+        /// Resident prefill weights (default on): the staging pass of the quantized prefill -- fp8 -> bf16 (W8A16), fp4 -> e4m3 (W4A8) --
+        /// is run ONCE when the weights are loaded and kept in an op-owned tensor (+2 / +1 bytes per weight), instead of into context
+        /// scratch on every forward as the reference must on a 12 GB card (CudaLinearOp.ixx:597-644, :646-715).  Decode still streams the
+        /// quantized weights; prefill results are bit-identical either way.
+        void setResidentPrefillWeights( bool on )
+        {
+            resident_ = on;
+            if ( !on ) { resident_bf16_.reset(); resident_e4m3_.reset(); }
+            else refreshResident();
+        }
+        bool residentPrefillWeights() const noexcept { return resident_; }
+        const uint16_t* residentBf16() const noexcept { return resident_bf16_ ? resident_bf16_->data() : nullptr; }
+        const uint8_t* residentE4m3() const noexcept { return resident_e4m3_ ? resident_e4m3_->data() : nullptr; }
+        /// scratch for the per-token e4m3 activations + their scales (fetched per forward, never cached)
+        void activationScratch( int M, int K, uint8_t*& x8, float*& ts ) const
+        {
+            const size_t xb = ( (size_t)M * K + 15 ) & ~(size_t)15;
+            auto* base = static_cast<uint8_t*>( this->context_->getScratch( xb + (size_t)M * 4 ) );
+            x8 = base; ts = reinterpret_cast<float*>( base + xb );
         }
         /// fp4 policy: W4A8 prefill (default on, as in the reference) or the dequantize -> bf16 GEMM fallback
         void setFp8ActivationPrefill( bool on ) noexcept { use_fp8_activation_prefill_ = on; }
@@ -192,7 +230,29 @@ namespace Mila::Dnn::Compute
         const float* scales_{ nullptr };
         bool built_{ false };
         bool use_fp8_activation_prefill_{ true };
+        bool resident_{ true };
         std::unique_ptr<Tensor<TensorDataType::FP32, RocmDeviceMemoryResource>> weight_fp8_scale_;
+        std::unique_ptr<RocmBf16Tensor> resident_bf16_;
+        std::unique_ptr<Tensor<TensorDataType::FP8_E4M3, RocmDeviceMemoryResource>> resident_e4m3_;
+
+        void refreshResident()
+        {
+            if constexpr ( kFmt == 0 ) return;
+            if ( !resident_ || !weight_ || !scales_ ) return;
+            const int K = narrowToKernelIndex( cfg_.in_features, "in_features" ), N = narrowToKernelIndex( cfg_.out_features, "out_features" );
+            mila_stream_t st = this->context_->getStream();
+            if constexpr ( kFmt == 1 )
+            {
+                if ( !resident_bf16_ ) resident_bf16_ = std::make_unique<RocmBf16Tensor>( this->context_->getDeviceId(), shape_t{ cfg_.out_features, cfg_.in_features } );
+                rocmCheck( mila_cdna4_dequantize_to_bf16( resident_bf16_->data(), weight_, scales_, 1, N, K, 0, st ) );
+            }
+            else if constexpr ( kFmt == 2 )
+            {
+                if ( !weight_fp8_scale_ || K % 32 != 0 ) return;
+                if ( !resident_e4m3_ ) resident_e4m3_ = std::make_unique<Tensor<TensorDataType::FP8_E4M3, RocmDeviceMemoryResource>>( this->context_->getDeviceId(), shape_t{ cfg_.out_features, cfg_.in_features } );
+                rocmCheck( mila_cdna4_upcast_fp4_to_fp8( resident_e4m3_->data(), static_cast<const uint8_t*>( weight_ ), scales_, weight_fp8_scale_->data(), N, K, kGroup, st ) );
+            }
+        }
     };
 
     template<typename TPolicy>

@@ -138,6 +138,12 @@ HOST_API int mila_gemma_set_combine_in_oproj( void* h, int on )
     auto* r = static_cast<Runner*>( h );
     return guarded( [&] { std::visit( [&]( auto& m ) { m->setCombineInOProj( on != 0 ); }, r->model ); } );
 }
+/// on != 0 (default): quantized policies keep their prefill staging resident; 0: re-stage on every forward (the reference's way)
+HOST_API int mila_gemma_set_resident_prefill_weights( void* h, int on )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&] { std::visit( [&]( auto& m ) { m->setResidentPrefillWeights( on != 0 ); }, r->model ); } );
+}
 /// on != 0: split decode attention runs in ONE launch (last-arriver merge) instead of attention + combine; same bits
 HOST_API int mila_gemma_set_onepass_attention( void* h, int on )
 {

@@ -148,6 +148,31 @@ def test_fused_prefill_glue_gives_the_same_logits_and_cache_as_one_launch_per_op
     b.close()
 
 
+WIDE_FFN = dict(vocab_size=2048, embedding_dim=1280, num_layers=2, num_heads=4, num_kv_heads=2, head_dim=64, hidden_dim=6400,
+                global_head_dim=128, num_global_kv_heads=1, window=64, sliding_window_pattern=2, global_rotary_dim=32)
+
+
+@pytest.mark.parametrize("policy", ["fp8", "fp4"])
+def test_resident_prefill_weights_give_the_bits_of_per_forward_staging(policy):
+    """the quantized prefill with its staging pass kept resident (fp8 -> bf16 / fp4 -> e4m3 once at load, the default) vs re-staged
+    into scratch on every forward (the reference's structure): identical logits and identical KV caches, on a shape whose
+    fc_gate_up takes the LDS-DMA kernels (T = 1024, F = 6400) while other Linears of the block do not"""
+    T = 1024
+    toks = [(13 * i + 5) % 2048 for i in range(T)]
+    a = host.Gemma(policy, WIDE_FFN, max_seq=T + 8, max_prefill=T, seed=3)
+    b = host.Gemma(policy, WIDE_FFN, max_seq=T + 8, max_prefill=T, seed=3)
+    b.set_resident_prefill_weights(False)
+    la, lb = a.prefill(toks), b.prefill(toks)
+    assert np.all(np.isfinite(la)) and np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    da, db = a.decode(11, T, "fused"), b.decode(11, T, "fused")
+    assert np.array_equal(da.view(np.uint32), db.view(np.uint32))
+    # switching it back on rebuilds the shadows from the quantized weights
+    b.set_resident_prefill_weights(True)
+    assert np.array_equal(b.prefill(toks).view(np.uint32), la.view(np.uint32))
+    a.close()
+    b.close()
+
+
 def test_sampled_generation_degenerates_to_greedy_and_is_reproducible():
     """top_k = 1 and temperature <= 0 both reproduce the greedy continuation; a fixed seed reproduces a sampled one; and a
     sampled continuation only ever picks tokens inside the top-k set of the logits it was drawn from"""
