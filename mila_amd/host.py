@@ -51,6 +51,11 @@ def load():
         _lib.mila_gemma_set_fused_prefill.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_set_onepass_attention.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_set_resident_prefill_weights.argtypes = [C.c_void_p, C.c_int]
+        _lib.mila_gemma_save_safetensors.argtypes = [C.c_void_p, C.c_char_p]
+        _lib.mila_gemma_load_safetensors.argtypes = [C.c_void_p, C.c_char_p]
+        _lib.mila_safetensors_list.restype = C.c_int64
+        _lib.mila_safetensors_list.argtypes = [C.c_char_p, C.c_char_p, C.c_int64]
+        _lib.mila_safetensors_copy.argtypes = [C.c_char_p, C.c_char_p]
         _lib.mila_gemma_set_warm_ahead.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64]
         _lib.mila_gemma_set_prefetch_ahead.argtypes = [C.c_void_p, C.c_int64, C.c_int]
         _lib.mila_gpt_last_error.restype = C.c_char_p
@@ -113,6 +118,14 @@ class Gemma:
         """fused / graph decode: fold the flash-decode combine into o_proj's prologue on layers with a small partial set
         (opt-in: measured slower than the combine launch it removes) or keep the combine launch; identical bits"""
         _check(load().mila_gemma_set_combine_in_oproj(self.h, int(bool(on))))
+
+    def save_safetensors(self, path):
+        """every parameter in its storage form (bf16, or e4m3 / packed e2m1 + fp32 scales) as a SafeTensors file"""
+        _check(load().mila_gemma_save_safetensors(self.h, str(path).encode()))
+
+    def load_safetensors(self, path):
+        """load every parameter from a SafeTensors file; bf16 Linear weights are quantized on load under a quantized policy"""
+        _check(load().mila_gemma_load_safetensors(self.h, str(path).encode()))
 
     def set_resident_prefill_weights(self, on):
         """quantized policies: keep the prefill staging of every layer Linear (fp8 -> bf16, fp4 -> e4m3) resident in HBM (default)
@@ -226,3 +239,27 @@ class Gpt:
         if self.h:
             load().mila_gpt_destroy(self.h)
             self.h = None
+
+
+def safetensors_list(path):
+    """host-only: [(name, dtype, nbytes, shape)], {metadata} of a SafeTensors file as the C++ reader sees it"""
+    lib = load()
+    need = lib.mila_safetensors_list(str(path).encode(), None, 0)
+    if need < 0:
+        _check(int(need))
+    buf = C.create_string_buffer(int(need) + 1)
+    lib.mila_safetensors_list(str(path).encode(), buf, int(need) + 1)
+    tensors, meta = [], {}
+    for line in buf.value.decode().splitlines():
+        if line.startswith("# "):
+            k, v = line[2:].split("=", 1)
+            meta[k] = v
+        else:
+            name, dtype, nbytes, shape = (line.split(" ") + [""])[:4]
+            tensors.append((name, dtype, int(nbytes), tuple(int(d) for d in shape.split(",") if d)))
+    return tensors, meta
+
+
+def safetensors_copy(src, dst):
+    """host-only: rewrite src as dst through the C++ reader and writer"""
+    _check(load().mila_safetensors_copy(str(src).encode(), str(dst).encode()))

@@ -13,6 +13,8 @@
 // embedding scaled by sqrt(D) with a second bf16 rounding; layer i is global iff (i+1) % 6 == 0;
 // tied table: bf16 for NoWeightQuant, per-row FP8 for quantized bodies (Gemma.ixx:143-147).
 #pragma once
+#include <functional>
+#include <map>
 
 #include <hip/hip_runtime_api.h>
 
@@ -20,6 +22,7 @@
 #include <cmath>
 
 #include "Components.h"
+#include "Serialization.h"
 #include "../../../csrc/internal.h"
 
 namespace Mila::Dnn
@@ -844,6 +847,127 @@ namespace Mila::Dnn
             if ( graph_exec_ ) throw std::runtime_error( "GemmaTransformer::setCombineInOProj: the graph is already captured" );
             combine_in_oproj_ = on;
         }
+        // ------------------------------------------------------------------------------------
+        // weight ingestion: the flat SafeTensors container with the component paths as tensor names,
+        // `<path>.weight` (+ `<path>.weight_scale` for a quantized Linear), norm weights, `<layer>.layer_scalar`
+        // ------------------------------------------------------------------------------------
+        /// every parameter in its STORAGE form (bf16, or e4m3 / packed e2m1 + fp32 scales): a file a quantized model reloads without
+        /// re-quantizing (Linear.ixx:370-400 writes the same siblings)
+        void saveSafeTensors( const std::string& path )
+        {
+            struct Item { std::string name, dtype; std::vector<int64_t> shape; const void* dev; size_t bytes; float host_scalar; };
+            std::vector<Item> items;
+            auto shapeOf = []( const auto& t ) { std::vector<int64_t> v; for ( auto d : t.shape() ) v.push_back( (int64_t)d ); return v; };
+            auto addLinear = [&]( auto& lin )
+            {
+                auto& w = lin.getWeight();
+                const char* dt = std::remove_reference_t<decltype( lin )>::kIsQuantized ? ( w.sizeInBytes() * 2 == (size_t)lin.getConfig().getOutputFeatures() * lin.getConfig().getInputFeatures() ? "U8" : "F8_E4M3" ) : "BF16";
+                items.push_back( { lin.getName() + ".weight", dt, shapeOf( w ), w.rawData(), w.sizeInBytes(), 0.0f } );
+                if constexpr ( std::remove_reference_t<decltype( lin )>::kIsQuantized )
+                    items.push_back( { lin.getName() + ".weight_scale", "F32", shapeOf( *lin.getWeightScale() ), lin.getWeightScale()->rawData(), lin.getWeightScale()->sizeInBytes(), 0.0f } );
+            };
+            auto addNorm = [&]( RmsNormType& n ) { items.push_back( { n.getName() + ".weight", "BF16", shapeOf( *n.getWeight() ), n.getWeight()->rawData(), n.getWeight()->sizeInBytes(), 0.0f } ); };
+            for ( size_t i = 0; i < layers_.size(); ++i )
+            {
+                auto& L = layers_[ i ];
+                addNorm( *L.input_norm ); addLinear( *L.qkv_proj ); addNorm( *L.q_norm ); addNorm( *L.k_norm ); addLinear( *L.o_proj ); addNorm( *L.post_attn_norm );
+                addNorm( *L.pre_ffn_norm ); addLinear( *L.fc_gate_up ); addLinear( *L.fc_down ); addNorm( *L.post_ffn_norm );
+                items.push_back( { "gemma.layer_" + std::to_string( i ) + ".layer_scalar", "F32", { 1 }, nullptr, 4, L.layer_scalar } );
+            }
+            addNorm( *final_norm_ );
+            addLinear( *lm_head_ );
+            Serialization::SafeTensorsWriter w( path );
+            for ( auto& it : items ) w.declareTensor( it.name, it.dtype, it.shape );
+            w.setMetadata( "format", "pt" );
+            w.setMetadata( "mila_quantization", kFmt == 0 ? "NoWeightQuant" : kFmt == 1 ? "PerChannelFp8" : "PerGroupFp4<128>" );
+            w.setMetadata( "mila_config", "{\"architecture\":\"gemma4\",\"num_layers\":" + std::to_string( cfg_.num_layers ) + ",\"embedding_dim\":" + std::to_string( cfg_.embedding_dim ) +
+                                              ",\"hidden_dim\":" + std::to_string( cfg_.hidden_dim ) + ",\"vocab_size\":" + std::to_string( cfg_.vocab_size ) + "}" );
+            w.beginData();
+            std::vector<unsigned char> host;
+            ctx_->synchronize();
+            for ( auto& it : items )
+            {
+                if ( !it.dev ) { w.writeTensorData( it.name, &it.host_scalar, 4 ); continue; }
+                host.resize( it.bytes );
+                Compute::rocmCheck( mila_cdna4_memcpy_d2h( host.data(), it.dev, it.bytes, ctx_->getStream() ) );
+                ctx_->synchronize();
+                w.writeTensorData( it.name, host.data(), it.bytes );
+            }
+            w.close();
+        }
+
+        /// load every parameter from a SafeTensors file, consuming it in file order.  A Linear's `.weight` may be bf16 [N, K]
+        /// (stored as is, or quantized on load under a quantized policy: Linear.ixx:529-558) or already in the policy's storage form
+        /// with its `.weight_scale` sibling (:559-574).  Unknown names and missing parameters are errors.
+        void loadSafeTensors( const std::string& path )
+        {
+            if ( graph_exec_ ) throw std::runtime_error( "GemmaTransformer::loadSafeTensors: the graph is already captured" );
+            Serialization::SafeTensorsReader r( path );
+            std::map<std::string, std::function<void( const Serialization::SafeTensorsEntry& )>> sinks;
+            std::map<std::string, bool> required;
+            auto bindLinear = [&]( auto& lin )
+            {
+                auto* lp = &lin;
+                constexpr bool q = std::remove_reference_t<decltype( lin )>::kIsQuantized;
+                sinks[ lin.getName() + ".weight" ] = [ lp ]( const Serialization::SafeTensorsEntry& e )
+                {
+                    const size_t NK = (size_t)lp->getConfig().getOutputFeatures() * lp->getConfig().getInputFeatures();
+                    if ( e.dtype == "BF16" ) { if ( (size_t)e.elements() != NK ) throw std::invalid_argument( e.name + ": expected " + std::to_string( NK ) + " bf16 elements" ); }
+                    else if ( !q || e.nbytes() != lp->getWeight().sizeInBytes() || ( e.dtype != "F8_E4M3" && e.dtype != "U8" ) )
+                        throw std::invalid_argument( e.name + ": dtype " + e.dtype + " / " + std::to_string( e.nbytes() ) + " bytes does not fit this Linear's weight policy" );
+                    lp->loadParameter( "weight", e.data, e.nbytes() );
+                };
+                required[ lin.getName() + ".weight" ] = false;
+                if constexpr ( q )
+                    sinks[ lin.getName() + ".weight_scale" ] = [ lp ]( const Serialization::SafeTensorsEntry& e )
+                    {
+                        if ( e.dtype != "F32" ) throw std::invalid_argument( e.name + ": weight scales must be F32" );
+                        lp->loadParameter( "weight_scale", e.data, e.nbytes() );
+                    };
+            };
+            auto bindNorm = [&]( RmsNormType& n )
+            {
+                auto* np = &n;
+                sinks[ n.getName() + ".weight" ] = [ np ]( const Serialization::SafeTensorsEntry& e )
+                {
+                    if ( e.dtype != "BF16" ) throw std::invalid_argument( e.name + ": norm weights must be BF16" );
+                    np->loadParameter( "weight", e.data, e.nbytes() );
+                };
+                required[ n.getName() + ".weight" ] = false;
+            };
+            for ( size_t i = 0; i < layers_.size(); ++i )
+            {
+                auto& L = layers_[ i ];
+                bindNorm( *L.input_norm ); bindLinear( *L.qkv_proj ); bindNorm( *L.q_norm ); bindNorm( *L.k_norm ); bindLinear( *L.o_proj ); bindNorm( *L.post_attn_norm );
+                bindNorm( *L.pre_ffn_norm ); bindLinear( *L.fc_gate_up ); bindLinear( *L.fc_down ); bindNorm( *L.post_ffn_norm );
+                Layer* lp = &L;
+                sinks[ "gemma.layer_" + std::to_string( i ) + ".layer_scalar" ] = [ lp ]( const Serialization::SafeTensorsEntry& e )
+                {
+                    if ( e.dtype != "F32" || e.elements() != 1 ) throw std::invalid_argument( e.name + ": layer_scalar must be one F32" );
+                    std::memcpy( &lp->layer_scalar, e.data, 4 );
+                };
+            }
+            bindNorm( *final_norm_ );
+            bindLinear( *lm_head_ );
+            // a quantized Linear loaded in storage form needs its scales too
+            std::vector<std::string> packed;
+            for ( const auto& e : r.entries() )
+            {
+                auto it = sinks.find( e.name );
+                if ( it == sinks.end() ) throw std::invalid_argument( "GemmaTransformer::loadSafeTensors: '" + path + "' holds an unknown tensor '" + e.name + "'" );
+                it->second( e );
+                if ( required.count( e.name ) ) required[ e.name ] = true;
+                if ( e.name.size() > 7 && e.name.compare( e.name.size() - 7, 7, ".weight" ) == 0 && e.dtype != "BF16" ) packed.push_back( e.name );
+            }
+            for ( auto& [ n, seen ] : required ) if ( !seen ) throw std::invalid_argument( "GemmaTransformer::loadSafeTensors: '" + path + "' lacks '" + n + "'" );
+            for ( auto& n : packed ) if ( !r.contains( n + "_scale" ) ) throw std::invalid_argument( "GemmaTransformer::loadSafeTensors: '" + n + "' is in storage form but '" + n + "_scale' is missing" );
+            // op-owned derived state (fp4 tensor scale, resident prefill weights) once every sibling is in place, whatever the file order
+            if constexpr ( TWeightQuant::kIsQuantized )
+                for ( auto& L : layers_ )
+                    for ( auto* lin : { L.qkv_proj.get(), L.o_proj.get(), L.fc_gate_up.get(), L.fc_down.get() } ) lin->getOperation().onQuantizedWeightsLoaded();
+            ctx_->synchronize();
+        }
+
         /// quantized policies: keep the prefill staging (fp8 -> bf16, fp4 -> e4m3) of every layer Linear resident (default on: +2 / +1
         /// bytes per weight of the 288 GB) or re-stage into scratch on every forward as the reference does; same bits
         void setResidentPrefillWeights( bool on )

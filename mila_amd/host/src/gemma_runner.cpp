@@ -138,6 +138,51 @@ HOST_API int mila_gemma_set_combine_in_oproj( void* h, int on )
     auto* r = static_cast<Runner*>( h );
     return guarded( [&] { std::visit( [&]( auto& m ) { m->setCombineInOProj( on != 0 ); }, r->model ); } );
 }
+/// every parameter of the model in its storage form -> a SafeTensors file / back (component paths as tensor names)
+HOST_API int mila_gemma_save_safetensors( void* h, const char* path )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&] { if ( !path ) throw std::invalid_argument( "save_safetensors: null path" ); std::visit( [&]( auto& m ) { m->saveSafeTensors( path ); }, r->model ); } );
+}
+HOST_API int mila_gemma_load_safetensors( void* h, const char* path )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&] { if ( !path ) throw std::invalid_argument( "load_safetensors: null path" ); std::visit( [&]( auto& m ) { m->loadSafeTensors( path ); }, r->model ); } );
+}
+/// host-only container checks (no device): list a file as "name dtype nbytes d0,d1,..\n" lines + "# key=value" metadata lines into out
+/// (returns the length needed, or < 0 with mila_gemma_last_error set); copy src -> dst tensor by tensor through the reader and the writer
+HOST_API int64_t mila_safetensors_list( const char* path, char* out, int64_t cap )
+{
+    int64_t need = -1;
+    const int rc = guarded( [&]
+    {
+        Mila::Dnn::Serialization::SafeTensorsReader rd( path ? path : "" );
+        std::string t;
+        for ( auto& e : rd.entries() )
+        {
+            t += e.name + " " + e.dtype + " " + std::to_string( e.nbytes() ) + " ";
+            for ( size_t d = 0; d < e.shape.size(); ++d ) t += ( d ? "," : "" ) + std::to_string( e.shape[ d ] );
+            t += "\n";
+        }
+        for ( auto& [ k, v ] : rd.metadata() ) t += "# " + k + "=" + v + "\n";
+        need = (int64_t)t.size();
+        if ( out && cap > 0 ) { const size_t n = std::min<size_t>( t.size(), (size_t)cap - 1 ); std::memcpy( out, t.data(), n ); out[ n ] = 0; }
+    } );
+    return rc ? rc : need;
+}
+HOST_API int mila_safetensors_copy( const char* src, const char* dst )
+{
+    return guarded( [&]
+    {
+        Mila::Dnn::Serialization::SafeTensorsReader rd( src ? src : "" );
+        Mila::Dnn::Serialization::SafeTensorsWriter wr( dst ? dst : "" );
+        for ( auto& e : rd.entries() ) wr.declareTensor( e.name, e.dtype, e.shape );
+        for ( auto& [ k, v ] : rd.metadata() ) wr.setMetadata( k, v );
+        wr.beginData();
+        for ( auto& e : rd.entries() ) wr.writeTensorData( e.name, e.data, e.nbytes() );
+        wr.close();
+    } );
+}
 /// on != 0 (default): quantized policies keep their prefill staging resident; 0: re-stage on every forward (the reference's way)
 HOST_API int mila_gemma_set_resident_prefill_weights( void* h, int on )
 {

@@ -173,6 +173,61 @@ def test_resident_prefill_weights_give_the_bits_of_per_forward_staging(policy):
     b.close()
 
 
+@pytest.mark.parametrize("policy", ["bf16", "fp8", "fp4"])
+def test_safetensors_round_trip_and_quantize_on_load(policy, tmp_path):
+    """weight ingestion: a model saved in its storage form reloads into a differently-initialised model
+    with identical logits; a BF16 checkpoint loads into a quantized model by quantize-on-load and gives the logits of the model whose
+    weights were quantized from the same bf16 values; the files are the public SafeTensors format (the Python package reads them)"""
+    st_torch = pytest.importorskip("safetensors.torch")      # torch carries bfloat16 / float8_e4m3fn, numpy does not
+    import torch
+    toks = [(7 * i + 3) % 2048 for i in range(24)]
+    a = host.Gemma(policy, MEDIUM, max_seq=MAX_SEQ, max_prefill=32, seed=5)
+    ref_prefill, ref_decode = a.prefill(toks), a.decode(11, len(toks), "fused")
+    f = tmp_path / ("gemma_%s.safetensors" % policy)
+    a.save_safetensors(f)
+    a.close()
+    names, meta = host.safetensors_list(f)
+    by = {n: (d, b, sh) for n, d, b, sh in names}
+    D, F = MEDIUM["embedding_dim"], MEDIUM["hidden_dim"]
+    want = {"bf16": ("BF16", 2 * F * D * 2, (2 * F, D)), "fp8": ("F8_E4M3", 2 * F * D, (2 * F, D)), "fp4": ("U8", 2 * F * D // 2, (2 * F, D // 2))}[policy]
+    assert by["gemma.layer_0.fc_gate_up.weight"] == want
+    assert ("gemma.layer_0.fc_gate_up.weight_scale" in by) == (policy != "bf16")
+    assert meta["mila_quantization"].startswith({"bf16": "NoWeightQuant", "fp8": "PerChannelFp8", "fp4": "PerGroupFp4"}[policy])
+    pub = st_torch.load_file(str(f))                                            # the public package reads the file
+    assert pub["gemma.final_norm.weight"].dtype == torch.bfloat16 and pub["gemma.final_norm.weight"].numel() == D
+    assert pub["gemma.layer_0.fc_gate_up.weight"].dtype == {"bf16": torch.bfloat16, "fp8": torch.float8_e4m3fn, "fp4": torch.uint8}[policy]
+    b = host.Gemma(policy, MEDIUM, max_seq=MAX_SEQ, max_prefill=32, seed=99)     # different synthetic weights
+    assert not np.array_equal(b.prefill(toks).view(np.uint32), ref_prefill.view(np.uint32))
+    b.load_safetensors(f)
+    assert np.array_equal(b.prefill(toks).view(np.uint32), ref_prefill.view(np.uint32))
+    assert np.array_equal(b.decode(11, len(toks), "fused").view(np.uint32), ref_decode.view(np.uint32))
+    b.close()
+    if policy != "bf16":
+        # the bf16 checkpoint of the same seed: the quantized model built from it must equal the one quantized at construction
+        # (the tied table keeps its own policy: the bf16 model's table is bf16, so it is taken from the quantized file)
+        src = host.Gemma("bf16", MEDIUM, max_seq=MAX_SEQ, max_prefill=32, seed=5)
+        fb = tmp_path / "gemma_bf16_src.safetensors"
+        src.save_safetensors(fb)
+        src.close()
+        c = host.Gemma(policy, MEDIUM, max_seq=MAX_SEQ, max_prefill=32, seed=99)
+        c.load_safetensors(fb)
+        assert np.array_equal(c.prefill(toks).view(np.uint32), ref_prefill.view(np.uint32))
+        c.close()
+    # errors: an unknown tensor, a missing one
+    t = dict(pub)
+    bad = tmp_path / "bad.safetensors"
+    st_torch.save_file(dict(t, **{"gemma.layer_0.bogus.weight": torch.zeros(4)}), str(bad))
+    d = host.Gemma(policy, MEDIUM, max_seq=MAX_SEQ, max_prefill=32, seed=1)
+    with pytest.raises(ValueError, match="unknown tensor"):
+        d.load_safetensors(bad)
+    t.pop("gemma.layer_1.o_proj.weight")
+    t.pop("gemma.layer_1.o_proj.weight_scale", None)
+    st_torch.save_file(t, str(bad))
+    with pytest.raises(ValueError, match="lacks"):
+        d.load_safetensors(bad)
+    d.close()
+
+
 def test_sampled_generation_degenerates_to_greedy_and_is_reproducible():
     """top_k = 1 and temperature <= 0 both reproduce the greedy continuation; a fixed seed reproduces a sampled one; and a
     sampled continuation only ever picks tokens inside the top-k set of the logits it was drawn from"""
