@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--onepass", type=int, default=None, help="1/0: split decode attention in one launch / with a combine launch (default: the model's)")
     ap.add_argument("--prefetch-mb", type=float, default=None, help="side-stream Infinity-Cache prefetch cap per Linear in MB (0 = off; default: the model's)")
     ap.add_argument("--prefetch-wgs", type=int, default=64)
+    ap.add_argument("--attn-split", type=int, default=None, help="tuning hook: positions per flash-decode split (default 64)")
+    ap.add_argument("--combine-in-oproj", type=int, default=None, help="1/0: fold the split combine into o_proj's prologue")
     ap.add_argument("--resident", type=int, default=None, help="1/0: resident prefill staging for the quantized policies (default: the model's = 1)")
     ap.add_argument("--gemm-schedule", type=int, default=None, help="tuning hook: 0 lockstep, 1 ping-pong (4 phases), 3 ping-pong (2 phases, default)")
     ap.add_argument("--warm", default=None, help="blocks_a,cap_a_MB,blocks_b,cap_b_MB: warm-ahead workgroups of the attention / combine launches")
@@ -113,6 +115,8 @@ def main():
     from mila_amd import capi, host
     capi.load()
     capi.check(capi.load().mila_cdna4_set_device(local_rank))
+    if a.attn_split is not None:
+        capi.load().mila_cdna4_tune_attn_split(a.attn_split)
     if a.gemm_schedule is not None:
         capi.load().mila_cdna4_tune_gemm_schedule(a.gemm_schedule)
     cfg = dict(host.GEMMA4_12B)
@@ -120,6 +124,8 @@ def main():
     results = {}
     for pol in policies:
         m = host.Gemma(pol, cfg, max_seq=CONTEXT + a.steps + a.warmup + 8, max_prefill=1 if a.no_prefill else CONTEXT, seed=1234)
+        if a.combine_in_oproj is not None:
+            m.set_combine_in_oproj(a.combine_in_oproj)
         if a.resident is not None:
             m.set_resident_prefill_weights(a.resident)
         if a.onepass is not None:

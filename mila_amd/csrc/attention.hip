@@ -21,6 +21,7 @@
 #include "common.h"
 #include "rms_common.h"
 #include "rope_common.h"
+#include "internal.h"
 
 namespace mila {
 
@@ -566,6 +567,8 @@ static int dispatch_hs(int HS, const AttnParams& p, int B, hipStream_t s)
     }
 }
 
+static int g_tune_positions_per_split = 64;     // tuning hook (mila_cdna4_tune_attn_split): positions one split covers
+
 static int decode_splits(int B, int NH, int NKV, int HS, int band)
 {
     // ~256 workgroups of 8 waves, 64 positions (8 per wave) per split
@@ -573,7 +576,7 @@ static int decode_splits(int B, int NH, int NKV, int HS, int band)
     const int hgroups = GS / heads_per_group(GS, HS);
     int cap = 256 / (NKV * hgroups * B);
     if (cap < 1) cap = 1;
-    int s = (band + 63) / 64;
+    int s = (band + g_tune_positions_per_split - 1) / g_tune_positions_per_split;
     if (s > cap) s = cap;
     if (s > kMaxSplits) s = kMaxSplits;
     if (s < 1) s = 1;
@@ -608,6 +611,12 @@ static int run_decode(uint16_t* Y, const uint16_t* Q, uint16_t* Kc, uint16_t* Vc
 using namespace mila;
 
 extern "C" {
+
+int mila_cdna4_tune_attn_split(int positions_per_split)
+{
+    g_tune_positions_per_split = (positions_per_split >= 8) ? positions_per_split : 64;
+    return MILA_OK;
+}
 
 int mila_cdna4_kv_write_bf16(uint16_t* Kc, uint16_t* Vc, const uint16_t* k, const uint16_t* v, int B, int chunk, int NKV,
                              int HS, int start_pos, int capacity, mila_stream_t stream)
