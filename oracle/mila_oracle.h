@@ -18,10 +18,12 @@
  *   - GELU-tanh/SiLU/...: pinned bit-for-bit against the reference's own functor header compiled
  *     from /root/reference (oracle/_ref, built by oracle/Makefile when the reference is present).
  *   - every other op: pinned by the reference tests' closed-form generators + in-test host
- *     references restated in tests/test_oracle_reference_kats.py (the reference ships no
+ *     references restated in tests/test_oracle_kats.py (the reference ships no
  *     golden-vector files), and by fixtures under tests/golden/.
- *   - Gemma block/transformer wiring: "parity unpinned" at block level in-tree (the reference
- *     only asserts shapes/finiteness there).
+ *   - net-level wiring (GPT-2 forward here; the Gemma-4 composition tests/ref_gemma.py over these ops): the reference's own
+ *     tree asserts only shapes/finiteness there, so the wiring is pinned against the implementation the reference validates
+ *     its checkpoints against -- the transformers GPT2LMHeadModel / Gemma4ForCausalLM FP32 logits on synthetic weights,
+ *     committed as tests/golden/gpt2_hf_logits.npz and gemma4_hf_logits.npz with their generating scripts.
  */
 #ifndef MILA_ORACLE_H
 #define MILA_ORACLE_H
