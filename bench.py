@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
-MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense, MI355X_MICROARCH.md
+MFMA_FP8_PEAK_TFLOPS = 5000.0       # dense e4m3 (block-scaled MFMA): the fp4 policy's W4A8 prefill runs its Linears there
 CONTEXT = 2048                # BASELINE.json configs[2..4]: B=1, T=2048
 
 
@@ -151,7 +152,10 @@ def main():
             r["prefill_ms"] = round(ms, 3)
             r["prefill_TFLOPs"] = round((lin + att) / ms / 1e9, 2)
             r["prefill_tok_s"] = round(CONTEXT / ms * 1e3, 1)
-            r["prefill_mfma_frac"] = round((lin + att) / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)
+            # the fp4 policy's Linears (97 % of the FLOPs) run on the fp8 matrix cores, attention on the bf16 ones: price each part at its own peak
+            ideal_ms = (lin / (MFMA_FP8_PEAK_TFLOPS if pol == "fp4" else MFMA_BF16_PEAK_TFLOPS) + att / MFMA_BF16_PEAK_TFLOPS) / 1e9
+            r["prefill_mfma_frac"] = round(ideal_ms / ms, 4)
+            r["prefill_mfma_peak_TFLOPs"] = {"linear": MFMA_FP8_PEAK_TFLOPS if pol == "fp4" else MFMA_BF16_PEAK_TFLOPS, "attention": MFMA_BF16_PEAK_TFLOPS}
         ranks.barrier()
         torch.cuda.synchronize()
         t = m.time_decode(CONTEXT, a.steps, a.warmup, a.mode)
