@@ -74,9 +74,10 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
     constexpr int CH_PER_THREAD = (kKeysPerTile * (ROWB / 16)) / 256;   // 16-byte chunks each thread stages per tile
     static_assert(CH_PER_THREAD >= 1, "tile too small");
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [K tile | V tile]
-    unsigned char* ldsK = smem;
-    unsigned char* ldsV = smem + TILE_BYTES;
+    // TWO [K tile | V tile] buffers: tile t is stored into buffer t & 1 while slower waves still read tile t - 1 from the other one, so a
+    // tile costs one workgroup barrier instead of two (the store of tile t follows the barrier of tile t - 1, which every wave reaches
+    // only after its reads of tile t - 2)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
             }
         }
     };
-    auto stage_store = [&](const StageRegs& r) {
+    auto stage_store = [&](const StageRegs& r, unsigned char* ldsK, unsigned char* ldsV) {
 #pragma unroll
         for (int i = 0; i < CH_PER_THREAD; ++i)
         {
@@ -178,8 +179,9 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
     if constexpr (DEEP) stage_load(rb, kt0 + kKeysPerTile);
     auto tile = [&](int t, StageRegs& regs) {
         const int kt = kt0 + t * kKeysPerTile;
-        __syncthreads();                     // previous tile fully consumed
-        stage_store(regs);
+        unsigned char* ldsK = smem + (t & 1) * 2 * TILE_BYTES;
+        unsigned char* ldsV = ldsK + TILE_BYTES;
+        stage_store(regs, ldsK, ldsV);
         __syncthreads();
         // DEEP: two tiles ahead, in flight during this tile's and the next one's math; else the next tile
         if (DEEP || t + 1 < ntiles) stage_load(regs, kt + (DEEP ? 2 : 1) * kKeysPerTile);
@@ -464,7 +466,7 @@ template <int HS, int HB>
 static int launch_flash(const FlashParams& p, int B, hipStream_t s)
 {
     constexpr int QROWS = 16 * (4 / HB);
-    const size_t lds = (size_t)2 * kKeysPerTile * HS * 2;
+    const size_t lds = (size_t)(HS >= 512 ? 2 : 4) * kKeysPerTile * HS * 2;      // HS <= 256: two [K | V] buffers
     FlashParams q = p;
     q.n_qtiles = (p.Tq + QROWS - 1) / QROWS;
     q.n_hblk = p.NH / HB;
