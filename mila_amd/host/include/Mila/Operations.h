@@ -241,17 +241,27 @@ namespace Mila::Dnn::Compute
             if ( !resident_ || !weight_ || !scales_ ) return;
             const int K = narrowToKernelIndex( cfg_.in_features, "in_features" ), N = narrowToKernelIndex( cfg_.out_features, "out_features" );
             mila_stream_t st = this->context_->getStream();
-            if constexpr ( kFmt == 1 )
+            // the shadows are an optimisation: if the device cannot hold them, fall back to per-forward staging (same results)
+            try
             {
-                if ( !resident_bf16_ ) resident_bf16_ = std::make_unique<RocmBf16Tensor>( this->context_->getDeviceId(), shape_t{ cfg_.out_features, cfg_.in_features } );
-                rocmCheck( mila_cdna4_dequantize_to_bf16( resident_bf16_->data(), weight_, scales_, 1, N, K, 0, st ) );
+                if constexpr ( kFmt == 1 )
+                {
+                    if ( !resident_bf16_ ) resident_bf16_ = std::make_unique<RocmBf16Tensor>( this->context_->getDeviceId(), shape_t{ cfg_.out_features, cfg_.in_features } );
+                }
+                else if constexpr ( kFmt == 2 )
+                {
+                    if ( !weight_fp8_scale_ || K % 32 != 0 ) return;
+                    if ( !resident_e4m3_ ) resident_e4m3_ = std::make_unique<Tensor<TensorDataType::FP8_E4M3, RocmDeviceMemoryResource>>( this->context_->getDeviceId(), shape_t{ cfg_.out_features, cfg_.in_features } );
+                }
             }
+            catch ( const std::exception& )
+            {
+                resident_ = false; resident_bf16_.reset(); resident_e4m3_.reset();
+                return;
+            }
+            if constexpr ( kFmt == 1 ) rocmCheck( mila_cdna4_dequantize_to_bf16( resident_bf16_->data(), weight_, scales_, 1, N, K, 0, st ) );
             else if constexpr ( kFmt == 2 )
-            {
-                if ( !weight_fp8_scale_ || K % 32 != 0 ) return;
-                if ( !resident_e4m3_ ) resident_e4m3_ = std::make_unique<Tensor<TensorDataType::FP8_E4M3, RocmDeviceMemoryResource>>( this->context_->getDeviceId(), shape_t{ cfg_.out_features, cfg_.in_features } );
                 rocmCheck( mila_cdna4_upcast_fp4_to_fp8( resident_e4m3_->data(), static_cast<const uint8_t*>( weight_ ), scales_, weight_fp8_scale_->data(), N, K, kGroup, st ) );
-            }
         }
     };
 
