@@ -138,6 +138,9 @@ def main():
             m.set_warm_ahead(int(wa), int(ca * 1e6), int(wb), int(cb * 1e6))
         info = m.info(CONTEXT)
         r = {"weight_GB": round(info["weight_bytes"] / 1e9, 3), "bytes_per_token_GB": round(info["decode_bytes_per_token"] / 1e9, 3)}
+        # the quantized policies keep their prefill staging resident: HBM it costs beside the quantized weights
+        resident = a.resident is None or bool(a.resident)
+        r["resident_prefill_weights_GB"] = round(info["linear_params"] * {"bf16": 0, "fp8": 2, "fp4": 1}[pol] / 1e9, 3) if resident else 0.0
         if not a.no_prefill:
             ms = m.time_prefill(CONTEXT, 1)
             # algorithmic FLOPs: Linear 2*params*T + head (last position) + attention 4*NH*HS*sum(keys)
