@@ -43,6 +43,9 @@ __global__ __launch_bounds__(256) void rmsnorm_block_kernel(uint16_t* __restrict
 // (rms_rstd_block) and element functions, so the outputs carry the same bits as the unfused launches.
 // One workgroup per row, dim <= 8 * 256 * kTailChunks.
 constexpr int kTailChunks = 4;
+// NCH = 16-byte chunks per thread actually needed (ceil(dim / 8 / 256)): a row of 3840 takes 2, not kTailChunks -- the groups a
+// smaller NCH leaves out are exactly the empty ones (g >= G), so the sums and their order do not change
+template <int NCH>
 __global__ __launch_bounds__(256) void tail_norm_kernel(uint16_t* __restrict__ R, uint16_t* __restrict__ XN,
                                                         const uint16_t* __restrict__ A, const uint16_t* __restrict__ RES,
                                                         const uint16_t* __restrict__ post_w, const uint16_t* __restrict__ next_w,
@@ -55,16 +58,16 @@ __global__ __launch_bounds__(256) void tail_norm_kernel(uint16_t* __restrict__ R
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int nx16 = dim / 8, G = (nx16 + 63) / 64;
     // chunk c = 64 g + lane of group g = wib + 4 k: the assignment rms_rstd_block<4> uses
-    u32x4 av[kTailChunks], rv[kTailChunks];
+    u32x4 av[NCH], rv[NCH];
 #pragma unroll
-    for (int k = 0; k < kTailChunks; ++k)
+    for (int k = 0; k < NCH; ++k)
     {
         const int c = 64 * (wib + 4 * k) + lane;
         av[k] = ld16(a + (size_t)min(c, nx16 - 1) * 8);
     }
     {
 #pragma unroll
-        for (int k = 0; k < kTailChunks; ++k)
+        for (int k = 0; k < NCH; ++k)
         {
             const int g = wib + 4 * k, c = 64 * g + lane;
             float s = c < nx16 ? sumsq8(av[k], 0.0f) : 0.0f;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void tail_norm_kernel(uint16_t* __restrict__ R
     for (int g = 0; g < G; ++g) t += red_a[g];
     const float rstd_a = rsqrtf(t / (float)dim + eps);
 #pragma unroll
-    for (int k = 0; k < kTailChunks; ++k)
+    for (int k = 0; k < NCH; ++k)
     {
         const int g = wib + 4 * k, c = 64 * g + lane;
         const size_t e = (size_t)min(c, nx16 - 1) * 8;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void tail_norm_kernel(uint16_t* __restrict__ R
     for (int g = 0; g < G; ++g) t2 += red_b[g];
     const float rstd_r = rsqrtf(t2 / (float)dim + eps);
 #pragma unroll
-    for (int k = 0; k < kTailChunks; ++k)
+    for (int k = 0; k < NCH; ++k)
     {
         const int c = 64 * (wib + 4 * k) + lane;
         if (c < nx16) st16(XN + row * dim + (size_t)c * 8, rms_apply8(rv[k], ld16(next_w + (size_t)c * 8), rstd_r, 0.0f));
@@ -258,7 +261,11 @@ int mila_cdna4_fused_tail_norm_bf16(uint16_t* R, uint16_t* XN, const uint16_t* A
     MILA_REQUIRE((XN == nullptr) == (next_w == nullptr), "fused_tail_norm_bf16: XN and next_w go together");
     MILA_REQUIRE(rows > 0 && dim > 0, "fused_tail_norm_bf16: rows/dim must be positive (%d,%d)", rows, dim);
     MILA_REQUIRE(dim % 8 == 0 && dim > 1024 && dim <= 8 * 256 * kTailChunks, "fused_tail_norm_bf16: dim=%d must be a multiple of 8 in (1024, %d]", dim, 8 * 256 * kTailChunks);
-    hipLaunchKernelGGL(tail_norm_kernel, dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps);
+    const int nch = (dim / 8 + 255) / 256;
+    if (nch <= 1) hipLaunchKernelGGL(tail_norm_kernel<1>, dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps);
+    else if (nch == 2) hipLaunchKernelGGL(tail_norm_kernel<2>, dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps);
+    else if (nch == 3) hipLaunchKernelGGL(tail_norm_kernel<3>, dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps);
+    else hipLaunchKernelGGL(tail_norm_kernel<4>, dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps);
     MILA_LAUNCH_CHECK("fused_tail_norm_bf16");
 }
 
