@@ -172,6 +172,9 @@ __global__ __launch_bounds__(256) void upcast_fp4_to_fp8_kernel(uint8_t* __restr
 }
 
 // per-token activation quantization: scale = max(absmax(row), 1e-12) / 448, q = e4m3(x * (1 / scale))  (CudaFp8Prefill.cu:108-160)
+// One workgroup per row; the row stays in registers between the absmax pass and the encoding pass (NCH 16-byte chunks per thread:
+// K <= 2048 NCH; NCH = 0 re-reads the row for longer ones).
+template <int NCH>
 __global__ __launch_bounds__(256) void quantize_fp8_per_token_kernel(uint8_t* __restrict__ dst, float* __restrict__ scales,
                                                                      const uint16_t* __restrict__ src, int K)
 {
@@ -181,20 +184,35 @@ __global__ __launch_bounds__(256) void quantize_fp8_per_token_kernel(uint8_t* __
     uint8_t* d = dst + row * K;
     const int nvec = K / 8;
     float m = 0.0f;
-    for (int i = threadIdx.x; i < nvec; i += 256)
+    u32x4 keep[NCH > 0 ? NCH : 1];
+    if constexpr (NCH > 0)
     {
-        const u32x4 v = ld16(s + (size_t)i * 8);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(fabsf(bf16_lo(v[e])), fabsf(bf16_hi(v[e]))));
+        for (int k = 0; k < NCH; ++k)
+        {
+            const int i = threadIdx.x + 256 * k;
+            keep[k] = (i < nvec) ? ld16(s + (size_t)i * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(fabsf(bf16_lo(keep[k][e])), fabsf(bf16_hi(keep[k][e]))));
+    }
+    else
+    {
+        for (int i = threadIdx.x; i < nvec; i += 256)
+        {
+            const u32x4 v = ld16(s + (size_t)i * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(fabsf(bf16_lo(v[e])), fabsf(bf16_hi(v[e]))));
+        }
     }
     m = block_max<4>(m, red);
     const float scale = fmaxf(m, 1e-12f) / 448.0f;
     if (threadIdx.x == 0) scales[row] = scale;
     const float inv = 1.0f / scale;
-    for (int i = threadIdx.x; i < nvec; i += 256)
-    {
-        const u32x4 v = ld16(s + (size_t)i * 8);
-        // |x * inv| <= 448 (1 + 2^-23): the hardware convert (RNE) needs no clamp here, and a NaN stays a NaN (0x7f)
+    // |x * inv| <= 448 (1 + 2^-23): the hardware convert (RNE) needs no clamp here, and a NaN stays a NaN (0x7f)
+    auto encode = [&](const u32x4 v, int i) {
         u32x2 o;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -204,6 +222,19 @@ __global__ __launch_bounds__(256) void quantize_fp8_per_token_kernel(uint8_t* __
             o[h] = (uint32_t)r;
         }
         *reinterpret_cast<u32x2*>(d + (size_t)i * 8) = o;
+    };
+    if constexpr (NCH > 0)
+    {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+        {
+            const int i = threadIdx.x + 256 * k;
+            if (i < nvec) encode(keep[k], i);
+        }
+    }
+    else
+    {
+        for (int i = threadIdx.x; i < nvec; i += 256) encode(ld16(s + (size_t)i * 8), i);
     }
 }
 
@@ -272,7 +303,11 @@ int mila_cdna4_quantize_fp8_per_token(uint8_t* dst, float* scales, const uint16_
 {
     MILA_REQUIRE(dst && scales && src, "quantize_fp8_per_token: null pointer");
     MILA_REQUIRE(M > 0 && K > 0 && K % 8 == 0, "quantize_fp8_per_token: bad sizes (M=%d K=%d)", M, K);
-    hipLaunchKernelGGL(quantize_fp8_per_token_kernel, dim3(M), dim3(256), 0, as_stream(stream), dst, scales, src, K);
+    const int nch = (K / 8 + 255) / 256;
+    if (nch <= 2) hipLaunchKernelGGL(quantize_fp8_per_token_kernel<2>, dim3(M), dim3(256), 0, as_stream(stream), dst, scales, src, K);
+    else if (nch <= 4) hipLaunchKernelGGL(quantize_fp8_per_token_kernel<4>, dim3(M), dim3(256), 0, as_stream(stream), dst, scales, src, K);
+    else if (nch <= 8) hipLaunchKernelGGL(quantize_fp8_per_token_kernel<8>, dim3(M), dim3(256), 0, as_stream(stream), dst, scales, src, K);
+    else hipLaunchKernelGGL(quantize_fp8_per_token_kernel<0>, dim3(M), dim3(256), 0, as_stream(stream), dst, scales, src, K);
     MILA_LAUNCH_CHECK("quantize_fp8_per_token");
 }
 
