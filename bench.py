@@ -117,9 +117,9 @@ def main():
     capi.load()
     capi.check(capi.load().mila_cdna4_set_device(local_rank))
     if a.attn_split is not None:
-        capi.load().mila_cdna4_tune_attn_split(a.attn_split)
+        capi.check(capi.load().mila_cdna4_tune_attn_split(a.attn_split))
     if a.gemm_schedule is not None:
-        capi.load().mila_cdna4_tune_gemm_schedule(a.gemm_schedule)
+        capi.check(capi.load().mila_cdna4_tune_gemm_schedule(a.gemm_schedule))
     cfg = dict(host.GEMMA4_12B)
     policies = [p for p in a.policies.split(",") if p]
     results = {}

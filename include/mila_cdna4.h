@@ -224,7 +224,7 @@ MILA_API int mila_cdna4_mha_bf16(uint16_t* Y, const uint16_t* QKV, int B, int T,
  * residual:  replaces Residual/Kernels/Residual.Bf16.cu:15-40.
  * ------------------------------------------------------------------------------------------- */
 MILA_API int mila_cdna4_rmsnorm_bf16(uint16_t* Y, uint16_t* rstd, const uint16_t* X, const uint16_t* w,
-                                     const uint16_t* b, int outer, int dim, int inner, float eps,
+                                     const uint16_t* b, int outer, int inner, int dim, float eps,
                                      float w_offset, mila_stream_t stream);
 MILA_API int mila_cdna4_layernorm_bf16(uint16_t* Y, float* mean, float* rstd, const uint16_t* X,
                                        const uint16_t* w, const uint16_t* b, int outer, int dim,
@@ -280,6 +280,11 @@ MILA_API int mila_cdna4_split3_bf16(uint16_t* a, uint16_t* b, uint16_t* c, const
                                     int na, int nb, int nc, mila_stream_t stream);
 MILA_API int mila_cdna4_scale_bf16(uint16_t* Y, const uint16_t* X, int64_t n, float s,
                                    mila_stream_t stream);
+/* Synthetic parameters, generated where they live: dst[i] = bf16(offset + amp * (2u - 1)), u in [0, 1) from the counter-based
+ * splitmix64(seed, i) -- the same bits for the same (seed, i) on any grid, so the CPU oracle regenerates them without a file
+ * (SURVEY.md section 8d).  Stands where the reference's initializeParameters kernels do (Linear.ixx:1029-1054); no checkpoint exists offline. */
+MILA_API int mila_cdna4_fill_uniform_bf16(uint16_t* dst, int64_t n, uint64_t seed, float amp, float offset,
+                                          mila_stream_t stream);
 MILA_API int mila_cdna4_convert_f32_to_bf16(uint16_t* Y, const float* X, int64_t n, mila_stream_t stream);
 MILA_API int mila_cdna4_convert_bf16_to_f32(float* Y, const uint16_t* X, int64_t n, mila_stream_t stream);
 

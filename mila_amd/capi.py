@@ -129,7 +129,7 @@ EXPORTED = [
     "gelu_bf16", "gelu_fp32", "geglu_bf16", "residual_bf16", "residual_fp32",
     "rope_build_cache", "rope_forward_bf16",
     "embedding_gather_bf16", "embedding_gather_bf16_qfp8", "lpe_bf16", "split3_bf16", "scale_bf16",
-    "convert_f32_to_bf16", "convert_bf16_to_f32",
+    "convert_f32_to_bf16", "convert_bf16_to_f32", "fill_uniform_bf16",
     "sample_scratch_bytes", "sample_argmax_fp32", "sample_argmax_bf16",
     "sample_stochastic_scratch_bytes", "sample_stochastic_fp32", "sample_stochastic_bf16",
     "fused_norm_matvec", "fused_qkv_post", "fused_qkv_post_prefill", "fused_tail_norm_bf16",

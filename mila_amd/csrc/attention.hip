@@ -614,6 +614,7 @@ extern "C" {
 
 int mila_cdna4_tune_attn_split(int positions_per_split)
 {
+    if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
     g_tune_positions_per_split = (positions_per_split >= 8) ? positions_per_split : 64;
     return MILA_OK;
 }

@@ -10,6 +10,10 @@ namespace mila {
 
 // ---- host-side error plumbing ----------------------------------------------------------------
 int set_error(int code, const char* fmt, ...);   // runtime.hip; returns `code`
+/// the mila_cdna4_tune_* hooks (csrc/internal.h) mutate process-wide launch heuristics: they act only in a process that set
+/// MILA_CDNA4_TUNING=1 before the library was loaded (tests, tools/); in any other process they return MILA_E_UNSUPPORTED and
+/// the library keeps no state between calls
+bool tuning_hooks_enabled();
 int check_hip(hipError_t e, const char* what);   // MILA_OK or MILA_E_RUNTIME (+ message)
 
 #define MILA_REQUIRE(cond, ...)                                        \

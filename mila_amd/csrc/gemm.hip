@@ -395,12 +395,14 @@ extern "C" {
 
 int mila_cdna4_tune_gemm(int force_128_tile)
 {
+    if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
     g_gemm_force128 = force_128_tile;
     return MILA_OK;
 }
 
 int mila_cdna4_tune_gemm_schedule(int pingpong)
 {
+    if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
     g_gemm_pingpong = pingpong;
     return MILA_OK;
 }

@@ -1,5 +1,7 @@
 // Test / tuning hooks exported by the shared object but NOT part of the drop-in ABI
-// (include/mila_cdna4.h).  Used by tests/ and the micro-benchmarks only.
+// (include/mila_cdna4.h).  Used by tests/ and the micro-benchmarks only; nothing under mila_amd/host includes this file.
+// The mila_cdna4_tune_* hooks change process-wide launch heuristics, so they are INERT (MILA_E_UNSUPPORTED, nothing stored)
+// unless the process set MILA_CDNA4_TUNING=1 before the library was loaded: a product process cannot reach that state.
 #pragma once
 #include "../../include/mila_cdna4.h"
 
@@ -25,9 +27,6 @@ MILA_API int mila_cdna4_selftest_mfma_fp8(float* C, const uint8_t* A, const uint
 /* streaming-copy ceiling: dst <- src with 16-byte accesses; used to report a measured HBM roof */
 MILA_API int mila_cdna4_stream_copy(void* dst, const void* src, size_t bytes, mila_stream_t stream);
 MILA_API int mila_cdna4_stream_read(float* sink, const void* src, size_t bytes, mila_stream_t stream);
-/* synthetic parameters: dst[i] = bf16(offset + amp * (2u - 1)), u from splitmix64(seed, i) */
-MILA_API int mila_cdna4_fill_uniform_bf16(uint16_t* dst, int64_t n, uint64_t seed, float amp, float offset,
-                                          mila_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -195,6 +195,7 @@ extern "C" {
 
 int mila_cdna4_tune_matvec(int R, int U, int max_blocks)
 {
+    if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
     g_tune_R = R;
     g_tune_U = U;
     g_tune_blocks = max_blocks;

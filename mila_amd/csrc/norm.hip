@@ -230,10 +230,10 @@ using namespace mila;
 extern "C" {
 
 int mila_cdna4_rmsnorm_bf16(uint16_t* Y, uint16_t* rstd, const uint16_t* X, const uint16_t* w, const uint16_t* b,
-                            int outer, int dim, int inner, float eps, float w_offset, mila_stream_t stream)
+                            int outer, int inner, int dim, float eps, float w_offset, mila_stream_t stream)
 {
     MILA_REQUIRE(Y && X, "rmsnorm_bf16: null pointer");
-    MILA_REQUIRE(outer > 0 && dim > 0 && inner > 0, "rmsnorm_bf16: outer/dim/inner must be positive (%d,%d,%d)", outer, dim, inner);
+    MILA_REQUIRE(outer > 0 && dim > 0 && inner > 0, "rmsnorm_bf16: outer/inner/dim must be positive (%d,%d,%d)", outer, inner, dim);
     MILA_REQUIRE(!(b && !w), "rmsnorm_bf16: bias without weight is not a reference configuration");
     hipStream_t s = as_stream(stream);
     if (inner == 1 && dim % 8 == 0)

@@ -5,11 +5,19 @@
 #include <cstdio>
 #include <cstring>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace mila {
 
 static thread_local char g_last_error[512] = "";
+
+bool tuning_hooks_enabled()
+{
+    static const bool on = [] { const char* v = std::getenv("MILA_CDNA4_TUNING"); return v && v[0] == '1'; }();
+    return on;
+}
 
 int set_error(int code, const char* fmt, ...)
 {
@@ -34,7 +42,7 @@ extern "C" {
 
 const char* mila_cdna4_last_error(void) { return g_last_error; }
 
-int mila_cdna4_abi_version(void) { return 1; }
+int mila_cdna4_abi_version(void) { return 2; }
 
 int mila_cdna4_device_count(int* count)
 {

@@ -36,6 +36,7 @@ def load():
         _lib.mila_gemma_create.restype = C.c_void_p
         _lib.mila_gemma_create.argtypes = [C.c_int, C.POINTER(GemmaConfigC), C.c_int64, C.c_int64, C.c_uint64, C.c_int]
         _lib.mila_gemma_destroy.argtypes = [C.c_void_p]
+        _lib.mila_gemma_init_synthetic.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         _lib.mila_gemma_prefill.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         _lib.mila_gemma_decode.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int, C.c_void_p]
         _lib.mila_gemma_time_decode.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -53,6 +54,13 @@ def load():
         _lib.mila_gemma_set_resident_prefill_weights.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_save_safetensors.argtypes = [C.c_void_p, C.c_char_p]
         _lib.mila_gemma_load_safetensors.argtypes = [C.c_void_p, C.c_char_p]
+        _lib.mila_gemma_save_milabin.argtypes = [C.c_void_p, C.c_char_p]
+        _lib.mila_gemma_load_pretrained.argtypes = [C.c_void_p, C.c_char_p]
+        _lib.mila_pretrained_list.restype = C.c_int64
+        _lib.mila_pretrained_list.argtypes = [C.c_char_p, C.c_char_p, C.c_int64]
+        _lib.mila_pretrained_to_milabin.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+        _lib.mila_pretrained_metadata_roundtrip.restype = C.c_int64
+        _lib.mila_pretrained_metadata_roundtrip.argtypes = [C.c_char_p, C.c_char_p, C.c_int64]
         _lib.mila_safetensors_list.restype = C.c_int64
         _lib.mila_safetensors_list.argtypes = [C.c_char_p, C.c_char_p, C.c_int64]
         _lib.mila_safetensors_copy.argtypes = [C.c_char_p, C.c_char_p]
@@ -82,8 +90,10 @@ class Gemma:
 
     MODES = {"reference": 0, "fused": 1, "graph": 2}
 
-    def __init__(self, policy="bf16", config=None, max_seq=4096, max_prefill=1, seed=1234, device=None):
-        """device: HIP device ordinal; default = this process's LOCAL_RANK (one replica per GPU under torch.distributed.run)"""
+    def __init__(self, policy="bf16", config=None, max_seq=4096, max_prefill=1, seed=1234, device=None, profile=None):
+        """device: HIP device ordinal; default = this process's LOCAL_RANK (one replica per GPU under torch.distributed.run).
+        profile: synthetic-parameter multipliers {linear_gain, qk_norm_center, post_norm_center, layer_scalar, table_gain}
+        (GemmaTransformer::SyntheticProfile; None = the unit-scale generator of SURVEY.md section 8d)"""
         lib = load()
         if device is None:
             from .replicas import local_device
@@ -97,6 +107,9 @@ class Gemma:
         if not self.h:
             text = lib.mila_host_last_error().decode()
             raise (ValueError if text.startswith("invalid_argument") else RuntimeError)("mila_gemma_create: " + text)
+        if profile is not None:
+            p = (C.c_float * 5)(*[float(profile[k]) for k in ("linear_gain", "qk_norm_center", "post_norm_center", "layer_scalar", "table_gain")])
+            _check(lib.mila_gemma_init_synthetic(self.h, seed, p))
 
     def close(self):
         if self.h:
@@ -126,6 +139,14 @@ class Gemma:
     def load_safetensors(self, path):
         """load every parameter from a SafeTensors file; bf16 Linear weights are quantized on load under a quantized policy"""
         _check(load().mila_gemma_load_safetensors(self.h, str(path).encode()))
+
+    def save_milabin(self, path):
+        """the same tensors in the reference's MILA .bin container (what fromPretrained streams)"""
+        _check(load().mila_gemma_save_milabin(self.h, str(path).encode()))
+
+    def load_pretrained(self, path):
+        """load every parameter from a MILA .bin or a SafeTensors artifact (sniffed by the leading magic)"""
+        _check(load().mila_gemma_load_pretrained(self.h, str(path).encode()))
 
     def set_resident_prefill_weights(self, on):
         """quantized policies: keep the prefill staging of every layer Linear (fp8 -> bf16, fp4 -> e4m3) resident in HBM (default)
@@ -263,3 +284,36 @@ def safetensors_list(path):
 def safetensors_copy(src, dst):
     """host-only: rewrite src as dst through the C++ reader and writer"""
     _check(load().mila_safetensors_copy(str(src).encode(), str(dst).encode()))
+
+
+def _text_call(fn, *args):
+    need = fn(*args, None, 0)
+    if need < 0:
+        _check(int(need))
+    buf = C.create_string_buffer(int(need) + 1)
+    fn(*args, buf, int(need) + 1)
+    return buf.value.decode()
+
+
+def pretrained_list(path):
+    """host-only: ([(name, dtype, nbytes, shape)] in ascending file-offset order, {container, mila_quantization, mila_config})
+    of a MILA .bin or SafeTensors file as the C++ PretrainedModelReader sees it"""
+    tensors, meta = [], {}
+    for line in _text_call(load().mila_pretrained_list, str(path).encode()).splitlines():
+        if line.startswith("# "):
+            k, v = line[2:].split("=", 1)
+            meta[k] = v
+        else:
+            name, dtype, nbytes, shape = (line.split(" ") + [""])[:4]
+            tensors.append((name, dtype, int(nbytes), tuple(int(d) for d in shape.split(",") if d)))
+    return tensors, meta
+
+
+def pretrained_to_milabin(src, dst, metadata_json=None):
+    """host-only: rewrite a SafeTensors (or MILA) file as a MILA .bin through the C++ reader and writer"""
+    _check(load().mila_pretrained_to_milabin(str(src).encode(), str(dst).encode(), None if metadata_json is None else metadata_json.encode()))
+
+
+def pretrained_metadata_roundtrip(json_text):
+    """host-only: toMetadataJSON(parseMetadataJSON(text))"""
+    return _text_call(load().mila_pretrained_metadata_roundtrip, json_text.encode())

@@ -298,25 +298,34 @@ namespace Mila::Dnn::Compute
             w_ = weight ? static_cast<const uint16_t*>( weight->rawData() ) : nullptr;
             b_ = bias ? static_cast<const uint16_t*>( bias->rawData() ) : nullptr;
         }
+        /// fixes the normalized (trailing) axis and the maximum slice count, and allocates the per-slice rstd the forward pass
+        /// writes -- op-owned, bf16 like the reference's (RmsNormOp.ixx:174-262: rstd_tensor_ of num_slices elements)
         void build( const BuildContext& ctx )
         {
             if ( ctx.inputShape().back() != cfg_.dim ) throw std::invalid_argument( "RocmRmsNormOp::build: trailing dimension does not match the normalized shape" );
+            const dim_t slices = shapeSize( ctx.inputShape() ) / cfg_.dim;
+            rstd_ = std::make_unique<TensorType>( context_->getDeviceId(), shape_t{ slices } );
             built_ = true;
         }
+        /// launch geometry follows the runtime tensor (built once at the prefill shape, decode arrives with one row, :271-300)
         void forward( const TensorType& in, TensorType& out ) const
         {
             if ( !built_ ) throw std::runtime_error( "RocmRmsNormOp::forward: not built" );
+            if ( in.shape().empty() || in.shape().back() != cfg_.dim ) throw std::runtime_error( "RocmRmsNormOp::forward: input shape is incompatible with the built normalization axis" );
             const int dim = narrowToKernelIndex( cfg_.dim, "dim" );
             const int outer = narrowToKernelIndex( static_cast<dim_t>( in.size() ) / cfg_.dim, "outer" );
-            rocmCheck( mila_cdna4_rmsnorm_bf16( static_cast<uint16_t*>( out.rawData() ), nullptr, static_cast<const uint16_t*>( in.rawData() ), w_, b_,
-                                                outer, dim, 1, cfg_.epsilon, cfg_.weight_offset, context_->getStream() ) );
+            if ( static_cast<size_t>( outer ) > rstd_->size() ) throw std::runtime_error( "RocmRmsNormOp::forward: runtime slice count exceeds the built maximum" );
+            rocmCheck( mila_cdna4_rmsnorm_bf16( static_cast<uint16_t*>( out.rawData() ), rstd_->data(), static_cast<const uint16_t*>( in.rawData() ), w_, b_,
+                                                outer, 1, dim, cfg_.epsilon, cfg_.weight_offset, context_->getStream() ) );
         }
+        const TensorType* rstd() const noexcept { return rstd_.get(); }
         const uint16_t* weightPtr() const noexcept { return w_; }
         float epsilon() const noexcept { return cfg_.epsilon; }
     private:
         NormOpConfig cfg_;
         const uint16_t* w_{ nullptr };
         const uint16_t* b_{ nullptr };
+        std::unique_ptr<TensorType> rstd_;
         bool built_{ false };
     };
     template<> struct OperationTraits<OperationType::RmsNormOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmRmsNormOp; };
@@ -547,7 +556,7 @@ namespace Mila::Dnn::Compute
         {
             requireCache();
             mila_stream_t st = context_->getStream();
-            const int NH = (int)cfg_.num_heads, NKV = (int)cfg_.num_kv_heads, HS = (int)cfg_.head_dim, cap = (int)capacity_;
+            const int NKV = (int)cfg_.num_kv_heads, HS = (int)cfg_.head_dim, cap = (int)capacity_;
             rocmCheck( mila_cdna4_kv_write_bf16( k_cache_->data(), v_cache_->data(), q_cast( k ), q_cast( v ), batch_, 1, NKV, HS, position, cap, st ) );
             attendDecode( q, out, position );
         }

@@ -25,7 +25,6 @@ namespace
                      std::unique_ptr<GemmaTransformer<PerGroupFp4<128>>>> model;
         std::unique_ptr<Tensor<TensorDataType::INT32, Compute::RocmDeviceMemoryResource>> tokens;
         dim_t max_prefill{ 1 };
-        bool graph_captured{ false };
     };
 
     template<typename F> int guarded( F&& f )
@@ -83,6 +82,22 @@ HOST_API void* mila_gemma_create( int policy, const mila_gemma_config* c, int64_
         r = rr.release();
     } );
     return rc == 0 ? r : nullptr;
+}
+
+/// regenerate the synthetic parameters under a profile: p = { linear_gain, qk_norm_center, post_norm_center, layer_scalar, table_gain }
+HOST_API int mila_gemma_init_synthetic( void* h, uint64_t seed, const float* p )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&]
+    {
+        if ( !p ) throw std::invalid_argument( "init_synthetic: null profile" );
+        std::visit( [&]( auto& m )
+        {
+            typename std::remove_reference_t<decltype( *m )>::SyntheticProfile pr;
+            pr.linear_gain = p[ 0 ]; pr.qk_norm_center = p[ 1 ]; pr.post_norm_center = p[ 2 ]; pr.layer_scalar = p[ 3 ]; pr.table_gain = p[ 4 ];
+            m->initSynthetic( seed, pr );
+        }, r->model );
+    } );
 }
 
 HOST_API void mila_gemma_destroy( void* h ) { delete static_cast<Runner*>( h ); }
@@ -148,6 +163,66 @@ HOST_API int mila_gemma_load_safetensors( void* h, const char* path )
 {
     auto* r = static_cast<Runner*>( h );
     return guarded( [&] { if ( !path ) throw std::invalid_argument( "load_safetensors: null path" ); std::visit( [&]( auto& m ) { m->loadSafeTensors( path ); }, r->model ); } );
+}
+/// the same tensors as a MILA .bin container / load from either container (sniffed by the leading magic, PretrainedReader.ixx:283-293)
+HOST_API int mila_gemma_save_milabin( void* h, const char* path )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&] { if ( !path ) throw std::invalid_argument( "save_milabin: null path" ); std::visit( [&]( auto& m ) { m->saveMilaBin( path ); }, r->model ); } );
+}
+HOST_API int mila_gemma_load_pretrained( void* h, const char* path )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&] { if ( !path ) throw std::invalid_argument( "load_pretrained: null path" ); std::visit( [&]( auto& m ) { m->loadPretrained( path ); }, r->model ); } );
+}
+/// host-only (no device): list either container as the PretrainedModelReader sees it -- "name dtype nbytes d0,d1,.." lines in ascending
+/// file-offset order, then "# container=mila|safetensors", "# mila_quantization=..", "# mila_config=<json>" lines
+HOST_API int64_t mila_pretrained_list( const char* path, char* out, int64_t cap )
+{
+    int64_t need = -1;
+    const int rc = guarded( [&]
+    {
+        Mila::Dnn::Serialization::PretrainedModelReader rd( path ? path : "" );
+        std::string t;
+        for ( auto& e : rd.entries() )
+        {
+            t += e.name + " " + e.dtype + " " + std::to_string( e.nbytes() ) + " ";
+            for ( size_t d = 0; d < e.shape.size(); ++d ) t += ( d ? "," : "" ) + std::to_string( e.shape[ d ] );
+            t += "\n";
+        }
+        t += std::string( "# container=" ) + ( rd.isMilaContainer() ? "mila" : "safetensors" ) + "\n";
+        t += "# mila_quantization=" + rd.getWeightQuantization() + "\n";
+        t += "# mila_config=" + rd.metadataJSON() + "\n";
+        need = (int64_t)t.size();
+        if ( out && cap > 0 ) { const size_t n = std::min<size_t>( t.size(), (size_t)cap - 1 ); std::memcpy( out, t.data(), n ); out[ n ] = 0; }
+    } );
+    return rc ? rc : need;
+}
+/// host-only: rewrite either container as a MILA .bin (tensor order = ascending source offsets); metadata_json == NULL keeps the source's
+HOST_API int mila_pretrained_to_milabin( const char* src, const char* dst, const char* metadata_json )
+{
+    return guarded( [&]
+    {
+        Mila::Dnn::Serialization::PretrainedModelReader rd( src ? src : "" );
+        Mila::Dnn::Serialization::MilaBinWriter wr( dst ? dst : "" );
+        for ( auto& e : rd.entries() ) wr.declareTensor( e.name, e.dtype, e.shape );
+        wr.setMetadataJSON( metadata_json ? std::string( metadata_json ) : rd.metadataJSON() );
+        wr.beginData();
+        for ( auto& e : rd.entries() ) wr.writeTensorData( e.name, e.data, e.nbytes() );
+        wr.close();
+    } );
+}
+/// host-only: the value the metadata parser extracts for `key` from a JSON text, round-tripped through toMetadataJSON (parser check)
+HOST_API int64_t mila_pretrained_metadata_roundtrip( const char* json, char* out, int64_t cap )
+{
+    int64_t need = -1;
+    const int rc = guarded( [&]
+    {
+        const std::string t = Mila::Dnn::Serialization::toMetadataJSON( Mila::Dnn::Serialization::parseMetadataJSON( json ? json : "" ) );
+        need = (int64_t)t.size();
+        if ( out && cap > 0 ) { const size_t n = std::min<size_t>( t.size(), (size_t)cap - 1 ); std::memcpy( out, t.data(), n ); out[ n ] = 0; }
+    } );
+    return rc ? rc : need;
 }
 /// host-only container checks (no device): list a file as "name dtype nbytes d0,d1,..\n" lines + "# key=value" metadata lines into out
 /// (returns the length needed, or < 0 with mila_gemma_last_error set); copy src -> dst tensor by tensor through the reader and the writer
@@ -236,7 +311,7 @@ HOST_API int mila_gemma_decode( void* h, int32_t token, int64_t position, int mo
             else if ( mode == 1 ) m->decodeFused( *r->tokens, position );
             else
             {
-                if ( !r->graph_captured ) { m->captureGraph( *r->tokens, position ); r->graph_captured = true; }
+                m->ensureGraph( *r->tokens, position );
                 m->setDevicePosition( position );
                 m->replayGraph();
             }
@@ -264,7 +339,7 @@ HOST_API int mila_gemma_time_decode( void* h, int64_t start_position, int steps,
             hipStream_t s = reinterpret_cast<hipStream_t>( ctx->getStream() );
             // every step ends with the greedy device sampler writing the next token: a real autoregressive loop
             m->setSampleInGraph( true );
-            if ( mode == 2 && !r->graph_captured ) { m->captureGraph( *r->tokens, start_position ); r->graph_captured = true; }
+            if ( mode == 2 ) m->ensureGraph( *r->tokens, start_position );
             if ( mode == 2 ) m->setDevicePosition( start_position );
             auto step = [&]( int64_t pos )
             {
@@ -370,7 +445,7 @@ HOST_API int mila_gemma_generate( void* h, int32_t first_token, int64_t start_po
         {
             auto* ctx = m->context();
             m->setSampleInGraph( true );
-            if ( mode == 2 && !r->graph_captured ) { m->captureGraph( *r->tokens, start_position ); r->graph_captured = true; }
+            if ( mode == 2 ) m->ensureGraph( *r->tokens, start_position );
             if ( mode == 2 ) m->setDevicePosition( start_position );
             for ( int i = 0; i < n_tokens; ++i )
             {

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the mila_cdna4_tune_* hooks are inert unless the process asked for them before the library was loaded (csrc/internal.h)
+os.environ.setdefault("MILA_CDNA4_TUNING", "1")
+
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 

@@ -19,11 +19,26 @@ def bf(x):
     return orc.round_bf16(np.asarray(x, dtype=np.float32))
 
 
+# synthetic-parameter profile (GemmaTransformer::SyntheticProfile, Mila/Gemma.h): multipliers on the generator of SURVEY.md section 8d
+DEFAULT_PROFILE = dict(linear_gain=1.0, qk_norm_center=1.0, post_norm_center=1.0, layer_scalar=1.0, table_gain=1.0)
+# a CONDITIONED model: like a trained one, every branch adds a small update to the residual stream (post-norm weights 0.1 against an
+# embedding of RMS ~2.3: table_gain 4), attention scores stay O(1) (q/k norm weights 0.35: score std sqrt(HD) * 0.35^2), and the
+# per-layer output scale is not 1.  A bf16 rounding difference then stays at the rounding floor instead of growing ~1.4x per layer
+# as under unit-scale random weights (tools/condition_probe.py: 12 layers 8e-2 -> 7e-4 of max|logit|).
+CONDITIONED_PROFILE = dict(linear_gain=1.0, qk_norm_center=0.35, post_norm_center=0.1, layer_scalar=0.96875, table_gain=4.0)
+
+
 class RefGemma:
-    def __init__(self, cfg, policy, seed, exact=False):
+    def __init__(self, cfg, policy, seed, exact=False, profile=None, f32_stand_in=False, staged_prefill=False):
         self.c = dict(cfg)
         self.policy = policy
         self.exact = exact          # True: keep every intermediate in FP32 (the wiring check against the HF FP32 forward)
+        self.p = dict(DEFAULT_PROFILE if profile is None else profile)
+        # True: a T > 1 forward under a quantized policy multiplies by bf16(dequantized weight), the arithmetic of the reference's 2-phase
+        # prefill (CudaLinearOp.ixx:597-644, :716-764: dequantize to a bf16 scratch, then a bf16 GEMM) that the in-register-dequantizing and
+        # the staged GEMMs both restate; False: the decode matvec's arithmetic (scales applied in FP32) for every T
+        self.staged_prefill = staged_prefill
+        self.f32_stand_in = f32_stand_in   # tools/condition_probe.py only: FP32 BLAS accumulation as a stand-in for another summation order
         c = self.c
         D, H = c["embedding_dim"], c["hidden_dim"]
         self.layers = []
@@ -38,13 +53,13 @@ class RefGemma:
             L = dict(g=g, HD=HD, NKV=NKV, NH=NH,
                      qkv=self._lin(b + 1, packed, D), o=self._lin(b + 2, D, qw), gu=self._lin(b + 3, 2 * H, D),
                      down=self._lin(b + 4, D, H),
-                     input_norm=self._norm(b + 5, D), q_norm=self._norm(b + 6, HD), k_norm=self._norm(b + 7, HD),
-                     post_attn=self._norm(b + 8, D), pre_ffn=self._norm(b + 9, D), post_ffn=self._norm(b + 10, D),
+                     input_norm=self._norm(b + 5, D), q_norm=self._norm(b + 6, HD, self.p["qk_norm_center"]), k_norm=self._norm(b + 7, HD, self.p["qk_norm_center"]),
+                     post_attn=self._norm(b + 8, D, self.p["post_norm_center"]), pre_ffn=self._norm(b + 9, D), post_ffn=self._norm(b + 10, D, self.p["post_norm_center"]),
                      K=np.zeros((1, 0, NKV, HD), np.float32), V=np.zeros((1, 0, NKV, HD), np.float32))
             self.layers.append(L)
         nl = c["num_layers"]
         self.final_norm = self._norm(seed * 1000003 + 64 * nl + 1, D)
-        tb = synth.fill_bf16(seed * 1000003 + 64 * nl + 2, c["vocab_size"] * D, 1.0 / np.sqrt(np.float32(D)), 0.0).reshape(c["vocab_size"], D)
+        tb = synth.fill_bf16(seed * 1000003 + 64 * nl + 2, c["vocab_size"] * D, np.float32(self.p["table_gain"]) / np.sqrt(np.float32(D)), 0.0).reshape(c["vocab_size"], D)
         if policy == "bf16":
             self.table = ("bf16", tb)
         else:
@@ -52,7 +67,7 @@ class RefGemma:
         self.rope = {}
 
     def _lin(self, seed, N, K):
-        wb = synth.fill_bf16(seed, N * K, 1.0 / np.sqrt(np.float32(K)), 0.0).reshape(N, K)
+        wb = synth.fill_bf16(seed, N * K, np.float32(self.p["linear_gain"]) / np.sqrt(np.float32(K)), 0.0).reshape(N, K)
         if self.policy == "bf16":
             return ("bf16", wb)
         if self.policy == "fp8":
@@ -60,15 +75,22 @@ class RefGemma:
         return ("fp4",) + orc.quantize_fp4_per_group(wb, 128)
 
     @staticmethod
-    def _norm(seed, n):
-        return orc.from_bf16_bits(synth.fill_bf16(seed, n, 0.1, 1.0))
+    def _norm(seed, n, center=1.0):
+        return orc.from_bf16_bits(synth.fill_bf16(seed, n, np.float32(0.1) * np.float32(center), np.float32(center)))
 
     def r(self, x):
         return np.asarray(x, dtype=np.float32) if self.exact else bf(x)
 
     def linear(self, x, W, round_out=True):
+        if self.f32_stand_in:
+            Wf = orc.from_bf16_bits(W[1]) if W[0] == "bf16" else orc.dequant_fp8(W[1], W[2]) if W[0] == "fp8" else orc.dequant_fp4(W[1], W[2], 128)
+            y = (np.asarray(x, np.float32)[..., ::-1] @ np.ascontiguousarray(Wf[:, ::-1].T)).astype(np.float32)
+            return self.r(y) if round_out else y
         if W[0] == "bf16":
             y = orc.linear_bf16w(x, W[1])
+        elif self.staged_prefill and round_out and np.asarray(x).reshape(-1, np.asarray(x).shape[-1]).shape[0] > 1:
+            Wf = orc.dequant_fp8(W[1], W[2]) if W[0] == "fp8" else orc.dequant_fp4(W[1], W[2], 128)
+            y = orc.linear_bf16w(x, orc.to_bf16_bits(Wf))
         elif W[0] == "fp8":
             y = orc.linear_fp8w(x, W[1], W[2])
         else:
@@ -119,7 +141,7 @@ class RefGemma:
         act = self.r(orc.geglu(gu))
         dn = self.linear(act, L["down"])
         res2 = self.r(res1 + self.rms(dn, L["post_ffn"]))
-        return self.r(res2 * np.float32(1.0))
+        return self.r(res2 * np.float32(self.p["layer_scalar"]))
 
     def forward(self, tokens, pos, max_seq):
         x = self.embed(np.asarray(tokens, dtype=np.int64))

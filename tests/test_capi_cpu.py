@@ -62,11 +62,11 @@ def test_validation_rejects_bad_arguments_without_touching_the_device(lib):
                                            C.c_float(1.0), null) == capi.MILA_E_INVALID_ARGUMENT
     assert lib.mila_cdna4_attn_decode_bf16(one, one, one, one, null, C.c_size_t(0), 1, 16, 8, 256, 64, 100, 0,
                                            C.c_float(1.0), null) == capi.MILA_E_INVALID_ARGUMENT   # band > capacity
-    assert lib.mila_cdna4_rmsnorm_bf16(one, null, null, one, null, 1, 8, 1, C.c_float(1e-6), C.c_float(0), null) \
+    assert lib.mila_cdna4_rmsnorm_bf16(one, null, null, one, null, 1, 1, 8, C.c_float(1e-6), C.c_float(0), null) \
         == capi.MILA_E_INVALID_ARGUMENT
     assert lib.mila_cdna4_rope_forward_bf16(one, null, one, null, one, one, 1, 4, 2, 1, 64, 30, 32, null) \
         == capi.MILA_E_INVALID_ARGUMENT
-    assert lib.mila_cdna4_abi_version() == 1
+    assert lib.mila_cdna4_abi_version() == 2
     assert lib.mila_cdna4_attn_decode_scratch_bytes(1, 16, 512) == 16 * 64 * 516 * 4      # [NH, max splits, HS + 4] floats
 
 

@@ -1,0 +1,24 @@
+"""CPU companion of tests/test_gemma_conditioned_gpu.py: the 1e-3 whole-model bar is the distance between two CORRECT
+implementations of the conditioned model -- the oracle composition (double accumulation) against the same composition on FP32
+accumulation in another order -- while the unit-scale random profile sits far outside it.  Small sizes: seconds on one core."""
+import numpy as np
+
+from ref_gemma import CONDITIONED_PROFILE, DEFAULT_PROFILE, RefGemma
+
+CFG = dict(vocab_size=1024, embedding_dim=512, num_layers=12, num_heads=4, num_kv_heads=2, head_dim=64, hidden_dim=1024,
+           global_head_dim=128, num_global_kv_heads=1, window=8, sliding_window_pattern=6, global_rotary_dim=32)
+TOK = [(7 * i + 3) % 1024 for i in range(12)]
+
+
+def _distance(profile):
+    a = RefGemma(CFG, "bf16", 7, profile=profile).forward(TOK, 0, 32)
+    b = RefGemma(CFG, "bf16", 7, profile=profile, f32_stand_in=True).forward(TOK, 0, 32)
+    return float(np.abs(a - b).max() / np.abs(a).max())
+
+
+def test_conditioned_profile_keeps_two_correct_implementations_within_1e3():
+    assert _distance(CONDITIONED_PROFILE) <= 1e-3
+
+
+def test_unit_scale_random_weights_do_not():
+    assert _distance(DEFAULT_PROFILE) > 1e-2

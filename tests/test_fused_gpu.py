@@ -60,7 +60,7 @@ def test_norm_matvec_equals_unfused_chain(fmt, K, N):
     W, s, _ = _weights(rng, N, K, fmt)
     # unfused: rmsnorm -> matvec
     xn, y0 = empty_u16(K), empty_u16(N)
-    capi.call("rmsnorm_bf16", xn, None, x, nw, None, 1, K, 1, 1e-6, 0.0)
+    capi.call("rmsnorm_bf16", xn, None, x, nw, None, 1, 1, K, 1e-6, 0.0)
     _matvec(fmt, y0, xn, W, s, K, N)
     y1 = empty_u16(N)
     a = _args(y=y1, x=x, W=W, scales=s if s is not None else 0, norm_w=nw, post_w=0, res=0, res_out=0,
@@ -82,11 +82,11 @@ def test_sandwich_tail_geglu_matvec_equals_unfused_chain(fmt, post_scale):
     nw = _d(_bf(1 + 0.1 * rng.uniform(-1, 1, K)))
     W, s, _ = _weights(rng, 2 * H, K, fmt)
     a_, r_, h_, gu, y0 = empty_u16(K), empty_u16(K), empty_u16(K), empty_u16(2 * H), empty_u16(H)
-    capi.call("rmsnorm_bf16", a_, None, x, pw, None, 1, K, 1, 1e-6, 0.0)
+    capi.call("rmsnorm_bf16", a_, None, x, pw, None, 1, 1, K, 1e-6, 0.0)
     capi.call("residual_bf16", r_, res, a_, C.c_int64(K))
     if post_scale != 1.0:
         capi.call("scale_bf16", r_, r_, C.c_int64(K), post_scale)
-    capi.call("rmsnorm_bf16", h_, None, r_, nw, None, 1, K, 1, 1e-6, 0.0)
+    capi.call("rmsnorm_bf16", h_, None, r_, nw, None, 1, 1, K, 1e-6, 0.0)
     _matvec(fmt, gu, h_, W, s, K, 2 * H)
     capi.call("geglu_bf16", y0, gu, 1, H)
     y1, r1 = empty_u16(H), empty_u16(K)
@@ -109,9 +109,9 @@ def test_qkv_post_equals_unfused_chain_and_oracle(NH, NKV, HS, rot, base, kv_sha
     capi.call("rope_build_cache", cos, sin, max_seq, HS, float(base), rot)
     # unfused chain
     qn, kn, vn = empty_u16(NH, HS), empty_u16(NKV, HS), empty_u16(NKV, HS)
-    capi.call("rmsnorm_bf16", qn, None, _d(q), _d(qw), None, NH, HS, 1, 1e-6, 0.0)
-    capi.call("rmsnorm_bf16", kn, None, _d(k), _d(kw), None, NKV, HS, 1, 1e-6, 0.0)
-    capi.call("rmsnorm_bf16", vn, None, _d(v), None, None, NKV, HS, 1, 1e-6, 0.0)
+    capi.call("rmsnorm_bf16", qn, None, _d(q), _d(qw), None, NH, 1, HS, 1e-6, 0.0)
+    capi.call("rmsnorm_bf16", kn, None, _d(k), _d(kw), None, NKV, 1, HS, 1e-6, 0.0)
+    capi.call("rmsnorm_bf16", vn, None, _d(v), None, None, NKV, 1, HS, 1e-6, 0.0)
     capi.call("rope_forward_bf16", qn, kn, qn, kn, cos, sin, 1, 1, NH, NKV, HS, pos, max_seq)
     K0 = torch.zeros((1, NKV, cap, HS), dtype=torch.int16, device="cuda")
     V0 = torch.zeros_like(K0)
@@ -254,9 +254,9 @@ def test_qkv_post_prefill_equals_split_norm_rope_kvwrite(NH, NKV, HS, rot, base,
     q0, k0, v0 = empty_u16(T, qd), empty_u16(T, kd), empty_u16(T, kd)
     capi.call("split3_bf16", q0, k0, None if kv_shared else v0, P, T, qd, kd, 0 if kv_shared else kd)
     qn, kn, vn = empty_u16(T, qd), empty_u16(T, kd), empty_u16(T, kd)
-    capi.call("rmsnorm_bf16", qn, None, q0, _d(qw), None, T * NH, HS, 1, 1e-6, 0.0)
-    capi.call("rmsnorm_bf16", kn, None, k0, _d(kw), None, T * NKV, HS, 1, 1e-6, 0.0)
-    capi.call("rmsnorm_bf16", vn, None, k0 if kv_shared else v0, _d(vw), None, T * NKV, HS, 1, 1e-6, 0.0)
+    capi.call("rmsnorm_bf16", qn, None, q0, _d(qw), None, T * NH, 1, HS, 1e-6, 0.0)
+    capi.call("rmsnorm_bf16", kn, None, k0, _d(kw), None, T * NKV, 1, HS, 1e-6, 0.0)
+    capi.call("rmsnorm_bf16", vn, None, k0 if kv_shared else v0, _d(vw), None, T * NKV, 1, HS, 1e-6, 0.0)
     capi.call("rope_forward_bf16", qn, kn, qn, kn, cos, sin, 1, T, NH, NKV, HS, pos0, max_seq)
     K0 = torch.zeros((1, NKV, cap, HS), dtype=torch.int16, device="cuda")
     V0 = torch.zeros_like(K0)
@@ -284,11 +284,11 @@ def test_tail_norm_equals_rmsnorm_residual_scale_rmsnorm(D, post_scale, with_nex
     res = _d(_bf(rng.standard_normal((T, D))))
     pw, nw = _d(_bf(1 + 0.1 * rng.uniform(-1, 1, D))), _d(_bf(1 + 0.1 * rng.uniform(-1, 1, D)))
     an, r0, x0 = empty_u16(T, D), empty_u16(T, D), empty_u16(T, D)
-    capi.call("rmsnorm_bf16", an, None, a, pw, None, T, D, 1, 1e-6, 0.0)
+    capi.call("rmsnorm_bf16", an, None, a, pw, None, T, 1, D, 1e-6, 0.0)
     capi.call("residual_bf16", r0, res, an, C.c_int64(T * D))
     if post_scale != 1.0:
         capi.call("scale_bf16", r0, r0, C.c_int64(T * D), post_scale)
-    capi.call("rmsnorm_bf16", x0, None, r0, nw, None, T, D, 1, 1e-6, 0.0)
+    capi.call("rmsnorm_bf16", x0, None, r0, nw, None, T, 1, D, 1e-6, 0.0)
     r1, x1 = empty_u16(T, D), empty_u16(T, D)
     capi.call("fused_tail_norm_bf16", r1, x1 if with_next else None, a, res, pw, nw if with_next else None, T, D, post_scale, 1e-6)
     assert np.array_equal(bits(r0), bits(r1)), "residual stream differs"

@@ -1,0 +1,83 @@
+"""Whole-model logits at the north star's 1e-3 (BASELINE.json: "logits within 1e-3 rel of reference").
+
+Under SURVEY.md's unit-scale random weights a 1-ulp bf16 difference between two CORRECT implementations grows ~1.4x per block
+(tools/depth_probe.py, tools/condition_probe.py), so tests/test_gemma_host_gpu.py can only hold a 6-layer random model to 1e-1 of the
+logit range.  Here the synthetic model is CONDITIONED like a trained one (tests/ref_gemma.py CONDITIONED_PROFILE: residual updates
+small against the stream, attention scores O(1), a layer scalar != 1) so that differences stay at the rounding floor, and a
+12-layer Gemma-shaped model with two global layers is held, for all three weight policies, decode and prefill, to
+
+    max |logit_gpu - logit_oracle|  <=  1e-3 * max |logit_oracle|
+
+against the oracle composition with every bf16 rounding on (block order: Gemma.Block.ixx:197-356; Gemma.ixx:281-297).  The same
+bar is met by the oracle composition run on a different summation order (tests/test_conditioned_cpu.py), i.e. it is the distance
+between two correct implementations, and a wrong term in a fused prologue (a dropped layer scalar, a norm weight from the wrong
+layer, eps misplaced) lands orders of magnitude outside it (checked below by perturbing the ORACLE)."""
+import numpy as np
+import pytest
+
+from mila_amd import host
+from ref_gemma import CONDITIONED_PROFILE, RefGemma
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(vocab_size=2048, embedding_dim=1280, num_layers=12, num_heads=4, num_kv_heads=2, head_dim=64, hidden_dim=2560,
+           global_head_dim=128, num_global_kv_heads=1, window=8, sliding_window_pattern=6, global_rotary_dim=32)
+TOKENS = [(7 * i + 3) % 2048 for i in range(20)]      # 20 positions: past the sliding window (8), both global layers see all of them
+MAX_SEQ = 64
+BAR = 1e-3
+
+
+def _report(tag, got, exp):
+    d = np.abs(got.astype(np.float64) - exp.astype(np.float64))
+    rel = d / np.abs(exp).max()
+    hist = np.histogram(np.log10(np.maximum(rel, 1e-12)), bins=[-12, -7, -6, -5, -4, -3.5, -3, -2, 0])[0]
+    print("%s: max %.2e of max|logit| (%.2e of std), histogram of log10(err/max|logit|) over (-inf,-7,-6,-5,-4,-3.5,-3,-2,0]: %s"
+          % (tag, rel.max(), d.max() / exp.std(), hist.tolist()))
+    return float(rel.max())
+
+
+@pytest.mark.parametrize("policy", ["bf16", "fp8", "fp4"])
+def test_conditioned_12_layer_model_holds_1e3_on_decode_and_prefill(policy):
+    ref = RefGemma(CFG, policy, seed=7, profile=CONDITIONED_PROFILE)
+    g = {m: host.Gemma(policy, CFG, max_seq=MAX_SEQ, max_prefill=1, seed=7, profile=CONDITIONED_PROFILE) for m in ("reference", "graph")}
+    worst = 0.0
+    for pos, tok in enumerate(TOKENS):
+        exp = ref.forward([tok], pos, MAX_SEQ)
+        out = {m: mdl.decode(tok, pos, m) for m, mdl in g.items()}
+        assert np.array_equal(out["reference"].view(np.uint32), out["graph"].view(np.uint32)), "graph replay != reference order at %d" % pos
+        assert np.all(np.isfinite(out["graph"]))
+        if pos in (0, 7, 8, 9, len(TOKENS) - 1):
+            worst = max(worst, _report("%s decode @%d" % (policy, pos), out["graph"], exp))
+        else:
+            worst = max(worst, float(np.abs(out["graph"] - exp).max() / np.abs(exp).max()))
+    assert worst <= BAR, worst
+    for mdl in g.values():
+        mdl.close()
+    # prefill (GEMM + flash attention + fused glue) of the same prompt; quantized policies multiply by bf16(dequantized weight) there
+    refp = RefGemma(CFG, policy, seed=7, profile=CONDITIONED_PROFILE, staged_prefill=True)
+    exp = refp.forward(TOKENS, 0, MAX_SEQ)
+    p = host.Gemma(policy, CFG, max_seq=MAX_SEQ, max_prefill=32, seed=7, profile=CONDITIONED_PROFILE)
+    got = p.prefill(TOKENS)
+    assert _report("%s prefill T=%d" % (policy, len(TOKENS)), got, exp) <= BAR
+    # and one decode step on top of the prefilled caches
+    exp1 = refp.forward([5], len(TOKENS), MAX_SEQ)
+    assert _report("%s decode after prefill" % policy, p.decode(5, len(TOKENS), "fused"), exp1) <= BAR
+    p.close()
+
+
+def test_the_bar_catches_small_wrong_terms():
+    """what "a wrong-but-small term in a fused prologue" costs on this model: a dropped layer scalar (0.969 -> 1) moves the logits by
+    ~1e-2 of max|logit|, a 10 % error in the post-norm or q/k-norm weights by ~4-7e-3 -- all outside the 1e-3 bar the GPU meets
+    (a 2 % norm-weight error would sit AT the bar: that is the resolution of a whole-model bf16 comparison)"""
+    base = RefGemma(CFG, "bf16", seed=7, profile=CONDITIONED_PROFILE).forward(TOKENS[:6], 0, MAX_SEQ)
+    g = host.Gemma("bf16", CFG, max_seq=MAX_SEQ, max_prefill=8, seed=7, profile=CONDITIONED_PROFILE)
+    got = g.prefill(TOKENS[:6])
+    g.close()
+    assert np.abs(got - base).max() <= BAR * np.abs(base).max()
+    for name, prof in (("layer scalar dropped", dict(CONDITIONED_PROFILE, layer_scalar=1.0)),
+                       ("post-norm weights 10 % off", dict(CONDITIONED_PROFILE, post_norm_center=CONDITIONED_PROFILE["post_norm_center"] * 1.10)),
+                       ("q/k-norm weights 10 % off", dict(CONDITIONED_PROFILE, qk_norm_center=CONDITIONED_PROFILE["qk_norm_center"] * 1.10))):
+        wrong = RefGemma(CFG, "bf16", seed=7, profile=prof).forward(TOKENS[:6], 0, MAX_SEQ)
+        err = np.abs(got - wrong).max() / np.abs(wrong).max()
+        print("%s: %.2e" % (name, err))
+        assert err > 2 * BAR, (name, err)

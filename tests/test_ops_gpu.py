@@ -33,7 +33,7 @@ def test_rmsnorm_rows(outer, dim, mode):
     use_w = mode != "noweight"
     use_b = mode == "bias"
     Y, rstd = empty_u16(outer, dim), empty_u16(outer)
-    capi.call("rmsnorm_bf16", Y, rstd, _d(X), _d(w) if use_w else None, _d(b) if use_b else None, outer, dim, 1,
+    capi.call("rmsnorm_bf16", Y, rstd, _d(X), _d(w) if use_w else None, _d(b) if use_b else None, outer, 1, dim,
               eps, off)
     exp, er = orc.rmsnorm(X, w if use_w else None, b if use_b else None, eps=eps, w_offset=off, return_rstd=True)
     assert_bf16_close(bits(Y), exp, 1, 1e-30, "rmsnorm %s" % mode)
@@ -45,7 +45,7 @@ def test_rmsnorm_strided_inner_axis():
     X = _bf(rng.standard_normal((3, 40, 6)))
     w = _bf(1 + 0.1 * rng.uniform(-1, 1, 40))
     Y = empty_u16(3, 40, 6)
-    capi.call("rmsnorm_bf16", Y, None, _d(X), _d(w), None, 3, 40, 6, 1e-5, 0.0)
+    capi.call("rmsnorm_bf16", Y, None, _d(X), _d(w), None, 3, 6, 40, 1e-5, 0.0)
     assert_bf16_close(bits(Y), orc.rmsnorm(X, w, None, eps=1e-5, inner=6), 1, 0, "rmsnorm strided")
 
 

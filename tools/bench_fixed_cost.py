@@ -1,5 +1,7 @@
 """Where the fixed cost of a decode matvec launch goes: chains of small launches replayed from a graph, microseconds per launch.
 Not part of the product path."""
+import os
+os.environ.setdefault("MILA_CDNA4_TUNING", "1")      # enables the mila_cdna4_tune_* hooks in this process (csrc/internal.h)
 import ctypes as C
 import json
 import os

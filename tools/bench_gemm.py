@@ -1,4 +1,6 @@
 """TFLOP/s of the prefill GEMM on the Gemma-4-12B shapes (M = 2048), 256-tile vs 128-tile kernel."""
+import os
+os.environ.setdefault("MILA_CDNA4_TUNING", "1")      # enables the mila_cdna4_tune_* hooks in this process (csrc/internal.h)
 import json
 import os
 import sys

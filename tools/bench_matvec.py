@@ -1,6 +1,8 @@
 """Micro-benchmark of the decode matvec on the Gemma-4-12B shapes: GB/s per (shape, format, R, U).
 Weights are cycled through enough distinct buffers (> 1 GiB) that the 256 MiB Infinity Cache never
 serves a re-read.  Prints one JSON line per configuration.  Not part of the product path."""
+import os
+os.environ.setdefault("MILA_CDNA4_TUNING", "1")      # enables the mila_cdna4_tune_* hooks in this process (csrc/internal.h)
 import argparse
 import ctypes as C
 import json

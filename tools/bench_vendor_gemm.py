@@ -1,5 +1,7 @@
 """Yardstick only (never on the product path): the vendor library's bf16 NT GEMM (torch.matmul -> hipBLASLt / rocBLAS) on the
 Gemma-4 12B prefill shapes, beside this repo's hand-written kernels through the C ABI.  TFLOP/s per shape."""
+import os
+os.environ.setdefault("MILA_CDNA4_TUNING", "1")      # enables the mila_cdna4_tune_* hooks in this process (csrc/internal.h)
 import json
 import os
 import sys

@@ -1,5 +1,7 @@
 """Launch this repo's bf16 GEMM on one Gemma prefill shape a few times (for rocprofv3 --pmc passes).  usage: gemm_only.py <K> <N> [schedule]"""
 import os
+os.environ.setdefault("MILA_CDNA4_TUNING", "1")      # enables the mila_cdna4_tune_* hooks in this process (csrc/internal.h)
+import os
 import sys
 
 import torch
