@@ -190,18 +190,45 @@ def test_safetensors_round_trip_and_quantize_on_load(policy, tmp_path):
     by = {n: (d, b, sh) for n, d, b, sh in names}
     D, F = MEDIUM["embedding_dim"], MEDIUM["hidden_dim"]
     want = {"bf16": ("BF16", 2 * F * D * 2, (2 * F, D)), "fp8": ("F8_E4M3", 2 * F * D, (2 * F, D)), "fp4": ("U8", 2 * F * D // 2, (2 * F, D // 2))}[policy]
-    assert by["gemma.layer_0.fc_gate_up.weight"] == want
-    assert ("gemma.layer_0.fc_gate_up.weight_scale" in by) == (policy != "bf16")
-    assert meta["mila_quantization"].startswith({"bf16": "NoWeightQuant", "fp8": "PerChannelFp8", "fp4": "PerGroupFp4"}[policy])
+    # the reference's flat vocabulary (root name dropped, Core/LanguageModel.ixx:137-146; Gemma.ixx:588-657; Gemma.Block.ixx:546-560)
+    assert by["tf_layer_0.fc_gate_up.weight"] == want
+    assert ("tf_layer_0.fc_gate_up.weight_scale" in by) == (policy != "bf16")
+    assert by["tf_layer_3.layer_scalar"] == ("F32", 4, (1,)) and "tf_layer_0.v_norm.weight" in by and "rmsn_final.weight" in by
+    V = MEDIUM["vocab_size"]
+    assert by["temb.wte"] == (("BF16", V * D * 2, (V, D)) if policy == "bf16" else ("F8_E4M3", V * D, (V, D)))
+    assert ("temb.wte_scale" in by) == (policy != "bf16")
+    assert not any(n.startswith("lm_head") for n in by)                          # tied: the head adopts the table (Gemma.ixx:540-555)
+    assert meta["mila_quantization"] == {"bf16": "none", "fp8": "per_channel_fp8_e4m3", "fp4": "per_group_fp4_128"}[policy]     # LanguageModelConfig.ixx:104-114
+    import json
+    mc = json.loads(meta["mila_config"])
+    assert mc["architecture"] == "gemma4" and mc["tie_word_embeddings"] is True and mc["num_layers"] == MEDIUM["num_layers"] and mc["hidden_dim"] == F
     pub = st_torch.load_file(str(f))                                            # the public package reads the file
-    assert pub["gemma.final_norm.weight"].dtype == torch.bfloat16 and pub["gemma.final_norm.weight"].numel() == D
-    assert pub["gemma.layer_0.fc_gate_up.weight"].dtype == {"bf16": torch.bfloat16, "fp8": torch.float8_e4m3fn, "fp4": torch.uint8}[policy]
+    assert pub["rmsn_final.weight"].dtype == torch.bfloat16 and pub["rmsn_final.weight"].numel() == D
+    assert pub["tf_layer_0.fc_gate_up.weight"].dtype == {"bf16": torch.bfloat16, "fp8": torch.float8_e4m3fn, "fp4": torch.uint8}[policy]
     b = host.Gemma(policy, MEDIUM, max_seq=MAX_SEQ, max_prefill=32, seed=99)     # different synthetic weights
     assert not np.array_equal(b.prefill(toks).view(np.uint32), ref_prefill.view(np.uint32))
     b.load_safetensors(f)
     assert np.array_equal(b.prefill(toks).view(np.uint32), ref_prefill.view(np.uint32))
     assert np.array_equal(b.decode(11, len(toks), "fused").view(np.uint32), ref_decode.view(np.uint32))
+    # the same tensors through the MILA .bin container (what fromPretrained streams, PretrainedReader.ixx:222-231): written by the model,
+    # and converted host-side from the SafeTensors file -- both reload to the same bits; a name prefixed with the root's name resolves too
+    fbin, fconv = tmp_path / ("gemma_%s.bin" % policy), tmp_path / ("gemma_%s_conv.bin" % policy)
+    b.save_milabin(fbin)
     b.close()
+    host.pretrained_to_milabin(f, fconv)
+    listed, bmeta = host.pretrained_list(fbin)
+    assert bmeta["container"] == "mila" and {n: (d, nb, sh) for n, d, nb, sh in listed} == by
+    for src in (fbin, fconv):
+        e = host.Gemma(policy, MEDIUM, max_seq=MAX_SEQ, max_prefill=32, seed=77)
+        e.load_pretrained(src)
+        assert np.array_equal(e.prefill(toks).view(np.uint32), ref_prefill.view(np.uint32)), src
+        e.close()
+    pref = tmp_path / "prefixed.safetensors"
+    st_torch.save_file({"gemma." + k: v for k, v in pub.items()}, str(pref), metadata={"mila_quantization": meta["mila_quantization"]})
+    e = host.Gemma(policy, MEDIUM, max_seq=MAX_SEQ, max_prefill=32, seed=77)
+    e.load_pretrained(pref)
+    assert np.array_equal(e.prefill(toks).view(np.uint32), ref_prefill.view(np.uint32))
+    e.close()
     if policy != "bf16":
         # the bf16 checkpoint of the same seed: the quantized model built from it must equal the one quantized at construction
         # (the tied table keeps its own policy: the bf16 model's table is bf16, so it is taken from the quantized file)
@@ -216,16 +243,91 @@ def test_safetensors_round_trip_and_quantize_on_load(policy, tmp_path):
     # errors: an unknown tensor, a missing one
     t = dict(pub)
     bad = tmp_path / "bad.safetensors"
-    st_torch.save_file(dict(t, **{"gemma.layer_0.bogus.weight": torch.zeros(4)}), str(bad))
+    st_torch.save_file(dict(t, **{"tf_layer_0.bogus.weight": torch.zeros(4)}), str(bad))
     d = host.Gemma(policy, MEDIUM, max_seq=MAX_SEQ, max_prefill=32, seed=1)
     with pytest.raises(ValueError, match="unknown tensor"):
         d.load_safetensors(bad)
-    t.pop("gemma.layer_1.o_proj.weight")
-    t.pop("gemma.layer_1.o_proj.weight_scale", None)
+    st_torch.save_file(dict(t, **{"lm_head.weight": t["temb.wte"].clone()}), str(bad))      # an untied head is not a Gemma-4 artifact
+    with pytest.raises(ValueError, match="untied"):
+        d.load_safetensors(bad)
+    t.pop("tf_layer_1.o_proj.weight")
+    t.pop("tf_layer_1.o_proj.weight_scale", None)
     st_torch.save_file(t, str(bad))
     with pytest.raises(ValueError, match="lacks"):
         d.load_safetensors(bad)
+    if policy != "bf16":      # a pre-quantized artifact loads only under the policy it was written with (GemmaModel.ixx:617-632)
+        other = host.Gemma({"fp8": "fp4", "fp4": "fp8"}[policy], MEDIUM, max_seq=MAX_SEQ, max_prefill=32, seed=1)
+        with pytest.raises(RuntimeError, match="pre-quantized"):
+            other.load_safetensors(f)
+        other.close()
     d.close()
+
+
+def test_a_reference_layout_checkpoint_loads(tmp_path):
+    """a file laid out as the reference's converter / writer lays it out -- bf16 tensors under the reference's names, written here by
+    the public safetensors package from host-generated values, tied (no lm_head.weight), no mila metadata at all -- loads into a
+    quantize-on-load model and gives the logits of the oracle composition on the same values"""
+    st_torch = pytest.importorskip("safetensors.torch")
+    import torch
+    import orc
+    import synth
+    cfg = SMALL
+    D, H, V = cfg["embedding_dim"], cfg["hidden_dim"], cfg["vocab_size"]
+    seed = 7
+    ref = RefGemma(cfg, "bf16", seed=seed)
+
+    def bf16(bits):
+        return torch.from_numpy(np.ascontiguousarray(bits).view(np.int16)).view(torch.bfloat16)
+    t = {"temb.wte": bf16(ref.table[1]), "rmsn_final.weight": bf16(orc.to_bf16_bits(ref.final_norm))}
+    for i, L in enumerate(ref.layers):
+        n = "tf_layer_%d." % i
+        for child, key in (("qkv_proj", "qkv"), ("o_proj", "o"), ("fc_gate_up", "gu"), ("fc_down", "down")):
+            t[n + child + ".weight"] = bf16(L[key][1])
+        for child, key in (("input_norm", "input_norm"), ("q_norm", "q_norm"), ("k_norm", "k_norm"), ("post_attn_norm", "post_attn"),
+                           ("pre_ffn_norm", "pre_ffn"), ("post_ffn_norm", "post_ffn")):
+            t[n + child + ".weight"] = bf16(orc.to_bf16_bits(L[key]))
+        t[n + "v_norm.weight"] = torch.ones(L["HD"], dtype=torch.bfloat16)
+        t[n + "layer_scalar"] = torch.tensor([1.0], dtype=torch.float32)
+    f = tmp_path / "converted.safetensors"
+    st_torch.save_file(t, str(f))
+    g = host.Gemma("bf16", cfg, max_seq=MAX_SEQ, max_prefill=16, seed=12345)      # other weights until the file is loaded
+    g.load_pretrained(f)
+    for pos, tok in enumerate(TOKENS[:4]):
+        out = g.decode(tok, pos, "fused")
+        exp = ref.forward([tok], pos, MAX_SEQ)
+        assert np.abs(out - exp).max() < 1e-1 * np.abs(exp).max()
+    same = host.Gemma("bf16", cfg, max_seq=MAX_SEQ, max_prefill=16, seed=seed)    # the generator's own weights: bit-identical logits
+    for pos, tok in enumerate(TOKENS[:4]):
+        a = same.decode(tok, pos, "fused")
+    assert np.array_equal(a.view(np.uint32), out.view(np.uint32))
+    same.close()
+    g.close()
+
+
+def test_graph_replay_survives_scratch_growth_and_follows_the_sampler_setting():
+    """(1) fp4 policy: graph decode, then a prefill whose W4A8 activation staging GROWS the context scratch, then graph decode again:
+    the captured nodes hold only model-owned pointers, so the replay still equals the fused path.  (2) decode('graph') captures a
+    graph WITHOUT the sampler node; a following generate(..., 'graph') must re-capture with it -- and produce what the fused loop does"""
+    T = 1024                                  # fc_gate_up (F = 6400) takes the W4A8 LDS-DMA path: per-token e4m3 activations staged in context scratch
+    cfg = WIDE_FFN
+    a = host.Gemma("fp4", cfg, max_seq=T + 32, max_prefill=T, seed=4)
+    b = host.Gemma("fp4", cfg, max_seq=T + 32, max_prefill=T, seed=4)
+    l0a, l0b = a.decode(9, 0, "graph"), b.decode(9, 0, "fused")
+    assert np.array_equal(l0a.view(np.uint32), l0b.view(np.uint32))
+    toks = [(13 * i + 5) % cfg["vocab_size"] for i in range(T)]
+    pa, pb = a.prefill(toks), b.prefill(toks)                                      # grows the context scratch far past the attention partials
+    assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32))
+    for pos in range(T, T + 4):
+        la, lb = a.decode(3, pos, "graph"), b.decode(3, pos, "fused")
+        assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), pos
+    ids_graph = a.generate(5, T + 4, 8, "graph")                                   # the captured graph had no sampler node
+    ids_fused = b.generate(5, T + 4, 8, "fused")
+    assert np.array_equal(ids_graph, ids_fused), (ids_graph, ids_fused)
+    assert len(set(ids_graph.tolist())) > 1 or int(ids_graph[0]) != 5             # not "first_token repeated"
+    la, lb = a.decode(3, T + 12, "graph"), b.decode(3, T + 12, "fused")            # and back to plain decode on the same model
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    a.close()
+    b.close()
 
 
 def test_sampled_generation_degenerates_to_greedy_and_is_reproducible():
