@@ -25,16 +25,38 @@ MFMA_FP8_PEAK_TFLOPS = 5000.0       # dense e4m3 (block-scaled MFMA): the fp4 po
 CONTEXT = 2048                # BASELINE.json configs[2..4]: B=1, T=2048
 
 
+def _oracle(omp_threads=None):
+    """the CPU oracle as a ctypes library: the serial build, or the OpenMP build (the reference's own `#pragma omp` placements,
+    oracle/mila_oracle.c) pinned to `omp_threads` threads.  bench.py's cpu_baseline leg is one of the three places allowed to."""
+    import ctypes as C
+    import subprocess
+    odir = os.path.join(ROOT, "oracle")
+    name = "libmila_oracle_omp.so" if omp_threads else "libmila_oracle.so"
+    path = os.path.join(odir, "_build", name)
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", odir, "-s", "_build/" + name])
+    if omp_threads:
+        os.environ["OMP_NUM_THREADS"] = str(omp_threads)       # read by libgomp when it is first loaded
+    return C.CDLL(path)
+
+
 def cpu_baseline(cfg):
-    """Reference CPU backend restated (oracle/mila_oracle.c: CpuLinearOp::forwardNaive, the path the
-    reference takes at batch 1) on a bounded sample of one decode token's Linear work:
-    30 passes over a local layer + 6 over a global layer + 1/4 of the lm_head rows, FP32, single thread (the reference
-    default: MILA_ENABLE_OPENMP is OFF).  Extrapolated to a whole token by weight count."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    """Mila's CPU backend, restated (oracle/mila_oracle.c, kind "port"), timed on this box's host cores -- SURVEY.md section 8d:
+      (i)  single thread, the reference default (MILA_ENABLE_OPENMP is OFF, CMakeLists.txt:78);
+      (ii) the reference's own `#pragma omp` placements on all host cores (os.cpu_count() threads).
+    Two workloads, each a BOUNDED sample:
+      * one Gemma-4 12B decode token's Linear work (CpuLinearOp::forwardNaive, the batch-1 path; the reference has no CPU
+        RMSNorm / RoPE / GQA / GeGLU ops -- < 1 % of the work): a few passes over a local and a global layer's four Linear shapes +
+        1/8 of the lm_head rows, extrapolated by weight count.  The reference parallelises forwardNaive over BATCH ROWS
+        (CpuLinearOp.ixx:389), so at batch 1 leg (ii) runs on one core as well: measured, not assumed;
+      * BASELINE config 1 end to end: GPT-2 124M FP32 forward, B = 1, T = 64 (the one configuration the CPU backend covers),
+        15.9 GFLOP, on random parameters."""
+    import ctypes as C
     import numpy as np
-    import orc
     rng = np.random.default_rng(0)
     D, H, V = cfg["embedding_dim"], cfg["hidden_dim"], cfg["vocab_size"]
+    f32p = C.POINTER(C.c_float)
+    ncores = os.cpu_count() or 1
 
     def shapes(g):
         hd = cfg["global_head_dim"] if g else cfg["head_dim"]
@@ -42,35 +64,64 @@ def cpu_baseline(cfg):
         qw = cfg["num_heads"] * hd
         return [(D, qw + (1 if g else 2) * nkv * hd), (qw, D), (D, 2 * H), (H, D)]
 
-    def time_shapes(shs, frac=1.0, reps=1):
-        total, macs = 0.0, 0
-        for K, N in shs:
-            n = max(1, int(N * frac))
-            W = rng.standard_normal((n, K), dtype=np.float32)       # 30-470 MB: far beyond the CPU caches, every pass streams it from DRAM
-            x = rng.standard_normal((1, K), dtype=np.float32)
-            for _ in range(reps):
-                t0 = time.perf_counter()
-                orc.cpu_linear(x, W, None)          # batch 1 -> forwardNaive (long double accumulation)
-                total += time.perf_counter() - t0
-                macs += n * K
-        return total, macs
-
-    # a bounded sample of one token (about 10-15 s on one core): 30 passes over a local layer's four Linear shapes, 6 over a global
-    # layer's (the model's 5 : 1 mix) and 1/4 of the lm_head rows
-    REPS_LOC, REPS_GLB, HEAD_FRAC = 30, 6, 1.0 / 4
-    t_loc, m_loc = time_shapes(shapes(False), reps=REPS_LOC)
-    t_glb, m_glb = time_shapes(shapes(True), reps=REPS_GLB)
-    t_head, m_head = time_shapes([(D, V)], HEAD_FRAC)
+    REPS_LOC, REPS_GLB, HEAD_FRAC = 8, 2, 1.0 / 8
     n_glb = sum(1 for i in range(cfg["num_layers"]) if (i + 1) % cfg["sliding_window_pattern"] == 0)
     n_loc = cfg["num_layers"] - n_glb
-    token_s = t_loc / REPS_LOC * n_loc + t_glb / REPS_GLB * n_glb + t_head / HEAD_FRAC
-    return {"value": round(1.0 / token_s, 5), "unit": "tok/s", "cores": 1, "kind": "port",
-            "sample": "restated CpuLinearOp::forwardNaive (FP32, long double acc; the reference's batch-1 path, single thread as "
-                      "MILA_ENABLE_OPENMP is OFF by default) on %d passes over a local + %d over a global layer's Linear shapes + 1/%d of the lm_head rows "
-                      "(%.2f GMAC, %.1f s), extrapolated by weight count to 48 layers + head; the reference has no CPU "
-                      "RMSNorm/RoPE/GQA/GeGLU ops, they are <1%% of the work and not timed"
-                      % (REPS_LOC, REPS_GLB, round(1 / HEAD_FRAC), (m_loc + m_glb + m_head) / 1e9, t_loc + t_glb + t_head),
-            "GFLOPs": round(2 * (m_loc + m_glb + m_head) / (t_loc + t_glb + t_head) / 1e9, 3)}
+    # the sample's operands, shared by both legs: 30-470 MB matrices, far beyond the CPU caches -- every pass streams from DRAM
+    mats = {}
+    for g in (False, True):
+        for K, N in shapes(g):
+            mats.setdefault((K, N), (rng.standard_normal((N, K), dtype=np.float32), rng.standard_normal((1, K), dtype=np.float32)))
+    nh = max(1, int(V * HEAD_FRAC))
+    head = (rng.standard_normal((nh, D), dtype=np.float32), rng.standard_normal((1, D), dtype=np.float32))
+
+    def linear(lib, W, x):
+        N, K = W.shape
+        y = np.empty((1, N), dtype=np.float32)
+        t0 = time.perf_counter()
+        lib.orc_cpu_linear(y.ctypes.data_as(f32p), x.ctypes.data_as(f32p), W.ctypes.data_as(f32p), None, C.c_int64(1), C.c_int64(K), C.c_int64(N))
+        return time.perf_counter() - t0
+
+    def token_leg(lib):
+        t_loc = sum(linear(lib, *mats[s]) for _ in range(REPS_LOC) for s in shapes(False))
+        t_glb = sum(linear(lib, *mats[s]) for _ in range(REPS_GLB) for s in shapes(True))
+        t_head = linear(lib, *head)
+        macs = REPS_LOC * sum(k * n for k, n in shapes(False)) + REPS_GLB * sum(k * n for k, n in shapes(True)) + nh * D
+        token_s = t_loc / REPS_LOC * n_loc + t_glb / REPS_GLB * n_glb + t_head / HEAD_FRAC
+        return {"tok_s": round(1.0 / token_s, 5), "sample_s": round(t_loc + t_glb + t_head, 2), "GFLOPs": round(2 * macs / (t_loc + t_glb + t_head) / 1e9, 3)}
+
+    # BASELINE config 1: GPT-2 124M, B = 1, T = 64 (oracle orc_cpu_gpt2_forward = GptTransformer::forward on the CPU backend)
+    Cg, Lg, NHg, Vg, Tg, maxT = 768, 12, 12, 50257, 64, 1024
+    params = [rng.standard_normal((Vg, Cg), dtype=np.float32) * np.float32(0.02), rng.standard_normal((maxT, Cg), dtype=np.float32) * np.float32(0.01)]
+    for _ in range(Lg):
+        params += [np.ones(Cg, np.float32), np.zeros(Cg, np.float32), rng.standard_normal((3 * Cg, Cg), dtype=np.float32) * np.float32(0.02), np.zeros(3 * Cg, np.float32),
+                   rng.standard_normal((Cg, Cg), dtype=np.float32) * np.float32(0.02), np.zeros(Cg, np.float32), np.ones(Cg, np.float32), np.zeros(Cg, np.float32),
+                   rng.standard_normal((4 * Cg, Cg), dtype=np.float32) * np.float32(0.02), np.zeros(4 * Cg, np.float32),
+                   rng.standard_normal((Cg, 4 * Cg), dtype=np.float32) * np.float32(0.02), np.zeros(Cg, np.float32)]
+    params += [np.ones(Cg, np.float32), np.zeros(Cg, np.float32), params[0]]
+    tokens = (np.arange(Tg, dtype=np.int32) * 7919 + 13) % Vg
+    arr = (f32p * len(params))(*[p.ctypes.data_as(f32p) for p in params])
+    logits = np.empty((1, Tg, Vg), dtype=np.float32)
+    gpt_flop = 2.0 * Tg * (Lg * 12 * Cg * Cg + Vg * Cg) + Lg * 4.0 * NHg * (Cg // NHg) * Tg * Tg
+
+    def gpt_leg(lib):
+        t0 = time.perf_counter()
+        lib.orc_cpu_gpt2_forward(logits.ctypes.data_as(f32p), tokens.ctypes.data_as(C.POINTER(C.c_int32)), arr, 1, Tg, Cg, Lg, NHg, Vg, maxT)
+        dt = time.perf_counter() - t0
+        return {"forward_ms": round(dt * 1e3, 1), "tok_s": round(Tg / dt, 2), "GFLOPs": round(gpt_flop / dt / 1e9, 3)}
+
+    serial = _oracle()
+    one_tok, one_gpt = token_leg(serial), gpt_leg(serial)
+    omp = _oracle(omp_threads=ncores)
+    all_tok, all_gpt = token_leg(omp), gpt_leg(omp)
+    return {"value": one_tok["tok_s"], "unit": "tok/s", "cores": 1, "kind": "port",
+            "sample": "restated CpuLinearOp::forwardNaive (FP32, long double accumulation: the reference's batch-1 path) on %d passes over a local + %d over a "
+                      "global layer's four Linear shapes + 1/%d of the lm_head rows (%.1f s on one core), extrapolated by weight count to %d layers + head; "
+                      "`value` is the single-thread leg = the reference's default build (MILA_ENABLE_OPENMP OFF)" % (REPS_LOC, REPS_GLB, round(1 / HEAD_FRAC), one_tok["sample_s"], cfg["num_layers"]),
+            "host_cores": ncores,
+            "legs": {"single_thread": dict(one_tok, cores=1),
+                     "all_cores_reference_omp_placements": dict(all_tok, cores=ncores, note="forwardNaive parallelises over batch rows (CpuLinearOp.ixx:389): one row at decode, so one busy core")},
+            "config1_gpt2_124M_fp32_B1_T64": {"GFLOP": round(gpt_flop / 1e9, 2), "single_thread": dict(one_gpt, cores=1), "all_cores_reference_omp_placements": dict(all_gpt, cores=ncores)}}
 
 
 def measured_traffic(policy):
@@ -88,6 +139,42 @@ def measured_traffic(policy):
     return None, None
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def spawn_replicas(n, argv):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start N child processes, one per GPU, BEFORE anything in this process
+    touches a GPU, with the env torch.distributed.run would give them; rank 0's JSON line is this command's output.  The path does
+    not shard: the children are independent replicas that only share the timing barrier (gloo)."""
+    import subprocess
+    port = str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    return max(abs(rc) for rc in rcs) if any(rcs) or not lines else 0
+
+
+def stub_result(steps, warmup, rank):
+    """--stub: no GPU work at all -- a sleep stands where the timed decode loop is, so that the launcher / barrier / aggregation
+    plumbing can be exercised on a CPU box (tests/test_replicas_cpu.py).  The line it prints says so in `data`."""
+    for _ in range(warmup):
+        time.sleep(0.001)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        time.sleep(0.002 + 0.001 * rank)        # rank 1 is the slow one: the aggregate must use the MAX over ranks
+    return (time.perf_counter() - t0) * 1e3 / steps
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,6 +184,7 @@ def main():
     ap.add_argument("--mode", default="graph", choices=["graph", "fused", "reference"])
     ap.add_argument("--no-prefill", action="store_true", help="skip the timed T=2048 prefill (KV cache left zero-filled)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--stub", action="store_true", help="plumbing test on a CPU box: no GPU work, the line says data = stub")
     ap.add_argument("--onepass", type=int, default=None, help="1/0: split decode attention in one launch / with a combine launch (default: the model's)")
     ap.add_argument("--prefetch-mb", type=float, default=None, help="side-stream Infinity-Cache prefetch cap per Linear in MB (0 = off; default: the model's)")
     ap.add_argument("--prefetch-wgs", type=int, default=64)
@@ -107,21 +195,46 @@ def main():
     ap.add_argument("--warm", default=None, help="blocks_a,cap_a_MB,blocks_b,cap_b_MB: warm-ahead workgroups of the attention / combine launches")
     a = ap.parse_args()
 
-    import torch
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    from mila_amd.replicas import Ranks
-    ranks = Ranks()
-    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
+    # N > 1 and no launcher env: this process only starts one child per GPU (it never initialises a GPU itself)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_replicas(a.gpus, sys.argv[1:]))
+    if a.attn_split is not None or a.gemm_schedule is not None:
+        os.environ["MILA_CDNA4_TUNING"] = "1"      # the tuning hooks are inert unless asked for before the library loads (csrc/internal.h)
 
-    from mila_amd import capi, host
+    from mila_amd import host
+    from mila_amd.replicas import Ranks
+    ranks = Ranks(backend="gloo")                  # timing barrier + MAX-over-ranks only; no RCCL on this path (north star)
+    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
+    if a.gpus != world:
+        print("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d" % (a.gpus, world, world), file=sys.stderr)
+    cfg = dict(host.GEMMA4_12B)
+    policies = [p for p in a.policies.split(",") if p]
+
+    # the CPU baseline FIRST (rank 0 of the single-GPU line only): the GPU phases then run back to back to the end of the process
+    cpu = cpu_baseline(cfg) if (rank == 0 and world == 1 and not a.no_cpu and not a.stub) else None
+
+    if a.stub:
+        ranks.barrier()
+        ms = stub_result(a.steps, a.warmup, rank)
+        ranks.barrier()
+        ms = ranks.max_over_ranks(ms)
+        if rank == 0:
+            print(json.dumps({"metric": "Gemma-4 12B decode tok/s (B=1, context 2048), 1xMI355X", "value": round(1e3 / ms * world, 2), "unit": "tok/s", "n_gpus": world,
+                              "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "none", "data": "stub (no GPU work: launcher / barrier / aggregation plumbing only)",
+                              "config": {"workload": "stub", "replicas": world, "parallelism": "replicas only (no collective)"}}), flush=True)
+        ranks.close()
+        return
+
+    import torch
+    torch.cuda.set_device(local_rank)
+    from mila_amd import capi
     capi.load()
     capi.check(capi.load().mila_cdna4_set_device(local_rank))
     if a.attn_split is not None:
         capi.check(capi.load().mila_cdna4_tune_attn_split(a.attn_split))
     if a.gemm_schedule is not None:
         capi.check(capi.load().mila_cdna4_tune_gemm_schedule(a.gemm_schedule))
-    cfg = dict(host.GEMMA4_12B)
-    policies = [p for p in a.policies.split(",") if p]
     results = {}
     for pol in policies:
         m = host.Gemma(pol, cfg, max_seq=CONTEXT + a.steps + a.warmup + 8, max_prefill=1 if a.no_prefill else CONTEXT, seed=1234)
@@ -213,8 +326,8 @@ def main():
         "policies": results,
     }
     if rank == 0:
-        if not a.no_cpu and world == 1:        # the CPU baseline belongs to the single-GPU line only
-            out["cpu_baseline"] = cpu_baseline(cfg)
+        if cpu is not None:                    # the CPU baseline belongs to the single-GPU line only
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     ranks.close()
 

@@ -17,14 +17,13 @@ class Ranks:
         self.dist = None
         self.backend = backend
         if self.world > 1:
-            import torch
             import torch.distributed as dist
-            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-            self.backend = backend
-            kw = {}
-            if backend == "nccl":
-                kw["device_id"] = torch.device("cuda", self.local_rank)
-            dist.init_process_group(backend, **kw)
+            # gloo: the replicas exchange two host scalars per run (barrier, MAX of the measured time); the north star rules RCCL out
+            # of this path and nothing here needs it
+            self.backend = backend or "gloo"
+            if self.backend != "gloo":
+                raise ValueError("replicas: only the gloo backend is used (no data-path collective, no RCCL)")
+            dist.init_process_group("gloo")
             self.dist = dist
 
     def barrier(self):
@@ -36,8 +35,7 @@ class Ranks:
         if self.dist is None:
             return float(value)
         import torch
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        t = torch.tensor([float(value)], dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 

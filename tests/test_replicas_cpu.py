@@ -42,3 +42,33 @@ def test_each_replica_builds_its_model_on_its_own_gpu(monkeypatch):
     assert replicas.local_device() == 5
     src = inspect.getsource(host.Gemma.__init__)
     assert "local_device()" in src and "mila_gemma_create(POLICIES[policy], C.byref(c), max_seq, max_prefill, seed, device)" in src
+
+
+def _bench(*args, env=None):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--steps", "6", "--warmup", "1", *args],
+                         capture_output=True, text=True, env=env or os.environ, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_gpus_flag_starts_one_replica_per_gpu_and_aggregates():
+    """`python bench.py --gpus 2` outside a launcher: the parent starts two children (it never touches a GPU itself), the line
+    reports n_gpus 2, the time is the MAX over ranks (rank 1 is the slow one in the stub) and value = all ranks' steps / that time"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    one, two = _bench(env=env), _bench("--gpus", "2", env=env)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["config"]["replicas"] == 2
+    assert two["ms_per_step"] >= 3.0 > one["ms_per_step"] >= 2.0            # stub: 2 ms + 1 ms per rank
+    assert abs(two["value"] - 2 * 1e3 / two["ms_per_step"]) < 0.02 * two["value"]
+    assert two["data"].startswith("stub")
+
+
+def test_bench_under_the_drivers_launcher():
+    """the driver's own form: torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 (ranks from the env, no second spawn)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--stub", "--gpus", "2", "--steps", "6", "--warmup", "1"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                                   # rank 0 prints ONE line
+    assert json.loads(lines[0])["n_gpus"] == 2
