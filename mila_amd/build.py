@@ -91,7 +91,7 @@ def build(force=False, verbose=False):
         hlib = os.path.join(LIBDIR, "libmila_host.so")
         if hobjs and (force or hjobs or _newer(hlib, hobjs + [lib])):
             _run([HOSTCXX, "-shared", "-fPIC", "-o", hlib] + hobjs +
-                 ["-L" + LIBDIR, "-lmila_cdna4", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN"])
+                 ["-L" + LIBDIR, "-lmila_cdna4", "-L/opt/rocm/lib", "-lamdhip64", "-lrocprofiler-sdk-roctx", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
     return lib
 
 

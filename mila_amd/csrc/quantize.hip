@@ -112,18 +112,20 @@ __global__ __launch_bounds__(256) void quantize_fp4_per_group_kernel(uint8_t* __
 
 // ---- W4A8 prefill staging (the reference's default fp4-policy prefill, CudaLinearOp.ixx:646-715) ----------------------
 // weight_fp8_scale = max(max(group scale), 1e-12) * (6 / 448)          (CudaW4A16Gemm.cu:244-294; exact max, any order)
+// Many workgroups, no scratch: f(m) = max(m, 1e-12) * (6 / 448) is non-decreasing and positive, and positive floats order like their bit
+// patterns, so max over blocks of f(block max) -- an integer atomicMax on the zero-initialised output -- IS f(max over all scales), bit for bit.
 __global__ __launch_bounds__(1024) void fp4_weight_fp8_scale_kernel(float* __restrict__ out, const float* __restrict__ scales, int64_t n)
 {
     __shared__ float red[16];
     float m = 0.0f;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, scales[i]);
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) m = fmaxf(m, scales[i]);
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0)
     {
         for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
-        out[0] = fmaxf(m, 1e-12f) * (6.0f / 448.0f);
+        atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(fmaxf(m, 1e-12f) * (6.0f / 448.0f)));
     }
 }
 
@@ -283,7 +285,10 @@ int mila_cdna4_quantize_fp4_per_group(uint8_t* dst_packed, float* scales, const 
 int mila_cdna4_fp4_weight_fp8_scale(float* out_scale, const float* group_scales, int64_t num_scales, mila_stream_t stream)
 {
     MILA_REQUIRE(out_scale && group_scales && num_scales > 0, "fp4_weight_fp8_scale: bad arguments");
-    hipLaunchKernelGGL(fp4_weight_fp8_scale_kernel, dim3(1), dim3(1024), 0, as_stream(stream), out_scale, group_scales, num_scales);
+    hipError_t e = hipMemsetAsync(out_scale, 0, sizeof(float), as_stream(stream));
+    if (e != hipSuccess) return check_hip(e, "fp4_weight_fp8_scale: hipMemsetAsync");
+    const int blocks = (int)std::min<int64_t>((num_scales + 4095) / 4096, 256);
+    hipLaunchKernelGGL(fp4_weight_fp8_scale_kernel, dim3(blocks), dim3(1024), 0, as_stream(stream), out_scale, group_scales, num_scales);
     MILA_LAUNCH_CHECK("fp4_weight_fp8_scale");
 }
 

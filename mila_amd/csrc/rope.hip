@@ -51,6 +51,27 @@ __global__ __launch_bounds__(256) void rope_rotate_bf16_kernel(uint16_t* __restr
     }
 }
 
+// any even head size (HS % 16 != 0: the reference's own test geometry is HS = 8, Tests/.../Rope.Cuda.cpp:42): one thread per
+// rotation pair, the same arithmetic and rounding as rope_rotate8_vals
+__global__ __launch_bounds__(256) void rope_rotate_bf16_pair_kernel(uint16_t* out, const uint16_t* in,   /* may alias (in place) */
+                                                                    const float* __restrict__ cos_c, const float* __restrict__ sin_c,
+                                                                    int64_t total_pairs, int half, int T, int n_heads, int pos_offset)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total_pairs; v += stride)
+    {
+        const int64_t bth = v / half;
+        const int i = (int)(v % half);
+        const int pos = (int)((bth / n_heads) % T) + pos_offset;
+        const size_t base = (size_t)bth * half * 2;
+        const float c = cos_c[(size_t)pos * half + i], s = sin_c[(size_t)pos * half + i];
+        const float x0 = bf16_bits_to_f32(in[base + i]), x1 = bf16_bits_to_f32(in[base + i + half]);
+        const uint32_t lo = pack_bf16x2(x0 * c - x1 * s, 0.0f), hi = pack_bf16x2(x0 * s + x1 * c, 0.0f);
+        out[base + i] = (uint16_t)(lo & 0xffffu);
+        out[base + i + half] = (uint16_t)(hi & 0xffffu);
+    }
+}
+
 }  // namespace mila
 
 using namespace mila;
@@ -76,11 +97,26 @@ int mila_cdna4_rope_forward_bf16(uint16_t* Qout, uint16_t* Kout, const uint16_t*
 {
     MILA_REQUIRE(cos_cache && sin_cache, "rope_forward_bf16: null cache");
     MILA_REQUIRE((Qout && Qin) || (Kout && Kin), "rope_forward_bf16: nothing to rotate");
-    MILA_REQUIRE(B > 0 && T > 0 && HS > 0 && HS % 16 == 0, "rope_forward_bf16: bad sizes (B=%d T=%d HS=%d)", B, T, HS);
+    MILA_REQUIRE(B > 0 && T > 0 && HS > 0 && HS % 2 == 0, "rope_forward_bf16: bad sizes (B=%d T=%d HS=%d)", B, T, HS);
     MILA_REQUIRE(pos_offset >= 0 && pos_offset + T <= max_seq,
                  "rope_forward_bf16: positions [%d,%d) exceed the cache length %d", pos_offset, pos_offset + T, max_seq);
     const int half = HS / 2;
     hipStream_t s = as_stream(stream);
+    if (HS % 16 != 0)
+    {
+        for (int which = 0; which < 2; ++which)
+        {
+            uint16_t* o = which ? Kout : Qout;
+            const uint16_t* in = which ? Kin : Qin;
+            if (!o || !in) continue;
+            const int heads = which ? NKV : NH;
+            const int64_t tp = (int64_t)B * T * heads * half;
+            int blocks = ceil_div(tp, 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(rope_rotate_bf16_pair_kernel, dim3(blocks), dim3(256), 0, s, o, in, cos_cache, sin_cache, tp, half, T, heads, pos_offset);
+        }
+        MILA_LAUNCH_CHECK("rope_forward_bf16");
+    }
     if (Qout && Qin)
     {
         const int64_t tv = (int64_t)B * T * NH * (half / 8);

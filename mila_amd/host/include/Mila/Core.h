@@ -26,10 +26,29 @@
 #include <string>
 #include <vector>
 
+#include <rocprofiler-sdk-roctx/roctx.h>
+
 #include "mila_cdna4.h"
 
 namespace Mila::Dnn
 {
+    // ---------------------------------------------------------------------------------------
+    // Tracing: ROCTx ranges (the counterpart of the reference's NVTX ranges) around the host-side phases --
+    // prefill, decode step, graph replay, sampler, checkpoint load.  `rocprofv3 --marker-trace` shows them on the timeline beside the
+    // kernels; without a profiler attached a push / pop pair is a few tens of nanoseconds.
+    // ---------------------------------------------------------------------------------------
+    namespace Compute
+    {
+        class TraceRange
+        {
+        public:
+            explicit TraceRange( const char* name ) noexcept { roctxRangePushA( name ); }
+            ~TraceRange() { roctxRangePop(); }
+            TraceRange( const TraceRange& ) = delete;
+            TraceRange& operator=( const TraceRange& ) = delete;
+        };
+    }
+
     // ---------------------------------------------------------------------------------------
     // Errors: the C ABI's status codes become the reference's exception types
     // ---------------------------------------------------------------------------------------

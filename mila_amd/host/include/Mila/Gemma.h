@@ -159,6 +159,7 @@ namespace Mila::Dnn
         // ------------------------------------------------------------------------------------
         LogitsTensor& decode( const TokenTensor& token, dim_t position )
         {
+            Compute::TraceRange tr( "gemma.decode(reference order)" );
             checkPosition( position, 1 );
             embed( token.data(), 1, *hidden_[ 0 ] );
             TensorType* x = hidden_[ 0 ].get();
@@ -173,6 +174,7 @@ namespace Mila::Dnn
         // ------------------------------------------------------------------------------------
         LogitsTensor& decodeFused( const TokenTensor& token, dim_t position )
         {
+            Compute::TraceRange tr( "gemma.decode(fused)" );
             checkPosition( position, 1 );
             enqueueFusedStep( token.data(), static_cast<int>( position ), nullptr );
             return *logits_;
@@ -185,6 +187,7 @@ namespace Mila::Dnn
         /// scratch cannot leave the graph pointing at freed memory.  A second capture replaces the first (the old graph is destroyed).
         void captureGraph( const TokenTensor& token, dim_t start_position )
         {
+            Compute::TraceRange tr( "gemma.captureGraph" );
             setDevicePosition( start_position );
             destroyGraph();
             hipStream_t s = reinterpret_cast<hipStream_t>( ctx_->getStream() );
@@ -226,6 +229,7 @@ namespace Mila::Dnn
         void replayGraph()
         {
             if ( !graph_exec_ ) throw std::runtime_error( "GemmaTransformer::replayGraph: captureGraph() first" );
+            Compute::TraceRange tr( "gemma.decode(graph replay)" );
             hipCheck( hipGraphLaunch( graph_exec_, reinterpret_cast<hipStream_t>( ctx_->getStream() ) ), "hipGraphLaunch" );
         }
         LogitsTensor& logits() { return *logits_; }
@@ -234,6 +238,7 @@ namespace Mila::Dnn
         /// (GemmaModel::enqueueSampleNext, Models/GemmaModel.ixx:568)
         void sampleGreedy( TokenTensor& token_out )
         {
+            Compute::TraceRange tr( "gemma.sample(greedy)" );
             Compute::rocmCheck( mila_cdna4_sample_argmax_fp32( logits_->data(), token_out.data(), (int)cfg_.vocab_size, sample_scratch_->data(),
                                                                sample_scratch_->sizeInBytes(), ctx_->getStream() ) );
         }
@@ -246,6 +251,7 @@ namespace Mila::Dnn
         void sampleStochastic( TokenTensor& token_out, const SamplingParams& sp, float r )
         {
             if ( sp.temperature <= 0.0f ) { sampleGreedy( token_out ); return; }
+            Compute::TraceRange tr( "gemma.sample(stochastic)" );
             const size_t need = mila_cdna4_sample_stochastic_scratch_bytes( (int)cfg_.vocab_size );
             void* scratch = ctx_->getScratch( need );
             Compute::rocmCheck( mila_cdna4_sample_stochastic_fp32( logits_->data(), token_out.data(), (int)cfg_.vocab_size, cfg_.final_logit_softcapping, sp.temperature,
@@ -259,6 +265,7 @@ namespace Mila::Dnn
         LogitsTensor& prefill( const TokenTensor& tokens, dim_t T, dim_t position_offset = 0 )
         {
             if ( T <= 0 || T > max_prefill_ ) throw std::invalid_argument( "GemmaTransformer::prefill: chunk length out of range" );
+            Compute::TraceRange tr( "gemma.prefill" );
             checkPosition( position_offset, T );
             const dim_t D = cfg_.embedding_dim;
             embed( tokens.data(), static_cast<int>( T ), *pf_x_[ 0 ] );
@@ -983,6 +990,7 @@ namespace Mila::Dnn
         void loadPretrained( const std::string& path )
         {
             destroyGraph();   // layer scalars are baked into the captured launches
+            Compute::TraceRange tr( "gemma.loadPretrained" );
             Serialization::PretrainedModelReader r( path );
             const auto& md = r.getPretrainedMetadata();
             if ( !r.metadataJSON().empty() )

@@ -131,6 +131,7 @@ namespace Mila::Dnn
         /// tokens [B,T] int32 on the device -> logits [B,T,V] (bf16)
         TensorType& forward( const TokenTensor& tokens )
         {
+            Compute::TraceRange tr( "gpt.forward" );
             const int B = (int)B_, T = (int)T_, C = (int)cfg_.embedding_dim;
             mila_stream_t st = ctx_->getStream();
             Compute::rocmCheck( mila_cdna4_lpe_bf16( x_->data(), tokens.data(), wte_->data(), wpe_->data(), B, T, C, T, (int)cfg_.vocab_size, err_flag_->data(), st ) );

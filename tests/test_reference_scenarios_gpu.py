@@ -110,7 +110,10 @@ def test_Linear_Cuda_cpp_265_Forward_MatchesReference_Bf16():
     capi.call("gemm_bf16", Y, _d(X), _d(W), _d(Bv), 8, K_IN, N_OUT)
     exp = reference_forward(X.reshape(8, K_IN), W, Bv)
     expect_near(_f(Y), exp, 5e-2, 5e-2, "forward")
-    assert_bf16_close(bits(Y), exp, 1, 1e-6, "forward (this build's bar)")
+    # this build's bar: the reference's batch path rounds the GEMM to bf16 and THEN adds the bias (cuda_add_bias,
+    # CudaFp8Prefill.cu:239-256; the fix the test's own comment describes, :267-270) -- two roundings, restated exactly
+    two_step = _bf(reference_forward(X.reshape(8, K_IN), W, None)).astype(np.float64) + Bv.astype(np.float64)
+    assert_bf16_close(bits(Y), two_step, 1, 1e-6, "forward (this build's bar)")
 
 
 def test_Linear_Cuda_cpp_310_Forward_DecodeMatchesReference_Bf16():
@@ -257,14 +260,15 @@ def test_Linear_Cuda_cpp_1055_PerGroupFp4_NibblePackedWeightAndPerGroupScales():
     assert np.all(np.isfinite(sh)) and np.all(sh > 0)
     eq, es = orc.quantize_fp4_per_group(Wb, G)
     assert np.array_equal(qh, eq) and np.array_equal(sh, es)
-    # low nibble = even column (Policies.ixx:85-97): reconstruct and compare within the e2m1 grid's half step
+    # low nibble = even column (Policies.ixx:85-97): reconstruct and compare within half of the e2m1 grid's largest step (4 -> 6)
     lut = orc.E2M1_LUT
     W = orc.from_bf16_bits(Wb)
     rec = np.empty((N, K), np.float32)
     rec[:, 0::2] = lut[qh & 0xF]
     rec[:, 1::2] = lut[qh >> 4]
     rec *= np.repeat(sh, G, axis=1)
-    assert np.all(np.abs(rec - W) <= 0.5 * np.repeat(sh, G, axis=1) + 1e-7)
+    assert np.all(np.abs(rec - W) <= 1.0 * np.repeat(sh, G, axis=1) + 1e-7)
+    assert np.abs(rec - W).max() > 0.25 * sh.max()                                     # ... and the bound is not vacuous
 
 
 # ------------------------------------------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ run devkernarg0 HIP_FORCE_DEV_KERNARG=0
 run devkernarg1 HIP_FORCE_DEV_KERNARG=1
 run pktcap0 DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 run pktcap1 DEBUG_CLR_GRAPH_PACKET_CAPTURE=1
-run sysscope0 ROC_SYSTEM_SCOPE_SIGNAL=0
+# ROC_SYSTEM_SCOPE_SIGNAL=0 is NOT swept: it removes the system-scope completion signal the graph replay's host wait depends on and hangs the replay (round 1)
 run kernargopt1 DEBUG_HIP_KERNARG_COPY_OPT=1
 run hdpwa0 DEBUG_CLR_KERNARG_HDP_FLUSH_WA=0
 run fgs ROC_USE_FGS_KERNARG=0
