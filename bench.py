@@ -40,10 +40,33 @@ def _oracle(omp_threads=None):
     return C.CDLL(path)
 
 
+def usable_cores():
+    """host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box exposes all of the
+    host's cores to os.cpu_count() but grants a share of them; oversubscribing OpenMP there is slower than one thread)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return min(n, int(os.environ.get("MILA_BENCH_CPU_CORES", "16")))    # one GPU's CPU share on the pool's boxes is 16 cores
+
+
 def cpu_baseline(cfg):
     """Mila's CPU backend, restated (oracle/mila_oracle.c, kind "port"), timed on this box's host cores -- SURVEY.md section 8d:
       (i)  single thread, the reference default (MILA_ENABLE_OPENMP is OFF, CMakeLists.txt:78);
-      (ii) the reference's own `#pragma omp` placements on all host cores (os.cpu_count() threads).
+      (ii) the reference's own `#pragma omp` placements on the host cores this process may use (usable_cores(); `host_cores_visible`
+          is os.cpu_count()).
     Two workloads, each a BOUNDED sample:
       * one Gemma-4 12B decode token's Linear work (CpuLinearOp::forwardNaive, the batch-1 path; the reference has no CPU
         RMSNorm / RoPE / GQA / GeGLU ops -- < 1 % of the work): a few passes over a local and a global layer's four Linear shapes +
@@ -56,7 +79,7 @@ def cpu_baseline(cfg):
     rng = np.random.default_rng(0)
     D, H, V = cfg["embedding_dim"], cfg["hidden_dim"], cfg["vocab_size"]
     f32p = C.POINTER(C.c_float)
-    ncores = os.cpu_count() or 1
+    ncores = usable_cores()
 
     def shapes(g):
         hd = cfg["global_head_dim"] if g else cfg["head_dim"]
@@ -118,7 +141,7 @@ def cpu_baseline(cfg):
             "sample": "restated CpuLinearOp::forwardNaive (FP32, long double accumulation: the reference's batch-1 path) on %d passes over a local + %d over a "
                       "global layer's four Linear shapes + 1/%d of the lm_head rows (%.1f s on one core), extrapolated by weight count to %d layers + head; "
                       "`value` is the single-thread leg = the reference's default build (MILA_ENABLE_OPENMP OFF)" % (REPS_LOC, REPS_GLB, round(1 / HEAD_FRAC), one_tok["sample_s"], cfg["num_layers"]),
-            "host_cores": ncores,
+            "host_cores": ncores, "host_cores_visible": os.cpu_count(),
             "legs": {"single_thread": dict(one_tok, cores=1),
                      "all_cores_reference_omp_placements": dict(all_tok, cores=ncores, note="forwardNaive parallelises over batch rows (CpuLinearOp.ixx:389): one row at decode, so one busy core")},
             "config1_gpt2_124M_fp32_B1_T64": {"GFLOP": round(gpt_flop / 1e9, 2), "single_thread": dict(one_gpt, cores=1), "all_cores_reference_omp_placements": dict(all_gpt, cores=ncores)}}
