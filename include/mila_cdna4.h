@@ -396,6 +396,18 @@ MILA_API int mila_cdna4_decode_chain_init(void* scratch, size_t scratch_bytes, m
 MILA_API int mila_cdna4_decode_chain_status(const void* scratch, int32_t* error_out, mila_stream_t stream);
 MILA_API int mila_cdna4_decode_chain(const mila_decode_chain_args* host_args, mila_stream_t stream);
 
+/* The same four phases, same arguments, same bits, as a persistent ENGINE (csrc/engine.hip): per CU one loader wave streams the CU's
+ * share of all four weight matrices HBM -> LDS with LDS-DMA into seven 16-KiB rings and never waits for a dependency, seven consumer
+ * waves accumulate out of their rings in matvec's canonical order, and a phase's outputs reach every CU as 4-byte data-tagged
+ * granules (no flag, no fence).  The weight stream runs ~4.5 us ahead of every hand-off, which is what the kernel boundaries of the
+ * launch sequence cannot do.  decode_engine_applicable() says whether the geometry fits (256 CUs, the LDS budget, fp4 scale
+ * alignment); scratch as for the chain (decode_engine_scratch_bytes, zeroed ONCE by decode_engine_init); status as for the chain. */
+MILA_API size_t mila_cdna4_decode_engine_scratch_bytes(int D, int F);
+MILA_API int mila_cdna4_decode_engine_init(void* scratch, size_t scratch_bytes, mila_stream_t stream);
+MILA_API int mila_cdna4_decode_engine_status(const void* scratch, int32_t* error_out, mila_stream_t stream);
+MILA_API int mila_cdna4_decode_engine_applicable(int fmt, int group, int D, int F, int K_attn, int N_next, int next_fmt);
+MILA_API int mila_cdna4_decode_engine(const mila_decode_chain_args* host_args, mila_stream_t stream);
+
 /* q/k(/v) per-head RMSNorm + RoPE + KV-cache append for one decode token, in one launch:
  *   q <- rope(rmsnorm(q; qw)), k' = rope(rmsnorm(k; kw)), v' = rmsnorm(v_src; vw or ones),
  *   cache[pos % capacity] <- (k', v').  v_src == k (raw) on Gemma global layers. */

@@ -52,6 +52,7 @@ def load():
     _lib.mila_cdna4_gemm_w4a8_scratch_bytes.restype = C.c_size_t
     _lib.mila_cdna4_sample_stochastic_scratch_bytes.restype = C.c_size_t
     _lib.mila_cdna4_decode_chain_scratch_bytes.restype = C.c_size_t
+    _lib.mila_cdna4_decode_engine_scratch_bytes.restype = C.c_size_t
     _lib.mila_cdna4_attn_decode_ticket_count.restype = C.c_size_t
     return _lib
 
@@ -136,5 +137,6 @@ EXPORTED = [
     "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position", "fused_attn_decode_bf16",
     "attn_decode_split_count", "fused_attn_decode_partials_bf16", "matvec_attn_combine",
     "decode_chain_scratch_bytes", "decode_chain_init", "decode_chain_status", "decode_chain",
+    "decode_engine_scratch_bytes", "decode_engine_init", "decode_engine_status", "decode_engine_applicable", "decode_engine",
     "attn_decode_ticket_count", "fused_attn_decode_onepass_bf16", "prefetch_l3", "fused_attn_decode_ex", "dequantize_to_bf16", "gemm_geglu_fp8_scaled",
 ]
