@@ -1,26 +1,41 @@
-// Decode ENGINE: the four Linears that sit between two attention calls of a Gemma decode step -- o_proj -> post-attention tail ->
-// fc_gate_up + GeGLU -> fc_down -> post-FFN tail -> the next layer's input norm + qkv_proj (or the final norm + tied lm_head)
-// (Components/Transformers/Gemma/Gemma.Block.ixx:287-356; matvec kernels CudaMatVecBias.Bf16.cu:134-508) -- as ONE persistent launch
-// whose weight stream never stops at a dependency.
+// Decode ENGINE (opt-in, measured SLOWER than the launch sequence on MI355X -- see the table below): the four Linears that sit
+// between two attention calls of a Gemma decode step -- o_proj -> post-attention tail -> fc_gate_up + GeGLU -> fc_down -> post-FFN tail
+// -> the next layer's input norm + qkv_proj (or the final norm + tied lm_head) (Components/Transformers/Gemma/Gemma.Block.ixx:287-356;
+// matvec kernels CudaMatVecBias.Bf16.cu:134-508) -- as ONE persistent launch whose weight stream runs THROUGH its dependencies.
 //
-// Why another form after chain.hip (which was slower than the launches it replaced): there every wave streamed its own rows into
-// registers, so at most two pipeline steps (32 KB per CU, ~1.3 us of HBM time) could run ahead of a grid-wide hand-off that took
-// ~8 us.  Here (MI355X_MICROARCH.md price list: ldsdma-fill, prefetch-credit, allgather, engine-vs-launches):
-//   * one LOADER wave per CU moves the CU's share of all four weight matrices, in order, HBM -> LDS with LDS-DMA
-//     (global_load_lds_dwordx4, non-temporal), into seven 16-KiB rings -- one per CONSUMER wave -- and never waits for a dependency:
-//     weights are constants.  112 KiB per CU = 28 MB chip-wide = ~4.5 us of HBM time run ahead of every hand-off;
-//   * seven consumer waves read their ring (ds_read_b128), dequantize and accumulate exactly as matvec_body does (lane l owns the
-//     16-byte chunks l, l + 64, ... of a row in ascending order, then the wave butterfly): bit-identical to the unfused kernels;
-//   * a phase's outputs go to every CU as 4-byte DATA-TAGGED granules {tag16 | bf16}: one write-through (sc1) store per element, no
-//     flag, no fence, no counter; a consumer sweeps the vector with sc1 loads until every tag is the current one.  One fabric round
-//     trip after the last producer's store, under the loader's cover.
-// Stream geometry (shared by loader and consumers): CU b, consumer wave cw owns the output columns col_t = b + 256 (cw + 7 t);
-// a column is one weight row (GeGLU: the gate row col, then the up row N + col); a row's RECORD is [spr scale units | cpr weight
-// units] in 16-byte units (fp4: the row's group scales, fetched as aligned 16-byte windows; else spr = 0); a wave's records follow
-// each other with no padding, a phase ends on a 1-KiB piece boundary.  Any lane can fetch any unit (LDS-DMA takes per-lane addresses).
+// Structure (MI355X_MICROARCH.md price list: ldsdma-fill, prefetch-credit, engine-vs-launches):
+//   * every wave owns a RING in LDS (8 waves x 12 KiB per CU = 24 MB chip-wide) that it fills itself with LDS-DMA
+//     (global_load_lds_dwordx4, non-temporal) from its share of ALL FOUR weight matrices, in order, as far ahead as the ring allows:
+//     weights are constants, so the requests of phase p + 1 are in flight while phase p's outputs are still being handed over.
+//     Completion is the wave's own vmcnt; there is no loader role and no LDS protocol;
+//   * requests, waits, LDS reads and releases work on GROUPS of B 1-KiB pieces (one per-lane address, one ring slot, B immediate
+//     offsets), all bookkeeping wave-uniform;
+//   * a wave consumes its ring exactly as matvec_body consumes registers (lane l owns the 16-byte chunks l, l + 64, ... of a row in
+//     ascending order, then the wave butterfly): bit-identical to the unfused kernels, whatever the shape (tests/test_engine_gpu.py);
+//   * a phase's outputs reach every CU as 4-byte DATA-TAGGED granules {tag16 | bf16}: one write-through (sc1) store per element, no
+//     flag, no fence, no counter; consumers sweep the vector with sc1 loads until every tag is the current one (and keep topping up
+//     their rings between sweeps).
+// Stream geometry: CU b, wave cw owns the output columns col_t = b + 256 (cw + NW t); a column is one weight row (GeGLU: the gate
+// row col, then the up row N + col); a row's RECORD is [one piece of group scales (fp4: aligned 16-byte windows, lanes < spr)] + its
+// weight pieces (the final piece only on its first `tail` lanes: the others are neither fetched nor used).
 //
-// Every spin is bounded by the wall clock (error word, checked by the host); all 256 workgroups must be resident (one per CU: the
-// kernel asks for > 80 KiB of LDS).  Nothing here is retained between launches except the epoch word that makes tags unique.
+// Measured (tools/bench_engine.py, Gemma-3 12B layer, 8 cold weight sets, us per layer; tools/engine_timeline.py for the in-kernel
+// stamps; profiles/r02_engine_*.txt):
+//     form                                                        bf16     fp8     fp4     (four graph-captured launches: 75.6 / 47.0 / 34.5)
+//     one loader wave + 7 consumer rings per CU                   262      163     128     loader issue-bound (1 KiB per ~250 cycles)
+//     the same, LDS control words through typed LDS pointers      202      132     116     (generic pointers made them flat ops + vmcnt(0))
+//     every wave its own loader, 15-16 waves, 1-KiB bookkeeping   124       93      70     younger waves of a SIMD starve (issue arbitration by age)
+//     8 waves, 15-KiB rings, scalar bookkeeping                   107       83      75
+//     8 waves, groups of 4 (3) pieces  [this file]                107       82      69
+// What the stamps say about the last two: while streaming, a wave waits for its pieces only ~15 % of the time and sits ~40 % in the
+// LDS-DMA requests themselves (the CU's memory pipeline is full: the same back-pressure a register-streaming kernel sees at its
+// waitcnt), so the phases run at the launches' rate (236 MB in 35-41 us) -- but a phase ends when its SLOWEST wave does (54 / 63 / 74 us
+// min / median / max for equal shares; a launch re-balances through the dispatcher, a static share cannot), and each hand-off adds
+// 3-5 us after that.  With perfect balance the launch would still be ~82 us against 76.  The launch sequence stays the default;
+// this file stays as the measured counter-example and is not used by GemmaTransformer.
+//
+// Every spin is bounded (error word, checked by the host); all 256 workgroups must be resident (one per CU: > 80 KiB of LDS each).
+// Nothing is retained between launches except the epoch word that makes tags unique.
 #include <algorithm>
 
 #include "common.h"
@@ -30,13 +45,8 @@
 
 namespace mila {
 
-constexpr int kEngCons = 7;                         // consumer waves (wave 0 of the workgroup is the loader)
-constexpr int kEngThreads = 64 * (kEngCons + 1);
-constexpr int kRingUnits = 1024;                    // 16-byte units per consumer ring (16 KiB)
-constexpr int kRingPieces = kRingUnits / 64;
-constexpr int kBurst = 4;                           // pieces the loader issues per ring and round
-constexpr int kMaxGroups = 3;                       // 64-chunk groups of x a consumer wave owns in a prologue: K <= 7 * 3 * 512
-constexpr long long kEngSpinTicks = 2000000;        // wall_clock64 at 100 MHz: 20 ms
+constexpr int kMaxGroups = 3;                       // 64-chunk groups of x a wave owns in a prologue at NW = 8: K <= 8 * 3 * 512
+constexpr int kEngMaxSpins = 1 << 18;               // polls of one wait before it gives up; no clock reads on a polling path
 
 struct EngPhase
 {
@@ -61,274 +71,314 @@ struct EngParams
     uint32_t* error;
     int xa_off, xb_off, ctrl_off; // LDS byte offsets behind the rings
     int nblocks;
+    unsigned long long* debug;    // diagnostic builds only (mila_cdna4_decode_engine_debug): wall-clock stamps [block][wave][16]; null otherwise
 };
 
-// control block in LDS (uint32 words)
-enum { C_FULL = 0, C_FREE = 8, C_BAR = 16, C_RED_A = 32, C_RED_B = 48, C_WORDS = 64 };
-
-__device__ __forceinline__ uint32_t lds_ld(volatile uint32_t* p) { return *p; }
-__device__ __forceinline__ void lds_st(volatile uint32_t* p, uint32_t v) { *p = v; }
-
-__device__ __forceinline__ bool eng_timed_out(long long t0, uint32_t* error, uint32_t code)
+__device__ __forceinline__ void eng_stamp(const EngParams& c, int b, int wave, int lane, int idx)
 {
-    if (wall_clock64() - t0 <= kEngSpinTicks) return false;
-    __hip_atomic_store(as_global(error), code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return true;
+    if (c.debug != nullptr && lane == 0 && wave < 16) c.debug[((size_t)b * 16 + wave) * 16 + idx] = (unsigned long long)wall_clock64();
 }
 
-// columns of consumer wave cw in a phase, its records and pieces
+// control block in LDS: the two reduction arrays of the sandwich prologue (floats) and the issue table
+enum { C_RED_A = 0, C_RED_B = 32, C_ISSUE = 64, C_WORDS = 64 + 48 };      // C_ISSUE: 4 EngIssue records (40 bytes each, 48 words)
+typedef __attribute__((address_space(3))) volatile float* ctrl_fptr;
+
+template <int NW>
 __device__ __forceinline__ int eng_ncols(int N, int b, int cw)
 {
     const int first = b + 256 * cw;
-    return first < N ? (N - 1 - first) / (256 * kEngCons) + 1 : 0;
-}
-__device__ __forceinline__ int eng_npieces(const EngPhase& P, int b, int cw)
-{
-    const long long units = (long long)eng_ncols(P.N, b, cw) * P.rpc * (P.cpr + P.spr);
-    return (int)((units + 63) / 64);
+    return first < N ? (N - 1 - first) / (256 * NW) + 1 : 0;
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------
-// loader wave
-// ------------------------------------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void eng_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+// wait until at most n (0 .. 15) of this wave's vector-memory requests are outstanding; requests retire in order
 __device__ __forceinline__ void eng_wait_vmcnt_at_most(int n)
 {
-    switch (n >> 2)
+    switch (n)
     {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+        case 0: eng_wait_vmcnt<0>(); break;
+        case 1: eng_wait_vmcnt<1>(); break;
+        case 2: eng_wait_vmcnt<2>(); break;
+        case 3: eng_wait_vmcnt<3>(); break;
+        case 4: eng_wait_vmcnt<4>(); break;
+        case 5: eng_wait_vmcnt<5>(); break;
+        case 6: eng_wait_vmcnt<6>(); break;
+        case 7: eng_wait_vmcnt<7>(); break;
+        case 8: eng_wait_vmcnt<8>(); break;
+        case 9: eng_wait_vmcnt<9>(); break;
+        case 10: eng_wait_vmcnt<10>(); break;
+        case 11: eng_wait_vmcnt<11>(); break;
+        case 12: eng_wait_vmcnt<12>(); break;
+        case 13: eng_wait_vmcnt<13>(); break;
+        case 14: eng_wait_vmcnt<14>(); break;
+        default: eng_wait_vmcnt<15>(); break;
     }
 }
 
-// One lane's cursor in one ring's stream: the record and the unit inside it that the lane fetches in the ring's NEXT piece, the
-// address of that unit, and how many more pieces the lane can fetch by just adding 1 KiB (it stays inside one contiguous region: a
-// row's weights, or its scale windows).  Most pieces take that fast path; a lane that leaves its region recomputes from (rec, pos).
-struct EngCur
+// The fields of a phase the issue side needs.  The issue side runs ahead of the consume side, so it picks its phase at run time; a
+// dynamic index into the kernel-argument struct would make the compiler copy the whole struct to scratch, so the four records are
+// copied once (constant indices) into LDS and read from there.
+struct EngIssue
 {
-    const uint8_t* addr;
-    int left;      // units from this lane's position to the end of its region
-    int pos, rec;
+    const uint8_t* W;
+    const uint8_t* S;
+    int N, cpr, spr, ngroups, rpc, pad;
 };
-
-__device__ __forceinline__ void eng_cur_locate(EngCur& cu, const EngPhase& P, int b, int w, int nrec, int upr, int rshift)
+typedef __attribute__((address_space(3))) EngIssue* issue_tab_ptr;
+__device__ __forceinline__ void eng_issue_store(issue_tab_ptr t, const EngPhase& P)
 {
-    while (cu.pos >= upr) { cu.pos -= upr; ++cu.rec; }
-    if (cu.rec >= nrec)
-    {
-        // padding behind the stream's last record (the rest of the phase's last piece): re-read a valid unit; nobody consumes it
-        cu.addr = P.W;
-        cu.left = 1 << 30;
-        return;
-    }
-    const int col = b + 256 * (w + kEngCons * (cu.rec >> rshift));
-    const int row = (cu.rec & (P.rpc - 1)) ? P.N + col : col;
-    if (cu.pos < P.spr)
-    {
-        const uintptr_t s0 = reinterpret_cast<uintptr_t>(P.S) + (uintptr_t)row * (uintptr_t)(P.ngroups * 4);
-        cu.addr = reinterpret_cast<const uint8_t*>((s0 & ~(uintptr_t)15) + (uintptr_t)cu.pos * 16);
-        cu.left = P.spr - cu.pos;
-    }
-    else
-    {
-        cu.addr = P.W + ((size_t)row * (size_t)P.cpr + (size_t)(cu.pos - P.spr)) * 16;
-        cu.left = upr - cu.pos;
-    }
+    t->W = P.W; t->S = P.S; t->N = P.N; t->cpr = P.cpr; t->spr = P.spr; t->ngroups = P.ngroups; t->rpc = P.rpc; t->pad = 0;
 }
-
-__device__ void eng_loader(const EngParams& c, unsigned char* lds, volatile uint32_t* ctrl, int b, int lane)
+__device__ __forceinline__ uint64_t eng_uniform64(uint64_t v)
 {
-    uint32_t issued[kEngCons], seen_free[kEngCons], published[kEngCons], prev_issued[kEngCons];
-#pragma unroll
-    for (int w = 0; w < kEngCons; ++w) issued[w] = seen_free[w] = published[w] = prev_issued[w] = 0u;
-
-    for (int p = 0; p < 4; ++p)
-    {
-        const EngPhase& P = c.ph[p];
-        const int upr = P.cpr + P.spr;
-        const int rshift = P.rpc == 2 ? 1 : 0;
-        int rem[kEngCons], nrec[kEngCons];
-        EngCur cur[kEngCons];
-#pragma unroll
-        for (int w = 0; w < kEngCons; ++w)
-        {
-            rem[w] = eng_npieces(P, b, w);
-            nrec[w] = eng_ncols(P.N, b, w) * P.rpc;
-            cur[w].rec = 0;
-            cur[w].pos = lane;
-            eng_cur_locate(cur[w], P, b, w, nrec[w], upr, rshift);
-        }
-        bool any = true;
-        long long t0 = wall_clock64();
-        while (any)
-        {
-            any = false;
-            int round_cnt = 0;
-#pragma unroll
-            for (int w = 0; w < kEngCons; ++w)
-            {
-                if (rem[w] <= 0) continue;
-                any = true;
-                int space = kRingPieces - (int)(issued[w] - seen_free[w]);
-                if (space < kBurst)
-                {
-                    seen_free[w] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_ld(ctrl + C_FREE + w));
-                    space = kRingPieces - (int)(issued[w] - seen_free[w]);
-                }
-                const int n = min(min(kBurst, rem[w]), space);
-                for (int k = 0; k < n; ++k)
-                {
-                    unsigned char* dst = lds + (size_t)w * (kRingUnits * 16) + (size_t)((issued[w] + (uint32_t)k) & (kRingPieces - 1)) * 1024;
-                    __builtin_amdgcn_global_load_lds(cur[w].addr, (__attribute__((address_space(3))) void*)dst, 16, 0, 2 /* nt: read once */);
-                    cur[w].pos += 64;
-                    cur[w].left -= 64;
-                    cur[w].addr += 1024;
-                    if (__any(cur[w].left <= 0))
-                    {
-                        if (cur[w].left <= 0) eng_cur_locate(cur[w], P, b, w, nrec[w], upr, rshift);
-                    }
-                }
-                issued[w] += (uint32_t)n;
-                rem[w] -= n;
-                round_cnt += n;
-            }
-            // everything issued before this round has landed once at most round_cnt requests are outstanding
-            eng_wait_vmcnt_at_most(round_cnt);
-#pragma unroll
-            for (int w = 0; w < kEngCons; ++w)
-                if (published[w] != prev_issued[w]) { published[w] = prev_issued[w]; lds_st(ctrl + C_FULL + w, published[w]); }
-#pragma unroll
-            for (int w = 0; w < kEngCons; ++w) prev_issued[w] = issued[w];
-            if (round_cnt == 0 && any)
-            {
-                __builtin_amdgcn_s_sleep(4);
-                if (eng_timed_out(t0, c.error, 100u + (uint32_t)p)) return;
-            }
-            else t0 = wall_clock64();
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int w = 0; w < kEngCons; ++w) lds_st(ctrl + C_FULL + w, issued[w]);
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ EngIssue eng_issue_load(issue_tab_ptr tab, int p)
+{
+    issue_tab_ptr t = tab + p;
+    EngIssue q;
+    q.W = reinterpret_cast<const uint8_t*>(eng_uniform64(reinterpret_cast<uint64_t>(t->W)));
+    q.S = reinterpret_cast<const uint8_t*>(eng_uniform64(reinterpret_cast<uint64_t>(t->S)));
+    q.N = __builtin_amdgcn_readfirstlane(t->N); q.cpr = __builtin_amdgcn_readfirstlane(t->cpr); q.spr = __builtin_amdgcn_readfirstlane(t->spr);
+    q.ngroups = __builtin_amdgcn_readfirstlane(t->ngroups); q.rpc = __builtin_amdgcn_readfirstlane(t->rpc); q.pad = 0;
+    return q;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// consumer waves
+// A worker wave.  Its stream over all four phases is a sequence of records (one weight row each): [a scale piece (fp4)] + the row's
+// weight pieces, a piece = 64 x 16 bytes = one LDS-DMA instruction.  Records are cut into groups of B pieces (the last one short); a
+// group is the unit of requesting, waiting, reading and releasing, so the bookkeeping -- all of it wave-uniform, one per-lane address
+// per group -- is paid once per B KiB.  The ring holds RG groups.
 // ------------------------------------------------------------------------------------------------------------------------------
-struct EngCons
+template <int NW, int B, int RG>
+struct EngW
 {
-    unsigned char* ring;          // this wave's ring
-    volatile uint32_t* ctrl;
+    static_assert(RG >= 2 && RG <= 4 && (RG - 1) * B <= 15, "ring shape");
+    unsigned char* ring;          // RG * B KiB
     uint32_t* error;
+    issue_tab_ptr itab;
     int cw, lane, b;
-    uint32_t base_piece;          // pieces of earlier phases
-    uint32_t full_seen;
-    uint32_t bar_gen;
+    // issue side
+    int iphase, icols_left, icol, iwhich;
+    int ig, igpr, inp_last, itail, ipre;      // group within the record; groups per record; pieces of its last group; lanes of its final piece; scale pieces (0/1)
+    EngIssue ip;
+    const uint8_t* iwrow;         // weight row of the record being requested
+    const uint8_t* isrow;         // its aligned scale windows (fp4)
+    int islot;
+    uint32_t issued;              // DMA instructions so far
+    uint32_t gissued;             // groups requested so far
+    uint32_t cum0, cum1, cum2, cum3;          // `issued` right after the group in ring slot 0..3 was requested
+    // consume side
+    uint32_t gconsumed;           // groups whose ring space may be overwritten
+    int cslot;
     uint32_t tag;                 // granule tag of the phase being PRODUCED
     bool failed;
+    bool dbg;                     // diagnostic launches: account the time spent waiting for pieces
+    unsigned long long stall, t_lds, t_issue, t_fin;
+
+    __device__ __forceinline__ void set_record_row()
+    {
+        const int row = iwhich ? ip.N + icol : icol;
+        iwrow = ip.W + (size_t)row * (size_t)ip.cpr * 16;
+        isrow = reinterpret_cast<const uint8_t*>((reinterpret_cast<uintptr_t>(ip.S) + (uintptr_t)row * (uintptr_t)(ip.ngroups * 4)) & ~(uintptr_t)15);
+    }
+    __device__ __forceinline__ void begin_phase()
+    {
+        while (iphase < 4)
+        {
+            ip = eng_issue_load(itab, iphase);
+            const int ncols = eng_ncols<NW>(ip.N, b, cw);
+            if (ncols > 0)
+            {
+                icols_left = ncols - 1;
+                icol = b + 256 * cw;
+                iwhich = 0;
+                ig = 0;
+                const int steps = (ip.cpr + 63) >> 6;
+                ipre = ip.spr > 0 ? 1 : 0;
+                const int ppr = ipre + steps;
+                igpr = (ppr + B - 1) / B;
+                inp_last = ppr - (igpr - 1) * B;
+                itail = ip.cpr - 64 * (steps - 1);
+                set_record_row();
+                return;
+            }
+            ++iphase;
+        }
+    }
+    __device__ __forceinline__ void next_record()
+    {
+        ig = 0;
+        if (ip.rpc == 2 && iwhich == 0) iwhich = 1;
+        else
+        {
+            iwhich = 0;
+            if (icols_left == 0) { ++iphase; begin_phase(); return; }
+            --icols_left;
+            icol += 256 * NW;
+        }
+        set_record_row();
+    }
+    template <int OFF>
+    __device__ __forceinline__ void dma(const uint8_t* src, unsigned char* dst)
+    {
+        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, OFF, 2 /* nt: read once */);
+    }
+    __device__ __forceinline__ void issue_group()
+    {
+        unsigned char* dst = ring + (size_t)islot * (B * 1024);
+        // piece k of this group is piece ig * B + k of the record; weight piece m sits at row + 1024 m
+        const uint8_t* src = iwrow + ((ptrdiff_t)(ig * B - ipre) * 1024 + lane * 16);
+        const bool last = ig + 1 == igpr;
+        if (!last && !(ipre && ig == 0))
+        {
+            dma<0>(src, dst);
+            if constexpr (B > 1) dma<1024>(src, dst);
+            if constexpr (B > 2) dma<2048>(src, dst);
+            if constexpr (B > 3) dma<3072>(src, dst);
+            issued += B;
+        }
+        else
+        {
+            const int np = last ? inp_last : B;
+            const int fin = last ? np - 1 : -1;          // the record's final piece: only its first `itail` lanes hold weights
+            const bool sc0 = ipre && ig == 0;
+            if (sc0) { if (lane < ip.spr) dma<0>(isrow + lane * 16, dst); }
+            else if (fin == 0) { if (lane < itail) dma<0>(src, dst); }
+            else dma<0>(src, dst);
+            if constexpr (B > 1)
+                if (np > 1) { if (fin == 1) { if (lane < itail) dma<1024>(src, dst); } else dma<1024>(src, dst); }
+            if constexpr (B > 2)
+                if (np > 2) { if (fin == 2) { if (lane < itail) dma<2048>(src, dst); } else dma<2048>(src, dst); }
+            if constexpr (B > 3)
+                if (np > 3) { if (fin == 3) { if (lane < itail) dma<3072>(src, dst); } else dma<3072>(src, dst); }
+            issued += (uint32_t)np;
+        }
+        cum0 = islot == 0 ? issued : cum0;
+        cum1 = islot == 1 ? issued : cum1;
+        if constexpr (RG > 2) cum2 = islot == 2 ? issued : cum2;
+        if constexpr (RG > 3) cum3 = islot == 3 ? issued : cum3;
+        islot = (islot + 1 == RG) ? 0 : islot + 1;
+        ++gissued;
+        if (++ig == igpr) next_record();
+    }
+    // request groups while the ring has room; never blocks
+    __device__ __forceinline__ void top_up()
+    {
+        while (iphase < 4 && (int)(gissued - gconsumed) < RG) issue_group();
+    }
+    // the oldest group is in LDS on return
+    __device__ __forceinline__ void need()
+    {
+        // (each field through readfirstlane: a plain select between fields becomes a select between their addresses and pins the whole struct in scratch)
+        const uint32_t c0 = __builtin_amdgcn_readfirstlane(cum0), c1 = __builtin_amdgcn_readfirstlane(cum1);
+        uint32_t cm = cslot == 0 ? c0 : c1;
+        if constexpr (RG > 2) { const uint32_t c2 = __builtin_amdgcn_readfirstlane(cum2); cm = cslot == 2 ? c2 : cm; }
+        if constexpr (RG > 3) { const uint32_t c3 = __builtin_amdgcn_readfirstlane(cum3); cm = cslot == 3 ? c3 : cm; }
+        const int allowed = (int)(issued - cm);           // requests younger than the group's last
+        unsigned long long t0 = 0ull;
+        if (dbg) t0 = __builtin_readcyclecounter();
+        if (allowed == (RG - 1) * B) eng_wait_vmcnt<(RG - 1) * B>();          // steady state: whole groups behind it
+        else eng_wait_vmcnt_at_most(allowed);
+        if (dbg) stall += __builtin_readcyclecounter() - t0;
+    }
+    // the oldest group is in registers: reuse its space (and request what goes there)
+    __device__ __forceinline__ void release()
+    {
+        ++gconsumed;
+        cslot = (cslot + 1 == RG) ? 0 : cslot + 1;
+        top_up();
+    }
+    // Only LDS data crosses these barriers, so only LDS operations are waited for: __syncthreads() would also wait for vmcnt(0),
+    // i.e. for every weight request in flight.  The ring is topped up first (a wave parked at s_barrier cannot issue).
+    __device__ __forceinline__ void barrier()
+    {
+        top_up();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    __device__ __forceinline__ bool timed_out(int& spins, uint32_t code)
+    {
+        if (++spins <= kEngMaxSpins) return false;
+        __hip_atomic_store(as_global(error), code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        failed = true;
+        return true;
+    }
 };
-
-// barrier among the consumer waves only (the loader never stops): an LDS arrival counter
-__device__ __forceinline__ void eng_cbar(EngCons& s)
-{
-    s.bar_gen += kEngCons;
-    if (s.failed) return;             // one give-up is enough: the rest of the launch runs through without waiting
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (s.lane == 0) __hip_atomic_fetch_add(const_cast<uint32_t*>(s.ctrl + C_BAR), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const long long t0 = wall_clock64();
-    while ((int)((uint32_t)__builtin_amdgcn_readfirstlane((int)lds_ld(s.ctrl + C_BAR)) - s.bar_gen) < 0)
-    {
-        __builtin_amdgcn_s_sleep(1);
-        if (eng_timed_out(t0, s.error, 200u)) { s.failed = true; break; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-__device__ __forceinline__ void eng_wait_full(EngCons& s, uint32_t piece)
-{
-    if ((int)(s.full_seen - piece) > 0 || s.failed) return;
-    const long long t0 = wall_clock64();
-    for (;;)
-    {
-        s.full_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_ld(s.ctrl + C_FULL + s.cw));
-        if ((int)(s.full_seen - piece) > 0) break;
-        __builtin_amdgcn_s_sleep(1);
-        if (eng_timed_out(t0, s.error, 300u + (uint32_t)s.cw)) { s.failed = true; break; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 
 __device__ __forceinline__ uint32_t eng_granule(uint32_t tag, uint32_t bf16_bits) { return (tag << 16) | (bf16_bits & 0xffffu); }
 
-// Sweep `n` granules (n % 4 == 0) of a vector every producer workgroup writes with 4-byte write-through stores; the seven consumer
-// waves split its 16-byte units; elements land in `dst` (LDS) as bf16.  Returns when every tag of this wave's share matched.
-__device__ void eng_gather(EngCons& s, const uint32_t* gv, int n, uint32_t want_tag, uint16_t* dst)
+// Sweep `n` granules (n % 4 == 0) of a vector every producer workgroup writes with 4-byte write-through stores; the NW waves split its
+// 16-byte units, each lane takes up to UPL of them per pass with all their loads in flight; elements land in `dst` (LDS) as bf16.
+template <int NW, int B, int RG>
+__device__ __forceinline__ void eng_gather(EngW<NW, B, RG>& s, const uint32_t* gv, int n, uint32_t want_tag, uint16_t* dst)
 {
+    constexpr int UPL = 8;
     const int nun = n >> 2;
-    const int per = (nun + kEngCons - 1) / kEngCons;
+    const int per = (nun + NW - 1) / NW;
     const int u0 = s.cw * per, u1 = min(nun, u0 + per);
     const gu64* q = as_global(reinterpret_cast<const unsigned long long*>(gv));
     if (s.failed) return;
-    const long long t0 = wall_clock64();
-    for (int base = u0 + s.lane; __any(base < u1); base += 64 * 4)
+    int spins = 0;
+    for (int base = u0 + s.lane; __any(base < u1); base += 64 * UPL)
     {
-        // four units per lane and pass; a unit is kept once all four of its tags match
-        bool done[4] = {false, false, false, false};
+        uint32_t pending = 0u;
+#pragma unroll
+        for (int k = 0; k < UPL; ++k) pending |= (base + 64 * k < u1) ? (1u << k) : 0u;
         for (;;)
         {
-            bool all_ok = true;
+            unsigned long long lo[UPL], hi[UPL];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < UPL; ++k)
             {
-                const int u = base + 64 * k;
-                if (u >= u1 || done[k]) continue;
-                const unsigned long long lo = __hip_atomic_load(q + (size_t)u * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long hi = __hip_atomic_load(q + (size_t)u * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t g0 = (uint32_t)lo, g1 = (uint32_t)(lo >> 32), g2 = (uint32_t)hi, g3 = (uint32_t)(hi >> 32);
-                const bool ok = (g0 >> 16) == want_tag && (g1 >> 16) == want_tag && (g2 >> 16) == want_tag && (g3 >> 16) == want_tag;
-                if (ok)
+                const int u = min(base + 64 * k, nun - 1);
+                lo[k] = __hip_atomic_load(q + (size_t)u * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hi[k] = __hip_atomic_load(q + (size_t)u * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < UPL; ++k)
+            {
+                if (!(pending & (1u << k))) continue;
+                const uint32_t g0 = (uint32_t)lo[k], g1 = (uint32_t)(lo[k] >> 32), g2 = (uint32_t)hi[k], g3 = (uint32_t)(hi[k] >> 32);
+                if ((g0 >> 16) == want_tag && (g1 >> 16) == want_tag && (g2 >> 16) == want_tag && (g3 >> 16) == want_tag)
                 {
                     u32x2 v;
                     v[0] = (g0 & 0xffffu) | (g1 << 16);
                     v[1] = (g2 & 0xffffu) | (g3 << 16);
-                    *reinterpret_cast<u32x2*>(dst + (size_t)u * 4) = v;
-                    done[k] = true;
+                    *reinterpret_cast<u32x2*>(dst + (size_t)(base + 64 * k) * 4) = v;
+                    pending &= ~(1u << k);
                 }
-                else all_ok = false;
             }
-            if (__all(all_ok)) break;
-            __builtin_amdgcn_s_sleep(8);
-            if (eng_timed_out(t0, s.error, 400u)) { s.failed = true; return; }
+            if (__all(pending == 0u)) break;
+            s.top_up();
+            __builtin_amdgcn_s_sleep(2);
+            if (s.timed_out(spins, 400u)) return;
         }
     }
 }
 
 // Stage x of a phase into LDS as matvec_body does (same canonical reductions, same roundings), zero-padded to the chunk positions the
 // streaming loop touches.  PRO: 0 = x as is; 2 = sandwich tail (post-norm, residual, layer scalar, next norm).  XSRC: plain memory
-// (phase 0) or the previous phase's granules.  rkeep: residual in (RES_REG) / the tail's result out; chunk 64 (cw + 7 k) + lane.
-template <int FMT, int PRO, int XSRC, int RSRC>
-__device__ void eng_stage_x(EngCons& s, const EngPhase& P, u32x4* xs, uint32_t want_tag, u32x4 (&rkeep)[kMaxGroups], bool write_res_out)
+// (phase 0) or the previous phase's granules.  rkeep: residual in (RES_REG) / the tail's result out; chunk 64 (cw + NW k) + lane.
+template <int NW, int B, int RG, int FMT, int PRO, int XSRC, int RSRC>
+__device__ __forceinline__ void eng_stage_x(const EngParams& c, EngW<NW, B, RG>& s, const EngPhase& P, u32x4* xs, ctrl_fptr ctrl, uint32_t want_tag,
+                                            u32x4 (&rkeep)[kMaxGroups], bool write_res_out)
 {
     constexpr int EPC = Fmt<FMT>::kElemsPerChunk;
     constexpr int XPC = EPC / 8;
+    constexpr int MG = (NW >= 12) ? 2 : kMaxGroups;      // groups per wave: K <= NW * MG * 512
     const int K = P.K, nx16 = K / 8;
     const int steps = (P.cpr + 63) / 64;
     const int nx16_pad = steps * 64 * XPC;
     const int G = (nx16 + 63) / 64;
     const int lane = s.lane, cw = s.cw;
     // operands that wait for nobody first
-    u32x4 pnw[kMaxGroups], ppw[kMaxGroups], pres[kMaxGroups];
+    u32x4 pnw[MG], ppw[MG], pres[MG];
     if constexpr (PRO == 2)
     {
 #pragma unroll
-        for (int k = 0; k < kMaxGroups; ++k)
+        for (int k = 0; k < MG; ++k)
         {
-            const size_t e = (size_t)min(64 * (cw + kEngCons * k) + lane, nx16 - 1) * 8;
+            const size_t e = (size_t)min(64 * (cw + NW * k) + lane, nx16 - 1) * 8;
             pnw[k] = ld16(P.norm_w + e);
             ppw[k] = ld16(P.post_w + e);
             if constexpr (RSRC == RES_MEM) pres[k] = ld16(P.res + e);
@@ -336,38 +386,38 @@ __device__ void eng_stage_x(EngCons& s, const EngPhase& P, u32x4* xs, uint32_t w
         }
     }
     // zero padding behind the vector
-    for (int i = nx16 + (cw * 64 + lane); i < nx16_pad; i += 64 * kEngCons) xs[i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = nx16 + (cw * 64 + lane); i < nx16_pad; i += 64 * NW) xs[i] = u32x4{0u, 0u, 0u, 0u};
     if constexpr (XSRC == X_PLAIN)
     {
         const uint16_t* xp = reinterpret_cast<const uint16_t*>(P.x);
-        for (int i = cw * 64 + lane; i < nx16; i += 64 * kEngCons) xs[i] = ld16(xp + (size_t)i * 8);
+        for (int i = cw * 64 + lane; i < nx16; i += 64 * NW) xs[i] = ld16(xp + (size_t)i * 8);
     }
     else
-        eng_gather(s, reinterpret_cast<const uint32_t*>(P.x), K, want_tag, reinterpret_cast<uint16_t*>(xs));
-    eng_cbar(s);
+        eng_gather<NW, B, RG>(s, reinterpret_cast<const uint32_t*>(P.x), K, want_tag, reinterpret_cast<uint16_t*>(xs));
+    s.barrier();
     if constexpr (PRO == 2)
     {
-        volatile float* red_a = reinterpret_cast<volatile float*>(s.ctrl + C_RED_A);
-        volatile float* red_b = reinterpret_cast<volatile float*>(s.ctrl + C_RED_B);
-        u32x4 a[kMaxGroups];
+        ctrl_fptr red_a = ctrl + C_RED_A;
+        ctrl_fptr red_b = ctrl + C_RED_B;
+        u32x4 a[MG];
 #pragma unroll
-        for (int k = 0; k < kMaxGroups; ++k)
+        for (int k = 0; k < MG; ++k)
         {
-            const int g = cw + kEngCons * k, ch = 64 * g + lane;
+            const int g = cw + NW * k, ch = 64 * g + lane;
             if (g >= G) continue;
             a[k] = xs[min(ch, nx16 - 1)];
             float ss = ch < nx16 ? sumsq8(a[k], 0.0f) : 0.0f;
             ss = wave_sum(ss);
             if (lane == 0) red_a[g] = ss;
         }
-        eng_cbar(s);
+        s.barrier();
         float t = 0.0f;
         for (int g = 0; g < G; ++g) t += red_a[g];
         const float rstd_a = rsqrtf(t / (float)K + P.eps);
 #pragma unroll
-        for (int k = 0; k < kMaxGroups; ++k)
+        for (int k = 0; k < MG; ++k)
         {
-            const int g = cw + kEngCons * k, ch = 64 * g + lane;
+            const int g = cw + NW * k, ch = 64 * g + lane;
             if (g >= G) continue;
             rkeep[k] = sandwich_tail8(rms_apply8(a[k], ppw[k], rstd_a, 0.0f), pres[k], P.post_scale);
             if (write_res_out && ch < nx16) st16(P.res_out + (size_t)ch * 8, rkeep[k]);
@@ -375,86 +425,107 @@ __device__ void eng_stage_x(EngCons& s, const EngPhase& P, u32x4* xs, uint32_t w
             ss = wave_sum(ss);
             if (lane == 0) red_b[g] = ss;
         }
-        eng_cbar(s);
+        s.barrier();
         float t2 = 0.0f;
         for (int g = 0; g < G; ++g) t2 += red_b[g];
         const float rstd_r = rsqrtf(t2 / (float)K + P.eps);
 #pragma unroll
-        for (int k = 0; k < kMaxGroups; ++k)
+        for (int k = 0; k < MG; ++k)
         {
-            const int g = cw + kEngCons * k, ch = 64 * g + lane;
+            const int g = cw + NW * k, ch = 64 * g + lane;
             if (g >= G || ch >= nx16) continue;
             xs[ch] = rms_apply8(rkeep[k], pnw[k], rstd_r, 0.0f);
         }
-        eng_cbar(s);
+        s.barrier();
     }
 }
 
 // stream this wave's records of one phase out of its ring
-template <int FMT, bool GEGLU, int YDST>
-__device__ void eng_stream(EngCons& s, const EngPhase& P, const u32x4* xs)
+template <int NW, int B, int RG, int FMT, bool GEGLU, int YDST>
+__device__ __forceinline__ void eng_stream(EngW<NW, B, RG>& s, const EngPhase& P, const u32x4* xs)
 {
     constexpr int NR = GEGLU ? 2 : 1;
-    constexpr int MAXSTEPS_FP4 = 8;          // K <= 16384
+    constexpr int PRE = FMT == FMT_FP4 ? 1 : 0;  // scale pieces ahead of the weights
+    constexpr int MAXSTEPS_FP4 = 8;              // K <= 16384
     const int lane = s.lane, cw = s.cw, b = s.b;
-    const int cpr = P.cpr, spr = P.spr, upr = cpr + spr;
-    const int steps = (cpr + 63) / 64;
-    const int ncols = eng_ncols(P.N, b, cw);
-    const uint32_t base_units = s.base_piece * 64u;
-    uint32_t u = 0;                          // units of this phase already behind us
+    const int cpr = P.cpr;
+    const int steps = (cpr + 63) >> 6;
+    const int ppr = PRE + steps;
+    const int gpr = (ppr + B - 1) / B;
+    const int np_last = ppr - (gpr - 1) * B;
+    const int tail = cpr - 64 * (steps - 1);
+    const int ncols = eng_ncols<NW>(P.N, b, cw);
     for (int t = 0; t < ncols; ++t)
     {
-        const int col = b + 256 * (cw + kEngCons * t);
+        const int col = b + 256 * (cw + NW * t);
         float acc[NR];
 #pragma unroll
         for (int j = 0; j < NR; ++j)
         {
-            const int row = j ? P.N + col : col;
-            float sc[MAXSTEPS_FP4];
-            if constexpr (FMT == FMT_FP4)
-            {
-                // the record's scale windows come first: copy this lane's scale of every step into registers
-                eng_wait_full(s, s.base_piece + (u + (uint32_t)spr - 1u) / 64u);
-                const uint32_t mis = (uint32_t)(((size_t)row * (size_t)(P.ngroups * 4)) & 15u);
-#pragma unroll
-                for (int m = 0; m < MAXSTEPS_FP4; ++m)
-                {
-                    const int cc = min(64 * m + lane, cpr - 1);
-                    const uint32_t off = (((base_units + u) * 16u) + mis + 4u * (uint32_t)(cc >> P.cpg_shift)) & (kRingUnits * 16 - 1);
-                    sc[m] = (m < steps) ? *reinterpret_cast<const float*>(s.ring + off) : 0.0f;
-                }
-            }
             float a = 0.0f;
-            for (int m = 0; m < steps; ++m)
+            float sc[MAXSTEPS_FP4];
+            for (int g = 0; g < gpr; ++g)
             {
-                const int c = 64 * m + lane;
-                const int cc = min(c, cpr - 1);
-                const uint32_t last = u + (uint32_t)spr + (uint32_t)min(64 * m + 63, cpr - 1);
-                eng_wait_full(s, s.base_piece + last / 64u);
-                const u32x4 w = *reinterpret_cast<const u32x4*>(s.ring + (((base_units + u + (uint32_t)spr + (uint32_t)cc) & (kRingUnits - 1)) * 16u));
-                if constexpr (FMT == FMT_FP4)
-                {
-                    float scm = sc[0];
+                s.need();
+                const unsigned char* gp = s.ring + (size_t)s.cslot * (B * 1024) + lane * 16;
+                const int np = g + 1 == gpr ? np_last : B;
+                const int fin = g + 1 == gpr ? np - 1 : -1;
+                u32x4 w[B];
 #pragma unroll
-                    for (int mm = 1; mm < MAXSTEPS_FP4; ++mm) scm = (m == mm) ? sc[mm] : scm;
-                    a = fmaf(scm, chunk_dot<FMT>(w, xs, c, 0.0f), a);
+                for (int k = 0; k < B; ++k)
+                    if (k < np) w[k] = *reinterpret_cast<const u32x4*>(gp + k * 1024);
+                if constexpr (PRE)
+                {
+                    if (g == 0)
+                    {
+                        // the record's first piece holds the row's aligned scale windows: this lane's scale of every step
+                        const int row = j ? P.N + col : col;
+                        const uint32_t mis = (uint32_t)(((size_t)row * (size_t)(P.ngroups * 4)) & 15u);
+                        const unsigned char* p0 = s.ring + (size_t)s.cslot * (B * 1024);
+#pragma unroll
+                        for (int m = 0; m < MAXSTEPS_FP4; ++m)
+                        {
+                            const int cc = min(64 * m + lane, cpr - 1);
+                            sc[m] = (m < steps) ? *reinterpret_cast<const float*>(p0 + mis + 4u * (uint32_t)(cc >> P.cpg_shift)) : 0.0f;
+                        }
+                    }
                 }
-                else
-                    a = chunk_dot<FMT>(w, xs, c, a);
-                // the ring units below this point are in registers: hand the space back
+                unsigned long long t0 = 0ull, t1 = 0ull;
+                if (s.dbg) t0 = __builtin_readcyclecounter();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const uint32_t consumed = u + (uint32_t)spr + (uint32_t)min(64 * (m + 1), cpr);
-                if (lane == 0) lds_st(s.ctrl + C_FREE + cw, s.base_piece + consumed / 64u);
+                if (s.dbg) { t1 = __builtin_readcyclecounter(); s.t_lds += t1 - t0; }
+                s.release();
+                if (s.dbg) s.t_issue += __builtin_readcyclecounter() - t1;
+#pragma unroll
+                for (int k = 0; k < B; ++k)
+                {
+                    if (k >= np) continue;
+                    if (PRE && g == 0 && k == 0) continue;
+                    const int m = g * B + k - PRE;               // step of the row
+                    const int ch = 64 * m + lane;
+                    u32x4 wk = w[k];
+                    if (k == fin && lane >= tail) wk = u32x4{0u, 0u, 0u, 0u};    // those lanes were not fetched
+                    if constexpr (FMT == FMT_FP4)
+                    {
+                        float scm = sc[0];
+#pragma unroll
+                        for (int mm = 1; mm < MAXSTEPS_FP4; ++mm) scm = (m == mm) ? sc[mm] : scm;
+                        a = fmaf(scm, chunk_dot<FMT>(wk, xs, ch, 0.0f), a);
+                    }
+                    else
+                        a = chunk_dot<FMT>(wk, xs, ch, a);
+                }
             }
             acc[j] = a;
-            u += (uint32_t)upr;
         }
         // finish: the arithmetic of matvec_body's finish()
+        unsigned long long tf = 0ull;
+        if (s.dbg) tf = __builtin_readcyclecounter();
 #pragma unroll
         for (int j = 0; j < NR; ++j)
         {
             float v = wave_sum(acc[j]);
-            const int row = j ? P.N + col : col;
+            const int row = __builtin_amdgcn_readfirstlane(j ? P.N + col : col);
             if constexpr (FMT == FMT_FP8) v = __builtin_bit_cast(float, sload32(P.row_scales + row)) * v;
             acc[j] = v;
         }
@@ -471,64 +542,83 @@ __device__ void eng_stream(EngCons& s, const EngPhase& P, const u32x4* xs)
                 __hip_atomic_store(as_global(reinterpret_cast<uint32_t*>(P.y)) + col, eng_granule(s.tag, f32_to_bf16_bits(v)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else reinterpret_cast<uint16_t*>(P.y)[col] = f32_to_bf16_bits(v);
         }
+        if (s.dbg) s.t_fin += __builtin_readcyclecounter() - tf;
     }
-    const uint32_t np = (uint32_t)eng_npieces(P, b, cw);
-    s.base_piece += np;
-    if (lane == 0) lds_st(s.ctrl + C_FREE + cw, s.base_piece);      // the padding of the last piece counts as consumed
 }
 
-// FMT: format of the four layer Linears; HEAD: the last phase is the tied lm_head (format HFMT, fp32 logits)
-template <int FMT, bool HEAD, int HFMT>
-__global__ __launch_bounds__(kEngThreads) void decode_engine_kernel(const EngParams c)
+// FMT: format of the four layer Linears; HEAD: the last phase is the tied lm_head (format HFMT, fp32 logits); NW waves, rings of RG groups of B KiB
+template <int FMT, bool HEAD, int HFMT, int NW, int B, int RG>
+__global__ __launch_bounds__(64 * NW) void decode_engine_kernel(const EngParams c)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    volatile uint32_t* ctrl = reinterpret_cast<volatile uint32_t*>(lds + c.ctrl_off);
+    ctrl_fptr ctrl = (ctrl_fptr)(lds + c.ctrl_off);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
-    if (tid < C_WORDS) ctrl[tid] = 0u;
-    __syncthreads();                                     // the only workgroup barrier: before the roles part
     const unsigned long long epoch = *c.epoch;
-    if (wave == 0)
-    {
-        eng_loader(c, lds, ctrl, b, lane);
-        return;
-    }
-    EngCons s;
-    s.cw = wave - 1; s.lane = lane; s.b = b;
-    s.ring = lds + (size_t)s.cw * (kRingUnits * 16);
-    s.ctrl = ctrl; s.error = c.error;
-    s.base_piece = 0u; s.full_seen = 0u; s.bar_gen = 0u; s.failed = false;
+    issue_tab_ptr itab = (issue_tab_ptr)(ctrl + C_ISSUE);
+    if (tid == 0) eng_issue_store(itab + 0, c.ph[0]);
+    if (tid == 64) eng_issue_store(itab + 1, c.ph[1]);
+    if (tid == 128) eng_issue_store(itab + 2, c.ph[2]);
+    if (tid == 192) eng_issue_store(itab + 3, c.ph[3]);
+    __syncthreads();
+    EngW<NW, B, RG> s;
+    s.itab = itab;
+    s.cw = wave; s.lane = lane; s.b = b;
+    s.ring = lds + (size_t)wave * (RG * B * 1024);
+    s.error = c.error;
+    s.dbg = c.debug != nullptr; s.stall = s.t_lds = s.t_issue = s.t_fin = 0ull;
+    s.iphase = 0; s.issued = 0u; s.gissued = 0u; s.islot = 0; s.gconsumed = 0u; s.cslot = 0; s.failed = false; s.tag = 0u;
+    s.cum0 = s.cum1 = s.cum2 = s.cum3 = 0u;
+    s.begin_phase();
+    s.top_up();                                           // the weight stream starts before anything else
+    eng_stamp(c, b, wave, lane, 0);
+    if (s.dbg && lane == 0) c.debug[((size_t)b * 16 + wave) * 16 + 13] = __builtin_readcyclecounter();
     u32x4* xa = reinterpret_cast<u32x4*>(lds + c.xa_off);
     u32x4* xb = reinterpret_cast<u32x4*>(lds + c.xb_off);
     // tags: three hand-offs per launch, never 0, unique against what the same words held after the previous launch
     auto tag_of = [&](int k) { return (uint32_t)((epoch * 3ull + (unsigned long long)k) % 65535ull) + 1u; };
     u32x4 r1[kMaxGroups], rk[kMaxGroups];
     // phase 0: a = o_proj(attn)
-    eng_stage_x<FMT, 0, X_PLAIN, RES_MEM>(s, c.ph[0], xa, 0u, rk, false);
+    eng_stage_x<NW, B, RG, FMT, 0, X_PLAIN, RES_MEM>(c, s, c.ph[0], xa, ctrl, 0u, rk, false);
+    eng_stamp(c, b, wave, lane, 1);
     s.tag = tag_of(0);
-    eng_stream<FMT, false, Y_HANDOFF>(s, c.ph[0], xa);
+    eng_stream<NW, B, RG, FMT, false, Y_HANDOFF>(s, c.ph[0], xa);
+    eng_stamp(c, b, wave, lane, 2);
     // phase 1: r1 = res + rmsnorm(a); h = GeGLU(fc_gate_up(rmsnorm(r1)))
-    eng_stage_x<FMT, 2, X_HANDOFF, RES_MEM>(s, c.ph[1], xb, tag_of(0), r1, false);
+    eng_stage_x<NW, B, RG, FMT, 2, X_HANDOFF, RES_MEM>(c, s, c.ph[1], xb, ctrl, tag_of(0), r1, false);
+    eng_stamp(c, b, wave, lane, 3);
     s.tag = tag_of(1);
-    eng_stream<FMT, true, Y_HANDOFF>(s, c.ph[1], xb);
+    eng_stream<NW, B, RG, FMT, true, Y_HANDOFF>(s, c.ph[1], xb);
+    eng_stamp(c, b, wave, lane, 4);
     // phase 2: d = fc_down(h)
-    eng_stage_x<FMT, 0, X_HANDOFF, RES_MEM>(s, c.ph[2], xa, tag_of(1), rk, false);
+    eng_stage_x<NW, B, RG, FMT, 0, X_HANDOFF, RES_MEM>(c, s, c.ph[2], xa, ctrl, tag_of(1), rk, false);
+    eng_stamp(c, b, wave, lane, 5);
     s.tag = tag_of(2);
-    eng_stream<FMT, false, Y_HANDOFF>(s, c.ph[2], xa);
+    eng_stream<NW, B, RG, FMT, false, Y_HANDOFF>(s, c.ph[2], xa);
+    eng_stamp(c, b, wave, lane, 6);
     // phase 3: r2 = (r1 + rmsnorm(d)) * layer_scalar; y = next(rmsnorm(r2))
     if constexpr (HEAD)
     {
-        eng_stage_x<HFMT, 2, X_HANDOFF, RES_REG>(s, c.ph[3], xb, tag_of(2), r1, b == 0 && c.ph[3].res_out != nullptr);
-        eng_stream<HFMT, false, Y_F32>(s, c.ph[3], xb);
+        eng_stage_x<NW, B, RG, HFMT, 2, X_HANDOFF, RES_REG>(c, s, c.ph[3], xb, ctrl, tag_of(2), r1, b == 0 && c.ph[3].res_out != nullptr);
+        eng_stamp(c, b, wave, lane, 7);
+        eng_stream<NW, B, RG, HFMT, false, Y_F32>(s, c.ph[3], xb);
     }
     else
     {
-        eng_stage_x<FMT, 2, X_HANDOFF, RES_REG>(s, c.ph[3], xb, tag_of(2), r1, b == 0 && c.ph[3].res_out != nullptr);
-        eng_stream<FMT, false, Y_BF16>(s, c.ph[3], xb);
+        eng_stage_x<NW, B, RG, FMT, 2, X_HANDOFF, RES_REG>(c, s, c.ph[3], xb, ctrl, tag_of(2), r1, b == 0 && c.ph[3].res_out != nullptr);
+        eng_stamp(c, b, wave, lane, 7);
+        eng_stream<NW, B, RG, FMT, false, Y_BF16>(s, c.ph[3], xb);
     }
+    eng_stamp(c, b, wave, lane, 8);
+    if (s.dbg && lane == 0)
+    {
+        unsigned long long* d = c.debug + ((size_t)b * 16 + wave) * 16;
+        d[9] = s.stall; d[10] = s.t_lds; d[11] = s.t_issue; d[12] = s.t_fin;
+    }
+    if (s.dbg && lane == 0) c.debug[((size_t)b * 16 + wave) * 16 + 14] = __builtin_readcyclecounter();
     // every workgroup read `epoch` before any could pass hand-off 2, which workgroup 0 has now behind it
-    if (b == 0 && wave == 1 && lane == 0) *c.epoch = epoch + 1ull;
+    if (b == 0 && wave == 0 && lane == 0) *c.epoch = epoch + 1ull;
 }
 
 static int eng_num_blocks()
@@ -544,7 +634,18 @@ static int eng_num_blocks()
     return n;
 }
 
+static unsigned long long* g_eng_debug = nullptr;   // diagnostic hook (mila_cdna4_decode_engine_debug), inert unless the tuning hooks are enabled
+
 constexpr size_t kEngHeaderBytes = 64;      // [0] unused (chain counter), [8] epoch, [16] error -- the chain's header layout
+
+// waves per workgroup and the ring: RG groups of B pieces (KiB) per wave.  8 waves x 12 KiB + 38 KiB of x (fp4: 40)
+template <int FMT> struct EngShape { static constexpr int NW = 8, B = 4, RG = 3; };
+template <> struct EngShape<FMT_FP4> { static constexpr int NW = 8, B = 3, RG = 4; };      // records of 3 / 9 pieces at Gemma's widths
+static size_t eng_ring_bytes(int fmt)
+{
+    return fmt == FMT_FP4 ? (size_t)EngShape<FMT_FP4>::NW * EngShape<FMT_FP4>::B * EngShape<FMT_FP4>::RG * 1024
+                          : (size_t)EngShape<FMT_BF16>::NW * EngShape<FMT_BF16>::B * EngShape<FMT_BF16>::RG * 1024;
+}
 
 static int eng_x_units(int fmt, int K)
 {
@@ -570,7 +671,8 @@ static void eng_fill_phase(EngPhase& P, int fmt, int group, bool geglu)
 template <int FMT, bool HEAD, int HFMT>
 static hipError_t eng_allow_big_lds()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_engine_kernel<FMT, HEAD, HFMT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_engine_kernel<FMT, HEAD, HFMT, EngShape<FMT>::NW, EngShape<FMT>::B, EngShape<FMT>::RG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 // every instantiation may use the CU's whole LDS; called from decode_engine_init (never inside a stream capture)
 static int eng_prepare_all()
@@ -592,7 +694,7 @@ static int eng_prepare_all()
 template <int FMT, bool HEAD, int HFMT>
 static int launch_engine(const EngParams& c, size_t lds, hipStream_t s)
 {
-    hipLaunchKernelGGL((decode_engine_kernel<FMT, HEAD, HFMT>), dim3(c.nblocks), dim3(kEngThreads), lds, s, c);
+    hipLaunchKernelGGL((decode_engine_kernel<FMT, HEAD, HFMT, EngShape<FMT>::NW, EngShape<FMT>::B, EngShape<FMT>::RG>), dim3(c.nblocks), dim3(64 * EngShape<FMT>::NW), lds, s, c);
     MILA_LAUNCH_CHECK("decode_engine");
 }
 
@@ -637,7 +739,7 @@ int mila_cdna4_decode_engine_applicable(int fmt, int group, int D, int F, int K_
     if (fmt < 0 || fmt > 2 || next_fmt < 0 || next_fmt > 2) return 0;
     if (D <= 0 || F <= 0 || K_attn <= 0 || N_next <= 0) return 0;
     if (D % 32 || F % 32 || K_attn % 32) return 0;
-    if (D > 7 * kMaxGroups * 512 || K_attn > 16384 || F > 16384) return 0;
+    if (D > 8 * kMaxGroups * 512 || K_attn > 16384 || F > 16384) return 0;
     if (fmt == FMT_FP4)
     {
         if (!((group == 64 || group == 128) && D % group == 0 && F % group == 0 && K_attn % group == 0)) return 0;
@@ -648,7 +750,15 @@ int mila_cdna4_decode_engine_applicable(int fmt, int group, int D, int F, int K_
     if (eng_num_blocks() != kNumCU) return 0;
     const size_t xa = (size_t)std::max(eng_x_units(fmt, K_attn), eng_x_units(fmt, F)) * 16;
     const size_t xb = (size_t)std::max(eng_x_units(fmt, D), eng_x_units(next_fmt, D)) * 16;
-    return (size_t)kEngCons * kRingUnits * 16 + xa + xb + C_WORDS * 4 <= 160 * 1024 ? 1 : 0;
+    return eng_ring_bytes(fmt) + xa + xb + C_WORDS * 4 <= 160 * 1024 ? 1 : 0;
+}
+
+/* diagnostic hook: wall-clock stamps of the first 8 workgroups' waves into `buf` (8 x 8 x 16 uint64) on the following launches */
+int mila_cdna4_decode_engine_debug(unsigned long long* buf)
+{
+    if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "decode_engine_debug: inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded");
+    g_eng_debug = buf;
+    return MILA_OK;
 }
 
 int mila_cdna4_decode_engine(const mila_decode_chain_args* a, mila_stream_t stream)
@@ -702,9 +812,10 @@ int mila_cdna4_decode_engine(const mila_decode_chain_args* a, mila_stream_t stre
     c.epoch = reinterpret_cast<unsigned long long*>(sc + 8);
     c.error = reinterpret_cast<uint32_t*>(sc + 16);
     c.nblocks = eng_num_blocks();
+    c.debug = g_eng_debug;
     const size_t xa = (size_t)std::max(eng_x_units(a->fmt, a->K_attn), eng_x_units(a->fmt, F)) * 16;
     const size_t xb = (size_t)std::max(eng_x_units(a->fmt, D), eng_x_units(a->next_fmt, D)) * 16;
-    c.xa_off = kEngCons * kRingUnits * 16;
+    c.xa_off = (int)eng_ring_bytes(a->fmt);
     c.xb_off = c.xa_off + (int)xa;
     c.ctrl_off = c.xb_off + (int)xb;
     const size_t lds = (size_t)c.ctrl_off + C_WORDS * 4;
