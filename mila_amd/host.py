@@ -219,6 +219,18 @@ class Gemma:
         _check(load().mila_gemma_time_prefill(self.h, T, reps, C.byref(out)))
         return out.value
 
+    def component_names(self):
+        """names of the model's components in construction order (each block, its children, temb, rmsn_final, lm_head)"""
+        lib = load()
+        lib.mila_gemma_component_names.restype = C.c_int64
+        lib.mila_gemma_component_names.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        need = lib.mila_gemma_component_names(self.h, None, 0)
+        if need < 0:
+            raise RuntimeError(lib.mila_host_last_error().decode())
+        buf = C.create_string_buffer(need)
+        lib.mila_gemma_component_names(self.h, buf, need)
+        return buf.value.decode().split("\n")[:-1]
+
     def info(self, context):
         out = (C.c_double * 4)()
         _check(load().mila_gemma_info(self.h, context, out))
@@ -293,6 +305,14 @@ def _text_call(fn, *args):
     buf = C.create_string_buffer(int(need) + 1)
     fn(*args, buf, int(need) + 1)
     return buf.value.decode()
+
+
+def component_scenarios(device=0):
+    """the leaf components (Residual, Swiglu<Gelu>, Rope, GroupedQueryAttention, TokenEmbedding + the tied Linear) used standalone on the GPU,
+    checked against the launchers they resolve to, with the reference's lifecycle errors; raises with the failing scenario's name"""
+    lib = load()
+    lib.mila_component_scenarios.argtypes = [C.c_int]
+    _check(lib.mila_component_scenarios(device))
 
 
 def pretrained_list(path):

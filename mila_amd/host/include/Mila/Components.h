@@ -202,6 +202,23 @@ namespace Mila::Dnn
             else Compute::rocmCheck( mila_cdna4_memcpy_d2d( weight_->rawData(), device_bf16, weight_->sizeInBytes(), ctx->getStream() ) );
         }
 
+        /// adopt another component's table instead of allocating (the tied lm_head: Linear.ixx:614-680, Gemma.ixx:659-684); precedes build()
+        void installSharedWeight( std::shared_ptr<WeightTensorType> shared_weight ) requires ( !kIsQuantized )
+        {
+            checkShared( shared_weight.get() );
+            weight_ = std::move( shared_weight );
+        }
+        void installSharedWeight( std::shared_ptr<WeightTensorType> shared_weight, std::shared_ptr<WeightScaleTensorType> shared_scales ) requires kIsQuantized
+        {
+            static_assert( !kIsQuantized || TWeightQuant::kPerChannel, "a shared quantized weight carries one scale per output row" );
+            checkShared( shared_weight.get() );
+            if ( !shared_scales || shared_scales->size() != static_cast<size_t>( config_.getOutputFeatures() ) )
+                throw std::invalid_argument( this->getName() + ": installSharedWeight needs one scale per output feature" );
+            weight_ = std::move( shared_weight );
+            weight_scale_ = std::move( shared_scales );
+        }
+        bool hasSharedWeight() const noexcept { return shared_weight_; }
+
         WeightTensorType& getWeight() { return *weight_; }
         WeightScaleTensorType* getWeightScale() { return weight_scale_.get(); }
         TensorType* getBias() { return bias_.get(); }
@@ -229,8 +246,9 @@ namespace Mila::Dnn
             validateInputShape( ctx.inputShape() );
             const auto dev = this->getExecutionContext()->getDeviceId();
             const dim_t N = config_.getOutputFeatures(), K = config_.getInputFeatures();
-            // initializeParameters (Linear.ixx:1029-1054)
-            if constexpr ( !kIsQuantized ) weight_ = std::make_shared<WeightTensorType>( dev, shape_t{ N, K } );
+            // initializeParameters (Linear.ixx:1029-1054); an installed shared weight is kept
+            if ( shared_weight_ ) {}
+            else if constexpr ( !kIsQuantized ) weight_ = std::make_shared<WeightTensorType>( dev, shape_t{ N, K } );
             else if constexpr ( TWeightQuant::kPerChannel )
             {
                 weight_ = std::make_shared<WeightTensorType>( dev, shape_t{ N, K } );
@@ -243,7 +261,7 @@ namespace Mila::Dnn
                 weight_ = std::make_shared<WeightTensorType>( dev, shape_t{ N, K / 2 } );
                 weight_scale_ = std::make_shared<WeightScaleTensorType>( dev, shape_t{ N, K / G } );
             }
-            weight_->setName( this->getName() + ".weight" );
+            if ( !shared_weight_ ) weight_->setName( this->getName() + ".weight" );
             if ( config_.hasBias() ) bias_ = std::make_shared<TensorType>( dev, shape_t{ N } );
             operation_->setParameters( weight_.get(), bias_.get() );
             if constexpr ( kIsQuantized ) operation_->setWeightScales( weight_scale_.get() );
@@ -255,6 +273,13 @@ namespace Mila::Dnn
         }
 
     private:
+        void checkShared( const WeightTensorType* w )
+        {
+            if ( this->isBuilt() ) throw std::runtime_error( this->getName() + ": installSharedWeight() must precede build()" );
+            const size_t N = static_cast<size_t>( config_.getOutputFeatures() ), K = static_cast<size_t>( config_.getInputFeatures() );
+            if ( !w || w->size() != N * K ) throw std::invalid_argument( this->getName() + ": the shared weight must hold [out_features, in_features] elements" );
+            shared_weight_ = true;
+        }
         void validateInputShape( const shape_t& s ) const
         {
             if ( s.empty() || s.back() != config_.getInputFeatures() )
@@ -273,6 +298,7 @@ namespace Mila::Dnn
         std::shared_ptr<TensorType> output_;
         std::unique_ptr<TensorType> output_view_;
         shape_t leading_shape_;
+        bool shared_weight_{ false };
     };
 
     // ---------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@
 #include <algorithm>
 #include <cmath>
 
-#include "Components.h"
+#include "GemmaBlock.h"
 #include "Serialization.h"
 
 namespace Mila::Dnn
@@ -79,19 +79,37 @@ namespace Mila::Dnn
         using TableQuantizationPolicy = std::conditional_t<TWeightQuant::kIsQuantized, Quant::Weight::PerChannelFp8<>, NoWeightQuant>;
         using LmHeadLinearType = Linear<kDevice, kPrecision, TableQuantizationPolicy>;
         using RmsNormType = RmsNorm<kDevice, kPrecision>;
-        using RopeOp = Compute::RocmRopeOp;
-        using GqaOp = Compute::RocmGqaOpBase;      // local layers: RocmGqaOp<cfg.bounded_local_kv>; global layers: RocmGqaOp<false>
+        using TokenEmbeddingType = TokenEmbedding<kDevice, TensorDataType::INT32, kPrecision, TableQuantizationPolicy>;
+        // Gemma.ixx:153-154: local blocks take the model's KV policy, global blocks attend to the whole context
+        using LocalBlockType = GemmaBlock<kDevice, kPrecision, false, TWeightQuant, Quant::KvCache::NoKvCompression>;
+        using BoundedLocalBlockType = GemmaBlock<kDevice, kPrecision, false, TWeightQuant, Quant::KvCache::SlidingWindowKvCache>;
+        using GlobalBlockType = GemmaBlock<kDevice, kPrecision, true, TWeightQuant, Quant::KvCache::NoKvCompression>;
         static constexpr int kFmt = Quant::Weight::abiWeightFormat<TWeightQuant>();
         static constexpr int kTableFmt = Quant::Weight::abiWeightFormat<TableQuantizationPolicy>();
 
-        struct Layer
+        /// a block behind its kind-independent face: the children (input_norm ... fc_down, rope, res_1/2, geglu), layer_scalar, the KV
+        /// cache surface, and IDecoderLayer's prefill / decode (the reference-order path)
+        using Layer = GemmaBlockBase<kDevice, kPrecision, TWeightQuant>;
+        /// the model's blocks, indexed and iterated as Layer&
+        class LayerList
         {
-            bool global{ false };
-            std::shared_ptr<RmsNormType> input_norm, q_norm, k_norm, v_norm, post_attn_norm, pre_ffn_norm, post_ffn_norm;
-            std::shared_ptr<LinearType> qkv_proj, o_proj, fc_gate_up, fc_down;
-            std::shared_ptr<RopeOp> rope;
-            std::shared_ptr<GqaOp> attn;
-            float layer_scalar{ 1.0f };
+        public:
+            using Store = std::vector<std::shared_ptr<Layer>>;
+            struct Iterator
+            {
+                typename Store::const_iterator p;
+                Layer& operator*() const { return **p; }
+                Iterator& operator++() { ++p; return *this; }
+                bool operator!=( const Iterator& o ) const { return p != o.p; }
+            };
+            size_t size() const noexcept { return v_.size(); }
+            Layer& operator[]( size_t i ) const { return *v_[ i ]; }
+            Iterator begin() const { return Iterator{ v_.begin() }; }
+            Iterator end() const { return Iterator{ v_.end() }; }
+            void push_back( std::shared_ptr<Layer> l ) { l->index = v_.size(); v_.push_back( std::move( l ) ); }
+            const std::shared_ptr<Layer>& shared( size_t i ) const { return v_[ i ]; }
+        private:
+            Store v_;
         };
 
         GemmaTransformer( const GemmaConfig& cfg, dim_t max_seq, dim_t max_prefill, DeviceId device = Compute::Device::Rocm( 0 ) )
@@ -114,7 +132,7 @@ namespace Mila::Dnn
 
         Compute::RocmExecutionContext* context() const noexcept { return ctx_; }
         const GemmaConfig& config() const noexcept { return cfg_; }
-        std::vector<Layer>& layers() noexcept { return layers_; }
+        LayerList& layers() noexcept { return layers_; }
 
         // ------------------------------------------------------------------------------------
         // synthetic parameters: counter-based uniform values generated on the
@@ -163,7 +181,7 @@ namespace Mila::Dnn
             checkPosition( position, 1 );
             embed( token.data(), 1, *hidden_[ 0 ] );
             TensorType* x = hidden_[ 0 ].get();
-            for ( auto& L : layers_ ) x = &blockDecode( L, *x, static_cast<int>( position ) );
+            for ( auto& L : layers_ ) x = &L.decode( x->view( shape_t{ 1, 1, cfg_.embedding_dim } ), position );
             auto& normed = final_norm_->forward( x->view( shape_t{ 1, 1, cfg_.embedding_dim } ) );
             head( normed.data() );
             return *logits_;
@@ -274,9 +292,9 @@ namespace Mila::Dnn
             const bool fused = fused_prefill_ && fusedPrefillApplicable();
             for ( size_t i = 0; i < layers_.size(); ++i )
             {
+                if ( !fused ) { x = &layers_[ i ].prefill( x->view( shape_t{ 1, T, D } ), position_offset ); continue; }   // GemmaBlock::prefill, one component per step
                 TensorType* out = pf_x_[ 1 - flip ].get();
-                if ( fused ) blockPrefillFused( layers_[ i ], *x, i > 0, *out, i + 1 < layers_.size() ? &layers_[ i + 1 ] : nullptr, static_cast<int>( T ), static_cast<int>( position_offset ) );
-                else blockPrefill( layers_[ i ], *x, *out, static_cast<int>( T ), static_cast<int>( position_offset ) );
+                blockPrefillFused( layers_[ i ], *x, i > 0, *out, i + 1 < layers_.size() ? &layers_[ i + 1 ] : nullptr, static_cast<int>( T ), static_cast<int>( position_offset ) );
                 x = out;
                 flip = 1 - flip;
             }
@@ -308,6 +326,7 @@ namespace Mila::Dnn
         }
         LmHeadLinearType& lmHead() { return *lm_head_; }
         RmsNormType& finalNorm() { return *final_norm_; }
+        TokenEmbeddingType& tokenEmbedding() { return *temb_; }
 
         /// launch only the dominant kernel (fc_gate_up fused matvec) of layer `i` -- used by the bench to
         /// time that kernel with HIP events on the model stream
@@ -356,66 +375,63 @@ namespace Mila::Dnn
             const dim_t D = cfg_.embedding_dim, P = max_prefill_;
             const auto dev = ctx_->getDeviceId();
             auto rms = [&]( dim_t dim ) { return RmsNormConfig( dim ).withEpsilon( cfg_.rms_norm_eps ).withBias( false ); };
-            layers_.resize( static_cast<size_t>( cfg_.num_layers ) );
+            // workspace every block shares (they run one after the other): split scratch, attention / GeGLU / residual outputs, two stream buffers
+            const dim_t maxq = std::max( cfg_.qWidth( false ), cfg_.qWidth( true ) ), maxkv = std::max( cfg_.kvWidth( false ), cfg_.kvWidth( true ) );
+            q_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, maxq } );
+            k_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, maxkv } );
+            v_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, maxkv } );
+            attn_out_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, maxq } );
+            res1_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, D } );
+            res2_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, D } );
+            geglu_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, cfg_.hidden_dim } );
+            for ( int i = 0; i < 2; ++i ) blk_out_[ i ] = std::make_shared<TensorType>( dev, shape_t{ 1, P, D } );
             for ( dim_t i = 0; i < cfg_.num_layers; ++i )
             {
-                auto& L = layers_[ static_cast<size_t>( i ) ];
                 const std::string n = name_ + ".tf_layer_" + std::to_string( i );
                 const bool g = cfg_.isGlobalLayer( i );
-                L.global = g;
-                const dim_t HD = cfg_.headDim( g ), NKV = cfg_.numKvHeads( g ), NH = cfg_.num_heads;
-                L.input_norm = make<RmsNormType>( n + ".input_norm", rms( D ) ); L.input_norm->build( BuildContext( shape_t{ 1, P, D }, RuntimeMode::Inference ) );
-                L.q_norm = make<RmsNormType>( n + ".q_norm", rms( HD ) ); L.q_norm->build( BuildContext( shape_t{ 1, P * NH, HD }, RuntimeMode::Inference ) );
-                L.k_norm = make<RmsNormType>( n + ".k_norm", rms( HD ) ); L.k_norm->build( BuildContext( shape_t{ 1, P * NKV, HD }, RuntimeMode::Inference ) );
-                L.v_norm = make<RmsNormType>( n + ".v_norm", rms( HD ) ); L.v_norm->build( BuildContext( shape_t{ 1, P * NKV, HD }, RuntimeMode::Inference ) );
-                L.post_attn_norm = make<RmsNormType>( n + ".post_attn_norm", rms( D ) ); L.post_attn_norm->build( BuildContext( shape_t{ 1, P, D }, RuntimeMode::Inference ) );
-                L.pre_ffn_norm = make<RmsNormType>( n + ".pre_ffn_norm", rms( D ) ); L.pre_ffn_norm->build( BuildContext( shape_t{ 1, P, D }, RuntimeMode::Inference ) );
-                L.post_ffn_norm = make<RmsNormType>( n + ".post_ffn_norm", rms( D ) ); L.post_ffn_norm->build( BuildContext( shape_t{ 1, P, D }, RuntimeMode::Inference ) );
-                L.qkv_proj = make<LinearType>( n + ".qkv_proj", LinearConfig( D, cfg_.packedQkvWidth( g ) ).withBias( false ) );
-                L.qkv_proj->build( BuildContext( shape_t{ 1, P, D }, RuntimeMode::Inference ) );
-                L.o_proj = make<LinearType>( n + ".o_proj", LinearConfig( cfg_.qWidth( g ), D ).withBias( false ) );
-                L.o_proj->build( BuildContext( shape_t{ 1, P, cfg_.qWidth( g ) }, RuntimeMode::Inference ) );
-                L.fc_gate_up = make<LinearType>( n + ".fc_gate_up", LinearConfig( D, 2 * cfg_.hidden_dim ).withBias( false ) );
-                L.fc_gate_up->build( BuildContext( shape_t{ 1, P, D }, RuntimeMode::Inference ) );
-                L.fc_down = make<LinearType>( n + ".fc_down", LinearConfig( cfg_.hidden_dim, D ).withBias( false ) );
-                L.fc_down->build( BuildContext( shape_t{ 1, P, cfg_.hidden_dim }, RuntimeMode::Inference ) );
-                L.rope = std::make_shared<RopeOp>( ctx_, Compute::RopeOpConfig{ max_seq_, HD, NH, NKV, g ? cfg_.rope_theta_global : cfg_.rope_theta_local,
-                                                                               g ? cfg_.global_rotary_dim : 0 } );
-                L.rope->build( BuildContext( shape_t{ 1, P, cfg_.qWidth( g ) }, RuntimeMode::Inference ) );
-                const Compute::GqaOpConfig acfg{ NH, NKV, HD, cfg_.windowFor( g ), 1.0f };   // scale 1.0: Gemma.Block.ixx:902-904
+                GemmaBlockConfig bc;
+                bc.model_dim = D; bc.hidden_dim = cfg_.hidden_dim; bc.num_heads = cfg_.num_heads; bc.num_kv_heads = cfg_.numKvHeads( g ); bc.head_dim = cfg_.headDim( g );
+                bc.window = cfg_.windowFor( g ); bc.rotary_dim = g ? cfg_.global_rotary_dim : 0; bc.rope_theta = g ? cfg_.rope_theta_global : cfg_.rope_theta_local;
+                bc.rms_norm_eps = cfg_.rms_norm_eps; bc.max_seq = max_seq_;
                 // KV policy (Quantization/KvCache policies; CudaGqaOp.ixx:552-574): 288 GB of HBM makes unbounded caches the default;
                 // SlidingWindowKvCache bounds the sliding-window layers to window + prefill_chunk - 1 rows, global layers stay unbounded
-                if ( cfg_.bounded_local_kv && !g ) L.attn = std::make_shared<Compute::RocmGqaOp<Quant::KvCache::SlidingWindowKvCache::kBoundedRing>>( ctx_, acfg );
-                else L.attn = std::make_shared<Compute::RocmGqaOp<Quant::KvCache::NoKvCompression::kBoundedRing>>( ctx_, acfg );
-                L.attn->initializeKvCache( 1, max_seq_, P );
+                auto wire = [&]( auto block )
+                {
+                    block->setExecutionContext( ctx_ );
+                    block->installSharedWorkspace( q_, k_, v_, blk_out_[ i & 1 ] );
+                    block->attn->installSharedOutput( attn_out_ );
+                    block->geglu->installSharedOutput( geglu_ );
+                    block->res_1->installSharedOutput( res1_ );
+                    block->res_2->installSharedOutput( res2_ );
+                    block->build( BuildContext( shape_t{ 1, P, D }, RuntimeMode::Inference ) );
+                    layers_.push_back( block );
+                };
+                if ( g ) wire( std::make_shared<GlobalBlockType>( n, bc ) );
+                else if ( cfg_.bounded_local_kv ) wire( std::make_shared<BoundedLocalBlockType>( n, bc ) );
+                else wire( std::make_shared<LocalBlockType>( n, bc ) );
             }
+            // TokenEmbedding owns the raw table; the tied head adopts it before its build, so it never allocates its own (Gemma.ixx:659-684)
+            temb_ = make<TokenEmbeddingType>( name_ + ".temb", TokenEmbeddingConfig().withVocabSize( cfg_.vocab_size ).withEmbeddingDim( D ).withEmbeddingScale( cfg_.embeddingScale() ) );
+            temb_->build( BuildContext( shape_t{ 1, P }, RuntimeMode::Inference ) );
             final_norm_ = make<RmsNormType>( name_ + ".rmsn_final", rms( D ) );
             final_norm_->build( BuildContext( shape_t{ 1, 1, D }, RuntimeMode::Inference ) );
             lm_head_ = make<LmHeadLinearType>( name_ + ".lm_head", LinearConfig( D, cfg_.vocab_size ).withBias( false ) );
+            if constexpr ( TableQuantizationPolicy::kIsQuantized ) lm_head_->installSharedWeight( temb_->getWeightTensorShared(), temb_->getWeightScalesTensorShared() );
+            else lm_head_->installSharedWeight( temb_->getWeightTensorShared() );
             lm_head_->build( BuildContext( shape_t{ 1, 1, D }, RuntimeMode::Inference ) );
 
-            const dim_t maxq = std::max( cfg_.qWidth( false ), cfg_.qWidth( true ) ), maxkv = std::max( cfg_.kvWidth( false ), cfg_.kvWidth( true ) );
             for ( int i = 0; i < 3; ++i ) hidden_[ i ] = std::make_unique<TensorType>( dev, shape_t{ 1, 1, D } );
             for ( int i = 0; i < 2; ++i ) pf_x_[ i ] = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
-            q_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, maxq } );
-            k_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, maxkv } );
-            v_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, maxkv } );
-            attn_out_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, maxq } );
-            res1_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
-            res2_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
             pf_norm_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
             pf_norm2_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
-            geglu_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, cfg_.hidden_dim } );
             f_qkv_ = std::make_unique<TensorType>( dev, shape_t{ std::max( cfg_.packedQkvWidth( false ), cfg_.packedQkvWidth( true ) ) } );
-            f_q_ = std::make_unique<TensorType>( dev, shape_t{ maxq } );
+            f_q_ = std::make_unique<TensorType>( dev, shape_t{ std::max( cfg_.qWidth( false ), cfg_.qWidth( true ) ) } );
             f_o_ = std::make_unique<TensorType>( dev, shape_t{ D } );
             f_down_ = std::make_unique<TensorType>( dev, shape_t{ D } );
             f_act_ = std::make_unique<TensorType>( dev, shape_t{ cfg_.hidden_dim } );
             logits_ = std::make_unique<LogitsTensor>( dev, shape_t{ 1, 1, cfg_.vocab_size } );
             pos_dev_ = std::make_unique<TokenTensor>( dev, shape_t{ 1 } );
             sample_scratch_ = std::make_unique<LogitsTensor>( dev, shape_t{ static_cast<dim_t>( mila_cdna4_sample_scratch_bytes() / 4 ) } );
-            err_flag_ = std::make_unique<TokenTensor>( dev, shape_t{ 1 } );
-            Compute::rocmCheck( mila_cdna4_memset_zero( err_flag_->data(), 4, ctx_->getStream() ) );
             tickets_ = std::make_unique<TokenTensor>( dev, shape_t{ static_cast<dim_t>( mila_cdna4_attn_decode_ticket_count( 1, (int)cfg_.num_heads ) ) } );
             Compute::rocmCheck( mila_cdna4_memset_zero( tickets_->data(), tickets_->sizeInBytes(), ctx_->getStream() ) );
             pf_sink_ = std::make_unique<LogitsTensor>( dev, shape_t{ 4 } );
@@ -443,18 +459,8 @@ namespace Mila::Dnn
                              mila_cdna4_attn_decode_scratch_bytes( 1, (int)cfg_.num_heads, (int)cfg_.global_head_dim ) );
         }
 
-        /// TokenEmbedding::forward: gather (bf16 table, or FP8 table x row scale) then scale(sqrt(D))
-        void embed( const int32_t* tokens_dev, int n, TensorType& out )
-        {
-            const int D = (int)cfg_.embedding_dim, V = (int)cfg_.vocab_size;
-            if constexpr ( kTableFmt == 0 )
-                Compute::rocmCheck( mila_cdna4_embedding_gather_bf16( out.data(), tokens_dev, static_cast<const uint16_t*>( lm_head_->getWeight().rawData() ), n, D, V,
-                                                                      cfg_.embeddingScale(), err_flag_->data(), ctx_->getStream() ) );
-            else
-                Compute::rocmCheck( mila_cdna4_embedding_gather_bf16_qfp8( out.data(), tokens_dev, static_cast<const uint8_t*>( lm_head_->getWeight().rawData() ),
-                                                                           lm_head_->getWeightScale()->data(), n, D, V, cfg_.embeddingScale(), err_flag_->data(),
-                                                                           ctx_->getStream() ) );
-        }
+        /// TokenEmbedding's gather (bf16 table, or FP8 table x row scale) and scale(sqrt(D)), token ids on the device
+        void embed( const int32_t* tokens_dev, int n, TensorType& out ) { temb_->gather( tokens_dev, n, out ); }
 
         /// lm_head on the normalized last hidden state, fp32 logits (the 1e-3 bar is asserted on fp32)
         void head( const uint16_t* normed )
@@ -465,46 +471,7 @@ namespace Mila::Dnn
                                                           (int)cfg_.vocab_size, 0, ctx_->getStream() ) );
         }
 
-        // ---- reference-order block (decode) --------------------------------------------------------
-        TensorType& blockDecode( Layer& L, TensorType& input, int position )
-        {
-            const bool g = L.global;
-            const dim_t NH = cfg_.num_heads, NKV = cfg_.numKvHeads( g ), HD = cfg_.headDim( g ), D = cfg_.embedding_dim;
-            mila_stream_t st = ctx_->getStream();
-            auto x3 = input.view( shape_t{ 1, 1, D } );
-            auto& normed = L.input_norm->forward( x3 );
-            auto& qkv = L.qkv_proj->forward( normed );
-            auto q = q_->view( shape_t{ 1, 1, NH * HD } );
-            auto k = k_->view( shape_t{ 1, 1, NKV * HD } );
-            auto v = v_->view( shape_t{ 1, 1, NKV * HD } );
-            Compute::rocmCheck( mila_cdna4_split3_bf16( q.data(), k.data(), g ? nullptr : v.data(), static_cast<const uint16_t*>( qkv.rawData() ), 1,
-                                                        (int)( NH * HD ), (int)( NKV * HD ), g ? 0 : (int)( NKV * HD ), st ) );
-            auto& q_normed = L.q_norm->forward( q.view( shape_t{ 1, NH, HD } ) );
-            auto& k_normed = L.k_norm->forward( k.view( shape_t{ 1, NKV, HD } ) );
-            auto q_roped = q_normed.view( shape_t{ 1, 1, NH * HD } );
-            auto k_roped = k_normed.view( shape_t{ 1, 1, NKV * HD } );
-            L.rope->decode( q_roped, k_roped, 1, position );
-            auto& v_normed = L.v_norm->forward( ( g ? k : v ).view( shape_t{ 1, NKV, HD } ) );   // global: V = v_norm(raw k_proj)
-            auto attn = attn_out_->view( shape_t{ 1, 1, NH * HD } );
-            L.attn->decode( q_roped, k_roped, v_normed.view( shape_t{ 1, 1, NKV * HD } ), attn, position );
-            auto& o = L.o_proj->forward( attn );
-            auto& o_normed = L.post_attn_norm->forward( o );
-            auto res1 = res1_->view( shape_t{ 1, 1, D } );
-            Compute::rocmCheck( mila_cdna4_residual_bf16( res1.data(), x3.data(), o_normed.data(), D, st ) );
-            auto& ffn_in = L.pre_ffn_norm->forward( res1 );
-            auto& gate_up = L.fc_gate_up->forward( ffn_in );
-            auto act = geglu_->view( shape_t{ 1, 1, cfg_.hidden_dim } );
-            Compute::rocmCheck( mila_cdna4_geglu_bf16( act.data(), gate_up.data(), 1, (int)cfg_.hidden_dim, st ) );
-            auto& ffn = L.fc_down->forward( act );
-            auto& ffn_normed = L.post_ffn_norm->forward( ffn );
-            auto res2 = res2_->view( shape_t{ 1, 1, D } );
-            Compute::rocmCheck( mila_cdna4_residual_bf16( res2.data(), res1.data(), ffn_normed.data(), D, st ) );
-            TensorType* out = ( &input == hidden_[ 0 ].get() ) ? hidden_[ 1 ].get() : hidden_[ 0 ].get();
-            Compute::rocmCheck( mila_cdna4_scale_bf16( out->data(), res2.data(), D, L.layer_scalar, st ) );
-            return *out;
-        }
-
-        // ---- reference-order block (prefill, T tokens) ------------------------------------------------
+        // ---- fused-glue prefill (the reference-order path is GemmaBlock::prefill) -----------------------
         /// act[T, F] = GeGLU(fc_gate_up(ffn_in)): one kernel when the fused GEMM serves the shape, else Linear + GeGLU
         void gateUpGeglu( Layer& L, TensorType& ffn_in, TensorType& act, int T )
         {
@@ -565,42 +532,7 @@ namespace Mila::Dnn
             }
         }
 
-        void blockPrefill( Layer& L, TensorType& input, TensorType& output, int T, int position_offset )
-        {
-            const bool g = L.global;
-            const dim_t NH = cfg_.num_heads, NKV = cfg_.numKvHeads( g ), HD = cfg_.headDim( g ), D = cfg_.embedding_dim;
-            mila_stream_t st = ctx_->getStream();
-            auto x3 = input.view( shape_t{ 1, T, D } );
-            auto& normed = L.input_norm->forward( x3 );
-            auto& qkv = L.qkv_proj->forward( normed );
-            auto q = q_->view( shape_t{ 1, T, NH * HD } );
-            auto k = k_->view( shape_t{ 1, T, NKV * HD } );
-            auto v = v_->view( shape_t{ 1, T, NKV * HD } );
-            Compute::rocmCheck( mila_cdna4_split3_bf16( q.data(), k.data(), g ? nullptr : v.data(), static_cast<const uint16_t*>( qkv.rawData() ), T,
-                                                        (int)( NH * HD ), (int)( NKV * HD ), g ? 0 : (int)( NKV * HD ), st ) );
-            auto& q_normed = L.q_norm->forward( q.view( shape_t{ 1, T * NH, HD } ) );
-            auto& k_normed = L.k_norm->forward( k.view( shape_t{ 1, T * NKV, HD } ) );
-            auto q_roped = q_normed.view( shape_t{ 1, T, NH * HD } );
-            auto k_roped = k_normed.view( shape_t{ 1, T, NKV * HD } );
-            L.rope->prefill( q_roped, k_roped, 1, T, position_offset );
-            auto& v_normed = L.v_norm->forward( ( g ? k : v ).view( shape_t{ 1, T * NKV, HD } ) );
-            auto attn = attn_out_->view( shape_t{ 1, T, NH * HD } );
-            L.attn->prefill( q_roped, k_roped, v_normed.view( shape_t{ 1, T, NKV * HD } ), attn, T, position_offset );
-            auto& o = L.o_proj->forward( attn );
-            auto& o_normed = L.post_attn_norm->forward( o );
-            auto res1 = res1_->view( shape_t{ 1, T, D } );
-            Compute::rocmCheck( mila_cdna4_residual_bf16( res1.data(), x3.data(), o_normed.data(), (int64_t)T * D, st ) );
-            auto& ffn_in = L.pre_ffn_norm->forward( res1 );
-            auto act = geglu_->view( shape_t{ 1, T, cfg_.hidden_dim } );
-            gateUpGeglu( L, ffn_in, act, T );
-            auto& ffn = L.fc_down->forward( act );
-            auto& ffn_normed = L.post_ffn_norm->forward( ffn );
-            auto res2 = res2_->view( shape_t{ 1, T, D } );
-            Compute::rocmCheck( mila_cdna4_residual_bf16( res2.data(), res1.data(), ffn_normed.data(), (int64_t)T * D, st ) );
-            Compute::rocmCheck( mila_cdna4_scale_bf16( output.data(), res2.data(), (int64_t)T * D, L.layer_scalar, st ) );
-        }
-
-        /// GemmaBlock::forward with the glue fused (bit-identical to blockPrefill): the packed qkv rows go straight through
+        /// GemmaBlock::forward with the glue fused (bit-identical to GemmaBlock::prefill): the packed qkv rows go straight through
         /// q/k/v norm + RoPE into q and the KV cache (no split3 / kv_write), and each sandwich tail (RmsNorm + Residual
         /// (+ layer scalar) + the next RmsNorm) is one launch.  `have_normed`: the previous block's tail already wrote
         /// input_norm(input) into pf_norm_; `nextL`: the block whose input_norm the second tail applies.
@@ -618,12 +550,12 @@ namespace Mila::Dnn
             const uint16_t* qp = static_cast<const uint16_t*>( qkv.rawData() );
             const uint16_t* kp = qp + (size_t)( NH * HD );
             const uint16_t* vp = g ? kp : kp + (size_t)( NKV * HD );
-            Compute::rocmCheck( mila_cdna4_fused_qkv_post_prefill( q.data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, (int64_t)cfg_.packedQkvWidth( g ),
+            Compute::rocmCheck( mila_cdna4_fused_qkv_post_prefill( q.data(), L.keyCache(), L.valueCache(), qp, kp, vp, (int64_t)cfg_.packedQkvWidth( g ),
                                                                    L.q_norm->getWeight()->data(), L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(),
                                                                    L.rope->cosCache(), L.rope->sinCache(), T, (int)NH, (int)NKV, (int)HD, position_offset,
-                                                                   (int)L.attn->cacheCapacity(), cfg_.rms_norm_eps, st ) );
+                                                                   (int)L.cacheCapacity(), cfg_.rms_norm_eps, st ) );
             auto attn = attn_out_->view( shape_t{ 1, T, NH * HD } );
-            L.attn->prefillFromCache( q, attn, T, position_offset );
+            L.prefillFromCache( q, attn, T, position_offset );
             auto& o = L.o_proj->forward( attn );
             auto res1 = res1_->view( shape_t{ 1, T, D } );
             auto ffn_in = pf_norm2_->view( shape_t{ 1, T, D } );
@@ -719,10 +651,10 @@ namespace Mila::Dnn
                 if ( splits > 1 )
                 {
                     // small partial set (sliding-window layers): no combine launch, o_proj combines the splits in its prologue
-                    Compute::rocmCheck( mila_cdna4_fused_attn_decode_partials_bf16( L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
+                    Compute::rocmCheck( mila_cdna4_fused_attn_decode_partials_bf16( L.keyCache(), L.valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
                                                                                     L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(),
-                                                                                    scratch, need, NH, NKV, HD, (int)L.attn->cacheCapacity(), position, pos_dev,
-                                                                                    (int)cfg_.windowFor( g ), L.attn->scale(), cfg_.rms_norm_eps, st ) );
+                                                                                    scratch, need, NH, NKV, HD, (int)L.cacheCapacity(), position, pos_dev,
+                                                                                    (int)cfg_.windowFor( g ), L.attentionScale(), cfg_.rms_norm_eps, st ) );
                     const float* sc = nullptr;
                     if constexpr ( TWeightQuant::kIsQuantized ) sc = L.o_proj->getWeightScale()->data();
                     Compute::rocmCheck( mila_cdna4_matvec_attn_combine( f_o_->data(), scratch, splits, NH, HD, L.o_proj->getWeight().rawData(), sc, kFmt,
@@ -734,7 +666,7 @@ namespace Mila::Dnn
                     if ( warm_a_blocks_ > 0 || warm_b_blocks_ > 0 )
                     {
                         mila_fused_attn_args a{};
-                        a.Y = attn_out_->data(); a.Kc = L.attn->keyCache(); a.Vc = L.attn->valueCache(); a.q_raw = qp; a.k_raw = kp; a.v_raw = vp;
+                        a.Y = attn_out_->data(); a.Kc = L.keyCache(); a.Vc = L.valueCache(); a.q_raw = qp; a.k_raw = kp; a.v_raw = vp;
                         a.qw = L.q_norm->getWeight()->data(); a.kw = L.k_norm->getWeight()->data(); a.vw = L.v_norm->getWeight()->data();
                         a.cos_cache = L.rope->cosCache(); a.sin_cache = L.rope->sinCache(); a.scratch = scratch; a.scratch_bytes = need;
                         if ( onepass_attn_ ) { a.tickets = reinterpret_cast<uint32_t*>( tickets_->data() ); a.ticket_count = (size_t)tickets_->size(); }
@@ -743,22 +675,22 @@ namespace Mila::Dnn
                         const size_t gub = L.fc_gate_up->getWeight().sizeInBytes();
                         a.warm_b = L.fc_gate_up->getWeight().rawData(); a.warm_b_bytes = std::min( gub, warm_b_cap_ ) / 256 * 256; a.warm_b_blocks = warm_b_blocks_;
                         a.warm_b_pair_offset = gub / 2;
-                        a.NH = NH; a.NKV = NKV; a.HS = HD; a.capacity = (int)L.attn->cacheCapacity(); a.position = position; a.position_dev = pos_dev;
-                        a.window = (int)cfg_.windowFor( g ); a.scale = L.attn->scale(); a.eps = cfg_.rms_norm_eps;
+                        a.NH = NH; a.NKV = NKV; a.HS = HD; a.capacity = (int)L.cacheCapacity(); a.position = position; a.position_dev = pos_dev;
+                        a.window = (int)cfg_.windowFor( g ); a.scale = L.attentionScale(); a.eps = cfg_.rms_norm_eps;
                         Compute::rocmCheck( mila_cdna4_fused_attn_decode_ex( &a, st ) );
                     }
                     else if ( onepass_attn_ )
-                        Compute::rocmCheck( mila_cdna4_fused_attn_decode_onepass_bf16( attn_out_->data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp,
+                        Compute::rocmCheck( mila_cdna4_fused_attn_decode_onepass_bf16( attn_out_->data(), L.keyCache(), L.valueCache(), qp, kp, vp,
                                                                                        L.q_norm->getWeight()->data(), L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(),
                                                                                        L.rope->cosCache(), L.rope->sinCache(), scratch, need,
                                                                                        reinterpret_cast<uint32_t*>( tickets_->data() ), (size_t)tickets_->size(), NH, NKV, HD,
-                                                                                       (int)L.attn->cacheCapacity(), position, pos_dev, (int)cfg_.windowFor( g ), L.attn->scale(),
+                                                                                       (int)L.cacheCapacity(), position, pos_dev, (int)cfg_.windowFor( g ), L.attentionScale(),
                                                                                        cfg_.rms_norm_eps, st ) );
                     else
-                        Compute::rocmCheck( mila_cdna4_fused_attn_decode_bf16( attn_out_->data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
+                        Compute::rocmCheck( mila_cdna4_fused_attn_decode_bf16( attn_out_->data(), L.keyCache(), L.valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
                                                                                L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(),
-                                                                               scratch, need, NH, NKV, HD, (int)L.attn->cacheCapacity(), position, pos_dev,
-                                                                               (int)cfg_.windowFor( g ), L.attn->scale(), cfg_.rms_norm_eps, st ) );
+                                                                               scratch, need, NH, NKV, HD, (int)L.cacheCapacity(), position, pos_dev,
+                                                                               (int)cfg_.windowFor( g ), L.attentionScale(), cfg_.rms_norm_eps, st ) );
                     // 4. o_proj
                     plainMatvec( *L.o_proj, f_o_->data(), attn_out_->data() );
                 }
@@ -767,7 +699,7 @@ namespace Mila::Dnn
                 fusedGateUp( L );
                 // 6. fc_down
                 {
-                    const size_t li = static_cast<size_t>( &L - layers_.data() );
+                    const size_t li = L.index;
                     if ( li + 1 < layers_.size() ) prefetchLinear( *layers_[ li + 1 ].qkv_proj );
                     else prefetchLinear( *lm_head_ );
                 }
@@ -799,10 +731,10 @@ namespace Mila::Dnn
             const uint16_t* vp = g ? kp : kp + (size_t)NKV * HD;
             const size_t need = attnScratchBytes();
             void* scratch = attn_partials_->data();
-            Compute::rocmCheck( mila_cdna4_fused_attn_decode_bf16( attn_out_->data(), L.attn->keyCache(), L.attn->valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
+            Compute::rocmCheck( mila_cdna4_fused_attn_decode_bf16( attn_out_->data(), L.keyCache(), L.valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
                                                                    L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(),
-                                                                   scratch, need, NH, NKV, HD, (int)L.attn->cacheCapacity(), position, pos_dev,
-                                                                   (int)cfg_.windowFor( g ), L.attn->scale(), cfg_.rms_norm_eps, ctx_->getStream() ) );
+                                                                   scratch, need, NH, NKV, HD, (int)L.cacheCapacity(), position, pos_dev,
+                                                                   (int)cfg_.windowFor( g ), L.attentionScale(), cfg_.rms_norm_eps, ctx_->getStream() ) );
         }
 
         /// The same step with the four Linears between two attention calls in one launch (mila_cdna4_decode_chain):
@@ -870,7 +802,7 @@ namespace Mila::Dnn
             const bool g = L.global;
             const int NH = (int)cfg_.num_heads, NKV = (int)cfg_.numKvHeads( g ), HD = (int)cfg_.headDim( g );
             if ( ( HD != 256 && HD != 512 ) || NH * HD > 8192 ) return 0;
-            const int splits = mila_cdna4_attn_decode_split_count( 1, NH, NKV, HD, (int)L.attn->cacheCapacity(), (int)cfg_.windowFor( g ) );
+            const int splits = mila_cdna4_attn_decode_split_count( 1, NH, NKV, HD, (int)L.cacheCapacity(), (int)cfg_.windowFor( g ) );
             if ( splits <= 1 || (size_t)NH * splits * ( HD + 4 ) * 4 > ( 512u << 10 ) ) return 0;
             return splits;
         }
@@ -1193,12 +1125,14 @@ namespace Mila::Dnn
         dim_t max_seq_, max_prefill_;
         std::unique_ptr<IExecutionContext> owned_ctx_;
         Compute::RocmExecutionContext* ctx_{ nullptr };
-        std::vector<Layer> layers_;
+        LayerList layers_;
         std::shared_ptr<RmsNormType> final_norm_;
         std::shared_ptr<LmHeadLinearType> lm_head_;
-        std::unique_ptr<TensorType> hidden_[ 3 ], pf_x_[ 2 ], q_, k_, v_, attn_out_, res1_, res2_, geglu_, f_qkv_, f_q_, f_o_, f_down_, f_act_;
+        std::unique_ptr<TensorType> hidden_[ 3 ], pf_x_[ 2 ], f_qkv_, f_q_, f_o_, f_down_, f_act_;
+        std::shared_ptr<TensorType> q_, k_, v_, attn_out_, res1_, res2_, geglu_, blk_out_[ 2 ];   // the blocks' shared workspace
+        std::shared_ptr<TokenEmbeddingType> temb_;
         std::unique_ptr<LogitsTensor> logits_;
-        std::unique_ptr<TokenTensor> pos_dev_, err_flag_;
+        std::unique_ptr<TokenTensor> pos_dev_;
         std::unique_ptr<LogitsTensor> sample_scratch_;
         bool sample_in_graph_{ false };
         bool use_chain_{ false };

@@ -2,6 +2,7 @@
 // Instantiates GemmaTransformer<TWeightQuant> for the three weight policies of BASELINE.json
 // configs 3-5 and exposes build / prefill / decode / timing.
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <random>
@@ -506,6 +507,195 @@ HOST_API int mila_gemma_info( void* h, int64_t context, double* out )
             out[ 2 ] = p;
             out[ 3 ] = static_cast<double>( c.vocab_size ) * c.embedding_dim;
         }, r->model );
+    } );
+}
+
+/// component names of the model, '\n'-separated, in construction order (children of each block, then temb / rmsn_final / lm_head);
+/// returns the length needed (including the terminator); writes at most `cap` bytes
+HOST_API int64_t mila_gemma_component_names( void* h, char* buf, int64_t cap )
+{
+    std::string out;
+    int rc = guarded( [&]
+    {
+        std::visit( [&]( auto& m )
+        {
+            for ( auto& L : m->layers() )
+            {
+                out += L.getName() + "\n";
+                for ( const std::string& n : L.childNames() ) out += n + "\n";
+            }
+            out += m->tokenEmbedding().getName() + "\n" + m->finalNorm().getName() + "\n" + m->lmHead().getName() + "\n";
+        }, static_cast<Runner*>( h )->model );
+    } );
+    if ( rc ) return -1;
+    if ( buf && cap > 0 ) { const size_t n = std::min<size_t>( out.size(), static_cast<size_t>( cap - 1 ) ); std::memcpy( buf, out.data(), n ); buf[ n ] = 0; }
+    return static_cast<int64_t>( out.size() + 1 );
+}
+
+/// The leaf components used on their own, as code written against the reference uses them (construct with a name and a config,
+/// setExecutionContext, build, forward): each result is compared on the host with the C-ABI launcher it resolves to, and the lifecycle
+/// errors are the reference's (forward before build -> runtime_error naming the component; bad shapes -> invalid_argument).
+/// Returns 0, or an error whose text says which scenario failed.
+HOST_API int mila_component_scenarios( int device )
+{
+    return guarded( [&]
+    {
+        using Dev = Compute::RocmDeviceMemoryResource;
+        using T16 = Tensor<TensorDataType::BF16, Dev>;
+        using TI = Tensor<TensorDataType::INT32, Dev>;
+        constexpr auto kD = DeviceType::Rocm;
+        constexpr auto kP = TensorDataType::BF16;
+        auto owned = Compute::createExecutionContext( Compute::Device::Rocm( device ) );
+        auto* ctx = Compute::cast_context<kD>( owned.get() );
+        const auto dev = ctx->getDeviceId();
+        auto fail = [&]( const std::string& what ) { throw std::runtime_error( "component scenario failed: " + what ); };
+        auto fillu = [&]( T16& t, uint64_t seed, float amp, float off ) { Compute::rocmCheck( mila_cdna4_fill_uniform_bf16( t.data(), (int64_t)t.size(), seed, amp, off, ctx->getStream() ) ); };
+        auto host = [&]( const T16& t, size_t n )
+        {
+            std::vector<uint16_t> v( n );
+            Compute::rocmCheck( mila_cdna4_memcpy_d2h( v.data(), t.rawData(), n * 2, ctx->getStream() ) );
+            ctx->synchronize();
+            return v;
+        };
+        auto expect_throw = [&]( auto&& f, bool invalid_arg, const std::string& what )
+        {
+            try { f(); }
+            catch ( const std::invalid_argument& ) { if ( !invalid_arg ) fail( what + " (threw invalid_argument, expected runtime_error)" ); return; }
+            catch ( const std::runtime_error& ) { if ( invalid_arg ) fail( what + " (threw runtime_error, expected invalid_argument)" ); return; }
+            fail( what + " (did not throw)" );
+        };
+        const dim_t B = 2, T = 5, NH = 4, NKV = 2, HD = 64, C = NH * HD;
+
+        // ---- Residual: forward(a, b) = a + b, component-owned output ----
+        {
+            Residual<kD, kP> res( "res_1", ResidualConfig{} );
+            T16 a( dev, shape_t{ B, T, C } ), b( dev, shape_t{ B, T, C } ), ref( dev, shape_t{ B, T, C } );
+            fillu( a, 1, 1.0f, 0.0f ); fillu( b, 2, 1.0f, 0.0f );
+            res.setExecutionContext( ctx );
+            expect_throw( [&] { res.forward( a, b ); }, false, "Residual::forward before build" );
+            res.build( BuildContext( shape_t{ B, T, C }, RuntimeMode::Inference ) );
+            auto& y = res.forward( a, b );
+            Compute::rocmCheck( mila_cdna4_residual_bf16( ref.data(), a.data(), b.data(), (int64_t)a.size(), ctx->getStream() ) );
+            if ( y.shape() != a.shape() || host( y, a.size() ) != host( ref, a.size() ) ) fail( "Residual::forward" );
+            expect_throw( [&] { ResidualConfig().withScalingFactor( 0.0f ).validate(); }, true, "ResidualConfig scaling_factor 0" );
+        }
+        // ---- Swiglu<Gelu>: [.., 2H] -> [.., H] ----
+        {
+            Swiglu<kD, kP, ActivationType::Gelu> g( "geglu", SwigluConfig() );
+            T16 x( dev, shape_t{ B, T, 2 * C } ), ref( dev, shape_t{ B, T, C } );
+            fillu( x, 3, 2.0f, 0.0f );
+            g.setExecutionContext( ctx );
+            g.build( BuildContext( shape_t{ B, T, 2 * C }, RuntimeMode::Inference ) );
+            auto& y = g.forward( x );
+            Compute::rocmCheck( mila_cdna4_geglu_bf16( ref.data(), x.data(), (int)( B * T ), (int)C, ctx->getStream() ) );
+            if ( y.shape() != shape_t{ B, T, C } || host( y, ref.size() ) != host( ref, ref.size() ) ) fail( "Swiglu<Gelu>::forward" );
+            T16 odd( dev, shape_t{ B, T, 7 } );
+            expect_throw( [&] { g.forward( odd ); }, true, "Swiglu odd width" );
+        }
+        // ---- Rope: prefill == decode position by position; bounds ----
+        {
+            const dim_t MAXS = 64;
+            Rope<kD, kP> rope( "rope", RopeConfig( C, NH, NKV, MAXS ).withBase( 10000.0f ) );
+            rope.setExecutionContext( ctx );
+            rope.build( BuildContext( shape_t{ 1, T, C }, RuntimeMode::Inference ) );
+            T16 q( dev, shape_t{ 1, T, C } ), k( dev, shape_t{ 1, T, NKV * HD } ), q1( dev, shape_t{ 1, T, C } ), k1( dev, shape_t{ 1, T, NKV * HD } );
+            fillu( q, 4, 1.0f, 0.0f ); fillu( k, 5, 1.0f, 0.0f );
+            Compute::rocmCheck( mila_cdna4_memcpy_d2d( q1.rawData(), q.rawData(), q.sizeInBytes(), ctx->getStream() ) );
+            Compute::rocmCheck( mila_cdna4_memcpy_d2d( k1.rawData(), k.rawData(), k.sizeInBytes(), ctx->getStream() ) );
+            rope.prefill( q, k, 7 );
+            for ( dim_t t = 0; t < T; ++t )
+            {
+                auto qt = q1.slice( static_cast<size_t>( t * C ), shape_t{ 1, 1, C } );
+                auto kt = k1.slice( static_cast<size_t>( t * NKV * HD ), shape_t{ 1, 1, NKV * HD } );
+                rope.decode( qt, kt, 7 + t );
+            }
+            if ( host( q, q.size() ) != host( q1, q.size() ) || host( k, k.size() ) != host( k1, k.size() ) ) fail( "Rope::prefill vs decode" );
+            expect_throw( [&] { rope.prefill( q, k, MAXS - 2 ); }, true, "Rope positions beyond the cache" );
+            expect_throw( [&] { RopeConfig( C, NH, 3, MAXS ).validate(); }, true, "RopeConfig n_heads % n_kv_heads" );
+        }
+        // ---- GroupedQueryAttention: chunked prefill then decode == one prefill over the same tokens (same cache, same kernels' contract) ----
+        {
+            const dim_t MAXS = 32;
+            auto mk = [&]( const char* name )
+            {
+                auto a = std::make_unique<GroupedQueryAttention<kD, kP>>( name, GqaConfig( C, NH, NKV ).withAttentionScale( 1.0f ) );
+                a->setExecutionContext( ctx );
+                a->build( BuildContext( shape_t{ 1, MAXS, ( NH + 2 * NKV ) * HD }, RuntimeMode::Inference, false, T + 1 ) );
+                return a;
+            };
+            auto a1 = mk( "gqa" ), a2 = mk( "gqa" );
+            T16 q( dev, shape_t{ 1, T + 1, C } ), k( dev, shape_t{ 1, T + 1, NKV * HD } ), v( dev, shape_t{ 1, T + 1, NKV * HD } );
+            fillu( q, 6, 1.0f, 0.0f ); fillu( k, 7, 1.0f, 0.0f ); fillu( v, 8, 1.0f, 0.0f );
+            auto& full = a1->prefill( q, k, v, 0 );
+            auto full_h = host( full, static_cast<size_t>( ( T + 1 ) * C ) );
+            a2->prefill( q.view( shape_t{ 1, T, C } ), k.view( shape_t{ 1, T, NKV * HD } ), v.view( shape_t{ 1, T, NKV * HD } ), 0 );
+            auto& last = a2->decode( q.slice( static_cast<size_t>( T * C ), shape_t{ 1, 1, C } ), k.slice( static_cast<size_t>( T * NKV * HD ), shape_t{ 1, 1, NKV * HD } ),
+                                     v.slice( static_cast<size_t>( T * NKV * HD ), shape_t{ 1, 1, NKV * HD } ), T );
+            auto last_h = host( last, static_cast<size_t>( C ) );
+            for ( dim_t i = 0; i < C; ++i )
+            {
+                auto f = []( uint16_t b ) { uint32_t u = (uint32_t)b << 16; float x; std::memcpy( &x, &u, 4 ); return x; };
+                const float d = std::fabs( f( last_h[ i ] ) - f( full_h[ static_cast<size_t>( T * C + i ) ] ) );
+                if ( !( d <= 2e-2f ) ) fail( "GroupedQueryAttention decode vs prefill row (|d| = " + std::to_string( d ) + ")" );
+            }
+            if ( a2->cacheLength() != T + 1 || !a2->supportsKVCache() ) fail( "GroupedQueryAttention cache bookkeeping" );
+            if ( !a2->rewindKvCache( 2 ) || a2->cacheLength() != 2 || a2->rewindKvCache( 9 ) ) fail( "GroupedQueryAttention::rewindKvCache" );
+            a2->resetKVCache();
+            if ( a2->cacheLength() != 0 ) fail( "GroupedQueryAttention::resetKVCache" );
+            expect_throw( [&] { GqaConfig( C, NH, 3 ).validate(); }, true, "GqaConfig num_heads % num_kv_heads" );
+            GroupedQueryAttention<kD, kP> unbuilt( "gqa", GqaConfig( C, NH, NKV ) );
+            expect_throw( [&] { unbuilt.prefill( q, k, v, 0 ); }, false, "GroupedQueryAttention::prefill before build" );
+        }
+        // ---- TokenEmbedding: forward(tokens) = wte[id] * scale; bf16 and FP8 tables; the tied Linear adopts the table ----
+        {
+            const dim_t V = 50, E = 32;
+            std::vector<uint16_t> table( static_cast<size_t>( V * E ) );
+            for ( size_t i = 0; i < table.size(); ++i ) { const float x = 0.01f * static_cast<float>( ( i * 37 ) % 101 ) - 0.5f; uint32_t u; std::memcpy( &u, &x, 4 ); table[ i ] = static_cast<uint16_t>( u >> 16 ); }
+            std::vector<int32_t> ids{ 3, 49, 0, 17, 17, 8 };
+            TI tok( dev, shape_t{ 2, 3 } );
+            Compute::rocmCheck( mila_cdna4_memcpy_h2d( tok.rawData(), ids.data(), ids.size() * 4, ctx->getStream() ) );
+            TokenEmbedding<kD, TensorDataType::INT32, kP> emb( "temb", TokenEmbeddingConfig().withVocabSize( V ).withEmbeddingDim( E ).withEmbeddingScale( 2.0f ) );
+            emb.setExecutionContext( ctx );
+            expect_throw( [&] { emb.forward( tok ); }, false, "TokenEmbedding::forward before build" );
+            emb.build( BuildContext( shape_t{ 2, 4 }, RuntimeMode::Inference ) );
+            emb.loadParameter( "wte", table.data(), table.size() * 2 );
+            auto& y = emb.forward( tok );
+            auto yh = host( y, ids.size() * static_cast<size_t>( E ) );
+            auto f = []( uint16_t b ) { uint32_t u = (uint32_t)b << 16; float x; std::memcpy( &x, &u, 4 ); return x; };
+            for ( size_t t = 0; t < ids.size(); ++t )
+                for ( dim_t e = 0; e < E; ++e )
+                    if ( f( yh[ t * E + e ] ) != 2.0f * f( table[ static_cast<size_t>( ids[ t ] * E + e ) ] ) ) fail( "TokenEmbedding::forward (bf16 table)" );
+            if ( emb.takeError() != 0 ) fail( "TokenEmbedding error flag set on valid ids" );
+            TI big( dev, shape_t{ 2, 5 } );
+            expect_throw( [&] { emb.forward( big ); }, false, "TokenEmbedding input beyond the built shape" );
+            expect_throw( [&] { emb.loadParameter( "wte_scale", table.data(), 4 ); }, true, "wte_scale on an unquantized table" );
+            // tied head: logits = x . wte^T through the SAME allocation
+            Linear<kD, kP> head( "lm_head", LinearConfig( E, V ).withBias( false ) );
+            head.setExecutionContext( ctx );
+            head.installSharedWeight( emb.getWeightTensorShared() );
+            head.build( BuildContext( shape_t{ 1, 1, E }, RuntimeMode::Inference ) );
+            if ( head.getWeight().rawData() != emb.getWeightTensorShared()->rawData() || !head.hasSharedWeight() ) fail( "Linear::installSharedWeight does not alias the table" );
+            // FP8 table: quantize on load, gather dequantizes with the row scale
+            TokenEmbedding<kD, TensorDataType::INT32, kP, PerChannelFp8<>> q8( "temb", TokenEmbeddingConfig().withVocabSize( V ).withEmbeddingDim( E ) );
+            q8.setExecutionContext( ctx );
+            q8.build( BuildContext( shape_t{ 2, 4 }, RuntimeMode::Inference ) );
+            q8.loadParameter( "wte", table.data(), table.size() * 2 );
+            auto& y8 = q8.forward( tok );
+            auto y8h = host( y8, ids.size() * static_cast<size_t>( E ) );
+            for ( size_t t = 0; t < ids.size(); ++t )
+                for ( dim_t e = 0; e < E; ++e )
+                {
+                    const float want = f( table[ static_cast<size_t>( ids[ t ] * E + e ) ] );
+                    if ( std::fabs( f( y8h[ t * E + e ] ) - want ) > 0.0625f * 0.5f + 1e-3f ) fail( "TokenEmbedding::forward (FP8 table)" );   // e4m3: 3 mantissa bits, |w| <= 0.5
+                }
+            Linear<kD, kP, PerChannelFp8<>> head8( "lm_head", LinearConfig( E, V ).withBias( false ) );
+            head8.setExecutionContext( ctx );
+            head8.installSharedWeight( q8.getWeightTensorShared(), q8.getWeightScalesTensorShared() );
+            head8.build( BuildContext( shape_t{ 1, 1, E }, RuntimeMode::Inference ) );
+            if ( head8.getWeightScale()->rawData() != q8.getWeightScalesTensorShared()->rawData() ) fail( "Linear::installSharedWeight(weight, scales)" );
+            expect_throw( [&] { head8.installSharedWeight( q8.getWeightTensorShared(), q8.getWeightScalesTensorShared() ); }, false, "installSharedWeight after build" );
+        }
+        ctx->synchronize();
     } );
 }
 

@@ -456,3 +456,24 @@ def test_chunked_prefill_equals_single_chunk_prefill(cfg_name):
     assert np.array_equal(da.view(np.uint32), db.view(np.uint32)), "the caches differ"
     a.close()
     b.close()
+
+
+def test_components_stand_alone_as_in_the_reference():
+    """Components/{Connections/Residual.ixx:93-127, FFN/Swiglu/Swiglu.ixx:92, Encodings/Rope/Rope.ixx:99-200, Attention/GQA/GroupedQueryAttention.ixx:234-400,
+    Embeddings/TokenEmbedding.ixx:155-190,336-384, Linear/Linear.ixx:614-680}: name + config constructor, setExecutionContext, build, forward; results against
+    the launchers, lifecycle errors (runtime_error before build, invalid_argument on bad shapes / configs), the tied head aliasing the table"""
+    host.component_scenarios(0)
+
+
+def test_the_block_is_the_references_graph():
+    """Gemma.Block.ixx:858-921: the children of every block under the reference's names, in its construction order; Gemma.ixx: temb, rmsn_final, lm_head"""
+    m = host.Gemma("bf16", SMALL, max_seq=32, max_prefill=8, seed=1)
+    names = m.component_names()
+    leaves = ["input_norm", "q_norm", "k_norm", "v_norm", "post_attn_norm", "pre_ffn_norm", "post_ffn_norm", "qkv_proj", "rope", "gqa", "o_proj", "res_1",
+              "fc_gate_up", "geglu", "fc_down", "res_2"]
+    want = []
+    for i in range(SMALL["num_layers"]):
+        want.append("gemma.tf_layer_%d" % i)
+        want += ["gemma.tf_layer_%d.%s" % (i, leaf) for leaf in leaves]
+    want += ["gemma.temb", "gemma.rmsn_final", "gemma.lm_head"]
+    assert names == want
