@@ -48,7 +48,7 @@ __device__ __forceinline__ void chain_arrive(unsigned long long* counter)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
     __syncthreads();
     if (threadIdx.x == 0)
-        __hip_atomic_fetch_add(as_global(counter), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(as_global(counter), 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // release: the arrival orders after this workgroup's stores
 }
 
 struct ChainWait
@@ -165,10 +165,28 @@ size_t mila_cdna4_decode_chain_scratch_bytes(int D, int F)
     return kChainHeaderBytes + (size_t)(2 * D + F) * 4 + 64;
 }
 
+/* every instantiation must fit one 1024-thread workgroup per CU with the largest x buffer: the grid-wide hand-offs need all of them resident */
+static int chain_check_residency()
+{
+    static int checked = 0;
+    if (checked) return checked > 0 ? MILA_OK : set_error(MILA_E_UNSUPPORTED, "decode_chain: a workgroup of the chain kernel does not fit a compute unit on this device");
+    auto fits = [](const void* fn) {
+        int n = 0;
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 1024, 65536) == hipSuccess && n >= 1;
+    };
+    const bool ok = fits(reinterpret_cast<const void*>(&decode_chain_kernel<FMT_BF16, false, FMT_BF16>)) && fits(reinterpret_cast<const void*>(&decode_chain_kernel<FMT_FP8, false, FMT_FP8>)) &&
+                    fits(reinterpret_cast<const void*>(&decode_chain_kernel<FMT_FP4, false, FMT_FP4>)) && fits(reinterpret_cast<const void*>(&decode_chain_kernel<FMT_BF16, true, FMT_BF16>)) &&
+                    fits(reinterpret_cast<const void*>(&decode_chain_kernel<FMT_FP8, true, FMT_FP8>)) && fits(reinterpret_cast<const void*>(&decode_chain_kernel<FMT_FP4, true, FMT_FP8>));
+    checked = ok ? 1 : -1;
+    return ok ? MILA_OK : set_error(MILA_E_UNSUPPORTED, "decode_chain: a workgroup of the chain kernel does not fit a compute unit on this device");
+}
+
 int mila_cdna4_decode_chain_init(void* scratch, size_t scratch_bytes, mila_stream_t stream)
 {
     MILA_REQUIRE(scratch != nullptr && scratch_bytes >= kChainHeaderBytes, "decode_chain_init: scratch too small");
     (void)chain_num_blocks();   // device query outside any later stream capture
+    const int rc = chain_check_residency();
+    if (rc) return rc;
     return check_hip(hipMemsetAsync(scratch, 0, kChainHeaderBytes, as_stream(stream)), "decode_chain_init");
 }
 

@@ -671,8 +671,14 @@ static void eng_fill_phase(EngPhase& P, int fmt, int group, bool geglu)
 template <int FMT, bool HEAD, int HFMT>
 static hipError_t eng_allow_big_lds()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_engine_kernel<FMT, HEAD, HFMT, EngShape<FMT>::NW, EngShape<FMT>::B, EngShape<FMT>::RG>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void* fn = reinterpret_cast<const void*>(&decode_engine_kernel<FMT, HEAD, HFMT, EngShape<FMT>::NW, EngShape<FMT>::B, EngShape<FMT>::RG>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    // the data-tagged hand-offs need every workgroup resident: one must fit a CU with the whole LDS it may ask for
+    int n = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64 * EngShape<FMT>::NW, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return n >= 1 ? hipSuccess : hipErrorLaunchOutOfResources;
 }
 // every instantiation may use the CU's whole LDS; called from decode_engine_init (never inside a stream capture)
 static int eng_prepare_all()

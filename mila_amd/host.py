@@ -247,6 +247,18 @@ class Gpt:
         if not self.h:
             raise (ValueError if b"invalid_argument" in lib.mila_gpt_last_error() else RuntimeError)(lib.mila_gpt_last_error().decode())
 
+    def component_names(self):
+        """names of the model's components in construction order (lenc, each block and its children, ln_final, lm_head)"""
+        lib = load()
+        lib.mila_gpt_component_names.restype = C.c_int64
+        lib.mila_gpt_component_names.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        need = lib.mila_gpt_component_names(self.h, None, 0)
+        if need < 0:
+            raise RuntimeError(lib.mila_gpt_last_error().decode())
+        buf = C.create_string_buffer(need)
+        lib.mila_gpt_component_names(self.h, buf, need)
+        return buf.value.decode().split("\n")[:-1]
+
     def load_parameters(self, params_bf16_bits):
         lib = load()
         assert len(params_bf16_bits) == lib.mila_gpt_parameter_count(self.h)

@@ -1029,6 +1029,7 @@ namespace Mila::Dnn
         {
             destroyGraph();   // the captured schedule no longer applies: ensureGraph() captures again
             if ( blocks_a < 0 || blocks_a > 64 || blocks_b < 0 || blocks_b > 64 ) throw std::invalid_argument( "GemmaTransformer::setWarmAhead: block counts must be in [0, 64]" );
+            if ( use_chain_ && ( blocks_a > 0 || blocks_b > 0 ) ) throw std::invalid_argument( "GemmaTransformer::setWarmAhead: not combinable with setUseChain (the chain needs every compute unit resident)" );
             warm_a_blocks_ = blocks_a; warm_a_cap_ = cap_a; warm_b_blocks_ = blocks_b; warm_b_cap_ = cap_b;
         }
         /// cap_bytes > 0: while one decode kernel runs, a side stream pulls the first cap_bytes of the NEXT Linear's weights into the
@@ -1038,6 +1039,7 @@ namespace Mila::Dnn
         {
             destroyGraph();   // the captured schedule no longer applies: ensureGraph() captures again
             if ( workgroups < 1 || workgroups > 4096 ) throw std::invalid_argument( "GemmaTransformer::setPrefetchAhead: workgroups out of range" );
+            if ( use_chain_ && cap_bytes > 0 ) throw std::invalid_argument( "GemmaTransformer::setPrefetchAhead: not combinable with setUseChain (the chain needs every compute unit resident)" );
             if ( cap_bytes > 0 && !side_ )
             {
                 hipCheck( hipStreamCreateWithFlags( &side_, hipStreamNonBlocking ), "hipStreamCreate" );
@@ -1107,6 +1109,9 @@ namespace Mila::Dnn
         void setUseChain( bool on )
         {
             if ( on && !chainApplicable() ) throw std::invalid_argument( "GemmaTransformer::setUseChain: configuration outside the chain kernel's limits" );
+            // the chain's grid-wide hand-offs need all its workgroups resident: nothing of this model may run beside it on another stream
+            if ( on && ( prefetch_cap_ > 0 || warm_a_blocks_ > 0 || warm_b_blocks_ > 0 ) )
+                throw std::invalid_argument( "GemmaTransformer::setUseChain: not combinable with setPrefetchAhead / setWarmAhead (their kernels take compute units the chain needs resident)" );
             destroyGraph();   // the captured schedule no longer applies: ensureGraph() captures again
             use_chain_ = on;
         }

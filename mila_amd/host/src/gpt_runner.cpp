@@ -1,4 +1,6 @@
 // C entry points for the GPT-2 host mirror (BASELINE.json configs 1-2).
+#include <algorithm>
+#include <cstring>
 #include <memory>
 #include <string>
 
@@ -50,6 +52,16 @@ HOST_API int mila_gpt_load_parameter( void* h, int64_t index, const void* host_b
     return guarded( [&] { static_cast<GptRunner*>( h )->model->loadParameter( static_cast<size_t>( index ), host_bf16, static_cast<size_t>( bytes ) ); } );
 }
 /// tokens [B,T] host int32 -> logits [B,T,V] host bf16 bits; returns 0, or a positive 1-based index of an out-of-range token
+/// component names in construction order, '\n'-separated; returns the bytes needed (with the terminator)
+HOST_API int64_t mila_gpt_component_names( void* h, char* buf, int64_t cap )
+{
+    std::string out;
+    try { for ( const auto& n : static_cast<GptRunner*>( h )->model->componentNames() ) out += n + "\n"; }
+    catch ( const std::exception& e ) { g_err = e.what(); return -1; }
+    if ( buf && cap > 0 ) { const size_t n = std::min<size_t>( out.size(), static_cast<size_t>( cap - 1 ) ); std::memcpy( buf, out.data(), n ); buf[ n ] = 0; }
+    return static_cast<int64_t>( out.size() + 1 );
+}
+
 HOST_API int mila_gpt_forward( void* h, const int32_t* host_tokens, uint16_t* host_logits, double* ms )
 {
     auto* r = static_cast<GptRunner*>( h );

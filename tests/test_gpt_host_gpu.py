@@ -95,3 +95,18 @@ def test_gpt2_124m_config2_full_size_properties():
     assert np.all(np.abs(f - short) <= 5e-2 + 5e-2 * np.abs(short)), np.abs(f - short).max()
     exp = orc.cpu_gpt2_forward(tokens[:1, :64], [orc.from_bf16_bits(p) for p in params], C_, L, NH, V, maxT)[0]
     assert np.all(np.abs(short - exp) <= 5e-2 + 5e-2 * np.abs(exp)), np.abs(short - exp).max()
+
+
+def test_the_model_is_the_references_graph():
+    """GptTransformer.ixx:828-858 (lenc, tf_layer_<i>, ln_final, lm_head), GptBlock.ixx:512-546 (attn, ln_1, ln_2, fc_qkv_proj, fc_out_proj, res_1, res_2, mlp),
+    MLP.ixx:410-412 (fc_1, gelu, fc_2): the same components under the same names, in construction order"""
+    m = host.Gpt(128, 16, 64, 2, 4, 1, 8)
+    try:
+        want = ["gpt.lenc"]
+        for i in range(2):
+            b = "gpt.tf_layer_%d" % i
+            want += [b] + [b + "." + leaf for leaf in ("attn", "ln_1", "ln_2", "fc_qkv_proj", "fc_out_proj", "res_1", "res_2", "mlp", "mlp.fc_1", "mlp.gelu", "mlp.fc_2")]
+        want += ["gpt.ln_final", "gpt.lm_head"]
+        assert m.component_names() == want
+    finally:
+        m.close()
