@@ -150,9 +150,11 @@ def cpu_baseline(cfg):
 def measured_traffic(policy):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, produced by
     tools/summarize_pmc.py with the gfx950 FETCH_SIZE correction); None when no pass exists for this policy."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % policy)
-    if not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic_%s.json" % policy)))      # the latest round's pass
+    if not found:
         return None, None
+    path = found[-1]
     fmt = {"bf16": 0, "fp8": 1, "fp4": 2}[policy]
     import re
     want = re.compile(r"matvec_kernel<%d, \d+, \d+, 2, true, false" % fmt)      # <FMT, R, U, PRO=2, GEGLU, !F32OUT, ...>: fc_gate_up
