@@ -134,7 +134,7 @@ EXPORTED = [
     "sample_scratch_bytes", "sample_argmax_fp32", "sample_argmax_bf16",
     "sample_stochastic_scratch_bytes", "sample_stochastic_fp32", "sample_stochastic_bf16",
     "fused_norm_matvec", "fused_qkv_post", "fused_qkv_post_prefill", "fused_tail_norm_bf16",
-    "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position", "fused_attn_decode_bf16",
+    "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position", "advance_position_snapshot", "snapshot_token", "fused_attn_decode_bf16",
     "attn_decode_split_count", "fused_attn_decode_partials_bf16", "matvec_attn_combine",
     "decode_chain_scratch_bytes", "decode_chain_init", "decode_chain_status", "decode_chain",
     "decode_engine_scratch_bytes", "decode_engine_init", "decode_engine_status", "decode_engine_applicable", "decode_engine",

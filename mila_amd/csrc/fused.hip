@@ -32,6 +32,14 @@ struct QkvPostParams
 };
 
 __global__ void advance_position_kernel(int32_t* pos) { *pos += 1; }
+// the decode-ahead loop's host side learns each sampled token from a ring slot no later step overwrites before it is read
+__global__ void advance_position_snapshot_kernel(int32_t* pos, const int32_t* token, int32_t* ring, int ring_size)
+{
+    const int32_t p = *pos + 1;
+    *pos = p;
+    ring[p % ring_size] = *token;
+}
+__global__ void snapshot_token_kernel(int32_t* ring, int slot, const int32_t* token) { ring[slot] = *token; }
 
 // sum over the hv = HS / 16 lanes of a lane group (hv a power of two <= 32): the first log2(hv) steps of wave_sum's butterfly
 __device__ __forceinline__ float group_tree_sum(float v, int hv)
@@ -182,6 +190,22 @@ int mila_cdna4_advance_position(int32_t* position_dev, mila_stream_t stream)
     MILA_REQUIRE(position_dev != nullptr, "advance_position: null pointer");
     hipLaunchKernelGGL(advance_position_kernel, dim3(1), dim3(1), 0, as_stream(stream), position_dev);
     MILA_LAUNCH_CHECK("advance_position");
+}
+
+int mila_cdna4_advance_position_snapshot(int32_t* position_dev, const int32_t* token, int32_t* ring, int ring_size, mila_stream_t stream)
+{
+    MILA_REQUIRE(position_dev != nullptr && token != nullptr && ring != nullptr, "advance_position_snapshot: null pointer");
+    MILA_REQUIRE(ring_size > 0, "advance_position_snapshot: ring_size must be positive");
+    hipLaunchKernelGGL(advance_position_snapshot_kernel, dim3(1), dim3(1), 0, as_stream(stream), position_dev, token, ring, ring_size);
+    MILA_LAUNCH_CHECK("advance_position_snapshot");
+}
+
+int mila_cdna4_snapshot_token(int32_t* ring, int ring_size, int slot, const int32_t* token, mila_stream_t stream)
+{
+    MILA_REQUIRE(token != nullptr && ring != nullptr, "snapshot_token: null pointer");
+    MILA_REQUIRE(ring_size > 0 && slot >= 0 && slot < ring_size, "snapshot_token: slot %d outside the ring of %d", slot, ring_size);
+    hipLaunchKernelGGL(snapshot_token_kernel, dim3(1), dim3(1), 0, as_stream(stream), ring, slot, token);
+    MILA_LAUNCH_CHECK("snapshot_token");
 }
 
 }  // extern "C"

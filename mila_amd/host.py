@@ -237,6 +237,81 @@ class Gemma:
         return {"decode_bytes_per_token": out[0], "weight_bytes": out[1], "linear_params": out[2], "table_params": out[3]}
 
 
+GENERATE_STATUS = {0: "stop", 1: "length", 2: "context_limit", 3: "cancelled"}      # GenerateStatus / to_string (Core/GenerateStatus.ixx)
+
+
+class GemmaModel:
+    """GemmaModel<Rocm, BF16> (Models/GemmaModel.ixx): fromPretrained / fromSynthetic, then generate()."""
+
+    def __init__(self, handle, device):
+        self.h, self.device = handle, device
+
+    @staticmethod
+    def _bind():
+        lib = load()
+        lib.mila_gemma_model_from_pretrained.restype = C.c_void_p
+        lib.mila_gemma_model_from_pretrained.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int]
+        lib.mila_gemma_model_synthetic.restype = C.c_void_p
+        lib.mila_gemma_model_synthetic.argtypes = [C.c_int, C.POINTER(GemmaConfigC), C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_int]
+        lib.mila_gemma_model_destroy.argtypes = [C.c_void_p]
+        lib.mila_gemma_model_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_float, C.c_int64,
+                                                  C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        return lib
+
+    @staticmethod
+    def _raise(lib, what):
+        text = lib.mila_host_last_error().decode()
+        raise (ValueError if text.startswith("invalid_argument") else RuntimeError)(what + ": " + text)
+
+    @classmethod
+    def from_pretrained(cls, path, policy="bf16", context=4096, prefill_chunk=0, bounded_local_kv=False, device=0):
+        """GemmaModel::fromPretrained(path, GemmaModelConfig(context).withWeightQuantization(policy)): the geometry comes from the artifact"""
+        lib = cls._bind()
+        h = lib.mila_gemma_model_from_pretrained(str(path).encode(), POLICIES[policy], context, prefill_chunk, int(bool(bounded_local_kv)), device)
+        if not h:
+            cls._raise(lib, "GemmaModel.from_pretrained")
+        return cls(h, device)
+
+    @classmethod
+    def synthetic(cls, policy="bf16", config=None, context=4096, prefill_chunk=0, seed=1234, profile=None, device=0):
+        lib = cls._bind()
+        cfg = dict(GEMMA4_12B if config is None else config)
+        cfg.setdefault("bounded_local_kv", 0)
+        c = GemmaConfigC(**cfg)
+        p = None
+        if profile is not None:
+            p = (C.c_float * 5)(*[float(profile[k]) for k in ("linear_gain", "qk_norm_center", "post_norm_center", "layer_scalar", "table_gain")])
+        h = lib.mila_gemma_model_synthetic(POLICIES[policy], C.byref(c), context, prefill_chunk, seed, p, device)
+        if not h:
+            cls._raise(lib, "GemmaModel.synthetic")
+        return cls(h, device)
+
+    def generate(self, prompt, max_new_tokens=None, stop_tokens=(), temperature=1.0, top_k=1, top_p=1.0, seed=None):
+        """-> (tokens passed to on_token, finish reason as GenerateStatus's to_string, prompt tokens served from the KV caches).
+        top_k = 1 is greedy (SamplingParams); seed reseeds the host RNG that draws the sampler's uniform"""
+        lib = load()
+        pr = np.ascontiguousarray(prompt, dtype=np.int32)
+        st = np.ascontiguousarray(list(stop_tokens), dtype=np.int32)
+        cap = int(max_new_tokens) if max_new_tokens is not None else 1 << 16
+        out = np.zeros(max(cap, 1), dtype=np.int32)
+        n, status, reused = C.c_int64(), C.c_int32(), C.c_int64()
+        _check(lib.mila_gemma_model_generate(self.h, pr.ctypes.data, len(pr), -1 if max_new_tokens is None else int(max_new_tokens), st.ctypes.data if len(st) else None, len(st),
+                                             float(temperature), int(top_k), float(top_p), -1 if seed is None else int(seed), out.ctypes.data, len(out), C.byref(n), C.byref(status),
+                                             C.byref(reused)))
+        return out[:min(n.value, len(out))].tolist(), GENERATE_STATUS[status.value], reused.value
+
+    def close(self):
+        if self.h:
+            load().mila_gemma_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Gpt:
     """GptTransformer (GPT-2) on cuda:0, BF16; parameters in the order of oracle orc_cpu_gpt2_forward."""
 

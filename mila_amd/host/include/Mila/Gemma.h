@@ -216,7 +216,10 @@ namespace Mila::Dnn
             {
                 enqueueFusedStep( token.data(), 0, pos_dev_->data() );
                 if ( sample_in_graph_ ) sampleGreedy( const_cast<TokenTensor&>( token ) );   // feeds the next replay
-                Compute::rocmCheck( mila_cdna4_advance_position( pos_dev_->data(), ctx_->getStream() ) );
+                if ( sample_in_graph_ && token_ring_ )
+                    Compute::rocmCheck( mila_cdna4_advance_position_snapshot( pos_dev_->data(), token.data(), token_ring_, token_ring_size_, ctx_->getStream() ) );
+                else
+                    Compute::rocmCheck( mila_cdna4_advance_position( pos_dev_->data(), ctx_->getStream() ) );
             }
             catch ( ... ) { (void)hipStreamEndCapture( s, &g ); if ( g ) (void)hipGraphDestroy( g ); throw; }
             hipCheck( hipStreamEndCapture( s, &g ), "hipStreamEndCapture" );
@@ -225,18 +228,26 @@ namespace Mila::Dnn
             if ( e != hipSuccess ) { graph_exec_ = nullptr; destroyGraph(); hipCheck( e, "hipGraphInstantiate" ); }
             captured_token_ = token.data();
             captured_sample_in_graph_ = sample_in_graph_;
+            captured_ring_ = token_ring_;
         }
         /// capture on first use, and again whenever the captured graph no longer matches what a replay must do: another token
         /// buffer, or a different sampler setting (a graph captured without the sampler node never writes the next token)
         void ensureGraph( const TokenTensor& token, dim_t start_position )
         {
-            if ( !graph_exec_ || captured_token_ != token.data() || captured_sample_in_graph_ != sample_in_graph_ ) captureGraph( token, start_position );
+            if ( !graph_exec_ || captured_token_ != token.data() || captured_sample_in_graph_ != sample_in_graph_ || captured_ring_ != token_ring_ ) captureGraph( token, start_position );
         }
         bool graphCaptured() const noexcept { return graph_exec_ != nullptr; }
         bool graphSamples() const noexcept { return graph_exec_ != nullptr && captured_sample_in_graph_; }
         /// when set, every replay ends with the greedy sampler writing the next token into the token buffer the graph reads from:
         /// a closed autoregressive loop with no host round trip.  Takes effect at the next ensureGraph() / captureGraph().
         void setSampleInGraph( bool on ) { sample_in_graph_ = on; }
+        /// a caller-owned device ring (GemmaModel's decode-ahead loop): with the sampler in the graph, the step's last node also stores the token to be
+        /// consumed at position p into ring[p % size].  Takes effect at the next ensureGraph() / captureGraph(); nullptr = off
+        void setTokenRing( int32_t* ring, int size )
+        {
+            if ( ring && size <= 0 ) throw std::invalid_argument( "GemmaTransformer::setTokenRing: size must be positive" );
+            token_ring_ = ring; token_ring_size_ = ring ? size : 0;
+        }
         void setDevicePosition( dim_t position )
         {
             checkPosition( position, 1 );
@@ -324,6 +335,16 @@ namespace Mila::Dnn
             for ( auto& L : layers_ ) b += L.qkv_proj->getParameterBytes() + L.o_proj->getParameterBytes() + L.fc_gate_up->getParameterBytes() + L.fc_down->getParameterBytes();
             return b;
         }
+        /// GemmaTransformer::rewindKvCache (Gemma.ixx): every block drops positions >= `position`; false when any block refuses (a bounded ring
+        /// that has already evicted what the rewind would need) -- the caller then prefills from 0, which overwrites positionally
+        bool rewindKvCache( dim_t position, dim_t written )
+        {
+            if ( position < 0 || position > written ) return false;
+            bool ok = true;
+            for ( auto& L : layers_ ) ok = L.rewindKvCache( position, written ) && ok;
+            return ok;
+        }
+        void resetKVCache() { for ( auto& L : layers_ ) L.resetKVCache(); }
         LmHeadLinearType& lmHead() { return *lm_head_; }
         RmsNormType& finalNorm() { return *final_norm_; }
         TokenEmbeddingType& tokenEmbedding() { return *temb_; }
@@ -1160,5 +1181,8 @@ namespace Mila::Dnn
         hipGraphExec_t graph_exec_{ nullptr };
         const int32_t* captured_token_{ nullptr };      // what the captured graph was built for: ensureGraph() re-captures on a mismatch
         bool captured_sample_in_graph_{ false };
+        int32_t* token_ring_{ nullptr };
+        const int32_t* captured_ring_{ nullptr };
+        int token_ring_size_{ 0 };
     };
 }

@@ -182,6 +182,7 @@ namespace Mila::Dnn
         uint16_t* valueCache() noexcept { return operation_->valueCache(); }
         dim_t cacheCapacity() const noexcept { return operation_->cacheCapacity(); }
         dim_t cacheLength() const noexcept { return operation_->cacheLength(); }
+        void noteCacheLength( dim_t length ) { operation_->noteCacheLength( length ); }
         float scale() const noexcept { return operation_->scale(); }
         const GqaConfig& getConfig() const noexcept { return config_; }
         OpType& getOperation() { return *operation_; }
@@ -530,6 +531,8 @@ namespace Mila::Dnn
         virtual dim_t cacheCapacity() const noexcept = 0;
         virtual float attentionScale() const noexcept = 0;
         virtual void prefillFromCache( const TensorType& q, TensorType& out, int chunk, int position ) = 0;
+        /// drop everything from `position` on, given that `written` positions were appended (the fused schedules append behind the op's back); false = refused
+        virtual bool rewindKvCache( dim_t position, dim_t written ) = 0;
 
         /// `layer_scalar` ([1] F32); children load through their own components
         void loadParameter( const std::string& n, const void* blob, size_t bytes ) override
@@ -644,6 +647,7 @@ namespace Mila::Dnn
         dim_t cacheCapacity() const noexcept override { return attn->cacheCapacity(); }
         float attentionScale() const noexcept override { return attn->scale(); }
         void prefillFromCache( const TensorType& q, TensorType& out, int chunk, int position ) override { attn->prefillFromCache( q, out, chunk, position ); }
+        bool rewindKvCache( dim_t position, dim_t written ) override { attn->noteCacheLength( written ); return attn->rewindKvCache( position ); }
 
     protected:
         void onExecutionContextSet() override

@@ -526,6 +526,8 @@ namespace Mila::Dnn::Compute
             length_ = length;
         }
         dim_t cacheLength() const noexcept { return length_; }
+        /// a caller that appended through the fused entry points (which take the cache pointers directly) reports how far it wrote
+        void noteCacheLength( dim_t length ) { if ( length < 0 ) throw std::invalid_argument( "RocmGqaOp::noteCacheLength: negative length" ); length_ = length; }
         dim_t cacheCapacity() const noexcept { return capacity_; }
 
         /// q [B,chunk,NH*HS], k/v [B,chunk,NKV*HS] at absolute positions [position, position+chunk)

@@ -6,10 +6,11 @@
 #include <cstring>
 #include <memory>
 #include <random>
+#include <span>
 #include <string>
 #include <variant>
 
-#include "Mila/Gemma.h"
+#include "Mila/GemmaModel.h"
 
 using namespace Mila::Dnn;
 using Quant::Weight::NoWeightQuant;
@@ -696,6 +697,73 @@ HOST_API int mila_component_scenarios( int device )
             expect_throw( [&] { head8.installSharedWeight( q8.getWeightTensorShared(), q8.getWeightScalesTensorShared() ); }, false, "installSharedWeight after build" );
         }
         ctx->synchronize();
+    } );
+}
+
+// ---- L6: GemmaModel (Models/GemmaModel.ixx): fromPretrained / generate -------------------------------------------------------------
+using RocmGemmaModel = GemmaModel<DeviceType::Rocm, TensorDataType::BF16>;
+
+static GemmaModelConfig model_config_of( int policy, int64_t context, int64_t chunk, int bounded )
+{
+    if ( policy < 0 || policy > 2 ) throw std::invalid_argument( "unknown weight policy" );
+    GemmaModelConfig mc;
+    mc.withContextLength( context ).withWeightQuantization( policy == 0 ? WeightQuantization::None : ( policy == 1 ? WeightQuantization::FP8 : WeightQuantization::FP4 ) );
+    mc.withPrefillChunk( chunk ).withBoundedLocalKv( bounded != 0 );
+    return mc;
+}
+
+/// GemmaModel::fromPretrained( path, GemmaModelConfig( context ).withWeightQuantization( policy ) ): geometry from the artifact's metadata
+HOST_API void* mila_gemma_model_from_pretrained( const char* path, int policy, int64_t context, int64_t prefill_chunk, int bounded_local_kv, int device )
+{
+    RocmGemmaModel* m = nullptr;
+    int rc = guarded( [&] { m = RocmGemmaModel::fromPretrained( path, model_config_of( policy, context, prefill_chunk, bounded_local_kv ), Compute::Device::Rocm( device ) ).release(); } );
+    return rc == 0 ? m : nullptr;
+}
+
+/// the same model over synthetic parameters; profile as in mila_gemma_init_synthetic (NULL = unit profile)
+HOST_API void* mila_gemma_model_synthetic( int policy, const mila_gemma_config* c, int64_t context, int64_t prefill_chunk, uint64_t seed, const float* p, int device )
+{
+    RocmGemmaModel* m = nullptr;
+    int rc = guarded( [&]
+    {
+        GemmaConfig cfg;
+        int bounded = 0;
+        if ( c )
+        {
+            cfg.vocab_size = c->vocab_size; cfg.embedding_dim = c->embedding_dim; cfg.num_layers = c->num_layers; cfg.num_heads = c->num_heads;
+            cfg.num_kv_heads = c->num_kv_heads; cfg.head_dim = c->head_dim; cfg.hidden_dim = c->hidden_dim; cfg.global_head_dim = c->global_head_dim;
+            cfg.num_global_kv_heads = c->num_global_kv_heads; cfg.window = c->window; cfg.sliding_window_pattern = c->sliding_window_pattern;
+            cfg.global_rotary_dim = c->global_rotary_dim;
+            bounded = c->bounded_local_kv != 0;
+        }
+        GemmaTransformer<NoWeightQuant>::SyntheticProfile pr;
+        if ( p ) { pr.linear_gain = p[ 0 ]; pr.qk_norm_center = p[ 1 ]; pr.post_norm_center = p[ 2 ]; pr.layer_scalar = p[ 3 ]; pr.table_gain = p[ 4 ]; }
+        m = RocmGemmaModel::fromSynthetic( cfg, model_config_of( policy, context, prefill_chunk, bounded ), seed, pr, Compute::Device::Rocm( device ) ).release();
+    } );
+    return rc == 0 ? m : nullptr;
+}
+
+HOST_API void mila_gemma_model_destroy( void* h ) { delete static_cast<RocmGemmaModel*>( h ); }
+
+/// generate(): max_new < 0 = no budget (run to a stop token or the context bound); n_stop == 0 = the model's default stop set; the callback's tokens
+/// are appended to out_tokens (at most cap).  *out_status = GenerateStatus; *out_reused = prompt tokens served from the KV caches
+HOST_API int mila_gemma_model_generate( void* h, const int32_t* prompt, int64_t n_prompt, int max_new, const int32_t* stop_tokens, int n_stop, float temperature, int top_k,
+                                        float top_p, int64_t seed, int32_t* out_tokens, int64_t cap, int64_t* out_count, int32_t* out_status, int64_t* out_reused )
+{
+    return guarded( [&]
+    {
+        auto* m = static_cast<RocmGemmaModel*>( h );
+        if ( !m || !prompt || !out_count || !out_status ) throw std::invalid_argument( "gemma_model_generate: null argument" );
+        GenerateParams gp;
+        if ( max_new >= 0 ) gp.max_new_tokens = max_new;
+        gp.sampling.temperature = temperature; gp.sampling.top_k = top_k; gp.sampling.top_p = top_p;
+        for ( int i = 0; i < n_stop; ++i ) gp.stop_tokens.push_back( stop_tokens[ i ] );
+        if ( seed >= 0 ) m->seedSampler( static_cast<uint64_t>( seed ) );
+        int64_t n = 0;
+        const GenerateStatus st = m->generate( std::span<const int32_t>( prompt, static_cast<size_t>( n_prompt ) ), [&]( int32_t t ) { if ( out_tokens && n < cap ) out_tokens[ n ] = t; ++n; }, gp );
+        *out_count = n;
+        *out_status = static_cast<int32_t>( st );
+        if ( out_reused ) *out_reused = m->lastReusedPrefix();
     } );
 }
 
