@@ -450,12 +450,13 @@ MILA_API int mila_cdna4_fused_qkv_post_devpos(uint16_t* q_out, uint16_t* Kc, uin
                                               mila_stream_t stream);
 MILA_API int mila_cdna4_advance_position(int32_t* position_dev, mila_stream_t stream);
 /* The host side of the reference's decode-ahead loop (Models/GemmaModel.ixx:496-568: enqueueSampleNext / awaitSampledToken) learns each
- * sampled token while the NEXT step already runs.  advance_position_snapshot: p = *position_dev + 1; *position_dev = p;
- * ring[p % ring_size] = *token -- the last node of a captured step, so the token to be consumed at position p waits in a slot that is
- * not rewritten for ring_size steps.  snapshot_token: ring[slot] = *token (the eager sampler's counterpart).  Both are one-thread kernels:
- * nothing on the decode stream goes through a copy engine. */
-MILA_API int mila_cdna4_advance_position_snapshot(int32_t* position_dev, const int32_t* token, int32_t* ring, int ring_size, mila_stream_t stream);
-MILA_API int mila_cdna4_snapshot_token(int32_t* ring, int ring_size, int slot, const int32_t* token, mila_stream_t stream);
+ * sampled token while the NEXT step already runs.  `ring` is ring_size 64-bit words of host-visible memory (pinned + mapped), `seq_dev` a device
+ * counter: both kernels do  seq = ++*seq_dev;  ring[seq % ring_size] = seq << 32 | (uint32)*token  with ONE system-scope release store, so the host
+ * polls the slot until it carries the sequence number it expects -- no event, no copy, no stream wait on the decode path.
+ * advance_position_snapshot additionally does *position_dev += 1 (the last node of a captured step); snapshot_token is the eager sampler's counterpart. */
+MILA_API int mila_cdna4_advance_position_snapshot(int32_t* position_dev, const int32_t* token, unsigned long long* seq_dev, unsigned long long* ring, int ring_size,
+                                                  mila_stream_t stream);
+MILA_API int mila_cdna4_snapshot_token(const int32_t* token, unsigned long long* seq_dev, unsigned long long* ring, int ring_size, mila_stream_t stream);
 
 /* One-launch decode attention for one token (B == 1): q/k/v per-head RMSNorm + RoPE + KV append (the
  * work of fused_qkv_post) folded into the flash-decode kernel's prologue, where it overlaps the first

@@ -32,14 +32,20 @@ struct QkvPostParams
 };
 
 __global__ void advance_position_kernel(int32_t* pos) { *pos += 1; }
-// the decode-ahead loop's host side learns each sampled token from a ring slot no later step overwrites before it is read
-__global__ void advance_position_snapshot_kernel(int32_t* pos, const int32_t* token, int32_t* ring, int ring_size)
+// The decode-ahead loop's host side learns each sampled token from a ring in host-visible (pinned, mapped) memory: entry = sequence number << 32 | token,
+// stored with one system-scope release store; the host polls the slot until it carries the sequence number it expects.  No event, no copy, no stream wait.
+__device__ __forceinline__ void publish_token(unsigned long long* seq_dev, unsigned long long* ring, int ring_size, const int32_t* token)
 {
-    const int32_t p = *pos + 1;
-    *pos = p;
-    ring[p % ring_size] = *token;
+    const unsigned long long seq = *seq_dev + 1ull;
+    *seq_dev = seq;
+    __hip_atomic_store(ring + (seq % (unsigned long long)ring_size), (seq << 32) | (unsigned long long)(uint32_t)*token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ void snapshot_token_kernel(int32_t* ring, int slot, const int32_t* token) { ring[slot] = *token; }
+__global__ void advance_position_snapshot_kernel(int32_t* pos, const int32_t* token, unsigned long long* seq_dev, unsigned long long* ring, int ring_size)
+{
+    *pos += 1;
+    publish_token(seq_dev, ring, ring_size, token);
+}
+__global__ void snapshot_token_kernel(const int32_t* token, unsigned long long* seq_dev, unsigned long long* ring, int ring_size) { publish_token(seq_dev, ring, ring_size, token); }
 
 // sum over the hv = HS / 16 lanes of a lane group (hv a power of two <= 32): the first log2(hv) steps of wave_sum's butterfly
 __device__ __forceinline__ float group_tree_sum(float v, int hv)
@@ -192,19 +198,19 @@ int mila_cdna4_advance_position(int32_t* position_dev, mila_stream_t stream)
     MILA_LAUNCH_CHECK("advance_position");
 }
 
-int mila_cdna4_advance_position_snapshot(int32_t* position_dev, const int32_t* token, int32_t* ring, int ring_size, mila_stream_t stream)
+int mila_cdna4_advance_position_snapshot(int32_t* position_dev, const int32_t* token, unsigned long long* seq_dev, unsigned long long* ring, int ring_size, mila_stream_t stream)
 {
-    MILA_REQUIRE(position_dev != nullptr && token != nullptr && ring != nullptr, "advance_position_snapshot: null pointer");
+    MILA_REQUIRE(position_dev != nullptr && token != nullptr && seq_dev != nullptr && ring != nullptr, "advance_position_snapshot: null pointer");
     MILA_REQUIRE(ring_size > 0, "advance_position_snapshot: ring_size must be positive");
-    hipLaunchKernelGGL(advance_position_snapshot_kernel, dim3(1), dim3(1), 0, as_stream(stream), position_dev, token, ring, ring_size);
+    hipLaunchKernelGGL(advance_position_snapshot_kernel, dim3(1), dim3(1), 0, as_stream(stream), position_dev, token, seq_dev, ring, ring_size);
     MILA_LAUNCH_CHECK("advance_position_snapshot");
 }
 
-int mila_cdna4_snapshot_token(int32_t* ring, int ring_size, int slot, const int32_t* token, mila_stream_t stream)
+int mila_cdna4_snapshot_token(const int32_t* token, unsigned long long* seq_dev, unsigned long long* ring, int ring_size, mila_stream_t stream)
 {
-    MILA_REQUIRE(token != nullptr && ring != nullptr, "snapshot_token: null pointer");
-    MILA_REQUIRE(ring_size > 0 && slot >= 0 && slot < ring_size, "snapshot_token: slot %d outside the ring of %d", slot, ring_size);
-    hipLaunchKernelGGL(snapshot_token_kernel, dim3(1), dim3(1), 0, as_stream(stream), ring, slot, token);
+    MILA_REQUIRE(token != nullptr && seq_dev != nullptr && ring != nullptr, "snapshot_token: null pointer");
+    MILA_REQUIRE(ring_size > 0, "snapshot_token: ring_size must be positive");
+    hipLaunchKernelGGL(snapshot_token_kernel, dim3(1), dim3(1), 0, as_stream(stream), token, seq_dev, ring, ring_size);
     MILA_LAUNCH_CHECK("snapshot_token");
 }
 

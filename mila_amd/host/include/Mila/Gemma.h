@@ -217,7 +217,7 @@ namespace Mila::Dnn
                 enqueueFusedStep( token.data(), 0, pos_dev_->data() );
                 if ( sample_in_graph_ ) sampleGreedy( const_cast<TokenTensor&>( token ) );   // feeds the next replay
                 if ( sample_in_graph_ && token_ring_ )
-                    Compute::rocmCheck( mila_cdna4_advance_position_snapshot( pos_dev_->data(), token.data(), token_ring_, token_ring_size_, ctx_->getStream() ) );
+                    Compute::rocmCheck( mila_cdna4_advance_position_snapshot( pos_dev_->data(), token.data(), token_seq_, token_ring_, token_ring_size_, ctx_->getStream() ) );
                 else
                     Compute::rocmCheck( mila_cdna4_advance_position( pos_dev_->data(), ctx_->getStream() ) );
             }
@@ -241,12 +241,12 @@ namespace Mila::Dnn
         /// when set, every replay ends with the greedy sampler writing the next token into the token buffer the graph reads from:
         /// a closed autoregressive loop with no host round trip.  Takes effect at the next ensureGraph() / captureGraph().
         void setSampleInGraph( bool on ) { sample_in_graph_ = on; }
-        /// a caller-owned device ring (GemmaModel's decode-ahead loop): with the sampler in the graph, the step's last node also stores the token to be
-        /// consumed at position p into ring[p % size].  Takes effect at the next ensureGraph() / captureGraph(); nullptr = off
-        void setTokenRing( int32_t* ring, int size )
+        /// a caller-owned token ring in host-visible memory + its device sequence counter (GemmaModel's decode-ahead loop): with the sampler in the graph, the
+        /// step's last node publishes the sampled token there (mila_cdna4_advance_position_snapshot).  Takes effect at the next ensureGraph(); nullptr = off
+        void setTokenRing( unsigned long long* ring, int size, unsigned long long* seq_dev )
         {
-            if ( ring && size <= 0 ) throw std::invalid_argument( "GemmaTransformer::setTokenRing: size must be positive" );
-            token_ring_ = ring; token_ring_size_ = ring ? size : 0;
+            if ( ring && ( size <= 0 || !seq_dev ) ) throw std::invalid_argument( "GemmaTransformer::setTokenRing: a ring needs a positive size and a sequence counter" );
+            token_ring_ = ring; token_ring_size_ = ring ? size : 0; token_seq_ = ring ? seq_dev : nullptr;
         }
         void setDevicePosition( dim_t position )
         {
@@ -1181,8 +1181,9 @@ namespace Mila::Dnn
         hipGraphExec_t graph_exec_{ nullptr };
         const int32_t* captured_token_{ nullptr };      // what the captured graph was built for: ensureGraph() re-captures on a mismatch
         bool captured_sample_in_graph_{ false };
-        int32_t* token_ring_{ nullptr };
-        const int32_t* captured_ring_{ nullptr };
+        unsigned long long* token_ring_{ nullptr };
+        unsigned long long* token_seq_{ nullptr };
+        const unsigned long long* captured_ring_{ nullptr };
         int token_ring_size_{ 0 };
     };
 }

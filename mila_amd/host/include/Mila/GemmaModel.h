@@ -4,11 +4,14 @@
 //   the decode-ahead pipeline, the four GenerateStatus outcomes), :750-770 (EOS / end-of-turn stop set, final logit softcap at the sampler);
 //   Models/QuantizationDispatch.ixx:34-95; Core/LanguageModelConfig.ixx:88-230; Core/GenerateStatus.ixx; Components/Transformers/{GenerateParams,SamplingParams}.ixx.
 // MI355X form of the decode-ahead pipeline: a greedy request runs the captured hipGraph whose last node is the device sampler (the next
-// token never leaves the device); the host learns each token from a 4-byte snapshot copied on a SIDE stream behind an event, while the
-// next step is already running.  A stochastic request enqueues fused step + sampler per token (the uniform draw is a host scalar).
+// token never leaves the device) and publishes it into a host-visible ring (sequence number << 32 | token, one system-scope store); the host
+// polls its slot while the next step is already running: no event, no copy, no stream wait on the decode path.  A stochastic request enqueues fused step + sampler per token (the uniform draw is a host scalar).
 #pragma once
 
 #include <atomic>
+#include <chrono>
+#include <cstring>
+#include <thread>
 #include <optional>
 #include <random>
 #include <span>
@@ -110,9 +113,7 @@ namespace Mila::Dnn
         GemmaModel& operator=( const GemmaModel& ) = delete;
         ~GemmaModel()
         {
-            for ( auto& e : sampled_ev_ ) if ( e ) (void)hipEventDestroy( e );
-            if ( copy_stream_ ) (void)hipStreamDestroy( copy_stream_ );
-            if ( host_tokens_ ) (void)hipHostFree( host_tokens_ );
+            if ( ring_host_ ) (void)hipHostFree( ring_host_ );
         }
 
         /// every architectural parameter comes from the artifact's metadata; `model_config` carries the deployment decisions
@@ -199,22 +200,24 @@ namespace Mila::Dnn
             const auto dev = std::visit( []( auto& n ) { return n->context()->getDeviceId(); }, network_ );
             prompt_dev_ = std::make_unique<TokenTensor>( dev, shape_t{ 1, mc.getPrefillChunk() } );
             decode_token_device_ = std::make_unique<TokenTensor>( dev, shape_t{ 1 } );
-            snapshots_ = std::make_unique<TokenTensor>( dev, shape_t{ kSnapshots } );
-            hipCheck( hipStreamCreateWithFlags( &copy_stream_, hipStreamNonBlocking ), "hipStreamCreate" );
-            for ( auto& e : sampled_ev_ ) hipCheck( hipEventCreateWithFlags( &e, hipEventDisableTiming ), "hipEventCreate" );
-            hipCheck( hipHostMalloc( reinterpret_cast<void**>( &host_tokens_ ), kSnapshots * sizeof( int32_t ), hipHostMallocDefault ), "hipHostMalloc" );
+            seq_dev_ = std::make_unique<Tensor<TensorDataType::INT32, Compute::RocmDeviceMemoryResource>>( dev, shape_t{ 2 } );      // one 64-bit counter
+            auto* ctx = std::visit( []( auto& n ) { return n->context(); }, network_ );
+            Compute::rocmCheck( mila_cdna4_memset_zero( seq_dev_->rawData(), 8, ctx->getStream() ) );
+            hipCheck( hipHostMalloc( reinterpret_cast<void**>( &ring_host_ ), kSnapshots * sizeof( unsigned long long ), hipHostMallocMapped ), "hipHostMalloc" );
+            std::memset( ring_host_, 0, kSnapshots * sizeof( unsigned long long ) );
+            void* dptr = nullptr;
+            hipCheck( hipHostGetDevicePointer( &dptr, ring_host_, 0 ), "hipHostGetDevicePointer" );
+            ring_dev_ = static_cast<unsigned long long*>( dptr );
+            ctx->synchronize();
         }
 
         static bool isGreedy( const SamplingParams& sp ) noexcept { return sp.top_k == 1 || sp.temperature <= 0.0f; }
 
-        // The token to be consumed at position q waits in ring slot q % kSnapshots, written on the decode stream by a one-thread kernel (eager sampler) or
-        // by the captured step's last node (graph), with an event per slot.  At most two samples are ever in flight, so a slot is read long before its reuse.
-        template<typename TNet> void markSampled( TNet& net, dim_t q )
-        {
-            hipCheck( hipEventRecord( sampled_ev_[ static_cast<size_t>( q ) % kSnapshots ], reinterpret_cast<hipStream_t>( net.context()->getStream() ) ), "hipEventRecord" );
-        }
-        /// sample from the network's current logits into decode_token_device_ (ready for the decode at position q) and publish it for the host
-        template<typename TNet> void enqueueSampleNext( TNet& net, const SamplingParams& sp, dim_t q )
+        // Every sample -- the eager sampler's or the captured step's -- takes the next sequence number on the device and lands in ring slot seq % kSnapshots of
+        // host-visible memory.  At most two samples are ever in flight, so a slot is read long before its reuse; the tag makes a stale slot unmistakable.
+        unsigned long long* seqCounter() { return reinterpret_cast<unsigned long long*>( seq_dev_->rawData() ); }
+        /// sample from the network's current logits into decode_token_device_ (ready for the next decode) and publish it for the host
+        template<typename TNet> void enqueueSampleNext( TNet& net, const SamplingParams& sp )
         {
             if ( isGreedy( sp ) ) net.sampleGreedy( *decode_token_device_ );
             else
@@ -222,19 +225,25 @@ namespace Mila::Dnn
                 typename TNet::SamplingParams p; p.temperature = sp.temperature; p.top_k = sp.top_k; p.top_p = sp.top_p;
                 net.sampleStochastic( *decode_token_device_, p, std::uniform_real_distribution<float>( 0.0f, 1.0f )( rng_ ) );
             }
-            Compute::rocmCheck( mila_cdna4_snapshot_token( snapshots_->data(), static_cast<int>( kSnapshots ), static_cast<int>( static_cast<size_t>( q ) % kSnapshots ), decode_token_device_->data(),
-                                                           net.context()->getStream() ) );
-            markSampled( net, q );
+            Compute::rocmCheck( mila_cdna4_snapshot_token( decode_token_device_->data(), seqCounter(), ring_dev_, static_cast<int>( kSnapshots ), net.context()->getStream() ) );
+            ++published_;
         }
-        /// blocks until the token for position q is host-visible: the side stream waits for THAT sample's event only, so device work enqueued after it --
-        /// the ahead-decoded step -- keeps running
-        int32_t awaitSampledToken( dim_t q )
+        /// blocks until sample number `seq` (1-based over this model's lifetime) is host-visible; device work enqueued after it -- the ahead-decoded step --
+        /// keeps running.  Polls host memory only; gives up after ~20 s (a wedged device), so a caller never spins forever
+        int32_t awaitSampledToken( uint64_t seq )
         {
-            const size_t slot = static_cast<size_t>( q ) % kSnapshots;
-            hipCheck( hipStreamWaitEvent( copy_stream_, sampled_ev_[ slot ], 0 ), "hipStreamWaitEvent" );
-            hipCheck( hipMemcpyAsync( host_tokens_ + slot, snapshots_->data() + slot, 4, hipMemcpyDeviceToHost, copy_stream_ ), "token readback" );
-            hipCheck( hipStreamSynchronize( copy_stream_ ), "hipStreamSynchronize" );
-            return host_tokens_[ slot ];
+            volatile unsigned long long* slot = ring_host_ + ( seq % kSnapshots );
+            const auto t0 = std::chrono::steady_clock::now();
+            for ( uint64_t spins = 0;; ++spins )
+            {
+                const unsigned long long v = __atomic_load_n( slot, __ATOMIC_ACQUIRE );
+                if ( ( v >> 32 ) == ( seq & 0xffffffffull ) ) return static_cast<int32_t>( static_cast<uint32_t>( v ) );
+                if ( ( spins & 1023 ) == 1023 )
+                {
+                    if ( std::chrono::steady_clock::now() - t0 > std::chrono::seconds( 20 ) ) throw std::runtime_error( "GemmaModel::awaitSampledToken: the device did not publish a token within 20 s" );
+                    std::this_thread::yield();
+                }
+            }
         }
 
         template<typename TNet>
@@ -272,13 +281,13 @@ namespace Mila::Dnn
 
             const bool greedy = isGreedy( params.sampling );
             dim_t position = seq_len;
-            enqueueSampleNext( net, params.sampling, position );
+            enqueueSampleNext( net, params.sampling );
             int emitted = 0;
             const int max_new = params.max_new_tokens.value_or( static_cast<int>( contextLength() ) );
             if ( greedy && position < contextLength() )
             {
                 net.setSampleInGraph( true );
-                net.setTokenRing( snapshots_->data(), static_cast<int>( kSnapshots ) );
+                net.setTokenRing( ring_dev_, static_cast<int>( kSnapshots ), seqCounter() );
                 net.ensureGraph( *decode_token_device_, position );
                 net.setDevicePosition( position );
             }
@@ -289,18 +298,19 @@ namespace Mila::Dnn
                 const bool more_steps_allowed = emitted + 1 < max_new;
                 const bool cache_has_room = position < contextLength();
                 const bool ahead = more_steps_allowed && cache_has_room;
+                const uint64_t mine = published_;          // the sample this iteration reports
                 if ( ahead )
                 {
-                    if ( greedy ) { net.replayGraph(); markSampled( net, position + 1 ); }     // the captured step ends with sampler + snapshot: the token for position + 1
+                    if ( greedy ) { net.replayGraph(); ++published_; }      // the captured step ends with sampler + publish: the NEXT token
                     else net.decodeFused( *decode_token_device_, position );
                 }
-                const int32_t token = awaitSampledToken( position );
+                const int32_t token = awaitSampledToken( mine );
                 if ( ahead ) { kv_token_history_.push_back( token ); ++position; }     // the ahead-decode entered it into the caches, whatever it is
                 if ( stop_ids.contains( token ) ) { ctx->synchronize(); return GenerateStatus::Success; }
                 on_token( token );
                 ++emitted;
                 if ( !ahead ) return more_steps_allowed ? GenerateStatus::ContextOverflow : GenerateStatus::MaxNewTokensReached;
-                if ( !greedy ) enqueueSampleNext( net, params.sampling, position );
+                if ( !greedy ) enqueueSampleNext( net, params.sampling );
             }
         }
 
@@ -309,12 +319,12 @@ namespace Mila::Dnn
         GemmaConfig network_config_;
         GemmaModelConfig model_config_;
         Serialization::PretrainedMetadata source_metadata_;
-        std::unique_ptr<TokenTensor> prompt_dev_, decode_token_device_, snapshots_;
+        std::unique_ptr<TokenTensor> prompt_dev_, decode_token_device_, seq_dev_;
         std::vector<int32_t> kv_token_history_;
         dim_t last_reuse_{ 0 };
         std::mt19937_64 rng_{ 0x4d494c41ull };
-        hipStream_t copy_stream_{ nullptr };
-        hipEvent_t sampled_ev_[ 8 ]{};
-        int32_t* host_tokens_{ nullptr };
+        unsigned long long* ring_host_{ nullptr };      // pinned + mapped: the device writes, the host polls
+        unsigned long long* ring_dev_{ nullptr };       // the same memory through its device address
+        uint64_t published_{ 0 };                       // samples enqueued so far (their sequence numbers are 1 .. published_)
     };
 }
