@@ -284,9 +284,11 @@ namespace Mila::Dnn
             enqueueSampleNext( net, params.sampling );
             int emitted = 0;
             const int max_new = params.max_new_tokens.value_or( static_cast<int>( contextLength() ) );
-            if ( greedy && position < contextLength() )
+            if ( position < contextLength() )
             {
-                net.setSampleInGraph( true );
+                // greedy: the captured step ends with the sampler and the publish; stochastic: the captured step ends at the logits and the sampler (its uniform
+                // draw is a host scalar) follows eagerly.  Switching between the two kinds of request re-captures (a few ms, once per switch)
+                net.setSampleInGraph( greedy );
                 net.setTokenRing( ring_dev_, static_cast<int>( kSnapshots ), seqCounter() );
                 net.ensureGraph( *decode_token_device_, position );
                 net.setDevicePosition( position );
@@ -301,8 +303,8 @@ namespace Mila::Dnn
                 const uint64_t mine = published_;          // the sample this iteration reports
                 if ( ahead )
                 {
-                    if ( greedy ) { net.replayGraph(); ++published_; }      // the captured step ends with sampler + publish: the NEXT token
-                    else net.decodeFused( *decode_token_device_, position );
+                    net.replayGraph();
+                    if ( greedy ) ++published_;      // the captured step ends with sampler + publish: the NEXT token
                 }
                 const int32_t token = awaitSampledToken( mine );
                 if ( ahead ) { kv_token_history_.push_back( token ); ++position; }     // the ahead-decode entered it into the caches, whatever it is

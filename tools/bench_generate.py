@@ -31,6 +31,6 @@ for policy in (sys.argv[1:] or ["bf16", "fp8", "fp4"]):
     tb, toks, why = timed(NEW + 1)
     sa, _, _ = timed(NEW // 2 + 1, temperature=0.8, top_k=64, top_p=0.95, seed=1)
     sb, _, _ = timed(NEW + 1, temperature=0.8, top_k=64, top_p=0.95, seed=1)
-    print("%s: time to first token, %d-token prompt: %.1f ms (full prefill) / %.1f ms (prefix reuse %d); greedy generate (graph + device sampler): %.1f tok/s (%s); stochastic (fused step + sampler per token): %.1f tok/s" % (
+    print("%s: time to first token, %d-token prompt: %.1f ms (full prefill) / %.1f ms (prefix reuse %d); greedy generate (graph + device sampler): %.1f tok/s (%s); stochastic (captured step + eager sampler): %.1f tok/s" % (
         policy, PROMPT, t_prefill * 1e3, t_reuse * 1e3, reused, (NEW // 2) / (tb - ta), why, (NEW // 2) / (sb - sa)), flush=True)
     g.close()
