@@ -255,7 +255,7 @@ class GemmaModel:
         lib.mila_gemma_model_synthetic.argtypes = [C.c_int, C.POINTER(GemmaConfigC), C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_int]
         lib.mila_gemma_model_destroy.argtypes = [C.c_void_p]
         lib.mila_gemma_model_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_float, C.c_int64,
-                                                  C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+                                                  C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         return lib
 
     @staticmethod
@@ -286,9 +286,10 @@ class GemmaModel:
             cls._raise(lib, "GemmaModel.synthetic")
         return cls(h, device)
 
-    def generate(self, prompt, max_new_tokens=None, stop_tokens=(), temperature=1.0, top_k=1, top_p=1.0, seed=None):
+    def generate(self, prompt, max_new_tokens=None, stop_tokens=(), temperature=1.0, top_k=1, top_p=1.0, seed=None, cancel_after=None):
         """-> (tokens passed to on_token, finish reason as GenerateStatus's to_string, prompt tokens served from the KV caches).
-        top_k = 1 is greedy (SamplingParams); seed reseeds the host RNG that draws the sampler's uniform"""
+        top_k = 1 is greedy (SamplingParams); seed reseeds the host RNG that draws the sampler's uniform; cancel_after = n raises the client's stop request
+        from inside on_token once n tokens were delivered"""
         lib = load()
         pr = np.ascontiguousarray(prompt, dtype=np.int32)
         st = np.ascontiguousarray(list(stop_tokens), dtype=np.int32)
@@ -297,7 +298,7 @@ class GemmaModel:
         n, status, reused = C.c_int64(), C.c_int32(), C.c_int64()
         _check(lib.mila_gemma_model_generate(self.h, pr.ctypes.data, len(pr), -1 if max_new_tokens is None else int(max_new_tokens), st.ctypes.data if len(st) else None, len(st),
                                              float(temperature), int(top_k), float(top_p), -1 if seed is None else int(seed), out.ctypes.data, len(out), C.byref(n), C.byref(status),
-                                             C.byref(reused)))
+                                             C.byref(reused), -1 if cancel_after is None else int(cancel_after)))
         return out[:min(n.value, len(out))].tolist(), GENERATE_STATUS[status.value], reused.value
 
     def close(self):

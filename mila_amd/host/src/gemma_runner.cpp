@@ -746,9 +746,11 @@ HOST_API void* mila_gemma_model_synthetic( int policy, const mila_gemma_config* 
 HOST_API void mila_gemma_model_destroy( void* h ) { delete static_cast<RocmGemmaModel*>( h ); }
 
 /// generate(): max_new < 0 = no budget (run to a stop token or the context bound); n_stop == 0 = the model's default stop set; the callback's tokens
-/// are appended to out_tokens (at most cap).  *out_status = GenerateStatus; *out_reused = prompt tokens served from the KV caches
+/// are appended to out_tokens (at most cap).  *out_status = GenerateStatus; *out_reused = prompt tokens served from the KV caches; cancel_after >= 0: the
+/// client's stop request is raised from inside on_token once that many tokens were delivered (the std::stop_token of the reference's generate)
 HOST_API int mila_gemma_model_generate( void* h, const int32_t* prompt, int64_t n_prompt, int max_new, const int32_t* stop_tokens, int n_stop, float temperature, int top_k,
-                                        float top_p, int64_t seed, int32_t* out_tokens, int64_t cap, int64_t* out_count, int32_t* out_status, int64_t* out_reused )
+                                        float top_p, int64_t seed, int32_t* out_tokens, int64_t cap, int64_t* out_count, int32_t* out_status, int64_t* out_reused,
+                                        int64_t cancel_after )
 {
     return guarded( [&]
     {
@@ -760,7 +762,9 @@ HOST_API int mila_gemma_model_generate( void* h, const int32_t* prompt, int64_t 
         for ( int i = 0; i < n_stop; ++i ) gp.stop_tokens.push_back( stop_tokens[ i ] );
         if ( seed >= 0 ) m->seedSampler( static_cast<uint64_t>( seed ) );
         int64_t n = 0;
-        const GenerateStatus st = m->generate( std::span<const int32_t>( prompt, static_cast<size_t>( n_prompt ) ), [&]( int32_t t ) { if ( out_tokens && n < cap ) out_tokens[ n ] = t; ++n; }, gp );
+        std::atomic<bool> stop{ cancel_after == 0 };
+        const GenerateStatus st = m->generate( std::span<const int32_t>( prompt, static_cast<size_t>( n_prompt ) ),
+                                               [&]( int32_t t ) { if ( out_tokens && n < cap ) out_tokens[ n ] = t; ++n; if ( cancel_after >= 0 && n >= cancel_after ) stop.store( true ); }, gp, &stop );
         *out_count = n;
         *out_status = static_cast<int32_t>( st );
         if ( out_reused ) *out_reused = m->lastReusedPrefix();

@@ -61,6 +61,15 @@ def test_stop_token_context_bound_and_budget_of_one():
         assert why == "context_limit" and got == want[:32 - len(PROMPT) + 1]
         got, why, _ = g.generate(PROMPT, max_new_tokens=1, stop_tokens=[unused])
         assert got == want[:1] and why == "length"
+        got, why, _ = g.generate(PROMPT, stop_tokens=[unused], cancel_after=3)      # the client's stop request between two steps: nothing runs past the return
+        assert why == "cancelled" and got == want[:3]
+        got, why, _ = g.generate(PROMPT, max_new_tokens=5, stop_tokens=[unused])     # and the model is usable afterwards (one ahead-decoded token was drained)
+        assert got == want[:5] and why == "length"
+        full = (PROMPT * 3)[:32]                                                       # a prompt that fills the context: one token, no decode step
+        got, why, _ = g.generate(full, stop_tokens=[unused])
+        assert len(got) == 1 and why == "context_limit"
+        with pytest.raises(ValueError, match="empty prompt"):
+            g.generate([], max_new_tokens=1)
         with pytest.raises(ValueError, match="exceeds deployment context length"):
             g.generate(list(range(40)), max_new_tokens=1)
         with pytest.raises(ValueError, match="outside the vocabulary"):
