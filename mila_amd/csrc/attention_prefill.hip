@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "internal.h"
 
 namespace mila {
 
@@ -280,23 +281,36 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
 // Single-staging form (one register set, next tile's loads in flight during the current tile's math): HS = 512, where the
 // accumulators (128 VGPRs) and Q fragments (64) leave no room for a second staging set.
 // HB = heads per workgroup (1, 2 or 4); QB = 4 / HB query sub-tiles of 16 rows
-template <int HS, int HB>
-__global__ __launch_bounds__(256) void flash_prefill_kernel_s1(const FlashParams p)
+// DS = 2: a head's output dimensions are SPLIT over two waves (each computes the whole S^T and softmax of its 16 rows -- identical in both -- and half of
+// O^T): 64 accumulator registers instead of 128, so the kernel fits 256 registers, two workgroups share a CU (two waves per SIMD cover each other's LDS
+// latency) and the compiler has registers left to batch its fragment reads.  QK^T is computed twice per head (1.5x the MFMA work at 8 % utilisation);
+// every output element is produced by the same instruction sequence as with DS = 1, so the results are bit-identical.
+// NW = 8 (HB = 4, DS = 2): ONE 8-wave workgroup per CU -- four heads x two d-halves share every K / V tile (half the L2 -> LDS traffic per FLOP of the 4-wave
+// form), the tiles are double-buffered in 128 KB of LDS, so tile t + 1 is requested at the top of tile t and lands under a whole tile of arithmetic, and
+// one barrier per tile suffices (it says both "tile t is here" and "everybody is done with tile t - 1").
+template <int HS, int HB, int DS, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void flash_prefill_kernel_s1(const FlashParams p)
 {
-    constexpr int QB = 4 / HB;
+    static_assert(DS == 1 || DS == 2, "d-split");
+    static_assert(NW == 4 || (NW == 8 && HB == 4 && DS == 2), "workgroup shapes");
+    // double-buffered tiles, one barrier per tile: the 8-wave form, and every HS <= 256 form (two [K | V] pairs are 64 KB there: two workgroups still share a CU)
+    constexpr bool DB = (NW == 8) || (HS <= 256);
+    constexpr int QB = NW / (HB * DS);
+    static_assert(QB >= 1, "at most NW (head, d-half) pairs per workgroup");
     constexpr int QROWS = 16 * QB;
     constexpr int KSTEPS = HS / 32;          // MFMA k-steps of the QK^T product
-    constexpr int DT = HS / 16;              // 16-wide d tiles of O^T
+    constexpr int DT = HS / 16 / DS;         // 16-wide d tiles of O^T this wave owns
     constexpr int ROWB = HS * 2;
     constexpr int TILE_BYTES = kKeysPerTile * ROWB;
-    constexpr int CH_PER_THREAD = (kKeysPerTile * (ROWB / 16)) / 256;   // 16-byte chunks each thread stages per tile
-    static_assert(CH_PER_THREAD >= 1, "tile too small");
+    constexpr int RPI = 1024 / ROWB;                     // K / V rows one LDS-DMA wave-instruction (64 lanes x 16 bytes) covers
+    static_assert(RPI == 1 || RPI == 2, "HS = 512 or 256");
+    constexpr int CPR = ROWB / 16;                       // 16-byte chunks per row
+    constexpr int DMAS = kKeysPerTile / NW / RPI;        // LDS-DMA instructions each wave issues per tile and matrix
+    static_assert(DMAS >= 1, "tile too small for the wave count");
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [K tile | V tile]
-    unsigned char* ldsK = smem;
-    unsigned char* ldsV = smem + TILE_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [K tile | V tile] (NW = 8: two of them)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
     const int GS = p.NH / p.NKV;
     // Causal work per query tile grows with its index.  Two workgroups are resident per CU and the hardware deals workgroup ids
@@ -304,13 +318,15 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel_s1(const FlashParams
     // the (tile, head-block) list, odd rounds from the light end -- every CU gets a heavy and a light workgroup instead of two heavy ones.
     const int n_items = p.n_qtiles * p.n_hblk;
     const int bid = blockIdx.x, round = bid / kNumCU, k = (round >> 1) * kNumCU + bid % kNumCU;
-    const int item = (round & 1) ? n_items - 1 - k : k;         // index in the heavy -> light order
+    // (NW = 8: one workgroup per CU at a time; the dispatcher hands the next id to the CU that frees up first, so plain heavy -> light order balances)
+    const int item = (NW == 8) ? bid : ((round & 1) ? n_items - 1 - k : k);         // index in the heavy -> light order
     const int qt = p.n_qtiles - 1 - item / p.n_hblk;
     const int hblk = item % p.n_hblk, b = blockIdx.z;
     const int h = hblk * HB + (wave % HB);
+    const int dsel = (wave / HB) % DS;                         // which share of the head's output dimensions this wave accumulates
     const int kvh = (hblk * HB) / GS;                          // all HB heads share one KV head (HB | GS)
     const int q0 = qt * QROWS;                                 // first query row (within the chunk) of this workgroup
-    const int wq0 = q0 + 16 * (wave / HB);                     // this wave's first row
+    const int wq0 = q0 + 16 * (wave / (HB * DS));              // this wave's first row
     const int my_row = wq0 + l15;                              // the query row on this lane
     const bool row_valid = my_row < p.Tq;
     const int my_pos = p.pos_offset + (row_valid ? my_row : p.Tq - 1);
@@ -342,46 +358,52 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel_s1(const FlashParams
     const uint16_t* kbase = p.K + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride;
     const uint16_t* vbase = p.V + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride;
 
-    u32x4 kreg[CH_PER_THREAD], vreg[CH_PER_THREAD];
-    auto stage_load = [&](int kt) {
+    // K / V tiles go global -> LDS by LDS-DMA, no staging registers: wave w requests rows w, w + 4, ... of a tile, one row per instruction; a lane's LDS slot
+    // is linear (M0 base + 16 lane), so the swizzle of k_off / v_off -- an involution on the chunk index -- is applied to the SOURCE chunk it fetches.
+    // Every tile requests all its rows, so the request counts the waits rely on are constant: a row beyond the last key any row of this workgroup may see
+    // re-reads that last key (a finite in-band row; the mask works on key positions, not contents).
+    auto stage_k = [&](int kt, unsigned char* ldsK) {
 #pragma unroll
-        for (int i = 0; i < CH_PER_THREAD; ++i)
+        for (int i = 0; i < DMAS; ++i)
         {
-            const int c = tid + 256 * i;
-            const int row = c / (ROWB / 16), chunk = c % (ROWB / 16);
-            const int pos = kt + row;
-            if (pos <= pos_last)     // rows beyond the last key any row of this workgroup may see stay zero
-            {
-                const size_t off = (size_t)(pos % p.capacity) * p.kv_r_stride + chunk * 8;
-                kreg[i] = ld16(kbase + off);
-                vreg[i] = ld16(vbase + off);
-            }
-            else
-            {
-                kreg[i] = u32x4{0u, 0u, 0u, 0u};
-                vreg[i] = u32x4{0u, 0u, 0u, 0u};
-            }
+            const int row0 = RPI * (NW * i + wave);                       // the instruction's first row: RPI consecutive rows = 1 KiB of LDS
+            const int row = row0 + lane / CPR, slot = lane % CPR, pos = min(kt + row, pos_last);
+            const uint16_t* src = kbase + (size_t)(pos % p.capacity) * p.kv_r_stride + (size_t)((k_off<HS>(row, slot) - row * ROWB) >> 4) * 8;
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(ldsK + row0 * ROWB), 16, 0, 0);
         }
     };
-    auto stage_store = [&]() {
+    auto stage_v = [&](int kt, unsigned char* ldsV) {
 #pragma unroll
-        for (int i = 0; i < CH_PER_THREAD; ++i)
+        for (int i = 0; i < DMAS; ++i)
         {
-            const int c = tid + 256 * i;
-            const int row = c / (ROWB / 16), chunk = c % (ROWB / 16);
-            *reinterpret_cast<u32x4*>(ldsK + k_off<HS>(row, chunk)) = kreg[i];
-            *reinterpret_cast<u32x4*>(ldsV + v_off<HS>(row, chunk)) = vreg[i];
+            const int row0 = RPI * (NW * i + wave);
+            const int row = row0 + lane / CPR, slot = lane % CPR, pos = min(kt + row, pos_last);
+            const uint16_t* src = vbase + (size_t)(pos % p.capacity) * p.kv_r_stride + (size_t)((v_off<HS>(row, slot) - row * ROWB) >> 4) * 8;
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(ldsV + row0 * ROWB), 16, 0, 0);
         }
     };
-
-    stage_load(kt0);
+    // Two barriers per tile.  B1: K(t) has landed everywhere and every wave is done with V(t - 1) -> request V(t), multiply K(t) Q^T under it.
+    // B2: V(t) has landed everywhere and every wave is done with K(t) -> request K(t + 1), softmax and the PV product under it.
+    // Double-buffered forms: one barrier per tile, tile t + 1 requested into the other buffer right behind it.
+    stage_k(kt0, smem);
+    if constexpr (DB) stage_v(kt0, smem + TILE_BYTES);
     for (int t = 0; t < ntiles; ++t)
     {
         const int kt = kt0 + t * kKeysPerTile;
-        __syncthreads();                     // previous tile fully consumed
-        stage_store();
+        unsigned char* ldsK = smem + (DB ? (t & 1) * 2 * TILE_BYTES : 0);
+        unsigned char* ldsV = ldsK + TILE_BYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows of tile t (NW = 4: its K rows; nothing else is in flight here)
         __syncthreads();
-        if (t + 1 < ntiles) stage_load(kt + kKeysPerTile);   // in flight during this tile's math
+        if constexpr (DB)
+        {
+            if (t + 1 < ntiles)
+            {
+                unsigned char* nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+                stage_k(kt + kKeysPerTile, nxt);
+                stage_v(kt + kKeysPerTile, nxt + TILE_BYTES);
+            }
+        }
+        else stage_v(kt, ldsV);
 
         // ---- S^T = K Q^T : two 16-key groups ----
         f32x4 s0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0;
@@ -393,6 +415,12 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel_s1(const FlashParams
             const s16x8 kb = *reinterpret_cast<const s16x8*>(ldsK + k_off<HS>(16 + l15, 4 * s + g));
             s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka), __builtin_bit_cast(bf16x8, qf[s]), s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb), __builtin_bit_cast(bf16x8, qf[s]), s1, 0, 0, 0);
+        }
+        if constexpr (!DB)
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's V rows of tile t
+            __syncthreads();                                     // every wave is done with K(t), and V(t) is complete
+            if (t + 1 < ntiles) stage_k(kt + kKeysPerTile, ldsK);      // in flight during the softmax and the PV product
         }
         // lane holds keys kt + 4 g + r (s0) and kt + 16 + 4 g + r (s1) of query row l15
         float sv[8];
@@ -434,7 +462,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel_s1(const FlashParams
             // A operand: V^T[dim 16 d + l15][keys as above] via the transposing read:
             // lane 4 q + pp of a 16-lane group supplies row q, columns 4 pp .. 4 pp + 3 of the block
             const int q4 = l15 >> 2, pp = l15 & 3;
-            const int col = 16 * d + 4 * pp;                   // first of 4 columns (8 bytes)
+            const int col = 16 * (dsel * DT + d) + 4 * pp;     // first of 4 columns (8 bytes)
             const int r_lo = 4 * g + q4, r_hi = 16 + 4 * g + q4;
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (__attribute__((address_space(3))) s16x4*)(ldsV + v_off<HS>(r_lo, col >> 3) + ((col & 7) << 1)));
@@ -455,13 +483,17 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel_s1(const FlashParams
     if (row_valid)
     {
         const float inv = (l_run > 0.0f) ? 1.0f / l_run : 0.0f;
-        uint16_t* y = p.Y + (((size_t)b * p.Tq + my_row) * p.NH + h) * HS + 4 * g;
+        uint16_t* y = p.Y + (((size_t)b * p.Tq + my_row) * p.NH + h) * HS + 16 * dsel * DT + 4 * g;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
             *reinterpret_cast<u32x2*>(y + 16 * d) = u32x2{pack_bf16x2(o[d][0] * inv, o[d][1] * inv), pack_bf16x2(o[d][2] * inv, o[d][3] * inv)};
     }
 }
 
+static int g_tune_flash_form = 8;      // tuning hook (mila_cdna4_tune_flash_dsplit): 8 = the LDS-DMA forms (default: 8-wave workgroups at HS = 512, double-buffered
+                                       // 4-wave ones at HS = 256), 2 = HS = 512 as 4-wave d-split workgroups, 1 = the register-staged kernels
+
+// the register-staged kernels (HS <= 256; every head size under form 1)
 template <int HS, int HB>
 static int launch_flash(const FlashParams& p, int B, hipStream_t s)
 {
@@ -471,8 +503,29 @@ static int launch_flash(const FlashParams& p, int B, hipStream_t s)
     q.n_qtiles = (p.Tq + QROWS - 1) / QROWS;
     q.n_hblk = p.NH / HB;
     const dim3 grid(q.n_qtiles * q.n_hblk, 1, B);
-    if constexpr (HS >= 512) hipLaunchKernelGGL((flash_prefill_kernel_s1<HS, HB>), grid, dim3(256), lds, s, q);
+    if constexpr (HS >= 512) hipLaunchKernelGGL((flash_prefill_kernel_s1<HS, HB, 1, 4>), grid, dim3(256), lds, s, q);
     else hipLaunchKernelGGL((flash_prefill_kernel<HS, HB>), grid, dim3(256), lds, s, q);
+    MILA_LAUNCH_CHECK("flash_prefill");
+}
+
+// the LDS-DMA kernel (HS = 256 or 512): HB heads x DS d-shares x (NW / (HB DS)) row blocks per workgroup of NW waves
+template <int HS, int HB, int DS, int NW>
+static int launch_flash_dma(const FlashParams& p, int B, hipStream_t s)
+{
+    constexpr int QROWS = 16 * (NW / (HB * DS));
+    constexpr bool DB = (NW == 8) || (HS <= 256);
+    const size_t lds = (size_t)(DB ? 4 : 2) * kKeysPerTile * HS * 2;
+    FlashParams q = p;
+    q.n_qtiles = (p.Tq + QROWS - 1) / QROWS;
+    q.n_hblk = p.NH / HB;
+    const dim3 grid(q.n_qtiles * q.n_hblk, 1, B);
+    if (lds > 65536)
+    {
+        // more than 64 KB of dynamic LDS must be allowed once per process (never inside a stream capture: the first prefill of a model is eager)
+        static const hipError_t allowed = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_prefill_kernel_s1<HS, HB, DS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (allowed != hipSuccess) return check_hip(allowed, "flash_prefill: hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    hipLaunchKernelGGL((flash_prefill_kernel_s1<HS, HB, DS, NW>), grid, dim3(64 * NW), lds, s, q);
     MILA_LAUNCH_CHECK("flash_prefill");
 }
 
@@ -480,6 +533,20 @@ template <int HS>
 static int dispatch_hb(const FlashParams& p, int B, hipStream_t s)
 {
     const int GS = p.NH / p.NKV;
+    if constexpr (HS == 512)
+    {
+        if (g_tune_flash_form == 8 && GS % 4 == 0) return launch_flash_dma<HS, 4, 2, 8>(p, B, s);      // four heads x two d-halves, double-buffered tiles
+        if (g_tune_flash_form >= 2) return GS % 2 == 0 ? launch_flash_dma<HS, 2, 2, 4>(p, B, s) : launch_flash_dma<HS, 1, 2, 4>(p, B, s);
+    }
+    if constexpr (HS == 256)
+    {
+        if (g_tune_flash_form == 8)
+        {
+            if (GS % 4 == 0) return launch_flash_dma<HS, 4, 1, 4>(p, B, s);
+            if (GS % 2 == 0) return launch_flash_dma<HS, 2, 1, 4>(p, B, s);
+            return launch_flash_dma<HS, 1, 1, 4>(p, B, s);
+        }
+    }
     if (GS % 4 == 0) return launch_flash<HS, 4>(p, B, s);
     if (GS % 2 == 0) return launch_flash<HS, 2>(p, B, s);
     return launch_flash<HS, 1>(p, B, s);
@@ -526,6 +593,14 @@ int mila_cdna4_attn_prefill_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t*
     p.Tq = chunk; p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.pos_offset = pos_offset; p.window = window;
     p.scale = scale;
     return flash_dispatch(HS, p, B, as_stream(stream));
+}
+
+int mila_cdna4_tune_flash_dsplit(int ds)
+{
+    if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
+    MILA_REQUIRE(ds == 1 || ds == 2 || ds == 8, "tune_flash_dsplit: 1, 2 or 8");
+    g_tune_flash_form = ds;
+    return MILA_OK;
 }
 
 int mila_cdna4_mha_bf16(uint16_t* Y, const uint16_t* QKV, int B, int T, int C, int NH, mila_stream_t stream)

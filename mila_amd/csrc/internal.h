@@ -17,6 +17,8 @@ MILA_API int mila_cdna4_tune_gemm(int force_128_tile);
 MILA_API int mila_cdna4_tune_gemm_schedule(int pingpong);
 /* positions of the live band one flash-decode split covers (default 64; 0 restores it): fewer, longer splits = smaller partial sets */
 MILA_API int mila_cdna4_tune_attn_split(int positions_per_split);
+/* 2 (default): the HS = 512 flash-prefill kernel splits a head's output dimensions over two waves; 1: one wave per head */
+MILA_API int mila_cdna4_tune_flash_dsplit(int ds);
 /* engine diagnostics: the next decode_engine launches write wall-clock stamps (100 MHz) of the first 8 workgroups' 8 waves, 16 slots each */
 MILA_API int mila_cdna4_decode_engine_debug(unsigned long long* buf);
 /* decode all 256 byte values with the hardware converts used by the kernels:

@@ -1,10 +1,13 @@
 """Time the flash prefill kernel on the Gemma-4 12B attention shapes (T = 2048).  MILA_FLASH_DBG skips parts of the kernel
 (1 softmax, 2 PV, 4 QK, 8 staging; results are then meaningless) to see where the time goes."""
 import json, os, sys
+os.environ.setdefault("MILA_CDNA4_TUNING", "1")
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mila_amd import capi
 T = 2048
+if os.environ.get("MILA_FLASH_DSPLIT"):
+    capi.check(capi.load().mila_cdna4_tune_flash_dsplit(int(os.environ["MILA_FLASH_DSPLIT"])))      # 1: one wave per head in the HS = 512 kernel; 2 (default): d-split
 for name, NH, NKV, HS, window in (("local", 16, 8, 256, 1024), ("global", 16, 1, 512, 0)):
     q = (torch.randn((T, NH * HS), device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)
     K = (torch.randn((1, NKV, T, HS), device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)
