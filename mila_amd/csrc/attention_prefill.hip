@@ -535,12 +535,13 @@ static int dispatch_hb(const FlashParams& p, int B, hipStream_t s)
     const int GS = p.NH / p.NKV;
     if constexpr (HS == 512)
     {
-        if (g_tune_flash_form == 8 && GS % 4 == 0) return launch_flash_dma<HS, 4, 2, 8>(p, B, s);      // four heads x two d-halves, double-buffered tiles
+        if (g_tune_flash_form >= 8 && GS % 4 == 0) return launch_flash_dma<HS, 4, 2, 8>(p, B, s);      // four heads x two d-halves, double-buffered tiles
         if (g_tune_flash_form >= 2) return GS % 2 == 0 ? launch_flash_dma<HS, 2, 2, 4>(p, B, s) : launch_flash_dma<HS, 1, 2, 4>(p, B, s);
     }
     if constexpr (HS == 256)
     {
-        if (g_tune_flash_form == 8)
+        // (the d-split does not pay here: 8-wave workgroups of 2 heads x 2 row blocks x 2 d-halves, four waves per SIMD, measured 92.7 us against 81.6)
+        if (g_tune_flash_form >= 8)
         {
             if (GS % 4 == 0) return launch_flash_dma<HS, 4, 1, 4>(p, B, s);
             if (GS % 2 == 0) return launch_flash_dma<HS, 2, 1, 4>(p, B, s);
