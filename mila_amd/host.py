@@ -127,6 +127,13 @@ class Gemma:
         configuration fits) or one launch per Linear; the two give identical bits.  Before the first graph decode."""
         _check(load().mila_gemma_set_chain(self.h, int(bool(on))))
 
+    def set_prefill_overlap(self, on):
+        """prefill: the chunk's two halves as two kernel sequences on two streams (the second half's attention waits for the first half's K / V rows);
+        bf16 and resident-fp8 policies, T % 512 == 0.  Identical bits."""
+        lib = load()
+        lib.mila_gemma_set_prefill_overlap.argtypes = [C.c_void_p, C.c_int]
+        _check(lib.mila_gemma_set_prefill_overlap(self.h, int(bool(on))))
+
     def set_combine_in_oproj(self, on):
         """fused / graph decode: fold the flash-decode combine into o_proj's prologue on layers with a small partial set
         (opt-in: measured slower than the combine launch it removes) or keep the combine launch; identical bits"""

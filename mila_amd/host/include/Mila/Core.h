@@ -318,6 +318,9 @@ namespace Mila::Dnn
             mila_stream_t getStream() const noexcept { return stream_; }
             /// adopt an externally owned stream (e.g. the host framework's current stream)
             void useExternalStream( mila_stream_t s ) { if ( stream_ && own_stream_ ) mila_cdna4_stream_destroy( stream_ ); stream_ = s; own_stream_ = false; }
+            /// every op enqueues on getStream(): a caller that runs part of its work on a second stream swaps it in for the duration of those enqueues
+            /// (RAII: StreamScope); ownership of the context's own stream is untouched
+            mila_stream_t swapStream( mila_stream_t s ) noexcept { mila_stream_t old = stream_; stream_ = s; return old; }
 
             void* getScratch( size_t bytes )
             {

@@ -128,6 +128,8 @@ namespace Mila::Dnn
             if ( fork_ev_ ) (void)hipEventDestroy( fork_ev_ );
             if ( join_ev_ ) (void)hipEventDestroy( join_ev_ );
             if ( side_ ) (void)hipStreamDestroy( side_ );
+            for ( auto& e : ov_ev_ ) if ( e ) (void)hipEventDestroy( e );
+            if ( ov_stream_ ) (void)hipStreamDestroy( ov_stream_ );
         }
 
         Compute::RocmExecutionContext* context() const noexcept { return ctx_; }
@@ -301,6 +303,7 @@ namespace Mila::Dnn
             TensorType* x = pf_x_[ 0 ].get();
             int flip = 0;
             const bool fused = fused_prefill_ && fusedPrefillApplicable();
+            if ( fused && prefill_overlap_ && overlapApplicable( T ) ) return prefillOverlapped( tokens, T, position_offset );
             for ( size_t i = 0; i < layers_.size(); ++i )
             {
                 if ( !fused ) { x = &layers_[ i ].prefill( x->view( shape_t{ 1, T, D } ), position_offset ); continue; }   // GemmaBlock::prefill, one component per step
@@ -589,7 +592,100 @@ namespace Mila::Dnn
                                                                  nextL ? nextL->input_norm->getWeight()->data() : nullptr, T, (int)D, L.layer_scalar, cfg_.rms_norm_eps, st ) );
         }
 
+        // ---- two halves of a chunk on two streams -------------------------------------------------------------------------------------------
+        // A GEMM launch leaves CUs idle in its last round of tiles (fc_gate_up: 960 tiles on 256 CUs) and at every kernel boundary.  Rows are independent
+        // but for attention, so the chunk's two halves run as two kernel sequences on two streams -- each on its own rows of every buffer -- and the second
+        // half's attention of a layer waits (an event) for the first half's K / V rows of that layer.  The idle CUs of one stream's tails take the other
+        // stream's workgroups.  Same kernels on the same rows: bit-identical to the one-stream form.
+        bool overlapApplicable( dim_t T ) const
+        {
+            if constexpr ( kFmt == 2 ) return false;       // the W4A8 path quantizes activations into per-op scratch sized for one call at a time
+            if constexpr ( kFmt == 1 ) { for ( auto& L : layers_ ) if ( !L.fc_down->getOperation().residentBf16() ) return false; }
+            return T >= 1024 && T % 512 == 0;
+        }
+        void halfBlock( Layer& L, int h, bool first_layer, Layer* nextL, int H, int position_offset, int flip, hipEvent_t kv_ready, bool wait_kv )
+        {
+            const bool g = L.global;
+            const dim_t NH = cfg_.num_heads, NKV = cfg_.numKvHeads( g ), HD = cfg_.headDim( g ), D = cfg_.embedding_dim, F = cfg_.hidden_dim;
+            const size_t r0 = static_cast<size_t>( h ) * static_cast<size_t>( H );
+            mila_stream_t st = ctx_->getStream();
+            auto rows = [&]( TensorType& t, dim_t width ) { return t.slice( r0 * static_cast<size_t>( width ), shape_t{ 1, H, width } ); };
+            auto x3 = rows( *pf_x_[ flip ], D );
+            auto out = rows( *pf_x_[ 1 - flip ], D );
+            auto normed = rows( *pf_norm_, D );
+            (void)first_layer;
+            auto qkv = rows( *ov_qkv_, cfg_.packedQkvWidth( g ) );
+            L.qkv_proj->getOperation().forward( normed, qkv );
+            auto q = rows( *q_, NH * HD );
+            const uint16_t* qp = qkv.data();
+            const uint16_t* kp = qp + (size_t)( NH * HD );
+            const uint16_t* vp = g ? kp : kp + (size_t)( NKV * HD );
+            Compute::rocmCheck( mila_cdna4_fused_qkv_post_prefill( q.data(), L.keyCache(), L.valueCache(), qp, kp, vp, (int64_t)cfg_.packedQkvWidth( g ),
+                                                                   L.q_norm->getWeight()->data(), L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(),
+                                                                   L.rope->cosCache(), L.rope->sinCache(), H, (int)NH, (int)NKV, (int)HD, position_offset + h * H,
+                                                                   (int)L.cacheCapacity(), cfg_.rms_norm_eps, st ) );
+            if ( h == 0 ) hipCheck( hipEventRecord( kv_ready, reinterpret_cast<hipStream_t>( st ) ), "hipEventRecord" );
+            else if ( wait_kv ) hipCheck( hipStreamWaitEvent( reinterpret_cast<hipStream_t>( st ), kv_ready, 0 ), "hipStreamWaitEvent" );
+            auto attn = rows( *attn_out_, NH * HD );
+            L.prefillFromCache( q, attn, H, position_offset + h * H );
+            auto o = rows( *ov_o_, D );
+            L.o_proj->getOperation().forward( attn, o );
+            auto res1 = rows( *res1_, D );
+            auto ffn_in = rows( *pf_norm2_, D );
+            Compute::rocmCheck( mila_cdna4_fused_tail_norm_bf16( res1.data(), ffn_in.data(), o.data(), x3.data(), L.post_attn_norm->getWeight()->data(),
+                                                                 L.pre_ffn_norm->getWeight()->data(), H, (int)D, 1.0f, cfg_.rms_norm_eps, st ) );
+            auto act = rows( *geglu_, F );
+            gateUpGeglu( L, ffn_in, act, H );
+            auto ffn = rows( *ov_o_, D );                      // o is dead after the first tail
+            L.fc_down->getOperation().forward( act, ffn );
+            Compute::rocmCheck( mila_cdna4_fused_tail_norm_bf16( out.data(), nextL ? normed.data() : nullptr, ffn.data(), res1.data(), L.post_ffn_norm->getWeight()->data(),
+                                                                 nextL ? nextL->input_norm->getWeight()->data() : nullptr, H, (int)D, L.layer_scalar, cfg_.rms_norm_eps, st ) );
+        }
+        LogitsTensor& prefillOverlapped( const TokenTensor& tokens, dim_t T, dim_t position_offset )
+        {
+            const dim_t D = cfg_.embedding_dim;
+            const int H = static_cast<int>( T / 2 );
+            const auto dev = ctx_->getDeviceId();
+            if ( !ov_qkv_ )
+            {
+                ov_qkv_ = std::make_unique<TensorType>( dev, shape_t{ 1, max_prefill_, std::max( cfg_.packedQkvWidth( false ), cfg_.packedQkvWidth( true ) ) } );
+                ov_o_ = std::make_unique<TensorType>( dev, shape_t{ 1, max_prefill_, D } );
+                hipCheck( hipStreamCreateWithFlags( &ov_stream_, hipStreamNonBlocking ), "hipStreamCreate" );
+                for ( auto& e : ov_ev_ ) hipCheck( hipEventCreateWithFlags( &e, hipEventDisableTiming ), "hipEventCreate" );
+            }
+            hipStream_t main = reinterpret_cast<hipStream_t>( ctx_->getStream() );
+            embed( tokens.data(), static_cast<int>( T ), *pf_x_[ 0 ] );
+            {
+                // the first block's input norm over the whole chunk, before the streams part (the op's rstd rows are per call)
+                auto x_all = pf_x_[ 0 ]->view( shape_t{ 1, T, D } );
+                auto n_all = pf_norm_->view( shape_t{ 1, T, D } );
+                layers_[ 0 ].input_norm->getOperation().forward( x_all, n_all );
+            }
+            hipCheck( hipEventRecord( ov_ev_[ 0 ], main ), "hipEventRecord" );
+            hipCheck( hipStreamWaitEvent( ov_stream_, ov_ev_[ 0 ], 0 ), "hipStreamWaitEvent" );
+            int flip = 0;
+            for ( size_t i = 0; i < layers_.size(); ++i )
+            {
+                Layer* nextL = i + 1 < layers_.size() ? &layers_[ i + 1 ] : nullptr;
+                hipEvent_t kv = ov_ev_[ 1 + ( i % 6 ) ];
+                halfBlock( layers_[ i ], 0, i == 0, nextL, H, static_cast<int>( position_offset ), flip, kv, false );
+                {
+                    struct Scope { Compute::RocmExecutionContext* c; mila_stream_t old; ~Scope() { c->swapStream( old ); } } scope{ ctx_, ctx_->swapStream( reinterpret_cast<mila_stream_t>( ov_stream_ ) ) };
+                    halfBlock( layers_[ i ], 1, i == 0, nextL, H, static_cast<int>( position_offset ), flip, kv, true );
+                }
+                flip = 1 - flip;
+            }
+            hipCheck( hipEventRecord( ov_ev_[ 7 ], ov_stream_ ), "hipEventRecord" );
+            hipCheck( hipStreamWaitEvent( main, ov_ev_[ 7 ], 0 ), "hipStreamWaitEvent" );
+            auto last = pf_x_[ flip ]->slice( static_cast<size_t>( ( T - 1 ) * D ), shape_t{ 1, 1, D } );
+            auto& normed = final_norm_->forward( last );
+            head( normed.data() );
+            return *logits_;
+        }
+
     public:
+        /// two half-chunks on two streams (see halfBlock): off by default until measured per deployment; same bits either way
+        void setPrefillOverlap( bool on ) { prefill_overlap_ = on; }
         /// the fused prefill glue serves 1024 < D <= 8192 (workgroup-per-row canonical RMS reduction)
         bool fusedPrefillApplicable() const { return cfg_.embedding_dim > 1024 && cfg_.embedding_dim <= 8192 && cfg_.embedding_dim % 8 == 0; }
         /// on (default): prefill runs the fused glue when the configuration fits; off: one launch per reference op.  Same bits.
@@ -1164,6 +1260,10 @@ namespace Mila::Dnn
         bool use_chain_{ false };
         bool combine_in_oproj_{ false };   // measured slower on MI355X (bf16 222 -> 217, fp4 415 -> 396 tok/s): opt-in, DESIGN.md section 5
         bool fused_prefill_{ true };
+        bool prefill_overlap_{ false };
+        std::unique_ptr<TensorType> ov_qkv_, ov_o_;
+        hipStream_t ov_stream_{ nullptr };
+        hipEvent_t ov_ev_[ 8 ]{};
         int warm_a_blocks_{ 0 }, warm_b_blocks_{ 0 };       // extra workgroups of the attention / combine launches that warm the Infinity Cache
         size_t warm_a_cap_{ 0 }, warm_b_cap_{ 0 };
         bool onepass_attn_{ false };       // split decode attention without the combine launch (last-arriver merge in the same launch)

@@ -150,6 +150,11 @@ HOST_API int mila_gemma_set_fused_prefill( void* h, int on )
     return guarded( [&] { std::visit( [&]( auto& m ) { m->setFusedPrefill( on != 0 ); }, r->model ); } );
 }
 /// on != 0 (default): layers with a small split-partial set run the attention combine inside o_proj's prologue
+HOST_API int mila_gemma_set_prefill_overlap( void* h, int on )
+{
+    return guarded( [&] { std::visit( [&]( auto& m ) { m->setPrefillOverlap( on != 0 ); }, static_cast<Runner*>( h )->model ); } );
+}
+
 HOST_API int mila_gemma_set_combine_in_oproj( void* h, int on )
 {
     auto* r = static_cast<Runner*>( h );

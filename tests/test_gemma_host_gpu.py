@@ -477,3 +477,27 @@ def test_the_block_is_the_references_graph():
         want += ["gemma.tf_layer_%d.%s" % (i, leaf) for leaf in leaves]
     want += ["gemma.temb", "gemma.rmsn_final", "gemma.lm_head"]
     assert names == want
+
+
+@pytest.mark.parametrize("policy", ["bf16", "fp8"])
+def test_two_stream_half_chunk_prefill_gives_the_same_bits(policy):
+    """setPrefillOverlap: the chunk's halves on two streams, the second half's attention behind an event on the first half's K / V rows: same kernels on
+    the same rows, so the logits and everything decoded afterwards are bit-identical"""
+    cfg = dict(vocab_size=2048, embedding_dim=1280, num_layers=6, num_heads=8, num_kv_heads=4, head_dim=64, hidden_dim=2560,
+               global_head_dim=128, num_global_kv_heads=1, window=256, sliding_window_pattern=3, global_rotary_dim=32)
+    T = 1024
+    toks = (np.arange(T, dtype=np.int64) * 7919 % 2048).astype(np.int32)
+    a = host.Gemma(policy, cfg, max_seq=T + 8, max_prefill=T, seed=3)
+    b = host.Gemma(policy, cfg, max_seq=T + 8, max_prefill=T, seed=3)
+    try:
+        b.set_prefill_overlap(True)
+        la, lb = a.prefill(toks), b.prefill(toks)
+        assert np.array_equal(la, lb)
+        ta, tb = int(np.argmax(la)), int(np.argmax(lb))
+        for pos in range(T, T + 4):                       # the caches the two forms left behind are the same
+            da, db = a.decode(ta, pos, "fused"), b.decode(tb, pos, "fused")
+            assert np.array_equal(da, db)
+            ta, tb = int(np.argmax(da)), int(np.argmax(db))
+    finally:
+        a.close()
+        b.close()
