@@ -292,7 +292,7 @@ template <int HS, int HB, int DS, int NW = 4>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void flash_prefill_kernel_s1(const FlashParams p)
 {
     static_assert(DS == 1 || DS == 2, "d-split");
-    static_assert(NW == 4 || (NW == 8 && HB == 4 && DS == 2), "workgroup shapes");
+    static_assert(NW == 4 || (NW == 8 && ((HB == 4 && DS == 2) || (HB == 2 && DS == 1))), "workgroup shapes");
     // double-buffered tiles, one barrier per tile: the 8-wave form, and every HS <= 256 form (two [K | V] pairs are 64 KB there: two workgroups still share a CU)
     constexpr bool DB = (NW == 8) || (HS <= 256);
     constexpr int QB = NW / (HB * DS);
@@ -540,7 +540,11 @@ static int dispatch_hb(const FlashParams& p, int B, hipStream_t s)
     }
     if constexpr (HS == 256)
     {
-        // (the d-split does not pay here: 8-wave workgroups of 2 heads x 2 row blocks x 2 d-halves, four waves per SIMD, measured 92.7 us against 81.6)
+        // 8-wave workgroups (2 heads x 4 row blocks = 64 query rows on one double-buffered K / V tile stream, one workgroup per CU) do 1.4x the work per tile
+        // load of the 4-wave form, but there are only as many of them as CUs at T = 2048, so a causal ramp leaves half the chip waiting for the last tiles:
+        // they are used when at least half the chunk's rows see a full window (every row's work is then the same).  76 vs 82 us on Gemma's sliding-window
+        // shape.  (The d-split does not pay at this head size: 2 heads x 2 row blocks x 2 d-halves, four waves per SIMD, measured 92.7 us.)
+        if (g_tune_flash_form >= 8 && GS % 2 == 0 && p.window > 0 && p.pos_offset + p.Tq / 2 >= p.window) return launch_flash_dma<HS, 2, 1, 8>(p, B, s);
         if (g_tune_flash_form >= 8)
         {
             if (GS % 4 == 0) return launch_flash_dma<HS, 4, 1, 4>(p, B, s);
