@@ -18,7 +18,7 @@ import pytest
 import torch
 
 import orc
-from gpu_util import assert_bf16_close, bits, dev_f32, dev_u16, dev_u8, empty_f32, empty_u16, empty_u8, host
+from gpu_util import assert_bf16_close, bits, dev_f32, dev_i32, dev_u16, dev_u8, empty_f32, empty_u16, empty_u8, host
 from mila_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -585,3 +585,141 @@ def test_flash_prefill_bounded_ring_two_chunks_of_1024_vs_oracle():
     capi.call("attn_prefill_bf16", Y3, _d(q3), Kc, Vc, B, 70, NH, NKV, HS, cap, T, window, 1.0)
     hk_all, hv_all = np.concatenate([hk, hk3], axis=1), np.concatenate([hv, hv3], axis=1)
     _check_rows(Y3, q3, hk_all, hv_all, [0, 1, 33, 69], T, window, 1.0, "ring chunk 2 (ragged 70 rows)")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the remaining leaf components of the path: Swiglu<Gelu>, Residual, TokenEmbedding (bf16 and FP8 tables), split3, and -- FP32-only on the
+# reference's CUDA side, bf16 rows here -- Lpe, LayerNorm, Softmax with the same generators, shapes and host formulas
+# ------------------------------------------------------------------------------------------------------------------------------
+def _near(got, want, atol, rtol, what):
+    got, want = np.asarray(got, dtype=np.float64).ravel(), np.asarray(want, dtype=np.float64).ravel()
+    bad = np.abs(got - want) > atol + rtol * np.abs(want)
+    assert not bad.any(), "%s: %d of %d outside %g + %g |e| (worst %g)" % (what, int(bad.sum()), bad.size, atol, rtol, float(np.abs(got - want).max()))
+
+
+def _f(t):
+    return orc.from_bf16_bits(bits(t))
+
+
+def test_swiglu_geglu_forward_matches_reference__Swiglu_Cuda_cpp_315():
+    """Swiglu.Cuda.cpp:315-349 (Bf16Precision :140-148): shape {2,3,16}, spreadHost i/n*4-2, Y[j] = GeluTanh(gate[j]) * up[j] on the device's own
+    (bf16-rounded) inputs, tolerance 5e-2 + 5e-2 |e|; and this repo's bar: 1 bf16 ulp"""
+    x = _bf(spread((2, 3, 16), 4.0, -2.0))
+    y = empty_u16(6, 8)
+    capi.call("geglu_bf16", y, _d(x), 6, 8)
+    rows = x.reshape(6, 16).astype(np.float64)
+    g, up = rows[:, :8], rows[:, 8:]
+    want = 0.5 * g * (1.0 + np.tanh(0.7978845608 * (g + 0.044715 * g ** 3))) * up
+    _near(_f(y), want, 5e-2, 5e-2, "GeGLU forward (reference tolerance)")
+    assert_bf16_close(bits(y), want.astype(np.float32), 1, 1e-6, "GeGLU forward (1 ulp)")
+
+
+def test_residual_forward_matches_sum__Residual_Cuda_cpp_145():
+    """Residual.Cuda.cpp:145-171 (Bf16Precision :38-44): shape {2,3,4}, rampHost(-1, 0.1) + rampHost(0.5, -0.05), tolerance 5e-2 + 5e-2 |e|; here exactly bf16(a + b)"""
+    i = np.arange(24, dtype=np.float32)
+    a, b = _bf(np.float32(-1.0) + np.float32(0.1) * i), _bf(np.float32(0.5) + np.float32(-0.05) * i)
+    y = empty_u16(24)
+    capi.call("residual_bf16", y, _d(a), _d(b), C.c_int64(24))
+    _near(_f(y), a.astype(np.float64) + b, 5e-2, 5e-2, "Residual forward (reference tolerance)")
+    assert np.array_equal(bits(y), orc.to_bf16_bits(a + b)), "Residual forward: not bf16(a + b)"
+
+
+def _wte_table(vocab=16, embed=8):      # TokenEmbedding.Cuda.cpp:60-64 wteValue
+    v, c = np.arange(vocab, dtype=np.float32)[:, None], np.arange(embed, dtype=np.float32)[None, :]
+    return (np.float32(0.25) * v - np.float32(0.5) + np.float32(0.1) * c).astype(np.float32)
+
+
+def _ramp_tokens(n, vocab=16):          # :67-70 tokenAt
+    return ((np.arange(n, dtype=np.int64) * 3 + 1) % vocab).astype(np.int32)
+
+
+@pytest.mark.parametrize("shape,scale", [((2, 3), 0.0), ((2, 1), 0.0), ((2, 3), 2.0)], ids=["Forward_GathersEmbeddingRows_266", "Forward_DecodeShapeSingleToken_303", "Forward_WithEmbeddingScale_342"])
+def test_token_embedding_forward__TokenEmbedding_Cuda_cpp(shape, scale):
+    """TokenEmbedding.Cuda.cpp:266-300 / 303-338 / 342-378 (Bf16Precision :80-86): kVocab 16, kEmbed 8, wte[v, c] = 0.25 v - 0.5 + 0.1 c, tokens (3 i + 1) % 16;
+    output[b, t, :] = wte[X[b, t], :] (x 2 with the embedding scale), tolerance 5e-3 + 5e-3 |e|; here exact bits (a gather; the scale is a power of two)"""
+    table = _bf(_wte_table())
+    n = int(np.prod(shape))
+    toks = _ramp_tokens(n)
+    y = empty_u16(n, 8)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    capi.call("embedding_gather_bf16", y, dev_i32(toks), _d(table), n, 8, 16, float(scale), flag)
+    want = table[toks] * (np.float32(scale) if scale else np.float32(1.0))
+    _near(_f(y), want, 5e-3, 5e-3, "TokenEmbedding forward (reference tolerance)")
+    assert np.array_equal(bits(y), orc.to_bf16_bits(want)) and int(flag.item()) == 0
+
+
+def test_token_embedding_fp8_table_matches_dequantized_reference__TokenEmbedding_Cuda_cpp_656():
+    """TokenEmbedding.Cuda.cpp:656-679 with expectDequantNear :557-581: the bf16 table quantized on load (per vocabulary row, scale = absmax / 448), gathered and
+    dequantized; |out - source| <= 0.07 |source| + 0.004 scale.  And :597-650: a table rebuilt from the stored bytes gathers bit-identically"""
+    table = _bf(_wte_table())
+    q8, s8 = empty_u8(16, 8), empty_f32(16)
+    capi.call("quantize_fp8_per_channel", q8, s8, _d(table), 16, 8)
+    toks = _ramp_tokens(6)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    y = empty_u16(6, 8)
+    capi.call("embedding_gather_bf16_qfp8", y, dev_i32(toks), q8, s8, 6, 8, 16, 0.0, flag)
+    out = _f(y).reshape(6, 8)
+    for r, idx in enumerate(toks):
+        src = table[idx]
+        amax = float(np.abs(src).max())
+        scale = amax / 448.0 if amax > 0 else 1.0
+        assert np.all(np.abs(out[r] - src) <= 0.07 * np.abs(src) + 0.004 * scale), "fp8 gather-dequant mismatch at row %d" % r
+    q8b, s8b = dev_u8(host(q8)), dev_f32(host(s8))          # "pre-quantized reload": the stored bytes, a new table
+    y2 = empty_u16(6, 8)
+    capi.call("embedding_gather_bf16_qfp8", y2, dev_i32(toks), q8b, s8b, 6, 8, 16, 0.0, flag)
+    assert np.array_equal(bits(y), bits(y2)) and int(flag.item()) == 0
+
+
+def test_split3_bf16_partitions_last_dimension__Structural_Cuda_cpp_156():
+    """Structural.Cuda.cpp:156-173: B 2, T 3, D = 8 + 8 + 16, value(b, t, d) = flat index (<= 191: exact in bf16); each output is exactly its slice of every row"""
+    B, T, D0, D1, D2 = 2, 3, 8, 8, 16
+    D = D0 + D1 + D2
+    x = np.arange(B * T * D, dtype=np.float32).reshape(B * T, D)
+    a, b, c = empty_u16(B * T, D0), empty_u16(B * T, D1), empty_u16(B * T, D2)
+    capi.call("split3_bf16", a, b, c, _d(x), B * T, D0, D1, D2)
+    assert np.array_equal(_f(a).reshape(B * T, D0), x[:, :D0]) and np.array_equal(_f(b).reshape(B * T, D1), x[:, D0:D0 + D1]) and np.array_equal(_f(c).reshape(B * T, D2), x[:, D0 + D1:])
+
+
+def test_lpe_forward_token_plus_positional__Lpe_Cuda_cpp_213():
+    """Lpe.Cuda.cpp:213-250 (FP32 there -- "add a Bf16Precision tag once a BF16 kernel exists", :65-67; this is that kernel): kVocab 8, kMaxSeq 8, kEmbed 4 (here 8: the
+    bf16 row moves 16-byte vectors), wte = 0.1 v + 0.01 c, wpe = -0.05 p + 0.2 c, tokens (3 i + 1) % 8, shape {2, 3}: out[b, t, :] = wte[X[b, t], :] + wpe[t, :]"""
+    V, P, E, B, T = 8, 8, 8, 2, 3
+    wte = _bf(np.float32(0.1) * np.arange(V, dtype=np.float32)[:, None] + np.float32(0.01) * np.arange(E, dtype=np.float32)[None, :])
+    wpe = _bf(np.float32(-0.05) * np.arange(P, dtype=np.float32)[:, None] + np.float32(0.2) * np.arange(E, dtype=np.float32)[None, :])
+    toks = _ramp_tokens(B * T, V)
+    y = empty_u16(B * T, E)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    capi.call("lpe_bf16", y, dev_i32(toks), _d(wte), _d(wpe), B, T, E, T, V, flag)
+    want = wte[toks].astype(np.float64) + np.tile(wpe[:T], (B, 1))
+    _near(_f(y), want, 5e-3, 5e-3, "Lpe forward")
+    assert_bf16_close(bits(y), want.astype(np.float32), 1, 1e-6, "Lpe forward (1 ulp)")
+    assert int(flag.item()) == 0
+
+
+def test_layernorm_forward_matches_reference__LayerNorm_Cuda_cpp_167():
+    """LayerNorm.Cuda.cpp:167-199 (FP32 there; the bf16 row here): shape {2, 3, 16}, eps 1e-5, W[i] = 0.5 + 0.1 ((i % 5) - 2), B[i] = 0.05 ((i % 7) - 3), spreadHost
+    i/n*4-2; double-precision mean / variance reference (:49-73); the reference's 1e-3 becomes 1 bf16 ulp + 1e-3 on bf16-rounded operands"""
+    Cn = 16
+    x = _bf(spread((6, Cn), 4.0, -2.0))
+    i = np.arange(Cn)
+    w = _bf((np.float32(0.5) + np.float32(0.1) * ((i % 5) - 2).astype(np.float32)))
+    b = _bf((np.float32(0.05) * ((i % 7) - 3).astype(np.float32)))
+    y = empty_u16(6, Cn)
+    capi.call("layernorm_bf16", y, None, None, _d(x), _d(w), _d(b), 6, Cn, 1e-5)
+    xd = x.astype(np.float64)
+    mean = xd.mean(axis=1, keepdims=True)
+    var = ((xd - mean) ** 2).mean(axis=1, keepdims=True)
+    want = (xd - mean) / np.sqrt(var + 1e-5) * w + b
+    assert_bf16_close(bits(y), want.astype(np.float32), 1, 1e-3, "LayerNorm forward")
+
+
+def test_softmax_forward_matches_reference__Softmax_Cuda_cpp_176():
+    """Softmax.Cuda.cpp:176-201 (FP32 there; the bf16 row here): shape {4, 8}, spreadHost i/n*4-2, y = exp(x - max) / sum in double (:44-64); rows sum to one"""
+    x = _bf(spread((4, 8), 4.0, -2.0))
+    y = empty_u16(4, 8)
+    capi.call("softmax_bf16", y, _d(x), 4, 8, 1)
+    xd = x.astype(np.float64)
+    e = np.exp(xd - xd.max(axis=1, keepdims=True))
+    want = e / e.sum(axis=1, keepdims=True)
+    assert_bf16_close(bits(y), want.astype(np.float32), 1, 1e-6, "Softmax forward")
+    assert np.allclose(_f(y).reshape(4, 8).sum(axis=1), 1.0, atol=2e-2)
