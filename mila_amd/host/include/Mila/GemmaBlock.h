@@ -514,6 +514,13 @@ namespace Mila::Dnn
         float layer_scalar{ 1.0f };      ///< Gemma 4: hidden_states *= layer_scalar at the end of the block (Gemma.Block.ixx:546-560)
 
         const GemmaBlockConfig& getConfig() const noexcept { return config_; }
+        // the block's geometry under the reference's accessor names (Gemma.Block.ixx:160-192)
+        bool isGlobal() const noexcept { return global; }
+        dim_t headDim() const noexcept { return config_.head_dim; }
+        dim_t numKVHeads() const noexcept { return config_.num_kv_heads; }
+        bool keyEqualsValue() const noexcept { return global; }          // global blocks have no v_proj: V = v_norm(raw k_proj)
+        dim_t window() const noexcept { return config_.window; }
+        dim_t kvProjWidth() const noexcept { return kvWidth(); }
         /// the children's names in construction order (Gemma.Block.ixx:858-921)
         std::vector<std::string> childNames() const
         {

@@ -701,6 +701,78 @@ HOST_API int mila_component_scenarios( int device )
             if ( head8.getWeightScale()->rawData() != q8.getWeightScalesTensorShared()->rawData() ) fail( "Linear::installSharedWeight(weight, scales)" );
             expect_throw( [&] { head8.installSharedWeight( q8.getWeightTensorShared(), q8.getWeightScalesTensorShared() ); }, false, "installSharedWeight after build" );
         }
+        // ---- GemmaBlock<kGlobal> as its own type: Tests/Dnn/Components/Transformers/Gemma/Gemma.Block.Cuda.cpp:132-262 on the same small geometry ----
+        {
+            using LocalBlock = GemmaBlock<kD, kP, false>;
+            using GlobalBlock = GemmaBlock<kD, kP, true>;
+            static_assert( LocalBlock::getDeviceType() == kD && LocalBlock::getPrecision() == kP );
+            auto cfg_of = []( bool g )
+            {
+                GemmaBlockConfig c;
+                c.model_dim = 64; c.hidden_dim = 128; c.num_heads = 4; c.num_kv_heads = g ? 1 : 2; c.head_dim = g ? 64 : 32;
+                c.window = g ? 0 : 8; c.rotary_dim = g ? 32 : 0; c.rope_theta = g ? 1000000.0f : 10000.0f; c.rms_norm_eps = 1e-6f; c.max_seq = 32;
+                return c;
+            };
+            const dim_t seq = 8;
+            LocalBlock local( "gemma_local", cfg_of( false ) );
+            GlobalBlock global( "gemma_global", cfg_of( true ) );
+            local.setExecutionContext( ctx ); global.setExecutionContext( ctx );
+            if ( local.isBuilt() || global.isBuilt() ) fail( "GemmaBlock built before build()" );                                       // ConstructLocal / ConstructGlobal
+            {
+                LocalBlock rank2( "gemma_local", cfg_of( false ) ); rank2.setExecutionContext( ctx );
+                expect_throw( [&] { rank2.build( BuildContext( shape_t{ seq, 64 }, RuntimeMode::Inference ) ); }, true, "GemmaBlock Build_ThrowsOnNonRank3Input (:185)" );
+                LocalBlock wrong( "gemma_local", cfg_of( false ) ); wrong.setExecutionContext( ctx );
+                expect_throw( [&] { wrong.build( BuildContext( shape_t{ 1, seq, 65 }, RuntimeMode::Inference ) ); }, true, "GemmaBlock Build_ThrowsOnModelDimMismatch (:194)" );
+            }
+            // LocalGeometry_SlidingWidthsAndWindow (:206), GlobalGeometry_WidenedHeadDimAndKEqualsV (:220), HeadDim_IsDecoupledFromResidualStream (:235)
+            if ( local.isGlobal() || local.headDim() != 32 || local.numKVHeads() != 2 || local.keyEqualsValue() || local.window() != 8 || local.qProjWidth() != 128 ||
+                 local.kvProjWidth() != 64 || local.packedQKVWidth() != 256 ) fail( "GemmaBlock local geometry" );
+            if ( !global.isGlobal() || global.headDim() != 64 || global.numKVHeads() != 1 || !global.keyEqualsValue() || global.window() != 0 || global.qProjWidth() != 256 ||
+                 global.kvProjWidth() != 64 || global.packedQKVWidth() != 320 ) fail( "GemmaBlock global geometry (K = V drops the V section)" );
+            if ( local.headDim() == 64 / 4 || local.qProjWidth() == 64 ) fail( "GemmaBlock head_dim must be decoupled from model_dim / num_heads" );
+            // GetComponents_ReturnsCorrectChildrenSize (:249), GlobalBlock_HasSameGraphShape (:258): 7 norms + qkv_proj + rope + gqa + o_proj + res_1 + fc_gate_up + geglu + fc_down + res_2
+            if ( local.childNames().size() != 16u || global.childNames().size() != 16u ) fail( "GemmaBlock children" );
+            local.build( BuildContext( shape_t{ 1, seq, 64 }, RuntimeMode::Inference ) );                                                 // BuildLocal_SetsIsBuilt / AllocatesParameters
+            global.build( BuildContext( shape_t{ 1, seq, 64 }, RuntimeMode::Inference ) );
+            if ( !local.isBuilt() || !global.isBuilt() || local.qkv_proj->getParameterBytes() != 256u * 64u * 2u || global.qkv_proj->getParameterBytes() != 320u * 64u * 2u )
+                fail( "GemmaBlock build / parameter allocation" );
+            // SaveThenLoad_RestoresLayerScalar (:357): the scalar travels as a one-element F32 parameter
+            const float two_and_a_half = 2.5f;
+            local.loadParameter( "layer_scalar", &two_and_a_half, 4 );
+            if ( local.layer_scalar != 2.5f ) fail( "GemmaBlock layer_scalar" );
+            expect_throw( [&] { local.loadParameter( "layer_scalar", &two_and_a_half, 8 ); }, true, "GemmaBlock layer_scalar blob size" );
+            expect_throw( [&] { local.loadParameter( "no_such", &two_and_a_half, 4 ); }, true, "GemmaBlock unknown parameter" );
+            // a forward through both kinds: prefill of the chunk, then one decode step continues it (finite outputs of the right shape)
+            auto fill_w = [&]( auto& blk, uint64_t seed )
+            {
+                for ( auto* lin : { blk.qkv_proj.get(), blk.o_proj.get(), blk.fc_gate_up.get(), blk.fc_down.get() } ) fillu( lin->getWeight(), seed++, 0.1f, 0.0f );
+                for ( auto* n : { blk.input_norm.get(), blk.q_norm.get(), blk.k_norm.get(), blk.v_norm.get(), blk.post_attn_norm.get(), blk.pre_ffn_norm.get(), blk.post_ffn_norm.get() } )
+                    fillu( *n->getWeight(), seed++, 0.1f, 1.0f );
+            };
+            // (the attention kernels serve head sizes 64 ... 512: the forward runs on the same graph with head_dim 64 / 128)
+            auto fwd_cfg = [&]( bool g ) { auto c = cfg_of( g ); c.head_dim = g ? 128 : 64; return c; };
+            LocalBlock flocal( "gemma_local", fwd_cfg( false ) );
+            GlobalBlock fglobal( "gemma_global", fwd_cfg( true ) );
+            flocal.setExecutionContext( ctx ); fglobal.setExecutionContext( ctx );
+            flocal.build( BuildContext( shape_t{ 1, seq, 64 }, RuntimeMode::Inference ) );
+            fglobal.build( BuildContext( shape_t{ 1, seq, 64 }, RuntimeMode::Inference ) );
+            fill_w( flocal, 100 ); fill_w( fglobal, 200 );
+            T16 x( dev, shape_t{ 1, seq, 64 } ), x1( dev, shape_t{ 1, 1, 64 } );
+            fillu( x, 7, 1.0f, 0.0f ); fillu( x1, 8, 1.0f, 0.0f );
+            for ( IDecoderLayer<kD, kP>* blk : { static_cast<IDecoderLayer<kD, kP>*>( &flocal ), static_cast<IDecoderLayer<kD, kP>*>( &fglobal ) } )
+            {
+                auto& y = blk->prefill( x, 0 );
+                if ( y.shape() != shape_t{ 1, seq, 64 } ) fail( "GemmaBlock::prefill output shape" );
+                auto yh = host( y, static_cast<size_t>( seq * 64 ) );
+                auto& d = blk->decode( x1, seq );
+                if ( d.shape() != shape_t{ 1, 1, 64 } ) fail( "GemmaBlock::decode output shape" );
+                auto dh = host( d, 64 );
+                for ( uint16_t b : yh ) if ( ( b & 0x7f80 ) == 0x7f80 ) fail( "GemmaBlock::prefill produced a non-finite value" );
+                for ( uint16_t b : dh ) if ( ( b & 0x7f80 ) == 0x7f80 ) fail( "GemmaBlock::decode produced a non-finite value" );
+                blk->resetKVCache();
+            }
+            expect_throw( [&] { flocal.decode( x, 0 ); }, true, "GemmaBlock::decode takes one token" );
+        }
         ctx->synchronize();
     } );
 }

@@ -461,7 +461,9 @@ def test_chunked_prefill_equals_single_chunk_prefill(cfg_name):
 def test_components_stand_alone_as_in_the_reference():
     """Components/{Connections/Residual.ixx:93-127, FFN/Swiglu/Swiglu.ixx:92, Encodings/Rope/Rope.ixx:99-200, Attention/GQA/GroupedQueryAttention.ixx:234-400,
     Embeddings/TokenEmbedding.ixx:155-190,336-384, Linear/Linear.ixx:614-680}: name + config constructor, setExecutionContext, build, forward; results against
-    the launchers, lifecycle errors (runtime_error before build, invalid_argument on bad shapes / configs), the tied head aliasing the table"""
+    the launchers, lifecycle errors (runtime_error before build, invalid_argument on bad shapes / configs), the tied head aliasing the table; and GemmaBlock<kGlobal>
+    as its own type on the reference test's geometry (Tests/Dnn/Components/Transformers/Gemma/Gemma.Block.Cuda.cpp:132-262, 357: construct, build errors, local /
+    global geometry with K = V, 16 children, layer_scalar as a parameter) with a prefill + decode through both kinds"""
     host.component_scenarios(0)
 
 
