@@ -127,6 +127,23 @@ class Gemma:
         configuration fits) or one launch per Linear; the two give identical bits.  Before the first graph decode."""
         _check(load().mila_gemma_set_chain(self.h, int(bool(on))))
 
+    def rewind(self, position):
+        """GemmaTransformer::rewindKvCache(position): True when every block accepted (False beyond the fill, or when a bounded ring has evicted what is needed)"""
+        lib = load()
+        lib.mila_gemma_rewind.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        ok = C.c_int()
+        _check(lib.mila_gemma_rewind(self.h, int(position), C.byref(ok)))
+        return bool(ok.value)
+
+    def prefill_from(self, tokens, offset):
+        """GemmaTransformer::prefillFrom: positions [0, offset) stay resident, tokens[offset:] are prefilled at their positions; logits of the last position"""
+        lib = load()
+        lib.mila_gemma_prefill_from.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = np.empty(self.vocab, dtype=np.float32)
+        _check(lib.mila_gemma_prefill_from(self.h, t.ctypes.data, t.size, int(offset), out.ctypes.data))
+        return out
+
     def set_prefill_overlap(self, on):
         """prefill: the chunk's two halves as two kernel sequences on two streams (the second half's attention waits for the first half's K / V rows);
         bf16 and resident-fp8 policies, T % 512 == 0.  Identical bits."""

@@ -181,6 +181,7 @@ namespace Mila::Dnn
         {
             Compute::TraceRange tr( "gemma.decode(reference order)" );
             checkPosition( position, 1 );
+            kv_fill_ = position + 1;
             embed( token.data(), 1, *hidden_[ 0 ] );
             TensorType* x = hidden_[ 0 ].get();
             for ( auto& L : layers_ ) x = &L.decode( x->view( shape_t{ 1, 1, cfg_.embedding_dim } ), position );
@@ -196,6 +197,7 @@ namespace Mila::Dnn
         {
             Compute::TraceRange tr( "gemma.decode(fused)" );
             checkPosition( position, 1 );
+            kv_fill_ = position + 1;
             enqueueFusedStep( token.data(), static_cast<int>( position ), nullptr );
             return *logits_;
         }
@@ -298,6 +300,7 @@ namespace Mila::Dnn
             if ( T <= 0 || T > max_prefill_ ) throw std::invalid_argument( "GemmaTransformer::prefill: chunk length out of range" );
             Compute::TraceRange tr( "gemma.prefill" );
             checkPosition( position_offset, T );
+            kv_fill_ = position_offset + T;
             const dim_t D = cfg_.embedding_dim;
             embed( tokens.data(), static_cast<int>( T ), *pf_x_[ 0 ] );
             TensorType* x = pf_x_[ 0 ].get();
@@ -345,7 +348,26 @@ namespace Mila::Dnn
             if ( position < 0 || position > written ) return false;
             bool ok = true;
             for ( auto& L : layers_ ) ok = L.rewindKvCache( position, written ) && ok;
+            if ( ok ) kv_fill_ = position;
             return ok;
+        }
+        /// the same against the fill this transformer has tracked itself (prefill / decode / decodeFused calls; graph replays advance on the device, so a
+        /// caller that replays -- GemmaModel -- passes the fill explicitly): positions beyond the fill are rejected (Gemma.Cuda.cpp:373-383)
+        bool rewindKvCache( dim_t position ) { return rewindKvCache( position, kv_fill_ ); }
+        dim_t kvFill() const noexcept { return kv_fill_; }
+        /// incremental prefill (prompt-prefix reuse): positions [0, offset) stay resident, tokens [offset, T) are prefilled at their positions, in chunks of
+        /// the built prefill size; logits of the last position (Gemma.ixx prefillFrom; Gemma.Cuda.cpp:338-391)
+        LogitsTensor& prefillFrom( const TokenTensor& tokens, dim_t T, dim_t offset )
+        {
+            if ( offset < 0 || offset >= T ) throw std::invalid_argument( "GemmaTransformer::prefillFrom: offset " + std::to_string( offset ) + " outside the prompt of " + std::to_string( T ) + " tokens" );
+            LogitsTensor* out = nullptr;
+            for ( dim_t p0 = offset; p0 < T; p0 += max_prefill_ )
+            {
+                const dim_t n = std::min( max_prefill_, T - p0 );
+                auto chunk = tokens.slice( static_cast<size_t>( p0 ), shape_t{ 1, n } );
+                out = &prefill( chunk, n, p0 );
+            }
+            return *out;
         }
         void resetKVCache() { for ( auto& L : layers_ ) L.resetKVCache(); }
         LmHeadLinearType& lmHead() { return *lm_head_; }
@@ -497,7 +519,7 @@ namespace Mila::Dnn
 
         // ---- fused-glue prefill (the reference-order path is GemmaBlock::prefill) -----------------------
         /// act[T, F] = GeGLU(fc_gate_up(ffn_in)): one kernel when the fused GEMM serves the shape, else Linear + GeGLU
-        void gateUpGeglu( Layer& L, TensorType& ffn_in, TensorType& act, int T )
+        void gateUpGeglu( Layer& L, TensorType& ffn_in, TensorType& act, int T, TensorType* private_gate_up = nullptr )
         {
             const dim_t D = cfg_.embedding_dim;
             mila_stream_t st = ctx_->getStream();
@@ -551,7 +573,9 @@ namespace Mila::Dnn
             }
             else
             {
-                auto& gate_up = L.fc_gate_up->forward( ffn_in );
+                // the unfused pair; a caller running two calls at once (halfBlock) hands each its own [T, 2F] rows instead of the component's output
+                if ( private_gate_up ) L.fc_gate_up->getOperation().forward( ffn_in, *private_gate_up );
+                auto& gate_up = private_gate_up ? *private_gate_up : L.fc_gate_up->forward( ffn_in );
                 Compute::rocmCheck( mila_cdna4_geglu_bf16( act.data(), gate_up.data(), T, (int)cfg_.hidden_dim, st ) );
             }
         }
@@ -609,7 +633,9 @@ namespace Mila::Dnn
             const dim_t NH = cfg_.num_heads, NKV = cfg_.numKvHeads( g ), HD = cfg_.headDim( g ), D = cfg_.embedding_dim, F = cfg_.hidden_dim;
             const size_t r0 = static_cast<size_t>( h ) * static_cast<size_t>( H );
             mila_stream_t st = ctx_->getStream();
-            auto rows = [&]( TensorType& t, dim_t width ) { return t.slice( r0 * static_cast<size_t>( width ), shape_t{ 1, H, width } ); };
+            // a half's region of a buffer starts at its first row in the buffer's OWN (widest) row pitch: the first half may run a layer of the other kind
+            // (wider q / qkv rows) ahead of the second half, and the regions of the two must not meet whatever the widths
+            auto rows = [&]( TensorType& t, dim_t width ) { return t.slice( r0 * static_cast<size_t>( t.shape().back() ), shape_t{ 1, H, width } ); };
             auto x3 = rows( *pf_x_[ flip ], D );
             auto out = rows( *pf_x_[ 1 - flip ], D );
             auto normed = rows( *pf_norm_, D );
@@ -635,7 +661,8 @@ namespace Mila::Dnn
             Compute::rocmCheck( mila_cdna4_fused_tail_norm_bf16( res1.data(), ffn_in.data(), o.data(), x3.data(), L.post_attn_norm->getWeight()->data(),
                                                                  L.pre_ffn_norm->getWeight()->data(), H, (int)D, 1.0f, cfg_.rms_norm_eps, st ) );
             auto act = rows( *geglu_, F );
-            gateUpGeglu( L, ffn_in, act, H );
+            auto gate_up = rows( *ov_gate_up_, 2 * F );        // only written when the fused Linear + GeGLU does not serve this [H, D, F]
+            gateUpGeglu( L, ffn_in, act, H, &gate_up );
             auto ffn = rows( *ov_o_, D );                      // o is dead after the first tail
             L.fc_down->getOperation().forward( act, ffn );
             Compute::rocmCheck( mila_cdna4_fused_tail_norm_bf16( out.data(), nextL ? normed.data() : nullptr, ffn.data(), res1.data(), L.post_ffn_norm->getWeight()->data(),
@@ -650,6 +677,7 @@ namespace Mila::Dnn
             {
                 ov_qkv_ = std::make_unique<TensorType>( dev, shape_t{ 1, max_prefill_, std::max( cfg_.packedQkvWidth( false ), cfg_.packedQkvWidth( true ) ) } );
                 ov_o_ = std::make_unique<TensorType>( dev, shape_t{ 1, max_prefill_, D } );
+                ov_gate_up_ = std::make_unique<TensorType>( dev, shape_t{ 1, max_prefill_, 2 * cfg_.hidden_dim } );
                 hipCheck( hipStreamCreateWithFlags( &ov_stream_, hipStreamNonBlocking ), "hipStreamCreate" );
                 for ( auto& e : ov_ev_ ) hipCheck( hipEventCreateWithFlags( &e, hipEventDisableTiming ), "hipEventCreate" );
             }
@@ -1260,8 +1288,9 @@ namespace Mila::Dnn
         bool use_chain_{ false };
         bool combine_in_oproj_{ false };   // measured slower on MI355X (bf16 222 -> 217, fp4 415 -> 396 tok/s): opt-in, DESIGN.md section 5
         bool fused_prefill_{ true };
+        dim_t kv_fill_{ 0 };      ///< positions the caches hold, as far as eager calls tell (see rewindKvCache)
         bool prefill_overlap_{ false };
-        std::unique_ptr<TensorType> ov_qkv_, ov_o_;
+        std::unique_ptr<TensorType> ov_qkv_, ov_o_, ov_gate_up_;
         hipStream_t ov_stream_{ nullptr };
         hipEvent_t ov_ev_[ 8 ]{};
         int warm_a_blocks_{ 0 }, warm_b_blocks_{ 0 };       // extra workgroups of the attention / combine launches that warm the Infinity Cache

@@ -150,6 +150,30 @@ HOST_API int mila_gemma_set_fused_prefill( void* h, int on )
     return guarded( [&] { std::visit( [&]( auto& m ) { m->setFusedPrefill( on != 0 ); }, r->model ); } );
 }
 /// on != 0 (default): layers with a small split-partial set run the attention combine inside o_proj's prologue
+/// GemmaTransformer::rewindKvCache( position ): *ok = 1 when every block accepted
+HOST_API int mila_gemma_rewind( void* h, int64_t position, int* ok )
+{
+    return guarded( [&] { std::visit( [&]( auto& m ) { *ok = m->rewindKvCache( position ) ? 1 : 0; }, static_cast<Runner*>( h )->model ); } );
+}
+
+/// GemmaTransformer::prefillFrom( tokens[0 .. T), offset ): positions [0, offset) stay resident, the tail is prefilled; logits of the last position
+HOST_API int mila_gemma_prefill_from( void* h, const int32_t* host_tokens, int64_t T, int64_t offset, float* host_logits )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&]
+    {
+        std::visit( [&]( auto& m )
+        {
+            if ( T <= 0 ) throw std::invalid_argument( "prefill_from: empty prompt" );
+            Tensor<TensorDataType::INT32, Compute::RocmDeviceMemoryResource> toks( m->context()->getDeviceId(), shape_t{ 1, T } );
+            Compute::rocmCheck( mila_cdna4_memcpy_h2d( toks.rawData(), host_tokens, static_cast<size_t>( T ) * 4, m->context()->getStream() ) );
+            m->prefillFrom( toks, T, offset );
+            m->context()->synchronize();
+        }, r->model );
+        download_logits( r, host_logits );
+    } );
+}
+
 HOST_API int mila_gemma_set_prefill_overlap( void* h, int on )
 {
     return guarded( [&] { std::visit( [&]( auto& m ) { m->setPrefillOverlap( on != 0 ); }, static_cast<Runner*>( h )->model ); } );

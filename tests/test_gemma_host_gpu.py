@@ -503,3 +503,25 @@ def test_two_stream_half_chunk_prefill_gives_the_same_bits(policy):
     finally:
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("policy", ["bf16", "fp4"])
+def test_prefill_from_after_rewind_matches_full_prefill__Gemma_Cuda_cpp_338(policy):
+    """Tests/Dnn/Components/Transformers/Gemma/Gemma.Cuda.cpp:338-371 (kSeq 24, kSplit 16: rewind to the split, prefill only the tail; tolerance 1e-4 + 1e-3 |e|),
+    :373-383 (a rewind beyond the fill is refused), :385-391 (prefillFrom rejects an offset outside the prompt).  Here rows are independent of the chunking: exact bits."""
+    seq, split = 24, 16
+    toks = ((np.arange(seq, dtype=np.int64) * 5 + 3) % SMALL["vocab_size"]).astype(np.int32)
+    m = host.Gemma(policy, SMALL, max_seq=32, max_prefill=seq, seed=4)
+    try:
+        full = m.prefill(toks)
+        assert m.rewind(split)
+        inc = m.prefill_from(toks, split)
+        assert np.all(np.abs(inc - full) <= 1e-4 + 1e-3 * np.abs(full))
+        assert np.array_equal(inc, full)
+        m.prefill(toks)
+        assert m.rewind(seq - 1) and not m.rewind(seq + 10)
+        for bad in (seq, -1):
+            with pytest.raises(ValueError, match="outside the prompt"):
+                m.prefill_from(toks, bad)
+    finally:
+        m.close()
