@@ -60,6 +60,16 @@ __device__ __forceinline__ void grouped_tile(int tile, int tiles_m, int tiles_n,
     tn = in / gm;
 }
 
+// Epilogue store of two 16-column sub-tiles (pt, pt + 1) of one output row as ONE 16-byte store per lane.  A lane (l15, g) holds columns 4 g .. 4 g + 3 of both
+// sub-tiles (a, b); v_permlane16_swap exchanges the odd lane rows of a with the even lane rows of b, after which an even-g lane holds columns 4 g .. 4 g + 7 of
+// sub-tile pt and an odd-g lane columns 4 (g - 1) .. 4 (g - 1) + 7 of sub-tile pt + 1: half the store instructions, 64 contiguous bytes per row and instruction.
+__device__ __forceinline__ void store_pair16(uint16_t* row_pt, int g, u32x2 a, u32x2 b)
+{
+    const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+    st16(row_pt + (g & 1) * 16 + 4 * (g & ~1), u32x4{r0[0], r1[0], r0[1], r1[1]});
+}
+
 // PP (ping-pong): waves 4-7 run one barrier behind waves 0-3 and every phase has TWO barriers, [stage + fragment reads + waits] | A |
 // [16 MFMAs] | B |, so that while one wave of a SIMD multiplies, the other one reads its fragments and issues the staging: LDS
 // reads (28 ds_read_b128 per wave and K-tile, as many LDS cycles per CU as a SIMD has MFMA cycles) leave the critical path.
@@ -110,7 +120,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
         {
             const int chunk = i * 8 + wave;                // 16 chunks of 8 rows
             const int row = chunk * 8 + srow;              // row within the half-tile
-            const int kslot = sslot ^ ((row >> 1) & 7);    // swizzle on the source address
+            const int lslot = sslot ^ ((row >> 1) & 7);    // swizzle on the source address: LDS slot sslot of this row holds logical slot lslot
+            // fp8: a lane's operand is the 32 contiguous bytes k = 32 g .. (source chunks 2 g, 2 g + 1); they are kept at the logical slots g and 4 + g the
+            // bf16 fragments use, so the fragment reads are the same conflict-free pattern (read as 2 g + ks they pair up on the banks: 2-way conflicts)
+            const int kslot = FP8 ? (((lslot & 3) << 1) | (lslot >> 2)) : lslot;
             const unsigned char* src = base + (size_t)row * K * ES + (size_t)kt * 128 + kslot * 16;
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(dst_half + chunk * 1024), 16, 0, 0);
         }
@@ -126,9 +139,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 #pragma unroll
                 for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // fragment registers: bf16 = [ks] halves of 16 B (k slots 4 ks + g); fp8 = the two 16-B slots 2 g, 2 g + 1 of one 32-byte operand
-    s16x8 fa[4][2], fb[2][2], fb1[PP == 2 ? 2 : 1][2];
-    auto frag_slot = [&](int ks) { return FP8 ? (2 * g + ks) : (ks * 4 + g); };
+    // fragment registers: [ks] = the logical 16-B slot 4 ks + g of the row (bf16: k = 8 (4 ks + g) ..; fp8: source chunk 2 g + ks, the halves of one 32-byte operand)
+    constexpr bool P2 = PP == 2;            // two phases per K-tile
+    s16x8 fa[4][2], fb[2][2], fb1[P2 ? 2 : 1][2];
+    auto frag_slot = [&](int ks) { return ks * 4 + g; };
     auto load_a = [&](int kt, int hA) {
         const unsigned char* hb = smem + (kt & 1) * kBufBytes + half_off(false, hA);
 #pragma unroll
@@ -150,13 +164,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
             for (int ks = 0; ks < 2; ++ks)
             {
                 const s16x8 v = *reinterpret_cast<const s16x8*>(hb + r * 128 + ((frag_slot(ks) ^ ((r >> 1) & 7)) << 4));
-                if (PP == 2 && hB == 1) fb1[PP == 2 ? qt : 0][ks] = v;
+                if (P2 && hB == 1) fb1[P2 ? qt : 0][ks] = v;
                 else fb[qt][ks] = v;
             }
         }
     };
     auto mma = [&](int hA, int hB) {
-        s16x8 (&fbx)[2][2] = *((PP == 2 && hB == 1) ? reinterpret_cast<s16x8 (*)[2][2]>(&fb1) : &fb);
+        s16x8 (&fbx)[2][2] = *((P2 && hB == 1) ? reinterpret_cast<s16x8 (*)[2][2]>(&fb1) : &fb);
         __builtin_amdgcn_s_setprio(1);
         if constexpr (FP8)
         {
@@ -193,12 +207,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 
     // ---- prologue: K-tile 0 complete, W0 / X1 of K-tile 1 in flight (PP == 2: W0 / X0 / X1 of K-tile 1) ----
     stage(0, false, 0); stage(0, true, 0); stage(0, true, 1); stage(0, false, 1);
-    if (nk > 1) { stage(1, false, 0); if constexpr (PP == 2) stage(1, true, 0); stage(1, true, 1); }
-    if (nk > 1) { if constexpr (PP == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    if (nk > 1) { stage(1, false, 0); if constexpr (P2) stage(1, true, 0); stage(1, true, 1); }
+    if (nk > 1) { if constexpr (P2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    if constexpr (PP == 2)
+    if constexpr (P2)
     {
         auto reads_end = [&](bool steady) {
             if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -314,69 +328,74 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 
     }
 
-    // ---- epilogue: D[p = 4 g + r][q = l15] -> Y[m0 + q][n0 + p] ----
+    // ---- epilogue: D[p = 4 g + r][q = l15] -> Y[m0 + q][n0 + p], two sub-tiles per 16-byte store (store_pair16) ----
     if constexpr (GEGLU)
     {
+        auto out4 = [&](int hB, int pt, int qt, int m) -> u32x2 {
+            float v[4];
+            if constexpr (FP8)
+            {
+                // gate / up as the W4A8 Linear stores them (bf16(float(bf16(acc * sB)) * s_m)), then the GeGLU kernel's product
+                const float ws = *p.w_scale, ts = p.x_scales[m];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = gelu_tanh(round_bf16(round_bf16(acc[0][hB][pt][qt][e] * ws) * ts)) * round_bf16(round_bf16(acc[1][hB][pt][qt][e] * ws) * ts);
+            }
+            else
+            {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = gelu_tanh(round_bf16(acc[0][hB][pt][qt][e])) * round_bf16(acc[1][hB][pt][qt][e]);
+            }
+            return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        };
 #pragma unroll
         for (int hB = 0; hB < 2; ++hB)
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt)
+            for (int pp = 0; pp < 4; pp += 2)
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
                 {
-                    const int n = n0 + wr * 64 + pt * 16 + 4 * g;
                     const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                    float v[4];
-                    if constexpr (FP8)
-                    {
-                        // gate / up as the W4A8 Linear stores them (bf16(float(bf16(acc * sB)) * s_m)), then the GeGLU kernel's product
-                        const float ws = *p.w_scale, ts = p.x_scales[m];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            v[e] = gelu_tanh(round_bf16(round_bf16(acc[0][hB][pt][qt][e] * ws) * ts)) * round_bf16(round_bf16(acc[1][hB][pt][qt][e] * ws) * ts);
-                    }
-                    else
-                    {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            v[e] = gelu_tanh(round_bf16(acc[0][hB][pt][qt][e])) * round_bf16(acc[1][hB][pt][qt][e]);
-                    }
-                    *reinterpret_cast<u32x2*>(p.Y + (size_t)m * p.N + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    store_pair16(p.Y + (size_t)m * p.N + n0 + wr * 64 + pp * 16, g, out4(hB, pp, qt, m), out4(hB, pp + 1, qt, m));
                 }
     }
     else
     {
+        auto out4 = [&](int hA, int hB, int pt, int qt, int m, int n) -> u32x2 {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[hA][hB][pt][qt][e];
+            if constexpr (FP8)
+            {
+                // the reference's two steps: the GEMM stores bf16(acc * weight scale), the per-token pass rescales (+ bias)
+                const float ws = *p.w_scale, ts = p.x_scales[m];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                {
+                    v[e] = round_bf16(v[e] * ws) * ts;
+                    if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
+                }
+            }
+            else if (p.bias)
+            {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
+            }
+            return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        };
 #pragma unroll
         for (int hA = 0; hA < 2; ++hA)
 #pragma unroll
             for (int hB = 0; hB < 2; ++hB)
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt)
+                for (int pp = 0; pp < 4; pp += 2)
 #pragma unroll
                     for (int qt = 0; qt < 2; ++qt)
                     {
-                        const int n = n0 + hA * 128 + wr * 64 + pt * 16 + 4 * g;
+                        const int nb = n0 + hA * 128 + wr * 64 + pp * 16;       // first column of sub-tile pp
                         const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[hA][hB][pt][qt][e];
-                        if constexpr (FP8)
-                        {
-                            // the reference's two steps: the GEMM stores bf16(acc * weight scale), the per-token pass rescales (+ bias)
-                            const float ws = *p.w_scale, ts = p.x_scales[m];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                            {
-                                v[e] = round_bf16(v[e] * ws) * ts;
-                                if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
-                            }
-                        }
-                        else if (p.bias)
-                        {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
-                        }
-                        *reinterpret_cast<u32x2*>(p.Y + (size_t)m * p.N + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        store_pair16(p.Y + (size_t)m * p.N + nb, g, out4(hA, hB, pp, qt, m, nb + 4 * g), out4(hA, hB, pp + 1, qt, m, nb + 16 + 4 * g));
                     }
     }
 }
@@ -426,7 +445,8 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
         {
             const int chunk = i * 8 + wave;
             const int row = chunk * 8 + srow;
-            const int kslot = sslot ^ ((row >> 1) & 7);
+            const int lslot = sslot ^ ((row >> 1) & 7);
+            const int kslot = FP8 ? (((lslot & 3) << 1) | (lslot >> 2)) : lslot;      // as in gemm256_kernel
             int grow = row;                                   // global row of `base`
             if (which == 0)
             {
@@ -448,7 +468,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             for (int d = 0; d < 2; ++d) acc[b][c][d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     s16x8 fa[4][2], fb[2][2], fb1[PP ? 2 : 1][2];          // PP keeps the fragments of both X halves live
-    auto frag_slot = [&](int ks) { return FP8 ? (2 * g + ks) : (ks * 4 + g); };
+    auto frag_slot = [&](int ks) { return ks * 4 + g; };
     auto load_a = [&](int kt) {
         const unsigned char* hb = smem + (kt % 3) * kStage3Bytes;
 #pragma unroll
@@ -552,60 +572,63 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
 
     if constexpr (GEGLU)
     {
+        auto out4 = [&](int hB, int pt, int qt, int m) -> u32x2 {
+            float v[4];
+            if constexpr (FP8)
+            {
+                const float ws = *p.w_scale, ts = p.x_scales[m];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = gelu_tanh(round_bf16(round_bf16(acc[hB][pt][qt][e] * ws) * ts)) * round_bf16(round_bf16(acc[hB][pt + 2][qt][e] * ws) * ts);
+            }
+            else
+            {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(round_bf16(acc[hB][pt][qt][e])) * round_bf16(acc[hB][pt + 2][qt][e]);
+            }
+            return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        };
 #pragma unroll
         for (int hB = 0; hB < 2; ++hB)
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
-                {
-                    const int n = n0 + wr * 32 + pt * 16 + 4 * g;
-                    const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                    float v[4];
-                    if constexpr (FP8)
-                    {
-                        const float ws = *p.w_scale, ts = p.x_scales[m];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            v[e] = gelu_tanh(round_bf16(round_bf16(acc[hB][pt][qt][e] * ws) * ts)) * round_bf16(round_bf16(acc[hB][pt + 2][qt][e] * ws) * ts);
-                    }
-                    else
-                    {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(round_bf16(acc[hB][pt][qt][e])) * round_bf16(acc[hB][pt + 2][qt][e]);
-                    }
-                    *reinterpret_cast<u32x2*>(p.Y + (size_t)m * p.N + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                }
+            for (int qt = 0; qt < 2; ++qt)
+            {
+                const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                store_pair16(p.Y + (size_t)m * p.N + n0 + wr * 32, g, out4(hB, 0, qt, m), out4(hB, 1, qt, m));
+            }
         return;
     }
+    auto out4 = [&](int hB, int pt, int qt, int m, int n) -> u32x2 {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[hB][pt][qt][e];
+        if constexpr (FP8)
+        {
+            const float ws = *p.w_scale, ts = p.x_scales[m];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+            {
+                v[e] = round_bf16(v[e] * ws) * ts;
+                if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
+            }
+        }
+        else if (p.bias)
+        {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
+        }
+        return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    };
 #pragma unroll
     for (int hB = 0; hB < 2; ++hB)
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt)
+        for (int pp = 0; pp < 4; pp += 2)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
             {
-                const int n = n0 + wr * 64 + pt * 16 + 4 * g;
+                const int nb = n0 + wr * 64 + pp * 16;
                 const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[hB][pt][qt][e];
-                if constexpr (FP8)
-                {
-                    const float ws = *p.w_scale, ts = p.x_scales[m];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                    {
-                        v[e] = round_bf16(v[e] * ws) * ts;
-                        if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
-                    }
-                }
-                else if (p.bias)
-                {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
-                }
-                *reinterpret_cast<u32x2*>(p.Y + (size_t)m * p.N + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                store_pair16(p.Y + (size_t)m * p.N + nb, g, out4(hB, pp, qt, m, nb + 4 * g), out4(hB, pp + 1, qt, m, nb + 16 + 4 * g));
             }
 }
 
