@@ -71,6 +71,11 @@ def build(force=False, verbose=False):
     lib = os.path.join(LIBDIR, "libmila_cdna4.so")
     if force or jobs or _newer(lib, objs):
         _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs)
+        # a kernel whose host stub the compiler dropped (seen with lambdas capturing arrays inside a kernel template: no diagnostic) only fails at dlopen
+        missing = [ln for ln in _run(["nm", "-u", lib]).splitlines() if "__device_stub__" in ln]
+        if missing:
+            os.remove(lib)
+            raise RuntimeError("kernels without a host stub in %s:\n%s" % (lib, "\n".join(missing)))
 
     # C++ host mirror (template surface + model runners) -> libmila_host.so
     host_src = os.path.join(HOST, "src")

@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include <type_traits>
 #include "internal.h"
 
 namespace mila {
@@ -278,6 +279,15 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
     }
 }
 
+// Diagnostic build only (-DMILA_FLASH_STAMPS, never the product library): wave 0 of workgroup 0 of flash_prefill_kernel_s1 accumulates the shader cycles of each
+// segment of its tile loop (wait + barrier | staging issue | QK^T | softmax | PV) into g_flash_stamps; read back with mila_dbg_flash_stamps().
+#ifdef MILA_FLASH_STAMPS
+__device__ unsigned long long g_flash_stamps[8];
+#define FLASH_STAMP(i) do { if (stamping) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); seg[i] += now_ - last_; last_ = now_; } } while (0)
+#else
+#define FLASH_STAMP(i) do { } while (0)
+#endif
+
 // Single-staging form (one register set, next tile's loads in flight during the current tile's math): HS = 512, where the
 // accumulators (128 VGPRs) and Q fragments (64) leave no room for a second staging set.
 // HB = heads per workgroup (1, 2 or 4); QB = 4 / HB query sub-tiles of 16 rows
@@ -358,17 +368,34 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
     const uint16_t* kbase = p.K + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride;
     const uint16_t* vbase = p.V + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride;
 
+    const bool ring = pos_last >= p.capacity;                   // uniform: only a bounded ring wraps inside one prefill
     // K / V tiles go global -> LDS by LDS-DMA, no staging registers: wave w requests rows w, w + 4, ... of a tile, one row per instruction; a lane's LDS slot
     // is linear (M0 base + 16 lane), so the swizzle of k_off / v_off -- an involution on the chunk index -- is applied to the SOURCE chunk it fetches.
     // Every tile requests all its rows, so the request counts the waits rely on are constant: a row beyond the last key any row of this workgroup may see
     // re-reads that last key (a finite in-band row; the mask works on key positions, not contents).
+    // Source addresses: a tile that lies whole below pos_last on an unwrapped cache (all but the last one or two) is fetched from the lane's first-tile address
+    // advanced by whole tiles -- one 64-bit add per instruction instead of the clamp / modulo / 64-bit multiply chain.  A wave's consecutive instructions are
+    // STEP rows apart and the swizzles repeat every 16 rows, so instructions i and i + 16 / STEP differ by exactly 16 rows: one or two first addresses per
+    // matrix (element offsets from kbase / vbase) cover them all.  (Kept in scalars, not arrays: this compiler silently drops the kernel's host stub when a
+    // lambda captures an array declared here.)
+    constexpr int STEP = RPI * NW, NB = 16 / STEP;
+    static_assert(!DB || NB == 1 || NB == 2, "the double-buffered forms issue whole 16-row groups per one or two instructions");
+    int64_t ks0 = 0, ks1 = 0, vs0 = 0, vs1 = 0;
+    {
+        const int slot = lane % CPR;
+        const int r0 = RPI * wave + lane / CPR, r1 = r0 + STEP;
+        ks0 = (int64_t)(kt0 + r0) * p.kv_r_stride + ((k_off<HS>(r0, slot) - r0 * ROWB) >> 4) * 8;
+        vs0 = (int64_t)(kt0 + r0) * p.kv_r_stride + ((v_off<HS>(r0, slot) - r0 * ROWB) >> 4) * 8;
+        ks1 = (int64_t)(kt0 + r1) * p.kv_r_stride + ((k_off<HS>(r1, slot) - r1 * ROWB) >> 4) * 8;
+        vs1 = (int64_t)(kt0 + r1) * p.kv_r_stride + ((v_off<HS>(r1, slot) - r1 * ROWB) >> 4) * 8;
+    }
     auto stage_k = [&](int kt, unsigned char* ldsK) {
 #pragma unroll
         for (int i = 0; i < DMAS; ++i)
         {
             const int row0 = RPI * (NW * i + wave);                       // the instruction's first row: RPI consecutive rows = 1 KiB of LDS
             const int row = row0 + lane / CPR, slot = lane % CPR, pos = min(kt + row, pos_last);
-            const uint16_t* src = kbase + (size_t)(pos % p.capacity) * p.kv_r_stride + (size_t)((k_off<HS>(row, slot) - row * ROWB) >> 4) * 8;
+            const uint16_t* src = kbase + (size_t)(ring ? pos % p.capacity : pos) * p.kv_r_stride + (size_t)((k_off<HS>(row, slot) - row * ROWB) >> 4) * 8;
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(ldsK + row0 * ROWB), 16, 0, 0);
         }
     };
@@ -378,43 +405,97 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
         {
             const int row0 = RPI * (NW * i + wave);
             const int row = row0 + lane / CPR, slot = lane % CPR, pos = min(kt + row, pos_last);
-            const uint16_t* src = vbase + (size_t)(pos % p.capacity) * p.kv_r_stride + (size_t)((v_off<HS>(row, slot) - row * ROWB) >> 4) * 8;
+            const uint16_t* src = vbase + (size_t)(ring ? pos % p.capacity : pos) * p.kv_r_stride + (size_t)((v_off<HS>(row, slot) - row * ROWB) >> 4) * 8;
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(ldsV + row0 * ROWB), 16, 0, 0);
         }
     };
+    // Per-lane LDS offsets of the fragment reads, once: the swizzles touch only the low four bits of the chunk index, so the offsets repeat every 16 chunks
+    // (256 bytes) and the second 16-key group of a tile is 16 rows further: four K and eight V offsets per lane, everything else is an immediate.
+    int kaddr[4], vaddr[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kaddr[i] = k_off<HS>(l15, 4 * i + g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+        const int col = 16 * (dsel * DT + i) + 4 * (l15 & 3);          // lane 4 q + pp of a 16-lane group supplies row q, columns 4 pp .. 4 pp + 3 of the block
+        vaddr[i] = v_off<HS>(4 * g + (l15 >> 2), col >> 3) + ((col & 7) << 1);
+    }
+    const int wpos0 = p.pos_offset + wq0;                        // position of this wave's first row (uniform)
+    const bool rows_ok = wq0 + 16 <= p.Tq;
+
     // Two barriers per tile.  B1: K(t) has landed everywhere and every wave is done with V(t - 1) -> request V(t), multiply K(t) Q^T under it.
     // B2: V(t) has landed everywhere and every wave is done with K(t) -> request K(t + 1), softmax and the PV product under it.
     // Double-buffered forms: one barrier per tile, tile t + 1 requested into the other buffer right behind it.
+    // The tile body is instantiated per buffer (tiles alternate), so every LDS address is a per-lane offset + an immediate.
     stage_k(kt0, smem);
     if constexpr (DB) stage_v(kt0, smem + TILE_BYTES);
-    for (int t = 0; t < ntiles; ++t)
-    {
+#ifdef MILA_FLASH_STAMPS
+    const bool stamping = blockIdx.x == 0 && wave == 0;
+    unsigned long long seg[5] = {0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long first_ = last_;
+#endif
+    auto tile_body = [&](int t, auto buf_c) {
+        constexpr int BUF = DB ? decltype(buf_c)::value : 0;
         const int kt = kt0 + t * kKeysPerTile;
-        unsigned char* ldsK = smem + (DB ? (t & 1) * 2 * TILE_BYTES : 0);
+        unsigned char* ldsK = smem + BUF * 2 * TILE_BYTES;
         unsigned char* ldsV = ldsK + TILE_BYTES;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows of tile t (NW = 4: its K rows; nothing else is in flight here)
         __syncthreads();
-        if constexpr (DB)
-        {
-            if (t + 1 < ntiles)
-            {
-                unsigned char* nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-                stage_k(kt + kKeysPerTile, nxt);
-                stage_v(kt + kKeysPerTile, nxt + TILE_BYTES);
-            }
-        }
-        else stage_v(kt, ldsV);
+        FLASH_STAMP(0);
 
-        // ---- S^T = K Q^T : two 16-key groups ----
+        // ---- S^T = K Q^T : two 16-key groups; the fragments of eight k-steps are requested together, then multiplied.  The next tile's staging is issued
+        // between the first requests and their use: its address arithmetic runs under the LDS latency ----
         f32x4 s0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0;
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
+        for (int s8 = 0; s8 < KSTEPS; s8 += 8)
         {
-            // A operand: K[key l15 (+16)][32 s + 8 g .. +7] -> chunk 4 s + g
-            const s16x8 ka = *reinterpret_cast<const s16x8*>(ldsK + k_off<HS>(l15, 4 * s + g));
-            const s16x8 kb = *reinterpret_cast<const s16x8*>(ldsK + k_off<HS>(16 + l15, 4 * s + g));
-            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka), __builtin_bit_cast(bf16x8, qf[s]), s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb), __builtin_bit_cast(bf16x8, qf[s]), s1, 0, 0, 0);
+            s16x8 ka[8], kb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                // A operand: K[key l15 (+16)][32 s + 8 g .. +7] -> chunk 4 s + g
+                const int s_ = s8 + j;
+                ka[j] = *reinterpret_cast<const s16x8*>(ldsK + kaddr[s_ & 3] + (s_ >> 2) * 256);
+                kb[j] = *reinterpret_cast<const s16x8*>(ldsK + kaddr[s_ & 3] + (s_ >> 2) * 256 + 16 * ROWB);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s8 == 0)
+            {
+                if constexpr (DB)
+                {
+                    if (t + 1 < ntiles)
+                    {
+                        unsigned char* nxt = smem + (BUF ^ 1) * 2 * TILE_BYTES;
+                        const int ktn = kt + kKeysPerTile;
+                        if (!ring && ktn + kKeysPerTile - 1 <= pos_last)
+                        {
+                            const int64_t adv = (int64_t)(ktn - kt0) * p.kv_r_stride;
+#pragma unroll
+                            for (int i = 0; i < DMAS; ++i)
+                                __builtin_amdgcn_global_load_lds(kbase + (((NB == 2 && (i & 1)) ? ks1 : ks0) + adv + (int64_t)(i / NB) * 16 * p.kv_r_stride),
+                                                                 (__attribute__((address_space(3))) void*)(nxt + RPI * (NW * i + wave) * ROWB), 16, 0, 0);
+#pragma unroll
+                            for (int i = 0; i < DMAS; ++i)
+                                __builtin_amdgcn_global_load_lds(vbase + (((NB == 2 && (i & 1)) ? vs1 : vs0) + adv + (int64_t)(i / NB) * 16 * p.kv_r_stride),
+                                                                 (__attribute__((address_space(3))) void*)(nxt + TILE_BYTES + RPI * (NW * i + wave) * ROWB), 16, 0, 0);
+                        }
+                        else
+                        {
+                            stage_k(ktn, nxt);
+                            stage_v(ktn, nxt + TILE_BYTES);
+                        }
+                    }
+                }
+                else stage_v(kt, ldsV);
+                FLASH_STAMP(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s1, 0, 0, 0);
+            }
         }
         if constexpr (!DB)
         {
@@ -422,18 +503,40 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
             __syncthreads();                                     // every wave is done with K(t), and V(t) is complete
             if (t + 1 < ntiles) stage_k(kt + kKeysPerTile, ldsK);      // in flight during the softmax and the PV product
         }
+        // ---- V^T fragments of the wave's d tiles, requested here so that they land under the softmax ----
+        // A operand: V^T[dim 16 d + l15][keys]: two transposing reads (keys 4 g .. and 16 + 4 g ..)
+        s16x4 vlo[DT], vhi[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+        {
+            vlo[d] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + vaddr[d & 7] + (d >> 3) * 256));
+            vhi[d] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + vaddr[d & 7] + (d >> 3) * 256 + 16 * ROWB));
+        }
+#ifdef MILA_FLASH_STAMPS
+        if (stamping && s0[0] == 12345.678f) seg[4] += 1;          // the stamp waits for the products
+#endif
+        FLASH_STAMP(2);
         // lane holds keys kt + 4 g + r (s0) and kt + 16 + 4 g + r (s1) of query row l15
         float sv[8];
-        float mt = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
+        // a tile every row of this wave sees whole (the interior of the band: most tiles) needs no mask
+        const bool whole = rows_ok && kt + kKeysPerTile - 1 <= wpos0 && (p.window == 0 || kt > wpos0 + 15 - p.window);
+        if (whole)
         {
-            const int key = kt + ((r < 4) ? (4 * g + r) : (16 + 4 * g + (r - 4)));
-            const float raw = (r < 4) ? s0[r] : s1[r - 4];
-            const bool vis = row_valid && key <= my_pos && (p.window == 0 || key > my_pos - p.window);
-            sv[r] = vis ? raw * p.scale : -INFINITY;
-            mt = fmaxf(mt, sv[r]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sv[r] = ((r < 4) ? s0[r] : s1[r - 4]) * p.scale;
         }
+        else
+        {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+            {
+                const int key = kt + ((r < 4) ? (4 * g + r) : (16 + 4 * g + (r - 4)));
+                const float raw = (r < 4) ? s0[r] : s1[r - 4];
+                const bool vis = row_valid && key <= my_pos && (p.window == 0 || key > my_pos - p.window);
+                sv[r] = vis ? raw * p.scale : -INFINITY;
+            }
+        }
+        float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
         mt = quad_rows_max(mt);                                 // the row's other keys sit on lanes l ^ 16, l ^ 32, l ^ 48
         const float mn = fmaxf(m_run, mt);
         const float msafe = (mn == -INFINITY) ? 0.0f : mn;      // row with nothing visible yet
@@ -455,29 +558,41 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
         pb[2] = pack_bf16x2(pe[4], pe[5]);
         pb[3] = pack_bf16x2(pe[6], pe[7]);
         const bf16x8 pfrag = __builtin_bit_cast(bf16x8, pb);
-        const bool rescale = __any(alpha != 1.0f);
+        // the running maximum of a row moves in its first tiles and then rarely: the accumulators are rescaled only in a tile where some row's did
+        // (a real branch: alpha is exactly 1 everywhere otherwise, so skipping the multiplications changes no bit)
+        if (__any(alpha != 1.0f))
+        {
+#pragma unroll
+            for (int d = 0; d < DT; ++d) { o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha; }
+            asm volatile("" ::: "memory");                     // keeps the block a branch target (no if-conversion into 4 DT selects)
+        }
+        FLASH_STAMP(3);
 #pragma unroll
         for (int d = 0; d < DT; ++d)
         {
-            // A operand: V^T[dim 16 d + l15][keys as above] via the transposing read:
-            // lane 4 q + pp of a 16-lane group supplies row q, columns 4 pp .. 4 pp + 3 of the block
-            const int q4 = l15 >> 2, pp = l15 & 3;
-            const int col = 16 * (dsel * DT + d) + 4 * pp;     // first of 4 columns (8 bytes)
-            const int r_lo = 4 * g + q4, r_hi = 16 + 4 * g + q4;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4*)(ldsV + v_off<HS>(r_lo, col >> 3) + ((col & 7) << 1)));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4*)(ldsV + v_off<HS>(r_hi, col >> 3) + ((col & 7) << 1)));
             s16x8 va;
-            va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3];
-            va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
-            if (rescale)
-            {
-                o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha;
-            }
+            va[0] = vlo[d][0]; va[1] = vlo[d][1]; va[2] = vlo[d][2]; va[3] = vlo[d][3];
+            va[4] = vhi[d][0]; va[5] = vhi[d][1]; va[6] = vhi[d][2]; va[7] = vhi[d][3];
             o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), pfrag, o[d], 0, 0, 0);
         }
+#ifdef MILA_FLASH_STAMPS
+        if (stamping && o[DT - 1][0] == 12345.678f) seg[0] += 1;
+#endif
+        FLASH_STAMP(4);
+    };
+    for (int t = 0; t < ntiles; t += 2)
+    {
+        tile_body(t, std::integral_constant<int, 0>{});
+        if (t + 1 < ntiles) tile_body(t + 1, std::integral_constant<int, 1>{});
     }
+#ifdef MILA_FLASH_STAMPS
+    if (stamping && lane == 0)
+    {
+        for (int i = 0; i < 5; ++i) g_flash_stamps[i] = seg[i];
+        g_flash_stamps[5] = (unsigned long long)ntiles;
+        g_flash_stamps[6] = __builtin_amdgcn_s_memtime() - first_;
+    }
+#endif
 
     // ---- epilogue: O^T[dim 16 d + 4 g + r][row l15] -> Y[row][h*HS + dim] ----
     if (row_valid)
@@ -625,3 +740,10 @@ int mila_cdna4_mha_bf16(uint16_t* Y, const uint16_t* QKV, int B, int T, int C, i
 }
 
 }  // extern "C"
+
+#ifdef MILA_FLASH_STAMPS
+extern "C" MILA_API int mila_dbg_flash_stamps(unsigned long long* out8)
+{
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(mila::g_flash_stamps), 8 * sizeof(unsigned long long));
+}
+#endif
