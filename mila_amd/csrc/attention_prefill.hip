@@ -443,15 +443,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
         __syncthreads();
         FLASH_STAMP(0);
 
-        // ---- S^T = K Q^T : two 16-key groups; the fragments of eight k-steps are requested together, then multiplied.  The next tile's staging is issued
+        // ---- S^T = K Q^T : two 16-key groups; the fragments of KB k-steps are requested together, then multiplied.  The next tile's staging is issued
         // between the first requests and their use: its address arithmetic runs under the LDS latency ----
         f32x4 s0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0;
+        constexpr int KB = (HS >= 512) ? 4 : 8;                  // k-steps whose fragments are fetched together (registers: HS = 512 holds 64 of Q)
 #pragma unroll
-        for (int s8 = 0; s8 < KSTEPS; s8 += 8)
+        for (int s8 = 0; s8 < KSTEPS; s8 += KB)
         {
-            s16x8 ka[8], kb[8];
+            s16x8 ka[KB], kb[KB];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < KB; ++j)
             {
                 // A operand: K[key l15 (+16)][32 s + 8 g .. +7] -> chunk 4 s + g
                 const int s_ = s8 + j;
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < KB; ++j)
             {
                 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s1, 0, 0, 0);
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
     }
 }
 
-static int g_tune_flash_form = 8;      // tuning hook (mila_cdna4_tune_flash_dsplit): 8 = the LDS-DMA forms (default: 8-wave workgroups at HS = 512, double-buffered
+static int g_tune_flash_form = 8;      // tuning hook (mila_cdna4_tune_flash_dsplit): 8 = the LDS-DMA forms (default: 8-wave workgroups at HS = 512, double-buffered; 9 = 8 with 8-wave workgroups at HS = 256 too
                                        // 4-wave ones at HS = 256), 2 = HS = 512 as 4-wave d-split workgroups, 1 = the register-staged kernels
 
 // the register-staged kernels (HS <= 256; every head size under form 1)
@@ -655,11 +656,12 @@ static int dispatch_hb(const FlashParams& p, int B, hipStream_t s)
     }
     if constexpr (HS == 256)
     {
-        // 8-wave workgroups (2 heads x 4 row blocks = 64 query rows on one double-buffered K / V tile stream, one workgroup per CU) do 1.4x the work per tile
-        // load of the 4-wave form, but there are only as many of them as CUs at T = 2048, so a causal ramp leaves half the chip waiting for the last tiles:
-        // they are used when at least half the chunk's rows see a full window (every row's work is then the same).  76 vs 82 us on Gemma's sliding-window
-        // shape.  (The d-split does not pay at this head size: 2 heads x 2 row blocks x 2 d-halves, four waves per SIMD, measured 92.7 us.)
-        if (g_tune_flash_form >= 8 && GS % 2 == 0 && p.window > 0 && p.pos_offset + p.Tq / 2 >= p.window) return launch_flash_dma<HS, 2, 1, 8>(p, B, s);
+        // Double-buffered 4-wave workgroups, two per CU (their phases drift apart, so one's softmax runs under the other's products): 58 us on Gemma's
+        // sliding-window shape at T = 2048.  The 8-wave form (2 heads x 4 row blocks on one tile stream, one workgroup per CU: 1.4x the work per tile load, but
+        // its eight waves move in lockstep) was the faster one -- 76 vs 82 us -- while the tile body was bound by its vector ALU work; with the lean body it
+        // is the slower one (62 us) and stays behind tuning form 9 where at least half the chunk's rows see a full window.  (A d-split does not pay at this
+        // head size: 92.7 us.)
+        if (g_tune_flash_form == 9 && GS % 2 == 0 && p.window > 0 && p.pos_offset + p.Tq / 2 >= p.window) return launch_flash_dma<HS, 2, 1, 8>(p, B, s);
         if (g_tune_flash_form >= 8)
         {
             if (GS % 4 == 0) return launch_flash_dma<HS, 4, 1, 4>(p, B, s);
@@ -718,7 +720,7 @@ int mila_cdna4_attn_prefill_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t*
 int mila_cdna4_tune_flash_dsplit(int ds)
 {
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
-    MILA_REQUIRE(ds == 1 || ds == 2 || ds == 8, "tune_flash_dsplit: 1, 2 or 8");
+    MILA_REQUIRE(ds == 1 || ds == 2 || ds == 8 || ds == 9, "tune_flash_dsplit: 1, 2, 8 or 9");
     g_tune_flash_form = ds;
     return MILA_OK;
 }

@@ -1,5 +1,5 @@
-"""Time the flash prefill kernel on the Gemma-4 12B attention shapes (T = 2048).  MILA_FLASH_DBG skips parts of the kernel
-(1 softmax, 2 PV, 4 QK, 8 staging; results are then meaningless) to see where the time goes."""
+"""Time the flash prefill kernel on the Gemma-4 12B attention shapes (T = 2048).  MILA_FLASH_DSPLIT selects a kernel form (tuning hook);
+where the cycles of a tile go: tools/experiments/flash_stamps.sh + flash_stamps.py (a diagnostic build with in-kernel stamps)."""
 import json, os, sys
 os.environ.setdefault("MILA_CDNA4_TUNING", "1")
 import torch
@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mila_amd import capi
 T = 2048
 if os.environ.get("MILA_FLASH_DSPLIT"):
-    capi.check(capi.load().mila_cdna4_tune_flash_dsplit(int(os.environ["MILA_FLASH_DSPLIT"])))      # 1: one wave per head in the HS = 512 kernel; 2 (default): d-split
+    capi.check(capi.load().mila_cdna4_tune_flash_dsplit(int(os.environ["MILA_FLASH_DSPLIT"])))      # 1: register-staged kernels; 2: HS = 512 as 4-wave d-split workgroups; 8 (default); 9: 8-wave workgroups at HS = 256 too
 for name, NH, NKV, HS, window in (("local", 16, 8, 256, 1024), ("global", 16, 1, 512, 0)):
     q = (torch.randn((T, NH * HS), device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)
     K = (torch.randn((1, NKV, T, HS), device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)
@@ -25,4 +25,4 @@ for name, NH, NKV, HS, window in (("local", 16, 8, 256, 1024), ("global", 16, 1,
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     keys = sum(min(t + 1, window) if window else t + 1 for t in range(T))
-    print(json.dumps({"shape": name, "dbg": os.environ.get("MILA_FLASH_DBG", "0"), "us": round(us, 1), "TFLOPs": round(4.0 * NH * HS * keys / us / 1e6, 1)}), flush=True)
+    print(json.dumps({"shape": name, "form": os.environ.get("MILA_FLASH_DSPLIT", "default"), "us": round(us, 1), "TFLOPs": round(4.0 * NH * HS * keys / us / 1e6, 1)}), flush=True)
