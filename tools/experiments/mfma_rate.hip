@@ -87,13 +87,13 @@ static int run(const char* name, double flops_per_mfma, int mfma_per_iter, int t
     std::vector<unsigned long long> h(2 * nwg);
     CK(hipMemcpy(h.data(), stamps, sizeof(unsigned long long) * 2 * nwg, hipMemcpyDeviceToHost));
     std::vector<double> cyc, clk;
-    for (int i = 0; i < nwg; ++i) { cyc.push_back((double)h[2 * i]); clk.push_back((double)h[2 * i] / ((double)h[2 * i + 1] * 10.0)); }   // s_memrealtime ticks at 100 MHz
+    for (int i = 0; i < nwg; ++i) { cyc.push_back((double)h[2 * i]); clk.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); }   // s_memrealtime ticks at 100 MHz: cycles per tick x 0.1 = GHz
     std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
     const int waves = threads / 64;
-    const double per_simd = (double)iters * mfma_per_iter * (waves / 4.0);
+    const double per_simd = (double)iters * mfma_per_iter;      // wave 0's own stream; its SIMD runs waves / 4 of them
     const double tf = flops_per_mfma * iters * mfma_per_iter * waves * nwg / (ms / reps * 1e-3) / 1e12;
-    printf("{\"mfma\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_mfma_per_simd\": %.2f, \"in_kernel_clock_GHz\": %.3f, \"wall_TFLOPs\": %.0f}\n", name, waves / 4,
-           cyc[nwg / 2] / per_simd, clk[nwg / 2] / 1e3 * 1e0, tf);
+    printf("{\"mfma\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_mfma_of_one_wave\": %.2f, \"in_kernel_clock_GHz\": %.3f, \"wall_TFLOPs\": %.0f}\n", name, waves / 4,
+           cyc[nwg / 2] / per_simd, clk[nwg / 2], tf);
     fflush(stdout);
     return 0;
 }
