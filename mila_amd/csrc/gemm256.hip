@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     // fragment registers: [ks] = the logical 16-B slot 4 ks + g of the row (bf16: k = 8 (4 ks + g) ..; fp8: source chunk 2 g + ks, the halves of one 32-byte operand)
-    constexpr bool P2 = PP == 2;            // two phases per K-tile
+    constexpr bool P2 = PP >= 2;            // two phases per K-tile (PP == 3: static priority for waves 4-7 instead of a raise around every MFMA block)
     s16x8 fa[4][2], fb[2][2], fb1[P2 ? 2 : 1][2];
     auto frag_slot = [&](int ks) { return ks * 4 + g; };
     auto load_a = [&](int kt, int hA) {
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     };
     auto mma = [&](int hA, int hB) {
         s16x8 (&fbx)[2][2] = *((P2 && hB == 1) ? reinterpret_cast<s16x8 (*)[2][2]>(&fb1) : &fb);
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (PP != 3) __builtin_amdgcn_s_setprio(1);
         if constexpr (FP8)
         {
 #pragma unroll
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                         acc[hA][hB][pt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, fa[pt][ks]), __builtin_bit_cast(bf16x8, fbx[qt][ks]), acc[hA][hB][pt][qt], 0, 0, 0);
         }
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (PP != 3) __builtin_amdgcn_s_setprio(0);
     };
     // end of a phase: retire everything but the 3 youngest half-tiles, then let every wave see it
     auto phase_end = [&](bool steady) {
@@ -225,6 +225,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
         };
+        if constexpr (PP == 3) { if (wr == 1) __builtin_amdgcn_s_setprio(1); }
         if (wr == 1) __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nk; ++t)
         {
@@ -413,7 +414,7 @@ constexpr int kStage3Bytes = 3 * kHalfBytes;   // W, X0, X1
 // waves 4-7 one barrier behind waves 0-3.  RAW: K-tile t + 1 is waited for (vmcnt(6)) at the end of the reads of phase t and read in
 // phase t + 1; WAR: ring slot (t + 2) % 3 held K-tile t - 1, whose reads every wave retired before barrier A(t - 1), and group 0
 // restages it behind B(t - 1) = group 1's A(t - 1).
-template <bool FP8, bool GEGLU, bool PP>
+template <bool FP8, bool GEGLU, int PP>      // PP: 0 lockstep, 1 staggered groups, 2 staggered with a static priority for waves 4-7
 __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     };
     auto mma = [&](int hB) {
         s16x8 (&fbx)[2][2] = *((PP && hB == 1) ? reinterpret_cast<s16x8 (*)[2][2]>(&fb1) : &fb);
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (PP != 2) __builtin_amdgcn_s_setprio(1);
         if constexpr (FP8)
         {
 #pragma unroll
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                         acc[hB][pt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, fa[pt][ks]), __builtin_bit_cast(bf16x8, fbx[qt][ks]), acc[hB][pt][qt], 0, 0, 0);
         }
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (PP != 2) __builtin_amdgcn_s_setprio(0);
     };
 
     stage_all(0);
@@ -531,8 +532,9 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    if constexpr (PP)
+    if constexpr (PP != 0)
     {
+        if constexpr (PP == 2) { if (wr == 1) __builtin_amdgcn_s_setprio(1); }
         if (wr == 1) __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nk; ++t)
         {
@@ -643,7 +645,7 @@ bool gemm256x128_applicable(int M, int K, int N)
 
 extern int g_gemm_pingpong;
 
-template <bool FP8, bool GEGLU, bool PP>
+template <bool FP8, bool GEGLU, int PP>
 static int launch_gemm256x128_tt(const Gemm256Params& p, hipStream_t s)
 {
     static bool attr_set = false;
@@ -660,7 +662,8 @@ static int launch_gemm256x128_tt(const Gemm256Params& p, hipStream_t s)
 template <bool FP8, bool GEGLU = false>
 static int launch_gemm256x128_t(const Gemm256Params& p, hipStream_t s)
 {
-    return g_gemm_pingpong ? launch_gemm256x128_tt<FP8, GEGLU, true>(p, s) : launch_gemm256x128_tt<FP8, GEGLU, false>(p, s);
+    if (g_gemm_pingpong == 5) return launch_gemm256x128_tt<FP8, GEGLU, 2>(p, s);
+    return g_gemm_pingpong ? launch_gemm256x128_tt<FP8, GEGLU, 1>(p, s) : launch_gemm256x128_tt<FP8, GEGLU, 0>(p, s);
 }
 int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
 {
@@ -677,9 +680,11 @@ bool gemm256_applicable(int M, int K, int N)
     return tiles >= 200 && tiles >= 0.85 * rounds * kNumCU;
 }
 
-int g_gemm_pingpong = 4;      // tuning hook (mila_cdna4_tune_gemm_schedule): 0 = all eight waves in lockstep; 1 = staggered (ping-pong), four phases per
+int g_gemm_pingpong = 5;      // tuning hook (mila_cdna4_tune_gemm_schedule): 0 = all eight waves in lockstep; 1 = staggered (ping-pong), four phases per
                               // K-tile in the 256 x 256 kernel; 2 = 1 + prefer the 256 x 128 ring; 3 = staggered, two phases per K-tile in the
-                              // 256 x 256 kernel; 4 (default) = 3 + fp8 x fp8 shapes take the 256 x 256 kernel wherever it applies
+                              // 256 x 256 kernel; 4 = 3 + fp8 x fp8 shapes take the 256 x 256 kernel wherever it applies; 5 (default) = 4 with ONE
+                              // s_setprio 1 for waves 4-7 (the later-dispatched half loses every issue arbitration by age) instead of a raise around
+                              // every MFMA block: 0.5-1 % on each bf16 shape, nothing on fp8; same bits
 
 template <int MODE, int PP>
 static int launch_gemm256_tt(const Gemm256Params& p, hipStream_t s)
@@ -698,6 +703,7 @@ static int launch_gemm256_tt(const Gemm256Params& p, hipStream_t s)
 template <int MODE>
 static int launch_gemm256_t(const Gemm256Params& p, hipStream_t s)
 {
+    if (g_gemm_pingpong == 5) return launch_gemm256_tt<MODE, 3>(p, s);
     if (g_gemm_pingpong >= 3) return launch_gemm256_tt<MODE, 2>(p, s);
     return g_gemm_pingpong ? launch_gemm256_tt<MODE, 1>(p, s) : launch_gemm256_tt<MODE, 0>(p, s);
 }
@@ -728,7 +734,7 @@ int gemm_fp8_kernel_for(int M, int K, int N)
     // at the fp8 rate the 4-barrier-per-K-tile 256 x 256 schedule is barrier-bound (1.36 PFLOP/s on fc_gate_up); the 3-stage
     // 256 x 128 ring (one barrier per K-tile) reaches 1.8-1.9, so it is preferred wherever its grid fills the chip
     if (K % 128 != 0) return 0;
-    if (g_gemm_pingpong == 4 && gemm256_applicable(M, K, N)) return 2;       // tuning: the two-phase 256 x 256 schedule for fp8 too
+    if (g_gemm_pingpong >= 4 && gemm256_applicable(M, K, N)) return 2;       // tuning: the two-phase 256 x 256 schedule for fp8 too
     if (gemm256x128_applicable(M, K, N)) return 1;
     if (gemm256_applicable(M, K, N)) return 2;
     return 0;
@@ -737,7 +743,7 @@ int gemm_fp8_kernel_for(int M, int K, int N)
 int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
                           hipStream_t s)
 {
-    if (M % 256 == 0 && F % 64 == 0 && gemm256x128_applicable(M, K, 2 * F) && !(g_gemm_pingpong == 4 && gemm256_geglu_applicable(M, K, F)))
+    if (M % 256 == 0 && F % 64 == 0 && gemm256x128_applicable(M, K, 2 * F) && !(g_gemm_pingpong >= 4 && gemm256_geglu_applicable(M, K, F)))
     {
         Gemm256Params q{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, M, K, F, M / 256, F / 64, x_scales, w_scale};
         return launch_gemm256x128_t<true, true>(q, s);

@@ -52,7 +52,7 @@ def main():
         t0 = timeit(ours)
         lib.mila_cdna4_tune_gemm_schedule(1)
         t1 = timeit(ours)
-        lib.mila_cdna4_tune_gemm_schedule(3)
+        lib.mila_cdna4_tune_gemm_schedule(5)      # the default: two phases per K-tile, static priority
         t2 = timeit(ours)
         i[0] = 0; ours()
         y3 = Y.clone()

@@ -18,7 +18,7 @@ for name, K, N in (("qkv_local", 3840, 8192), ("gate_up", 3840, 30720), ("o_loca
     W = ((torch.rand((N, K), device="cuda") * 2 - 1) / K ** 0.5).to(torch.bfloat16).view(torch.int16)
     Y = torch.empty((M, N), dtype=torch.int16, device="cuda")
     ref = None
-    for rep in range(2):
+    for rep in range(4):
         for sc in scheds:
             lib.mila_cdna4_tune_gemm_schedule(sc)
             for _ in range(5):
@@ -35,4 +35,4 @@ for name, K, N in (("qkv_local", 3840, 8192), ("gate_up", 3840, 30720), ("o_loca
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 30
             print(json.dumps({"shape": name, "schedule": sc, "rep": rep, "us": round(ms * 1e3, 1), "TFLOPs": round(2.0 * M * K * N / ms / 1e9, 1), "same_bits": same}), flush=True)
-lib.mila_cdna4_tune_gemm_schedule(4)
+lib.mila_cdna4_tune_gemm_schedule(5)      # the default
