@@ -103,6 +103,16 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostParams p)
     }
     float rstd;
     u32x4 xlo, xhi;
+    // the norm weights are requested with the row (they used to follow the reduction: a second round trip); rr is clamped, so the addresses are valid on
+    // every lane
+    u32x4 wlo = u32x4{0u, 0u, 0u, 0u}, whi = wlo;
+    if (w) { wlo = ld16(w + (size_t)gl * 8); whi = ld16(w + (size_t)(gl + hv) * 8); }
+    f32x4 c0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, c1 = c0, s0 = c0, s1 = c0;
+    if (rotate)
+    {
+        c0 = *reinterpret_cast<const f32x4*>(cos_row + gl * 8); c1 = *reinterpret_cast<const f32x4*>(cos_row + gl * 8 + 4);
+        s0 = *reinterpret_cast<const f32x4*>(sin_row + gl * 8); s1 = *reinterpret_cast<const f32x4*>(sin_row + gl * 8 + 4);
+    }
     if (hv <= 32)
     {
         xlo = ld16(src + (size_t)gl * 8);
@@ -121,15 +131,15 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const QkvPostParams p)
     u32x4 lo, hi;
     if (w)
     {
-        lo = rms_apply8(xlo, ld16(w + (size_t)gl * 8), rstd, 0.0f);
-        hi = rms_apply8(xhi, ld16(w + (size_t)(gl + hv) * 8), rstd, 0.0f);
+        lo = rms_apply8(xlo, wlo, rstd, 0.0f);
+        hi = rms_apply8(xhi, whi, rstd, 0.0f);
     }
     else
     {
         lo = rms_apply8_now(xlo, rstd);
         hi = rms_apply8_now(xhi, rstd);
     }
-    if (rotate) rope_rotate8_vals(lo, hi, cos_row, sin_row, gl * 8);
+    if (rotate) rope_rotate8_regs(lo, hi, c0, c1, s0, s1);
     st16(dst + (size_t)gl * 8, lo);
     st16(dst + (size_t)(gl + hv) * 8, hi);
 }

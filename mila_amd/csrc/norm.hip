@@ -58,12 +58,18 @@ __global__ __launch_bounds__(256) void tail_norm_kernel(uint16_t* __restrict__ R
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int nx16 = dim / 8, G = (nx16 + 63) / 64;
     // chunk c = 64 g + lane of group g = wib + 4 k: the assignment rms_rstd_block<4> uses
-    u32x4 av[NCH], rv[NCH];
+    // every operand of the row is requested up front: the residual and the two weight rows arrive under the first reduction instead of costing a second
+    // memory round trip behind its barrier
+    u32x4 av[NCH], rv[NCH], resv[NCH], pwv[NCH], nwv[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k)
     {
         const int c = 64 * (wib + 4 * k) + lane;
-        av[k] = ld16(a + (size_t)min(c, nx16 - 1) * 8);
+        const size_t e = (size_t)min(c, nx16 - 1) * 8;
+        av[k] = ld16(a + e);
+        resv[k] = ld16(res + e);
+        pwv[k] = ld16(post_w + e);
+        nwv[k] = next_w != nullptr ? ld16(next_w + e) : u32x4{0u, 0u, 0u, 0u};
     }
     {
 #pragma unroll
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256) void tail_norm_kernel(uint16_t* __restrict__ R
     {
         const int g = wib + 4 * k, c = 64 * g + lane;
         const size_t e = (size_t)min(c, nx16 - 1) * 8;
-        rv[k] = sandwich_tail8(rms_apply8(av[k], ld16(post_w + e), rstd_a, 0.0f), ld16(res + e), post_scale);
+        rv[k] = sandwich_tail8(rms_apply8(av[k], pwv[k], rstd_a, 0.0f), resv[k], post_scale);
         if (c < nx16) st16(R + row * dim + e, rv[k]);
         if (next_w != nullptr)
         {
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256) void tail_norm_kernel(uint16_t* __restrict__ R
     for (int k = 0; k < NCH; ++k)
     {
         const int c = 64 * (wib + 4 * k) + lane;
-        if (c < nx16) st16(XN + row * dim + (size_t)c * 8, rms_apply8(rv[k], ld16(next_w + (size_t)c * 8), rstd_r, 0.0f));
+        if (c < nx16) st16(XN + row * dim + (size_t)c * 8, rms_apply8(rv[k], nwv[k], rstd_r, 0.0f));
     }
 }
 
