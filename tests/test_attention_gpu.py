@@ -127,7 +127,17 @@ def test_decode_online_softmax_rescale_branch_is_exercised():
     assert_bf16_close(bits(Y), orc.gqa_attention(q, hk, hv, length - 1, 0, 1.0)[:, 0], 1, 2e-3, "spiked decode")
 
 
-@pytest.mark.parametrize("name,NH,NKV,HS,window,scale", GEOMS)
+# every workgroup shape of the LDS-DMA flash kernels: heads per workgroup follow the group size (4 | GS, 2 | GS, odd), at HS = 512 with the d-split
+FLASH_FORM_GEOMS = [
+    ("hs256_gs4", 8, 2, 256, 40, 1.0),
+    ("hs256_gs1", 2, 2, 256, 0, 0.5),
+    ("hs512_gs2", 4, 2, 512, 0, 1.0),
+    ("hs512_gs1", 2, 2, 512, 16, 1.0),
+    ("hs128_gs1", 2, 2, 128, 0, 1.0),
+]
+
+
+@pytest.mark.parametrize("name,NH,NKV,HS,window,scale", GEOMS + FLASH_FORM_GEOMS)
 def test_prefill_attention_chunked(name, NH, NKV, HS, window, scale):
     """two chunks with a position offset; local window smaller than the history"""
     rng = np.random.default_rng(HS + NH)
