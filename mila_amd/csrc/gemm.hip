@@ -272,6 +272,7 @@ bool gemm256_geglu_applicable(int M, int K, int F);
 int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s);
 static int g_gemm_force128 = 0;
 extern int g_gemm_pingpong;     // gemm256.hip
+extern int g_gemm_persistent;
 
 // which direct-to-LDS kernel serves a bf16-weight GEMM of this shape: 2 = 256 x 256, 1 = 256 x 128, 0 = none (128 x 128 register-staged)
 static int glds_kernel_for(int M, int K, int N)
@@ -403,7 +404,8 @@ int mila_cdna4_tune_gemm(int force_128_tile)
 int mila_cdna4_tune_gemm_schedule(int pingpong)
 {
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
-    g_gemm_pingpong = pingpong;
+    g_gemm_persistent = pingpong != 6;
+    g_gemm_pingpong = pingpong == 6 ? 5 : pingpong;
     return MILA_OK;
 }
 

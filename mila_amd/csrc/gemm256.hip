@@ -31,6 +31,9 @@ struct Gemm256Params
     // FP8 mode (W4A8 / W8A8 prefill): X and W are e4m3 bytes [M, K] / [N, K]; y = bf16(float(bf16(acc * *w_scale)) * x_scales[m] + bias)
     const float* x_scales;   // [M] per-token activation scales
     const float* w_scale;    // device scalar: per-tensor weight scale
+#ifdef MILA_GEMM_SKIP
+    int dbg = 0;             // diagnostic build (tools/experiments/gemm_skip.sh): leave out the staging (1), the fragment reads (2), the MFMAs (4), the plain epilogue's stores (8)
+#endif
 };
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 enum { G_PLAIN = 0, G_GEGLU = 1, G_FP8 = 2, G_FP8_GEGLU = 3 };
@@ -94,13 +97,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     constexpr int KT = 128 / ES;               // elements of K per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int nwg = gridDim.x, id = blockIdx.x;
-    const int xcd = id & 7, qd = nwg >> 3, rem = nwg & 7;
-    const int tile = ((xcd < rem) ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (id >> 3);
-    int tm, tn;
-    grouped_tile(tile, p.tiles_m, p.tiles_n, tm, tn);
-    const int m0 = tm * 256, n0 = tn * (GEGLU ? 128 : 256);
-    const int wrow1 = GEGLU ? p.N + n0 : n0 + 128;      // first W row of half-tile 1
+    // Workgroup id -> tiles id, id + gridDim.x, ... (the launcher starts one workgroup per CU when the two-phase schedule runs PERSISTENT, else one per tile).
+    // The XCD remap is taken over the whole tile list: a workgroup's later tiles are the ones the dispatcher would have handed to its XCD anyway.
+    const int ntiles = p.tiles_m * p.tiles_n;
+    auto tile_origin = [&](int idv, int& m0_, int& n0_, int& wrow1_) {
+        const int xcd = idv & 7, qd = ntiles >> 3, rem = ntiles & 7;
+        const int tile = ((xcd < rem) ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (idv >> 3);
+        int tm, tn;
+        grouped_tile(tile, p.tiles_m, p.tiles_n, tm, tn);
+        m0_ = tm * 256;
+        n0_ = tn * (GEGLU ? 128 : 256);
+        wrow1_ = GEGLU ? p.N + n0_ : n0_ + 128;            // first W row of half-tile 1
+    };
+    int m0, n0, wrow1, xm0 = 0, xn0 = 0, xwrow1 = 0;       // this tile and (persistent form) the next one
+    tile_origin(blockIdx.x, m0, n0, wrow1);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -112,8 +122,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 
     // ---- staging: half-tile (isX, half) of K-tile kt into buffer kt & 1 ----
     const int srow = lane >> 3, sslot = lane & 7;          // this lane's row within a 1 KiB chunk / 16-byte slot
-    auto stage = [&](int kt, bool isX, int half) {
-        const unsigned char* base = isX ? Xb + (size_t)(m0 + half * 128) * K * ES : Wb + (size_t)(half ? wrow1 : n0) * K * ES;
+    auto stage = [&](int kt_flat, bool isX, int half) {
+        // persistent form: K-tile nk + k is K-tile k of the workgroup's NEXT tile (nk is even there, so the buffer parity runs on)
+        const bool nxt = kt_flat >= nk;
+        const int kt = nxt ? kt_flat - nk : kt_flat;
+        const int sm0 = nxt ? xm0 : m0, sn0 = nxt ? xn0 : n0, sw1 = nxt ? xwrow1 : wrow1;
+        const unsigned char* base = isX ? Xb + (size_t)(sm0 + half * 128) * K * ES : Wb + (size_t)(half ? sw1 : sn0) * K * ES;
         unsigned char* dst_half = smem + (kt & 1) * kBufBytes + half_off(isX, half);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -130,14 +144,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     };
 
     f32x4 acc[2][2][4][2];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    };
+    zero_acc();
 
     // fragment registers: [ks] = the logical 16-B slot 4 ks + g of the row (bf16: k = 8 (4 ks + g) ..; fp8: source chunk 2 g + ks, the halves of one 32-byte operand)
     constexpr bool P2 = PP >= 2;            // two phases per K-tile (PP == 3: static priority for waves 4-7 instead of a raise around every MFMA block)
@@ -205,6 +222,104 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
         __builtin_amdgcn_s_barrier();
     };
 
+    auto epilogue = [&]() {
+        // ---- epilogue: D[p = 4 g + r][q = l15] -> Y[m0 + q][n0 + p], two sub-tiles per 16-byte store (store_pair16) ----
+        if constexpr (GEGLU)
+        {
+            // fp8 epilogue scales, fetched ONCE before the stores: read inside the store loop they are re-fetched after every store (the compiler cannot
+            // prove that Y does not alias them) -- a dependent global load in front of each of the 16 stores, 7-11 us per tile
+            float ws_ = 1.0f, tsv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+            if constexpr (FP8)
+            {
+                ws_ = *p.w_scale;
+            #pragma unroll
+                for (int hb_ = 0; hb_ < 2; ++hb_)
+            #pragma unroll
+                    for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15];
+            }
+            auto out4 = [&](int hB, int pt, int qt, int m) -> u32x2 {
+                float v[4];
+                if constexpr (FP8)
+                {
+                    // gate / up as the W4A8 Linear stores them (bf16(float(bf16(acc * sB)) * s_m)), then the GeGLU kernel's product
+                    const float ws = ws_, ts = tsv[hB][qt];
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = gelu_tanh(round_bf16(round_bf16(acc[0][hB][pt][qt][e] * ws) * ts)) * round_bf16(round_bf16(acc[1][hB][pt][qt][e] * ws) * ts);
+                }
+                else
+                {
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = gelu_tanh(round_bf16(acc[0][hB][pt][qt][e])) * round_bf16(acc[1][hB][pt][qt][e]);
+                }
+                return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            };
+    #pragma unroll
+            for (int hB = 0; hB < 2; ++hB)
+    #pragma unroll
+                for (int pp = 0; pp < 4; pp += 2)
+    #pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                    {
+                        const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                        store_pair16(p.Y + (size_t)m * p.N + n0 + wr * 64 + pp * 16, g, out4(hB, pp, qt, m), out4(hB, pp + 1, qt, m));
+                    }
+        }
+        else
+        {
+            // fp8 epilogue scales, fetched ONCE before the stores: read inside the store loop they are re-fetched after every store (the compiler cannot
+            // prove that Y does not alias them) -- a dependent global load in front of each of the 16 stores, 7-11 us per tile
+            float ws_ = 1.0f, tsv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+            if constexpr (FP8)
+            {
+                ws_ = *p.w_scale;
+            #pragma unroll
+                for (int hb_ = 0; hb_ < 2; ++hb_)
+            #pragma unroll
+                    for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15];
+            }
+            auto out4 = [&](int hA, int hB, int pt, int qt, int m, int n) -> u32x2 {
+                float v[4];
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[hA][hB][pt][qt][e];
+                if constexpr (FP8)
+                {
+                    // the reference's two steps: the GEMM stores bf16(acc * weight scale), the per-token pass rescales (+ bias)
+                    const float ws = ws_, ts = tsv[hB][qt];
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                    {
+                        v[e] = round_bf16(v[e] * ws) * ts;
+                        if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
+                    }
+                }
+                else if (p.bias)
+                {
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
+                }
+                return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            };
+    #pragma unroll
+            for (int hA = 0; hA < 2; ++hA)
+    #pragma unroll
+                for (int hB = 0; hB < 2; ++hB)
+    #pragma unroll
+                    for (int pp = 0; pp < 4; pp += 2)
+    #pragma unroll
+                        for (int qt = 0; qt < 2; ++qt)
+                        {
+                            const int nb = n0 + hA * 128 + wr * 64 + pp * 16;       // first column of sub-tile pp
+                            const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+    #ifdef MILA_GEMM_SKIP
+                            if ((p.dbg & 8) && acc[hA][hB][pp][qt][0] != 12345.678f) continue;      // diagnostic: no epilogue stores (8)
+    #endif
+                            store_pair16(p.Y + (size_t)m * p.N + nb, g, out4(hA, hB, pp, qt, m, nb + 4 * g), out4(hA, hB, pp + 1, qt, m, nb + 16 + 4 * g));
+                        }
+        }
+    };
+
     // ---- prologue: K-tile 0 complete, W0 / X1 of K-tile 1 in flight (PP == 2: W0 / X0 / X1 of K-tile 1) ----
     stage(0, false, 0); stage(0, true, 0); stage(0, true, 1); stage(0, false, 1);
     if (nk > 1) { stage(1, false, 0); if constexpr (P2) stage(1, true, 0); stage(1, true, 1); }
@@ -214,38 +329,59 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 
     if constexpr (P2)
     {
-        auto reads_end = [&](bool steady) {
-            if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        };
         auto mma_end = [&]() {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
         };
         if constexpr (PP == 3) { if (wr == 1) __builtin_amdgcn_s_setprio(1); }
         if (wr == 1) __builtin_amdgcn_s_barrier();
-        for (int t = 0; t < nk; ++t)
+#ifdef MILA_GEMM_SKIP
+        const bool dns = p.dbg & 1, dnr = p.dbg & 2, dnm = p.dbg & 4;
+        if (dnr) { load_a(0, 0); load_b(0, 0); load_b(0, 1); }
+#else
+        constexpr bool dns = false, dnr = false, dnm = false;
+#endif
+        // PERSISTENT: the K loop runs on across the workgroup's tiles.  The last two K-tiles of a tile stage the first two of the next one in the slots that used
+        // to stay empty (no prologue bubble), the epilogue's stores are issued and NOT waited for -- they drain under the next tile's first K-tile, whose two phases
+        // allow kEpilogueStores more operations in flight (vmcnt counts loads and stores together, in order) -- so a tile costs its K loop and the issue of its
+        // stores, not a prologue's memory latency plus the write burst of every CU at once.
+        // (kEpilogueStores = 8 with the GeGLU epilogue, 16 with the plain one: the vmcnt(8 + kEpilogueStores) below)
+        const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+        for (int j = 0; j < my_tiles; ++j)
         {
-            const bool steady = t + 2 < nk;
-            // phase A: quadrants (0,0) (0,1)
-            if (t + 1 < nk) stage(t + 1, false, 1);
-            load_a(t, 0);
-            load_b(t, 0);
-            load_b(t, 1);
-            reads_end(steady);
-            mma(0, 0);
-            mma(0, 1);
-            mma_end();
-            // phase B: quadrants (1,0) (1,1)
-            if (t + 2 < nk) { stage(t + 2, false, 0); stage(t + 2, true, 0); stage(t + 2, true, 1); }
-            load_a(t, 1);
-            reads_end(steady);
-            mma(1, 0);
-            mma(1, 1);
-            mma_end();
+            const bool has_next = j + 1 < my_tiles;
+            if (has_next) tile_origin(blockIdx.x + (j + 1) * gridDim.x, xm0, xn0, xwrow1);
+            for (int t = 0; t < nk; ++t)
+            {
+                const bool steady = (t + 2 < nk) || has_next;
+                const bool post = j > 0 && t == 0;                // the previous tile's stores are still in flight
+                auto reads_done = [&]() {
+                    if (!steady) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (post) { if constexpr (GEGLU) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); }
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                // phase A: quadrants (0,0) (0,1)
+                if ((t + 1 < nk || has_next) && !dns) stage(t + 1, false, 1);
+                if (!dnr) { load_a(t, 0); load_b(t, 0); load_b(t, 1); }
+                reads_done();
+                if (!dnm) { mma(0, 0); mma(0, 1); }
+                mma_end();
+                // phase B: quadrants (1,0) (1,1)
+                if ((t + 2 < nk || has_next) && !dns) { stage(t + 2, false, 0); stage(t + 2, true, 0); stage(t + 2, true, 1); }
+                if (!dnr) load_a(t, 1);
+                reads_done();
+                if (!dnm) { mma(1, 0); mma(1, 1); }
+                mma_end();
+            }
+            epilogue();
+            if (has_next)
+            {
+                m0 = xm0; n0 = xn0; wrow1 = xwrow1;
+                zero_acc();
+            }
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();
     }
@@ -329,76 +465,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 
     }
 
-    // ---- epilogue: D[p = 4 g + r][q = l15] -> Y[m0 + q][n0 + p], two sub-tiles per 16-byte store (store_pair16) ----
-    if constexpr (GEGLU)
-    {
-        auto out4 = [&](int hB, int pt, int qt, int m) -> u32x2 {
-            float v[4];
-            if constexpr (FP8)
-            {
-                // gate / up as the W4A8 Linear stores them (bf16(float(bf16(acc * sB)) * s_m)), then the GeGLU kernel's product
-                const float ws = *p.w_scale, ts = p.x_scales[m];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[e] = gelu_tanh(round_bf16(round_bf16(acc[0][hB][pt][qt][e] * ws) * ts)) * round_bf16(round_bf16(acc[1][hB][pt][qt][e] * ws) * ts);
-            }
-            else
-            {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[e] = gelu_tanh(round_bf16(acc[0][hB][pt][qt][e])) * round_bf16(acc[1][hB][pt][qt][e]);
-            }
-            return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        };
-#pragma unroll
-        for (int hB = 0; hB < 2; ++hB)
-#pragma unroll
-            for (int pp = 0; pp < 4; pp += 2)
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
-                {
-                    const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                    store_pair16(p.Y + (size_t)m * p.N + n0 + wr * 64 + pp * 16, g, out4(hB, pp, qt, m), out4(hB, pp + 1, qt, m));
-                }
-    }
-    else
-    {
-        auto out4 = [&](int hA, int hB, int pt, int qt, int m, int n) -> u32x2 {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[hA][hB][pt][qt][e];
-            if constexpr (FP8)
-            {
-                // the reference's two steps: the GEMM stores bf16(acc * weight scale), the per-token pass rescales (+ bias)
-                const float ws = *p.w_scale, ts = p.x_scales[m];
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                {
-                    v[e] = round_bf16(v[e] * ws) * ts;
-                    if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
-                }
-            }
-            else if (p.bias)
-            {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
-            }
-            return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        };
-#pragma unroll
-        for (int hA = 0; hA < 2; ++hA)
-#pragma unroll
-            for (int hB = 0; hB < 2; ++hB)
-#pragma unroll
-                for (int pp = 0; pp < 4; pp += 2)
-#pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
-                    {
-                        const int nb = n0 + hA * 128 + wr * 64 + pp * 16;       // first column of sub-tile pp
-                        const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                        store_pair16(p.Y + (size_t)m * p.N + nb, g, out4(hA, hB, pp, qt, m, nb + 4 * g), out4(hA, hB, pp + 1, qt, m, nb + 16 + 4 * g));
-                    }
-    }
+    if constexpr (!P2) epilogue();
 }
 
 // ---- 256 (M) x 128 (N) x 64 tile: shapes whose N leaves the 256 x 256 grid half empty (Gemma o_proj / fc_down, N = 3840:
@@ -574,11 +641,22 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
 
     if constexpr (GEGLU)
     {
+        // fp8 epilogue scales, fetched ONCE before the stores: read inside the store loop they are re-fetched after every store (the compiler cannot
+        // prove that Y does not alias them) -- a dependent global load in front of each of the 16 stores, 7-11 us per tile
+        float ws_ = 1.0f, tsv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+        if constexpr (FP8)
+        {
+            ws_ = *p.w_scale;
+        #pragma unroll
+            for (int hb_ = 0; hb_ < 2; ++hb_)
+        #pragma unroll
+                for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15];
+        }
         auto out4 = [&](int hB, int pt, int qt, int m) -> u32x2 {
             float v[4];
             if constexpr (FP8)
             {
-                const float ws = *p.w_scale, ts = p.x_scales[m];
+                const float ws = ws_, ts = tsv[hB][qt];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     v[e] = gelu_tanh(round_bf16(round_bf16(acc[hB][pt][qt][e] * ws) * ts)) * round_bf16(round_bf16(acc[hB][pt + 2][qt][e] * ws) * ts);
@@ -600,13 +678,24 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             }
         return;
     }
+    // fp8 epilogue scales, fetched ONCE before the stores: read inside the store loop they are re-fetched after every store (the compiler cannot
+    // prove that Y does not alias them) -- a dependent global load in front of each of the 16 stores, 7-11 us per tile
+    float ws_ = 1.0f, tsv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+    if constexpr (FP8)
+    {
+        ws_ = *p.w_scale;
+    #pragma unroll
+        for (int hb_ = 0; hb_ < 2; ++hb_)
+    #pragma unroll
+            for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15];
+    }
     auto out4 = [&](int hB, int pt, int qt, int m, int n) -> u32x2 {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[hB][pt][qt][e];
         if constexpr (FP8)
         {
-            const float ws = *p.w_scale, ts = p.x_scales[m];
+            const float ws = ws_, ts = tsv[hB][qt];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
             {
@@ -680,6 +769,7 @@ bool gemm256_applicable(int M, int K, int N)
     return tiles >= 200 && tiles >= 0.85 * rounds * kNumCU;
 }
 
+int g_gemm_persistent = 1;    // tuning: schedule 6 = schedule 5 with one workgroup per tile (not persistent)
 int g_gemm_pingpong = 5;      // tuning hook (mila_cdna4_tune_gemm_schedule): 0 = all eight waves in lockstep; 1 = staggered (ping-pong), four phases per
                               // K-tile in the 256 x 256 kernel; 2 = 1 + prefer the 256 x 128 ring; 3 = staggered, two phases per K-tile in the
                               // 256 x 256 kernel; 4 = 3 + fp8 x fp8 shapes take the 256 x 256 kernel wherever it applies; 5 (default) = 4 with ONE
@@ -697,7 +787,17 @@ static int launch_gemm256_tt(const Gemm256Params& p, hipStream_t s)
         if (rc) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<MODE, PP>), dim3(p.tiles_m * p.tiles_n), dim3(512), 2 * kBufBytes, s, p);
+    // two-phase schedules run persistent (one workgroup per CU walking its tiles) when the K-tile count is even (the LDS buffer parity then runs on across tiles)
+    const int tiles = p.tiles_m * p.tiles_n, nk = p.K / ((MODE == G_FP8 || MODE == G_FP8_GEGLU) ? 128 : 64);
+    const int grid = (PP >= 2 && nk >= 2 && nk % 2 == 0 && g_gemm_persistent) ? (tiles < kNumCU ? tiles : kNumCU) : tiles;
+#ifdef MILA_GEMM_SKIP
+    static const int dbg = getenv("MILA_GEMM_SKIP") ? atoi(getenv("MILA_GEMM_SKIP")) : 0;
+    Gemm256Params q = p;
+    q.dbg = dbg;
+    hipLaunchKernelGGL((gemm256_kernel<MODE, PP>), dim3(grid), dim3(512), 2 * kBufBytes, s, q);
+#else
+    hipLaunchKernelGGL((gemm256_kernel<MODE, PP>), dim3(grid), dim3(512), 2 * kBufBytes, s, p);
+#endif
     MILA_LAUNCH_CHECK("gemm256");
 }
 template <int MODE>
