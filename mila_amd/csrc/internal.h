@@ -13,11 +13,14 @@ extern "C" {
 MILA_API int mila_cdna4_tune_matvec(int R, int U, int max_blocks);
 /* 1 = always use the 128 x 128 register-staged GEMM (A/B against the 256 x 256 direct-to-LDS kernel) */
 MILA_API int mila_cdna4_tune_gemm(int force_128_tile);
-/* 1 (default) = the staggered two-barrier (ping-pong) schedule of the LDS-DMA GEMMs, 0 = all eight waves in lockstep */
+/* schedule of the LDS-DMA GEMMs: 0 = all eight waves in lockstep; 1 = staggered (ping-pong), four phases per K-tile; 2 = 1, preferring the 256 x 128 ring;
+ * 3 = staggered, two phases per K-tile; 4 = 3 + the fp8 shapes on the 256 x 256 kernel wherever it applies; 5 (default) = 4 with a static priority for waves 4-7
+ * and persistent tiles; 6 = 5 with one workgroup per tile.  All give the same bits. */
 MILA_API int mila_cdna4_tune_gemm_schedule(int pingpong);
 /* positions of the live band one flash-decode split covers (default 64; 0 restores it): fewer, longer splits = smaller partial sets */
 MILA_API int mila_cdna4_tune_attn_split(int positions_per_split);
-/* 2 (default): the HS = 512 flash-prefill kernel splits a head's output dimensions over two waves; 1: one wave per head */
+/* flash-prefill form: 8 (default) = LDS-DMA kernels (HS 512: 8-wave workgroups, four heads x two d-halves; HS 256: double-buffered 4-wave workgroups);
+ * 9 = 8 with 8-wave workgroups at HS 256 too; 2 = HS 512 as 4-wave d-split workgroups; 1 = the register-staged kernels.  All give the same bits. */
 MILA_API int mila_cdna4_tune_flash_dsplit(int ds);
 /* engine diagnostics: the next decode_engine launches write wall-clock stamps (100 MHz) of the first 8 workgroups' 8 waves, 16 slots each */
 MILA_API int mila_cdna4_decode_engine_debug(unsigned long long* buf);
