@@ -324,7 +324,10 @@ def test_invalid_arguments_are_reported_not_launched():
         capi.call("quantize_fp4_per_group", y, y, y, 2, 100, 128)
 
 
-@pytest.mark.parametrize("M,K,N,bias", [(2048, 128, 8192, False), (512, 3840, 30720, True), (256, 64, 51200, False), (2048, 192, 3840, True), (2048, 64, 3840, False), (512, 320, 14848, False)])
+# the last three: more tiles than CUs -- the persistent form walks 2 / 1 and 4 / 3 tiles per workgroup (K-tile counts 2 and 4), and an odd K-tile count (3) that
+# must take the one-workgroup-per-tile launch
+@pytest.mark.parametrize("M,K,N,bias", [(2048, 128, 8192, False), (512, 3840, 30720, True), (256, 64, 51200, False), (2048, 192, 3840, True), (2048, 64, 3840, False), (512, 320, 14848, False),
+                                        (2048, 128, 14336, True), (2048, 256, 30720, False), (2048, 192, 14336, False)])
 def test_gemm_256_tile_kernel_agrees_with_the_128_tile_kernel(M, K, N, bias):
     """shapes with >= 200 tiles of 256 x 256 take the direct-to-LDS 8-wave kernel; same products, fp32
     accumulation in a different order -> equal to the register-staged kernel within 1 bf16 ulp, and to the
@@ -395,7 +398,7 @@ def test_staged_quantized_gemm_equals_register_dequantizing_gemm(M, K, N):
         capi.call("gemm_bf16_w8a16_staged", Ys, Xd, dev_u8(q), dev_f32(s[:, 0].copy() if s.ndim > 1 else s), None, M, K, N, scratch, C.c_size_t(16))
 
 
-@pytest.mark.parametrize("M,K,F", [(512, 256, 15360), (2048, 128, 3584)])
+@pytest.mark.parametrize("M,K,F", [(512, 256, 15360), (2048, 128, 3584), (2048, 128, 15360)])      # the last: 960 tiles, persistent, 4 / 3 tiles per workgroup
 def test_gemm_with_geglu_epilogue_is_bit_identical_to_gemm_then_geglu(M, K, F):
     """prefill fc_gate_up + GeGLU in one kernel (Gemma.Block.ixx:343-348): a tile pairs 128 gate rows with the matching
     128 up rows, so the [M, 2F] intermediate never reaches memory; the K loop of every output is unchanged -> same bits as
@@ -451,7 +454,7 @@ def test_scaled_fp8_mfma_operand_layout():
     assert np.array_equal(Cd.cpu().numpy().reshape(16, 16), (A.astype(np.float64) @ B.astype(np.float64).T).astype(np.float32))
 
 
-@pytest.mark.parametrize("M,K,N,bias", [(2048, 256, 8192, False), (512, 384, 30720, True), (2048, 128, 3840, True), (2048, 1280, 3840, False)])
+@pytest.mark.parametrize("M,K,N,bias", [(2048, 256, 8192, False), (512, 384, 30720, True), (2048, 128, 3840, True), (2048, 1280, 3840, False), (2048, 256, 30720, True)])      # the last: fp8 tiles walked persistently
 def test_w4a8_prefill_matches_the_restated_reference(M, K, N, bias):
     """the fp4 policy's default prefill (CudaLinearOp.ixx:646-715): weight scale, fp4 -> e4m3 staging and per-token activation
     quantization are integer outputs -> bit-exact; the fp8 x fp8 MFMA GEMM with the two-step scaling epilogue -> within 2 bf16 ulp
