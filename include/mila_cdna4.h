@@ -432,6 +432,12 @@ MILA_API int mila_cdna4_fused_qkv_post_prefill(uint16_t* q_out, uint16_t* Kc, ui
 MILA_API int mila_cdna4_fused_tail_norm_bf16(uint16_t* R, uint16_t* XN, const uint16_t* A, const uint16_t* RES,
                                              const uint16_t* post_w, const uint16_t* next_w, int rows, int dim,
                                              float post_scale, float eps, mila_stream_t stream);
+/* fused_tail_norm_bf16 whose XN row is ALSO written as the W4A8 Linear's activation operand: XQ[row] = e4m3(XN[row] / XS[row]),
+ * XS[row] = max(absmax(XN[row]), 1e-12) / 448 -- bit for bit what quantize_fp8_per_token(XQ, XS, XN) would produce (the reference's
+ * cuda_fp8_quantize_per_token, Fp8Prefill/CudaFp8Prefill.cu:108-160, folded into the producer of its input). */
+MILA_API int mila_cdna4_fused_tail_norm_quant_bf16(uint16_t* R, uint16_t* XN, uint8_t* XQ, float* XS, const uint16_t* A,
+                                                   const uint16_t* RES, const uint16_t* post_w, const uint16_t* next_w, int rows,
+                                                   int dim, float post_scale, float eps, mila_stream_t stream);
 
 /* Graph-replay forms: the decode position lives in DEVICE memory so that one captured hipGraph
  * serves every step (the reference re-launches ~1100 kernels per token from the host,

@@ -133,7 +133,7 @@ EXPORTED = [
     "convert_f32_to_bf16", "convert_bf16_to_f32", "fill_uniform_bf16",
     "sample_scratch_bytes", "sample_argmax_fp32", "sample_argmax_bf16",
     "sample_stochastic_scratch_bytes", "sample_stochastic_fp32", "sample_stochastic_bf16",
-    "fused_norm_matvec", "fused_qkv_post", "fused_qkv_post_prefill", "fused_tail_norm_bf16",
+    "fused_norm_matvec", "fused_qkv_post", "fused_qkv_post_prefill", "fused_tail_norm_bf16", "fused_tail_norm_quant_bf16",
     "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position", "advance_position_snapshot", "snapshot_token", "fused_attn_decode_bf16",
     "attn_decode_split_count", "fused_attn_decode_partials_bf16", "matvec_attn_combine",
     "decode_chain_scratch_bytes", "decode_chain_init", "decode_chain_status", "decode_chain",

@@ -45,13 +45,18 @@ __global__ __launch_bounds__(256) void rmsnorm_block_kernel(uint16_t* __restrict
 constexpr int kTailChunks = 4;
 // NCH = 16-byte chunks per thread actually needed (ceil(dim / 8 / 256)): a row of 3840 takes 2, not kTailChunks -- the groups a
 // smaller NCH leaves out are exactly the empty ones (g >= G), so the sums and their order do not change
-template <int NCH>
+// QUANT: XN's row is also written as per-token e4m3 (XQ) with its scale (XS) -- the arithmetic of quantize_fp8_per_token_kernel (csrc/quantize.hip) on the values
+// XN receives (the maximum is exact in any order, the scale and the converts are the same expressions), so the W4A8 Linear that consumes XN needs no
+// quantization launch of its own.
+template <int NCH, bool QUANT = false>
 __global__ __launch_bounds__(256) void tail_norm_kernel(uint16_t* __restrict__ R, uint16_t* __restrict__ XN,
                                                         const uint16_t* __restrict__ A, const uint16_t* __restrict__ RES,
                                                         const uint16_t* __restrict__ post_w, const uint16_t* __restrict__ next_w,
-                                                        int dim, float post_scale, float eps)
+                                                        int dim, float post_scale, float eps, uint8_t* __restrict__ XQ = nullptr,
+                                                        float* __restrict__ XS = nullptr)
 {
     __shared__ float red_a[kRmsBlockMaxGroups], red_b[kRmsBlockMaxGroups];
+    __shared__ float red_q[4];
     const size_t row = blockIdx.x;
     const uint16_t* a = A + row * dim;
     const uint16_t* res = RES + row * dim;
@@ -104,11 +109,46 @@ __global__ __launch_bounds__(256) void tail_norm_kernel(uint16_t* __restrict__ R
     float t2 = 0.0f;
     for (int g = 0; g < G; ++g) t2 += red_b[g];
     const float rstd_r = rsqrtf(t2 / (float)dim + eps);
+    u32x4 xn[NCH];
+    float qm = 0.0f;
 #pragma unroll
     for (int k = 0; k < NCH; ++k)
     {
         const int c = 64 * (wib + 4 * k) + lane;
-        if (c < nx16) st16(XN + row * dim + (size_t)c * 8, rms_apply8(rv[k], nwv[k], rstd_r, 0.0f));
+        xn[k] = rms_apply8(rv[k], nwv[k], rstd_r, 0.0f);
+        if (c < nx16)
+        {
+            st16(XN + row * dim + (size_t)c * 8, xn[k]);
+            if constexpr (QUANT)
+            {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qm = fmaxf(qm, fmaxf(fabsf(bf16_lo(xn[k][e])), fabsf(bf16_hi(xn[k][e]))));
+            }
+        }
+    }
+    if constexpr (QUANT)
+    {
+        qm = block_max<4>(qm, red_q);
+        const float scale = fmaxf(qm, 1e-12f) / 448.0f;
+        if (threadIdx.x == 0) XS[row] = scale;
+        const float inv = 1.0f / scale;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+        {
+            const int c = 64 * (wib + 4 * k) + lane;
+            if (c < nx16)
+            {
+                u32x2 o;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                {
+                    int r = __builtin_amdgcn_cvt_pk_fp8_f32(bf16_lo(xn[k][2 * h]) * inv, bf16_hi(xn[k][2 * h]) * inv, 0, false);
+                    r = __builtin_amdgcn_cvt_pk_fp8_f32(bf16_lo(xn[k][2 * h + 1]) * inv, bf16_hi(xn[k][2 * h + 1]) * inv, r, true);
+                    o[h] = (uint32_t)r;
+                }
+                *reinterpret_cast<u32x2*>(XQ + row * dim + (size_t)c * 8) = o;
+            }
+        }
     }
 }
 
@@ -260,6 +300,20 @@ int mila_cdna4_rmsnorm_bf16(uint16_t* Y, uint16_t* rstd, const uint16_t* X, cons
     MILA_LAUNCH_CHECK("rmsnorm_bf16");
 }
 
+int mila_cdna4_fused_tail_norm_quant_bf16(uint16_t* R, uint16_t* XN, uint8_t* XQ, float* XS, const uint16_t* A, const uint16_t* RES, const uint16_t* post_w,
+                                          const uint16_t* next_w, int rows, int dim, float post_scale, float eps, mila_stream_t stream)
+{
+    MILA_REQUIRE(R && XN && XQ && XS && A && RES && post_w && next_w, "fused_tail_norm_quant_bf16: null pointer");
+    MILA_REQUIRE(rows > 0 && dim > 0, "fused_tail_norm_quant_bf16: rows/dim must be positive (%d,%d)", rows, dim);
+    MILA_REQUIRE(dim % 8 == 0 && dim > 1024 && dim <= 8 * 256 * kTailChunks, "fused_tail_norm_quant_bf16: dim=%d must be a multiple of 8 in (1024, %d]", dim, 8 * 256 * kTailChunks);
+    const int nch = (dim / 8 + 255) / 256;
+    if (nch <= 1) hipLaunchKernelGGL((tail_norm_kernel<1, true>), dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps, XQ, XS);
+    else if (nch == 2) hipLaunchKernelGGL((tail_norm_kernel<2, true>), dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps, XQ, XS);
+    else if (nch == 3) hipLaunchKernelGGL((tail_norm_kernel<3, true>), dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps, XQ, XS);
+    else hipLaunchKernelGGL((tail_norm_kernel<4, true>), dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps, XQ, XS);
+    MILA_LAUNCH_CHECK("fused_tail_norm_quant_bf16");
+}
+
 int mila_cdna4_fused_tail_norm_bf16(uint16_t* R, uint16_t* XN, const uint16_t* A, const uint16_t* RES, const uint16_t* post_w,
                                     const uint16_t* next_w, int rows, int dim, float post_scale, float eps, mila_stream_t stream)
 {
@@ -268,10 +322,10 @@ int mila_cdna4_fused_tail_norm_bf16(uint16_t* R, uint16_t* XN, const uint16_t* A
     MILA_REQUIRE(rows > 0 && dim > 0, "fused_tail_norm_bf16: rows/dim must be positive (%d,%d)", rows, dim);
     MILA_REQUIRE(dim % 8 == 0 && dim > 1024 && dim <= 8 * 256 * kTailChunks, "fused_tail_norm_bf16: dim=%d must be a multiple of 8 in (1024, %d]", dim, 8 * 256 * kTailChunks);
     const int nch = (dim / 8 + 255) / 256;
-    if (nch <= 1) hipLaunchKernelGGL(tail_norm_kernel<1>, dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps);
-    else if (nch == 2) hipLaunchKernelGGL(tail_norm_kernel<2>, dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps);
-    else if (nch == 3) hipLaunchKernelGGL(tail_norm_kernel<3>, dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps);
-    else hipLaunchKernelGGL(tail_norm_kernel<4>, dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps);
+    if (nch <= 1) hipLaunchKernelGGL(tail_norm_kernel<1>, dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps, (uint8_t*)nullptr, (float*)nullptr);
+    else if (nch == 2) hipLaunchKernelGGL(tail_norm_kernel<2>, dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps, (uint8_t*)nullptr, (float*)nullptr);
+    else if (nch == 3) hipLaunchKernelGGL(tail_norm_kernel<3>, dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps, (uint8_t*)nullptr, (float*)nullptr);
+    else hipLaunchKernelGGL(tail_norm_kernel<4>, dim3(rows), dim3(256), 0, as_stream(stream), R, XN, A, RES, post_w, next_w, dim, post_scale, eps, (uint8_t*)nullptr, (float*)nullptr);
     MILA_LAUNCH_CHECK("fused_tail_norm_bf16");
 }
 

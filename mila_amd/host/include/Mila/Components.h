@@ -140,6 +140,21 @@ namespace Mila::Dnn
             return *output_view_;
         }
 
+        /// forward() on rows the producer already quantized per token (W4A8 policy; see RocmLinearOp::acceptsFp8Activations): `leading` is the shape of the
+        /// bf16 input those rows stand for; returns the component-owned output or a shape-adjusted view, with the bits forward() would have produced
+        TensorType& forwardFp8Activations( const uint8_t* x8, const float* ts, const shape_t& leading )
+        {
+            if ( !this->isBuilt() ) throw std::runtime_error( "Linear must be built before calling forward." );
+            validateInputShape( leading );
+            auto out_shape = leading;
+            out_shape.back() = config_.getOutputFeatures();
+            dim_t rows = 1;
+            for ( size_t i = 0; i + 1 < leading.size(); ++i ) rows *= leading[ i ];
+            output_view_ = std::make_unique<TensorType>( output_->view( out_shape ) );
+            operation_->forwardFp8Activations( x8, ts, output_view_->data(), static_cast<int>( rows ) );
+            return *output_view_;
+        }
+
         TensorType& backward( const TensorType&, const TensorType& )
         {
             if constexpr ( kIsQuantized ) throw std::logic_error( "Linear: backward is not supported on quantized weights" );

@@ -470,6 +470,12 @@ namespace Mila::Dnn
             for ( int i = 0; i < 2; ++i ) pf_x_[ i ] = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
             pf_norm_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
             pf_norm2_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
+            if constexpr ( kFmt == 2 )
+                for ( int i = 0; i < 2; ++i )
+                {
+                    pf_q8_[ i ] = std::make_unique<TensorType>( dev, shape_t{ 1, P, ( D + 1 ) / 2 } );
+                    pf_ts_[ i ] = std::make_unique<LogitsTensor>( dev, shape_t{ P } );
+                }
             f_qkv_ = std::make_unique<TensorType>( dev, shape_t{ std::max( cfg_.packedQkvWidth( false ), cfg_.packedQkvWidth( true ) ) } );
             f_q_ = std::make_unique<TensorType>( dev, shape_t{ std::max( cfg_.qWidth( false ), cfg_.qWidth( true ) ) } );
             f_o_ = std::make_unique<TensorType>( dev, shape_t{ D } );
@@ -519,7 +525,8 @@ namespace Mila::Dnn
 
         // ---- fused-glue prefill (the reference-order path is GemmaBlock::prefill) -----------------------
         /// act[T, F] = GeGLU(fc_gate_up(ffn_in)): one kernel when the fused GEMM serves the shape, else Linear + GeGLU
-        void gateUpGeglu( Layer& L, TensorType& ffn_in, TensorType& act, int T, TensorType* private_gate_up = nullptr )
+        /// `x8` / `ts` (W4A8 policy): ffn_in's rows already quantized per token by the tail that produced them -- the quantization launch is then skipped
+        void gateUpGeglu( Layer& L, TensorType& ffn_in, TensorType& act, int T, TensorType* private_gate_up = nullptr, const uint8_t* x8_in = nullptr, const float* ts_in = nullptr )
         {
             const dim_t D = cfg_.embedding_dim;
             mila_stream_t st = ctx_->getStream();
@@ -533,6 +540,11 @@ namespace Mila::Dnn
                 {
                     // resident e4m3 weights (staged once at load): only the activations are quantized per forward
                     auto& op = L.fc_gate_up->getOperation();
+                    if ( x8_in && ts_in )
+                    {
+                        Compute::rocmCheck( mila_cdna4_gemm_geglu_fp8_scaled( act.data(), x8_in, op.residentE4m3(), ts_in, op.weightFp8Scale(), T, (int)D, (int)cfg_.hidden_dim, st ) );
+                        return;
+                    }
                     uint8_t* x8; float* ts;
                     op.activationScratch( T, (int)D, x8, ts );
                     Compute::rocmCheck( mila_cdna4_quantize_fp8_per_token( x8, ts, ffn_in.data(), T, (int)D, st ) );
@@ -592,8 +604,12 @@ namespace Mila::Dnn
             auto x3 = input.view( shape_t{ 1, T, D } );
             auto normed_view = pf_norm_->view( shape_t{ 1, T, D } );
             TensorType* normed = &normed_view;
-            if ( !have_normed ) normed = &L.input_norm->forward( x3 );
-            auto& qkv = L.qkv_proj->forward( *normed );
+            if ( !have_normed ) { normed = &L.input_norm->forward( x3 ); pf_q8_normed_ = false; }
+            // W4A8 policy: the previous block's second tail wrote these rows quantized as well -- the Linear's own quantization launch is skipped (same bits)
+            bool q8_in = false;
+            if constexpr ( kFmt == 2 ) q8_in = have_normed && pf_q8_normed_ && L.qkv_proj->getOperation().acceptsFp8Activations( T );
+            auto& qkv = q8_in ? L.qkv_proj->forwardFp8Activations( static_cast<const uint8_t*>( pf_q8_[ 1 ]->rawData() ), pf_ts_[ 1 ]->data(), normed->shape() )
+                              : L.qkv_proj->forward( *normed );
             auto q = q_->view( shape_t{ 1, T, NH * HD } );
             const uint16_t* qp = static_cast<const uint16_t*>( qkv.rawData() );
             const uint16_t* kp = qp + (size_t)( NH * HD );
@@ -607,13 +623,32 @@ namespace Mila::Dnn
             auto& o = L.o_proj->forward( attn );
             auto res1 = res1_->view( shape_t{ 1, T, D } );
             auto ffn_in = pf_norm2_->view( shape_t{ 1, T, D } );
-            Compute::rocmCheck( mila_cdna4_fused_tail_norm_bf16( res1.data(), ffn_in.data(), o.data(), x3.data(), L.post_attn_norm->getWeight()->data(),
-                                                                 L.pre_ffn_norm->getWeight()->data(), T, (int)D, 1.0f, cfg_.rms_norm_eps, st ) );
+            // W4A8 policy: a tail whose normalised rows feed a Linear on the fp8 x fp8 path writes them quantized per token as well (fused_tail_norm_quant)
+            bool q8_ffn = false, q8_next = false;
+            if constexpr ( kFmt == 2 )
+            {
+                auto& gu = L.fc_gate_up->getOperation();
+                q8_ffn = gu.acceptsFp8Activations( T ) && mila_cdna4_gemm_geglu_w4a8_applicable( T, (int)D, (int)cfg_.hidden_dim ) != 0;
+                q8_next = nextL && nextL->qkv_proj->getOperation().acceptsFp8Activations( T );
+            }
+            if ( q8_ffn )
+                Compute::rocmCheck( mila_cdna4_fused_tail_norm_quant_bf16( res1.data(), ffn_in.data(), static_cast<uint8_t*>( pf_q8_[ 0 ]->rawData() ), pf_ts_[ 0 ]->data(), o.data(), x3.data(),
+                                                                           L.post_attn_norm->getWeight()->data(), L.pre_ffn_norm->getWeight()->data(), T, (int)D, 1.0f, cfg_.rms_norm_eps, st ) );
+            else
+                Compute::rocmCheck( mila_cdna4_fused_tail_norm_bf16( res1.data(), ffn_in.data(), o.data(), x3.data(), L.post_attn_norm->getWeight()->data(),
+                                                                     L.pre_ffn_norm->getWeight()->data(), T, (int)D, 1.0f, cfg_.rms_norm_eps, st ) );
             auto act = geglu_->view( shape_t{ 1, T, cfg_.hidden_dim } );
-            gateUpGeglu( L, ffn_in, act, T );
+            if ( q8_ffn ) gateUpGeglu( L, ffn_in, act, T, nullptr, static_cast<const uint8_t*>( pf_q8_[ 0 ]->rawData() ), pf_ts_[ 0 ]->data() );
+            else gateUpGeglu( L, ffn_in, act, T );
             auto& ffn = L.fc_down->forward( act );
-            Compute::rocmCheck( mila_cdna4_fused_tail_norm_bf16( output.data(), nextL ? pf_norm_->data() : nullptr, ffn.data(), res1.data(), L.post_ffn_norm->getWeight()->data(),
-                                                                 nextL ? nextL->input_norm->getWeight()->data() : nullptr, T, (int)D, L.layer_scalar, cfg_.rms_norm_eps, st ) );
+            if ( q8_next )
+                Compute::rocmCheck( mila_cdna4_fused_tail_norm_quant_bf16( output.data(), pf_norm_->data(), static_cast<uint8_t*>( pf_q8_[ 1 ]->rawData() ), pf_ts_[ 1 ]->data(), ffn.data(), res1.data(),
+                                                                           L.post_ffn_norm->getWeight()->data(), nextL->input_norm->getWeight()->data(), T, (int)D, L.layer_scalar,
+                                                                           cfg_.rms_norm_eps, st ) );
+            else
+                Compute::rocmCheck( mila_cdna4_fused_tail_norm_bf16( output.data(), nextL ? pf_norm_->data() : nullptr, ffn.data(), res1.data(), L.post_ffn_norm->getWeight()->data(),
+                                                                     nextL ? nextL->input_norm->getWeight()->data() : nullptr, T, (int)D, L.layer_scalar, cfg_.rms_norm_eps, st ) );
+            pf_q8_normed_ = q8_next;
         }
 
         // ---- two halves of a chunk on two streams -------------------------------------------------------------------------------------------
@@ -1304,6 +1339,11 @@ namespace Mila::Dnn
         std::unique_ptr<TokenTensor> tickets_;
         std::unique_ptr<LogitsTensor> pf_sink_, attn_partials_;
         std::unique_ptr<TensorType> pf_norm_, pf_norm2_;
+        // W4A8 policy: the sandwich tails also write their normalised rows as per-token e4m3 + scales for the Linear that follows ([0]: pre_ffn_norm -> fc_gate_up,
+        // [1]: the next block's input_norm -> its qkv_proj); model-owned like every prefill workspace
+        std::unique_ptr<TensorType> pf_q8_[ 2 ];          // [1, P, D / 2] bf16 elements = P * D bytes of e4m3
+        std::unique_ptr<LogitsTensor> pf_ts_[ 2 ];        // [P] fp32 per-token scales
+        bool pf_q8_normed_{ false };       // pf_q8_[1] / pf_ts_[1] hold the rows of pf_norm_ (written by the previous block's second tail in this prefill)
         std::unique_ptr<LogitsTensor> chain_scratch_;
         const uint16_t* cur_hidden_{ nullptr };
         hipGraph_t graph_{ nullptr };

@@ -207,6 +207,21 @@ namespace Mila::Dnn::Compute
         bool residentPrefillWeights() const noexcept { return resident_; }
         const uint16_t* residentBf16() const noexcept { return resident_bf16_ ? resident_bf16_->data() : nullptr; }
         const uint8_t* residentE4m3() const noexcept { return resident_e4m3_ ? resident_e4m3_->data() : nullptr; }
+        /// true when forward() of M rows would take the resident W4A8 path (fp8 x fp8 GEMM on weights staged at load): a producer may then hand over its
+        /// output already quantized per token (forwardFp8Activations) instead of as bf16
+        bool acceptsFp8Activations( int M ) const
+        {
+            if constexpr ( kFmt != 2 ) return false;
+            else return use_fp8_activation_prefill_ && weight_fp8_scale_ && resident_e4m3_ && mila_cdna4_gemm_fp8_applicable( M, (int)cfg_.in_features, (int)cfg_.out_features ) != 0;
+        }
+        /// the W4A8 forward on activations the caller quantized (x8 [M, K] e4m3, ts [M] per-token scales -- exactly what quantize_fp8_per_token gives): the same
+        /// GEMM call forward() makes, so the output carries the same bits
+        void forwardFp8Activations( const uint8_t* x8, const float* ts, uint16_t* y, int M )
+        {
+            if ( !acceptsFp8Activations( M ) ) throw std::logic_error( "RocmLinearOp::forwardFp8Activations: the W4A8 path does not serve this call" );
+            rocmCheck( mila_cdna4_gemm_fp8_scaled( y, x8, resident_e4m3_->data(), ts, weight_fp8_scale_->data(), bias_, M, (int)cfg_.in_features, (int)cfg_.out_features,
+                                                   this->context_->getStream() ) );
+        }
         /// scratch for the per-token e4m3 activations + their scales (fetched per forward, never cached)
         void activationScratch( int M, int K, uint8_t*& x8, float*& ts ) const
         {

@@ -298,6 +298,35 @@ def test_tail_norm_equals_rmsnorm_residual_scale_rmsnorm(D, post_scale, with_nex
         capi.call("fused_tail_norm_bf16", r1, None, a, res, pw, None, T, 512, post_scale, 1e-6)
 
 
+@pytest.mark.parametrize("D", [3840, 2056, 8192])
+def test_tail_norm_with_per_token_fp8_output_equals_tail_norm_then_quantize(D):
+    """fused_tail_norm_quant_bf16: the normalised rows also as the W4A8 Linear's operand -- bit for bit what quantize_fp8_per_token makes of XN
+    (Fp8Prefill/CudaFp8Prefill.cu:108-160 folded into the producer); an all-zero row takes the 1e-12 floor"""
+    rng = np.random.default_rng(D + 1)
+    T = 21
+    A = _bf(rng.standard_normal((T, D)) * 3)
+    R = _bf(rng.standard_normal((T, D)))
+    A[5] = 0.0
+    R[5] = 0.0                                                   # a row whose tail output is exactly zero
+    a, res = _d(A), _d(R)
+    pw, nw = _d(_bf(1 + 0.1 * rng.uniform(-1, 1, D))), _d(_bf(1 + 0.1 * rng.uniform(-1, 1, D)))
+    r0, x0 = empty_u16(T, D), empty_u16(T, D)
+    capi.call("fused_tail_norm_bf16", r0, x0, a, res, pw, nw, T, D, 0.75, 1e-6)
+    q0 = torch.empty((T, D), dtype=torch.uint8, device="cuda")
+    s0 = torch.empty((T,), dtype=torch.float32, device="cuda")
+    capi.call("quantize_fp8_per_token", q0, s0, x0, T, D)
+    r1, x1 = empty_u16(T, D), empty_u16(T, D)
+    q1 = torch.full((T, D), 0x55, dtype=torch.uint8, device="cuda")
+    s1 = torch.full((T,), -1.0, dtype=torch.float32, device="cuda")
+    capi.call("fused_tail_norm_quant_bf16", r1, x1, q1, s1, a, res, pw, nw, T, D, 0.75, 1e-6)
+    assert np.array_equal(bits(r0), bits(r1)) and np.array_equal(bits(x0), bits(x1))
+    assert torch.equal(s0, s1), "per-token scales differ"
+    assert torch.equal(q0, q1), "e4m3 rows differ"
+    assert float(s1[5]) == np.float32(1e-12) / np.float32(448.0)
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("fused_tail_norm_quant_bf16", r1, x1, q1, None, a, res, pw, nw, T, D, 0.75, 1e-6)
+
+
 @pytest.mark.parametrize("NH,NKV,HS,rot,base,window,kv_shared,cap", [(16, 8, 256, 0, 1e4, 1024, False, 2048), (16, 1, 512, 128, 1e6, 0, True, 512),
                                                                      (4, 2, 256, 0, 1e4, 128, False, 256)])
 @pytest.mark.parametrize("fmt", [0, 1, 2])
