@@ -166,6 +166,30 @@ def test_prefill_attention_chunked(name, NH, NKV, HS, window, scale):
     assert_bf16_close(bits(Yd), exp[:, T - 1], 1, 2e-3, "decode == last prefill row")
 
 
+@pytest.mark.parametrize("name,NH,NKV,HS,window", [("gemma_local", 16, 8, 256, 1024), ("gemma_global", 16, 1, 512, 0)])
+def test_flash_prefill_forms_give_the_same_bits(name, NH, NKV, HS, window):
+    """the tuning forms of the flash prefill kernel (9: 8-wave workgroups at HS 256 too -- taken where half the chunk sees a full window --, 2: HS 512 as 4-wave
+    d-split workgroups, 1: the register-staged kernels) run the same operations per output element as the default form 8: identical outputs"""
+    rng = np.random.default_rng(HS)
+    B, off, T = 1, 1024, 256                                  # a chunk behind 1024 cached positions: every row of a window-1024 layer sees a full window
+    cap = off + T
+    K = dev_u16(orc.to_bf16_bits(_bf(rng.uniform(-1, 1, (B, NKV, cap, HS)) * 0.5)))
+    V = dev_u16(orc.to_bf16_bits(_bf(rng.uniform(-1, 1, (B, NKV, cap, HS)))))
+    q = _d(_bf(rng.uniform(-1, 1, (B, T, NH, HS))))
+    lib = capi.load()
+    outs = {}
+    try:
+        for form in (8, 9, 2, 1):
+            capi.check(lib.mila_cdna4_tune_flash_dsplit(form))
+            Y = empty_u16(B, T, NH * HS)
+            capi.call("attn_prefill_bf16", Y, q, K, V, B, T, NH, NKV, HS, cap, off, window, 1.0)
+            outs[form] = bits(Y).copy()
+    finally:
+        capi.check(lib.mila_cdna4_tune_flash_dsplit(8))
+    for form in (9, 2, 1):
+        assert np.array_equal(outs[8], outs[form]), "form %d differs from the default" % form
+
+
 @pytest.mark.parametrize("B,T,Cm,NH", [(2, 3, 8 * 8, 1), (2, 33, 768, 12), (1, 130, 256, 4)])
 def test_mha_packed_qkv_vs_reference_cpu_op(B, T, Cm, NH):
     """GPT-2 attention vs the restated CpuAttentionOp (MultiHeadAttention.Cpu.cpp scenario: sin spread)"""
