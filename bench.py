@@ -181,12 +181,41 @@ def spawn_replicas(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    # poll every child: as soon as one exits non-zero the rest are ended (fresh processes of ours, so killing them is safe) instead of
+    # rank 0 sitting in the gloo barrier until the process-group timeout; rank 0's stdout is drained by a thread so its pipe never fills
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.read().splitlines()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() not in (None, 0):
+                failed = p.returncode
+                break
+        else:
+            time.sleep(0.05)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    reader.join(timeout=10)
+    rcs = [p.returncode for p in procs]
+    lines = [ln for ln in out0 if ln.startswith("{")]
     if lines:
         print(lines[-1], flush=True)
-    return max(abs(rc) for rc in rcs) if any(rcs) or not lines else 0
+    if failed is not None or any(rcs):
+        return max(1, max(abs(rc) for rc in rcs))
+    if not lines:
+        print("bench.py: every replica exited 0 but rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    return 0
 
 
 def stub_result(steps, warmup, rank):
@@ -239,6 +268,8 @@ def main():
     cpu = cpu_baseline(cfg) if (rank == 0 and world == 1 and not a.no_cpu and not a.stub) else None
 
     if a.stub:
+        if os.environ.get("MILA_BENCH_STUB_FAIL_RANK") == str(rank):      # tests: a replica that dies before the barrier must end the whole command, promptly
+            os._exit(3)
         ranks.barrier()
         ms = stub_result(a.steps, a.warmup, rank)
         ranks.barrier()

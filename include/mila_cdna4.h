@@ -126,10 +126,12 @@ MILA_API int mila_cdna4_gemm_geglu_bf16_w4a16_staged(uint16_t* Y, const uint16_t
  *   W8   = e4m3( lut(nibble) * (group scale * (1 / sB)) )                 (upcast_fp4_to_fp8: CudaW4A16Gemm.cu:300-323)
  *   s_m  = max(absmax(x_m), 1e-12) / 448,  X8 = e4m3( x * (1 / s_m) )     (quantize_fp8_per_token: Fp8Prefill/CudaFp8Prefill.cu:108-160)
  *   y    = bf16( float(bf16(sB * sum_k X8 W8)) * s_m + bias )             (fp8 x fp8 GEMM + cuda_fp8_apply_per_token_scales, :191-211)
- * The contraction runs on v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3, unit block scales, fp32 accumulate) in the two LDS-DMA
- * GEMM kernels; integer outputs (W8, X8) are bit-exact, y is within 1 bf16 ulp of the restated reference.  gemm_fp8_applicable()
- * says whether a shape has an fp8 kernel (K % 128 == 0 and a full 256 x 256 or 256 x 128 grid); gemm_bf16_w4a8 runs the three
- * steps with scratch = [W8 | X8 | s_m] of gemm_w4a8_scratch_bytes(M, K, N) bytes. */
+ * The contraction runs on v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3, unit block scales, fp32 accumulate): the two LDS-DMA
+ * GEMM kernels on the leading multiple of 256 rows where one serves the shape, a masked 128-row kernel on every other row -- the
+ * same instruction chain per output element, so a row's bits do not depend on M.  Integer outputs (W8, X8) are bit-exact, y is
+ * within 1 bf16 ulp of the restated reference.  As in the reference the path serves EVERY M > 1: gemm_fp8_applicable() is true for
+ * any M, N > 0 with K % 16 == 0 (ABI 3; it used to require M % 256 == 0 and a full grid).  gemm_bf16_w4a8 runs the three steps with
+ * scratch = [W8 | X8 | s_m] of gemm_w4a8_scratch_bytes(M, K, N) bytes. */
 MILA_API int mila_cdna4_fp4_weight_fp8_scale(float* out_scale, const float* group_scales, int64_t num_scales,
                                              mila_stream_t stream);
 MILA_API int mila_cdna4_upcast_fp4_to_fp8(uint8_t* out, const uint8_t* W_packed, const float* scales,

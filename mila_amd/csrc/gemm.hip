@@ -273,6 +273,7 @@ int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int 
 static int g_gemm_force128 = 0;
 extern int g_gemm_pingpong;     // gemm256.hip
 extern int g_gemm_persistent;
+extern int g_gemm_fp8_tail_only;
 
 // which direct-to-LDS kernel serves a bf16-weight GEMM of this shape: 2 = 256 x 256, 1 = 256 x 128, 0 = none (128 x 128 register-staged)
 static int glds_kernel_for(int M, int K, int N)
@@ -406,6 +407,13 @@ int mila_cdna4_tune_gemm_schedule(int pingpong)
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
     g_gemm_persistent = pingpong != 6;
     g_gemm_pingpong = pingpong == 6 ? 5 : pingpong;
+    return MILA_OK;
+}
+
+int mila_cdna4_tune_gemm_fp8_tail_only(int on)
+{
+    if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
+    g_gemm_fp8_tail_only = on;
     return MILA_OK;
 }
 

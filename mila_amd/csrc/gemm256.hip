@@ -839,27 +839,63 @@ int gemm_fp8_kernel_for(int M, int K, int N)
     if (gemm256_applicable(M, K, N)) return 2;
     return 0;
 }
+// gemm_fp8_tail.hip: the same arithmetic for any row count (masked 128-row tiles, register-staged)
+int launch_gemm_fp8_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
+                         int M, int K, int N, hipStream_t s);
+int launch_gemm_fp8_geglu_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
+                               hipStream_t s);
+
+// Ragged row counts, as launch_bf16_rows splits them (gemm.hip): the LDS-DMA kernels take the leading multiple of 256 rows when one serves
+// that many, the tail kernel the rest (or everything).  Rows are independent and both kernels run the same instruction chain per output
+// element, so a row's bits do not depend on where the split falls -- the fp4 policy's prefill is W4A8 for EVERY M > 1 (CudaLinearOp.ixx:646-715).
+int g_gemm_fp8_tail_only = 0;      // tuning hook (mila_cdna4_tune_gemm_fp8_tail_only): every row through the masked kernel -- the bit-identity check
+static int fp8_main_rows(int M, int K, int N, int* which)
+{
+    *which = 0;
+    if (g_gemm_fp8_tail_only) return 0;
+    *which = gemm_fp8_kernel_for(M, K, N);
+    if (*which) return M;
+    const int main_rows = M - M % 256;
+    if (main_rows >= 512 && (*which = gemm_fp8_kernel_for(main_rows, K, N)) != 0) return main_rows;
+    return 0;
+}
+static bool fp8_geglu_big(int M, int K, int F) { return K % 128 == 0 && gemm256_geglu_applicable(M, K, F); }
+
 // Y[M, F] = GeGLU of the W4A8 Linear over W8 = [gate rows | up rows] (2F x K e4m3)
 int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
                           hipStream_t s)
 {
-    if (M % 256 == 0 && F % 64 == 0 && gemm256x128_applicable(M, K, 2 * F) && !(g_gemm_pingpong >= 4 && gemm256_geglu_applicable(M, K, F)))
+    int main_rows = (!g_gemm_fp8_tail_only && fp8_geglu_big(M, K, F)) ? M : 0;
+    if (!g_gemm_fp8_tail_only && !main_rows && M - M % 256 >= 512 && fp8_geglu_big(M - M % 256, K, F)) main_rows = M - M % 256;
+    if (main_rows)
     {
-        Gemm256Params q{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, M, K, F, M / 256, F / 64, x_scales, w_scale};
-        return launch_gemm256x128_t<true, true>(q, s);
+        int rc;
+        if (F % 64 == 0 && gemm256x128_applicable(main_rows, K, 2 * F) && !(g_gemm_pingpong >= 4 && gemm256_geglu_applicable(main_rows, K, F)))
+        {
+            Gemm256Params q{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, main_rows, K, F, main_rows / 256, F / 64, x_scales, w_scale};
+            rc = launch_gemm256x128_t<true, true>(q, s);
+        }
+        else
+        {
+            Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, main_rows, K, F, main_rows / 256, F / 128, x_scales, w_scale};
+            rc = launch_gemm256_t<G_FP8_GEGLU>(p, s);
+        }
+        if (rc || main_rows == M) return rc;
     }
-    Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, M, K, F, M / 256, F / 128, x_scales, w_scale};
-    return launch_gemm256_t<G_FP8_GEGLU>(p, s);
+    return launch_gemm_fp8_geglu_tail(Y + (size_t)main_rows * F, X8 + (size_t)main_rows * K, W8, x_scales + main_rows, w_scale, M - main_rows, K, F, s);
 }
 int launch_gemm_fp8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
                     int M, int K, int N, hipStream_t s)
 {
-    const int which = gemm_fp8_kernel_for(M, K, N);
-    Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), bias, M, K, N, M / 256,
-                    which == 2 ? N / 256 : N / 128, x_scales, w_scale};
-    if (which == 2) return launch_gemm256_t<G_FP8>(p, s);
-    if (which == 1) return launch_gemm256x128_t<true>(p, s);
-    return set_error(MILA_E_UNSUPPORTED, "gemm_fp8: no fp8 MFMA kernel for M=%d K=%d N=%d", M, K, N);
+    int which;
+    const int main_rows = fp8_main_rows(M, K, N, &which);
+    if (main_rows)
+    {
+        Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), bias, main_rows, K, N, main_rows / 256,
+                        which == 2 ? N / 256 : N / 128, x_scales, w_scale};
+        const int rc = which == 2 ? launch_gemm256_t<G_FP8>(p, s) : launch_gemm256x128_t<true>(p, s);
+        if (rc || main_rows == M) return rc;
+    }
+    return launch_gemm_fp8_tail(Y + (size_t)main_rows * N, X8 + (size_t)main_rows * K, W8, x_scales + main_rows, w_scale, bias, M - main_rows, K, N, s);
 }
-
 }  // namespace mila

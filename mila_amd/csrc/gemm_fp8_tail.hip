@@ -1,0 +1,224 @@
+// fp8 x fp8 (e4m3) GEMM for the rows the LDS-DMA kernels of gemm256.hip do not take: ragged prompt lengths (M % 256 != 0), short prompts,
+// the last chunk of a chunked prefill, and shapes whose N / K are outside the big tiles.  With it the fp4 policy's prefill runs W4A8 for
+// EVERY M > 1, as the reference does (CudaLinearOp.ixx:646-715: kUseFp8ActivationPrefillPath is unconditional), instead of changing
+// arithmetic with the prompt length.
+//
+//   Y[M, N] = bf16( float( bf16( (X8 W8^T)[m, n] * *w_scale ) ) * x_scales[m] + bias[n] )        (CudaFp8Prefill.cu:191-211)
+//
+// Bit-identical to gemm256_kernel<G_FP8> / gemm256x128_kernel<true> on the same rows: one v_mfma_scale_f32_16x16x128_f8f6f4 (unit block
+// scales) per 16 x 16 sub-tile and 128-byte K-tile, K-tiles in ascending order, A operand = W rows, B operand = X rows, and a lane
+// (l15, g) supplies the same 32 bytes k = 32 g .. 32 g + 31 of its row -- so an output element is the same chain of the same
+// instruction on the same operand bytes whichever kernel computes it (tests/test_linear_gpu.py holds the two against each other).
+//
+// Tile: 128 X rows x BN W rows x 128 bytes of K, 256 threads = 4 waves as WN (W side) x 4 / WN (X side).  Rows past M / N and K
+// chunks past K are staged as zeros (e4m3 0x00 = +0: the products vanish) and never stored.  Register staging (masked loads cannot be
+// LDS-DMA), two LDS buffers, one barrier per K-tile; the kernel is bound by reading W once per 128 rows of M, so BN is picked by the
+// launcher to give the chip enough workgroups (N = 3840 at BN = 128 would be 30).
+// LDS image: 128-byte rows, source chunk c (16 bytes) at logical slot ((c & 1) << 2) | (c >> 1) -- the two halves of a lane's 32-byte
+// operand at slots g and 4 + g, the conflict-free pattern of gemm256.hip -- XOR-swizzled by (row >> 1) & 7.
+#include "common.h"
+
+namespace mila {
+
+struct Fp8TailParams
+{
+    uint16_t* Y;
+    const uint8_t* X;         // [M, K] e4m3
+    const uint8_t* W;         // [N, K] e4m3 (GEGLU: [2 F, K], gate rows then up rows, N = F)
+    const uint16_t* bias;
+    const float* x_scales;    // [M]
+    const float* w_scale;     // device scalar
+    int M, K, N, tiles_m, tiles_n;
+};
+typedef int i32x8t __attribute__((ext_vector_type(8)));
+
+template <int WN, int PT, int QT, bool GEGLU>
+__global__ __launch_bounds__(256) void gemm_fp8_tail_kernel(const Fp8TailParams p)
+{
+    constexpr int WM = 4 / WN;
+    constexpr int BN = WN * PT * 16;                  // W rows per tile
+    constexpr int BM = WM * QT * 16;                  // X rows per tile
+    static_assert(BM == 128, "the X tile is 128 rows");
+    constexpr int BO = GEGLU ? BN / 2 : BN;           // output columns per tile
+    constexpr int kXBytes = BM * 128, kWBytes = BN * 128, kBuf = kXBytes + kWBytes;
+    constexpr int NX = BM * 8 / 256, NW = BN * 8 / 256;      // 16-byte chunks per thread and K-tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kBuf];
+
+    const int tm = blockIdx.x % p.tiles_m, tn = blockIdx.x / p.tiles_m;      // the M-tiles of one W panel run side by side
+    const int m0 = tm * BM, n0 = tn * BO;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WM, wm = wave % WM;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int K = p.K, nk = (K + 127) / 128;
+
+    // W tile row -> global W row and whether it exists
+    auto w_row = [&](int row, bool& ok) -> size_t {
+        if constexpr (GEGLU)
+        {
+            constexpr int HALF = PT * 8;                                      // a wave's rows: HALF gate rows, then the matching HALF up rows
+            const int w = row / (PT * 16), in = row % (PT * 16);
+            const int col = n0 + w * HALF + (in % HALF);
+            ok = col < p.N;
+            return (size_t)(in < HALF ? col : p.N + col);
+        }
+        else
+        {
+            ok = n0 + row < p.N;
+            return (size_t)(n0 + row);
+        }
+    };
+    auto lds_off = [](int row, int c) { return row * 128 + (((((c & 1) << 2) | (c >> 1)) ^ ((row >> 1) & 7)) << 4); };
+
+    u32x4 rx[NX], rw[NW];
+    auto stage_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+        {
+            const int s = tid + 256 * i, row = s >> 3, c = s & 7;
+            const int m = m0 + row, k = kt * 128 + c * 16;
+            rx[i] = (m < p.M && k < K) ? ld16(p.X + (size_t)m * K + k) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+        {
+            const int s = tid + 256 * i, row = s >> 3, c = s & 7;
+            const int k = kt * 128 + c * 16;
+            bool ok;
+            const size_t n = w_row(row, ok);
+            rw[i] = (ok && k < K) ? ld16(p.W + n * K + k) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto stage_store = [&](unsigned char* buf) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+        {
+            const int s = tid + 256 * i;
+            *reinterpret_cast<u32x4*>(buf + lds_off(s >> 3, s & 7)) = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+        {
+            const int s = tid + 256 * i;
+            *reinterpret_cast<u32x4*>(buf + kXBytes + lds_off(s >> 3, s & 7)) = rw[i];
+        }
+    };
+
+    f32x4 acc[PT][QT];
+#pragma unroll
+    for (int a = 0; a < PT; ++a)
+#pragma unroll
+        for (int b = 0; b < QT; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    stage_load(0);
+    stage_store(smem);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t)
+    {
+        const unsigned char* cur = smem + (t & 1) * kBuf;
+        const bool more = t + 1 < nk;
+        if (more) stage_load(t + 1);
+        struct Pair { s16x8 lo, hi; };
+        i32x8t fa[PT], fb[QT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+        {
+            const int r = wn * PT * 16 + pt * 16 + l15;
+            const unsigned char* rowp = cur + kXBytes + r * 128;
+            const int sw = (r >> 1) & 7;
+            fa[pt] = __builtin_bit_cast(i32x8t, (Pair{*reinterpret_cast<const s16x8*>(rowp + ((g ^ sw) << 4)), *reinterpret_cast<const s16x8*>(rowp + (((4 + g) ^ sw) << 4))}));
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+        {
+            const int r = wm * QT * 16 + qt * 16 + l15;
+            const unsigned char* rowp = cur + r * 128;
+            const int sw = (r >> 1) & 7;
+            fb[qt] = __builtin_bit_cast(i32x8t, (Pair{*reinterpret_cast<const s16x8*>(rowp + ((g ^ sw) << 4)), *reinterpret_cast<const s16x8*>(rowp + (((4 + g) ^ sw) << 4))}));
+        }
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+                acc[pt][qt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[pt], fb[qt], acc[pt][qt], 0, 0, 0, 127, 0, 127);
+        if (more) stage_store(smem + ((t + 1) & 1) * kBuf);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[p = 4 g + e][q = l15] -> Y[m0 + .. + q][n0 + .. + p] ----
+    const float ws = *p.w_scale;
+    const bool vec_ok = (p.N & 3) == 0;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+    {
+        const int m = m0 + wm * QT * 16 + qt * 16 + l15;
+        if (m >= p.M) continue;
+        const float ts = p.x_scales[m];
+        uint16_t* yrow = p.Y + (size_t)m * p.N;
+#pragma unroll
+        for (int pt = 0; pt < (GEGLU ? PT / 2 : PT); ++pt)
+        {
+            const int n = n0 + wn * (GEGLU ? PT * 8 : PT * 16) + pt * 16 + 4 * g;
+            if (n >= p.N) continue;
+            float v[4];
+            if constexpr (GEGLU)
+            {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = gelu_tanh(round_bf16(round_bf16(acc[pt][qt][e] * ws) * ts)) * round_bf16(round_bf16(acc[pt + PT / 2][qt][e] * ws) * ts);
+            }
+            else
+            {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                {
+                    v[e] = round_bf16(acc[pt][qt][e] * ws) * ts;
+                    if (p.bias && n + e < p.N) v[e] += bf16_bits_to_f32(p.bias[n + e]);
+                }
+            }
+            if (vec_ok) *reinterpret_cast<u32x2*>(yrow + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            else
+            {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < p.N) yrow[n + e] = f32_to_bf16_bits(v[e]);
+            }
+        }
+    }
+}
+
+template <int WN, int PT, int QT, bool GEGLU>
+static int launch_tail_t(Fp8TailParams p, hipStream_t s)
+{
+    constexpr int BO = (GEGLU ? WN * PT * 8 : WN * PT * 16);
+    p.tiles_m = (p.M + 127) / 128;
+    p.tiles_n = (p.N + BO - 1) / BO;
+    hipLaunchKernelGGL((gemm_fp8_tail_kernel<WN, PT, QT, GEGLU>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+    MILA_LAUNCH_CHECK("gemm_fp8_tail");
+}
+
+// the widest W tile that still gives the chip about one workgroup per CU
+template <bool GEGLU>
+static int launch_tail(const Fp8TailParams& p, hipStream_t s)
+{
+    const int tiles_m = (p.M + 127) / 128;
+    auto wgs = [&](int bo) { return tiles_m * ((p.N + bo - 1) / bo); };
+    constexpr int D = GEGLU ? 2 : 1;
+    if (wgs(128 / D) >= 192) return launch_tail_t<2, 4, 4, GEGLU>(p, s);
+    if (wgs(64 / D) >= 192) return launch_tail_t<1, 4, 2, GEGLU>(p, s);
+    return launch_tail_t<1, 2, 2, GEGLU>(p, s);
+}
+
+int launch_gemm_fp8_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
+                         int M, int K, int N, hipStream_t s)
+{
+    Fp8TailParams p{Y, X8, W8, bias, x_scales, w_scale, M, K, N, 0, 0};
+    return launch_tail<false>(p, s);
+}
+int launch_gemm_fp8_geglu_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
+                               hipStream_t s)
+{
+    Fp8TailParams p{Y, X8, W8, nullptr, x_scales, w_scale, M, K, F, 0, 0};
+    return launch_tail<true>(p, s);
+}
+
+}  // namespace mila

@@ -17,6 +17,9 @@ MILA_API int mila_cdna4_tune_gemm(int force_128_tile);
  * 3 = staggered, two phases per K-tile; 4 = 3 + the fp8 shapes on the 256 x 256 kernel wherever it applies; 5 (default) = 4 with a static priority for waves 4-7
  * and persistent tiles; 6 = 5 with one workgroup per tile.  All give the same bits. */
 MILA_API int mila_cdna4_tune_gemm_schedule(int pingpong);
+/* 1 = the fp8 x fp8 GEMM entry points run EVERY row on the masked 128-row kernel (gemm_fp8_tail.hip), 0 (default) = LDS-DMA kernels on the leading
+ * multiple of 256 rows.  Same bits either way: the test of that statement. */
+MILA_API int mila_cdna4_tune_gemm_fp8_tail_only(int on);
 /* positions of the live band one flash-decode split covers (default 64; 0 restores it): fewer, longer splits = smaller partial sets */
 MILA_API int mila_cdna4_tune_attn_split(int positions_per_split);
 /* flash-prefill form: 8 (default) = LDS-DMA kernels (HS 512: 8-wave workgroups, four heads x two d-halves; HS 256: double-buffered 4-wave workgroups);

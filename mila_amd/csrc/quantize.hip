@@ -316,7 +316,8 @@ int mila_cdna4_quantize_fp8_per_token(uint8_t* dst, float* scales, const uint16_
     MILA_LAUNCH_CHECK("quantize_fp8_per_token");
 }
 
-int mila_cdna4_gemm_fp8_applicable(int M, int K, int N) { return (M > 0 && K > 0 && N > 0 && gemm_fp8_kernel_for(M, K, N) != 0) ? 1 : 0; }
+// every M: the LDS-DMA kernels on the leading multiple of 256 rows where one applies, the masked tail kernel on the rest (gemm256.hip: launch_gemm_fp8)
+int mila_cdna4_gemm_fp8_applicable(int M, int K, int N) { return (M > 0 && K > 0 && N > 0 && K % 16 == 0) ? 1 : 0; }
 
 int mila_cdna4_gemm_fp8_scaled(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* weight_scale,
                                const uint16_t* bias, int M, int K, int N, mila_stream_t stream)
@@ -350,7 +351,7 @@ int mila_cdna4_gemm_bf16_w4a8(uint16_t* Y, const uint16_t* X, const uint8_t* W_p
     return launch_gemm_fp8(Y, x8, w8, ts, weight_fp8_scale, bias, M, K, N, as_stream(stream));
 }
 
-int mila_cdna4_gemm_geglu_w4a8_applicable(int M, int K, int F) { return (M > 0 && K > 0 && F > 0 && K % 128 == 0 && gemm256_geglu_applicable(M, K, F)) ? 1 : 0; }
+int mila_cdna4_gemm_geglu_w4a8_applicable(int M, int K, int F) { return (M > 0 && K > 0 && F > 0 && K % 16 == 0) ? 1 : 0; }
 
 int mila_cdna4_gemm_geglu_fp8_scaled(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* weight_scale, int M, int K, int F,
                                      mila_stream_t stream)

@@ -45,12 +45,8 @@ def load():
         _lib.mila_gemma_info.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         _lib.mila_gemma_generate.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         _lib.mila_gemma_generate_sampled.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_uint32, C.c_void_p]
-        _lib.mila_gemma_set_chain.argtypes = [C.c_void_p, C.c_int]
-        _lib.mila_gemma_uses_chain.argtypes = [C.c_void_p]
         _lib.mila_gemma_set_fp8_activation_prefill.argtypes = [C.c_void_p, C.c_int]
-        _lib.mila_gemma_set_combine_in_oproj.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_set_fused_prefill.argtypes = [C.c_void_p, C.c_int]
-        _lib.mila_gemma_set_onepass_attention.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_set_resident_prefill_weights.argtypes = [C.c_void_p, C.c_int]
         _lib.mila_gemma_save_safetensors.argtypes = [C.c_void_p, C.c_char_p]
         _lib.mila_gemma_load_safetensors.argtypes = [C.c_void_p, C.c_char_p]
@@ -64,8 +60,6 @@ def load():
         _lib.mila_safetensors_list.restype = C.c_int64
         _lib.mila_safetensors_list.argtypes = [C.c_char_p, C.c_char_p, C.c_int64]
         _lib.mila_safetensors_copy.argtypes = [C.c_char_p, C.c_char_p]
-        _lib.mila_gemma_set_warm_ahead.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64]
-        _lib.mila_gemma_set_prefetch_ahead.argtypes = [C.c_void_p, C.c_int64, C.c_int]
         _lib.mila_gpt_last_error.restype = C.c_char_p
         _lib.mila_gpt_create.restype = C.c_void_p
         _lib.mila_gpt_create.argtypes = [C.c_int64] * 7
@@ -122,11 +116,6 @@ class Gemma:
         except Exception:
             pass
 
-    def set_chain(self, on):
-        """fused / graph decode with the four Linears between two attention calls as ONE launch (default when the
-        configuration fits) or one launch per Linear; the two give identical bits.  Before the first graph decode."""
-        _check(load().mila_gemma_set_chain(self.h, int(bool(on))))
-
     def rewind(self, position):
         """GemmaTransformer::rewindKvCache(position): True when every block accepted (False beyond the fill, or when a bounded ring has evicted what is needed)"""
         lib = load()
@@ -151,11 +140,6 @@ class Gemma:
         lib.mila_gemma_set_prefill_overlap.argtypes = [C.c_void_p, C.c_int]
         _check(lib.mila_gemma_set_prefill_overlap(self.h, int(bool(on))))
 
-    def set_combine_in_oproj(self, on):
-        """fused / graph decode: fold the flash-decode combine into o_proj's prologue on layers with a small partial set
-        (opt-in: measured slower than the combine launch it removes) or keep the combine launch; identical bits"""
-        _check(load().mila_gemma_set_combine_in_oproj(self.h, int(bool(on))))
-
     def save_safetensors(self, path):
         """every parameter in its storage form (bf16, or e4m3 / packed e2m1 + fp32 scales) as a SafeTensors file"""
         _check(load().mila_gemma_save_safetensors(self.h, str(path).encode()))
@@ -177,21 +161,6 @@ class Gemma:
         or re-stage it into scratch on every forward as the reference does; identical bits"""
         _check(load().mila_gemma_set_resident_prefill_weights(self.h, int(bool(on))))
 
-    def set_onepass_attention(self, on):
-        """fused / graph decode: split decode attention in ONE launch (the workgroup whose partials arrive last merges its
-        head-group's splits) instead of attention + combine launches; identical bits"""
-        _check(load().mila_gemma_set_onepass_attention(self.h, int(bool(on))))
-
-    def set_warm_ahead(self, blocks_a, cap_a, blocks_b, cap_b):
-        """fused / graph decode: extra workgroups of the attention (a) and combine (b) launches touch the lines of o_proj (cap_a
-        bytes) and of the heads of fc_gate_up's halves (cap_b bytes), so those Linears start from the Infinity Cache; same bits"""
-        _check(load().mila_gemma_set_warm_ahead(self.h, int(blocks_a), int(cap_a), int(blocks_b), int(cap_b)))
-
-    def set_prefetch_ahead(self, cap_bytes, workgroups=64):
-        """fused / graph decode: a side stream warms the Infinity Cache with the first cap_bytes of the next Linear's weights
-        while the current kernel runs (0 = off); results unaffected"""
-        _check(load().mila_gemma_set_prefetch_ahead(self.h, int(cap_bytes), int(workgroups)))
-
     def set_fp8_activation_prefill(self, on):
         """fp4 policy: W4A8 prefill on the fp8 matrix cores (default, the reference's default) or the exact-weight bf16 fallback"""
         _check(load().mila_gemma_set_fp8_activation_prefill(self.h, int(bool(on))))
@@ -199,10 +168,6 @@ class Gemma:
     def set_fused_prefill(self, on):
         """prefill with the fused glue kernels (default, when 1024 < D <= 8192) or one launch per reference op; same bits"""
         _check(load().mila_gemma_set_fused_prefill(self.h, int(bool(on))))
-
-    @property
-    def uses_chain(self):
-        return bool(load().mila_gemma_uses_chain(self.h))
 
     def prefill(self, tokens, position_offset=0):
         t = np.ascontiguousarray(tokens, dtype=np.int32)

@@ -125,9 +125,6 @@ namespace Mila::Dnn
         ~GemmaTransformer()
         {
             destroyGraph();
-            if ( fork_ev_ ) (void)hipEventDestroy( fork_ev_ );
-            if ( join_ev_ ) (void)hipEventDestroy( join_ev_ );
-            if ( side_ ) (void)hipStreamDestroy( side_ );
             for ( auto& e : ov_ev_ ) if ( e ) (void)hipEventDestroy( e );
             if ( ov_stream_ ) (void)hipStreamDestroy( ov_stream_ );
         }
@@ -378,24 +375,13 @@ namespace Mila::Dnn
         /// time that kernel with HIP events on the model stream
         void launchGateUp( size_t i ) { fusedGateUp( layers_[ i ] ); }
         double gateUpBytes( size_t i ) const { return static_cast<double>( layers_[ i ].fc_gate_up->getParameterBytes() ); }
-        /// the dominant decode kernel of the active schedule: the chain launch of layer i (not the last layer), or the
-        /// fc_gate_up fused matvec when the chain is off
+        /// the dominant decode kernel of the schedule: the fc_gate_up fused matvec of layer i
         void launchDominant( size_t i )
         {
             if ( !cur_hidden_ ) cur_hidden_ = hidden_[ 0 ]->data();   // no fused step has run yet (reference-order timing)
-            if ( use_chain_ && layers_.size() > 1 ) { const size_t l = i % ( layers_.size() - 1 ); launchChain( l, hidden_[ 0 ]->data(), hidden_[ 1 ]->data() ); }
-            else fusedGateUp( layers_[ i % layers_.size() ] );
+            fusedGateUp( layers_[ i % layers_.size() ] );
         }
-        double dominantBytes( size_t i ) const
-        {
-            if ( use_chain_ && layers_.size() > 1 )
-            {
-                const size_t l = i % ( layers_.size() - 1 );
-                return static_cast<double>( layers_[ l ].o_proj->getParameterBytes() + layers_[ l ].fc_gate_up->getParameterBytes() +
-                                            layers_[ l ].fc_down->getParameterBytes() + layers_[ l + 1 ].qkv_proj->getParameterBytes() );
-            }
-            return gateUpBytes( i % layers_.size() );
-        }
+        double dominantBytes( size_t i ) const { return gateUpBytes( i % layers_.size() ); }
 
     private:
         void destroyGraph() noexcept
@@ -484,20 +470,8 @@ namespace Mila::Dnn
             logits_ = std::make_unique<LogitsTensor>( dev, shape_t{ 1, 1, cfg_.vocab_size } );
             pos_dev_ = std::make_unique<TokenTensor>( dev, shape_t{ 1 } );
             sample_scratch_ = std::make_unique<LogitsTensor>( dev, shape_t{ static_cast<dim_t>( mila_cdna4_sample_scratch_bytes() / 4 ) } );
-            tickets_ = std::make_unique<TokenTensor>( dev, shape_t{ static_cast<dim_t>( mila_cdna4_attn_decode_ticket_count( 1, (int)cfg_.num_heads ) ) } );
-            Compute::rocmCheck( mila_cdna4_memset_zero( tickets_->data(), tickets_->sizeInBytes(), ctx_->getStream() ) );
-            pf_sink_ = std::make_unique<LogitsTensor>( dev, shape_t{ 4 } );
             // split-attention partials of the fused / graph decode step: model-owned and never re-allocated (see captureGraph)
             attn_partials_ = std::make_unique<LogitsTensor>( dev, shape_t{ static_cast<dim_t>( ( attnScratchBytes() + 3 ) / 4 ) } );
-            if ( chainApplicable() )
-            {
-                const size_t nb = mila_cdna4_decode_chain_scratch_bytes( (int)cfg_.embedding_dim, (int)cfg_.hidden_dim );
-                chain_scratch_ = std::make_unique<LogitsTensor>( dev, shape_t{ static_cast<dim_t>( ( nb + 3 ) / 4 ) } );
-                Compute::rocmCheck( mila_cdna4_decode_chain_init( chain_scratch_->data(), chain_scratch_->sizeInBytes(), ctx_->getStream() ) );
-                // opt-in (setUseChain): measured on MI355X the in-launch hand-offs cost MORE than the kernel boundaries
-                // they replace (Gemma-4 12B decode 222 -> 200 tok/s bf16, 410 -> 313 fp4)
-                use_chain_ = false;
-            }
             ctx_->synchronize();
         }
 
@@ -801,7 +775,6 @@ namespace Mila::Dnn
         /// is the prologue of layer l's qkv kernel; the tail of the last layer is the prologue of the head.
         void enqueueFusedStep( const int32_t* token_dev, int position, const int32_t* pos_dev )
         {
-            if ( use_chain_ ) { enqueueChainStep( token_dev, position, pos_dev ); return; }
             mila_stream_t st = ctx_->getStream();
             embed( token_dev, 1, *hidden_[ 0 ] );
             cur_hidden_ = hidden_[ 0 ]->data();
@@ -827,62 +800,15 @@ namespace Mila::Dnn
                 const uint16_t* vp = g ? kp : kp + (size_t)NKV * HD;
                 const size_t need = attnScratchBytes();
                 void* scratch = attn_partials_->data();
-                const int splits = combineSplits( L );
-                if ( splits > 1 )
-                {
-                    // small partial set (sliding-window layers): no combine launch, o_proj combines the splits in its prologue
-                    Compute::rocmCheck( mila_cdna4_fused_attn_decode_partials_bf16( L.keyCache(), L.valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
-                                                                                    L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(),
-                                                                                    scratch, need, NH, NKV, HD, (int)L.cacheCapacity(), position, pos_dev,
-                                                                                    (int)cfg_.windowFor( g ), L.attentionScale(), cfg_.rms_norm_eps, st ) );
-                    const float* sc = nullptr;
-                    if constexpr ( TWeightQuant::kIsQuantized ) sc = L.o_proj->getWeightScale()->data();
-                    Compute::rocmCheck( mila_cdna4_matvec_attn_combine( f_o_->data(), scratch, splits, NH, HD, L.o_proj->getWeight().rawData(), sc, kFmt,
-                                                                        (int)cfg_.embedding_dim, Quant::Weight::groupSizeOf<TWeightQuant>(), st ) );
-                }
-                else
-                {
-                    prefetchLinear( *L.o_proj ); prefetchLinear( *L.fc_gate_up, true );   // beside the latency-bound attention launches
-                    if ( warm_a_blocks_ > 0 || warm_b_blocks_ > 0 )
-                    {
-                        mila_fused_attn_args a{};
-                        a.Y = attn_out_->data(); a.Kc = L.keyCache(); a.Vc = L.valueCache(); a.q_raw = qp; a.k_raw = kp; a.v_raw = vp;
-                        a.qw = L.q_norm->getWeight()->data(); a.kw = L.k_norm->getWeight()->data(); a.vw = L.v_norm->getWeight()->data();
-                        a.cos_cache = L.rope->cosCache(); a.sin_cache = L.rope->sinCache(); a.scratch = scratch; a.scratch_bytes = need;
-                        if ( onepass_attn_ ) { a.tickets = reinterpret_cast<uint32_t*>( tickets_->data() ); a.ticket_count = (size_t)tickets_->size(); }
-                        // the attention launch warms o_proj, the combine launch the heads of fc_gate_up's gate and up halves
-                        a.warm_a = L.o_proj->getWeight().rawData(); a.warm_a_bytes = std::min( L.o_proj->getWeight().sizeInBytes(), warm_a_cap_ ); a.warm_a_blocks = warm_a_blocks_;
-                        const size_t gub = L.fc_gate_up->getWeight().sizeInBytes();
-                        a.warm_b = L.fc_gate_up->getWeight().rawData(); a.warm_b_bytes = std::min( gub, warm_b_cap_ ) / 256 * 256; a.warm_b_blocks = warm_b_blocks_;
-                        a.warm_b_pair_offset = gub / 2;
-                        a.NH = NH; a.NKV = NKV; a.HS = HD; a.capacity = (int)L.cacheCapacity(); a.position = position; a.position_dev = pos_dev;
-                        a.window = (int)cfg_.windowFor( g ); a.scale = L.attentionScale(); a.eps = cfg_.rms_norm_eps;
-                        Compute::rocmCheck( mila_cdna4_fused_attn_decode_ex( &a, st ) );
-                    }
-                    else if ( onepass_attn_ )
-                        Compute::rocmCheck( mila_cdna4_fused_attn_decode_onepass_bf16( attn_out_->data(), L.keyCache(), L.valueCache(), qp, kp, vp,
-                                                                                       L.q_norm->getWeight()->data(), L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(),
-                                                                                       L.rope->cosCache(), L.rope->sinCache(), scratch, need,
-                                                                                       reinterpret_cast<uint32_t*>( tickets_->data() ), (size_t)tickets_->size(), NH, NKV, HD,
-                                                                                       (int)L.cacheCapacity(), position, pos_dev, (int)cfg_.windowFor( g ), L.attentionScale(),
-                                                                                       cfg_.rms_norm_eps, st ) );
-                    else
-                        Compute::rocmCheck( mila_cdna4_fused_attn_decode_bf16( attn_out_->data(), L.keyCache(), L.valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
-                                                                               L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(),
-                                                                               scratch, need, NH, NKV, HD, (int)L.cacheCapacity(), position, pos_dev,
-                                                                               (int)cfg_.windowFor( g ), L.attentionScale(), cfg_.rms_norm_eps, st ) );
-                    // 4. o_proj
-                    plainMatvec( *L.o_proj, f_o_->data(), attn_out_->data() );
-                }
+                Compute::rocmCheck( mila_cdna4_fused_attn_decode_bf16( attn_out_->data(), L.keyCache(), L.valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
+                                                                       L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(),
+                                                                       scratch, need, NH, NKV, HD, (int)L.cacheCapacity(), position, pos_dev,
+                                                                       (int)cfg_.windowFor( g ), L.attentionScale(), cfg_.rms_norm_eps, st ) );
+                // 4. o_proj
+                plainMatvec( *L.o_proj, f_o_->data(), attn_out_->data() );
                 // 5. post_attn_norm + residual + pre_ffn_norm + gate_up + GeGLU
-                prefetchLinear( *L.fc_down );
                 fusedGateUp( L );
                 // 6. fc_down
-                {
-                    const size_t li = L.index;
-                    if ( li + 1 < layers_.size() ) prefetchLinear( *layers_[ li + 1 ].qkv_proj );
-                    else prefetchLinear( *lm_head_ );
-                }
                 plainMatvec( *L.fc_down, f_down_->data(), f_act_->data() );
                 prev = &L;
             }
@@ -897,104 +823,9 @@ namespace Mila::Dnn
                 a.fmt = kTableFmt; a.K = (int)cfg_.embedding_dim; a.N = (int)cfg_.vocab_size; a.group = 0; a.geglu = 0; a.f32_out = 1;
                 Compute::rocmCheck( mila_cdna4_fused_norm_matvec( &a, st ) );
             }
-            joinSide();
-        }
-
-        /// q/k/v norms + RoPE + KV append + flash-decode in one launch (+ combine) for layer L; qkv row = [q | k | v]
-        /// (global: [q | k], V from the raw k projection)
-        void fusedAttention( Layer& L, int position, const int32_t* pos_dev )
-        {
-            const bool g = L.global;
-            const int NH = (int)cfg_.num_heads, NKV = (int)cfg_.numKvHeads( g ), HD = (int)cfg_.headDim( g );
-            const uint16_t* qp = f_qkv_->data();
-            const uint16_t* kp = qp + (size_t)NH * HD;
-            const uint16_t* vp = g ? kp : kp + (size_t)NKV * HD;
-            const size_t need = attnScratchBytes();
-            void* scratch = attn_partials_->data();
-            Compute::rocmCheck( mila_cdna4_fused_attn_decode_bf16( attn_out_->data(), L.keyCache(), L.valueCache(), qp, kp, vp, L.q_norm->getWeight()->data(),
-                                                                   L.k_norm->getWeight()->data(), L.v_norm->getWeight()->data(), L.rope->cosCache(), L.rope->sinCache(),
-                                                                   scratch, need, NH, NKV, HD, (int)L.cacheCapacity(), position, pos_dev,
-                                                                   (int)cfg_.windowFor( g ), L.attentionScale(), cfg_.rms_norm_eps, ctx_->getStream() ) );
-        }
-
-        /// The same step with the four Linears between two attention calls in one launch (mila_cdna4_decode_chain):
-        /// per layer 3 launches (attention, combine, chain) instead of 6; bit-identical to enqueueFusedStep.
-        /// Opt-in: see the note in buildAll().
-        void enqueueChainStep( const int32_t* token_dev, int position, const int32_t* pos_dev )
-        {
-            mila_stream_t st = ctx_->getStream();
-            embed( token_dev, 1, *hidden_[ 0 ] );
-            cur_hidden_ = hidden_[ 0 ]->data();
-            int next = 1;
-            {   // layer 0: input_norm + qkv projection
-                auto a = baseArgs( *layers_[ 0 ].qkv_proj, f_qkv_->data(), cur_hidden_ );
-                a.norm_w = layers_[ 0 ].input_norm->getWeight()->data();
-                Compute::rocmCheck( mila_cdna4_fused_norm_matvec( &a, st ) );
-            }
-            for ( size_t i = 0; i < layers_.size(); ++i )
-            {
-                fusedAttention( layers_[ i ], position, pos_dev );
-                launchChain( i, cur_hidden_, hidden_[ next ]->data() );
-                cur_hidden_ = hidden_[ next ]->data(); next = ( next == 1 ) ? 2 : 1;
-            }
-        }
-
-        /// chain launch of layer i: attention output + residual stream `res` -> next layer's packed qkv (or the logits)
-        /// and the new residual stream `res_out`
-        void launchChain( size_t i, const uint16_t* res, uint16_t* res_out )
-        {
-            auto& L = layers_[ i ];
-            const bool last = ( i + 1 == layers_.size() );
-            mila_decode_chain_args c{};
-            c.attn = attn_out_->data(); c.res = res; c.res_out = res_out;
-            auto scales = []( auto& lin ) -> const float* { if constexpr ( TWeightQuant::kIsQuantized ) return lin.getWeightScale()->data(); else return nullptr; };
-            c.W_o = L.o_proj->getWeight().rawData(); c.s_o = scales( *L.o_proj );
-            c.W_gate_up = L.fc_gate_up->getWeight().rawData(); c.s_gate_up = scales( *L.fc_gate_up );
-            c.W_down = L.fc_down->getWeight().rawData(); c.s_down = scales( *L.fc_down );
-            c.post_attn_w = L.post_attn_norm->getWeight()->data(); c.pre_ffn_w = L.pre_ffn_norm->getWeight()->data();
-            c.post_ffn_w = L.post_ffn_norm->getWeight()->data();
-            c.layer_scalar = L.layer_scalar; c.eps = cfg_.rms_norm_eps;
-            c.fmt = kFmt; c.group = Quant::Weight::groupSizeOf<TWeightQuant>();
-            c.D = (int)cfg_.embedding_dim; c.F = (int)cfg_.hidden_dim; c.K_attn = (int)L.o_proj->getConfig().getInputFeatures();
-            if ( last )
-            {
-                c.y = logits_->data(); c.W_next = lm_head_->getWeight().rawData(); c.s_next = nullptr;
-                if constexpr ( kTableFmt != 0 ) c.s_next = lm_head_->getWeightScale()->data();
-                c.next_norm_w = final_norm_->getWeight()->data(); c.next_fmt = kTableFmt; c.next_group = 0; c.f32_out = 1;
-                c.N_next = (int)cfg_.vocab_size;
-            }
-            else
-            {
-                auto& Nx = layers_[ i + 1 ];
-                c.y = f_qkv_->data(); c.W_next = Nx.qkv_proj->getWeight().rawData(); c.s_next = scales( *Nx.qkv_proj );
-                c.next_norm_w = Nx.input_norm->getWeight()->data(); c.next_fmt = kFmt; c.next_group = c.group; c.f32_out = 0;
-                c.N_next = (int)Nx.qkv_proj->getConfig().getOutputFeatures();
-            }
-            c.scratch = chain_scratch_->data(); c.scratch_bytes = chain_scratch_->sizeInBytes();
-            Compute::rocmCheck( mila_cdna4_decode_chain( &c, ctx_->getStream() ) );
-        }
-
-        /// split count when layer L's attention combine is folded into its o_proj (0 = keep the combine launch): the partial set
-        /// every o_proj workgroup re-reads must stay small, and a wave's 64 x-chunks must span whole heads (HS 256 / 512)
-        int combineSplits( Layer& L ) const
-        {
-            if ( !combine_in_oproj_ ) return 0;
-            const bool g = L.global;
-            const int NH = (int)cfg_.num_heads, NKV = (int)cfg_.numKvHeads( g ), HD = (int)cfg_.headDim( g );
-            if ( ( HD != 256 && HD != 512 ) || NH * HD > 8192 ) return 0;
-            const int splits = mila_cdna4_attn_decode_split_count( 1, NH, NKV, HD, (int)L.cacheCapacity(), (int)cfg_.windowFor( g ) );
-            if ( splits <= 1 || (size_t)NH * splits * ( HD + 4 ) * 4 > ( 512u << 10 ) ) return 0;
-            return splits;
         }
 
     public:
-        /// fold the flash-decode combine into o_proj's prologue where the partial set is small (opt-in: every o_proj workgroup
-        /// re-reading the partials from L2 costs more than the combine launch it removes; same bits)
-        void setCombineInOProj( bool on )
-        {
-            destroyGraph();   // the captured schedule no longer applies: ensureGraph() captures again
-            combine_in_oproj_ = on;
-        }
         // ------------------------------------------------------------------------------------
         // weight ingestion.  Tensor vocabulary = the reference's flat names (the root's own name dropped,
         // Core/LanguageModel.ixx:137-146): `tf_layer_<i>.<child>.weight` (+ `.weight_scale` for a quantized Linear, Linear.ixx:370-400),
@@ -1196,114 +1027,6 @@ namespace Mila::Dnn
                 for ( auto* lin : { L.qkv_proj.get(), L.o_proj.get(), L.fc_gate_up.get(), L.fc_down.get() } ) lin->getOperation().setResidentPrefillWeights( on );
             ctx_->synchronize();
         }
-        /// split decode attention in ONE launch (the workgroup whose partials arrive last merges its head-group's splits) instead of
-        /// attention + combine launches; same bits
-        void setOnepassAttention( bool on )
-        {
-            destroyGraph();   // the captured schedule no longer applies: ensureGraph() captures again
-            onepass_attn_ = on;
-        }
-        /// extra workgroups of the latency-bound attention (a) and combine (b) launches touch the lines of o_proj (up to cap_a bytes)
-        /// and of the heads of fc_gate_up's two halves (cap_b bytes in all): the following Linears start from the Infinity Cache
-        void setWarmAhead( int blocks_a, size_t cap_a, int blocks_b, size_t cap_b )
-        {
-            destroyGraph();   // the captured schedule no longer applies: ensureGraph() captures again
-            if ( blocks_a < 0 || blocks_a > 64 || blocks_b < 0 || blocks_b > 64 ) throw std::invalid_argument( "GemmaTransformer::setWarmAhead: block counts must be in [0, 64]" );
-            if ( use_chain_ && ( blocks_a > 0 || blocks_b > 0 ) ) throw std::invalid_argument( "GemmaTransformer::setWarmAhead: not combinable with setUseChain (the chain needs every compute unit resident)" );
-            warm_a_blocks_ = blocks_a; warm_a_cap_ = cap_a; warm_b_blocks_ = blocks_b; warm_b_cap_ = cap_b;
-        }
-        /// cap_bytes > 0: while one decode kernel runs, a side stream pulls the first cap_bytes of the NEXT Linear's weights into the
-        /// 256 MiB Infinity Cache (mila_cdna4_prefetch_l3), so that the memory system works through kernel ramps, tails and the
-        /// latency-bound attention launches; 0 = off.  Results are unaffected (the prefetch only reads).
-        void setPrefetchAhead( size_t cap_bytes, int workgroups = 64 )
-        {
-            destroyGraph();   // the captured schedule no longer applies: ensureGraph() captures again
-            if ( workgroups < 1 || workgroups > 4096 ) throw std::invalid_argument( "GemmaTransformer::setPrefetchAhead: workgroups out of range" );
-            if ( use_chain_ && cap_bytes > 0 ) throw std::invalid_argument( "GemmaTransformer::setPrefetchAhead: not combinable with setUseChain (the chain needs every compute unit resident)" );
-            if ( cap_bytes > 0 && !side_ )
-            {
-                hipCheck( hipStreamCreateWithFlags( &side_, hipStreamNonBlocking ), "hipStreamCreate" );
-                hipCheck( hipEventCreateWithFlags( &fork_ev_, hipEventDisableTiming ), "hipEventCreate" );
-                hipCheck( hipEventCreateWithFlags( &join_ev_, hipEventDisableTiming ), "hipEventCreate" );
-            }
-            prefetch_cap_ = cap_bytes;
-            prefetch_wgs_ = workgroups;
-        }
-
-    private:
-        /// enqueue (side stream) a prefetch of the first min(bytes, cap) bytes at p, ordered after everything enqueued on the main
-        /// stream so far -- i.e. it runs beside the main-stream kernel enqueued next
-        void prefetchAhead( const void* p, size_t bytes, bool fork = true )
-        {
-            if ( prefetch_cap_ == 0 || p == nullptr || bytes == 0 ) return;
-            hipStream_t main = reinterpret_cast<hipStream_t>( ctx_->getStream() );
-            if ( fork )
-            {
-                hipCheck( hipEventRecord( fork_ev_, main ), "hipEventRecord" );
-                hipCheck( hipStreamWaitEvent( side_, fork_ev_, 0 ), "hipStreamWaitEvent" );
-            }
-            Compute::rocmCheck( mila_cdna4_prefetch_l3( p, std::min( bytes, prefetch_cap_ ), prefetch_wgs_, pf_sink_->data(), reinterpret_cast<mila_stream_t>( side_ ) ) );
-            side_dirty_ = true;
-        }
-        template<typename Lin> void prefetchLinear( Lin& lin, bool geglu = false )
-        {
-            if ( prefetch_cap_ == 0 ) return;
-            const uint8_t* w = static_cast<const uint8_t*>( lin.getWeight().rawData() );
-            const size_t wb = lin.getWeight().sizeInBytes();
-            if ( geglu && wb > prefetch_cap_ )
-            {
-                // the fused gate_up kernel reads gate row n and up row F + n together: warm the head of both halves
-                const size_t cap = prefetch_cap_;
-                prefetch_cap_ = cap / 2;
-                prefetchAhead( w, wb / 2 ); prefetchAhead( w + wb / 2, wb / 2, false );
-                prefetch_cap_ = cap;
-            }
-            else prefetchAhead( w, wb );
-            if constexpr ( Lin::kIsQuantized )
-                if ( lin.getWeightScale() && lin.getWeightScale()->sizeInBytes() > ( 1u << 20 ) ) prefetchAhead( lin.getWeightScale()->data(), lin.getWeightScale()->sizeInBytes(), false );
-        }
-        /// the side stream rejoins the main stream (end of a step; required before hipStreamEndCapture)
-        void joinSide()
-        {
-            if ( !side_dirty_ ) return;
-            hipStream_t main = reinterpret_cast<hipStream_t>( ctx_->getStream() );
-            hipCheck( hipEventRecord( join_ev_, side_ ), "hipEventRecord" );
-            hipCheck( hipStreamWaitEvent( main, join_ev_, 0 ), "hipStreamWaitEvent" );
-            side_dirty_ = false;
-        }
-
-    public:
-        /// whether the decode chain kernel serves this configuration (D, attention width <= 8192, F <= 16384, ...)
-        bool chainApplicable() const
-        {
-            const dim_t D = cfg_.embedding_dim, F = cfg_.hidden_dim;
-            const dim_t ka = cfg_.num_heads * std::max( cfg_.headDim( false ), cfg_.headDim( true ) );
-            const dim_t g = TWeightQuant::kIsQuantized ? std::max<dim_t>( 32, Quant::Weight::groupSizeOf<TWeightQuant>() ) : 32;
-            bool ok = D <= 8192 && ka <= 8192 && F <= 16384 && D % g == 0 && F % g == 0;
-            for ( dim_t i = 0; i < cfg_.num_layers; ++i ) ok = ok && ( cfg_.num_heads * cfg_.headDim( cfg_.isGlobalLayer( i ) ) ) % g == 0;
-            return ok && kTableFmt != 2;
-        }
-        bool usesChain() const { return use_chain_; }
-        /// choose between the one-launch chain and one launch per Linear for the fused / graph decode paths
-        /// (before captureGraph); the two produce identical bits
-        void setUseChain( bool on )
-        {
-            if ( on && !chainApplicable() ) throw std::invalid_argument( "GemmaTransformer::setUseChain: configuration outside the chain kernel's limits" );
-            // the chain's grid-wide hand-offs need all its workgroups resident: nothing of this model may run beside it on another stream
-            if ( on && ( prefetch_cap_ > 0 || warm_a_blocks_ > 0 || warm_b_blocks_ > 0 ) )
-                throw std::invalid_argument( "GemmaTransformer::setUseChain: not combinable with setPrefetchAhead / setWarmAhead (their kernels take compute units the chain needs resident)" );
-            destroyGraph();   // the captured schedule no longer applies: ensureGraph() captures again
-            use_chain_ = on;
-        }
-        /// after a synchronisation point: throws if a hand-off wait inside a chain launch gave up
-        void checkChainStatus()
-        {
-            if ( !chain_scratch_ ) return;
-            int32_t e = 0;
-            Compute::rocmCheck( mila_cdna4_decode_chain_status( chain_scratch_->data(), &e, ctx_->getStream() ) );
-            if ( e != 0 ) throw std::runtime_error( "GemmaTransformer: a decode-chain hand-off wait gave up (phase " + std::to_string( e ) + "): not all workgroups were resident" );
-        }
-
     private:
         std::string name_{ "gemma" };      // the root's name (metadata.model_name in the reference); dropped from flat tensor names
         GemmaConfig cfg_;
@@ -1320,31 +1043,19 @@ namespace Mila::Dnn
         std::unique_ptr<TokenTensor> pos_dev_;
         std::unique_ptr<LogitsTensor> sample_scratch_;
         bool sample_in_graph_{ false };
-        bool use_chain_{ false };
-        bool combine_in_oproj_{ false };   // measured slower on MI355X (bf16 222 -> 217, fp4 415 -> 396 tok/s): opt-in, DESIGN.md section 5
         bool fused_prefill_{ true };
         dim_t kv_fill_{ 0 };      ///< positions the caches hold, as far as eager calls tell (see rewindKvCache)
         bool prefill_overlap_{ false };
         std::unique_ptr<TensorType> ov_qkv_, ov_o_, ov_gate_up_;
         hipStream_t ov_stream_{ nullptr };
         hipEvent_t ov_ev_[ 8 ]{};
-        int warm_a_blocks_{ 0 }, warm_b_blocks_{ 0 };       // extra workgroups of the attention / combine launches that warm the Infinity Cache
-        size_t warm_a_cap_{ 0 }, warm_b_cap_{ 0 };
-        bool onepass_attn_{ false };       // split decode attention without the combine launch (last-arriver merge in the same launch)
-        size_t prefetch_cap_{ 0 };         // > 0: side-stream Infinity-Cache prefetch of the next Linear's weights, at most this many bytes each
-        int prefetch_wgs_{ 64 };
-        bool side_dirty_{ false };
-        hipStream_t side_{ nullptr };
-        hipEvent_t fork_ev_{ nullptr }, join_ev_{ nullptr };
-        std::unique_ptr<TokenTensor> tickets_;
-        std::unique_ptr<LogitsTensor> pf_sink_, attn_partials_;
+        std::unique_ptr<LogitsTensor> attn_partials_;
         std::unique_ptr<TensorType> pf_norm_, pf_norm2_;
         // W4A8 policy: the sandwich tails also write their normalised rows as per-token e4m3 + scales for the Linear that follows ([0]: pre_ffn_norm -> fc_gate_up,
         // [1]: the next block's input_norm -> its qkv_proj); model-owned like every prefill workspace
         std::unique_ptr<TensorType> pf_q8_[ 2 ];          // [1, P, D / 2] bf16 elements = P * D bytes of e4m3
         std::unique_ptr<LogitsTensor> pf_ts_[ 2 ];        // [P] fp32 per-token scales
         bool pf_q8_normed_{ false };       // pf_q8_[1] / pf_ts_[1] hold the rows of pf_norm_ (written by the previous block's second tail in this prefill)
-        std::unique_ptr<LogitsTensor> chain_scratch_;
         const uint16_t* cur_hidden_{ nullptr };
         hipGraph_t graph_{ nullptr };
         hipGraphExec_t graph_exec_{ nullptr };

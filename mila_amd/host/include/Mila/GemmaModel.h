@@ -190,7 +190,19 @@ namespace Mila::Dnn
         [[nodiscard]] GenerateStatus generate( std::span<const int32_t> prompt_tokens, const std::function<void( int32_t )>& on_token, const GenerateParams& params = {},
                                                const std::atomic<bool>* stop = nullptr )
         {
-            return std::visit( [&]( auto& net ) { return onGenerating( *net, prompt_tokens, on_token, params, stop ); }, network_ );
+            return std::visit( [&]( auto& net )
+            {
+                try { return onGenerating( *net, prompt_tokens, on_token, params, stop ); }
+                catch ( const std::invalid_argument& ) { throw; }      // the request checks: nothing was enqueued, the caches are untouched
+                catch ( ... )
+                {
+                    // a replay may still be in flight (awaitSampledToken's timeout, a throwing on_token): drain it before the caller sees the exception,
+                    // and drop the reuse key -- what the in-flight step wrote is not in the history
+                    try { net->context()->synchronize(); } catch ( ... ) {}
+                    kv_token_history_.clear();
+                    throw;
+                }
+            }, network_ );
         }
 
     private:
@@ -203,7 +215,7 @@ namespace Mila::Dnn
             seq_dev_ = std::make_unique<Tensor<TensorDataType::INT32, Compute::RocmDeviceMemoryResource>>( dev, shape_t{ 2 } );      // one 64-bit counter
             auto* ctx = std::visit( []( auto& n ) { return n->context(); }, network_ );
             Compute::rocmCheck( mila_cdna4_memset_zero( seq_dev_->rawData(), 8, ctx->getStream() ) );
-            hipCheck( hipHostMalloc( reinterpret_cast<void**>( &ring_host_ ), kSnapshots * sizeof( unsigned long long ), hipHostMallocMapped ), "hipHostMalloc" );
+            hipCheck( hipHostMalloc( reinterpret_cast<void**>( &ring_host_ ), kSnapshots * sizeof( unsigned long long ), hipHostMallocMapped | hipHostMallocCoherent ), "hipHostMalloc (mapped, coherent token ring)" );      // coherence stated, not left to HIP_HOST_COHERENT: the host polls what the device stores
             std::memset( ring_host_, 0, kSnapshots * sizeof( unsigned long long ) );
             void* dptr = nullptr;
             hipCheck( hipHostGetDevicePointer( &dptr, ring_host_, 0 ), "hipHostGetDevicePointer" );
@@ -270,14 +282,17 @@ namespace Mila::Dnn
             last_reuse_ = reuse;
             const dim_t chunk = model_config_.getPrefillChunk();
             auto* ctx = net.context();
+            // the history claims only what the caches hold at every instant: cut to the reused prefix before the first chunk overwrites positions >= reuse,
+            // extended chunk by chunk, so a chunk that throws leaves no stale claim for the next generate() to "reuse"
+            kv_token_history_.resize( static_cast<size_t>( reuse ) );
             for ( dim_t p0 = reuse; p0 < seq_len; p0 += chunk )
             {
                 const dim_t n = std::min( chunk, seq_len - p0 );
                 Compute::rocmCheck( mila_cdna4_memcpy_h2d( prompt_dev_->rawData(), prompt.data() + p0, static_cast<size_t>( n ) * 4, ctx->getStream() ) );
                 net.prefill( *prompt_dev_, n, p0 );
                 ctx->synchronize();       // prompt_dev_ is reused by the next chunk
+                kv_token_history_.insert( kv_token_history_.end(), prompt.begin() + p0, prompt.begin() + p0 + n );
             }
-            kv_token_history_.assign( prompt.begin(), prompt.end() );
 
             const bool greedy = isGreedy( params.sampling );
             dim_t position = seq_len;

@@ -537,7 +537,9 @@ namespace Mila::Dnn::Compute
         void rewindKvCache( dim_t length )
         {
             if ( length < 0 || length > length_ ) throw std::invalid_argument( "RocmGqaOp::rewindKvCache: bad length" );
-            if ( kBoundedRing && length_ - length >= capacity_ ) throw std::runtime_error( "RocmGqaOp::rewindKvCache: evicted positions cannot be restored" );
+            // ring validity as the reference states it (CudaGqaOp.ixx:182-203): a continuation from `length` attends down to length - window,
+            // so the stale tail [length, length_) must not have wrapped over that range: at most capacity - window (= chunk - 1) stale tokens
+            if ( kBoundedRing && length_ - length > capacity_ - cfg_.window ) throw std::runtime_error( "RocmGqaOp::rewindKvCache: evicted positions cannot be restored" );
             length_ = length;
         }
         dim_t cacheLength() const noexcept { return length_; }

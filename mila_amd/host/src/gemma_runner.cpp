@@ -136,13 +136,6 @@ HOST_API int mila_gemma_prefill( void* h, const int32_t* host_tokens, int64_t T,
     } );
 }
 
-/// on != 0: the fused / graph decode paths run the four Linears between two attention calls as one chain launch
-/// (default when the configuration fits); 0: one launch per Linear.  Call before the first graph-mode decode.
-HOST_API int mila_gemma_set_chain( void* h, int on )
-{
-    auto* r = static_cast<Runner*>( h );
-    return guarded( [&] { std::visit( [&]( auto& m ) { m->setUseChain( on != 0 ); }, r->model ); } );
-}
 /// on != 0 (default): prefill runs the fused glue kernels when the configuration fits; 0: one launch per reference op
 HOST_API int mila_gemma_set_fused_prefill( void* h, int on )
 {
@@ -179,11 +172,6 @@ HOST_API int mila_gemma_set_prefill_overlap( void* h, int on )
     return guarded( [&] { std::visit( [&]( auto& m ) { m->setPrefillOverlap( on != 0 ); }, static_cast<Runner*>( h )->model ); } );
 }
 
-HOST_API int mila_gemma_set_combine_in_oproj( void* h, int on )
-{
-    auto* r = static_cast<Runner*>( h );
-    return guarded( [&] { std::visit( [&]( auto& m ) { m->setCombineInOProj( on != 0 ); }, r->model ); } );
-}
 /// every parameter of the model in its storage form -> a SafeTensors file / back (component paths as tensor names)
 HOST_API int mila_gemma_save_safetensors( void* h, const char* path )
 {
@@ -295,38 +283,11 @@ HOST_API int mila_gemma_set_resident_prefill_weights( void* h, int on )
     auto* r = static_cast<Runner*>( h );
     return guarded( [&] { std::visit( [&]( auto& m ) { m->setResidentPrefillWeights( on != 0 ); }, r->model ); } );
 }
-/// on != 0: split decode attention runs in ONE launch (last-arriver merge) instead of attention + combine; same bits
-HOST_API int mila_gemma_set_onepass_attention( void* h, int on )
-{
-    auto* r = static_cast<Runner*>( h );
-    return guarded( [&] { std::visit( [&]( auto& m ) { m->setOnepassAttention( on != 0 ); }, r->model ); } );
-}
-/// extra workgroups of the attention / combine launches warm the Infinity Cache with o_proj / the head of fc_gate_up (0 blocks = off)
-HOST_API int mila_gemma_set_warm_ahead( void* h, int blocks_a, int64_t cap_a, int blocks_b, int64_t cap_b )
-{
-    auto* r = static_cast<Runner*>( h );
-    return guarded( [&] { std::visit( [&]( auto& m ) { m->setWarmAhead( blocks_a, (size_t)std::max<int64_t>( cap_a, 0 ), blocks_b, (size_t)std::max<int64_t>( cap_b, 0 ) ); }, r->model ); } );
-}
-/// cap_bytes > 0: side-stream Infinity-Cache prefetch of the next Linear's weights (at most cap_bytes each) beside the running
-/// decode kernel; 0 = off.  Call before the first graph-mode decode.
-HOST_API int mila_gemma_set_prefetch_ahead( void* h, int64_t cap_bytes, int workgroups )
-{
-    auto* r = static_cast<Runner*>( h );
-    return guarded( [&] { std::visit( [&]( auto& m ) { m->setPrefetchAhead( cap_bytes > 0 ? (size_t)cap_bytes : 0, workgroups ); }, r->model ); } );
-}
 /// fp4 policy: on != 0 (default, as in the reference) = W4A8 prefill on the fp8 matrix cores; 0 = dequantize -> bf16 GEMM
 HOST_API int mila_gemma_set_fp8_activation_prefill( void* h, int on )
 {
     auto* r = static_cast<Runner*>( h );
     return guarded( [&] { std::visit( [&]( auto& m ) { m->setFp8ActivationPrefill( on != 0 ); }, r->model ); } );
-}
-/// 1 if the chain launch is in use, 0 if not
-HOST_API int mila_gemma_uses_chain( void* h )
-{
-    auto* r = static_cast<Runner*>( h );
-    int u = 0;
-    std::visit( [&]( auto& m ) { u = m->usesChain() ? 1 : 0; }, r->model );
-    return u;
 }
 
 /// mode: 0 reference-order (one launch per component), 1 fused schedule, 2 graph replay (position from device)
@@ -347,7 +308,6 @@ HOST_API int mila_gemma_decode( void* h, int32_t token, int64_t position, int mo
                 m->replayGraph();
             }
             m->context()->synchronize();
-            if ( mode != 0 ) m->checkChainStatus();
         }, r->model );
         download_logits( r, host_logits );
     } );
@@ -395,7 +355,6 @@ HOST_API int mila_gemma_time_decode( void* h, int64_t start_position, int steps,
             (void)hipEventDestroy( e0 ); (void)hipEventDestroy( e1 );
             out[ 0 ] = std::chrono::duration<double, std::milli>( t1 - t0 ).count() / steps;
             out[ 1 ] = static_cast<double>( ms ) / steps;
-            if ( mode != 0 ) m->checkChainStatus();
         }, r->model );
     } );
 }
@@ -430,7 +389,6 @@ HOST_API int mila_gemma_time_dominant_kernel( void* h, int rounds, double* out )
             double bytes = 0;
             for ( size_t i = 0; i < L; ++i ) bytes += m->dominantBytes( i );
             out[ 1 ] = bytes / static_cast<double>( L );
-            m->checkChainStatus();
         }, r->model );
     } );
 }

@@ -105,6 +105,39 @@ def test_kv_prefix_reuse_never_changes_the_tokens(bounded):
         b.close()
 
 
+def test_bounded_ring_refuses_a_rewind_whose_stale_tail_wrapped_over_the_window():
+    """CudaGqaOp.ixx:182-203: a bounded ring accepts a rewind only while the stale tail is at most capacity - window (= chunk - 1) tokens; a tail of
+    chunk .. capacity - 1 tokens has overwritten ring slots the continuation's window still needs (the port used to accept it and
+    attended to future K/V).  window 16, chunk 8 => capacity 23; 45 positions written, divergence 15 before the fill: refused, full prefill, and the
+    tokens are a fresh model's"""
+    cfg = dict(SMALL, bounded_local_kv=1)
+    rng = np.random.default_rng(11)
+    long_prompt = [int(t) for t in rng.integers(2, 1000, 40)]
+    stop = [1023]
+    a = host.GemmaModel.synthetic("bf16", cfg, context=64, prefill_chunk=8, seed=5)
+    b = host.GemmaModel.synthetic("bf16", cfg, context=64, prefill_chunk=8, seed=5)
+    try:
+        first, _, _ = a.generate(long_prompt, max_new_tokens=6, stop_tokens=stop)
+        written = len(long_prompt) + len(first) - 1
+        for keep in (written - 15, written - 8, written - 22):          # stale tails of chunk .. capacity - 1 tokens: every one must be refused
+            other = long_prompt[:keep] + [601, 602, 603]
+            a.generate(long_prompt, max_new_tokens=6, stop_tokens=stop)                    # refill the caches to `written`
+            got, _, reused = a.generate(other, max_new_tokens=6, stop_tokens=stop)
+            fresh, _, _ = b.generate(other, max_new_tokens=6, stop_tokens=stop)
+            b.generate([5], max_new_tokens=1, stop_tokens=stop)                           # b never reuses: its history is one unrelated token
+            assert reused == 0, keep
+            assert got == fresh, keep
+        # a tail of at most chunk - 1 tokens is still served from the caches, with the same tokens
+        a.generate(long_prompt, max_new_tokens=6, stop_tokens=stop)
+        other = (long_prompt + first)[:written - 5] + [604]
+        got, _, reused = a.generate(other, max_new_tokens=6, stop_tokens=stop)
+        fresh, _, _ = b.generate(other, max_new_tokens=6, stop_tokens=stop)
+        assert reused == written - 5 and got == fresh
+    finally:
+        a.close()
+        b.close()
+
+
 def test_stochastic_sampling_is_seeded_and_top_k_1_is_greedy():
     """SamplingParams (Components/Transformers/SamplingParams.ixx): top_k = 1 == greedy; the same seed gives the same draw sequence"""
     g = host.GemmaModel.synthetic("bf16", SMALL, context=64, prefill_chunk=16, seed=21)

@@ -460,7 +460,7 @@ def test_w4a8_prefill_matches_the_restated_reference(M, K, N, bias):
     quantization are integer outputs -> bit-exact; the fp8 x fp8 MFMA GEMM with the two-step scaling epilogue -> within 2 bf16 ulp
     of the restated reference (fp32 accumulation order is the only freedom), for the 256x256 and the 256x128 kernels"""
     lib = capi.load()
-    assert lib.mila_cdna4_gemm_fp8_applicable(M, K, N) == 1 and lib.mila_cdna4_gemm_fp8_applicable(M, K + 64, N) == 0
+    assert lib.mila_cdna4_gemm_fp8_applicable(M, K, N) == 1 and lib.mila_cdna4_gemm_fp8_applicable(M, K + 8, N) == 0
     rng = np.random.default_rng(N + K)
     Wb = _weights(rng, N, K, "random")
     q4, s4 = orc.quantize_fp4_per_group(Wb, 128)
@@ -527,6 +527,83 @@ def test_w4a8_gemm_with_geglu_epilogue_is_bit_identical_to_w4a8_gemm_then_geglu(
     capi.call("geglu_bf16", Y0, GU, M, F)
     capi.call("gemm_geglu_bf16_w4a8", Y1, X, dev_u8(q4), dev_f32(s4), ws, M, K, F, 128, scratch, C.c_size_t(need))
     assert np.array_equal(bits(Y0), bits(Y1))
+
+
+def _w4a8_operands(rng, M, K, N, G=128):
+    Wb = _weights(rng, N, K, "random")
+    q4, s4 = orc.quantize_fp4_per_group(Wb, G)
+    X = orc.round_bf16((rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32))
+    ws = orc.fp8_weight_scale_from_groups(s4)
+    w8 = orc.upcast_fp4_to_fp8(q4, s4, ws, G)
+    x8, ts = orc.quantize_act_fp8_per_token(X)
+    return X, q4, s4, ws, w8, x8, ts
+
+
+@pytest.mark.parametrize("M,K,N,bias,G", [(2, 3840, 8704, False, 128), (16, 512, 256, True, 128), (33, 192, 250, True, 64), (300, 384, 3840, True, 128),
+                                          (2000, 256, 8192, False, 128), (2049, 256, 8192, True, 128), (2048 + 77, 128, 3840, False, 128),
+                                          (1024 + 255, 256, 30720, True, 128)])
+def test_w4a8_serves_every_row_count_like_the_reference(M, K, N, bias, G):
+    """CudaLinearOp.ixx:646-715 runs W4A8 for EVERY M > 1; here the LDS-DMA fp8 kernels take the leading multiple of 256 rows and the masked 128-row
+    kernel (csrc/gemm_fp8_tail.hip) the rest, or all of them: gemm_fp8_applicable is true at M in {2, 16, 2000, 2049, ...}, sampled rows of both parts are
+    within 2 ulp of the restated reference, and the split changes no bit (every row through the masked kernel == the default split)"""
+    lib = capi.load()
+    assert lib.mila_cdna4_gemm_fp8_applicable(M, K, N) == 1
+    rng = np.random.default_rng(M * 7 + N)
+    X, q4, s4, ws, w8, x8, ts = _w4a8_operands(rng, M, K, N, G)
+    bb = orc.to_bf16_bits(rng.uniform(-0.1, 0.1, N).astype(np.float32)) if bias else None
+    ws_d = dev_f32(np.array([ws], dtype=np.float32))
+    X8, W8, ts_d = dev_u8(x8), dev_u8(w8), dev_f32(ts)
+    Y = empty_u16(M, N)
+    capi.call("gemm_fp8_scaled", Y, X8, W8, ts_d, ws_d, dev_u16(bb) if bias else None, M, K, N)
+    main = M - M % 256
+    rows = sorted({0, 1, M // 2, M - 1, max(0, main - 1), min(M - 1, main), min(M - 1, main + 127), min(M - 1, main + 128)})
+    raw = orc.linear_fp8a_fp8w(x8[rows], np.ones(len(rows), dtype=np.float32), w8, None, ws, None)
+    exp = orc.round_bf16(raw.astype(np.float32)).astype(np.float64) * ts[rows].astype(np.float64)[:, None]
+    if bias:
+        exp = exp + orc.from_bf16_bits(bb).astype(np.float64)
+    assert_bf16_close(bits(Y)[rows], exp, 2, 1e-3 * float(np.abs(exp).max()), "fp8 GEMM (ragged M) vs restated reference")
+    # the one-call form (stages W8 / X8 itself) gives the same bits
+    need = lib.mila_cdna4_gemm_w4a8_scratch_bytes(M, K, N)
+    scratch = torch.empty(need, dtype=torch.uint8, device="cuda")
+    Y2 = empty_u16(M, N)
+    capi.call("gemm_bf16_w4a8", Y2, dev_u16(orc.to_bf16_bits(X)), dev_u8(q4), dev_f32(s4), ws_d, dev_u16(bb) if bias else None, M, K, N, G,
+              scratch, C.c_size_t(need))
+    assert np.array_equal(bits(Y2), bits(Y))
+    # every row on the masked kernel: bit-identical to the split
+    Y3 = empty_u16(M, N)
+    capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(1))
+    try:
+        capi.call("gemm_fp8_scaled", Y3, X8, W8, ts_d, ws_d, dev_u16(bb) if bias else None, M, K, N)
+    finally:
+        capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(0))
+    assert np.array_equal(bits(Y3), bits(Y)), "the masked fp8 kernel and the LDS-DMA fp8 kernels differ"
+
+
+@pytest.mark.parametrize("M,K,F", [(2, 256, 15360), (100, 384, 1000), (512 + 100, 256, 15360), (2049, 128, 15360)])
+def test_w4a8_geglu_form_serves_every_row_count(M, K, F):
+    """the fused Linear + GeGLU W4A8 form at ragged M: bit-identical to gemm_bf16_w4a8 + geglu_bf16 (Gemma.Block.ixx:343-348), and to itself with every row on
+    the masked kernel"""
+    lib = capi.load()
+    assert lib.mila_cdna4_gemm_geglu_w4a8_applicable(M, K, F) == 1
+    rng = np.random.default_rng(M + F)
+    Wb = _weights(rng, 2 * F, K, "random")
+    q4, s4 = orc.quantize_fp4_per_group(Wb, 128)
+    X = dev_u16(orc.to_bf16_bits(orc.round_bf16(rng.uniform(-2, 2, (M, K)).astype(np.float32))))
+    ws = empty_f32(1)
+    capi.call("fp4_weight_fp8_scale", ws, dev_f32(s4), C.c_int64(s4.size))
+    need = lib.mila_cdna4_gemm_w4a8_scratch_bytes(M, K, 2 * F)
+    scratch = torch.empty(need, dtype=torch.uint8, device="cuda")
+    GU, Y0, Y1, Y2 = empty_u16(M, 2 * F), empty_u16(M, F), empty_u16(M, F), empty_u16(M, F)
+    capi.call("gemm_bf16_w4a8", GU, X, dev_u8(q4), dev_f32(s4), ws, None, M, K, 2 * F, 128, scratch, C.c_size_t(need))
+    capi.call("geglu_bf16", Y0, GU, M, F)
+    capi.call("gemm_geglu_bf16_w4a8", Y1, X, dev_u8(q4), dev_f32(s4), ws, M, K, F, 128, scratch, C.c_size_t(need))
+    assert np.array_equal(bits(Y0), bits(Y1))
+    capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(1))
+    try:
+        capi.call("gemm_geglu_bf16_w4a8", Y2, X, dev_u8(q4), dev_f32(s4), ws, M, K, F, 128, scratch, C.c_size_t(need))
+    finally:
+        capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(0))
+    assert np.array_equal(bits(Y2), bits(Y1))
 
 
 @pytest.mark.parametrize("M", [2048 + 77, 1024 + 255, 768 + 1, 512 + 3])

@@ -172,18 +172,37 @@ def _decode_rows(X, q, s, G):
 
 def test_Linear_Cuda_cpp_773_Forward_Fp4PrefillMatchesDecodeAcrossTokenMagnitudes():
     """16 rows spanning fifteen decades, K = 512 (four FP4 groups), N = 256: the batched prefill forward must match the decode
-    matvec over the SAME loaded weights row for row within 1e-1 * row_absmax (:838-879).  At this shape the op's prefill is the
-    dequantize -> bf16 MFMA GEMM (RocmLinearOp::forward: no fp8 kernel serves M = 16), as the reference's is with the toggle off"""
+    matvec over the SAME loaded weights row for row within 1e-1 * row_absmax (:838-879).  The op's prefill at this shape is the
+    reference's default, W4A8 (fp4 -> e4m3 weights, per-token e4m3 activations, fp8 x fp8 MFMA: CudaLinearOp.ixx:646-715) -- served
+    at M = 16 by the masked fp8 kernel (round 3; it used to fall back to the dequantize -> bf16 GEMM) -- and the toggle-off leg
+    (W4A16) is held to the same bar, as the reference's comment says it must (:755-758)"""
     M, K, N, G = 16, 512, 256, 128
     Wb, X = _fp4_fixture(M, N, K)
     q, s = empty_u8(N, K // 2), empty_f32(N, K // G)
     capi.call("quantize_fp4_per_group", q, s, dev_u16(Wb), N, K, G)
     eq, es = orc.quantize_fp4_per_group(Wb, G)
     assert np.array_equal(host(q), eq) and np.array_equal(host(s), es)          # loadParameter's quantize-on-load, bit-exact
-    assert not capi.load().mila_cdna4_gemm_fp8_applicable(M, K, N)
+    lib = capi.load()
+    assert lib.mila_cdna4_gemm_fp8_applicable(M, K, N)                          # RocmLinearOp::forward takes the W4A8 route at every M > 1
+    decode = _decode_rows(X, eq, es, G)
+    # --- the default route: W4A8 ---
+    sB = empty_f32(1)
+    capi.call("fp4_weight_fp8_scale", sB, s, C.c_int64(N * (K // G)))
+    need = lib.mila_cdna4_gemm_w4a8_scratch_bytes(M, K, N)
+    scratch = torch.empty(need, dtype=torch.uint8, device="cuda")
+    Y8 = empty_u16(M, N)
+    capi.call("gemm_bf16_w4a8", Y8, _d(X), q, s, sB, None, M, K, N, G, scratch, C.c_size_t(need))
+    prefill8 = _f(Y8).reshape(M, N)
+    for m in range(M):
+        tol = 1e-1 * np.abs(decode[m]).max()
+        assert np.abs(prefill8[m] - decode[m]).max() <= tol, "W4A8 row %d (magnitude 1e%d)" % (m, m - 8)
+    W8 = orc.upcast_fp4_to_fp8(eq, es, float(host(sB)[0]), G)
+    X8, ts = orc.quantize_act_fp8_per_token(X)
+    assert_bf16_close(bits(Y8), orc.linear_fp8a_fp8w(X8, ts, W8, None, float(host(sB)[0])), 2, 0.0, "W4A8 at M = 16 vs the restated reference")
+    # --- the toggle-off route: W4A16 ---
     Y = empty_u16(M, N)
     capi.call("gemm_bf16_w4a16", Y, _d(X), q, s, None, M, K, N, G)
-    prefill, decode = _f(Y).reshape(M, N), _decode_rows(X, eq, es, G)
+    prefill = _f(Y).reshape(M, N)
     for m in range(M):
         tol = 1e-1 * np.abs(decode[m]).max()
         assert np.abs(prefill[m] - decode[m]).max() <= tol, "row %d (magnitude 1e%d)" % (m, m - 8)

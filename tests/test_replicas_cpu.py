@@ -72,3 +72,17 @@ def test_bench_under_the_drivers_launcher():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                                   # rank 0 prints ONE line
     assert json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_a_replica_that_dies_ends_the_command_non_zero_and_promptly():
+    """a rank >= 1 that exits before the barrier: the parent ends the others instead of leaving rank 0 in the gloo barrier until the
+    process-group timeout, and the command's exit code is non-zero"""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MILA_BENCH_STUB_FAIL_RANK"] = "1"
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--gpus", "2", "--steps", "6", "--warmup", "1"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0
+    assert time.time() - t0 < 120
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

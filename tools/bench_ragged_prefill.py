@@ -1,0 +1,20 @@
+"""fp4 policy (W4A8) prefill at ragged prompt lengths: T = 2049 / 2000 / 100 against T = 2048 (within 1.1x)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mila_amd import host
+
+policies = sys.argv[1].split(",") if len(sys.argv) > 1 else ["fp4"]
+out = {}
+for pol in policies:
+    m = host.Gemma(pol, max_seq=4096, max_prefill=2304, seed=1)
+    res = {}
+    for T in (2048, 2049, 2000, 2303, 300, 16):
+        m.time_prefill(T, 1)
+        res[T] = round(m.time_prefill(T, 3), 3)
+    m.close()
+    out[pol] = res
+    print(pol, res, flush=True)
+print(json.dumps(out))
