@@ -6,6 +6,7 @@
 Outputs (git-ignored, but they travel with gpurun):
     mila_amd/lib/libmila_cdna4.so       the C-ABI device backend (include/mila_cdna4.h)
     mila_amd/lib/libmila_host.so        the C++ host mirror's C entry points (model runners)
+    mila_amd/lib/libmila_cdna4_experiments.so   csrc/experiments/: the measured-slower in-launch decode forms (chain, engine); tests / tools only
 """
 import concurrent.futures as cf
 import os
@@ -76,6 +77,25 @@ def build(force=False, verbose=False):
         if missing:
             os.remove(lib)
             raise RuntimeError("kernels without a host stub in %s:\n%s" % (lib, "\n".join(missing)))
+
+    # experiments (csrc/experiments/*.hip): a library of their own, linked against the product's, loaded only by tests/ and tools/
+    exp_dir = os.path.join(CSRC, "experiments")
+    if os.path.isdir(exp_dir):
+        eobjs, ejobs = [], []
+        for s_ in sorted(f for f in os.listdir(exp_dir) if f.endswith(".hip")):
+            src = os.path.join(exp_dir, s_)
+            obj = os.path.join(OBJDIR, "exp_" + s_[:-4] + ".o")
+            eobjs.append(obj)
+            if force or _newer(obj, [src] + hdrs):
+                ejobs.append([HIPCC] + KERNEL_FLAGS + ["-c", src, "-o", obj])
+        if ejobs:
+            with cf.ThreadPoolExecutor(max_workers=min(6, len(ejobs))) as ex:
+                for out in ex.map(_run, ejobs):
+                    if verbose and out.strip():
+                        print(out)
+        elib = os.path.join(LIBDIR, "libmila_cdna4_experiments.so")
+        if eobjs and (force or ejobs or _newer(elib, eobjs + [lib])):
+            _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", elib] + eobjs + ["-L" + LIBDIR, "-lmila_cdna4", "-Wl,-rpath,$ORIGIN"])
 
     # C++ host mirror (template surface + model runners) -> libmila_host.so
     host_src = os.path.join(HOST, "src")

@@ -30,6 +30,31 @@ class InvalidArgument(MilaError, ValueError):
 
 
 _lib = None
+EXPERIMENTS_PATH = os.path.join(_HERE, "lib", "libmila_cdna4_experiments.so")
+
+
+class _Libs:
+    """the product library, with libmila_cdna4_experiments.so (csrc/experiments/: decode chain + engine, tests / tools only) behind it: a symbol the
+    product does not export is looked up there, and only then is that library loaded"""
+
+    def __init__(self, main):
+        self.__dict__["_main"] = main
+        self.__dict__["_exp"] = None
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._main, name)
+        except AttributeError:
+            if not name.startswith("mila_cdna4_"):
+                raise
+        if self._exp is None:
+            if not os.path.exists(EXPERIMENTS_PATH):
+                raise AttributeError("%s: not exported by libmila_cdna4.so, and %s is missing" % (name, EXPERIMENTS_PATH))
+            exp = C.CDLL(EXPERIMENTS_PATH)
+            exp.mila_cdna4_decode_chain_scratch_bytes.restype = C.c_size_t
+            exp.mila_cdna4_decode_engine_scratch_bytes.restype = C.c_size_t
+            self.__dict__["_exp"] = exp
+        return getattr(self._exp, name)
 
 
 def load():
@@ -44,16 +69,15 @@ def load():
         import torch  # noqa: F401  (loads torch's libamdhip64 first so there is one runtime in-process)
     except Exception:
         pass
-    _lib = C.CDLL(LIB_PATH)
-    _lib.mila_cdna4_last_error.restype = C.c_char_p
-    _lib.mila_cdna4_attn_decode_scratch_bytes.restype = C.c_size_t
-    _lib.mila_cdna4_gemm_staging_bytes.restype = C.c_size_t
-    _lib.mila_cdna4_sample_scratch_bytes.restype = C.c_size_t
-    _lib.mila_cdna4_gemm_w4a8_scratch_bytes.restype = C.c_size_t
-    _lib.mila_cdna4_sample_stochastic_scratch_bytes.restype = C.c_size_t
-    _lib.mila_cdna4_decode_chain_scratch_bytes.restype = C.c_size_t
-    _lib.mila_cdna4_decode_engine_scratch_bytes.restype = C.c_size_t
-    _lib.mila_cdna4_attn_decode_ticket_count.restype = C.c_size_t
+    main = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)      # global: the experiments library resolves the shared runtime helpers against it
+    main.mila_cdna4_last_error.restype = C.c_char_p
+    main.mila_cdna4_attn_decode_scratch_bytes.restype = C.c_size_t
+    main.mila_cdna4_gemm_staging_bytes.restype = C.c_size_t
+    main.mila_cdna4_sample_scratch_bytes.restype = C.c_size_t
+    main.mila_cdna4_gemm_w4a8_scratch_bytes.restype = C.c_size_t
+    main.mila_cdna4_sample_stochastic_scratch_bytes.restype = C.c_size_t
+    main.mila_cdna4_attn_decode_ticket_count.restype = C.c_size_t
+    _lib = _Libs(main)
     return _lib
 
 
@@ -126,7 +150,7 @@ EXPORTED = [
     "gemm_geglu_applicable", "gemm_geglu_bf16", "gemm_geglu_bf16_w8a16_staged", "gemm_geglu_bf16_w4a16_staged",
     "quantize_fp8_per_channel", "quantize_fp4_per_group",
     "kv_write_bf16", "attn_decode_scratch_bytes", "attn_decode_bf16", "attn_prefill_bf16", "mha_bf16",
-    "rmsnorm_bf16", "layernorm_bf16", "layernorm_fp32", "softmax_fp32", "softmax_bf16",
+    "rmsnorm_bf16", "rmsnorm_fp32", "layernorm_bf16", "layernorm_fp32", "softmax_fp32", "softmax_bf16",
     "gelu_bf16", "gelu_fp32", "geglu_bf16", "residual_bf16", "residual_fp32",
     "rope_build_cache", "rope_forward_bf16",
     "embedding_gather_bf16", "embedding_gather_bf16_qfp8", "lpe_bf16", "split3_bf16", "scale_bf16",
@@ -135,8 +159,20 @@ EXPORTED = [
     "sample_stochastic_scratch_bytes", "sample_stochastic_fp32", "sample_stochastic_bf16",
     "fused_norm_matvec", "fused_qkv_post", "fused_qkv_post_prefill", "fused_tail_norm_bf16", "fused_tail_norm_quant_bf16",
     "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position", "advance_position_snapshot", "snapshot_token", "fused_attn_decode_bf16",
+    "dequantize_to_bf16", "gemm_geglu_fp8_scaled",
+]
+
+# csrc/internal.h: test / tuning hooks and the measured-slower experiments -- exported, but not part of the drop-in ABI
+INTERNAL = [
+    "tune_matvec", "tune_gemm", "tune_gemm_schedule", "tune_gemm_fp8_tail_only", "tune_attn_split", "tune_flash_dsplit", "decode_engine_debug",
+    "selftest_decode", "selftest_wave_reduce", "selftest_mfma_fp8", "stream_copy", "stream_read",
     "attn_decode_split_count", "fused_attn_decode_partials_bf16", "matvec_attn_combine",
     "decode_chain_scratch_bytes", "decode_chain_init", "decode_chain_status", "decode_chain",
     "decode_engine_scratch_bytes", "decode_engine_init", "decode_engine_status", "decode_engine_applicable", "decode_engine",
-    "attn_decode_ticket_count", "fused_attn_decode_onepass_bf16", "prefetch_l3", "fused_attn_decode_ex", "dequantize_to_bf16", "gemm_geglu_fp8_scaled",
+    "attn_decode_ticket_count", "fused_attn_decode_onepass_bf16", "prefetch_l3", "fused_attn_decode_ex",
+]
+# ... of which these live in libmila_cdna4_experiments.so
+EXPERIMENTS_LIB = [
+    "decode_chain_scratch_bytes", "decode_chain_init", "decode_chain_status", "decode_chain",
+    "decode_engine_scratch_bytes", "decode_engine_init", "decode_engine_status", "decode_engine_applicable", "decode_engine", "decode_engine_debug",
 ]

@@ -9,12 +9,14 @@
 namespace mila {
 
 // ---- host-side error plumbing ----------------------------------------------------------------
-int set_error(int code, const char* fmt, ...);   // runtime.hip; returns `code`
+// (default visibility: libmila_cdna4_experiments.so -- csrc/experiments/, never loaded by the product -- links these three from libmila_cdna4.so)
+#define MILA_SHARED_HELPER __attribute__((visibility("default")))
+MILA_SHARED_HELPER int set_error(int code, const char* fmt, ...);   // runtime.hip; returns `code`
 /// the mila_cdna4_tune_* hooks (csrc/internal.h) mutate process-wide launch heuristics: they act only in a process that set
 /// MILA_CDNA4_TUNING=1 before the library was loaded (tests, tools/); in any other process they return MILA_E_UNSUPPORTED and
 /// the library keeps no state between calls
-bool tuning_hooks_enabled();
-int check_hip(hipError_t e, const char* what);   // MILA_OK or MILA_E_RUNTIME (+ message)
+MILA_SHARED_HELPER bool tuning_hooks_enabled();
+MILA_SHARED_HELPER int check_hip(hipError_t e, const char* what);   // MILA_OK or MILA_E_RUNTIME (+ message)
 
 #define MILA_REQUIRE(cond, ...)                                        \
     do {                                                               \

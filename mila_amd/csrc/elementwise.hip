@@ -299,18 +299,24 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(u32x4* __restrict__ ds
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) dst[i] = src[i];
 }
-__global__ __launch_bounds__(256) void stream_read_kernel(float* __restrict__ sink, const u32x4* __restrict__ src, int64_t nvec)
+// The streaming yardstick in the matvec's own launch shape: one 16-wave workgroup per CU, every wave pulls contiguous 8 KiB pieces (eight 1-KiB
+// non-temporal wave-loads in flight, as the distance-2 pipeline of matvec_body.h keeps), pieces dealt round-robin over all waves of the grid.
+__global__ __launch_bounds__(1024) void stream_read_kernel(float* __restrict__ sink, const u32x4* __restrict__ src, int64_t nvec)
 {
-    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    constexpr int U = 8;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 16;
     uint32_t acc = 0;
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * (stride / 4) < nvec; i += stride)
+    int64_t base = wave * (64 * U);
+    for (; base + 64 * U <= nvec; base += nwaves * (64 * U))
     {
-        const u32x4 a = ld16_nt(src + i), b = ld16_nt(src + i + stride / 4), c = ld16_nt(src + i + 2 * (stride / 4)),
-                    d = ld16_nt(src + i + 3 * (stride / 4));
-        acc ^= a[0] ^ a[1] ^ a[2] ^ a[3] ^ b[0] ^ b[1] ^ b[2] ^ b[3] ^ c[0] ^ c[1] ^ c[2] ^ c[3] ^ d[0] ^ d[1] ^ d[2] ^ d[3];
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ld16_nt(src + base + u * 64 + lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u][0] ^ v[u][1] ^ v[u][2] ^ v[u][3];
     }
-    for (; i < nvec; i += stride / 4)
+    for (int64_t i = base + lane; i < nvec && i < base + 64 * U; i += 64)
     {
         const u32x4 a = ld16_nt(src + i);
         acc ^= a[0] ^ a[1] ^ a[2] ^ a[3];
@@ -499,7 +505,7 @@ int mila_cdna4_stream_copy(void* dst, const void* src, size_t bytes, mila_stream
 int mila_cdna4_stream_read(float* sink, const void* src, size_t bytes, mila_stream_t stream)
 {
     MILA_REQUIRE(sink && src && bytes % 16 == 0, "stream_read: bad arguments");
-    hipLaunchKernelGGL(stream_read_kernel, dim3(2048), dim3(256), 0, as_stream(stream), sink, (const u32x4*)src,
+    hipLaunchKernelGGL(stream_read_kernel, dim3(kNumCU), dim3(1024), 0, as_stream(stream), sink, (const u32x4*)src,
                        (int64_t)(bytes / 16));
     MILA_LAUNCH_CHECK("stream_read");
 }

@@ -25,10 +25,10 @@
 // run: results are bit-identical to the unfused sequence whatever (R, U) a phase uses.
 #include <algorithm>
 
-#include "common.h"
-#include "internal.h"
-#include "rms_common.h"
-#include "matvec_body.h"
+#include "../common.h"
+#include "../internal.h"
+#include "../rms_common.h"
+#include "../matvec_body.h"
 
 namespace mila {
 

@@ -38,10 +38,10 @@
 // Nothing is retained between launches except the epoch word that makes tags unique.
 #include <algorithm>
 
-#include "common.h"
-#include "internal.h"
-#include "rms_common.h"
-#include "matvec_body.h"
+#include "../common.h"
+#include "../internal.h"
+#include "../rms_common.h"
+#include "../matvec_body.h"
 
 namespace mila {
 

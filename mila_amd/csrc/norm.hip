@@ -269,6 +269,68 @@ __global__ __launch_bounds__(256) void softmax_kernel(T* __restrict__ Y, const T
         store_f(Y, base + (size_t)i * inner, expf(load_f(X, base + (size_t)i * inner) - m) * inv);
 }
 
+// ---- RMSNorm, fp32 row (RmsNorm.Fp32.cu:20-86: a warp per slice there, a 64-lane wave per slice here) --------------------------
+// y = (x * rstd) * (w + w_offset) + b with rstd = rsqrtf(sum x^2 * (1 / dim) + eps); slices of a [outer, dim, inner] tensor, element i of
+// slice (o, j) at ((o * dim) + i) * inner + j.  VEC: inner == 1 and dim % 4 == 0 -> 16-byte accesses.
+template <bool VEC>
+__global__ __launch_bounds__(256) void rmsnorm_fp32_kernel(float* __restrict__ Y, float* __restrict__ rstd_out, const float* __restrict__ X,
+                                                           const float* __restrict__ w, const float* __restrict__ b, int slices, int dim, int inner,
+                                                           float eps, float w_offset)
+{
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= slices) return;
+    const int o = idx / inner, j = idx - o * inner;
+    const float* x = X + (size_t)o * dim * inner + j;
+    float* y = Y + (size_t)o * dim * inner + j;
+    float m2 = 0.0f;
+    if constexpr (VEC)
+    {
+        for (int i = lane; i < dim / 4; i += 64)
+        {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)i * 4);
+            m2 += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+    }
+    else
+    {
+        for (int i = lane; i < dim; i += 64)
+        {
+            const float v = x[(size_t)i * inner];
+            m2 += v * v;
+        }
+    }
+    m2 = wave_sum(m2);
+    const float rs = rsqrtf(m2 * (1.0f / (float)dim) + eps);
+    if (lane == 0 && rstd_out) rstd_out[idx] = rs;
+    if constexpr (VEC)
+    {
+        for (int i = lane; i < dim / 4; i += 64)
+        {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)i * 4);
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+            {
+                const float wv = w ? w[i * 4 + e] + w_offset : 1.0f;
+                const float bv = b ? b[i * 4 + e] : 0.0f;
+                r[e] = (v[e] * rs) * wv + bv;
+            }
+            *reinterpret_cast<f32x4*>(y + (size_t)i * 4) = r;
+        }
+    }
+    else
+    {
+        for (int i = lane; i < dim; i += 64)
+        {
+            const size_t off = (size_t)i * inner;
+            const float wv = w ? w[i] + w_offset : 1.0f;
+            const float bv = b ? b[i] : 0.0f;
+            y[off] = (x[off] * rs) * wv + bv;
+        }
+    }
+}
+
 }  // namespace mila
 
 using namespace mila;
@@ -298,6 +360,22 @@ int mila_cdna4_rmsnorm_bf16(uint16_t* Y, uint16_t* rstd, const uint16_t* X, cons
                            (int)slices, dim, inner, eps, w_offset);
     }
     MILA_LAUNCH_CHECK("rmsnorm_bf16");
+}
+
+int mila_cdna4_rmsnorm_fp32(float* Y, float* rstd, const float* X, const float* w, const float* b, int outer, int inner, int dim, float eps,
+                            float w_offset, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X, "rmsnorm_fp32: null pointer");
+    MILA_REQUIRE(outer > 0 && dim > 0 && inner > 0, "rmsnorm_fp32: outer/inner/dim must be positive (%d,%d,%d)", outer, inner, dim);
+    MILA_REQUIRE(!(b && !w), "rmsnorm_fp32: bias without weight is not a reference configuration");
+    const int64_t slices = (int64_t)outer * inner;
+    MILA_REQUIRE(slices < (1ll << 31), "rmsnorm_fp32: too many slices");
+    hipStream_t s = as_stream(stream);
+    if (inner == 1 && dim % 4 == 0)
+        hipLaunchKernelGGL(rmsnorm_fp32_kernel<true>, dim3(ceil_div(slices, 4)), dim3(256), 0, s, Y, rstd, X, w, b, (int)slices, dim, inner, eps, w_offset);
+    else
+        hipLaunchKernelGGL(rmsnorm_fp32_kernel<false>, dim3(ceil_div(slices, 4)), dim3(256), 0, s, Y, rstd, X, w, b, (int)slices, dim, inner, eps, w_offset);
+    MILA_LAUNCH_CHECK("rmsnorm_fp32");
 }
 
 int mila_cdna4_fused_tail_norm_quant_bf16(uint16_t* R, uint16_t* XN, uint8_t* XQ, float* XS, const uint16_t* A, const uint16_t* RES, const uint16_t* post_w,

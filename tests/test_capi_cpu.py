@@ -19,8 +19,8 @@ def lib():
     return capi.load()
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "mila_cdna4.h")).read()
+def _declared(path=("include", "mila_cdna4.h")):
+    text = open(os.path.join(ROOT, *path)).read()
     return sorted(set(re.findall(r"MILA_API\s+[\w\s\*]+?\b(mila_cdna4_\w+)\s*\(", text)))
 
 
@@ -35,6 +35,27 @@ def test_every_declared_symbol_is_exported(lib):
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted("mila_cdna4_" + n for n in capi.EXPORTED) == names
+
+
+def test_experiments_and_hooks_are_behind_the_internal_header_not_the_drop_in_abi(lib):
+    """the measured-slower in-launch decode forms (decode chain, engine, one-pass attention, combine-in-o_proj, warm-ahead, Infinity-Cache
+    prefetch) and the tuning hooks are declared in csrc/internal.h only; the chain and the engine are not even in the product library"""
+    public, internal = _declared(), _declared(("mila_amd", "csrc", "internal.h"))
+    assert sorted("mila_cdna4_" + n for n in capi.INTERNAL) == internal
+    assert not set(public) & set(internal)
+    for n in ("decode_chain", "decode_engine", "matvec_attn_combine", "fused_attn_decode_onepass_bf16", "fused_attn_decode_ex", "prefetch_l3"):
+        assert "mila_cdna4_" + n not in public
+    main = C.CDLL(capi.LIB_PATH)
+    for n in capi.EXPERIMENTS_LIB:
+        assert not hasattr(main, "mila_cdna4_" + n), n
+        assert hasattr(lib, "mila_cdna4_" + n), n              # ... but reachable for tests / tools through libmila_cdna4_experiments.so
+    for n in set(capi.INTERNAL) - set(capi.EXPERIMENTS_LIB):
+        assert hasattr(main, "mila_cdna4_" + n), n
+    # nothing under the host mirror includes the internal header or names an experiment
+    for root, _, files in os.walk(os.path.join(ROOT, "mila_amd", "host")):
+        for f in files:
+            text = open(os.path.join(root, f)).read()
+            assert "internal.h" not in text and "decode_chain" not in text and "decode_engine" not in text and "prefetch_l3" not in text, f
 
 
 def test_code_object_targets_gfx950_only():
@@ -66,7 +87,7 @@ def test_validation_rejects_bad_arguments_without_touching_the_device(lib):
         == capi.MILA_E_INVALID_ARGUMENT
     assert lib.mila_cdna4_rope_forward_bf16(one, null, one, null, one, one, 1, 4, 2, 1, 64, 30, 32, null) \
         == capi.MILA_E_INVALID_ARGUMENT
-    assert lib.mila_cdna4_abi_version() == 2
+    assert lib.mila_cdna4_abi_version() == 3
     assert lib.mila_cdna4_attn_decode_scratch_bytes(1, 16, 512) == 16 * 64 * 516 * 4      # [NH, max splits, HS + 4] floats
 
 

@@ -22,15 +22,12 @@ MAX_SEQ = 64
 @pytest.mark.parametrize("policy", ["bf16", "fp8", "fp4"])
 def test_three_decode_paths_are_bit_identical_and_match_the_oracle(policy):
     ref = RefGemma(SMALL, policy, seed=7)
-    models = {m: host.Gemma(policy, SMALL, max_seq=MAX_SEQ, max_prefill=1, seed=7) for m in ("reference", "fused", "graph", "chain", "chain-graph")}
-    assert not models["fused"].uses_chain and not models["graph"].uses_chain      # one launch per Linear is the default
-    models["chain"].set_chain(True)                                               # opt-in: one chain launch per layer
-    models["chain-graph"].set_chain(True)
-    mode_of = {"chain": "fused", "chain-graph": "graph"}
+    models = {m: host.Gemma(policy, SMALL, max_seq=MAX_SEQ, max_prefill=1, seed=7) for m in ("reference", "fused", "graph")}
+    mode_of = {}
     worst, errs = 0.0, []
     for pos, tok in enumerate(TOKENS):
         out = {m: g.decode(tok, pos, mode_of.get(m, m)) for m, g in models.items()}
-        for m in ("fused", "graph", "chain", "chain-graph"):
+        for m in ("fused", "graph"):
             assert np.array_equal(out["reference"].view(np.uint32), out[m].view(np.uint32)), "%s != reference-order at %d" % (m, pos)
         exp = ref.forward([tok], pos, MAX_SEQ)
         assert np.all(np.isfinite(out["fused"]))
@@ -389,50 +386,19 @@ SPLIT = dict(vocab_size=1024, embedding_dim=1280, num_layers=6, num_heads=4, num
              global_head_dim=512, num_global_kv_heads=1, window=128, sliding_window_pattern=6, global_rotary_dim=128)
 
 
-@pytest.mark.parametrize("policy", ["bf16", "fp4"])
-def test_combine_in_o_proj_gives_the_reference_order_bits(policy):
-    """a configuration whose decode attention really splits (window 128 -> 2 splits, global 256-row cache -> 4): with the
-    combine folded into o_proj (opt-in) the fused and graph paths must still equal the one-launch-per-component path"""
-    models = {m: host.Gemma(policy, SPLIT, max_seq=256, max_prefill=1, seed=21) for m in ("reference", "fused", "graph", "folded", "folded-graph")}
-    models["folded"].set_combine_in_oproj(True)
-    models["folded-graph"].set_combine_in_oproj(True)
-    mode_of = {"folded": "fused", "folded-graph": "graph"}
-    tok = 9
-    for pos in range(0, 140, 1):
-        step = {m: g.decode(tok, pos, mode_of.get(m, m)) for m, g in models.items()} if pos in (0, 1, 63, 64, 127, 128, 139) else None
-        if step is None:
-            for m, g in models.items():
-                g.decode(tok, pos, "fused" if m == "reference" else mode_of.get(m, m))      # advance every cache cheaply
-        else:
-            for m in ("fused", "graph", "folded", "folded-graph"):
-                assert np.array_equal(step["reference"].view(np.uint32), step[m].view(np.uint32)), "%s != reference-order at %d" % (m, pos)
-        tok = (tok * 7 + pos) % 1024
-    for g in models.values():
-        g.close()
-
-
 @pytest.mark.parametrize("policy", ["bf16", "fp8", "fp4"])
-def test_onepass_attention_and_prefetch_ahead_give_the_reference_order_bits(policy):
-    """the split configuration again: decode attention in one launch (last-arriver merge) and the side-stream Infinity-Cache
-    prefetch of the next Linear's weights (its own graph branch) change no bit of the logits, eager or replayed"""
-    models = {m: host.Gemma(policy, SPLIT, max_seq=256, max_prefill=1, seed=21) for m in ("reference", "onepass", "onepass-graph", "prefetch", "both-graph")}
-    models["onepass"].set_onepass_attention(True)
-    models["onepass-graph"].set_onepass_attention(True)
-    models["prefetch"].set_prefetch_ahead(1 << 20, 8)
-    models["both-graph"].set_onepass_attention(True)
-    models["both-graph"].set_prefetch_ahead(4 << 20)
-    models["warm-graph"] = host.Gemma(policy, SPLIT, max_seq=256, max_prefill=1, seed=21)
-    models["warm-graph"].set_warm_ahead(4, 1 << 20, 3, 3 << 20)        # warm blocks inside the attention and combine launches
-    models["warm-onepass"] = host.Gemma(policy, SPLIT, max_seq=256, max_prefill=1, seed=21)
-    models["warm-onepass"].set_warm_ahead(2, 64 << 20, 0, 0)
-    models["warm-onepass"].set_onepass_attention(True)
-    mode_of = {"onepass": "fused", "onepass-graph": "graph", "prefetch": "fused", "both-graph": "graph", "warm-graph": "graph", "warm-onepass": "fused"}
+def test_split_decode_attention_gives_the_reference_order_bits(policy):
+    """a configuration whose decode attention really splits (window 128 -> 2 splits, global 256-row cache -> 4): the fused and the graph-replayed
+    step (attention + combine launches) equal the one-launch-per-component path bit for bit, at positions around every split boundary.
+    (The in-launch alternatives -- combine folded into o_proj, one-pass attention, warm-ahead blocks, side-stream prefetch, the decode chain and the
+    engine -- were measured slower, left the host mirror in round 3 and are held at kernel level only: tests/test_fused_gpu.py, test_engine_gpu.py.)"""
+    models = {m: host.Gemma(policy, SPLIT, max_seq=256, max_prefill=1, seed=21) for m in ("reference", "fused", "graph")}
     tok = 9
     for pos in range(0, 140, 1):
         check = pos in (0, 1, 63, 64, 65, 127, 128, 139)
-        step = {m: g.decode(tok, pos, mode_of.get(m, m) if (check or m != "reference") else "fused") for m, g in models.items()}
+        step = {m: g.decode(tok, pos, m if (check or m != "reference") else "fused") for m, g in models.items()}
         if check:
-            for m in mode_of:
+            for m in ("fused", "graph"):
                 assert np.array_equal(step["reference"].view(np.uint32), step[m].view(np.uint32)), "%s != reference-order at %d" % (m, pos)
         tok = (tok * 7 + pos) % 1024
     for g in models.values():

@@ -49,6 +49,27 @@ def test_rmsnorm_strided_inner_axis():
     assert_bf16_close(bits(Y), orc.rmsnorm(X, w, None, eps=1e-5, inner=6), 1, 0, "rmsnorm strided")
 
 
+@pytest.mark.parametrize("outer,dim,inner", [(6, 8, 1), (5, 3840, 1), (33, 513, 1), (3, 40, 6), (2, 256, 3)])
+@pytest.mark.parametrize("mode", ["gemma", "bias", "unit_offset", "noweight"])
+def test_rmsnorm_fp32_row(outer, dim, inner, mode):
+    """RmsNorm.cuh:84-123 (cuda_rmsnorm_forward_fp32; kernel RmsNorm.Fp32.cu:20-86): fp32 tensors and fp32 rstd, contiguous and strided slices; fp32 math on
+    both sides, so the bar is a few fp32 ulp of the float64 oracle (the sum's association differs: 64 lanes here, 32 there)"""
+    rng = np.random.default_rng(outer * dim + inner)
+    X = (rng.standard_normal((outer, dim, inner) if inner > 1 else (outer, dim)) * 3).astype(np.float32)
+    w = (1 + 0.1 * rng.uniform(-1, 1, dim)).astype(np.float32)
+    b = (0.05 * rng.uniform(-1, 1, dim)).astype(np.float32)
+    eps, off = (1e-6, 0.0) if mode == "gemma" else (1e-5, 1.0 if mode == "unit_offset" else 0.0)
+    use_w, use_b = mode != "noweight", mode == "bias"
+    Y, rstd = empty_f32(*X.shape), empty_f32(outer * inner)
+    capi.call("rmsnorm_fp32", Y, rstd, dev_f32(X), dev_f32(w) if use_w else None, dev_f32(b) if use_b else None, outer, inner, dim, eps, off)
+    exp, er = orc.rmsnorm(X, w if use_w else None, b if use_b else None, eps=eps, w_offset=off, inner=inner, return_rstd=True)
+    got = host(Y).reshape(X.shape)
+    assert np.abs(got - exp).max() <= 4e-6 * max(1.0, float(np.abs(exp).max()))
+    assert np.abs(host(rstd) - er.reshape(-1)).max() <= 4e-7 * float(np.abs(er).max())
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("rmsnorm_fp32", Y, rstd, dev_f32(X), None, dev_f32(b), outer, inner, dim, eps, off)      # bias without weight
+
+
 @pytest.mark.parametrize("outer,dim", [(6, 8), (25, 768), (3, 1000)])
 @pytest.mark.parametrize("bias", [True, False])
 def test_layernorm_bf16_and_fp32(outer, dim, bias):
