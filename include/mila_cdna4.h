@@ -95,7 +95,7 @@ MILA_API int mila_cdna4_matvec_f32out(float* y, const uint16_t* x, const void* W
  * Common/CublasLtLinearPlan.ixx:307-381) + cuda_add_bias (Fp8Prefill/CudaFp8Prefill.cu:239-256),
  * and for quantized weights the 2-phase dequantize-to-scratch + GEMM path
  * (Linear/CudaLinearOp.ixx:597-644, :716-764) by dequantizing in registers inside the GEMM (same
- * arithmetic: weights rounded to bf16, fp32 accumulate).  K % 32 == 0.
+ * arithmetic: weights rounded to bf16, fp32 accumulate).  K % 8 == 0 (bf16 weights), K % 16 == 0 (fp8), K % 32 == 0 (fp4).
  * ------------------------------------------------------------------------------------------- */
 MILA_API int mila_cdna4_gemm_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W,
                                   const uint16_t* bias, int M, int K, int N, mila_stream_t stream);
@@ -195,7 +195,8 @@ MILA_API int mila_cdna4_quantize_fp4_per_group(uint8_t* dst_packed, float* scale
  *   decode: q [B, NH*HS], len = position + 1, keys [max(0,len-window), len) (window 0 = all).
  *   prefill: q [B, chunk, NH*HS]; query t has absolute position pos_offset + t and sees keys
  *            max(0,pos-window+1) .. pos.  The cache must already contain the chunk (kv_write first).
- *   scale multiplies q.k before max/exp (Gemma passes 1.0).  HS in {64,128,256,512}.
+ *   scale multiplies q.k before max/exp (Gemma passes 1.0).  HS in {64,128,256,512} on the MFMA / split-K kernels; any other HS <= 512 on a generic
+ *   kernel (the unfused entry points only; the fused and device-position forms take the four sizes).
  * ------------------------------------------------------------------------------------------- */
 MILA_API int mila_cdna4_kv_write_bf16(uint16_t* Kc, uint16_t* Vc, const uint16_t* k, const uint16_t* v,
                                       int B, int chunk, int NKV, int HS, int start_pos, int capacity,
@@ -213,6 +214,18 @@ MILA_API int mila_cdna4_attn_prefill_bf16(uint16_t* Y, const uint16_t* Q, const 
  * replaces Attention/MHA/CudaMhaOp.ixx:456-553 (permute + 2 batched GEMMs + softmax + unpermute). */
 MILA_API int mila_cdna4_mha_bf16(uint16_t* Y, const uint16_t* QKV, int B, int T, int C, int NH,
                                  mila_stream_t stream);
+/* The same op over a KV cache (CudaMhaOp.ixx:137-380: IPositionalUnaryOp::prefill / decode + IKvCacheLifecycle).  Cache [B, NH, capacity, HS] bf16.
+ *   mha_kv_write: K / V of the packed rows [B, T, 3C] into cache rows start_pos .. start_pos + T - 1 (the K / V half of permute_qkv[_decode]);
+ *     prefill = mha_bf16 + mha_kv_write(start_pos 0).
+ *   mha_decode: QKV [B, 1, 3C] of the token at `position`: appends its K / V, then Y[B, C] = attention of its q over keys 0 .. position
+ *     (replaces permute_qkv_decode + 2 cuBLASLt GEMMs + softmax_decode + unpermute, :276-380).  scratch: mha_decode_scratch_bytes(B, C, NH).
+ *   Any head size: 64 / 128 / 256 / 512 run the MFMA flash and the split-K flash-decode kernels, every other HS <= 512 a generic kernel. */
+MILA_API int mila_cdna4_mha_kv_write_bf16(uint16_t* Kc, uint16_t* Vc, const uint16_t* QKV, int B, int T, int C, int NH,
+                                          int start_pos, int capacity, mila_stream_t stream);
+MILA_API size_t mila_cdna4_mha_decode_scratch_bytes(int B, int C, int NH);
+MILA_API int mila_cdna4_mha_decode_bf16(uint16_t* Y, const uint16_t* QKV, uint16_t* Kc, uint16_t* Vc, void* scratch,
+                                        size_t scratch_bytes, int B, int C, int NH, int capacity, int position,
+                                        mila_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Normalisation / activations.

@@ -77,6 +77,7 @@ def load():
     main.mila_cdna4_gemm_w4a8_scratch_bytes.restype = C.c_size_t
     main.mila_cdna4_sample_stochastic_scratch_bytes.restype = C.c_size_t
     main.mila_cdna4_attn_decode_ticket_count.restype = C.c_size_t
+    main.mila_cdna4_mha_decode_scratch_bytes.restype = C.c_size_t
     _lib = _Libs(main)
     return _lib
 
@@ -149,7 +150,7 @@ EXPORTED = [
     "gemm_w4a8_scratch_bytes", "gemm_bf16_w4a8", "gemm_geglu_w4a8_applicable", "gemm_geglu_bf16_w4a8",
     "gemm_geglu_applicable", "gemm_geglu_bf16", "gemm_geglu_bf16_w8a16_staged", "gemm_geglu_bf16_w4a16_staged",
     "quantize_fp8_per_channel", "quantize_fp4_per_group",
-    "kv_write_bf16", "attn_decode_scratch_bytes", "attn_decode_bf16", "attn_prefill_bf16", "mha_bf16",
+    "kv_write_bf16", "attn_decode_scratch_bytes", "attn_decode_bf16", "attn_prefill_bf16", "mha_bf16", "mha_kv_write_bf16", "mha_decode_scratch_bytes", "mha_decode_bf16",
     "rmsnorm_bf16", "rmsnorm_fp32", "layernorm_bf16", "layernorm_fp32", "softmax_fp32", "softmax_bf16",
     "gelu_bf16", "gelu_fp32", "geglu_bf16", "residual_bf16", "residual_fp32",
     "rope_build_cache", "rope_forward_bf16",

@@ -22,6 +22,7 @@
 #include "rms_common.h"
 #include "rope_common.h"
 #include "internal.h"
+#include "attention_generic.h"
 
 namespace mila {
 
@@ -56,6 +57,7 @@ struct AttnParams
 {
     uint16_t* Y;              // [B, NH*HS]
     const uint16_t* Q;        // [B, NH*HS] post-norm/rope queries (unfused form), or NULL in the fused form
+    int64_t q_b_stride;       // elements between two batches' query rows (0 = NH*HS; a packed [B, 1, 3C] MHA row: 3C)
     uint16_t* K;              // cache [B, NKV, capacity, HS]
     uint16_t* V;
     float* scratch;           // [B, NH, splits, HS+4] partials when splits > 1: O (HS) | m | l | pad (rows stay 16-byte aligned)
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(kDecodeWaves * 64) void attn_decode_kernel(const At
 #pragma unroll
         for (int g = 0; g < GH; ++g)
         {
-            const uint16_t* qp = p.Q + ((size_t)b * p.NH + (h0 + g)) * HS + lane * EPL;
+            const uint16_t* qp = p.Q + (size_t)b * (p.q_b_stride ? (size_t)p.q_b_stride : (size_t)p.NH * HS) + (size_t)(h0 + g) * HS + lane * EPL;
             if (owner) load_row<EPL>(q[g], qp);
             else
             {
@@ -563,7 +565,18 @@ static int dispatch_hs(int HS, const AttnParams& p, int B, hipStream_t s)
         case 128: return dispatch_gs<128, FUSED>(p, B, s);
         case 256: return dispatch_gs<256, FUSED>(p, B, s);
         case 512: return dispatch_gs<512, FUSED>(p, B, s);
-        default: return set_error(MILA_E_UNSUPPORTED, "attention: head size %d must be 64, 128, 256 or 512", HS);
+        default:
+            if constexpr (!FUSED)
+            {
+                // any other head size: one wave per (batch, head) row on the generic kernel (attention_generic.hip); the position may live on the device only in the
+                // captured forms, which the benchmarked head sizes alone use
+                if (p.pos_dev) return set_error(MILA_E_UNSUPPORTED, "attention: the device-position form needs a head size of 64, 128, 256 or 512 (got %d)", HS);
+                const int64_t qbs = p.q_b_stride ? p.q_b_stride : (int64_t)p.NH * HS;
+                GenericAttnParams g{p.Y, p.Q, p.K, p.V, qbs, qbs, (int64_t)p.NKV * p.capacity * HS, (int64_t)p.capacity * HS, HS,
+                                    B, 1, p.NH, p.NKV, HS, p.capacity, p.position, p.window, p.scale};
+                return launch_attn_generic(g, s);
+            }
+            return set_error(MILA_E_UNSUPPORTED, "attention: head size %d must be 64, 128, 256 or 512", HS);
     }
 }
 
@@ -597,13 +610,53 @@ static int run_decode(uint16_t* Y, const uint16_t* Q, uint16_t* Kc, uint16_t* Vc
     p.splits = decode_splits(B, NH, NKV, HS, band_max);
     p.scale = scale;
     p.pos_dev = pos_dev;
-    if (p.splits > 1)
+    const bool split_kernel = HS == 64 || HS == 128 || HS == 256 || HS == 512;
+    if (split_kernel && p.splits > 1)
     {
         const size_t need = (size_t)B * NH * p.splits * (HS + 4) * sizeof(float);
         if (!scratch || scratch_bytes < need)
             return set_error(MILA_E_SCRATCH_TOO_SMALL, "%s: scratch %zu bytes < required %zu", who, scratch_bytes, need);
     }
     return fused ? dispatch_hs<true>(HS, p, B, stream) : dispatch_hs<false>(HS, p, B, stream);
+}
+
+// unfused decode whose query rows are `q_b_stride` elements apart (a packed [B, 1, 3C] MHA projection)
+static int run_decode_q(uint16_t* Y, const uint16_t* Q, int64_t q_b_stride, uint16_t* Kc, uint16_t* Vc, void* scratch, size_t scratch_bytes, int B,
+                        int NH, int NKV, int HS, int capacity, int position, int window, float scale, const char* who, hipStream_t stream)
+{
+    AttnParams p{};
+    p.Y = Y; p.Q = Q; p.q_b_stride = q_b_stride; p.K = Kc; p.V = Vc; p.scratch = reinterpret_cast<float*>(scratch);
+    p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.position = position; p.window = window;
+    const int band_max = (window > 0 && window < capacity) ? window : capacity;
+    p.splits = decode_splits(B, NH, NKV, HS, band_max);
+    p.scale = scale;
+    const bool split_kernel = HS == 64 || HS == 128 || HS == 256 || HS == 512;
+    if (split_kernel && p.splits > 1)
+    {
+        const size_t need = (size_t)B * NH * p.splits * (HS + 4) * sizeof(float);
+        if (!scratch || scratch_bytes < need) return set_error(MILA_E_SCRATCH_TOO_SMALL, "%s: scratch %zu bytes < required %zu", who, scratch_bytes, need);
+    }
+    return dispatch_hs<false>(HS, p, B, stream);
+}
+
+// packed [B, T, 3C] rows -> K / V rows of a [B, NH, capacity, HS] cache at positions start_pos .. start_pos + T - 1 (the K / V part of the reference's
+// permute_qkv / permute_qkv_decode, CudaMhaOp.ixx:166-170, :276-280)
+__global__ __launch_bounds__(256) void mha_kv_write_kernel(uint16_t* __restrict__ Kc, uint16_t* __restrict__ Vc, const uint16_t* __restrict__ QKV,
+                                                           int64_t total, int T, int C, int HS, int start_pos, int capacity)
+{
+    const int NH = C / HS;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride)
+    {
+        const int c = (int)(i % C);
+        const int64_t bt = i / C;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const int h = c / HS, d = c - h * HS;
+        const size_t dst = (((size_t)b * NH + h) * capacity + (start_pos + t)) * HS + d;
+        const uint16_t* row = QKV + bt * 3 * (int64_t)C;
+        Kc[dst] = row[C + c];
+        Vc[dst] = row[2 * C + c];
+    }
 }
 
 }  // namespace mila
@@ -691,6 +744,40 @@ int mila_cdna4_fused_attn_decode_bf16(uint16_t* Y, uint16_t* Kc, uint16_t* Vc, c
     f.eps = eps;
     return run_decode(Y, nullptr, Kc, Vc, scratch, scratch_bytes, 1, NH, NKV, HS, capacity, position, position_dev, window, scale, &f,
                       "fused_attn_decode_bf16", as_stream(stream));
+}
+
+// ---- GPT-2 multi-head attention over a KV cache (CudaMhaOp.ixx:137-380: prefill / decode of IPositionalUnaryOp + IKvCacheLifecycle) ----
+// The cache is [B, NH, capacity, HS] like the GQA one (NKV = NH); K / V come from the packed [B, T, 3C] projection.
+int mila_cdna4_mha_kv_write_bf16(uint16_t* Kc, uint16_t* Vc, const uint16_t* QKV, int B, int T, int C, int NH, int start_pos, int capacity,
+                                 mila_stream_t stream)
+{
+    MILA_REQUIRE(Kc && Vc && QKV, "mha_kv_write_bf16: null pointer");
+    MILA_REQUIRE(B > 0 && T > 0 && C > 0 && NH > 0 && C % NH == 0 && capacity > 0, "mha_kv_write_bf16: bad sizes (B=%d T=%d C=%d NH=%d capacity=%d)", B, T, C, NH, capacity);
+    MILA_REQUIRE(start_pos >= 0 && start_pos + T <= capacity, "mha_kv_write_bf16: positions [%d, %d) do not fit the cache capacity %d", start_pos, start_pos + T, capacity);
+    const int64_t total = (int64_t)B * T * C;
+    int blocks = ceil_div(total, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mha_kv_write_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), Kc, Vc, QKV, total, T, C, C / NH, start_pos, capacity);
+    MILA_LAUNCH_CHECK("mha_kv_write_bf16");
+}
+
+size_t mila_cdna4_mha_decode_scratch_bytes(int B, int C, int NH)
+{
+    if (B <= 0 || C <= 0 || NH <= 0 || C % NH != 0) return 0;
+    return mila_cdna4_attn_decode_scratch_bytes(B, NH, C / NH);
+}
+
+int mila_cdna4_mha_decode_bf16(uint16_t* Y, const uint16_t* QKV, uint16_t* Kc, uint16_t* Vc, void* scratch, size_t scratch_bytes, int B, int C,
+                               int NH, int capacity, int position, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && QKV && Kc && Vc, "mha_decode_bf16: null pointer");
+    MILA_REQUIRE(B > 0 && C > 0 && NH > 0 && C % NH == 0 && capacity > 0, "mha_decode_bf16: bad sizes (B=%d C=%d NH=%d capacity=%d)", B, C, NH, capacity);
+    MILA_REQUIRE(position >= 0 && position < capacity, "mha_decode_bf16: position %d out of range [0, %d)", position, capacity);     // CudaMhaOp.ixx:262-265
+    const int HS = C / NH;
+    int rc = mila_cdna4_mha_kv_write_bf16(Kc, Vc, QKV, B, 1, C, NH, position, capacity, stream);
+    if (rc) return rc;
+    return run_decode_q(Y, QKV, 3 * (int64_t)C, Kc, Vc, scratch, scratch_bytes, B, NH, NH, HS, capacity, position, 0, 1.0f / sqrtf((float)HS),
+                        "mha_decode_bf16", as_stream(stream));
 }
 
 int mila_cdna4_attn_decode_split_count(int B, int NH, int NKV, int HS, int capacity, int window)

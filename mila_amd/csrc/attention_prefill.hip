@@ -26,6 +26,7 @@
 #include "common.h"
 #include <type_traits>
 #include "internal.h"
+#include "attention_generic.h"
 
 namespace mila {
 
@@ -682,7 +683,13 @@ int flash_dispatch(int HS, const FlashParams& p, int B, hipStream_t s)
         case 128: return dispatch_hb<128>(p, B, s);
         case 256: return dispatch_hb<256>(p, B, s);
         case 512: return dispatch_hb<512>(p, B, s);
-        default: return set_error(MILA_E_UNSUPPORTED, "attention: head size %d must be 64, 128, 256 or 512", HS);
+        default:
+        {
+            // any other head size (the reference tests' own HS = 4 / 8 geometries): the one-wave-per-row kernel of attention_generic.hip
+            GenericAttnParams g{p.Y, p.Q, p.K, p.V, (int64_t)p.Tq * p.q_row_stride, p.q_row_stride, p.kv_b_stride, p.kv_h_stride, p.kv_r_stride,
+                                B, p.Tq, p.NH, p.NKV, HS, p.capacity, p.pos_offset, p.window, p.scale};
+            return launch_attn_generic(g, s);
+        }
     }
 }
 

@@ -371,7 +371,7 @@ static int validate_gemm(const char* who, const void* Y, const void* X, const vo
 {
     MILA_REQUIRE(Y && X && W, "%s: null pointer", who);
     MILA_REQUIRE(M > 0 && K > 0 && N > 0, "%s: M, K, N must be positive (%d,%d,%d)", who, M, K, N);
-    MILA_REQUIRE(K % 32 == 0, "%s: K=%d must be a multiple of 32", who, K);
+    MILA_REQUIRE(K % 8 == 0, "%s: K=%d must be a multiple of 8 (16-byte rows)", who, K);
     return MILA_OK;
 }
 
@@ -431,6 +431,7 @@ int mila_cdna4_gemm_bf16_w8a16(uint16_t* Y, const uint16_t* X, const uint8_t* W,
     int rc = validate_gemm("gemm_bf16_w8a16", Y, X, W, M, K, N);
     if (rc) return rc;
     MILA_REQUIRE(scales != nullptr, "gemm_bf16_w8a16: per-channel scales are required");
+    MILA_REQUIRE(K % 16 == 0, "gemm_bf16_w8a16: K=%d must be a multiple of 16", K);
     GemmParams p{Y, X, W, scales, bias, M, K, N, 0, 0, 0};
     return launch_gemm<G_FP8>(p, as_stream(stream));
 }
@@ -443,6 +444,7 @@ int mila_cdna4_gemm_bf16_w4a16(uint16_t* Y, const uint16_t* X, const uint8_t* W_
     MILA_REQUIRE(scales != nullptr, "gemm_bf16_w4a16: per-group scales are required");
     MILA_REQUIRE(group == 64 || group == 128, "gemm_bf16_w4a16: group size must be 64 or 128 (got %d)", group);
     MILA_REQUIRE(K % group == 0, "gemm_bf16_w4a16: K=%d must be a multiple of the group size %d", K, group);
+    MILA_REQUIRE(K % 32 == 0, "gemm_bf16_w4a16: K=%d must be a multiple of 32", K);
     GemmParams p{Y, X, W_packed, scales, bias, M, K, N, group, 0, 0};
     return launch_gemm<G_FP4>(p, as_stream(stream));
 }

@@ -345,6 +345,32 @@ class Gpt:
         self.last_ms = ms.value
         return out
 
+    def prefill(self, tokens):
+        """GptTransformer::prefill: tokens [B, T' <= T] -> logits [B, V] (bf16 bits) of the last position; every block's KV cache is filled"""
+        lib = load()
+        lib.mila_gpt_prefill.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        assert t.ndim == 2 and t.shape[0] == self.shape[0]
+        out = np.empty((self.shape[0], self.shape[2]), dtype=np.uint16)
+        rc = lib.mila_gpt_prefill(self.h, t.ctypes.data, t.shape[1], out.ctypes.data)
+        if rc:
+            text = lib.mila_gpt_last_error().decode()
+            raise (ValueError if rc == capi.MILA_E_INVALID_ARGUMENT else RuntimeError)(text)
+        return out
+
+    def decode(self, tokens, position):
+        """GptTransformer::decode: one token per sequence [B] at absolute `position` -> logits [B, V] (bf16 bits)"""
+        lib = load()
+        lib.mila_gpt_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        t = np.ascontiguousarray(tokens, dtype=np.int32).reshape(-1)
+        assert t.size == self.shape[0]
+        out = np.empty((self.shape[0], self.shape[2]), dtype=np.uint16)
+        rc = lib.mila_gpt_decode(self.h, t.ctypes.data, int(position), out.ctypes.data)
+        if rc:
+            text = lib.mila_gpt_last_error().decode()
+            raise (ValueError if rc == capi.MILA_E_INVALID_ARGUMENT else RuntimeError)(text)
+        return out
+
     def close(self):
         if self.h:
             load().mila_gpt_destroy(self.h)

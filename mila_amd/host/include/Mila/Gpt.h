@@ -1,5 +1,5 @@
 // GPT-2 on the CDNA4 device (BASELINE.json configs 1-2): GptConfig and GptTransformer in the
-// reference's forward order --
+// reference's forward order, plus its inference pair prefill() / decode() over per-block KV caches (GptTransformer.ixx:330-441, GptBlock.ixx:253-281) --
 //   GptTransformer::forward  (/root/reference/Mila/Src/Dnn/Components/Transformers/Gpt/GptTransformer.ixx:221-254)
 //   GptBlock::forward        (Gpt/GptBlock.ixx:148-184): ln_1 -> fc_qkv_proj -> attn -> fc_out_proj -> res_1 ->
 //                            ln_2 -> MLP(fc1 -> GELU -> fc2, Components/FFN/MLP/MLP.ixx:148-161) -> res_2
@@ -114,6 +114,37 @@ namespace Mila::Dnn
             return lm_head_->forward( ln_final_->forward( *x ) );
         }
 
+        /// inference prefill (GptTransformer.ixx:330-385): the whole prompt [B, T' <= T] through lenc + blocks (each block's attention fills its KV cache), then only the
+        /// last position's row through ln_final + lm_head -> logits [B, 1, V].  No chunking and no position offset: GPT-2 has learned positions
+        TensorType& prefill( const TokenTensor& tokens )
+        {
+            Compute::TraceRange tr( "gpt.prefill" );
+            const auto& s = tokens.shape();
+            if ( s.size() != 2 || s[ 0 ] != B_ || s[ 1 ] <= 0 || s[ 1 ] > T_ ) throw std::invalid_argument( "GptTransformer::prefill: tokens must be [B, T <= built T]" );
+            const dim_t Tp = s[ 1 ], C = cfg_.embedding_dim;
+            TensorType* x = &lenc_->forward( tokens );
+            for ( auto& b : blocks_ ) x = &b->forward( *x );
+            if ( !last_rows_ ) last_rows_ = std::make_unique<TensorType>( ctx_->getDeviceId(), shape_t{ B_, 1, C } );
+            for ( dim_t b = 0; b < B_; ++b )      // row (b, T' - 1) of every sequence (the reference's single view is this for B = 1)
+                Compute::rocmCheck( mila_cdna4_memcpy_d2d( last_rows_->data() + static_cast<size_t>( b * C ), x->data() + static_cast<size_t>( ( b * Tp + Tp - 1 ) * C ),
+                                                           static_cast<size_t>( C ) * 2, ctx_->getStream() ) );
+            return lm_head_->forward( ln_final_->forward( *last_rows_ ) );
+        }
+        /// inference-only single-token step (GptTransformer.ixx:387-441): tokens [B, 1] at absolute `position`; every block runs decode() (attention over its KV
+        /// cache).  Precondition: prefill() (or forward()) has populated the caches.
+        TensorType& decode( const TokenTensor& tokens, dim_t position )
+        {
+            Compute::TraceRange tr( "gpt.decode" );
+            const auto& s = tokens.shape();
+            if ( s.size() != 2 || s[ 0 ] != B_ || s[ 1 ] != 1 ) throw std::invalid_argument( "GptTransformer::decode: tokens must be [B, 1]" );
+            if ( position < 0 || position >= T_ ) throw std::invalid_argument( "GptTransformer::decode: position beyond the built sequence length" );
+            TensorType* x = &lenc_->decode( tokens, position );
+            for ( auto& b : blocks_ ) x = &b->decode( *x, position );
+            return lm_head_->forward( ln_final_->forward( *x ) );
+        }
+        void resetKVCache() { for ( auto& b : blocks_ ) b->resetKVCache(); }
+        bool supportsKVCache() const noexcept { return !blocks_.empty() && blocks_.front()->supportsKVCache(); }
+
         int32_t indexError() { return lenc_->indexError(); }
 
         /// component names in construction order
@@ -135,5 +166,6 @@ namespace Mila::Dnn
         std::vector<std::shared_ptr<TransformerBlockType>> blocks_;
         std::shared_ptr<LayerNormType> ln_final_;
         std::shared_ptr<LinearType> lm_head_;
+        std::unique_ptr<TensorType> last_rows_;
     };
 }

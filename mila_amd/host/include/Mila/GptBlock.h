@@ -125,7 +125,9 @@ namespace Mila::Dnn
         dim_t model_dim_, num_heads_;
     };
 
-    /// causal self-attention over a packed [B, T, 3C] projection; forward() is the whole-sequence entry point (the one GPT-2's forward path uses)
+    /// causal self-attention over a packed [B, T, 3C] projection (Components/Attention/MHA/MultiHeadAttention.ixx).  forward() is the sole entry point for prefill:
+    /// the first call initializes the KV cache and fills it; called again after decode() steps it resets the cache and starts a new session (:124-158).
+    /// decode() is the single-token step over the cache (:209-227).
     template<DeviceType TDeviceType, TensorDataType TPrecision>
     class MultiHeadAttention : public Component<TDeviceType, TPrecision>
     {
@@ -142,24 +144,50 @@ namespace Mila::Dnn
             const shape_t os{ s[ 0 ], s[ 1 ], config_.getModelDim() };
             if ( shapeSize( os ) > output_->size() ) throw std::invalid_argument( this->getName() + ": input exceeds the built shape" );
             view_ = std::make_unique<TensorType>( output_->view( os ) );
-            operation_->forward( input, *view_ );
+            if ( s[ 0 ] == max_input_shape_[ 0 ] )
+            {
+                if ( decode_active_ ) { operation_->resetKvCache(); cache_initialized_ = false; decode_active_ = false; }      // called after decode steps: a new session
+                if ( !cache_initialized_ ) { operation_->initializeKvCache( max_input_shape_[ 0 ], max_input_shape_[ 1 ] ); cache_initialized_ = true; }
+                operation_->prefill( input, *view_ );      // populates the cache as a side effect
+                return *view_;
+            }
+            operation_->forward( input, *view_ );          // a batch other than the built one has no cache behind it
             return *view_;
         }
-        bool supportsKVCache() const noexcept { return false; }      // GPT-2 here is the forward() path only (BASELINE configs 1-2)
+        /// Precondition: forward() has populated the cache.  input [B, 1, 3 * model_dim] -> [B, 1, model_dim]
+        TensorType& decode( const TensorType& input, dim_t position )
+        {
+            if ( !this->isBuilt() ) throw std::runtime_error( "MultiHeadAttention must be built before calling decode()." );
+            if ( !cache_initialized_ ) throw std::runtime_error( this->getName() + ": decode() before forward() has populated the KV cache" );
+            operation_->decode( input, *decode_output_, position );
+            decode_active_ = true;
+            return *decode_output_;
+        }
+        bool supportsKVCache() const noexcept { return true; }
+        void initializeKVCache( dim_t max_seq_len ) { operation_->initializeKvCache( max_input_shape_[ 0 ], max_seq_len ); cache_initialized_ = true; decode_active_ = false; }
+        void resetKVCache() { operation_->resetKvCache(); decode_active_ = false; }
         const MultiHeadAttentionConfig& getConfig() const noexcept { return config_; }
+        OpType& getOperation() noexcept { return *operation_; }
     protected:
         void onExecutionContextSet() override { operation_ = std::make_shared<OpType>( this->getExecutionContext(), config_.getModelDim(), config_.getNumHeads() ); }
         void onBuilding( const BuildContext& ctx ) override
         {
             const auto& s = ctx.inputShape();
             if ( s.size() != 3 || s[ 2 ] != 3 * config_.getModelDim() ) throw std::invalid_argument( this->getName() + ": build shape must be [B, T, 3 * model_dim]" );
-            output_ = std::make_shared<TensorType>( this->getExecutionContext()->getDeviceId(), shape_t{ s[ 0 ], s[ 1 ], config_.getModelDim() } );
+            max_input_shape_ = s;
+            const auto dev = this->getExecutionContext()->getDeviceId();
+            output_ = std::make_shared<TensorType>( dev, shape_t{ s[ 0 ], s[ 1 ], config_.getModelDim() } );
+            decode_output_ = std::make_unique<TensorType>( dev, shape_t{ s[ 0 ], 1, config_.getModelDim() } );
+            operation_->build( ctx );
+            cache_initialized_ = false; decode_active_ = false;
         }
     private:
         MultiHeadAttentionConfig config_;
         std::shared_ptr<OpType> operation_;
         std::shared_ptr<TensorType> output_;
-        std::unique_ptr<TensorType> view_;
+        std::unique_ptr<TensorType> view_, decode_output_;
+        shape_t max_input_shape_;
+        bool cache_initialized_{ false }, decode_active_{ false };
     };
 
     class LpeConfig
@@ -199,6 +227,20 @@ namespace Mila::Dnn
             auto* ctx = Compute::cast_context<TDeviceType>( this->getExecutionContext() );
             view_ = std::make_unique<EmbeddingsTensorType>( output_->view( shape_t{ s[ 0 ], s[ 1 ], config_.getEmbeddingDim() } ) );
             Compute::rocmCheck( mila_cdna4_lpe_bf16( view_->data(), input.data(), wte_->data(), wpe_->data(), (int)s[ 0 ], (int)s[ 1 ], (int)config_.getEmbeddingDim(), (int)s[ 1 ],
+                                                     (int)config_.getVocabularyLength(), error_flag_->data(), ctx->getStream() ) );
+            return *view_;
+        }
+        /// single-token step: output[b, 0, :] = wte[X[b, 0], :] + wpe[position, :] (Lpe.ixx:240-257; B rows here, the reference's view is [1, 1, C])
+        EmbeddingsTensorType& decode( const TokenIndexType& input, dim_t position )
+        {
+            if ( !this->isBuilt() ) throw std::runtime_error( "Lpe must be built before calling decode()." );
+            const auto& s = input.shape();
+            if ( s.size() != 2 || s[ 0 ] > max_batch_ || s[ 1 ] != 1 ) throw std::invalid_argument( this->getName() + ": decode input must be [B, 1]" );
+            if ( position < 0 || position >= config_.getMaxSequenceLength() ) throw std::invalid_argument( this->getName() + ": decode position out of range" );
+            auto* ctx = Compute::cast_context<TDeviceType>( this->getExecutionContext() );
+            const dim_t C = config_.getEmbeddingDim();
+            view_ = std::make_unique<EmbeddingsTensorType>( output_->view( shape_t{ s[ 0 ], 1, C } ) );
+            Compute::rocmCheck( mila_cdna4_lpe_bf16( view_->data(), input.data(), wte_->data(), wpe_->data() + static_cast<size_t>( position * C ), (int)s[ 0 ], 1, (int)C, 1,
                                                      (int)config_.getVocabularyLength(), error_flag_->data(), ctx->getStream() ) );
             return *view_;
         }
@@ -279,6 +321,12 @@ namespace Mila::Dnn
             if ( !this->isBuilt() ) throw std::runtime_error( "MLP must be built before calling forward." );
             return fc_2->forward( gelu->forward( fc_1->forward( input ) ) );
         }
+        /// single-token step (MLP.ixx:214): the same chain on a [B, 1, C] row (the Linears take their matvec branch at one row)
+        TensorType& decode( const TensorType& input )
+        {
+            if ( !this->isBuilt() ) throw std::runtime_error( "MLP must be built before decode()." );
+            return fc_2->forward( gelu->forward( fc_1->forward( input ) ) );
+        }
     protected:
         void onExecutionContextSet() override
         {
@@ -345,6 +393,26 @@ namespace Mila::Dnn
             auto& ffn = mlp->forward( ln2 );
             return res_2->forward( r1, ffn );
         }
+        /// inference-only single-token step (GptBlock.ixx:253-281): every component's forward() except attention, which is driven through decode()
+        TensorType& decode( const TensorType& input, dim_t position )
+        {
+            if ( !this->isBuilt() ) throw std::runtime_error( "GptBlock must be built before decode()." );
+            auto& ln1 = ln_1->forward( input );
+            auto& qkv = fc_qkv_proj->forward( ln1 );
+            auto& att = attn->decode( qkv, position );
+            auto& proj = fc_out_proj->forward( att );
+            auto& r1 = res_1->forward( input, proj );
+            auto& ln2 = ln_2->forward( r1 );
+            auto& ffn = mlp->decode( ln2 );
+            return res_2->forward( r1, ffn );
+        }
+        bool supportsKVCache() const noexcept { return attn && attn->supportsKVCache(); }
+        void initializeKVCache( dim_t max_seq_len )
+        {
+            if ( !this->isBuilt() ) throw std::runtime_error( "GptBlock must be built before initializeKVCache()." );
+            attn->initializeKVCache( max_seq_len );
+        }
+        void resetKVCache() { attn->resetKVCache(); }
         std::vector<std::string> childNames() const
         {
             return { attn->getName(), ln_1->getName(), ln_2->getName(), fc_qkv_proj->getName(), fc_out_proj->getName(), res_1->getName(), res_2->getName(), mlp->getName(),

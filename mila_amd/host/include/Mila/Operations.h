@@ -618,8 +618,8 @@ namespace Mila::Dnn::Compute
         using type = RocmGqaOp<TKvPolicy::kBoundedRing>;
     };
 
-    /// GPT-2 attention on packed QKV (new BF16 row; the reference's CUDA MHA is FP32-only,
-    /// OPS/OperationTraits.Cuda.ixx:274-282)
+    /// GPT-2 attention on packed QKV (new BF16 row; the reference's CUDA MHA is FP32-only, OPS/OperationTraits.Cuda.ixx:274-282) with the KV-cache
+    /// interface of CudaMultiHeadAttentionOp (OPS/Attention/MHA/CudaMhaOp.ixx:107-380: IPositionalUnaryOp::prefill / decode + IKvCacheLifecycle)
     class RocmMultiHeadAttentionOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
     {
     public:
@@ -628,14 +628,78 @@ namespace Mila::Dnn::Compute
         {
             if ( model_dim <= 0 || num_heads <= 0 || model_dim % num_heads != 0 ) throw std::invalid_argument( "RocmMultiHeadAttentionOp: model_dim must be a positive multiple of num_heads" );
         }
+        /// the built [B, T, 3C] shape bounds every later call (CudaMhaOp.ixx:423-447)
+        void build( const BuildContext& ctx )
+        {
+            const auto& s = ctx.inputShape();
+            if ( s.size() != 3 || s[ 2 ] != 3 * C_ ) throw std::invalid_argument( "RocmMultiHeadAttentionOp::build: expected [B, T, 3C]" );
+            B_ = s[ 0 ]; T_ = s[ 1 ];
+            cached_seq_len_ = 0; kv_cache_enabled_ = false;
+        }
         void forward( const TensorType& qkv, TensorType& out ) const
         {
             const auto& s = qkv.shape();
             if ( s.size() != 3 || s[ 2 ] != 3 * C_ ) throw std::invalid_argument( "RocmMultiHeadAttentionOp::forward: expected [B, T, 3C]" );
             rocmCheck( mila_cdna4_mha_bf16( out.data(), static_cast<const uint16_t*>( qkv.rawData() ), (int)s[ 0 ], (int)s[ 1 ], (int)C_, (int)NH_, context_->getStream() ) );
         }
+
+        // ---- IKvCacheLifecycle (CudaMhaOp.ixx:112-143) ----
+        void initializeKvCache( dim_t batch_size, dim_t max_sequence_length )
+        {
+            if ( batch_size != B_ ) throw std::invalid_argument( "RocmMultiHeadAttentionOp::initializeKvCache batch size must match the built shape" );
+            if ( max_sequence_length <= 0 || max_sequence_length > T_ ) throw std::invalid_argument( "RocmMultiHeadAttentionOp::initializeKvCache max_sequence_length out of range" );
+            if ( !k_cache_ || active_max_seq_len_ != max_sequence_length )
+            {
+                const shape_t cs{ B_, NH_, max_sequence_length, C_ / NH_ };
+                k_cache_ = std::make_unique<TensorType>( context_->getDeviceId(), cs );
+                v_cache_ = std::make_unique<TensorType>( context_->getDeviceId(), cs );
+            }
+            active_max_seq_len_ = max_sequence_length;
+            cached_seq_len_ = 0;
+            kv_cache_enabled_ = true;
+        }
+        void resetKvCache() noexcept { cached_seq_len_ = 0; }
+        bool rewindKvCache( dim_t position ) noexcept
+        {
+            if ( position < 0 || position > cached_seq_len_ ) return false;
+            cached_seq_len_ = position;
+            return true;
+        }
+        dim_t cacheLength() const noexcept { return cached_seq_len_; }
+
+        // ---- IPositionalUnaryOp ----
+        /// the whole prompt [B, T' <= max_seq, 3C]: causal attention + the prompt's K / V rows into the cache (CudaMhaOp.ixx:145-232)
+        void prefill( const TensorType& qkv, TensorType& out )
+        {
+            ensureKvCacheEnabled();
+            const auto& s = qkv.shape();
+            if ( s.size() != 3 || s[ 0 ] != B_ || s[ 2 ] != 3 * C_ || s[ 1 ] <= 0 || s[ 1 ] > active_max_seq_len_ )
+                throw std::invalid_argument( "RocmMultiHeadAttentionOp::prefill: input must be [B, T <= max_sequence_length, 3C]" );
+            const auto* x = static_cast<const uint16_t*>( qkv.rawData() );
+            mila_stream_t st = context_->getStream();
+            rocmCheck( mila_cdna4_mha_bf16( out.data(), x, (int)B_, (int)s[ 1 ], (int)C_, (int)NH_, st ) );
+            rocmCheck( mila_cdna4_mha_kv_write_bf16( k_cache_->data(), v_cache_->data(), x, (int)B_, (int)s[ 1 ], (int)C_, (int)NH_, 0, (int)active_max_seq_len_, st ) );
+            cached_seq_len_ = s[ 1 ];
+        }
+        /// one token per sequence [B, 1, 3C] at absolute `position`: appends its K / V, attends to keys 0 .. position (CudaMhaOp.ixx:252-380)
+        void decode( const TensorType& qkv, TensorType& out, dim_t position )
+        {
+            ensureKvCacheEnabled();
+            const auto& s = qkv.shape();
+            if ( s.size() != 3 || s[ 0 ] != B_ || s[ 1 ] != 1 || s[ 2 ] != 3 * C_ ) throw std::invalid_argument( "RocmMultiHeadAttentionOp::decode: input must be [B, 1, 3C]" );
+            if ( position < 0 || position >= active_max_seq_len_ ) throw std::invalid_argument( "RocmMultiHeadAttentionOp::decode position out of range" );
+            const size_t need = mila_cdna4_mha_decode_scratch_bytes( (int)B_, (int)C_, (int)NH_ );
+            void* scratch = context_->getScratch( need );      // fetched per call, never cached
+            rocmCheck( mila_cdna4_mha_decode_bf16( out.data(), static_cast<const uint16_t*>( qkv.rawData() ), k_cache_->data(), v_cache_->data(), scratch, need, (int)B_, (int)C_,
+                                                   (int)NH_, (int)active_max_seq_len_, (int)position, context_->getStream() ) );
+            if ( position + 1 > cached_seq_len_ ) cached_seq_len_ = position + 1;
+        }
     private:
+        void ensureKvCacheEnabled() const { if ( !kv_cache_enabled_ ) throw std::runtime_error( "RocmMultiHeadAttentionOp: initializeKvCache() must be called first" ); }
         dim_t C_, NH_;
+        dim_t B_{ 0 }, T_{ 0 }, active_max_seq_len_{ 0 }, cached_seq_len_{ 0 };
+        bool kv_cache_enabled_{ false };
+        std::unique_ptr<TensorType> k_cache_, v_cache_;
     };
     template<> struct OperationTraits<OperationType::MultiHeadAttentionOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmMultiHeadAttentionOp; };
 }

@@ -62,6 +62,37 @@ HOST_API int64_t mila_gpt_component_names( void* h, char* buf, int64_t cap )
     return static_cast<int64_t>( out.size() + 1 );
 }
 
+/// GptTransformer::prefill: host tokens [B, Tp] -> host logits [B, V] (bf16 bits) of the last position; fills every block's KV cache
+HOST_API int mila_gpt_prefill( void* h, const int32_t* host_tokens, int64_t Tp, uint16_t* host_logits )
+{
+    auto* r = static_cast<GptRunner*>( h );
+    return guarded( [&]
+    {
+        auto* ctx = r->model->context();
+        if ( Tp <= 0 || Tp > r->T ) throw std::invalid_argument( "mila_gpt_prefill: prompt length outside (0, built T]" );
+        GptTransformer::TokenTensor toks( ctx->getDeviceId(), shape_t{ r->B, Tp } );
+        Compute::rocmCheck( mila_cdna4_memcpy_h2d( toks.data(), host_tokens, static_cast<size_t>( r->B * Tp ) * 4, ctx->getStream() ) );
+        auto& logits = r->model->prefill( toks );
+        ctx->synchronize();
+        if ( r->model->indexError() ) throw std::invalid_argument( "mila_gpt_prefill: token index outside the vocabulary" );
+        if ( host_logits ) copyToHost( host_logits, logits, logits.sizeInBytes(), ctx );
+    } );
+}
+/// GptTransformer::decode: host tokens [B] at absolute `position` -> host logits [B, V] (bf16 bits)
+HOST_API int mila_gpt_decode( void* h, const int32_t* host_tokens, int64_t position, uint16_t* host_logits )
+{
+    auto* r = static_cast<GptRunner*>( h );
+    return guarded( [&]
+    {
+        auto* ctx = r->model->context();
+        GptTransformer::TokenTensor toks( ctx->getDeviceId(), shape_t{ r->B, 1 } );
+        Compute::rocmCheck( mila_cdna4_memcpy_h2d( toks.data(), host_tokens, static_cast<size_t>( r->B ) * 4, ctx->getStream() ) );
+        auto& logits = r->model->decode( toks, position );
+        ctx->synchronize();
+        if ( host_logits ) copyToHost( host_logits, logits, logits.sizeInBytes(), ctx );
+    } );
+}
+
 HOST_API int mila_gpt_forward( void* h, const int32_t* host_tokens, uint16_t* host_logits, double* ms )
 {
     auto* r = static_cast<GptRunner*>( h );

@@ -29,7 +29,7 @@ CONDITIONED_PROFILE = dict(linear_gain=1.0, qk_norm_center=0.35, post_norm_cente
 
 
 class RefGemma:
-    def __init__(self, cfg, policy, seed, exact=False, profile=None, f32_stand_in=False, staged_prefill=False):
+    def __init__(self, cfg, policy, seed, exact=False, profile=None, f32_stand_in=False, staged_prefill=False, w4a8_prefill=False, w4a8_f32_order=False):
         self.c = dict(cfg)
         self.policy = policy
         self.exact = exact          # True: keep every intermediate in FP32 (the wiring check against the HF FP32 forward)
@@ -38,6 +38,12 @@ class RefGemma:
         # prefill (CudaLinearOp.ixx:597-644, :716-764: dequantize to a bf16 scratch, then a bf16 GEMM) that the in-register-dequantizing and
         # the staged GEMMs both restate; False: the decode matvec's arithmetic (scales applied in FP32) for every T
         self.staged_prefill = staged_prefill
+        # True (fp4 policy only): a T > 1 forward runs the reference's DEFAULT prefill for PerGroupFp4 -- W4A8 (CudaLinearOp.ixx:646-715): the fp4 weights upcast
+        # to e4m3 against the per-tensor scale sB, the activations quantized per token to e4m3, an fp8 x fp8 contraction, and the two-step epilogue
+        # bf16(float(bf16(acc * sB)) * s_m).  Takes precedence over staged_prefill for fp4 weights.
+        self.w4a8_prefill = w4a8_prefill
+        self.w4a8_f32_order = w4a8_f32_order      # tests/test_conditioned_cpu.py: the same arithmetic accumulated in FP32 in another order (a second correct implementation)
+        self._w8 = {}
         self.f32_stand_in = f32_stand_in   # tools/condition_probe.py only: FP32 BLAS accumulation as a stand-in for another summation order
         c = self.c
         D, H = c["embedding_dim"], c["hidden_dim"]
@@ -86,6 +92,9 @@ class RefGemma:
             Wf = orc.from_bf16_bits(W[1]) if W[0] == "bf16" else orc.dequant_fp8(W[1], W[2]) if W[0] == "fp8" else orc.dequant_fp4(W[1], W[2], 128)
             y = (np.asarray(x, np.float32)[..., ::-1] @ np.ascontiguousarray(Wf[:, ::-1].T)).astype(np.float32)
             return self.r(y) if round_out else y
+        rows = np.asarray(x).reshape(-1, np.asarray(x).shape[-1]).shape[0]
+        if W[0] == "fp4" and self.w4a8_prefill and round_out and rows > 1:
+            return self._linear_w4a8(x, W)
         if W[0] == "bf16":
             y = orc.linear_bf16w(x, W[1])
         elif self.staged_prefill and round_out and np.asarray(x).reshape(-1, np.asarray(x).shape[-1]).shape[0] > 1:
@@ -96,6 +105,25 @@ class RefGemma:
         else:
             y = orc.linear_fp4w(x, W[1], W[2], 128)
         return self.r(y) if round_out else y
+
+    def _linear_w4a8(self, x, W):
+        """CudaW4A16Gemm.cu:244-323 (sB, fp4 -> e4m3), CudaFp8Prefill.cu:108-211 (per-token activations, epilogue); oracle ops of tests/orc.py"""
+        key = id(W[1])
+        if key not in self._w8:
+            ws = orc.fp8_weight_scale_from_groups(W[2])
+            self._w8[key] = (orc.upcast_fp4_to_fp8(W[1], W[2], ws, 128), ws)
+        w8, ws = self._w8[key]
+        x2 = np.asarray(x, dtype=np.float32)
+        shp = x2.shape
+        x8, ts = orc.quantize_act_fp8_per_token(x2.reshape(-1, shp[-1]))
+        if self.w4a8_f32_order:
+            a = orc.E4M3_LUT[x8].astype(np.float32)[:, ::-1]
+            b = np.ascontiguousarray(orc.E4M3_LUT[w8].astype(np.float32)[:, ::-1].T)
+            raw = (a @ b).astype(np.float32) * np.float32(ws)
+        else:
+            raw = orc.linear_fp8a_fp8w(x8, np.ones(len(ts), dtype=np.float32), w8, None, ws)      # sB * acc
+        y = bf(raw).astype(np.float32) * ts.astype(np.float32)[:, None]
+        return self.r(y).reshape(shp[:-1] + (w8.shape[0],))
 
     def rms(self, x, w):
         return self.r(orc.rmsnorm(x, w, None, eps=1e-6))

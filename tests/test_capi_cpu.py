@@ -77,7 +77,7 @@ def test_validation_rejects_bad_arguments_without_touching_the_device(lib):
     assert lib.mila_cdna4_matvec_bf16_qfp8(one, one, one, null, null, 64, 8, null) == capi.MILA_E_INVALID_ARGUMENT
     assert lib.mila_cdna4_matvec_bf16_qfp4(one, one, one, one, null, 128, 8, 32, null) == capi.MILA_E_INVALID_ARGUMENT
     assert lib.mila_cdna4_matvec_bf16_qfp4(one, one, one, one, null, 96, 8, 64, null) == capi.MILA_E_INVALID_ARGUMENT
-    assert lib.mila_cdna4_gemm_bf16(one, one, one, null, 4, 40, 8, null) == capi.MILA_E_INVALID_ARGUMENT
+    assert lib.mila_cdna4_gemm_bf16(one, one, one, null, 4, 44, 8, null) == capi.MILA_E_INVALID_ARGUMENT
     assert lib.mila_cdna4_quantize_fp4_per_group(one, one, one, 4, 100, 128, null) == capi.MILA_E_INVALID_ARGUMENT
     assert lib.mila_cdna4_attn_decode_bf16(one, one, one, one, null, C.c_size_t(0), 1, 16, 3, 256, 64, 10, 0,
                                            C.c_float(1.0), null) == capi.MILA_E_INVALID_ARGUMENT

@@ -22,3 +22,14 @@ def test_conditioned_profile_keeps_two_correct_implementations_within_1e3():
 
 def test_unit_scale_random_weights_do_not():
     assert _distance(DEFAULT_PROFILE) > 1e-2
+
+
+def test_w4a8_prefill_composition_is_held_by_two_accumulation_orders_too():
+    """the fp4 policy's default prefill (W4A8: e4m3 weights x per-token e4m3 activations): products of two e4m3 values are exact in FP32, so a second
+    implementation that accumulates in FP32 in another order lands on (nearly) the same bf16 outputs -- and the path is a different arithmetic from the
+    exact-weight W4A16 prefill, by more than the bar (which is why the GPU must not switch between the two with the prompt length)"""
+    a = RefGemma(CFG, "fp4", 7, profile=CONDITIONED_PROFILE, w4a8_prefill=True).forward(TOK, 0, 32)
+    b = RefGemma(CFG, "fp4", 7, profile=CONDITIONED_PROFILE, w4a8_prefill=True, w4a8_f32_order=True).forward(TOK, 0, 32)
+    c = RefGemma(CFG, "fp4", 7, profile=CONDITIONED_PROFILE, staged_prefill=True).forward(TOK, 0, 32)
+    assert np.abs(a - b).max() <= 1e-3 * np.abs(a).max()
+    assert np.abs(a - c).max() > 2e-3 * np.abs(a).max()

@@ -60,8 +60,9 @@ def test_conditioned_12_layer_model_holds_1e3_on_decode_and_prefill(policy):
     assert worst <= BAR, worst
     for mdl in g.values():
         mdl.close()
-    # prefill (GEMM + flash attention + fused glue) of the same prompt; quantized policies multiply by bf16(dequantized weight) there
-    refp = RefGemma(CFG, policy, seed=7, profile=CONDITIONED_PROFILE, staged_prefill=True)
+    # prefill (GEMM + flash attention + fused glue) of the same prompt: the fp8 policy multiplies by bf16(dequantized weight) there (W8A16), the fp4 policy
+    # runs the reference's default W4A8 (e4m3 weights x per-token e4m3 activations, CudaLinearOp.ixx:646-715) at EVERY M > 1 -- T = 20 included, since round 3
+    refp = RefGemma(CFG, policy, seed=7, profile=CONDITIONED_PROFILE, staged_prefill=True, w4a8_prefill=True)
     exp = refp.forward(TOKENS, 0, MAX_SEQ)
     p = host.Gemma(policy, CFG, max_seq=MAX_SEQ, max_prefill=32, seed=7, profile=CONDITIONED_PROFILE)
     got = p.prefill(TOKENS)

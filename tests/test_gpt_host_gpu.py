@@ -97,6 +97,40 @@ def test_gpt2_124m_config2_full_size_properties():
     assert np.all(np.abs(short - exp) <= 5e-2 + 5e-2 * np.abs(exp)), np.abs(short - exp).max()
 
 
+@pytest.mark.parametrize("V,maxT,C_,L,NH,B,T,Tp", [(512, 64, 128, 2, 2, 2, 24, 9), (1000, 128, 768, 3, 12, 1, 64, 40), (256, 32, 64, 2, 8, 3, 16, 5)],
+                         ids=["HS64_B2", "HS64_width768", "HS8_generic_kernel_B3"])
+def test_gpt2_prefill_then_decode_matches_the_full_forward_and_the_cpu_backend(V, maxT, C_, L, NH, B, T, Tp):
+    """GptTransformer::prefill / decode (GptTransformer.ixx:330-441) over the per-block KV caches (GptBlock::decode, GptBlock.ixx:253-281; MHA over a KV
+    cache, CudaMhaOp.ixx:145-380): prefill T' tokens, then decode the rest one by one -- every step's logits equal that position's row of the full-sequence
+    forward (another kernel family: the reference's BF16 bar) and of the restated CPU backend; prefill after decode steps starts a new session"""
+    rng = np.random.default_rng(C_ + T + B)
+    params = make_params(rng, V, maxT, C_, L)
+    tokens = rng.integers(0, V, (B, T)).astype(np.int32)
+    g = host.Gpt(V, maxT, C_, L, NH, B, T)
+    g.load_parameters(params)
+    full = orc.from_bf16_bits(g.forward(tokens))                       # [B, T, V]
+    exp = orc.cpu_gpt2_forward(tokens, [orc.from_bf16_bits(p) for p in params], C_, L, NH, V, maxT)
+
+    def near(got, want, what):
+        assert np.all(np.isfinite(got)), what
+        assert np.all(np.abs(got - want) <= 5e-2 + 5e-2 * np.abs(want)), (what, float(np.abs(got - want).max()))
+
+    for session in range(2):
+        lp = orc.from_bf16_bits(g.prefill(tokens[:, :Tp]))             # [B, V]: the last prompt position
+        near(lp, full[:, Tp - 1], "prefill logits vs forward (session %d)" % session)
+        near(lp, exp[:, Tp - 1], "prefill logits vs CPU backend")
+        for pos in range(Tp, T):
+            ld = orc.from_bf16_bits(g.decode(tokens[:, pos], pos))
+            near(ld, full[:, pos], "decode @%d vs forward" % pos)
+            near(ld, exp[:, pos], "decode @%d vs CPU backend" % pos)
+            srt = np.sort(exp[:, pos], axis=-1)
+            clear = (srt[:, -1] - srt[:, -2]) > 0.2
+            assert np.array_equal(ld.argmax(-1)[clear], exp[:, pos].argmax(-1)[clear])
+    with pytest.raises(ValueError):
+        g.decode(tokens[:, 0], T)                                      # position beyond the built sequence length
+    g.close()
+
+
 def test_the_model_is_the_references_graph():
     """GptTransformer.ixx:828-858 (lenc, tf_layer_<i>, ln_final, lm_head), GptBlock.ixx:512-546 (attn, ln_1, ln_2, fc_qkv_proj, fc_out_proj, res_1, res_2, mlp),
     MLP.ixx:410-412 (fc_1, gelu, fc_2): the same components under the same names, in construction order"""

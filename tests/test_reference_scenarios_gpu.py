@@ -742,3 +742,98 @@ def test_softmax_forward_matches_reference__Softmax_Cuda_cpp_176():
     want = e / e.sum(axis=1, keepdims=True)
     assert_bf16_close(bits(y), want.astype(np.float32), 1, 1e-6, "Softmax forward")
     assert np.allclose(_f(y).reshape(4, 8).sum(axis=1), 1.0, atol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# MultiHeadAttention.Cuda.cpp / Gelu.Cuda.cpp / GatedMLP.Cuda.cpp (round 3)
+# ------------------------------------------------------------------------------------------------------------------------------
+def _mha_reference(X, B, T, C_, NH):       # MultiHeadAttention.Cuda.cpp:49-100 referenceAttention: float scores, double softmax sum / value accumulation
+    HS, qkv = C_ // NH, 3 * C_
+    X = np.asarray(X, np.float32).reshape(B, T, qkv)
+    scale = np.float32(1.0) / np.sqrt(np.float32(HS))
+    Y = np.zeros((B, T, C_), np.float32)
+    for b in range(B):
+        for h in range(NH):
+            for i in range(T):
+                q = X[b, i, h * HS:(h + 1) * HS]
+                sc = np.array([np.float32(np.dot(q, X[b, j, C_ + h * HS:C_ + (h + 1) * HS])) * scale for j in range(i + 1)], np.float32)
+                e = np.exp(sc - sc.max()).astype(np.float32)
+                tot = e.astype(np.float64).sum()
+                for d in range(HS):
+                    acc = sum((float(e[j]) / tot) * float(X[b, j, 2 * C_ + h * HS + d]) for j in range(i + 1))
+                    Y[b, i, h * HS + d] = np.float32(acc)
+    return Y
+
+
+def _mha_input(B, T, C_):                  # :170-178 spreadHost: sin(0.2 i + phase), phase 0
+    n = B * T * 3 * C_
+    return _bf(np.sin(np.float32(0.2) * np.arange(n, dtype=np.float32)).reshape(B, T, 3 * C_))
+
+
+@pytest.mark.parametrize("C_,NH", [(8, 2), (128, 2)], ids=["reference_geometry_HS4", "HS64_mfma_kernels"])
+def test_MultiHeadAttention_Cuda_cpp_232_Forward_MatchesCausalReference(C_, NH):
+    """B = 2, T = 3, model_dim 8, 2 heads (head size 4: the any-head-size kernel), packed [B, T, 3C] = sin(0.2 i): forward against the in-test causal
+    reference (:232-262; FP32-only on the reference's CUDA side, the bf16 row here: <= 1 bf16 ulp + the reference's atol 2e-3); and the same scenario at a
+    head size the MFMA flash kernel serves"""
+    B, T = 2, 3
+    X = _mha_input(B, T, C_)
+    Y = empty_u16(B, T, C_)
+    capi.call("mha_bf16", Y, _d(X), B, T, C_, NH)
+    assert_bf16_close(bits(Y), _mha_reference(X, B, T, C_, NH), 1, 2e-3, "MHA forward")
+
+
+@pytest.mark.parametrize("C_,NH", [(8, 2), (128, 2)], ids=["reference_geometry_HS4", "HS64_split_kernel"])
+def test_MultiHeadAttention_Cuda_cpp_264_Decode_MatchesReferenceAfterPrefill(C_, NH):
+    """prefill tokens [0, 1] (forward = attention + the prompt's K / V into the cache), then decode token 2 at position 2: the decode output must equal that
+    query's row of the full-sequence reference (:266-320) -- the KV cache supplies the earlier keys / values"""
+    B, T = 2, 3
+    lib = capi.load()
+    full = _mha_input(B, T, C_)
+    prefill, decode = np.ascontiguousarray(full[:, :2]), np.ascontiguousarray(full[:, 2:3])
+    HS = C_ // NH
+    Kc, Vc = torch.zeros((B, NH, T, HS), dtype=torch.int16, device="cuda"), torch.zeros((B, NH, T, HS), dtype=torch.int16, device="cuda")
+    Yp = empty_u16(B, 2, C_)
+    capi.call("mha_bf16", Yp, _d(prefill), B, 2, C_, NH)
+    capi.call("mha_kv_write_bf16", Kc, Vc, _d(prefill), B, 2, C_, NH, 0, T)
+    need = lib.mila_cdna4_mha_decode_scratch_bytes(B, C_, NH)
+    scratch = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
+    Y = empty_u16(B, 1, C_)
+    capi.call("mha_decode_bf16", Y, _d(decode), Kc, Vc, scratch, C.c_size_t(need), B, C_, NH, T, 2)
+    ref = _mha_reference(full, B, T, C_, NH)
+    assert_bf16_close(bits(Yp), ref[:, :2], 1, 2e-3, "MHA prefill rows")
+    assert_bf16_close(bits(Y).reshape(B, C_), ref[:, 2], 1, 2e-3, "MHA decode after prefill")
+    # the cache now holds all three positions' K / V, head-major
+    k_exp = orc.to_bf16_bits(full[:, :, C_:2 * C_]).reshape(B, T, NH, HS).transpose(0, 2, 1, 3)
+    assert np.array_equal(Kc.cpu().numpy().view(np.uint16), k_exp)
+    with pytest.raises(capi.InvalidArgument):          # CudaMhaOp.ixx:262-265: position out of range
+        capi.call("mha_decode_bf16", Y, _d(decode), Kc, Vc, scratch, C.c_size_t(need), B, C_, NH, T, 3)
+
+
+def test_Gelu_Cuda_cpp_131_Forward_MatchesReference():
+    """shape [2, 3, 4], x_i = i / size * 4 - 2 (:89-99), y within 1e-4 of the in-test tanh-GELU (:44-49): the FP32 row as the reference runs it, and the bf16 row"""
+    n = 24
+    x = (np.arange(n, dtype=np.float32) / np.float32(n) * np.float32(4.0) - np.float32(2.0)).astype(np.float32)
+    exp = (np.float32(0.5) * x * (np.float32(1.0) + np.tanh(np.float32(0.7978845608) * (x + np.float32(0.044715) * x * x * x)))).astype(np.float32)
+    Y = empty_f32(n)
+    capi.call("gelu_fp32", Y, dev_f32(x), C.c_int64(n))
+    assert np.abs(host(Y) - exp).max() <= 1e-4
+    xb = _bf(x)
+    eb = 0.5 * xb.astype(np.float64) * (1.0 + np.tanh(0.7978845608 * (xb.astype(np.float64) + 0.044715 * xb.astype(np.float64) ** 3)))
+    Yb = empty_u16(n)
+    capi.call("gelu_bf16", Yb, _d(xb), C.c_int64(n))
+    assert_bf16_close(bits(Yb), eb, 1, 1e-4, "gelu bf16")
+
+
+def test_GatedMLP_Cuda_cpp_207_Forward_ZeroInputYieldsZero():
+    """bias-free GatedMLP (in 8, hidden 8), input zeros [2, 3, 8]: 0 -> fc_gate_up = 0 -> gate(0) * 0 = 0 -> fc_down(0) = 0, exactly, with finite random weights
+    (:212-240); the chain as the component runs it: Linear (M = 6 > 1: the GEMM branch) -> GeGLU -> Linear"""
+    IN, H, M = 8, 8, 6
+    rng = np.random.default_rng(207)
+    Wgu, Wd = _bf(rng.standard_normal((2 * H, IN))), _bf(rng.standard_normal((IN, H)))
+    x = torch.zeros((M, IN), dtype=torch.int16, device="cuda")
+    gu, act, out = empty_u16(M, 2 * H), empty_u16(M, H), empty_u16(M, IN)
+    out.fill_(0x3F80)                                   # poison: the kernels must write the zeros
+    capi.call("gemm_bf16", gu, x, _d(Wgu), None, M, IN, 2 * H)
+    capi.call("geglu_bf16", act, gu, M, H)
+    capi.call("gemm_bf16", out, act, _d(Wd), None, M, H, IN)
+    assert not np.any(bits(gu) & 0x7FFF) and not np.any(bits(act) & 0x7FFF) and not np.any(bits(out) & 0x7FFF)
