@@ -274,6 +274,7 @@ static int g_gemm_force128 = 0;
 extern int g_gemm_pingpong;     // gemm256.hip
 extern int g_gemm_persistent;
 extern int g_gemm_fp8_tail_only;
+extern int g_gemm_fp8_tail_form;      // gemm_fp8_tail.hip
 
 // which direct-to-LDS kernel serves a bf16-weight GEMM of this shape: 2 = 256 x 256, 1 = 256 x 128, 0 = none (128 x 128 register-staged)
 static int glds_kernel_for(int M, int K, int N)
@@ -413,7 +414,8 @@ int mila_cdna4_tune_gemm_schedule(int pingpong)
 int mila_cdna4_tune_gemm_fp8_tail_only(int on)
 {
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
-    g_gemm_fp8_tail_only = on;
+    g_gemm_fp8_tail_only = on != 0;      // 1: every row on the masked 128-row LDS tiles (bit-identical to the LDS-DMA kernels); 2: every row as skinny pieces
+    g_gemm_fp8_tail_form = (on == 1 || on == 2) ? on : 0;
     return MILA_OK;
 }
 

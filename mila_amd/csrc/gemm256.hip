@@ -848,7 +848,7 @@ int launch_gemm_fp8_geglu_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8
 // Ragged row counts, as launch_bf16_rows splits them (gemm.hip): the LDS-DMA kernels take the leading multiple of 256 rows when one serves
 // that many, the tail kernel the rest (or everything).  Rows are independent and both kernels run the same instruction chain per output
 // element, so a row's bits do not depend on where the split falls -- the fp4 policy's prefill is W4A8 for EVERY M > 1 (CudaLinearOp.ixx:646-715).
-int g_gemm_fp8_tail_only = 0;      // tuning hook (mila_cdna4_tune_gemm_fp8_tail_only): every row through the masked kernel -- the bit-identity check
+int g_gemm_fp8_tail_only = 0;      // tuning hook (mila_cdna4_tune_gemm_fp8_tail_only): != 0: every row through the tail kernels (gemm_fp8_tail.hip: g_gemm_fp8_tail_form picks which)
 static int fp8_main_rows(int M, int K, int N, int* which)
 {
     *which = 0;

@@ -16,6 +16,8 @@
 // launcher to give the chip enough workgroups (N = 3840 at BN = 128 would be 30).
 // LDS image: 128-byte rows, source chunk c (16 bytes) at logical slot ((c & 1) << 2) | (c >> 1) -- the two halves of a lane's 32-byte
 // operand at slots g and 4 + g, the conflict-free pattern of gemm256.hip -- XOR-swizzled by (row >> 1) & 7.
+#include <algorithm>
+
 #include "common.h"
 
 namespace mila {
@@ -186,6 +188,174 @@ __global__ __launch_bounds__(256) void gemm_fp8_tail_kernel(const Fp8TailParams 
     }
 }
 
+// ---- the SKINNY form: M <= 64 rows (a prompt of 2049 tokens leaves a 1-row tail; short prompts; small chunk tails) --------------------------------------
+// At these row counts the GEMM is a weight stream: every byte of W is read once for 2 M FLOP, and the 128-row LDS tile above -- load, LDS round trip,
+// barrier, one K-tile in flight -- moves W at ~1 TB/s (a T = 2049 prefill cost 1.31x a T = 2048 one).  Here W never touches LDS:
+//   * a workgroup owns 16 W rows (GEGLU: 16 gate + the matching 16 up rows) and ALL of K; its 8 waves take the K-tiles 8 s + w of step s, so a step of the
+//     workgroup covers 1 KiB of every row and the eight partial sums meet in LDS once, at the end, in wave order (a fixed order: the result does not depend
+//     on M or on the grid);
+//   * a lane's MFMA A operand IS its two 16-byte global loads (row l15, bytes 32 g .. 32 g + 31 of the K-tile), non-temporal, requested PF steps ahead
+//     (8 waves x PF x 2 KiB in flight per workgroup, several workgroups per CU);
+//   * the X rows of a step (MG x 16 rows x 1 KiB) are staged once per workgroup through LDS (same image as above) and feed one MFMA per 16-row group.
+// Same instruction, same operand bytes per K-tile as the LDS-DMA kernels; the K-tiles are summed in another order (eight interleaved chains instead of one),
+// so results agree with them to fp32 rounding of exact e4m3 products -- within the 2 bf16 ulp the restated reference is held to -- not bit for bit.
+struct Fp8SkinnyParams
+{
+    uint16_t* Y;
+    const uint8_t* X;
+    const uint8_t* W;
+    const uint16_t* bias;
+    const float* x_scales;
+    const float* w_scale;
+    int M, K, N;              // M <= 16 MG
+};
+
+template <int MG, bool GEGLU>
+__global__ __launch_bounds__(512) void gemm_fp8_skinny_kernel(const Fp8SkinnyParams p)
+{
+    constexpr int PF = 3;                                   // W fragments requested this many steps ahead
+    constexpr int NA = GEGLU ? 2 : 1;                       // A fragments per wave and K-tile
+    constexpr int kRows = MG * 16;
+    constexpr int kStepBytes = 8 * kRows * 128;             // X image of one step: [8 K-tiles][rows][128 B]
+    constexpr int NXC = kRows * 64 / 512;                   // 16-byte X chunks per thread and step (2 MG)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kStepBytes];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int K = p.K, nk = (K + 127) / 128, steps = (nk + 7) / 8;
+    const int n0 = blockIdx.x * 16;
+    const bool row_ok = n0 + l15 < p.N;
+    const uint8_t* wrow[NA];
+    wrow[0] = p.W + (size_t)(row_ok ? n0 + l15 : 0) * K;
+    if constexpr (GEGLU) wrow[1] = p.W + (size_t)(row_ok ? p.N + n0 + l15 : 0) * K;
+
+    auto load_w = [&](u32x4 (&dst)[NA][2], int s) {
+        const int k = (8 * s + wave) * 128 + 32 * g;
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                dst[a][h] = (row_ok && k + 16 * h < K) ? ld16_nt(wrow[a] + k + 16 * h) : u32x4{0u, 0u, 0u, 0u};
+    };
+    u32x4 xr[NXC];
+    auto load_x = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < NXC; ++i)
+        {
+            const int c = tid + 512 * i, row = c >> 6, cc = c & 63;       // chunk cc of the row's 1 KiB of this step
+            const int k = s * 1024 + cc * 16;
+            xr[i] = (row < p.M && k < K) ? ld16(p.X + (size_t)row * K + k) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_x = [&](unsigned char* buf) {
+#pragma unroll
+        for (int i = 0; i < NXC; ++i)
+        {
+            const int c = tid + 512 * i, row = c >> 6, cc = c & 63;
+            const int ktl = cc >> 3, ch = cc & 7;
+            *reinterpret_cast<u32x4*>(buf + (ktl * kRows + row) * 128 + (((((ch & 1) << 2) | (ch >> 1)) ^ ((row >> 1) & 7)) << 4)) = xr[i];
+        }
+    };
+
+    f32x4 acc[NA][MG];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int m = 0; m < MG; ++m) acc[a][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // the W pipeline: wq[j] holds step s + j
+    u32x4 wq[PF][NA][2];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) load_w(wq[j], j);          // steps past the end load zeros (masked by k < K)
+    load_x(0);
+    store_x(smem);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s)
+    {
+        const bool more = s + 1 < steps;
+        if (more) load_x(s + 1);
+        const unsigned char* xb = smem + (s & 1) * kStepBytes + wave * (kRows * 128);
+        struct Pair { u32x4 lo, hi; };
+        i32x8t fa[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) fa[a] = __builtin_bit_cast(i32x8t, (Pair{wq[0][a][0], wq[0][a][1]}));
+#pragma unroll
+        for (int m = 0; m < MG; ++m)
+        {
+            const int r = m * 16 + l15, sw = (r >> 1) & 7;
+            const unsigned char* rowp = xb + r * 128;
+            const i32x8t fb = __builtin_bit_cast(i32x8t, (Pair{*reinterpret_cast<const u32x4*>(rowp + ((g ^ sw) << 4)), *reinterpret_cast<const u32x4*>(rowp + (((4 + g) ^ sw) << 4))}));
+#pragma unroll
+            for (int a = 0; a < NA; ++a) acc[a][m] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[a], fb, acc[a][m], 0, 0, 0, 127, 0, 127);
+        }
+        // shift the W pipeline and request step s + PF
+#pragma unroll
+        for (int j = 0; j + 1 < PF; ++j)
+#pragma unroll
+            for (int a = 0; a < NA; ++a) { wq[j][a][0] = wq[j + 1][a][0]; wq[j][a][1] = wq[j + 1][a][1]; }
+        load_w(wq[PF - 1], s + PF);
+        if (more) store_x(smem + ((s + 1) & 1) * kStepBytes);
+        __syncthreads();
+    }
+
+    // ---- the eight K-interleaved partial sums meet in LDS, in wave order ----
+    float* red = reinterpret_cast<float*>(smem);            // [8 waves][NA][MG][64 lanes] f32x4 : 8 NA MG KiB <= the X buffers
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int m = 0; m < MG; ++m) *reinterpret_cast<f32x4*>(red + ((((wave * NA + a) * MG + m) * 64 + lane) << 2)) = acc[a][m];
+    __syncthreads();
+    if (wave >= MG) return;
+    const int m = wave;                                      // wave m finishes row group m
+    f32x4 sum[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+    {
+        sum[a] = *reinterpret_cast<const f32x4*>(red + ((((0 * NA + a) * MG + m) * 64 + lane) << 2));
+#pragma unroll
+        for (int w = 1; w < 8; ++w)
+        {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(red + ((((w * NA + a) * MG + m) * 64 + lane) << 2));
+            sum[a] = f32x4{sum[a][0] + v[0], sum[a][1] + v[1], sum[a][2] + v[2], sum[a][3] + v[3]};
+        }
+    }
+    const int row = m * 16 + l15, n = n0 + 4 * g;
+    if (row >= p.M || n >= p.N) return;
+    const float ws = *p.w_scale, ts = p.x_scales[row];
+    float v[4];
+    if constexpr (GEGLU)
+    {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(round_bf16(round_bf16(sum[0][e] * ws) * ts)) * round_bf16(round_bf16(sum[1][e] * ws) * ts);
+    }
+    else
+    {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+        {
+            v[e] = round_bf16(sum[0][e] * ws) * ts;
+            if (p.bias && n + e < p.N) v[e] += bf16_bits_to_f32(p.bias[n + e]);
+        }
+    }
+    uint16_t* y = p.Y + (size_t)row * p.N + n;
+    if ((p.N & 3) == 0) *reinterpret_cast<u32x2*>(y) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    else
+    {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) y[e] = f32_to_bf16_bits(v[e]);
+    }
+}
+
+template <bool GEGLU>
+static int launch_skinny(const Fp8SkinnyParams& p, hipStream_t s)
+{
+    const int groups = (p.M + 15) / 16, blocks = (p.N + 15) / 16;
+    if (groups <= 1) hipLaunchKernelGGL((gemm_fp8_skinny_kernel<1, GEGLU>), dim3(blocks), dim3(512), 0, s, p);
+    else if (groups == 2) hipLaunchKernelGGL((gemm_fp8_skinny_kernel<2, GEGLU>), dim3(blocks), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((gemm_fp8_skinny_kernel<4, GEGLU>), dim3(blocks), dim3(512), 0, s, p);
+    MILA_LAUNCH_CHECK("gemm_fp8_skinny");
+}
+
 template <int WN, int PT, int QT, bool GEGLU>
 static int launch_tail_t(Fp8TailParams p, hipStream_t s)
 {
@@ -208,15 +378,41 @@ static int launch_tail(const Fp8TailParams& p, hipStream_t s)
     return launch_tail_t<1, 2, 2, GEGLU>(p, s);
 }
 
+int g_gemm_fp8_tail_form = 0;       // tuning hook (mila_cdna4_tune_gemm_fp8_tail_only): 0 = by row count, 1 = the 128-row LDS tiles for every row, 2 = skinny pieces for every row
+constexpr int kSkinnyRows = 64;     // rows one skinny launch takes
+constexpr int kSkinnyMaxTail = 255; // tails up to here run as skinny pieces (W re-streamed per piece, from the Infinity Cache where it fits)
+
+static bool use_skinny(int M) { return g_gemm_fp8_tail_form == 2 || (g_gemm_fp8_tail_form == 0 && M <= kSkinnyMaxTail); }
+
 int launch_gemm_fp8_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
                          int M, int K, int N, hipStream_t s)
 {
+    if (use_skinny(M))
+    {
+        for (int r0 = 0; r0 < M; r0 += kSkinnyRows)
+        {
+            Fp8SkinnyParams q{Y + (size_t)r0 * N, X8 + (size_t)r0 * K, W8, bias, x_scales + r0, w_scale, std::min(kSkinnyRows, M - r0), K, N};
+            const int rc = launch_skinny<false>(q, s);
+            if (rc) return rc;
+        }
+        return MILA_OK;
+    }
     Fp8TailParams p{Y, X8, W8, bias, x_scales, w_scale, M, K, N, 0, 0};
     return launch_tail<false>(p, s);
 }
 int launch_gemm_fp8_geglu_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
                                hipStream_t s)
 {
+    if (use_skinny(M))
+    {
+        for (int r0 = 0; r0 < M; r0 += kSkinnyRows)
+        {
+            Fp8SkinnyParams q{Y + (size_t)r0 * F, X8 + (size_t)r0 * K, W8, nullptr, x_scales + r0, w_scale, std::min(kSkinnyRows, M - r0), K, F};
+            const int rc = launch_skinny<true>(q, s);
+            if (rc) return rc;
+        }
+        return MILA_OK;
+    }
     Fp8TailParams p{Y, X8, W8, nullptr, x_scales, w_scale, M, K, F, 0, 0};
     return launch_tail<true>(p, s);
 }

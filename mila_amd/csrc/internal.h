@@ -17,8 +17,9 @@ MILA_API int mila_cdna4_tune_gemm(int force_128_tile);
  * 3 = staggered, two phases per K-tile; 4 = 3 + the fp8 shapes on the 256 x 256 kernel wherever it applies; 5 (default) = 4 with a static priority for waves 4-7
  * and persistent tiles; 6 = 5 with one workgroup per tile.  All give the same bits. */
 MILA_API int mila_cdna4_tune_gemm_schedule(int pingpong);
-/* 1 = the fp8 x fp8 GEMM entry points run EVERY row on the masked 128-row kernel (gemm_fp8_tail.hip), 0 (default) = LDS-DMA kernels on the leading
- * multiple of 256 rows.  Same bits either way: the test of that statement. */
+/* fp8 x fp8 GEMM entry points: 0 (default) = LDS-DMA kernels on the leading multiple of 256 rows, the tail kernels of gemm_fp8_tail.hip on the rest (skinny
+ * weight-streaming pieces up to 255 rows, masked 128-row LDS tiles beyond); 1 = EVERY row on the masked 128-row tiles (bit-identical to the LDS-DMA kernels:
+ * the test of that statement); 2 = every row as skinny pieces (same products, K-tiles summed in eight interleaved chains: fp32-rounding-level differences). */
 MILA_API int mila_cdna4_tune_gemm_fp8_tail_only(int on);
 /* positions of the live band one flash-decode split covers (default 64; 0 restores it): fewer, longer splits = smaller partial sets */
 MILA_API int mila_cdna4_tune_attn_split(int positions_per_split);

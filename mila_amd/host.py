@@ -208,6 +208,15 @@ class Gemma:
         _check(load().mila_gemma_time_prefill(self.h, T, reps, C.byref(out)))
         return out.value
 
+    def time_prefill_chunked(self, total_T):
+        """device ms of a total_T-token prompt prefilled from an empty cache in chunks of the built prefill size (GemmaTransformer::prefillFrom); the caches
+        hold total_T positions afterwards"""
+        lib = load()
+        lib.mila_gemma_time_prefill_chunked.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        out = C.c_double()
+        _check(lib.mila_gemma_time_prefill_chunked(self.h, int(total_T), C.byref(out)))
+        return out.value
+
     def component_names(self):
         """names of the model's components in construction order (each block, its children, temb, rmsn_final, lm_head)"""
         lib = load()

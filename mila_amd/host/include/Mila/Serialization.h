@@ -39,7 +39,7 @@ namespace Mila::Dnn::Serialization
         if ( dtype == "BF16" || dtype == "F16" || dtype == "I16" || dtype == "U16" ) return 2;
         if ( dtype == "F8_E4M3" || dtype == "F8_E5M2" || dtype == "U8" || dtype == "I8" || dtype == "BOOL" ) return 1;
         if ( dtype == "F64" || dtype == "I64" || dtype == "U64" ) return 8;
-        throw std::invalid_argument( "SafeTensors: unsupported dtype '" + dtype + "'" );
+        throw std::runtime_error( "SafeTensors: unsupported dtype '" + dtype + "'" );
     }
 
     struct SafeTensorsEntry
@@ -52,7 +52,7 @@ namespace Mila::Dnn::Serialization
         int64_t elements() const noexcept { int64_t n = 1; for ( auto d : shape ) n *= d; return n; }
     };
 
-    /// Memory-mapped reader.  Throws std::runtime_error on I/O errors and std::invalid_argument on a malformed container.
+    /// Memory-mapped reader.  Throws std::runtime_error on I/O errors and on a malformed container (as the reference's does).
     class SafeTensorsReader
     {
     public:
@@ -83,7 +83,7 @@ namespace Mila::Dnn::Serialization
         const SafeTensorsEntry& get( const std::string& name ) const
         {
             auto it = index_.find( name );
-            if ( it == index_.end() ) throw std::invalid_argument( "SafeTensorsReader: '" + path_ + "' has no tensor '" + name + "'" );
+            if ( it == index_.end() ) throw std::runtime_error( "SafeTensorsReader: '" + path_ + "' has no tensor '" + name + "'" );
             return entries_[ it->second ];
         }
 
@@ -91,7 +91,7 @@ namespace Mila::Dnn::Serialization
         // ---- a JSON reader for exactly the header's grammar: objects, arrays, strings, integers ----
         struct Cur { const char* p; const char* e; };
         static void ws( Cur& c ) { while ( c.p < c.e && ( *c.p == ' ' || *c.p == '\n' || *c.p == '\t' || *c.p == '\r' ) ) ++c.p; }
-        [[noreturn]] void bad( const char* what ) const { throw std::invalid_argument( "SafeTensorsReader: malformed header in '" + path_ + "': " + what ); }
+        [[noreturn]] void bad( const char* what ) const { throw std::runtime_error( "SafeTensorsReader: malformed header in '" + path_ + "': " + what ); }
         void expect( Cur& c, char ch ) const { ws( c ); if ( c.p >= c.e || *c.p != ch ) bad( "unexpected character" ); ++c.p; }
         std::string str( Cur& c ) const
         {
@@ -253,24 +253,25 @@ namespace Mila::Dnn::Serialization
 
         void declareTensor( const std::string& name, const std::string& dtype, const std::vector<int64_t>& shape )
         {
-            if ( header_written_ ) throw std::logic_error( "SafeTensorsWriter: declareTensor after beginData" );
-            for ( auto& e : entries_ ) if ( e.name == name ) throw std::invalid_argument( "SafeTensorsWriter: duplicate tensor '" + name + "'" );
+            if ( header_written_ ) throw std::runtime_error( "SafeTensorsWriter: declareTensor after beginData" );
+            for ( auto& e : entries_ ) if ( e.name == name ) throw std::runtime_error( "SafeTensorsWriter: duplicate tensor '" + name + "'" );
             SafeTensorsEntry e;
             e.name = name; e.dtype = dtype; e.shape = shape;
-            for ( auto d : shape ) if ( d < 0 ) throw std::invalid_argument( "SafeTensorsWriter: negative dimension in '" + name + "'" );
+            for ( auto d : shape ) if ( d < 0 ) throw std::runtime_error( "SafeTensorsWriter: negative dimension in '" + name + "'" );
             e.begin = next_offset_;
             e.end = e.begin + static_cast<uint64_t>( e.elements() ) * safeTensorsElementBytes( dtype );
             next_offset_ = e.end;
             entries_.push_back( std::move( e ) );
         }
+        size_t getTensorCount() const noexcept { return entries_.size(); }
         void setMetadata( const std::string& key, const std::string& value )
         {
-            if ( header_written_ ) throw std::logic_error( "SafeTensorsWriter: setMetadata after beginData" );
+            if ( header_written_ ) throw std::runtime_error( "SafeTensorsWriter: setMetadata after beginData" );
             metadata_[ key ] = value;
         }
         void beginData()
         {
-            if ( header_written_ ) throw std::logic_error( "SafeTensorsWriter: beginData called twice" );
+            if ( header_written_ ) throw std::runtime_error( "SafeTensorsWriter: beginData called twice" );
             std::string h = "{";
             if ( !metadata_.empty() )
             {
@@ -299,18 +300,18 @@ namespace Mila::Dnn::Serialization
         }
         void writeTensorData( const std::string& name, const void* data, size_t nbytes )
         {
-            if ( !header_written_ ) throw std::logic_error( "SafeTensorsWriter: writeTensorData before beginData" );
-            if ( next_write_ >= entries_.size() ) throw std::logic_error( "SafeTensorsWriter: more tensors written than declared" );
+            if ( !header_written_ ) throw std::runtime_error( "SafeTensorsWriter: writeTensorData before beginData" );
+            if ( next_write_ >= entries_.size() ) throw std::runtime_error( "SafeTensorsWriter: more tensors written than declared" );
             const auto& e = entries_[ next_write_ ];
-            if ( e.name != name ) throw std::logic_error( "SafeTensorsWriter: tensors must be written in declaration order (expected '" + e.name + "', got '" + name + "')" );
-            if ( nbytes != e.nbytes() ) throw std::invalid_argument( "SafeTensorsWriter: '" + name + "' has " + std::to_string( nbytes ) + " bytes, declared " + std::to_string( e.nbytes() ) );
+            if ( e.name != name ) throw std::runtime_error( "SafeTensorsWriter: tensors must be written in declaration order (expected '" + e.name + "', got '" + name + "')" );
+            if ( nbytes != e.nbytes() ) throw std::runtime_error( "SafeTensorsWriter: '" + name + "' has " + std::to_string( nbytes ) + " bytes, declared " + std::to_string( e.nbytes() ) );
             writeExact( data, nbytes );
             ++next_write_;
         }
         void close()
         {
             if ( !file_ ) return;
-            if ( header_written_ && next_write_ != entries_.size() ) { std::fclose( file_ ); file_ = nullptr; throw std::logic_error( "SafeTensorsWriter: close() before every declared tensor was written" ); }
+            if ( header_written_ && next_write_ != entries_.size() ) { std::fclose( file_ ); file_ = nullptr; throw std::runtime_error( "SafeTensorsWriter: close() before every declared tensor was written" ); }
             if ( std::fclose( file_ ) != 0 ) { file_ = nullptr; throw std::runtime_error( "SafeTensorsWriter: closing '" + path_ + "' failed" ); }
             file_ = nullptr;
         }
@@ -458,14 +459,14 @@ namespace Mila::Dnn::Serialization
     inline const char* milaWireCodeToDtypeName( uint32_t code )
     {
         static const char* names[] = { "F32", "F16", "BF16", "I32", "U8", "F8_E4M3", "F8_E5M2", "I8" };
-        if ( code >= 8 ) throw std::invalid_argument( "MILA container: unknown dtype code " + std::to_string( code ) );
+        if ( code >= 8 ) throw std::runtime_error( "MILA container: unknown dtype code " + std::to_string( code ) );
         return names[ code ];
     }
     inline uint32_t dtypeNameToMilaWireCode( const std::string& dtype )
     {
         static const char* names[] = { "F32", "F16", "BF16", "I32", "U8", "F8_E4M3", "F8_E5M2", "I8" };
         for ( uint32_t i = 0; i < 8; ++i ) if ( dtype == names[ i ] ) return i;
-        throw std::invalid_argument( "MILA container: dtype '" + dtype + "' has no wire code" );
+        throw std::runtime_error( "MILA container: dtype '" + dtype + "' has no wire code" );
     }
 
     /// Writer with the SafeTensorsWriter's call sequence (declareTensor* -> setMetadataJSON -> beginData -> writeTensorData in declaration
@@ -485,14 +486,14 @@ namespace Mila::Dnn::Serialization
 
         void declareTensor( const std::string& name, const std::string& dtype, const std::vector<int64_t>& shape )
         {
-            if ( header_written_ ) throw std::logic_error( "MilaBinWriter: declareTensor after beginData" );
-            if ( name.empty() || name.size() > 1024 ) throw std::invalid_argument( "MilaBinWriter: tensor names are 1..1024 bytes" );
-            if ( shape.size() > kMilaBinMaxRank ) throw std::invalid_argument( "MilaBinWriter: rank above " + std::to_string( kMilaBinMaxRank ) );
-            for ( auto& e : entries_ ) if ( e.name == name ) throw std::invalid_argument( "MilaBinWriter: duplicate tensor '" + name + "'" );
+            if ( header_written_ ) throw std::runtime_error( "MilaBinWriter: declareTensor after beginData" );
+            if ( name.empty() || name.size() > 1024 ) throw std::runtime_error( "MilaBinWriter: tensor names are 1..1024 bytes" );
+            if ( shape.size() > kMilaBinMaxRank ) throw std::runtime_error( "MilaBinWriter: rank above " + std::to_string( kMilaBinMaxRank ) );
+            for ( auto& e : entries_ ) if ( e.name == name ) throw std::runtime_error( "MilaBinWriter: duplicate tensor '" + name + "'" );
             SafeTensorsEntry e;
             e.name = name; e.dtype = dtype; e.shape = shape;
             (void)dtypeNameToMilaWireCode( dtype );
-            for ( auto d : shape ) if ( d < 0 || d > 0xffffffffLL ) throw std::invalid_argument( "MilaBinWriter: extent of '" + name + "' does not fit 32 bits" );
+            for ( auto d : shape ) if ( d < 0 || d > 0xffffffffLL ) throw std::runtime_error( "MilaBinWriter: extent of '" + name + "' does not fit 32 bits" );
             e.begin = next_offset_;
             e.end = e.begin + static_cast<uint64_t>( e.elements() ) * safeTensorsElementBytes( dtype );
             next_offset_ = e.end;
@@ -500,13 +501,13 @@ namespace Mila::Dnn::Serialization
         }
         void setMetadataJSON( const std::string& json )
         {
-            if ( header_written_ ) throw std::logic_error( "MilaBinWriter: setMetadataJSON after beginData" );
+            if ( header_written_ ) throw std::runtime_error( "MilaBinWriter: setMetadataJSON after beginData" );
             metadata_json_ = json;
         }
         void beginData()
         {
-            if ( header_written_ ) throw std::logic_error( "MilaBinWriter: beginData called twice" );
-            if ( metadata_json_.empty() ) throw std::logic_error( "MilaBinWriter: the container requires a metadata block" );
+            if ( header_written_ ) throw std::runtime_error( "MilaBinWriter: beginData called twice" );
+            if ( metadata_json_.empty() ) throw std::runtime_error( "MilaBinWriter: the container requires a metadata block" );
             uint64_t data0 = 16 + metadata_json_.size();
             for ( auto& e : entries_ ) data0 += 4 + e.name.size() + 4 + 4 + 4 * e.shape.size() + 8 + 8;
             u32( kMilaBinMagic ); u32( kMilaBinVersion ); u32( static_cast<uint32_t>( entries_.size() ) );
@@ -523,18 +524,18 @@ namespace Mila::Dnn::Serialization
         }
         void writeTensorData( const std::string& name, const void* data, size_t nbytes )
         {
-            if ( !header_written_ ) throw std::logic_error( "MilaBinWriter: writeTensorData before beginData" );
-            if ( next_write_ >= entries_.size() ) throw std::logic_error( "MilaBinWriter: more tensors written than declared" );
+            if ( !header_written_ ) throw std::runtime_error( "MilaBinWriter: writeTensorData before beginData" );
+            if ( next_write_ >= entries_.size() ) throw std::runtime_error( "MilaBinWriter: more tensors written than declared" );
             const auto& e = entries_[ next_write_ ];
-            if ( e.name != name ) throw std::logic_error( "MilaBinWriter: tensors must be written in declaration order (expected '" + e.name + "', got '" + name + "')" );
-            if ( nbytes != e.nbytes() ) throw std::invalid_argument( "MilaBinWriter: '" + name + "' has " + std::to_string( nbytes ) + " bytes, declared " + std::to_string( e.nbytes() ) );
+            if ( e.name != name ) throw std::runtime_error( "MilaBinWriter: tensors must be written in declaration order (expected '" + e.name + "', got '" + name + "')" );
+            if ( nbytes != e.nbytes() ) throw std::runtime_error( "MilaBinWriter: '" + name + "' has " + std::to_string( nbytes ) + " bytes, declared " + std::to_string( e.nbytes() ) );
             writeExact( data, nbytes );
             ++next_write_;
         }
         void close()
         {
             if ( !file_ ) return;
-            if ( header_written_ && next_write_ != entries_.size() ) { std::fclose( file_ ); file_ = nullptr; throw std::logic_error( "MilaBinWriter: close() before every declared tensor was written" ); }
+            if ( header_written_ && next_write_ != entries_.size() ) { std::fclose( file_ ); file_ = nullptr; throw std::runtime_error( "MilaBinWriter: close() before every declared tensor was written" ); }
             if ( std::fclose( file_ ) != 0 ) { file_ = nullptr; throw std::runtime_error( "MilaBinWriter: closing '" + path_ + "' failed" ); }
             file_ = nullptr;
         }
@@ -552,7 +553,7 @@ namespace Mila::Dnn::Serialization
 
     /// Counterpart of PretrainedModelReader (PretrainedReader.ixx:262-296): opens either container, sniffed by the leading magic, and
     /// fills ONE tensor index; entries() is in ascending file-offset order, the order streamTensorBlobs consumes them in (:453-470), so
-    /// loading is a single sequential pass over the mapping.  Malformed files throw std::invalid_argument, I/O failures std::runtime_error.
+    /// loading is a single sequential pass over the mapping.  Every failure -- a malformed file, a writer call out of sequence, an I/O error -- throws std::runtime_error, as every throw of the reference's readers and writers does (SafeTensors.ixx, PretrainedReader.ixx).
     class PretrainedModelReader
     {
     public:
@@ -593,10 +594,11 @@ namespace Mila::Dnn::Serialization
         const std::string& getWeightQuantization() const noexcept { return weight_quantization_; }
         const std::vector<SafeTensorsEntry>& entries() const noexcept { return entries_; }
         bool hasTensor( const std::string& name ) const noexcept { return index_.count( name ) != 0; }
+        std::vector<std::string> getTensorNames() const { std::vector<std::string> n; for ( auto& e : entries_ ) n.push_back( e.name ); return n; }
         const SafeTensorsEntry& get( const std::string& name ) const
         {
             auto it = index_.find( name );
-            if ( it == index_.end() ) throw std::invalid_argument( "PretrainedModelReader: '" + path_ + "' has no tensor '" + name + "'" );
+            if ( it == index_.end() ) throw std::runtime_error( "PretrainedModelReader: '" + path_ + "' has no tensor '" + name + "'" );
             return entries_[ it->second ];
         }
         size_t getMaxTensorSizeBytes() const noexcept { size_t m = 0; for ( auto& e : entries_ ) m = std::max( m, e.nbytes() ); return m; }
@@ -604,7 +606,7 @@ namespace Mila::Dnn::Serialization
         template<typename F> void streamTensorBlobs( F&& consume ) const { for ( auto& e : entries_ ) consume( e.name, e ); }
 
     private:
-        [[noreturn]] void bad( const std::string& what ) const { throw std::invalid_argument( "PretrainedModelReader: malformed MILA container '" + path_ + "': " + what ); }
+        [[noreturn]] void bad( const std::string& what ) const { throw std::runtime_error( "PretrainedModelReader: malformed MILA container '" + path_ + "': " + what ); }
         void openMila()
         {
             fd_ = ::open( path_.c_str(), O_RDONLY );

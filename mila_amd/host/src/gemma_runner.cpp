@@ -393,6 +393,39 @@ HOST_API int mila_gemma_time_dominant_kernel( void* h, int rounds, double* out )
     } );
 }
 
+/// a long prompt as the L6 caller feeds it (Gemma.ixx:234-267 prefill in chunks of the built prefill size, positions p0 .. p0 + n): device time of the whole
+/// chunked prefill of total_T tokens from an empty cache, in ms.  The caches hold total_T positions afterwards (decode can continue at total_T).
+HOST_API int mila_gemma_time_prefill_chunked( void* h, int64_t total_T, double* out_ms )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&]
+    {
+        if ( total_T <= 0 ) throw std::invalid_argument( "time_prefill_chunked: empty prompt" );
+        std::vector<int32_t> toks( static_cast<size_t>( total_T ) );
+        for ( int64_t i = 0; i < total_T; ++i ) toks[ i ] = static_cast<int32_t>( ( i * 7919 + 13 ) % 1000 );
+        std::visit( [&]( auto& m )
+        {
+            auto* ctx = m->context();
+            hipStream_t s = reinterpret_cast<hipStream_t>( ctx->getStream() );
+            Tensor<TensorDataType::INT32, Compute::RocmDeviceMemoryResource> dev( ctx->getDeviceId(), shape_t{ 1, total_T } );
+            Compute::rocmCheck( mila_cdna4_memcpy_h2d( dev.rawData(), toks.data(), static_cast<size_t>( total_T ) * 4, ctx->getStream() ) );
+            m->resetKVCache();
+            ctx->synchronize();
+            hipEvent_t e0, e1;
+            hipCheck( hipEventCreate( &e0 ), "hipEventCreate" );
+            hipCheck( hipEventCreate( &e1 ), "hipEventCreate" );
+            hipCheck( hipEventRecord( e0, s ), "hipEventRecord" );
+            m->prefillFrom( dev, total_T, 0 );
+            hipCheck( hipEventRecord( e1, s ), "hipEventRecord" );
+            ctx->synchronize();
+            float ms = 0;
+            hipCheck( hipEventElapsedTime( &ms, e0, e1 ), "hipEventElapsedTime" );
+            (void)hipEventDestroy( e0 ); (void)hipEventDestroy( e1 );
+            *out_ms = static_cast<double>( ms );
+        }, r->model );
+    } );
+}
+
 HOST_API int mila_gemma_time_prefill( void* h, int64_t T, int reps, double* out_ms )
 {
     auto* r = static_cast<Runner*>( h );

@@ -33,3 +33,20 @@ def test_w4a8_prefill_composition_is_held_by_two_accumulation_orders_too():
     c = RefGemma(CFG, "fp4", 7, profile=CONDITIONED_PROFILE, staged_prefill=True).forward(TOK, 0, 32)
     assert np.abs(a - b).max() <= 1e-3 * np.abs(a).max()
     assert np.abs(a - c).max() > 2e-3 * np.abs(a).max()
+
+
+class _Fp32Norm(RefGemma):
+    """a second correct implementation whose RMSNorm reduces in float32 in reverse order: 1-ulp bf16 differences upstream of every Linear"""
+    def rms(self, x, w):
+        x = np.asarray(x, np.float32)
+        ms = (x[..., ::-1] ** 2).sum(-1, dtype=np.float32, keepdims=True) / np.float32(x.shape[-1])
+        return self.r(x * (np.float32(1) / np.sqrt(ms + np.float32(1e-6))) * np.asarray(w, np.float32))
+
+
+def test_w4a8_turns_upstream_rounding_into_e4m3_steps_hence_its_own_bar():
+    """why tests/test_gemma_conditioned_gpu.py holds the fp4 policy's W4A8 prefill to 3e-3 and not 1e-3: with per-token e4m3 activations a 1-ulp bf16 difference
+    upstream flips e4m3 codes (6 % steps), so two correct compositions differ by more than under bf16 activations -- but stay far inside 3e-3"""
+    a = RefGemma(CFG, "fp4", 7, profile=CONDITIONED_PROFILE, w4a8_prefill=True).forward(TOK, 0, 32)
+    b = _Fp32Norm(CFG, "fp4", 7, profile=CONDITIONED_PROFILE, w4a8_prefill=True).forward(TOK, 0, 32)
+    d = float(np.abs(a - b).max() / np.abs(a).max())
+    assert 0.0 < d <= 3e-3, d

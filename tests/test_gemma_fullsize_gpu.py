@@ -92,12 +92,12 @@ def test_full_size_gemm_schedules_give_the_same_bits(policy, bf16_run):
     outs = []
     try:
         for sched in ((0, 3) if policy == "bf16" else (1, 3)):
-            lib.mila_cdna4_tune_gemm_schedule(sched)
+            capi.check(lib.mila_cdna4_tune_gemm_schedule(sched))       # an inert hook (MILA_CDNA4_TUNING unset) must fail the test, not compare the default with itself
             g = host.Gemma(policy, max_seq=T + 16, max_prefill=T, seed=1234)
             outs.append(g.prefill(TOKS))
             g.close()
     finally:
-        lib.mila_cdna4_tune_gemm_schedule(5)      # the default
+        capi.check(lib.mila_cdna4_tune_gemm_schedule(5))      # the default
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
     if policy == "bf16":
         assert np.array_equal(outs[1].view(np.uint32), bf16_run["prefill"].view(np.uint32))

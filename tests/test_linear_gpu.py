@@ -104,7 +104,7 @@ def test_matvec_every_launch_shape_gives_the_same_answer(R, U):
     xd = dev_u16(orc.to_bf16_bits(x))
     lib = capi.load()
     try:
-        lib.mila_cdna4_tune_matvec(R, U, 3)
+        capi.check(lib.mila_cdna4_tune_matvec(R, U, 3))
         y = empty_u16(N)
         capi.call("matvec_bf16", y, xd, dev_u16(Wb), None, K, N)
         assert_bf16_close(bits(y), orc.linear_bf16w(x[None], Wb)[0], 1, 1e-5, "bf16 R%d U%d" % (R, U))
@@ -113,7 +113,7 @@ def test_matvec_every_launch_shape_gives_the_same_answer(R, U):
         capi.call("matvec_bf16_qfp4", y, xd, dev_u8(q4), dev_f32(s4), None, K, N, G)
         assert_bf16_close(bits(y), orc.linear_fp4w(x[None], q4, s4, G)[0], 1, 1e-5, "fp4 R%d U%d" % (R, U))
     finally:
-        lib.mila_cdna4_tune_matvec(0, 0, 0)
+        capi.check(lib.mila_cdna4_tune_matvec(0, 0, 0))
 
 
 @pytest.mark.parametrize("fmt", [0, 1, 2])
@@ -342,10 +342,10 @@ def test_gemm_256_tile_kernel_agrees_with_the_128_tile_kernel(M, K, N, bias):
     Y256, Y128 = empty_u16(M, N), empty_u16(M, N)
     capi.call("gemm_bf16", Y256, Xi, Wi, bi, M, K, N)
     try:
-        lib.mila_cdna4_tune_gemm(1)
+        capi.check(lib.mila_cdna4_tune_gemm(1))
         capi.call("gemm_bf16", Y128, Xi, Wi, bi, M, K, N)
     finally:
-        lib.mila_cdna4_tune_gemm(0)
+        capi.check(lib.mila_cdna4_tune_gemm(0))
     a = bits(Y256).astype(np.int32)
     c = bits(Y128).astype(np.int32)
     oa = np.where(a & 0x8000, -(a & 0x7fff), a)
@@ -545,7 +545,7 @@ def _w4a8_operands(rng, M, K, N, G=128):
 def test_w4a8_serves_every_row_count_like_the_reference(M, K, N, bias, G):
     """CudaLinearOp.ixx:646-715 runs W4A8 for EVERY M > 1; here the LDS-DMA fp8 kernels take the leading multiple of 256 rows and the masked 128-row
     kernel (csrc/gemm_fp8_tail.hip) the rest, or all of them: gemm_fp8_applicable is true at M in {2, 16, 2000, 2049, ...}, sampled rows of both parts are
-    within 2 ulp of the restated reference, and the split changes no bit (every row through the masked kernel == the default split)"""
+    within 2 ulp of the restated reference; tails up to 255 rows run as skinny weight-streaming pieces, longer ones on masked 128-row LDS tiles"""
     lib = capi.load()
     assert lib.mila_cdna4_gemm_fp8_applicable(M, K, N) == 1
     rng = np.random.default_rng(M * 7 + N)
@@ -569,14 +569,27 @@ def test_w4a8_serves_every_row_count_like_the_reference(M, K, N, bias, G):
     capi.call("gemm_bf16_w4a8", Y2, dev_u16(orc.to_bf16_bits(X)), dev_u8(q4), dev_f32(s4), ws_d, dev_u16(bb) if bias else None, M, K, N, G,
               scratch, C.c_size_t(need))
     assert np.array_equal(bits(Y2), bits(Y))
-    # every row on the masked kernel: bit-identical to the split
-    Y3 = empty_u16(M, N)
-    capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(1))
-    try:
-        capi.call("gemm_fp8_scaled", Y3, X8, W8, ts_d, ws_d, dev_u16(bb) if bias else None, M, K, N)
-    finally:
-        capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(0))
-    assert np.array_equal(bits(Y3), bits(Y)), "the masked fp8 kernel and the LDS-DMA fp8 kernels differ"
+    # the tail kernels over EVERY row (tuning hook): form 1 = masked 128-row LDS tiles -- the LDS-DMA kernels' instruction chain, bit for bit; form 2 = skinny
+    # weight-streaming pieces -- the same products summed as eight interleaved K chains, so fp32-rounding-level differences only
+    forms = {}
+    for form in (1, 2):
+        Yf = empty_u16(M, N)
+        capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(form))
+        try:
+            capi.call("gemm_fp8_scaled", Yf, X8, W8, ts_d, ws_d, dev_u16(bb) if bias else None, M, K, N)
+        finally:
+            capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(0))
+        forms[form] = bits(Yf)
+        assert_bf16_close(forms[form][rows], exp, 2, 1e-3 * float(np.abs(exp).max()), "fp8 GEMM, tail form %d, vs restated reference" % form)
+    main_served = main if (main >= 512 and K % 128 == 0 and lib.mila_cdna4_gemm_staging_bytes(main, K, N) != 0) else 0      # the same grid rule serves bf16 and fp8
+    if main_served:
+        assert np.array_equal(forms[1][:main_served], bits(Y)[:main_served]), "the masked LDS-tile kernel and the LDS-DMA fp8 kernels differ"
+    if M - main_served > 255:
+        assert np.array_equal(forms[1][main_served:], bits(Y)[main_served:])        # tails beyond 255 rows run the LDS tiles by default
+    else:
+        assert np.array_equal(forms[2][main_served:], bits(Y)[main_served:])        # ... shorter ones the skinny pieces
+    a, b = orc.from_bf16_bits(forms[1]).astype(np.float64), orc.from_bf16_bits(forms[2]).astype(np.float64)
+    assert np.abs(a - b).max() <= 2.0 ** -6 * np.abs(a).max(), "the two tail forms differ by more than rounding"
 
 
 @pytest.mark.parametrize("M,K,F", [(2, 256, 15360), (100, 384, 1000), (512 + 100, 256, 15360), (2049, 128, 15360)])
@@ -598,12 +611,17 @@ def test_w4a8_geglu_form_serves_every_row_count(M, K, F):
     capi.call("geglu_bf16", Y0, GU, M, F)
     capi.call("gemm_geglu_bf16_w4a8", Y1, X, dev_u8(q4), dev_f32(s4), ws, M, K, F, 128, scratch, C.c_size_t(need))
     assert np.array_equal(bits(Y0), bits(Y1))
-    capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(1))
-    try:
-        capi.call("gemm_geglu_bf16_w4a8", Y2, X, dev_u8(q4), dev_f32(s4), ws, M, K, F, 128, scratch, C.c_size_t(need))
-    finally:
-        capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(0))
-    assert np.array_equal(bits(Y2), bits(Y1))
+    for form in (1, 2):
+        capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(form))
+        try:
+            capi.call("gemm_geglu_bf16_w4a8", Y2, X, dev_u8(q4), dev_f32(s4), ws, M, K, F, 128, scratch, C.c_size_t(need))
+            capi.call("gemm_bf16_w4a8", GU, X, dev_u8(q4), dev_f32(s4), ws, None, M, K, 2 * F, 128, scratch, C.c_size_t(need))
+            capi.call("geglu_bf16", Y0, GU, M, F)
+        finally:
+            capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(0))
+        assert np.array_equal(bits(Y2), bits(Y0)), "tail form %d: fused GeGLU epilogue != Linear + GeGLU" % form      # per form, the fusion changes no bit
+        a, b = orc.from_bf16_bits(bits(Y2)).astype(np.float64), orc.from_bf16_bits(bits(Y1)).astype(np.float64)
+        assert np.abs(a - b).max() <= 2.0 ** -5 * max(np.abs(b).max(), 1e-30), "tail form %d differs from the default by more than rounding" % form
 
 
 @pytest.mark.parametrize("M", [2048 + 77, 1024 + 255, 768 + 1, 512 + 3])

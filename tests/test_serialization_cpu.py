@@ -173,7 +173,7 @@ def test_safetensors_to_mila_bin_keeps_every_byte(tmp_path):
     again, meta2 = host.pretrained_list(dst)
     assert meta2["container"] == "mila" and {g[0]: g[2] for g in again} == {g[0]: g[2] for g in listed}
     st_numpy.save_file({"w": u16}, str(src))
-    with pytest.raises(ValueError, match="no wire code"):     # the container's dtype set is closed (PretrainedReader.ixx:209-220)
+    with pytest.raises(RuntimeError, match="no wire code"):     # the container's dtype set is closed (PretrainedReader.ixx:209-220)
         host.pretrained_to_milabin(src, dst, "{}")
 
 
@@ -231,3 +231,38 @@ def test_mila_bin_reader_rejects_malformed_containers(tmp_path, damage):
     open(p, "wb").write(raw)
     with pytest.raises((ValueError, RuntimeError)):
         host.pretrained_list(p)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The reference's own 16 container scenarios (Tests/Dnn/Serialization/SafeTensors.Cpu.cpp:133-532), one to one against the host
+# mirror's containers: tests/cpp/safetensors_scenarios.cpp holds them under the reference's test names (same call sequences, values,
+# expectations, and the exception type its tests expect, std::runtime_error); each runs as its own process.
+# ------------------------------------------------------------------------------------------------------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAFETENSORS_CPU_CPP = [(133, "RoundTripsTensorsOfMixedDataTypes"), (187, "CarriesMilaConfigThroughMetadata"), (220, "ReadsAFileThatCarriesNoMilaConfig"),
+                       (242, "MetadataSurvivesAFullWriteReadCycle"), (320, "SurfacesTheDeclaredWeightQuantization"), (340, "TreatsAnUnquantizedDeclarationAsAbsent"),
+                       (368, "LegacyMilaContainerDeclaresNoQuantization"), (384, "RejectsOutOfOrderBodyWrites"), (402, "RejectsBodySizeMismatch"),
+                       (417, "RejectsDuplicateTensorNames"), (429, "RejectsDeclarationAfterHeaderIsWritten"), (442, "CloseRefusesWhenADeclaredTensorWasNeverWritten"),
+                       (463, "RejectsAFileThatIsNeitherContainer"), (478, "RejectsATensorExtendingPastEndOfFile"), (502, "StillReadsTheLegacyMilaContainer"),
+                       (532, "LegacyContainerStillRejectsAWrongVersion")]
+
+
+@pytest.fixture(scope="module")
+def scenario_driver(tmp_path_factory):
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    exe = tmp_path_factory.mktemp("st_scenarios") / "safetensors_scenarios"
+    subprocess.check_call(["g++", "-std=c++20", "-Wall", "-Wextra", "-Werror", "-O1", "-I" + os.path.join(ROOT, "mila_amd", "host", "include"),
+                           os.path.join(ROOT, "tests", "cpp", "safetensors_scenarios.cpp"), "-o", str(exe)])
+    listed = subprocess.run([str(exe)], capture_output=True, text=True).stdout.split()
+    assert sorted(listed) == sorted(n for _, n in SAFETENSORS_CPU_CPP)          # the driver holds exactly the reference's 16
+    return str(exe)
+
+
+@pytest.mark.parametrize("line,name", SAFETENSORS_CPU_CPP, ids=["SafeTensors_Cpu_cpp_%d_%s" % ln for ln in SAFETENSORS_CPU_CPP])
+def test_reference_container_scenario(scenario_driver, tmp_path, line, name):
+    import subprocess
+    p = subprocess.run([scenario_driver, name, str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, "SafeTensors.Cpu.cpp:%d %s\n%s%s" % (line, name, p.stdout, p.stderr)
