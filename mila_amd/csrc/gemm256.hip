@@ -808,8 +808,15 @@ static int launch_gemm256_t(const Gemm256Params& p, hipStream_t s)
     return g_gemm_pingpong ? launch_gemm256_tt<MODE, 1>(p, s) : launch_gemm256_tt<MODE, 0>(p, s);
 }
 
+// gemm4w.hip: the same tile on four waves (one per SIMD, 128 x 128 each), bit-identical results
+int launch_gemm4w(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s);
+int launch_gemm4w_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s);
+bool gemm4w_addressable(int M, int K, int N_rows_of_W);
+int g_gemm_four_wave = 0;     // tuning hook (mila_cdna4_tune_gemm_schedule(7)): bf16 256 x 256 shapes on the four-wave kernel
+
 int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
 {
+    if (g_gemm_four_wave && gemm4w_addressable(M, K, N)) return launch_gemm4w(Y, X, W, bias, M, K, N, s);
     Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, N / 256, nullptr, nullptr};
     return launch_gemm256_t<G_PLAIN>(p, s);
 }
@@ -824,6 +831,7 @@ bool gemm256_geglu_applicable(int M, int K, int F)
 }
 int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s)
 {
+    if (g_gemm_four_wave && gemm4w_addressable(M, K, 2 * F)) return launch_gemm4w_geglu(Y, X, W, M, K, F, s);
     Gemm256Params p{Y, X, W, nullptr, M, K, F, M / 256, F / 128, nullptr, nullptr};
     return launch_gemm256_t<G_GEGLU>(p, s);
 }

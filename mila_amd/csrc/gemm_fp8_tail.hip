@@ -71,14 +71,17 @@ __global__ __launch_bounds__(256) void gemm_fp8_tail_kernel(const Fp8TailParams 
     };
     auto lds_off = [](int row, int c) { return row * 128 + (((((c & 1) << 2) | (c >> 1)) ^ ((row >> 1) & 7)) << 4); };
 
-    u32x4 rx[NX], rw[NW];
-    auto stage_load = [&](int kt) {
+    // two named register sets: the K-tile staged to LDS at the end of iteration t was requested at iteration t - 2 (two K-tiles of latency cover; with one
+    // set -- requested at t, stored at t -- a 208-row tail ran the tile at ~1 us per K-tile, the global latency laid bare)
+    struct Regs { u32x4 x[NX], w[NW]; };
+    Regs ra, rb;
+    auto stage_load = [&](Regs& r, int kt) {
 #pragma unroll
         for (int i = 0; i < NX; ++i)
         {
             const int s = tid + 256 * i, row = s >> 3, c = s & 7;
             const int m = m0 + row, k = kt * 128 + c * 16;
-            rx[i] = (m < p.M && k < K) ? ld16(p.X + (size_t)m * K + k) : u32x4{0u, 0u, 0u, 0u};
+            r.x[i] = (m < p.M && k < K) ? ld16(p.X + (size_t)m * K + k) : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i)
@@ -87,21 +90,21 @@ __global__ __launch_bounds__(256) void gemm_fp8_tail_kernel(const Fp8TailParams 
             const int k = kt * 128 + c * 16;
             bool ok;
             const size_t n = w_row(row, ok);
-            rw[i] = (ok && k < K) ? ld16(p.W + n * K + k) : u32x4{0u, 0u, 0u, 0u};
+            r.w[i] = (ok && k < K) ? ld16(p.W + n * K + k) : u32x4{0u, 0u, 0u, 0u};
         }
     };
-    auto stage_store = [&](unsigned char* buf) {
+    auto stage_store = [&](const Regs& r, unsigned char* buf) {
 #pragma unroll
         for (int i = 0; i < NX; ++i)
         {
             const int s = tid + 256 * i;
-            *reinterpret_cast<u32x4*>(buf + lds_off(s >> 3, s & 7)) = rx[i];
+            *reinterpret_cast<u32x4*>(buf + lds_off(s >> 3, s & 7)) = r.x[i];
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i)
         {
             const int s = tid + 256 * i;
-            *reinterpret_cast<u32x4*>(buf + kXBytes + lds_off(s >> 3, s & 7)) = rw[i];
+            *reinterpret_cast<u32x4*>(buf + kXBytes + lds_off(s >> 3, s & 7)) = r.w[i];
         }
     };
 
@@ -111,14 +114,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_tail_kernel(const Fp8TailParams 
 #pragma unroll
         for (int b = 0; b < QT; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    stage_load(0);
-    stage_store(smem);
-    __syncthreads();
-    for (int t = 0; t < nk; ++t)
-    {
-        const unsigned char* cur = smem + (t & 1) * kBuf;
-        const bool more = t + 1 < nk;
-        if (more) stage_load(t + 1);
+    auto compute = [&](const unsigned char* cur) {
         struct Pair { s16x8 lo, hi; };
         i32x8t fa[PT], fb[QT];
 #pragma unroll
@@ -142,7 +138,26 @@ __global__ __launch_bounds__(256) void gemm_fp8_tail_kernel(const Fp8TailParams 
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt)
                 acc[pt][qt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[pt], fb[qt], acc[pt][qt], 0, 0, 0, 127, 0, 127);
-        if (more) stage_store(smem + ((t + 1) & 1) * kBuf);
+    };
+
+    // prologue: K-tile 0 in LDS buffer 0; set A holds K-tile 1, set B K-tile 2 (both in flight)
+    stage_load(ra, 0);
+    stage_store(ra, smem);
+    if (nk > 1) stage_load(ra, 1);
+    if (nk > 2) stage_load(rb, 2);
+    __syncthreads();
+    for (int t = 0; t < nk; t += 2)
+    {
+        // even K-tile t (buffer 0): A -> buffer 1 is K-tile t + 1, then A requests t + 3
+        compute(smem);
+        if (t + 1 < nk) stage_store(ra, smem + kBuf);
+        if (t + 3 < nk) stage_load(ra, t + 3);
+        __syncthreads();
+        if (t + 1 >= nk) break;
+        // odd K-tile t + 1 (buffer 1): B -> buffer 0 is K-tile t + 2, then B requests t + 4
+        compute(smem + kBuf);
+        if (t + 2 < nk) stage_store(rb, smem);
+        if (t + 4 < nk) stage_load(rb, t + 4);
         __syncthreads();
     }
 
@@ -210,23 +225,32 @@ struct Fp8SkinnyParams
     int M, K, N;              // M <= 16 MG
 };
 
-template <int MG, bool GEGLU>
+template <int MG, bool GEGLU, int NR>       // NR: 16-row groups of W per workgroup (2 where N gives the chip enough workgroups anyway: half the prologues / reductions per byte)
 __global__ __launch_bounds__(512) void gemm_fp8_skinny_kernel(const Fp8SkinnyParams p)
 {
     constexpr int PF = 3;                                   // W fragments requested this many steps ahead
-    constexpr int NA = GEGLU ? 2 : 1;                       // A fragments per wave and K-tile
+    constexpr int NG = GEGLU ? 2 : 1;                       // gate / up
+    constexpr int NA = NG * NR;                             // A fragments per wave and K-tile
     constexpr int kRows = MG * 16;
     constexpr int kStepBytes = 8 * kRows * 128;             // X image of one step: [8 K-tiles][rows][128 B]
     constexpr int NXC = kRows * 64 / 512;                   // 16-byte X chunks per thread and step (2 MG)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kStepBytes];
+    constexpr int kRedBytes = 8 * NA * MG * 1024;
+    constexpr int kSmem = 2 * kStepBytes > kRedBytes ? 2 * kStepBytes : kRedBytes;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kSmem];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
     const int K = p.K, nk = (K + 127) / 128, steps = (nk + 7) / 8;
-    const int n0 = blockIdx.x * 16;
-    const bool row_ok = n0 + l15 < p.N;
+    const int n0 = blockIdx.x * (16 * NR);
+    bool row_ok[NR];
     const uint8_t* wrow[NA];
-    wrow[0] = p.W + (size_t)(row_ok ? n0 + l15 : 0) * K;
-    if constexpr (GEGLU) wrow[1] = p.W + (size_t)(row_ok ? p.N + n0 + l15 : 0) * K;
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+    {
+        row_ok[r] = n0 + r * 16 + l15 < p.N;
+        const int n = row_ok[r] ? n0 + r * 16 + l15 : 0;
+        wrow[r * NG] = p.W + (size_t)n * K;
+        if constexpr (GEGLU) wrow[r * NG + 1] = p.W + (size_t)(p.N + n) * K;
+    }
 
     auto load_w = [&](u32x4 (&dst)[NA][2], int s) {
         const int k = (8 * s + wave) * 128 + 32 * g;
@@ -234,7 +258,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_skinny_kernel(const Fp8SkinnyPar
         for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-                dst[a][h] = (row_ok && k + 16 * h < K) ? ld16_nt(wrow[a] + k + 16 * h) : u32x4{0u, 0u, 0u, 0u};
+                dst[a][h] = (row_ok[a / NG] && k + 16 * h < K) ? ld16_nt(wrow[a] + k + 16 * h) : u32x4{0u, 0u, 0u, 0u};
     };
     u32x4 xr[NXC];
     auto load_x = [&](int s) {
@@ -298,61 +322,74 @@ __global__ __launch_bounds__(512) void gemm_fp8_skinny_kernel(const Fp8SkinnyPar
     }
 
     // ---- the eight K-interleaved partial sums meet in LDS, in wave order ----
-    float* red = reinterpret_cast<float*>(smem);            // [8 waves][NA][MG][64 lanes] f32x4 : 8 NA MG KiB <= the X buffers
+    float* red = reinterpret_cast<float*>(smem);            // [8 waves][NA][MG][64 lanes] f32x4
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int m = 0; m < MG; ++m) *reinterpret_cast<f32x4*>(red + ((((wave * NA + a) * MG + m) * 64 + lane) << 2)) = acc[a][m];
     __syncthreads();
-    if (wave >= MG) return;
-    const int m = wave;                                      // wave m finishes row group m
-    f32x4 sum[NA];
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
+    // (row group of X, row group of W) pairs are dealt to the waves
+    for (int job = wave; job < MG * NR; job += 8)
     {
-        sum[a] = *reinterpret_cast<const f32x4*>(red + ((((0 * NA + a) * MG + m) * 64 + lane) << 2));
+        const int m = job % MG, r = job / MG;
+        f32x4 sum[NG];
 #pragma unroll
-        for (int w = 1; w < 8; ++w)
+        for (int q = 0; q < NG; ++q)
         {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(red + ((((w * NA + a) * MG + m) * 64 + lane) << 2));
-            sum[a] = f32x4{sum[a][0] + v[0], sum[a][1] + v[1], sum[a][2] + v[2], sum[a][3] + v[3]};
+            const int a = r * NG + q;
+            sum[q] = *reinterpret_cast<const f32x4*>(red + ((((0 * NA + a) * MG + m) * 64 + lane) << 2));
+#pragma unroll
+            for (int w = 1; w < 8; ++w)
+            {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(red + ((((w * NA + a) * MG + m) * 64 + lane) << 2));
+                sum[q] = f32x4{sum[q][0] + v[0], sum[q][1] + v[1], sum[q][2] + v[2], sum[q][3] + v[3]};
+            }
+        }
+        const int row = m * 16 + l15, n = n0 + r * 16 + 4 * g;
+        if (row >= p.M || n >= p.N) continue;
+        const float ws = *p.w_scale, ts = p.x_scales[row];
+        float v[4];
+        if constexpr (GEGLU)
+        {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(round_bf16(round_bf16(sum[0][e] * ws) * ts)) * round_bf16(round_bf16(sum[1][e] * ws) * ts);
+        }
+        else
+        {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+            {
+                v[e] = round_bf16(sum[0][e] * ws) * ts;
+                if (p.bias && n + e < p.N) v[e] += bf16_bits_to_f32(p.bias[n + e]);
+            }
+        }
+        uint16_t* y = p.Y + (size_t)row * p.N + n;
+        if ((p.N & 3) == 0) *reinterpret_cast<u32x2*>(y) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        else
+        {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) y[e] = f32_to_bf16_bits(v[e]);
         }
     }
-    const int row = m * 16 + l15, n = n0 + 4 * g;
-    if (row >= p.M || n >= p.N) return;
-    const float ws = *p.w_scale, ts = p.x_scales[row];
-    float v[4];
-    if constexpr (GEGLU)
-    {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(round_bf16(round_bf16(sum[0][e] * ws) * ts)) * round_bf16(round_bf16(sum[1][e] * ws) * ts);
-    }
-    else
-    {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-        {
-            v[e] = round_bf16(sum[0][e] * ws) * ts;
-            if (p.bias && n + e < p.N) v[e] += bf16_bits_to_f32(p.bias[n + e]);
-        }
-    }
-    uint16_t* y = p.Y + (size_t)row * p.N + n;
-    if ((p.N & 3) == 0) *reinterpret_cast<u32x2*>(y) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-    else
-    {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) y[e] = f32_to_bf16_bits(v[e]);
-    }
+}
+
+template <int MG, bool GEGLU>
+static void launch_skinny_mg(const Fp8SkinnyParams& p, hipStream_t s)
+{
+    // two W row groups per workgroup where that still leaves >= 2 workgroups per CU
+    constexpr bool kTwoFits = !(GEGLU && MG == 4);       // 4 A fragments x 4 row groups of accumulators + the W pipeline do not fit 256 registers
+    if (kTwoFits && (p.N + 31) / 32 >= 2 * kNumCU) hipLaunchKernelGGL((gemm_fp8_skinny_kernel<MG, GEGLU, 2>), dim3((p.N + 31) / 32), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((gemm_fp8_skinny_kernel<MG, GEGLU, 1>), dim3((p.N + 15) / 16), dim3(512), 0, s, p);
 }
 
 template <bool GEGLU>
 static int launch_skinny(const Fp8SkinnyParams& p, hipStream_t s)
 {
-    const int groups = (p.M + 15) / 16, blocks = (p.N + 15) / 16;
-    if (groups <= 1) hipLaunchKernelGGL((gemm_fp8_skinny_kernel<1, GEGLU>), dim3(blocks), dim3(512), 0, s, p);
-    else if (groups == 2) hipLaunchKernelGGL((gemm_fp8_skinny_kernel<2, GEGLU>), dim3(blocks), dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((gemm_fp8_skinny_kernel<4, GEGLU>), dim3(blocks), dim3(512), 0, s, p);
+    const int groups = (p.M + 15) / 16;
+    if (groups <= 1) launch_skinny_mg<1, GEGLU>(p, s);
+    else if (groups == 2) launch_skinny_mg<2, GEGLU>(p, s);
+    else launch_skinny_mg<4, GEGLU>(p, s);
     MILA_LAUNCH_CHECK("gemm_fp8_skinny");
 }
 
@@ -380,7 +417,7 @@ static int launch_tail(const Fp8TailParams& p, hipStream_t s)
 
 int g_gemm_fp8_tail_form = 0;       // tuning hook (mila_cdna4_tune_gemm_fp8_tail_only): 0 = by row count, 1 = the 128-row LDS tiles for every row, 2 = skinny pieces for every row
 constexpr int kSkinnyRows = 64;     // rows one skinny launch takes
-constexpr int kSkinnyMaxTail = 255; // tails up to here run as skinny pieces (W re-streamed per piece, from the Infinity Cache where it fits)
+constexpr int kSkinnyMaxTail = 64;  // tails up to here run as ONE skinny launch; longer ones on the 128-row LDS tiles (measured: four skinny pieces of a 208-row tail cost more than two LDS tile rows)
 
 static bool use_skinny(int M) { return g_gemm_fp8_tail_form == 2 || (g_gemm_fp8_tail_form == 0 && M <= kSkinnyMaxTail); }
 
