@@ -414,6 +414,11 @@ MILA_API int mila_cdna4_advance_position(int32_t* position_dev, mila_stream_t st
 MILA_API int mila_cdna4_advance_position_snapshot(int32_t* position_dev, const int32_t* token, unsigned long long* seq_dev, unsigned long long* ring, int ring_size,
                                                   mila_stream_t stream);
 MILA_API int mila_cdna4_snapshot_token(const int32_t* token, unsigned long long* seq_dev, unsigned long long* ring, int ring_size, mila_stream_t stream);
+/* the tail of a captured greedy step in two launches instead of three: sample_argmax_fp32 whose final reduction also does *position_dev += 1 and, when ring != NULL,
+ * the publication of advance_position_snapshot (seq_dev / ring / ring_size as there; NULL / NULL / 0 = no publication).  Same token as sample_argmax_fp32. */
+MILA_API int mila_cdna4_sample_argmax_advance_fp32(const float* logits, int32_t* token_out, int vocab, void* scratch, size_t scratch_bytes,
+                                                   int32_t* position_dev, unsigned long long* seq_dev, unsigned long long* ring, int ring_size,
+                                                   mila_stream_t stream);
 
 /* One-launch decode attention for one token (B == 1): q/k/v per-head RMSNorm + RoPE + KV append (the
  * work of fused_qkv_post) folded into the flash-decode kernel's prologue, where it overlaps the first

@@ -66,11 +66,11 @@ __device__ __forceinline__ void grouped_tile(int tile, int tiles_m, int tiles_n,
 // Epilogue store of two 16-column sub-tiles (pt, pt + 1) of one output row as ONE 16-byte store per lane.  A lane (l15, g) holds columns 4 g .. 4 g + 3 of both
 // sub-tiles (a, b); v_permlane16_swap exchanges the odd lane rows of a with the even lane rows of b, after which an even-g lane holds columns 4 g .. 4 g + 7 of
 // sub-tile pt and an odd-g lane columns 4 (g - 1) .. 4 (g - 1) + 7 of sub-tile pt + 1: half the store instructions, 64 contiguous bytes per row and instruction.
-__device__ __forceinline__ void store_pair16(uint16_t* row_pt, int g, u32x2 a, u32x2 b)
+__device__ __forceinline__ void store_pair16(uint16_t* row_pt, int g, u32x2 a, u32x2 b, bool ok = true)
 {
-    const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);      // every lane takes part in the exchange; `ok` (row < M) only guards the store
     const auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-    st16(row_pt + (g & 1) * 16 + 4 * (g & ~1), u32x4{r0[0], r1[0], r0[1], r1[1]});
+    if (ok) st16(row_pt + (g & 1) * 16 + 4 * (g & ~1), u32x4{r0[0], r1[0], r0[1], r1[1]});
 }
 
 // PP (ping-pong): waves 4-7 run one barrier behind waves 0-3 and every phase has TWO barriers, [stage + fragment reads + waits] | A |
@@ -127,7 +127,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
         const bool nxt = kt_flat >= nk;
         const int kt = nxt ? kt_flat - nk : kt_flat;
         const int sm0 = nxt ? xm0 : m0, sn0 = nxt ? xn0 : n0, sw1 = nxt ? xwrow1 : wrow1;
-        const unsigned char* base = isX ? Xb + (size_t)(sm0 + half * 128) * K * ES : Wb + (size_t)(half ? sw1 : sn0) * K * ES;
+        // X rows past M (a ragged last tile-row: M % 256 != 0) re-read row M - 1 -- inside the tensor, never stored
+        const int row0 = isX ? sm0 + half * 128 : (half ? sw1 : sn0);
+        const unsigned char* base = isX ? Xb : Wb;
         unsigned char* dst_half = smem + (kt & 1) * kBufBytes + half_off(isX, half);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -138,7 +140,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
             // fp8: a lane's operand is the 32 contiguous bytes k = 32 g .. (source chunks 2 g, 2 g + 1); they are kept at the logical slots g and 4 + g the
             // bf16 fragments use, so the fragment reads are the same conflict-free pattern (read as 2 g + ks they pair up on the banks: 2-way conflicts)
             const int kslot = FP8 ? (((lslot & 3) << 1) | (lslot >> 2)) : lslot;
-            const unsigned char* src = base + (size_t)row * K * ES + (size_t)kt * 128 + kslot * 16;
+            const int grow = isX ? min(row0 + row, p.M - 1) : row0 + row;
+            const unsigned char* src = base + (size_t)grow * K * ES + (size_t)kt * 128 + kslot * 16;
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(dst_half + chunk * 1024), 16, 0, 0);
         }
     };
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
             #pragma unroll
                 for (int hb_ = 0; hb_ < 2; ++hb_)
             #pragma unroll
-                    for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15];
+                    for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[min(m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15, p.M - 1)];
             }
             auto out4 = [&](int hB, int pt, int qt, int m) -> u32x2 {
                 float v[4];
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                     for (int qt = 0; qt < 2; ++qt)
                     {
                         const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                        store_pair16(p.Y + (size_t)m * p.N + n0 + wr * 64 + pp * 16, g, out4(hB, pp, qt, m), out4(hB, pp + 1, qt, m));
+                        store_pair16(p.Y + (size_t)m * p.N + n0 + wr * 64 + pp * 16, g, out4(hB, pp, qt, m), out4(hB, pp + 1, qt, m), m < p.M);
                     }
         }
         else
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
             #pragma unroll
                 for (int hb_ = 0; hb_ < 2; ++hb_)
             #pragma unroll
-                    for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15];
+                    for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[min(m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15, p.M - 1)];
             }
             auto out4 = [&](int hA, int hB, int pt, int qt, int m, int n) -> u32x2 {
                 float v[4];
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     #ifdef MILA_GEMM_SKIP
                             if ((p.dbg & 8) && acc[hA][hB][pp][qt][0] != 12345.678f) continue;      // diagnostic: no epilogue stores (8)
     #endif
-                            store_pair16(p.Y + (size_t)m * p.N + nb, g, out4(hA, hB, pp, qt, m, nb + 4 * g), out4(hA, hB, pp + 1, qt, m, nb + 16 + 4 * g));
+                            store_pair16(p.Y + (size_t)m * p.N + nb, g, out4(hA, hB, pp, qt, m, nb + 4 * g), out4(hA, hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
                         }
         }
     };
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     const int srow = lane >> 3, sslot = lane & 7;
     // which: 0 = W rows n0 .., 1 = X rows m0 .., 2 = X rows m0 + 128 ..
     auto stage = [&](int kt, int which) {
-        const unsigned char* base = which == 0 ? Wb : Xb + (size_t)(m0 + (which - 1) * 128) * K * ES;
+        const unsigned char* base = which == 0 ? Wb : Xb;
         unsigned char* dst_half = smem + (kt % 3) * kStage3Bytes + which * kHalfBytes;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -521,6 +524,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                 if constexpr (GEGLU) { const int q = row & 63; grow = (q < 32 ? 0 : p.N - 32) + n0 + (row >> 6) * 32 + q; }   // N = F: up rows start at F
                 else grow = n0 + row;
             }
+            else grow = min(m0 + (which - 1) * 128 + row, p.M - 1);      // X rows past M (ragged last tile-row) re-read row M - 1, never stored
             const unsigned char* src = base + (size_t)grow * K * ES + (size_t)kt * 128 + kslot * 16;
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(dst_half + chunk * 1024), 16, 0, 0);
         }
@@ -650,7 +654,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
         #pragma unroll
             for (int hb_ = 0; hb_ < 2; ++hb_)
         #pragma unroll
-                for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15];
+                for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[min(m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15, p.M - 1)];
         }
         auto out4 = [&](int hB, int pt, int qt, int m) -> u32x2 {
             float v[4];
@@ -674,7 +678,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             for (int qt = 0; qt < 2; ++qt)
             {
                 const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                store_pair16(p.Y + (size_t)m * p.N + n0 + wr * 32, g, out4(hB, 0, qt, m), out4(hB, 1, qt, m));
+                store_pair16(p.Y + (size_t)m * p.N + n0 + wr * 32, g, out4(hB, 0, qt, m), out4(hB, 1, qt, m), m < p.M);
             }
         return;
     }
@@ -687,7 +691,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     #pragma unroll
         for (int hb_ = 0; hb_ < 2; ++hb_)
     #pragma unroll
-            for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15];
+            for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[min(m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15, p.M - 1)];
     }
     auto out4 = [&](int hB, int pt, int qt, int m, int n) -> u32x2 {
         float v[4];
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             {
                 const int nb = n0 + wr * 64 + pp * 16;
                 const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                store_pair16(p.Y + (size_t)m * p.N + nb, g, out4(hB, pp, qt, m, nb + 4 * g), out4(hB, pp + 1, qt, m, nb + 16 + 4 * g));
+                store_pair16(p.Y + (size_t)m * p.N + nb, g, out4(hB, pp, qt, m, nb + 4 * g), out4(hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
             }
 }
 
@@ -847,63 +851,70 @@ int gemm_fp8_kernel_for(int M, int K, int N)
     if (gemm256_applicable(M, K, N)) return 2;
     return 0;
 }
-// gemm_fp8_tail.hip: the same arithmetic for any row count (masked 128-row tiles, register-staged)
+// gemm_fp8_tail.hip: the same arithmetic for any row count (masked 128-row tiles; skinny weight streaming for <= 64 rows)
 int launch_gemm_fp8_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
                          int M, int K, int N, hipStream_t s);
 int launch_gemm_fp8_geglu_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
                                hipStream_t s);
-
-// Ragged row counts, as launch_bf16_rows splits them (gemm.hip): the LDS-DMA kernels take the leading multiple of 256 rows when one serves
-// that many, the tail kernel the rest (or everything).  Rows are independent and both kernels run the same instruction chain per output
-// element, so a row's bits do not depend on where the split falls -- the fp4 policy's prefill is W4A8 for EVERY M > 1 (CudaLinearOp.ixx:646-715).
 int g_gemm_fp8_tail_only = 0;      // tuning hook (mila_cdna4_tune_gemm_fp8_tail_only): != 0: every row through the tail kernels (gemm_fp8_tail.hip: g_gemm_fp8_tail_form picks which)
-static int fp8_main_rows(int M, int K, int N, int* which)
+
+// Row counts of any kind (the fp4 policy's prefill is W4A8 for EVERY M > 1, CudaLinearOp.ixx:646-715):
+//   M >= 256 and N % 128 == 0, K % 128 == 0: the LDS-DMA kernels over ceil(M / 256) tile-rows -- a ragged last tile-row stages row M - 1 for the rows past M
+//     and masks its stores (a 208-row tail costs one tile-row, 1/8 of a T = 2048 chunk; on the masked 128-row tiles it cost 40 % of the chunk) -- except that a
+//     tail of <= 64 rows goes to the skinny weight-streaming kernel instead (a 1-row tail: +11 % of the chunk instead of +12.5 %, and no MFMA work on padding);
+//   everything else: the tail kernels of gemm_fp8_tail.hip alone.
+// Rows are independent and the LDS-DMA kernels and the masked tiles run the same instruction chain per output element.
+constexpr int kSkinnyTailRows = 64;
+static int fp8_big_rows(int M, int K, int N_mult)      // rows the LDS-DMA kernels take (0 = none); N_mult: the column granularity the form needs (128, or 64 for 256 x 128 GeGLU)
 {
-    *which = 0;
-    if (g_gemm_fp8_tail_only) return 0;
-    *which = gemm_fp8_kernel_for(M, K, N);
-    if (*which) return M;
-    const int main_rows = M - M % 256;
-    if (main_rows >= 512 && (*which = gemm_fp8_kernel_for(main_rows, K, N)) != 0) return main_rows;
-    return 0;
+    if (g_gemm_fp8_tail_only || M < 256 || K % 128 != 0 || N_mult == 0) return 0;
+    const int tail = M % 256;
+    return (tail > 0 && tail <= kSkinnyTailRows) ? M - tail : M;
 }
-static bool fp8_geglu_big(int M, int K, int F) { return K % 128 == 0 && gemm256_geglu_applicable(M, K, F); }
+// which LDS-DMA kernel: 2 = 256 x 256 (enough tiles for the chip, N % 256 == 0), 1 = 256 x 128
+static int fp8_pick(int rows, int N)
+{
+    const int tm = (rows + 255) / 256;
+    if (N % 256 == 0 && tm * (N / 256) >= 200) return 2;
+    return 1;
+}
 
 // Y[M, F] = GeGLU of the W4A8 Linear over W8 = [gate rows | up rows] (2F x K e4m3)
 int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
                           hipStream_t s)
 {
-    int main_rows = (!g_gemm_fp8_tail_only && fp8_geglu_big(M, K, F)) ? M : 0;
-    if (!g_gemm_fp8_tail_only && !main_rows && M - M % 256 >= 512 && fp8_geglu_big(M - M % 256, K, F)) main_rows = M - M % 256;
-    if (main_rows)
+    const bool form256 = F % 128 == 0 && ((M + 255) / 256) * (F / 128) >= 200;
+    const int rows = fp8_big_rows(M, K, form256 ? 128 : (F % 64 == 0 ? 64 : 0));
+    if (rows)
     {
         int rc;
-        if (F % 64 == 0 && gemm256x128_applicable(main_rows, K, 2 * F) && !(g_gemm_pingpong >= 4 && gemm256_geglu_applicable(main_rows, K, F)))
+        const int tm = (rows + 255) / 256;
+        if (!form256)
         {
-            Gemm256Params q{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, main_rows, K, F, main_rows / 256, F / 64, x_scales, w_scale};
+            Gemm256Params q{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, rows, K, F, tm, F / 64, x_scales, w_scale};
             rc = launch_gemm256x128_t<true, true>(q, s);
         }
         else
         {
-            Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, main_rows, K, F, main_rows / 256, F / 128, x_scales, w_scale};
+            Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, rows, K, F, tm, F / 128, x_scales, w_scale};
             rc = launch_gemm256_t<G_FP8_GEGLU>(p, s);
         }
-        if (rc || main_rows == M) return rc;
+        if (rc || rows == M) return rc;
     }
-    return launch_gemm_fp8_geglu_tail(Y + (size_t)main_rows * F, X8 + (size_t)main_rows * K, W8, x_scales + main_rows, w_scale, M - main_rows, K, F, s);
+    return launch_gemm_fp8_geglu_tail(Y + (size_t)rows * F, X8 + (size_t)rows * K, W8, x_scales + rows, w_scale, M - rows, K, F, s);
 }
 int launch_gemm_fp8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
                     int M, int K, int N, hipStream_t s)
 {
-    int which;
-    const int main_rows = fp8_main_rows(M, K, N, &which);
-    if (main_rows)
+    const int rows = fp8_big_rows(M, K, N % 128 == 0 ? 128 : 0);
+    if (rows)
     {
-        Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), bias, main_rows, K, N, main_rows / 256,
-                        which == 2 ? N / 256 : N / 128, x_scales, w_scale};
+        const int which = fp8_pick(rows, N), tm = (rows + 255) / 256;
+        Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), bias, rows, K, N, tm, which == 2 ? N / 256 : N / 128, x_scales, w_scale};
         const int rc = which == 2 ? launch_gemm256_t<G_FP8>(p, s) : launch_gemm256x128_t<true>(p, s);
-        if (rc || main_rows == M) return rc;
+        if (rc || rows == M) return rc;
     }
-    return launch_gemm_fp8_tail(Y + (size_t)main_rows * N, X8 + (size_t)main_rows * K, W8, x_scales + main_rows, w_scale, bias, M - main_rows, K, N, s);
+    return launch_gemm_fp8_tail(Y + (size_t)rows * N, X8 + (size_t)rows * K, W8, x_scales + rows, w_scale, bias, M - rows, K, N, s);
 }
+
 }  // namespace mila

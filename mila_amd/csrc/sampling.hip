@@ -69,6 +69,35 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restri
     }
 }
 
+// the last node of a captured decode step: the final reduction of the greedy sampler, the position bump of the next step and (ring != NULL) the publication
+// of the sampled token to the host -- what argmax_final + advance_position[_snapshot] did in two launches (round 3: one launch fewer per token)
+__global__ __launch_bounds__(256) void argmax_final_advance_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int n, int32_t* __restrict__ token_out,
+                                                                   int32_t* __restrict__ pos, unsigned long long* seq_dev, unsigned long long* ring, int ring_size)
+{
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    float bv = -FLT_MAX;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 256) better(bv, bi, pv[i], pi[i]);
+    wave_argmax(bv, bi);
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) better(bv, bi, sv[w], si[w]);
+        const int tok = (bi == 0x7fffffff) ? 0 : bi;
+        token_out[0] = tok;
+        *pos += 1;
+        if (ring != nullptr)
+        {
+            const unsigned long long seq = *seq_dev + 1ull;
+            *seq_dev = seq;
+            __hip_atomic_store(ring + (seq % (unsigned long long)ring_size), (seq << 32) | (unsigned long long)(uint32_t)tok, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 template <typename T>
 static int run_argmax(const T* logits, int32_t* token_out, int vocab, void* scratch, size_t scratch_bytes, hipStream_t s, const char* who)
 {
@@ -377,6 +406,25 @@ int mila_cdna4_sample_argmax_fp32(const float* logits, int32_t* token_out, int v
                                   mila_stream_t stream)
 {
     return run_argmax<float>(logits, token_out, vocab, scratch, scratch_bytes, as_stream(stream), "sample_argmax_fp32");
+}
+
+int mila_cdna4_sample_argmax_advance_fp32(const float* logits, int32_t* token_out, int vocab, void* scratch, size_t scratch_bytes, int32_t* position_dev,
+                                          unsigned long long* seq_dev, unsigned long long* ring, int ring_size, mila_stream_t stream)
+{
+    MILA_REQUIRE(logits && token_out && position_dev, "sample_argmax_advance_fp32: null pointer");
+    MILA_REQUIRE(vocab > 0, "sample_argmax_advance_fp32: vocab must be positive");
+    MILA_REQUIRE((ring == nullptr) == (seq_dev == nullptr) && (ring == nullptr || ring_size > 0), "sample_argmax_advance_fp32: ring, seq_dev and ring_size go together");
+    const size_t need = (size_t)kArgmaxBlocks * 8;
+    if (!scratch || scratch_bytes < need) return set_error(MILA_E_SCRATCH_TOO_SMALL, "sample_argmax_advance_fp32: scratch %zu bytes < required %zu", scratch_bytes, need);
+    float* pv = reinterpret_cast<float*>(scratch);
+    int* pi = reinterpret_cast<int*>(pv + kArgmaxBlocks);
+    int blocks = (vocab + 255) / 256;
+    if (blocks > kArgmaxBlocks) blocks = kArgmaxBlocks;
+    hipLaunchKernelGGL(argmax_partial_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), logits, pv, pi, vocab);
+    int rc = check_hip(hipGetLastError(), "sample_argmax_advance_fp32");
+    if (rc) return rc;
+    hipLaunchKernelGGL(argmax_final_advance_kernel, dim3(1), dim3(256), 0, as_stream(stream), pv, pi, blocks, token_out, position_dev, seq_dev, ring, ring_size);
+    MILA_LAUNCH_CHECK("sample_argmax_advance_fp32");
 }
 
 int mila_cdna4_sample_argmax_bf16(const uint16_t* logits, int32_t* token_out, int vocab, void* scratch, size_t scratch_bytes,

@@ -216,9 +216,11 @@ namespace Mila::Dnn
             try
             {
                 enqueueFusedStep( token.data(), 0, pos_dev_->data() );
-                if ( sample_in_graph_ ) sampleGreedy( const_cast<TokenTensor&>( token ) );   // feeds the next replay
-                if ( sample_in_graph_ && token_ring_ )
-                    Compute::rocmCheck( mila_cdna4_advance_position_snapshot( pos_dev_->data(), token.data(), token_seq_, token_ring_, token_ring_size_, ctx_->getStream() ) );
+                if ( sample_in_graph_ )
+                    // greedy sampler (feeds the next replay) + position bump + publication of the token: the sampler's final reduction does all three
+                    Compute::rocmCheck( mila_cdna4_sample_argmax_advance_fp32( logits_->data(), const_cast<TokenTensor&>( token ).data(), (int)cfg_.vocab_size, sample_scratch_->data(),
+                                                                               sample_scratch_->sizeInBytes(), pos_dev_->data(), token_ring_ ? token_seq_ : nullptr, token_ring_,
+                                                                               token_ring_ ? token_ring_size_ : 0, ctx_->getStream() ) );
                 else
                     Compute::rocmCheck( mila_cdna4_advance_position( pos_dev_->data(), ctx_->getStream() ) );
             }

@@ -98,12 +98,18 @@ def test_prefill_then_decode_matches_token_by_token_decode(policy):
     # and the prefill logits agree with the oracle composition of the arithmetic that ran
     ref = RefGemma(SMALL, pol, seed=3, w4a8_prefill=w4a8, staged_prefill=(policy == "fp4"))
     exp = ref.forward(TOKENS[:T], 0, MAX_SEQ)
-    assert np.abs(lp - exp).max() <= bar * np.abs(exp).max()
     if w4a8:
-        # one decode step on the caches the W4A8 prefill wrote, against the oracle continuing its own W4A8 history
-        exp1 = ref.forward([TOKENS[T]], T, MAX_SEQ)
+        # unit-scale random weights amplify a difference ~1.4x per block, and under W4A8 a 1-ulp bf16 difference in an activation is a 6 % e4m3 step: two correct
+        # implementations sit at 0.1-0.2 of the logit range here (measured 0.14; the conditioned models of test_gemma_conditioned_gpu.py /
+        # test_gemma_fullwidth_gpu.py hold the same path to 3e-3 / 1e-3) -- this leg only guards against a wrong ARITHMETIC (W4A16 instead of W4A8 sits at ~0.5)
+        bar = 2.5e-1
+        assert np.abs(lp - exp).max() <= bar * np.abs(exp).max()
+        assert float(np.dot(lp, exp) / (np.linalg.norm(lp) * np.linalg.norm(exp))) > 0.97
+        exp1 = ref.forward([TOKENS[T]], T, MAX_SEQ)     # one decode step on the caches the W4A8 prefill wrote, against the oracle continuing its own W4A8 history
         l1 = a.decode(TOKENS[T], T, "fused")
-        assert np.abs(l1 - exp1).max() <= 2 * bar * np.abs(exp1).max()
+        assert np.abs(l1 - exp1).max() <= bar * np.abs(exp1).max()
+    else:
+        assert np.abs(lp - exp).max() <= bar * np.abs(exp).max()
     a.close()
     b.close()
 

@@ -545,7 +545,7 @@ def _w4a8_operands(rng, M, K, N, G=128):
 def test_w4a8_serves_every_row_count_like_the_reference(M, K, N, bias, G):
     """CudaLinearOp.ixx:646-715 runs W4A8 for EVERY M > 1; here the LDS-DMA fp8 kernels take the leading multiple of 256 rows and the masked 128-row
     kernel (csrc/gemm_fp8_tail.hip) the rest, or all of them: gemm_fp8_applicable is true at M in {2, 16, 2000, 2049, ...}, sampled rows of both parts are
-    within 2 ulp of the restated reference; tails up to 255 rows run as skinny weight-streaming pieces, longer ones on masked 128-row LDS tiles"""
+    within 2 ulp of the restated reference; a ragged last tile-row runs masked inside the LDS-DMA kernels, tails of <= 64 rows on the skinny weight-streaming kernel"""
     lib = capi.load()
     assert lib.mila_cdna4_gemm_fp8_applicable(M, K, N) == 1
     rng = np.random.default_rng(M * 7 + N)
@@ -581,13 +581,15 @@ def test_w4a8_serves_every_row_count_like_the_reference(M, K, N, bias, G):
             capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(0))
         forms[form] = bits(Yf)
         assert_bf16_close(forms[form][rows], exp, 2, 1e-3 * float(np.abs(exp).max()), "fp8 GEMM, tail form %d, vs restated reference" % form)
-    main_served = main if (main >= 512 and K % 128 == 0 and lib.mila_cdna4_gemm_staging_bytes(main, K, N) != 0) else 0      # the same grid rule serves bf16 and fp8
-    if main_served:
-        assert np.array_equal(forms[1][:main_served], bits(Y)[:main_served]), "the masked LDS-tile kernel and the LDS-DMA fp8 kernels differ"
-    if M - main_served > 255:
-        assert np.array_equal(forms[1][main_served:], bits(Y)[main_served:])        # tails beyond 255 rows run the LDS tiles by default
+    # who serves which rows by default (csrc/gemm256.hip: launch_gemm_fp8): with M >= 256 (and K % 128 == N % 128 == 0) the LDS-DMA kernels take every tile-row,
+    # a ragged last one masked -- unless the tail is <= 64 rows, which goes to the skinny kernel; below 256 rows: skinny up to 64, masked LDS tiles beyond
+    tail = M % 256
+    big = 0 if (M < 256 or K % 128 or N % 128) else (M - tail if 0 < tail <= 64 else M)
+    assert np.array_equal(forms[1][:big], bits(Y)[:big]), "the masked LDS-tile kernel and the LDS-DMA fp8 kernels differ"
+    if M - big > 64:
+        assert np.array_equal(forms[1][big:], bits(Y)[big:])
     else:
-        assert np.array_equal(forms[2][main_served:], bits(Y)[main_served:])        # ... shorter ones the skinny pieces
+        assert np.array_equal(forms[2][big:], bits(Y)[big:])
     a, b = orc.from_bf16_bits(forms[1]).astype(np.float64), orc.from_bf16_bits(forms[2]).astype(np.float64)
     assert np.abs(a - b).max() <= 2.0 ** -6 * np.abs(a).max(), "the two tail forms differ by more than rounding"
 

@@ -245,6 +245,17 @@ def test_greedy_sampler_argmax_ties_to_lowest_index(V):
     xb = orc.to_bf16_bits(x)
     capi.call("sample_argmax_bf16", dev_u16(xb), tok, V, scratch, C.c_size_t(nb))
     assert int(host(tok)[0]) == int(np.argmax(orc.from_bf16_bits(xb)))
+    # the captured step's tail in one launch fewer: the same token, the position bumped, the token published as sequence << 32 | token
+    tok2, pos = dev_i32(np.array([-1])), dev_i32(np.array([41]))
+    seq = torch.tensor([6], dtype=torch.int64, device="cuda")
+    ring = torch.zeros(8, dtype=torch.int64, device="cuda")
+    capi.call("sample_argmax_advance_fp32", dev_f32(x), tok2, V, scratch, C.c_size_t(nb), pos, seq, ring, 8)
+    assert int(host(tok2)[0]) == int(np.argmax(x)) and int(host(pos)[0]) == 42 and int(seq.item()) == 7
+    assert int(ring[7].item()) == (7 << 32) | int(np.argmax(x)) and int(ring.abs().sum().item()) == int(ring[7].item())
+    capi.call("sample_argmax_advance_fp32", dev_f32(x), tok2, V, scratch, C.c_size_t(nb), pos, None, None, 0)      # no ring: token + position only
+    assert int(host(pos)[0]) == 43 and int(seq.item()) == 7
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("sample_argmax_advance_fp32", dev_f32(x), tok2, V, scratch, C.c_size_t(nb), pos, seq, None, 0)
 
 
 def _sample_gpu(logits, softcap, t, k, p, r, bf16=False):
