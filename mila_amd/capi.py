@@ -171,9 +171,11 @@ INTERNAL = [
     "decode_chain_scratch_bytes", "decode_chain_init", "decode_chain_status", "decode_chain",
     "decode_engine_scratch_bytes", "decode_engine_init", "decode_engine_status", "decode_engine_applicable", "decode_engine",
     "attn_decode_ticket_count", "fused_attn_decode_onepass_bf16", "prefetch_l3", "fused_attn_decode_ex",
+    "exp_gemm4w_bf16", "exp_gemm4w_geglu_bf16",
 ]
 # ... of which these live in libmila_cdna4_experiments.so
 EXPERIMENTS_LIB = [
     "decode_chain_scratch_bytes", "decode_chain_init", "decode_chain_status", "decode_chain",
     "decode_engine_scratch_bytes", "decode_engine_init", "decode_engine_status", "decode_engine_applicable", "decode_engine", "decode_engine_debug",
+    "exp_gemm4w_bf16", "exp_gemm4w_geglu_bf16",
 ]

@@ -1,3 +1,9 @@
+// EXPERIMENT (round 3), MEASURED SLOWER than the eight-wave ping-pong kernel it was meant to replace: 942-1147 TFLOP/s against 1214-1358 on the Gemma shapes
+// (M 2048; N 8192 / 30720, K 1920 .. 7680; profiles/r03_gemm4w.txt), bit-identical results.  The K-tile slope went from 1.55 to 1.75 us: with ONE wave per SIMD
+// every LDS-DMA request (16 per wave and K-tile, ~60 issue cycles each) and every ds_read stalls that SIMD's only MFMA stream, where the eight-wave form
+// hides them under the partner wave's MFMAs; and hipcc spends 56 v_accvgpr copies per K-tile keeping 256 accumulators in 256 AGPRs.  Kept in
+// libmila_cdna4_experiments.so (mila_cdna4_exp_gemm4w_bf16 / _geglu_bf16; tools/bench_gemm4w.py); the product does not use it.
+//
 // bf16 GEMM, 256 x 256 x 64 tile, FOUR waves -- one per SIMD, each owning 128 x 128 of the tile -- instead of the eight of gemm256.hip.
 //   Y[M,N] = X[M,K] * W[N,K]^T (+ bias)  /  GeGLU form,   M % 256 == 0, N % 256 == 0 (GeGLU: F % 128), K % 64 == 0.
 //
@@ -18,7 +24,8 @@
 // gate and up of an output meet in one lane.
 #include <type_traits>
 
-#include "common.h"
+#include "../common.h"
+#include "../internal.h"
 
 // MILA_G4W_DIRECTIVES: pin the MFMA / DS-read / LDS-DMA interleave with sched_group_barrier.  Off by default: with 256 accumulator registers (every AGPR) the
 // directive form makes hipcc (ROCm 7.2) rotate accumulators through v_accvgpr copies -- hundreds of vector-ALU instructions per K-tile.
@@ -264,3 +271,23 @@ int launch_gemm4w_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M
 }
 
 }  // namespace mila
+
+extern "C" {
+
+int mila_cdna4_exp_gemm4w_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X && W, "exp_gemm4w_bf16: null pointer");
+    MILA_REQUIRE(M > 0 && M % 256 == 0 && N > 0 && N % 256 == 0 && K > 0 && K % 64 == 0, "exp_gemm4w_bf16: M, N multiples of 256 and K a multiple of 64 (%d, %d, %d)", M, N, K);
+    MILA_REQUIRE(mila::gemm4w_addressable(M, K, N), "exp_gemm4w_bf16: operands beyond 2 GiB");
+    return mila::launch_gemm4w(Y, X, W, bias, M, K, N, mila::as_stream(stream));
+}
+
+int mila_cdna4_exp_gemm4w_geglu_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X && W, "exp_gemm4w_geglu_bf16: null pointer");
+    MILA_REQUIRE(M > 0 && M % 256 == 0 && F > 0 && F % 128 == 0 && K > 0 && K % 64 == 0, "exp_gemm4w_geglu_bf16: M a multiple of 256, F of 128, K of 64 (%d, %d, %d)", M, F, K);
+    MILA_REQUIRE(mila::gemm4w_addressable(M, K, 2 * F), "exp_gemm4w_geglu_bf16: operands beyond 2 GiB");
+    return mila::launch_gemm4w_geglu(Y, X, W, M, K, F, mila::as_stream(stream));
+}
+
+}  // extern "C"

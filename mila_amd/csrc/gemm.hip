@@ -273,7 +273,6 @@ int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int 
 static int g_gemm_force128 = 0;
 extern int g_gemm_pingpong;     // gemm256.hip
 extern int g_gemm_persistent;
-extern int g_gemm_four_wave;
 extern int g_gemm_fp8_tail_only;
 extern int g_gemm_fp8_tail_form;      // gemm_fp8_tail.hip
 
@@ -408,8 +407,7 @@ int mila_cdna4_tune_gemm_schedule(int pingpong)
 {
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
     g_gemm_persistent = pingpong != 6;
-    g_gemm_four_wave = pingpong == 7;
-    g_gemm_pingpong = (pingpong == 6 || pingpong == 7) ? 5 : pingpong;
+    g_gemm_pingpong = pingpong == 6 ? 5 : pingpong;
     return MILA_OK;
 }
 

@@ -121,28 +121,52 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
 
     // ---- staging: half-tile (isX, half) of K-tile kt into buffer kt & 1 ----
+    // `buffer_load_dwordx4 ... lds` with the K-tile (and, for W, the tile's first row) in the SCALAR offset: a lane's two byte offsets per operand are computed once per
+    // tile, so a staging request costs no vector ALU work.  (Round 3: the global_load_lds form recomputed a 64-bit address per request -- two v_mul_lo_u32, a
+    // v_mad_u64_u32 and five more vector instructions in front of each of the 16 requests of a K-tile, ~500 issue cycles per wave and K-tile inside the very
+    // phases that must fit under the partner wave's 512 MFMA cycles; profiles/r03_ksweep.txt: the K loop ran at 1.5 us per K-tile where the MFMAs need 1.0.)
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Xb), 0, 0x7fffffff, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Wb), 0, 0x7fffffff, 0x00020000);
     const int srow = lane >> 3, sslot = lane & 7;          // this lane's row within a 1 KiB chunk / 16-byte slot
+    const int rowbytes = K * ES;
+    int voffW[2], voffX[2][2], voffXn[2][2];               // W: relative to the half-tile's first row; X: absolute (rows past M re-read row M - 1: a ragged last tile-row)
+    auto x_offsets = [&](int (&vo)[2][2], int mm0) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+            {
+                const int row = (i * 8 + wave) * 8 + srow;
+                const int lslot = sslot ^ ((row >> 1) & 7);
+                const int kslot = FP8 ? (((lslot & 3) << 1) | (lslot >> 2)) : lslot;
+                vo[half][i] = min(mm0 + half * 128 + row, p.M - 1) * rowbytes + kslot * 16;
+            }
+    };
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+    {
+        const int row = (i * 8 + wave) * 8 + srow;             // chunk i * 8 + wave: 16 chunks of 8 rows
+        const int lslot = sslot ^ ((row >> 1) & 7);            // swizzle on the source address: LDS slot sslot of this row holds logical slot lslot
+        // fp8: a lane's operand is the 32 contiguous bytes k = 32 g .. (source chunks 2 g, 2 g + 1); they are kept at the logical slots g and 4 + g the
+        // bf16 fragments use, so the fragment reads are the same conflict-free pattern (read as 2 g + ks they pair up on the banks: 2-way conflicts)
+        const int kslot = FP8 ? (((lslot & 3) << 1) | (lslot >> 2)) : lslot;
+        voffW[i] = row * rowbytes + kslot * 16;
+    }
+    x_offsets(voffX, m0);
     auto stage = [&](int kt_flat, bool isX, int half) {
         // persistent form: K-tile nk + k is K-tile k of the workgroup's NEXT tile (nk is even there, so the buffer parity runs on)
         const bool nxt = kt_flat >= nk;
         const int kt = nxt ? kt_flat - nk : kt_flat;
-        const int sm0 = nxt ? xm0 : m0, sn0 = nxt ? xn0 : n0, sw1 = nxt ? xwrow1 : wrow1;
-        // X rows past M (a ragged last tile-row: M % 256 != 0) re-read row M - 1 -- inside the tensor, never stored
-        const int row0 = isX ? sm0 + half * 128 : (half ? sw1 : sn0);
-        const unsigned char* base = isX ? Xb : Wb;
         unsigned char* dst_half = smem + (kt & 1) * kBufBytes + half_off(isX, half);
+        const int wrow = nxt ? (half ? xwrow1 : xn0) : (half ? wrow1 : n0);
+        const int soff = __builtin_amdgcn_readfirstlane(isX ? kt * 128 : wrow * rowbytes + kt * 128);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
         {
-            const int chunk = i * 8 + wave;                // 16 chunks of 8 rows
-            const int row = chunk * 8 + srow;              // row within the half-tile
-            const int lslot = sslot ^ ((row >> 1) & 7);    // swizzle on the source address: LDS slot sslot of this row holds logical slot lslot
-            // fp8: a lane's operand is the 32 contiguous bytes k = 32 g .. (source chunks 2 g, 2 g + 1); they are kept at the logical slots g and 4 + g the
-            // bf16 fragments use, so the fragment reads are the same conflict-free pattern (read as 2 g + ks they pair up on the banks: 2-way conflicts)
-            const int kslot = FP8 ? (((lslot & 3) << 1) | (lslot >> 2)) : lslot;
-            const int grow = isX ? min(row0 + row, p.M - 1) : row0 + row;
-            const unsigned char* src = base + (size_t)grow * K * ES + (size_t)kt * 128 + kslot * 16;
-            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(dst_half + chunk * 1024), 16, 0, 0);
+            const int chunk = i * 8 + wave;
+            if (isX) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(dst_half + chunk * 1024), 16, nxt ? voffXn[half][i] : voffX[half][i], soff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(dst_half + chunk * 1024), 16, voffW[i], soff, 0, 0);
         }
     };
 
@@ -353,7 +377,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
         for (int j = 0; j < my_tiles; ++j)
         {
             const bool has_next = j + 1 < my_tiles;
-            if (has_next) tile_origin(blockIdx.x + (j + 1) * gridDim.x, xm0, xn0, xwrow1);
+            if (has_next) { tile_origin(blockIdx.x + (j + 1) * gridDim.x, xm0, xn0, xwrow1); x_offsets(voffXn, xm0); }
             for (int t = 0; t < nk; ++t)
             {
                 const bool steady = (t + 2 < nk) || has_next;
@@ -383,6 +407,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
             if (has_next)
             {
                 m0 = xm0; n0 = xn0; wrow1 = xwrow1;
+#pragma unroll
+                for (int h_ = 0; h_ < 2; ++h_)
+#pragma unroll
+                    for (int i_ = 0; i_ < 2; ++i_) voffX[h_][i_] = voffXn[h_][i_];
                 zero_acc();
             }
         }
@@ -507,26 +535,38 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
 
     const int srow = lane >> 3, sslot = lane & 7;
-    // which: 0 = W rows n0 .., 1 = X rows m0 .., 2 = X rows m0 + 128 ..
-    auto stage = [&](int kt, int which) {
-        const unsigned char* base = which == 0 ? Wb : Xb;
-        unsigned char* dst_half = smem + (kt % 3) * kStage3Bytes + which * kHalfBytes;
+    // which: 0 = W rows n0 .., 1 = X rows m0 .., 2 = X rows m0 + 128 ..   `buffer_load ... lds`, per-lane offsets computed once (see gemm256_kernel)
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Xb), 0, 0x7fffffff, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Wb), 0, 0x7fffffff, 0x00020000);
+    const int rowbytes = K * ES;
+    int voff[3][2];
+#pragma unroll
+    for (int which = 0; which < 3; ++which)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
         {
-            const int chunk = i * 8 + wave;
-            const int row = chunk * 8 + srow;
+            const int row = (i * 8 + wave) * 8 + srow;
             const int lslot = sslot ^ ((row >> 1) & 7);
             const int kslot = FP8 ? (((lslot & 3) << 1) | (lslot >> 2)) : lslot;      // as in gemm256_kernel
-            int grow = row;                                   // global row of `base`
+            int grow;
             if (which == 0)
             {
                 if constexpr (GEGLU) { const int q = row & 63; grow = (q < 32 ? 0 : p.N - 32) + n0 + (row >> 6) * 32 + q; }   // N = F: up rows start at F
                 else grow = n0 + row;
             }
             else grow = min(m0 + (which - 1) * 128 + row, p.M - 1);      // X rows past M (ragged last tile-row) re-read row M - 1, never stored
-            const unsigned char* src = base + (size_t)grow * K * ES + (size_t)kt * 128 + kslot * 16;
-            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(dst_half + chunk * 1024), 16, 0, 0);
+            voff[which][i] = grow * rowbytes + kslot * 16;
+        }
+    auto stage = [&](int kt, int which) {
+        unsigned char* dst_half = smem + (kt % 3) * kStage3Bytes + which * kHalfBytes;
+        const int soff = __builtin_amdgcn_readfirstlane(kt * 128);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+        {
+            const int chunk = i * 8 + wave;
+            if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(dst_half + chunk * 1024), 16, voff[0][i], soff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(dst_half + chunk * 1024), 16, voff[which][i], soff, 0, 0);
         }
     };
     auto stage_all = [&](int kt) { stage(kt, 0); stage(kt, 1); stage(kt, 2); };
@@ -727,10 +767,13 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             }
 }
 
+// the LDS-DMA kernels address their operands through 32-bit buffer offsets (bytes, signed int arithmetic): both tensors must stay below 2 GiB
+static bool lds_dma_addressable(int M, int K, int w_rows) { return (int64_t)M * K * 2 < 0x7fffffffll && (int64_t)w_rows * K * 2 < 0x7fffffffll; }
+
 // taken when the 256 x 256 grid does not apply and the 256 x 128 grid fills most of one round of CUs (or several)
 bool gemm256x128_applicable(int M, int K, int N)
 {
-    if (M % 256 != 0 || N % 128 != 0 || K % 64 != 0) return false;
+    if (M % 256 != 0 || N % 128 != 0 || K % 64 != 0 || !lds_dma_addressable(M, K, N)) return false;
     const int tiles = (M / 256) * (N / 128);
     const int rounds = (tiles + kNumCU - 1) / kNumCU;
     return tiles >= 160 && tiles >= 0.70 * rounds * kNumCU;      // (192 tiles -- GPT-2's 768-wide projections at B T = 8192 -- beat the 128-tile kernel's 384: 18 / 51 vs 29 / 74 us)
@@ -767,7 +810,7 @@ int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const 
 // one 512-thread workgroup per CU: worth it only when the tile count fills whole rounds of 256 CUs
 bool gemm256_applicable(int M, int K, int N)
 {
-    if (M % 256 != 0 || N % 256 != 0 || K % 64 != 0) return false;
+    if (M % 256 != 0 || N % 256 != 0 || K % 64 != 0 || !lds_dma_addressable(M, K, N)) return false;
     const int tiles = (M / 256) * (N / 256);
     const int rounds = (tiles + kNumCU - 1) / kNumCU;
     return tiles >= 200 && tiles >= 0.85 * rounds * kNumCU;
@@ -812,15 +855,8 @@ static int launch_gemm256_t(const Gemm256Params& p, hipStream_t s)
     return g_gemm_pingpong ? launch_gemm256_tt<MODE, 1>(p, s) : launch_gemm256_tt<MODE, 0>(p, s);
 }
 
-// gemm4w.hip: the same tile on four waves (one per SIMD, 128 x 128 each), bit-identical results
-int launch_gemm4w(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s);
-int launch_gemm4w_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s);
-bool gemm4w_addressable(int M, int K, int N_rows_of_W);
-int g_gemm_four_wave = 0;     // tuning hook (mila_cdna4_tune_gemm_schedule(7)): bf16 256 x 256 shapes on the four-wave kernel
-
 int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
 {
-    if (g_gemm_four_wave && gemm4w_addressable(M, K, N)) return launch_gemm4w(Y, X, W, bias, M, K, N, s);
     Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, N / 256, nullptr, nullptr};
     return launch_gemm256_t<G_PLAIN>(p, s);
 }
@@ -828,14 +864,13 @@ int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint
 // Y[M, F] = GeGLU(X W^T), W = [gate rows 0 .. F-1 | up rows F .. 2F-1]
 bool gemm256_geglu_applicable(int M, int K, int F)
 {
-    if (M % 256 != 0 || F % 128 != 0 || K % 64 != 0) return false;
+    if (M % 256 != 0 || F % 128 != 0 || K % 64 != 0 || !lds_dma_addressable(M, K, 2 * F)) return false;
     const int tiles = (M / 256) * (F / 128);
     const int rounds = (tiles + kNumCU - 1) / kNumCU;
     return tiles >= 200 && tiles >= 0.85 * rounds * kNumCU;
 }
 int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s)
 {
-    if (g_gemm_four_wave && gemm4w_addressable(M, K, 2 * F)) return launch_gemm4w_geglu(Y, X, W, M, K, F, s);
     Gemm256Params p{Y, X, W, nullptr, M, K, F, M / 256, F / 128, nullptr, nullptr};
     return launch_gemm256_t<G_GEGLU>(p, s);
 }
@@ -859,15 +894,16 @@ int launch_gemm_fp8_geglu_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8
 int g_gemm_fp8_tail_only = 0;      // tuning hook (mila_cdna4_tune_gemm_fp8_tail_only): != 0: every row through the tail kernels (gemm_fp8_tail.hip: g_gemm_fp8_tail_form picks which)
 
 // Row counts of any kind (the fp4 policy's prefill is W4A8 for EVERY M > 1, CudaLinearOp.ixx:646-715):
-//   M >= 256 and N % 128 == 0, K % 128 == 0: the LDS-DMA kernels over ceil(M / 256) tile-rows -- a ragged last tile-row stages row M - 1 for the rows past M
+//   M >= 512 and N % 128 == 0, K % 128 == 0: the LDS-DMA kernels over ceil(M / 256) tile-rows -- a ragged last tile-row stages row M - 1 for the rows past M
 //     and masks its stores (a 208-row tail costs one tile-row, 1/8 of a T = 2048 chunk; on the masked 128-row tiles it cost 40 % of the chunk) -- except that a
 //     tail of <= 64 rows goes to the skinny weight-streaming kernel instead (a 1-row tail: +11 % of the chunk instead of +12.5 %, and no MFMA work on padding);
 //   everything else: the tail kernels of gemm_fp8_tail.hip alone.
 // Rows are independent and the LDS-DMA kernels and the masked tiles run the same instruction chain per output element.
 constexpr int kSkinnyTailRows = 64;
-static int fp8_big_rows(int M, int K, int N_mult)      // rows the LDS-DMA kernels take (0 = none); N_mult: the column granularity the form needs (128, or 64 for 256 x 128 GeGLU)
+static int fp8_big_rows(int M, int K, int N_mult, int w_rows)      // rows the LDS-DMA kernels take (0 = none); N_mult: the column granularity the form needs (128, or 64 for 256 x 128 GeGLU)
 {
-    if (g_gemm_fp8_tail_only || M < 256 || K % 128 != 0 || N_mult == 0) return 0;
+    if (!lds_dma_addressable(M, K, w_rows)) return 0;
+    if (g_gemm_fp8_tail_only || M < 512 || K % 128 != 0 || N_mult == 0) return 0;      // below two full tile-rows the masked 128-row tiles are as fast (T = 300: 15 ms vs 18 ms)
     const int tail = M % 256;
     return (tail > 0 && tail <= kSkinnyTailRows) ? M - tail : M;
 }
@@ -884,7 +920,7 @@ int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, con
                           hipStream_t s)
 {
     const bool form256 = F % 128 == 0 && ((M + 255) / 256) * (F / 128) >= 200;
-    const int rows = fp8_big_rows(M, K, form256 ? 128 : (F % 64 == 0 ? 64 : 0));
+    const int rows = fp8_big_rows(M, K, form256 ? 128 : (F % 64 == 0 ? 64 : 0), 2 * F);
     if (rows)
     {
         int rc;
@@ -906,7 +942,7 @@ int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, con
 int launch_gemm_fp8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
                     int M, int K, int N, hipStream_t s)
 {
-    const int rows = fp8_big_rows(M, K, N % 128 == 0 ? 128 : 0);
+    const int rows = fp8_big_rows(M, K, N % 128 == 0 ? 128 : 0, N);
     if (rows)
     {
         const int which = fp8_pick(rows, N), tm = (rows + 255) / 256;

@@ -154,6 +154,10 @@ typedef struct mila_fused_attn_args {
 } mila_fused_attn_args;
 MILA_API int mila_cdna4_fused_attn_decode_ex(const mila_fused_attn_args* host_args, mila_stream_t stream);
 
+/* the 256 x 256 bf16 GEMM tile on FOUR waves (one per SIMD, 128 x 128 each; csrc/experiments/gemm4w.hip): bit-identical to gemm_bf16 / gemm_geglu_bf16 on the
+ * shapes both take, measured 15-25 % slower (profiles/r03_gemm4w.txt).  libmila_cdna4_experiments.so. */
+MILA_API int mila_cdna4_exp_gemm4w_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, mila_stream_t stream);
+MILA_API int mila_cdna4_exp_gemm4w_geglu_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, mila_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -581,10 +581,10 @@ def test_w4a8_serves_every_row_count_like_the_reference(M, K, N, bias, G):
             capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(0))
         forms[form] = bits(Yf)
         assert_bf16_close(forms[form][rows], exp, 2, 1e-3 * float(np.abs(exp).max()), "fp8 GEMM, tail form %d, vs restated reference" % form)
-    # who serves which rows by default (csrc/gemm256.hip: launch_gemm_fp8): with M >= 256 (and K % 128 == N % 128 == 0) the LDS-DMA kernels take every tile-row,
-    # a ragged last one masked -- unless the tail is <= 64 rows, which goes to the skinny kernel; below 256 rows: skinny up to 64, masked LDS tiles beyond
+    # who serves which rows by default (csrc/gemm256.hip: launch_gemm_fp8): with M >= 512 (and K % 128 == N % 128 == 0) the LDS-DMA kernels take every tile-row,
+    # a ragged last one masked -- unless the tail is <= 64 rows, which goes to the skinny kernel; below 512 rows: skinny up to 64, masked LDS tiles beyond
     tail = M % 256
-    big = 0 if (M < 256 or K % 128 or N % 128) else (M - tail if 0 < tail <= 64 else M)
+    big = 0 if (M < 512 or K % 128 or N % 128) else (M - tail if 0 < tail <= 64 else M)
     assert np.array_equal(forms[1][:big], bits(Y)[:big]), "the masked LDS-tile kernel and the LDS-DMA fp8 kernels differ"
     if M - big > 64:
         assert np.array_equal(forms[1][big:], bits(Y)[big:])
