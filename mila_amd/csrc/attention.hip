@@ -658,6 +658,24 @@ __global__ __launch_bounds__(256) void mha_kv_write_kernel(uint16_t* __restrict_
         Vc[dst] = row[2 * C + c];
     }
 }
+// the same with 16-byte accesses (HS % 8 == 0: a head row is whole 8-element vectors; C % 8 == 0 follows)
+__global__ __launch_bounds__(256) void mha_kv_write_vec_kernel(uint16_t* __restrict__ Kc, uint16_t* __restrict__ Vc, const uint16_t* __restrict__ QKV,
+                                                               int64_t total_vec, int T, int C, int HS, int start_pos, int capacity)
+{
+    const int NH = C / HS, cv = C / 8;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += stride)
+    {
+        const int c = (int)(i % cv) * 8;
+        const int64_t bt = i / cv;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const int h = c / HS, d = c - h * HS;
+        const size_t dst = (((size_t)b * NH + h) * capacity + (start_pos + t)) * HS + d;
+        const uint16_t* row = QKV + bt * 3 * (int64_t)C;
+        st16(Kc + dst, ld16(row + C + c));
+        st16(Vc + dst, ld16(row + 2 * C + c));
+    }
+}
 
 }  // namespace mila
 
@@ -754,10 +772,13 @@ int mila_cdna4_mha_kv_write_bf16(uint16_t* Kc, uint16_t* Vc, const uint16_t* QKV
     MILA_REQUIRE(Kc && Vc && QKV, "mha_kv_write_bf16: null pointer");
     MILA_REQUIRE(B > 0 && T > 0 && C > 0 && NH > 0 && C % NH == 0 && capacity > 0, "mha_kv_write_bf16: bad sizes (B=%d T=%d C=%d NH=%d capacity=%d)", B, T, C, NH, capacity);
     MILA_REQUIRE(start_pos >= 0 && start_pos + T <= capacity, "mha_kv_write_bf16: positions [%d, %d) do not fit the cache capacity %d", start_pos, start_pos + T, capacity);
-    const int64_t total = (int64_t)B * T * C;
+    const int HS = C / NH;
+    const bool vec = HS % 8 == 0 && ((uintptr_t)QKV % 16 == 0) && ((uintptr_t)Kc % 16 == 0) && ((uintptr_t)Vc % 16 == 0);
+    const int64_t total = vec ? (int64_t)B * T * (C / 8) : (int64_t)B * T * C;
     int blocks = ceil_div(total, 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(mha_kv_write_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), Kc, Vc, QKV, total, T, C, C / NH, start_pos, capacity);
+    if (blocks > 4096) blocks = 4096;
+    if (vec) hipLaunchKernelGGL(mha_kv_write_vec_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), Kc, Vc, QKV, total, T, C, HS, start_pos, capacity);
+    else hipLaunchKernelGGL(mha_kv_write_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), Kc, Vc, QKV, total, T, C, HS, start_pos, capacity);
     MILA_LAUNCH_CHECK("mha_kv_write_bf16");
 }
 

@@ -553,7 +553,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             if (which == 0)
             {
                 if constexpr (GEGLU) { const int q = row & 63; grow = (q < 32 ? 0 : p.N - 32) + n0 + (row >> 6) * 32 + q; }   // N = F: up rows start at F
-                else grow = n0 + row;
+                else grow = min(n0 + row, p.N - 1);      // W rows past N (a ragged last column tile) re-read row N - 1, never stored
             }
             else grow = min(m0 + (which - 1) * 128 + row, p.M - 1);      // X rows past M (ragged last tile-row) re-read row M - 1, never stored
             voff[which][i] = grow * rowbytes + kslot * 16;
@@ -754,6 +754,31 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
         }
         return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
     };
+    if (!FP8 && ((p.N & 7) != 0 || n0 + 128 > p.N))
+    {
+        // an output row pitch that is not a multiple of 16 bytes (GPT-2's lm_head: N = 50257) or a ragged last column tile: element stores under a column mask
+#pragma unroll
+        for (int hB = 0; hB < 2; ++hB)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                {
+                    const int n = n0 + wr * 64 + pt * 16 + 4 * g;
+                    const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                    if (m >= p.M) continue;
+                    uint16_t* y = p.Y + (size_t)m * p.N + n;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.N)
+                        {
+                            float v = acc[hB][pt][qt][e];
+                            if (p.bias) v = round_bf16(v) + bf16_bits_to_f32(p.bias[n + e]);
+                            y[e] = f32_to_bf16_bits(v);
+                        }
+                }
+        return;
+    }
 #pragma unroll
     for (int hB = 0; hB < 2; ++hB)
 #pragma unroll
@@ -777,6 +802,13 @@ bool gemm256x128_applicable(int M, int K, int N)
     const int tiles = (M / 256) * (N / 128);
     const int rounds = (tiles + kNumCU - 1) / kNumCU;
     return tiles >= 160 && tiles >= 0.70 * rounds * kNumCU;      // (192 tiles -- GPT-2's 768-wide projections at B T = 8192 -- beat the 128-tile kernel's 384: 18 / 51 vs 29 / 74 us)
+}
+
+// bf16 only: N of any size (ragged last column tile, any row pitch) when the grid is many rounds deep -- GPT-2's lm_head (N = 50257, 12 576 tiles at M = 8192)
+bool gemm256x128_ragged_n_applicable(int M, int K, int N)
+{
+    if (M % 256 != 0 || K % 64 != 0 || N % 128 == 0 || !lds_dma_addressable(M, K, N)) return false;
+    return (int64_t)(M / 256) * ((N + 127) / 128) >= 4 * kNumCU;
 }
 
 extern int g_gemm_pingpong;
@@ -803,7 +835,7 @@ static int launch_gemm256x128_t(const Gemm256Params& p, hipStream_t s)
 }
 int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
 {
-    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, N / 128, nullptr, nullptr};
+    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, (N + 127) / 128, nullptr, nullptr};
     return launch_gemm256x128_t<false>(p, s);
 }
 

@@ -650,3 +650,37 @@ def test_ragged_prompt_lengths_split_between_the_lds_dma_and_the_128_tile_kernel
     capi.call("gemm_bf16_w4a16_staged", Y, Xd, dev_u8(q4), dev_f32(s4), None, M, K, N, 64, scratch, C.c_size_t(need))
     Wdq = orc.to_bf16_bits(orc.dequant_fp4(q4, s4, 64))                   # the staged path multiplies the bf16-rounded dequantized weights
     assert_bf16_close(bits(Y)[rows], orc.linear_bf16w(X[rows], Wdq), 1, 2e-3, "ragged staged fp4 gemm")
+
+
+@pytest.mark.parametrize("N,bias", [(50257, True), (50257 - 128 + 3, False)])
+def test_lds_dma_gemm_serves_a_ragged_n_with_an_odd_row_pitch(N, bias):
+    """GPT-2's lm_head (GptTransformer.ixx:854-855: Linear(768 -> 50257), no bias there; bias exercised here too): N is no multiple of the 128-column tile and the output
+    row pitch no multiple of 16 bytes -- the 256 x 128 LDS-DMA kernel takes it with a clamped last W tile and element stores under a column mask (round 3; it
+    used to fall to the 128-tile register-staged kernel at 1.6 ms of config 2's 6.8).  Rows / columns around every edge against the float64 oracle, and the
+    whole output against the 128-tile kernel within 1 bf16 ulp (another MFMA shape, same math)"""
+    M, K = 768, 192
+    lib = capi.load()
+    rng = np.random.default_rng(N)
+    Wb = _weights(rng, N, K, "random")
+    X = orc.round_bf16(rng.uniform(-1, 1, (M, K)).astype(np.float32))
+    bb = orc.to_bf16_bits(rng.uniform(-0.1, 0.1, N).astype(np.float32)) if bias else None
+    Xd, Wd = dev_u16(orc.to_bf16_bits(X)), dev_u16(Wb)
+    Y = torch.full((M, N), 0x7fc0, dtype=torch.int16, device="cuda")          # NaN-poisoned: every element must be written
+    guard = torch.full((64,), 0x1234, dtype=torch.int16, device="cuda")
+    capi.call("gemm_bf16", Y, Xd, Wd, dev_u16(bb) if bias else None, M, K, N)
+    got = bits(Y)
+    assert not np.any((got & 0x7fff) > 0x7f80), "unwritten (NaN) outputs"
+    rows = [0, 1, 255, 256, 511, M - 1]
+    exp = orc.linear_bf16w(X[rows], Wb, None)
+    if bias:
+        exp = orc.round_bf16(exp).astype(np.float64) + orc.from_bf16_bits(bb).astype(np.float64)
+    assert_bf16_close(got[rows], exp, 2 if bias else 1, 2e-3, "ragged-N gemm_bf16")
+    Y2 = torch.empty((M, N), dtype=torch.int16, device="cuda")
+    capi.check(lib.mila_cdna4_tune_gemm(1))
+    try:
+        capi.call("gemm_bf16", Y2, Xd, Wd, dev_u16(bb) if bias else None, M, K, N)
+    finally:
+        capi.check(lib.mila_cdna4_tune_gemm(0))
+    a, b = orc.from_bf16_bits(got).astype(np.float64), orc.from_bf16_bits(bits(Y2)).astype(np.float64)
+    assert np.abs(a - b).max() <= 2.0 ** -7 * max(np.abs(b).max(), 1e-30)
+    assert np.all(guard.cpu().numpy() == 0x1234)
