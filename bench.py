@@ -238,6 +238,8 @@ def main():
     ap.add_argument("--mode", default="graph", choices=["graph", "fused", "reference"])
     ap.add_argument("--no-prefill", action="store_true", help="skip the timed T=2048 prefill (KV cache left zero-filled)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--context", type=int, default=None, help="decode at this context instead of 2048 (e.g. 32768, the reference's published regime): the prompt is prefilled in chunks of 2048 through the KV caches")
+    ap.add_argument("--no-gpt2", action="store_true", help="skip the BASELINE config-2 entry (GPT-2 124M bf16, B=8, T=1024 forward)")
     ap.add_argument("--stub", action="store_true", help="plumbing test on a CPU box: no GPU work, the line says data = stub")
     ap.add_argument("--attn-split", type=int, default=None, help="tuning hook: positions per flash-decode split (default 64)")
     ap.add_argument("--resident", type=int, default=None, help="1/0: resident prefill staging for the quantized policies (default: the model's = 1)")
@@ -287,11 +289,15 @@ def main():
     if a.gemm_schedule is not None:
         capi.check(capi.load().mila_cdna4_tune_gemm_schedule(a.gemm_schedule))
     results = {}
+    CHUNK = CONTEXT                      # the prefill chunk (BASELINE config 3-5: T = 2048)
+    ctx = a.context if a.context else CONTEXT
+    if ctx < CHUNK:
+        raise SystemExit("bench.py: --context must be at least %d" % CHUNK)
     for pol in policies:
-        m = host.Gemma(pol, cfg, max_seq=CONTEXT + a.steps + a.warmup + 8, max_prefill=1 if a.no_prefill else CONTEXT, seed=1234)
+        m = host.Gemma(pol, cfg, max_seq=ctx + a.steps + a.warmup + 8, max_prefill=1 if a.no_prefill else CHUNK, seed=1234)
         if a.resident is not None:
             m.set_resident_prefill_weights(a.resident)
-        info = m.info(CONTEXT)
+        info = m.info(ctx)
         r = {"weight_GB": round(info["weight_bytes"] / 1e9, 3), "bytes_per_token_GB": round(info["decode_bytes_per_token"] / 1e9, 3)}
         # the quantized policies keep their prefill staging resident: HBM it costs beside the quantized weights
         resident = a.resident is None or bool(a.resident)
@@ -314,9 +320,15 @@ def main():
             ideal_ms = (lin / (MFMA_FP8_PEAK_TFLOPS if pol == "fp4" else MFMA_BF16_PEAK_TFLOPS) + att / MFMA_BF16_PEAK_TFLOPS) / 1e9
             r["prefill_mfma_frac"] = round(ideal_ms / ms, 4)
             r["prefill_mfma_peak_TFLOPs"] = {"linear": MFMA_FP8_PEAK_TFLOPS if pol == "fp4" else MFMA_BF16_PEAK_TFLOPS, "attention": MFMA_BF16_PEAK_TFLOPS}
+            if ctx > CHUNK:
+                # the long prompt as the L6 caller feeds it: chunks of 2048 through the KV caches (Gemma.ixx:234-267); fills the caches to the context
+                cms = m.time_prefill_chunked(ctx)
+                r["chunked_prefill_tokens"] = ctx
+                r["chunked_prefill_ms"] = round(cms, 2)
+                r["chunked_prefill_tok_s"] = round(ctx / cms * 1e3, 1)
         ranks.barrier()
         torch.cuda.synchronize()
-        t = m.time_decode(CONTEXT, a.steps, a.warmup, a.mode)
+        t = m.time_decode(ctx, a.steps, a.warmup, a.mode)
         torch.cuda.synchronize()
         ranks.barrier()
         t["wall_ms_per_step"] = ranks.max_over_ranks(t["wall_ms_per_step"])      # timing only: max over ranks
@@ -329,6 +341,13 @@ def main():
         results[pol] = r
         m.close()
         del m
+
+    # BASELINE config 2 beside the headline: GPT-2 124M bf16 forward, B = 8, T = 1024 (tools/bench_gpt2.py; rank 0 of the single-GPU line only)
+    gpt2 = None
+    if rank == 0 and world == 1 and not a.no_gpt2:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_gpt2
+        gpt2 = bench_gpt2.run(5)
 
     # measured streaming ceiling beside the 8 TB/s spec: a read-only pass over 2 GiB with 16-byte loads
     import ctypes as C
@@ -350,12 +369,12 @@ def main():
 
     head = results[policies[0]]
     out = {
-        "metric": "Gemma-4 12B decode tok/s (B=1, context 2048), 1xMI355X",
+        "metric": "Gemma-4 12B decode tok/s (B=1, context %d), 1xMI355X" % ctx,
         "value": round(head["tok_s"] * world, 2), "unit": "tok/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"bf16": "bf16", "fp8": "bf16 activations x fp8_e4m3 weights", "fp4": "bf16 activations x fp4_e2m1 weights"}[policies[0]],
         "data": "synthetic (counter-based uniform weights, random-init architecture; KV cache filled by a T=2048 prefill)",
-        "config": {"workload": "Gemma-4 12B, weight policy %s, B=1, prefill T=2048 then decode at positions 2048.." % policies[0],
+        "config": {"workload": "Gemma-4 12B, weight policy %s, B=1, prefill T=2048%s then decode at positions %d.." % (policies[0], "" if ctx == CONTEXT else " (chunked to %d)" % ctx, ctx),
                    "decode_mode": a.mode, "replicas": world, "parallelism": "replicas only (no collective)"},
         "roofline": {"bound": "hbm", "achieved": head["dominant_kernel"]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(head["dominant_kernel"]["GBps"] / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(policies[0])[0],
@@ -371,6 +390,8 @@ def main():
                      "whole_token_frac_of_guide_achievable_6300GBps": round(head["token_roofline_frac"] * HBM_PEAK_GBPS / 6300.0, 4)},
         "policies": results,
     }
+    if gpt2 is not None:
+        out["gpt2_124M_bf16_B8_T1024"] = gpt2
     if rank == 0:
         if cpu is not None:                    # the CPU baseline belongs to the single-GPU line only
             out["cpu_baseline"] = cpu

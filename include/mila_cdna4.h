@@ -99,6 +99,10 @@ MILA_API int mila_cdna4_matvec_f32out(float* y, const uint16_t* x, const void* W
  * ------------------------------------------------------------------------------------------- */
 MILA_API int mila_cdna4_gemm_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W,
                                   const uint16_t* bias, int M, int K, int N, mila_stream_t stream);
+/* Linear + tanh-GELU in one kernel (the GPT-2 MLP's fc_1 -> gelu, Components/FFN/MLP/MLP.ixx:148-161): Y = bf16(gelu(bf16(X W^T (+ bias)))), every rounding of the two
+ * launches kept, so the result is bit-identical to gemm_bf16 followed by gelu_bf16 -- the [M, N] intermediate is neither written nor re-read. */
+MILA_API int mila_cdna4_gemm_gelu_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K,
+                                       int N, mila_stream_t stream);
 MILA_API int mila_cdna4_gemm_bf16_w8a16(uint16_t* Y, const uint16_t* X, const uint8_t* W,
                                         const float* scales, const uint16_t* bias, int M, int K,
                                         int N, mila_stream_t stream);

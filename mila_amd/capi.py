@@ -145,7 +145,7 @@ EXPORTED = [
     "stream_destroy", "stream_synchronize", "malloc", "free", "host_alloc_pinned", "host_free_pinned",
     "memcpy_h2d", "memcpy_d2h", "memcpy_d2d", "memset_zero",
     "matvec_bf16", "matvec_bf16_qfp8", "matvec_bf16_qfp4", "matvec_f32out",
-    "gemm_bf16", "gemm_bf16_w8a16", "gemm_bf16_w4a16", "gemm_staging_bytes", "gemm_bf16_w8a16_staged", "gemm_bf16_w4a16_staged",
+    "gemm_bf16", "gemm_gelu_bf16", "gemm_bf16_w8a16", "gemm_bf16_w4a16", "gemm_staging_bytes", "gemm_bf16_w8a16_staged", "gemm_bf16_w4a16_staged",
     "fp4_weight_fp8_scale", "upcast_fp4_to_fp8", "quantize_fp8_per_token", "gemm_fp8_applicable", "gemm_fp8_scaled",
     "gemm_w4a8_scratch_bytes", "gemm_bf16_w4a8", "gemm_geglu_w4a8_applicable", "gemm_geglu_bf16_w4a8",
     "gemm_geglu_applicable", "gemm_geglu_bf16", "gemm_geglu_bf16_w8a16_staged", "gemm_geglu_bf16_w4a16_staged",

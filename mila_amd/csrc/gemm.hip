@@ -38,6 +38,7 @@ struct GemmParams
     const uint16_t* bias;
     int M, K, N, group;
     int tiles_m, tiles_n;
+    int act = 0;          // 1 = tanh-GELU on the stored Linear output (see Gemm256Params::act)
 };
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
@@ -241,6 +242,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p)
                     for (int e = 0; e < 4; ++e)
                         if (n + e < p.N) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
                 }
+                if (p.act)
+                {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(round_bf16(v[e]));
+                }
                 uint16_t* dst = p.Y + (size_t)m * p.N + n;
                 if (n + 3 < p.N && (p.N & 3) == 0)
                     *reinterpret_cast<u32x2*>(dst) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -265,10 +271,10 @@ static int launch_gemm(GemmParams p, hipStream_t s)
 }
 
 bool gemm256_applicable(int M, int K, int N);
-int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s);
+int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act = 0);
 bool gemm256x128_applicable(int M, int K, int N);
 bool gemm256x128_ragged_n_applicable(int M, int K, int N);
-int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s);
+int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act = 0);
 bool gemm256_geglu_applicable(int M, int K, int F);
 int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s);
 static int g_gemm_force128 = 0;
@@ -287,9 +293,9 @@ static int glds_kernel_for(int M, int K, int N)
     if (gemm256x128_ragged_n_applicable(M, K, N)) return 1;
     return 0;
 }
-static int launch_glds(int which, uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
+static int launch_glds(int which, uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act = 0)
 {
-    return which == 2 ? launch_gemm256(Y, X, W, bias, M, K, N, s) : launch_gemm256x128(Y, X, W, bias, M, K, N, s);
+    return which == 2 ? launch_gemm256(Y, X, W, bias, M, K, N, s, act) : launch_gemm256x128(Y, X, W, bias, M, K, N, s, act);
 }
 // Ragged prompt lengths: the LDS-DMA kernels take M % 256 == 0, so the first floor(M / 256) * 256 rows go to them and the
 // remaining < 256 rows to the register-staged 128-tile kernel (rows are independent; no padding, nothing read past the tensors).
@@ -302,7 +308,7 @@ static int glds_rows_for(int M, int K, int N, int* which)
     if (main_rows >= 512 && (*which = glds_kernel_for(main_rows, K, N)) != 0) return main_rows;
     return 0;
 }
-static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s);
+static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act = 0);
 
 // ---- 2-phase staging (the reference's own prefill structure for quantized weights,
 // OPS/Linear/CudaLinearOp.ixx:597-644, :716-764): dequantize the whole matrix to bf16 scratch, then the bf16 GEMM.
@@ -379,16 +385,16 @@ static int validate_gemm(const char* who, const void* Y, const void* X, const vo
 }
 
 // bf16-weight GEMM over M rows: LDS-DMA kernel on the leading multiple of 256 rows when one applies, 128-tile kernel on the rest
-static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
+static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act)
 {
     int which;
     const int main_rows = glds_rows_for(M, K, N, &which);
     if (main_rows > 0)
     {
-        int rc = launch_glds(which, Y, X, W, bias, main_rows, K, N, s);
+        int rc = launch_glds(which, Y, X, W, bias, main_rows, K, N, s, act);
         if (rc || main_rows == M) return rc;
     }
-    GemmParams p{Y + (size_t)main_rows * N, X + (size_t)main_rows * K, reinterpret_cast<const uint8_t*>(W), nullptr, bias, M - main_rows, K, N, 0, 0, 0};
+    GemmParams p{Y + (size_t)main_rows * N, X + (size_t)main_rows * K, reinterpret_cast<const uint8_t*>(W), nullptr, bias, M - main_rows, K, N, 0, 0, 0, act};
     return launch_gemm<G_BF16>(p, s);
 }
 
@@ -427,6 +433,13 @@ int mila_cdna4_gemm_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, cons
     int rc = validate_gemm("gemm_bf16", Y, X, W, M, K, N);
     if (rc) return rc;
     return launch_bf16_rows(Y, X, W, bias, M, K, N, as_stream(stream));
+}
+
+int mila_cdna4_gemm_gelu_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, mila_stream_t stream)
+{
+    int rc = validate_gemm("gemm_gelu_bf16", Y, X, W, M, K, N);
+    if (rc) return rc;
+    return launch_bf16_rows(Y, X, W, bias, M, K, N, as_stream(stream), 1);
 }
 
 int mila_cdna4_gemm_bf16_w8a16(uint16_t* Y, const uint16_t* X, const uint8_t* W, const float* scales,

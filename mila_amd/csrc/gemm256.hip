@@ -31,6 +31,7 @@ struct Gemm256Params
     // FP8 mode (W4A8 / W8A8 prefill): X and W are e4m3 bytes [M, K] / [N, K]; y = bf16(float(bf16(acc * *w_scale)) * x_scales[m] + bias)
     const float* x_scales;   // [M] per-token activation scales
     const float* w_scale;    // device scalar: per-tensor weight scale
+    int act = 0;             // bf16 plain epilogue: 1 = tanh-GELU on the stored Linear output, y = bf16(gelu(bf16(acc) [+ bias, rounded again])): Linear + Gelu of MLP.ixx:148-161 in one kernel
 #ifdef MILA_GEMM_SKIP
     int dbg = 0;             // diagnostic build (tools/experiments/gemm_skip.sh): leave out the staging (1), the fragment reads (2), the MFMAs (4), the plain epilogue's stores (8)
 #endif
@@ -325,6 +326,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 {
     #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
+                }
+                if (!FP8 && p.act)
+                {
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(round_bf16(v[e]));
                 }
                 return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             };
@@ -752,6 +758,11 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
         }
+        if (!FP8 && p.act)
+        {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(round_bf16(v[e]));
+        }
         return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
     };
     if (!FP8 && ((p.N & 7) != 0 || n0 + 128 > p.N))
@@ -774,6 +785,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                         {
                             float v = acc[hB][pt][qt][e];
                             if (p.bias) v = round_bf16(v) + bf16_bits_to_f32(p.bias[n + e]);
+                            if (p.act) v = gelu_tanh(round_bf16(v));
                             y[e] = f32_to_bf16_bits(v);
                         }
                 }
@@ -833,9 +845,9 @@ static int launch_gemm256x128_t(const Gemm256Params& p, hipStream_t s)
     if (g_gemm_pingpong == 5) return launch_gemm256x128_tt<FP8, GEGLU, 2>(p, s);
     return g_gemm_pingpong ? launch_gemm256x128_tt<FP8, GEGLU, 1>(p, s) : launch_gemm256x128_tt<FP8, GEGLU, 0>(p, s);
 }
-int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
+int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act)
 {
-    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, (N + 127) / 128, nullptr, nullptr};
+    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, (N + 127) / 128, nullptr, nullptr, act};
     return launch_gemm256x128_t<false>(p, s);
 }
 
@@ -887,9 +899,9 @@ static int launch_gemm256_t(const Gemm256Params& p, hipStream_t s)
     return g_gemm_pingpong ? launch_gemm256_tt<MODE, 1>(p, s) : launch_gemm256_tt<MODE, 0>(p, s);
 }
 
-int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s)
+int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act)
 {
-    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, N / 256, nullptr, nullptr};
+    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, N / 256, nullptr, nullptr, act};
     return launch_gemm256_t<G_PLAIN>(p, s);
 }
 

@@ -140,6 +140,31 @@ namespace Mila::Dnn
             return *output_view_;
         }
 
+        /// true when forwardGelu() serves an input of this shape (unquantized weights, more than one row)
+        bool fusesGelu( const shape_t& in_shape ) const noexcept
+        {
+            dim_t rows = 1;
+            for ( size_t i = 0; i + 1 < in_shape.size(); ++i ) rows *= in_shape[ i ];
+            return this->isBuilt() && operation_->fusesGelu( rows );
+        }
+
+        /// forward() followed by a tanh-GELU on its output, in one kernel: same bits, the intermediate stays in registers
+        TensorType& forwardGelu( const TensorType& input )
+        {
+            if ( !this->isBuilt() ) throw std::runtime_error( "Linear must be built before calling forward." );
+            validateInputShape( input.shape() );
+            auto out_shape = input.shape();
+            out_shape.back() = config_.getOutputFeatures();
+            if ( input.shape() == leading_shape_ )
+            {
+                operation_->forwardGelu( input, *output_ );
+                return *output_;
+            }
+            output_view_ = std::make_unique<TensorType>( output_->view( out_shape ) );
+            operation_->forwardGelu( input, *output_view_ );
+            return *output_view_;
+        }
+
         /// forward() on rows the producer already quantized per token (W4A8 policy; see RocmLinearOp::acceptsFp8Activations): `leading` is the shape of the
         /// bf16 input those rows stand for; returns the component-owned output or a shape-adjusted view, with the bits forward() would have produced
         TensorType& forwardFp8Activations( const uint8_t* x8, const float* ts, const shape_t& leading )

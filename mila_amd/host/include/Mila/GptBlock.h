@@ -319,6 +319,8 @@ namespace Mila::Dnn
         TensorType& forward( const TensorType& input )
         {
             if ( !this->isBuilt() ) throw std::runtime_error( "MLP must be built before calling forward." );
+            // fc_1 -> gelu in one kernel where the backend has it (tanh GELU on bf16 GEMM rows): the same bits, without the [B, T, 4C] round trip through HBM
+            if ( fc_1->fusesGelu( input.shape() ) ) return fc_2->forward( fc_1->forwardGelu( input ) );
             return fc_2->forward( gelu->forward( fc_1->forward( input ) ) );
         }
         /// single-token step (MLP.ixx:214): the same chain on a [B, 1, C] row (the Linears take their matvec branch at one row)

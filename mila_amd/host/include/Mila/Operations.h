@@ -163,6 +163,22 @@ namespace Mila::Dnn::Compute
             }
         }
 
+        /// true when forwardGelu() serves this op and row count: unquantized weights on the GEMM branch
+        bool fusesGelu( dim_t rows ) const noexcept { return kFmt == 0 && rows > 1; }
+
+        /// Linear -> tanh-GELU in one kernel (the MLP's fc_1 -> gelu, MLP.ixx:148-161): the bits of forward() followed by RocmGeluOp::forward()
+        void forwardGelu( const TensorType& in, TensorType& out ) const
+        {
+            if ( !built_ ) throw std::runtime_error( "RocmLinearOp::forwardGelu: not built" );
+            const int K = narrowToKernelIndex( cfg_.in_features, "in_features" );
+            const int N = narrowToKernelIndex( cfg_.out_features, "out_features" );
+            const int M = narrowToKernelIndex( static_cast<dim_t>( in.size() ) / cfg_.in_features, "outer size" );
+            if ( !fusesGelu( M ) ) throw std::logic_error( "RocmLinearOp::forwardGelu: only unquantized weights at more than one row" );
+            if constexpr ( kFmt == 0 )
+                rocmCheck( mila_cdna4_gemm_gelu_bf16( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( in.rawData() ), static_cast<const uint16_t*>( weight_ ), bias_, M, K, N,
+                                                      this->context_->getStream() ) );
+        }
+
         void backward( const TensorType&, const TensorType&, TensorType& ) const
         {
             throw std::logic_error( "RocmLinearOp::backward: the CDNA4 backend is inference-only (and the reference forbids backward on quantized weights)" );

@@ -684,3 +684,33 @@ def test_lds_dma_gemm_serves_a_ragged_n_with_an_odd_row_pitch(N, bias):
     a, b = orc.from_bf16_bits(got).astype(np.float64), orc.from_bf16_bits(bits(Y2)).astype(np.float64)
     assert np.abs(a - b).max() <= 2.0 ** -7 * max(np.abs(b).max(), 1e-30)
     assert np.all(guard.cpu().numpy() == 0x1234)
+
+
+@pytest.mark.parametrize("M,K,N,bias", [(2048, 256, 3072, True),      # 256 x 256 LDS-DMA tiles (GPT-2 fc_1's N)
+                                        (1024, 128, 3200, True),      # 256 x 128 tiles (N % 256 != 0)
+                                        (768, 192, 50257 - 128 + 3, True),      # 256 x 128 tiles with the ragged-N element epilogue
+                                        (300, 136, 520, True), (300, 136, 520, False),      # main rows on LDS-DMA tiles + a 44-row rest on the 128-tile register kernel
+                                        (7, 64, 96, True)])           # 128-tile register kernel only
+def test_gemm_with_gelu_epilogue_is_bit_identical_to_gemm_then_gelu(M, K, N, bias):
+    """the GPT-2 MLP's fc_1 -> gelu (Components/FFN/MLP/MLP.ixx:148-161) in one kernel: every epilogue rounds the Linear output to bf16 exactly as gemm_bf16 stores it
+    and applies gelu_bf16's arithmetic to that value, so the result has the bits of the two launches while the [M, N] intermediate never reaches HBM"""
+    rng = np.random.default_rng(M * 7 + N)
+    Wb = _weights(rng, N, K, "random")
+    X = orc.round_bf16(rng.uniform(-2, 2, (M, K)).astype(np.float32))
+    bb = orc.to_bf16_bits(rng.uniform(-0.5, 0.5, N).astype(np.float32)) if bias else None
+    Xd, Wd, bd = dev_u16(orc.to_bf16_bits(X)), dev_u16(Wb), dev_u16(bb) if bias else None
+    H, Y0 = empty_u16(M, N), empty_u16(M, N)
+    Y1 = torch.full((M, N), 0x7fc0, dtype=torch.int16, device="cuda")
+    capi.call("gemm_bf16", H, Xd, Wd, bd, M, K, N)
+    capi.call("gelu_bf16", Y0, H, M * N)
+    capi.call("gemm_gelu_bf16", Y1, Xd, Wd, bd, M, K, N)
+    assert np.array_equal(bits(Y0), bits(Y1)), "fused GELU epilogue differs from gemm + gelu"
+    rows = [0, M // 2, M - 1]
+    h = orc.linear_bf16w(X[rows], Wb, None)
+    if bias:
+        h = orc.round_bf16(h).astype(np.float64) + orc.from_bf16_bits(bb).astype(np.float64)
+    h = orc.round_bf16(np.asarray(h, np.float32)).astype(np.float64)
+    exp = 0.5 * h * (1 + np.tanh(0.7978845608028654 * (h + 0.044715 * h ** 3)))
+    assert_bf16_close(bits(Y1)[rows], exp, 2, 2e-3, "gemm+gelu vs oracle")
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("gemm_gelu_bf16", Y1, Xd, Wd, bd, M, K + 4, N)
