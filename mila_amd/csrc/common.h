@@ -192,6 +192,10 @@ __device__ __forceinline__ u32x4 ld16_nt(const void* p)
     return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
 }
 __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+// the same 16-byte store to an address that is only 2-byte aligned (a bf16 row whose pitch is odd: GPT-2's N = 50257).  Global memory takes unaligned vector
+// accesses on this target (amdhsa runs with unaligned-access mode on; the compiler itself emits global_store_dwordx4 for an align-2 16-byte object)
+struct __attribute__((packed, aligned(2))) u32x4_a2 { uint32_t x, y, z, w; };
+__device__ __forceinline__ void st16_a2(void* p, u32x4 v) { *reinterpret_cast<u32x4_a2*>(p) = u32x4_a2{v[0], v[1], v[2], v[3]}; }
 
 // ---- GELU (tanh) exactly as the reference functor writes it ------------------------------------
 // Components/Activations/Activation/Kernels/ElementwiseActivation.h:41-50

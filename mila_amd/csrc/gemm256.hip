@@ -67,11 +67,14 @@ __device__ __forceinline__ void grouped_tile(int tile, int tiles_m, int tiles_n,
 // Epilogue store of two 16-column sub-tiles (pt, pt + 1) of one output row as ONE 16-byte store per lane.  A lane (l15, g) holds columns 4 g .. 4 g + 3 of both
 // sub-tiles (a, b); v_permlane16_swap exchanges the odd lane rows of a with the even lane rows of b, after which an even-g lane holds columns 4 g .. 4 g + 7 of
 // sub-tile pt and an odd-g lane columns 4 (g - 1) .. 4 (g - 1) + 7 of sub-tile pt + 1: half the store instructions, 64 contiguous bytes per row and instruction.
+template<bool ALIGNED = true>
 __device__ __forceinline__ void store_pair16(uint16_t* row_pt, int g, u32x2 a, u32x2 b, bool ok = true)
 {
     const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);      // every lane takes part in the exchange; `ok` (row < M) only guards the store
     const auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-    if (ok) st16(row_pt + (g & 1) * 16 + 4 * (g & ~1), u32x4{r0[0], r1[0], r0[1], r1[1]});
+    if (!ok) return;
+    if constexpr (ALIGNED) st16(row_pt + (g & 1) * 16 + 4 * (g & ~1), u32x4{r0[0], r1[0], r0[1], r1[1]});
+    else st16_a2(row_pt + (g & 1) * 16 + 4 * (g & ~1), u32x4{r0[0], r1[0], r0[1], r1[1]});      // odd row pitch: rows start on 2-byte boundaries
 }
 
 // PP (ping-pong): waves 4-7 run one barrier behind waves 0-3 and every phase has TWO barriers, [stage + fragment reads + waits] | A |
@@ -765,9 +768,25 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
         }
         return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
     };
-    if (!FP8 && ((p.N & 7) != 0 || n0 + 128 > p.N))
+    if (!FP8 && (p.N & 7) != 0 && n0 + 128 <= p.N)
     {
-        // an output row pitch that is not a multiple of 16 bytes (GPT-2's lm_head: N = 50257) or a ragged last column tile: element stores under a column mask
+        // an output row pitch that is not a multiple of 16 bytes (GPT-2's lm_head: N = 50257), whole tile: the paired 16-byte stores at 2-byte alignment
+#pragma unroll
+        for (int hB = 0; hB < 2; ++hB)
+#pragma unroll
+            for (int pp = 0; pp < 4; pp += 2)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                {
+                    const int nb = n0 + wr * 64 + pp * 16;
+                    const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                    store_pair16<false>(p.Y + (size_t)m * p.N + nb, g, out4(hB, pp, qt, m, nb + 4 * g), out4(hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
+                }
+        return;
+    }
+    if (!FP8 && n0 + 128 > p.N)
+    {
+        // the ragged last column tile: element stores under a column mask
 #pragma unroll
         for (int hB = 0; hB < 2; ++hB)
 #pragma unroll

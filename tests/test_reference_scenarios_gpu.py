@@ -607,6 +607,54 @@ def test_flash_prefill_bounded_ring_two_chunks_of_1024_vs_oracle():
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
+# the reference's PUBLISHED regime (DecodePerformanceCampaign.md:113-117: 22.5K-token chunked prefill, decode in a 32K context; chunking Gemma.ixx:234-267):
+# the global layer's caches hold every position, the local layers' bounded rings have wrapped ten times over
+# ------------------------------------------------------------------------------------------------------------------------------
+def _uniform_rows(seed, shape, gain=1.0):
+    return _bf(np.random.default_rng(seed).uniform(-1, 1, shape) * gain)
+
+
+def test_decode_in_a_32K_context_global_layer_vs_oracle():
+    """HS 512, 16 query heads on one KV head, 32768 live positions: the split-K decode streams 2 x 32 MB per launch (kMaxSplits splits of 512+ keys each);
+    every head of the step against the double-precision oracle, and a second step at a length that is no multiple of the split size"""
+    B, NH, NKV, HS, ctx = 1, 16, 1, 512, 32768
+    hk, hv = _uniform_rows(1, (B, ctx, NKV, HS), 0.25), _uniform_rows(2, (B, ctx, NKV, HS))
+    q = _uniform_rows(3, (B, 2, NH, HS))
+    Kc, Vc = _poisoned(B, NKV, ctx, HS), _poisoned(B, NKV, ctx, HS)
+    capi.call("kv_write_bf16", Kc, Vc, _d(hk), _d(hv), B, ctx, NKV, HS, 0, ctx)
+    scratch, nb = _scratch(B, NH, HS)
+    for i, length in enumerate((ctx, ctx - 1029)):
+        Yd = empty_u16(B, NH * HS)
+        capi.call("attn_decode_bf16", Yd, _d(q[:, i]), Kc, Vc, scratch, nb, B, NH, NKV, HS, ctx, length, 0, 1.0)
+        exp = orc.gqa_attention(q[:, i:i + 1], hk[:, :length], hv[:, :length], length - 1, 0, 1.0)[:, 0]
+        assert_bf16_close(bits(Yd), exp, 1, 2e-3, "global decode at length %d" % length)
+
+
+@pytest.mark.parametrize("name,NH,NKV,HS,window", [("gemma_global", 16, 1, 512, 0), ("gemma_local_ring", 16, 8, 256, 1024)])
+def test_chunked_prefill_of_22528_tokens_last_chunk_vs_oracle(name, NH, NKV, HS, window):
+    """the 11th chunk of 2048 rows of a 22528-token prompt (positions 20480 .. 22527): the global layer attends over all 22528 cached positions (704 key tiles), the
+    local layer over a bounded ring of capacity window + chunk - 1 = 3071 that ten earlier chunks have wrapped (slot -> position, Gqa.Prefill.Bf16.cu:145-151).
+    Sampled rows, all heads; then one decode step at position 22528 on the same caches"""
+    B, chunk, total = 1, 2048, 22528
+    cap = _capacity(total + 64, window, chunk, bool(window))
+    hk, hv = _uniform_rows(HS, (B, total + 1, NKV, HS), 0.25), _uniform_rows(HS + 1, (B, total + 1, NKV, HS))
+    pos0 = total - chunk
+    q = _uniform_rows(HS + 2, (B, chunk + 1, NH, HS))
+    Kc, Vc = _poisoned(B, NKV, cap, HS), _poisoned(B, NKV, cap, HS)
+    for off in range(0, total, chunk):      # every chunk's rows go through the ring in order, as GemmaTransformer::prefillFrom writes them
+        capi.call("kv_write_bf16", Kc, Vc, _d(hk[:, off:off + chunk]), _d(hv[:, off:off + chunk]), B, chunk, NKV, HS, off, cap)
+    Y = empty_u16(B, chunk, NH * HS)
+    capi.call("attn_prefill_bf16", Y, _d(q[:, :chunk]), Kc, Vc, B, chunk, NH, NKV, HS, cap, pos0, window, 1.0)
+    _check_rows(Y, q[:, :chunk], hk, hv, [0, 1, 15, 16, 1023, 1024, 2046, 2047], pos0, window, 1.0, name + " chunk 10")
+    capi.call("kv_write_bf16", Kc, Vc, _d(hk[:, total:]), _d(hv[:, total:]), B, 1, NKV, HS, total, cap)
+    scratch, nb = _scratch(B, NH, HS)
+    Yd = empty_u16(B, NH * HS)
+    capi.call("attn_decode_bf16", Yd, _d(q[:, chunk]), Kc, Vc, scratch, nb, B, NH, NKV, HS, cap, total + 1, window, 1.0)
+    exp = orc.gqa_attention(q[:, chunk:], hk, hv, total, window, 1.0)[:, 0]
+    assert_bf16_close(bits(Yd), exp, 1, 2e-3, name + " decode @22528")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
 # the remaining leaf components of the path: Swiglu<Gelu>, Residual, TokenEmbedding (bf16 and FP8 tables), split3, and -- FP32-only on the
 # reference's CUDA side, bf16 rows here -- Lpe, LayerNorm, Softmax with the same generators, shapes and host formulas
 # ------------------------------------------------------------------------------------------------------------------------------
