@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void gelu_bf16_kernel(uint16_t* __restrict__ Y
 __global__ __launch_bounds__(256) void gelu_fp32_kernel(float* __restrict__ Y, const float* __restrict__ X, int64_t n)
 {
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) Y[i] = gelu_tanh(X[i]);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) Y[i] = gelu_tanh_precise(X[i]);
 }
 
 // row = [gate(0..half) | up(half..2half)]; half % 8 == 0

@@ -274,6 +274,7 @@ bool gemm256_applicable(int M, int K, int N);
 int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act = 0);
 bool gemm256x128_applicable(int M, int K, int N);
 bool gemm256x128_ragged_n_applicable(int M, int K, int N);
+bool gemm256_ragged_n_applicable(int M, int K, int N);
 int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act = 0);
 bool gemm256_geglu_applicable(int M, int K, int F);
 int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s);
@@ -290,6 +291,7 @@ static int glds_kernel_for(int M, int K, int N)
     if (g_gemm_pingpong == 2 && gemm256x128_applicable(M, K, N)) return 1;      // tuning: the 256 x 128 ring wherever it applies
     if (gemm256_applicable(M, K, N)) return 2;
     if (gemm256x128_applicable(M, K, N)) return 1;
+    if (g_gemm_pingpong >= 3 && g_gemm_persistent && gemm256_ragged_n_applicable(M, K, N)) return 2;
     if (gemm256x128_ragged_n_applicable(M, K, N)) return 1;
     return 0;
 }

@@ -77,6 +77,25 @@ __device__ __forceinline__ void store_pair16(uint16_t* row_pt, int g, u32x2 a, u
     else st16_a2(row_pt + (g & 1) * 16 + 4 * (g & ~1), u32x4{r0[0], r1[0], r0[1], r1[1]});      // odd row pitch: rows start on 2-byte boundaries
 }
 
+// a lane's byte offsets into W for its two staging requests per half-tile (chunks wave and 8 + wave of 16 chunks of 8 rows; the XOR swizzle lives on the source
+// address).  WABS: absolute rows, clamped to the last row of W (ragged N); else relative to the half-tile's first row
+template <bool WABS, bool FP8>
+__device__ __forceinline__ void gemm256_w_offsets(int (&vo)[2][2], int wrow0, int wrow1, int wave, int srow, int sslot, int rowbytes, int n_rows)
+{
+#pragma unroll
+    for (int half = 0; half < (WABS ? 2 : 1); ++half)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+        {
+            const int row = (i * 8 + wave) * 8 + srow;             // chunk i * 8 + wave: 16 chunks of 8 rows
+            const int lslot = sslot ^ ((row >> 1) & 7);            // swizzle on the source address: LDS slot sslot of this row holds logical slot lslot
+            // fp8: a lane's operand is the 32 contiguous bytes k = 32 g .. (source chunks 2 g, 2 g + 1); they are kept at the logical slots g and 4 + g the
+            // bf16 fragments use, so the fragment reads are the same conflict-free pattern (read as 2 g + ks they pair up on the banks: 2-way conflicts)
+            const int kslot = FP8 ? (((lslot & 3) << 1) | (lslot >> 2)) : lslot;
+            vo[half][i] = (WABS ? min((half ? wrow1 : wrow0) + row, n_rows - 1) : row) * rowbytes + kslot * 16;
+        }
+}
+
 // PP (ping-pong): waves 4-7 run one barrier behind waves 0-3 and every phase has TWO barriers, [stage + fragment reads + waits] | A |
 // [16 MFMAs] | B |, so that while one wave of a SIMD multiplies, the other one reads its fragments and issues the staging: LDS
 // reads (28 ds_read_b128 per wave and K-tile, as many LDS cycles per CU as a SIMD has MFMA cycles) leave the critical path.
@@ -134,7 +153,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Wb), 0, 0x7fffffff, 0x00020000);
     const int srow = lane >> 3, sslot = lane & 7;          // this lane's row within a 1 KiB chunk / 16-byte slot
     const int rowbytes = K * ES;
-    int voffW[2], voffX[2][2], voffXn[2][2];               // W: relative to the half-tile's first row; X: absolute (rows past M re-read row M - 1: a ragged last tile-row)
+    // absolute byte offsets of this lane's two requests per half-tile, for this tile and (persistent form) the next one.  Rows past the tensors are CLAMPED: X rows past
+    // M re-read row M - 1 (a ragged last tile-row), W rows past the last one re-read it (a ragged last tile-column, GPT-2's N = 50257) -- their products are never stored
+    // (W: only the plain bf16 mode takes a ragged N and keeps absolute, clamped W offsets -- WABS; the other modes keep two offsets relative to the half-tile's first
+    // row, which then rides in the scalar offset: they have no registers to spare)
+    constexpr bool WABS = MODE == G_PLAIN;
+    int voffW[2][2], voffWn[2][2], voffX[2][2], voffXn[2][2];      // (relative form: row [0] only)
     auto x_offsets = [&](int (&vo)[2][2], int mm0) {
 #pragma unroll
         for (int half = 0; half < 2; ++half)
@@ -147,16 +171,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 vo[half][i] = min(mm0 + half * 128 + row, p.M - 1) * rowbytes + kslot * 16;
             }
     };
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-    {
-        const int row = (i * 8 + wave) * 8 + srow;             // chunk i * 8 + wave: 16 chunks of 8 rows
-        const int lslot = sslot ^ ((row >> 1) & 7);            // swizzle on the source address: LDS slot sslot of this row holds logical slot lslot
-        // fp8: a lane's operand is the 32 contiguous bytes k = 32 g .. (source chunks 2 g, 2 g + 1); they are kept at the logical slots g and 4 + g the
-        // bf16 fragments use, so the fragment reads are the same conflict-free pattern (read as 2 g + ks they pair up on the banks: 2-way conflicts)
-        const int kslot = FP8 ? (((lslot & 3) << 1) | (lslot >> 2)) : lslot;
-        voffW[i] = row * rowbytes + kslot * 16;
-    }
+    auto w_offsets = [&](int (&vo)[2][2], int wrow0_, int wrow1_) {
+        gemm256_w_offsets<WABS, FP8>(vo, wrow0_, wrow1_, wave, srow, sslot, rowbytes, p.N);
+    };
+    w_offsets(voffW, n0, wrow1);
     x_offsets(voffX, m0);
     auto stage = [&](int kt_flat, bool isX, int half) {
         // persistent form: K-tile nk + k is K-tile k of the workgroup's NEXT tile (nk is even there, so the buffer parity runs on)
@@ -164,13 +182,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
         const int kt = nxt ? kt_flat - nk : kt_flat;
         unsigned char* dst_half = smem + (kt & 1) * kBufBytes + half_off(isX, half);
         const int wrow = nxt ? (half ? xwrow1 : xn0) : (half ? wrow1 : n0);
-        const int soff = __builtin_amdgcn_readfirstlane(isX ? kt * 128 : wrow * rowbytes + kt * 128);
+        const int soff = __builtin_amdgcn_readfirstlane((isX || WABS) ? kt * 128 : wrow * rowbytes + kt * 128);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
         {
             const int chunk = i * 8 + wave;
             if (isX) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(dst_half + chunk * 1024), 16, nxt ? voffXn[half][i] : voffX[half][i], soff, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(dst_half + chunk * 1024), 16, voffW[i], soff, 0, 0);
+            else if constexpr (WABS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(dst_half + chunk * 1024), 16, nxt ? voffWn[half][i] : voffW[half][i], soff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(dst_half + chunk * 1024), 16, voffW[0][i], soff, 0, 0);
         }
     };
 
@@ -337,6 +356,54 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 }
                 return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             };
+            if constexpr (!FP8)
+            {
+                if (n0 + 256 > p.N)
+                {
+                    // the ragged last tile-column (N % 256 != 0): element stores under a column mask
+    #pragma unroll
+                    for (int hA = 0; hA < 2; ++hA)
+    #pragma unroll
+                        for (int hB = 0; hB < 2; ++hB)
+    #pragma unroll
+                            for (int pt = 0; pt < 4; ++pt)
+    #pragma unroll
+                                for (int qt = 0; qt < 2; ++qt)
+                                {
+                                    const int n = n0 + hA * 128 + wr * 64 + pt * 16 + 4 * g;
+                                    const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                                    uint16_t* y = p.Y + (size_t)m * p.N + n;
+    #pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (n + e < p.N && m < p.M)
+                                        {
+                                            float v = acc[hA][hB][pt][qt][e];
+                                            if (p.bias) v = round_bf16(v) + bf16_bits_to_f32(p.bias[n + e]);
+                                            if (p.act) v = gelu_tanh(round_bf16(v));
+                                            y[e] = f32_to_bf16_bits(v);
+                                        }
+                                }
+                    return;
+                }
+                if ((p.N & 7) != 0)
+                {
+                    // whole tile of an output whose row pitch is no multiple of 16 bytes: the paired 16-byte stores at 2-byte alignment
+    #pragma unroll
+                    for (int hA = 0; hA < 2; ++hA)
+    #pragma unroll
+                        for (int hB = 0; hB < 2; ++hB)
+    #pragma unroll
+                            for (int pp = 0; pp < 4; pp += 2)
+    #pragma unroll
+                                for (int qt = 0; qt < 2; ++qt)
+                                {
+                                    const int nb = n0 + hA * 128 + wr * 64 + pp * 16;
+                                    const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                                    store_pair16<false>(p.Y + (size_t)m * p.N + nb, g, out4(hA, hB, pp, qt, m, nb + 4 * g), out4(hA, hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
+                                }
+                    return;
+                }
+            }
     #pragma unroll
             for (int hA = 0; hA < 2; ++hA)
     #pragma unroll
@@ -383,14 +450,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
         // stores, not a prologue's memory latency plus the write burst of every CU at once.
         // (kEpilogueStores = 8 with the GeGLU epilogue, 16 with the plain one: the vmcnt(8 + kEpilogueStores) below)
         const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+        bool prev_edge = false;
         for (int j = 0; j < my_tiles; ++j)
         {
             const bool has_next = j + 1 < my_tiles;
-            if (has_next) { tile_origin(blockIdx.x + (j + 1) * gridDim.x, xm0, xn0, xwrow1); x_offsets(voffXn, xm0); }
+            if (has_next)
+            {
+                tile_origin(blockIdx.x + (j + 1) * gridDim.x, xm0, xn0, xwrow1);
+                x_offsets(voffXn, xm0);
+                if constexpr (WABS) w_offsets(voffWn, xn0, xwrow1);
+            }
             for (int t = 0; t < nk; ++t)
             {
                 const bool steady = (t + 2 < nk) || has_next;
-                const bool post = j > 0 && t == 0;                // the previous tile's stores are still in flight
+                // the previous tile's stores are still in flight -- kEpilogueStores of them, counted; a tile on the ragged edge of Y issues another number (masked rows:
+                // possibly fewer), so behind such a tile the wait is the plain one (its stores are retired with it)
+                const bool post = j > 0 && t == 0 && !prev_edge;
                 auto reads_done = [&]() {
                     if (!steady) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     else if (post) { if constexpr (GEGLU) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); }
@@ -413,13 +488,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 mma_end();
             }
             epilogue();
+            prev_edge = m0 + 256 > p.M || n0 + (GEGLU ? 128 : 256) > p.N;
             if (has_next)
             {
                 m0 = xm0; n0 = xn0; wrow1 = xwrow1;
 #pragma unroll
                 for (int h_ = 0; h_ < 2; ++h_)
 #pragma unroll
-                    for (int i_ = 0; i_ < 2; ++i_) voffX[h_][i_] = voffXn[h_][i_];
+                    for (int i_ = 0; i_ < 2; ++i_)
+                    {
+                        voffX[h_][i_] = voffXn[h_][i_];
+                        if constexpr (WABS) voffW[h_][i_] = voffWn[h_][i_];
+                    }
                 zero_acc();
             }
         }
@@ -879,6 +959,15 @@ bool gemm256_applicable(int M, int K, int N)
     return tiles >= 200 && tiles >= 0.85 * rounds * kNumCU;
 }
 
+// bf16 only: N of any size (ragged last tile-column, any row pitch) on the PERSISTENT 256 x 256 schedule when the grid is many rounds deep -- GPT-2's lm_head
+// (N = 50257: 6 304 tiles at M = 8192, K = 768).  A tile there is 12 K-tiles, as long as what a one-tile workgroup pays around them (launch, first-load latency, the
+// store drain): the persistent walk overlaps all three with the next tile's K loop
+bool gemm256_ragged_n_applicable(int M, int K, int N)
+{
+    if (M % 256 != 0 || K % 128 != 0 || N % 256 == 0 || !lds_dma_addressable(M, K, N)) return false;
+    return (int64_t)(M / 256) * ((N + 255) / 256) >= 4 * kNumCU;
+}
+
 int g_gemm_persistent = 1;    // tuning: schedule 6 = schedule 5 with one workgroup per tile (not persistent)
 int g_gemm_pingpong = 5;      // tuning hook (mila_cdna4_tune_gemm_schedule): 0 = all eight waves in lockstep; 1 = staggered (ping-pong), four phases per
                               // K-tile in the 256 x 256 kernel; 2 = 1 + prefer the 256 x 128 ring; 3 = staggered, two phases per K-tile in the
@@ -920,7 +1009,7 @@ static int launch_gemm256_t(const Gemm256Params& p, hipStream_t s)
 
 int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act)
 {
-    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, N / 256, nullptr, nullptr, act};
+    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, (N + 255) / 256, nullptr, nullptr, act};
     return launch_gemm256_t<G_PLAIN>(p, s);
 }
 

@@ -652,13 +652,13 @@ def test_ragged_prompt_lengths_split_between_the_lds_dma_and_the_128_tile_kernel
     assert_bf16_close(bits(Y)[rows], orc.linear_bf16w(X[rows], Wdq), 1, 2e-3, "ragged staged fp4 gemm")
 
 
-@pytest.mark.parametrize("N,bias", [(50257, True), (50257 - 128 + 3, False)])
-def test_lds_dma_gemm_serves_a_ragged_n_with_an_odd_row_pitch(N, bias):
+@pytest.mark.parametrize("M,K,N,bias", [(768, 192, 50257, True), (768, 192, 50257 - 128 + 3, False),      # 256 x 128 tiles (K-tile count odd)
+                                        (1536, 256, 50257, True), (1280, 128, 50257 - 256 + 8, False)])     # persistent 256 x 256 tiles (round 3: GPT-2's lm_head)
+def test_lds_dma_gemm_serves_a_ragged_n_with_an_odd_row_pitch(M, K, N, bias):
     """GPT-2's lm_head (GptTransformer.ixx:854-855: Linear(768 -> 50257), no bias there; bias exercised here too): N is no multiple of the 128-column tile and the output
     row pitch no multiple of 16 bytes -- the 256 x 128 LDS-DMA kernel takes it with a clamped last W tile and element stores under a column mask (round 3; it
     used to fall to the 128-tile register-staged kernel at 1.6 ms of config 2's 6.8).  Rows / columns around every edge against the float64 oracle, and the
     whole output against the 128-tile kernel within 1 bf16 ulp (another MFMA shape, same math)"""
-    M, K = 768, 192
     lib = capi.load()
     rng = np.random.default_rng(N)
     Wb = _weights(rng, N, K, "random")
@@ -675,6 +675,14 @@ def test_lds_dma_gemm_serves_a_ragged_n_with_an_odd_row_pitch(N, bias):
     if bias:
         exp = orc.round_bf16(exp).astype(np.float64) + orc.from_bf16_bits(bb).astype(np.float64)
     assert_bf16_close(got[rows], exp, 2 if bias else 1, 2e-3, "ragged-N gemm_bf16")
+    if K % 128 == 0:      # the 256 x 256 and the 256 x 128 LDS-DMA kernels accumulate every output in the same order: same bits
+        Y3 = torch.empty((M, N), dtype=torch.int16, device="cuda")
+        capi.check(lib.mila_cdna4_tune_gemm_schedule(2))
+        try:
+            capi.call("gemm_bf16", Y3, Xd, Wd, dev_u16(bb) if bias else None, M, K, N)
+        finally:
+            capi.check(lib.mila_cdna4_tune_gemm_schedule(5))
+        assert np.array_equal(got, bits(Y3)), "256 x 256 ragged-N tiles differ from the 256 x 128 ones"
     Y2 = torch.empty((M, N), dtype=torch.int16, device="cuda")
     capi.check(lib.mila_cdna4_tune_gemm(1))
     try:
@@ -689,6 +697,7 @@ def test_lds_dma_gemm_serves_a_ragged_n_with_an_odd_row_pitch(N, bias):
 @pytest.mark.parametrize("M,K,N,bias", [(2048, 256, 3072, True),      # 256 x 256 LDS-DMA tiles (GPT-2 fc_1's N)
                                         (1024, 128, 3200, True),      # 256 x 128 tiles (N % 256 != 0)
                                         (768, 192, 50257 - 128 + 3, True),      # 256 x 128 tiles with the ragged-N element epilogue
+                                        (1536, 128, 50257, True),               # persistent 256 x 256 tiles with a ragged last tile-column
                                         (300, 136, 520, True), (300, 136, 520, False),      # main rows on LDS-DMA tiles + a 44-row rest on the 128-tile register kernel
                                         (7, 64, 96, True)])           # 128-tile register kernel only
 def test_gemm_with_gelu_epilogue_is_bit_identical_to_gemm_then_gelu(M, K, N, bias):

@@ -113,7 +113,9 @@ def test_gelu_residual_scale(n):
     Z = _bf(rng.standard_normal(n))
     Y = empty_u16(n)
     capi.call("gelu_bf16", Y, _d(X), C.c_int64(n))
-    assert_bf16_close(bits(Y), orc.cpu_gelu(X), 1, 1e-30, "gelu_bf16")
+    # 1 bf16 ulp, or 1e-6 absolute: the oracle restates the reference's float functor 0.5 x (1 + tanhf(u)), whose (1 + tanhf) cancels to 0 below x ~ -5.2 (absolute
+    # error 0.5 |x| 2^-24); the device evaluates the same function as x / (1 + exp(-2 u)), which keeps the tail (-5e-8 where the functor gives -0)
+    assert_bf16_close(bits(Y), orc.cpu_gelu(X), 1, 1e-6, "gelu_bf16")
     Yf = empty_f32(n)
     capi.call("gelu_fp32", Yf, dev_f32(X), C.c_int64(n))
     np.testing.assert_allclose(host(Yf), orc.cpu_gelu(X), atol=1e-6, rtol=1e-5)
@@ -132,7 +134,7 @@ def test_geglu(tokens, half):
     X = _bf(rng.standard_normal((tokens, 2 * half)) * 2)
     Y = empty_u16(tokens, half)
     capi.call("geglu_bf16", Y, _d(X), tokens, half)
-    assert_bf16_close(bits(Y), orc.geglu(X), 1, 1e-30, "geglu")
+    assert_bf16_close(bits(Y), orc.geglu(X), 1, 1e-5, "geglu")      # absolute floor: see test_gelu_residual_scale (times |up| <= ~10)
 
 
 @pytest.mark.parametrize("HS,base,rot", [(256, 1e4, 0), (512, 1e6, 128), (64, 1e4, 0), (8 * 2, 1e4, 4 * 2)])
