@@ -608,12 +608,19 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     constexpr int ES = FP8 ? 1 : 2;
     constexpr int KT = 128 / ES;
 
-    const int nwg = gridDim.x, id = blockIdx.x;
-    const int xcd = id & 7, qd = nwg >> 3, rem = nwg & 7;
-    const int tile = ((xcd < rem) ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (id >> 3);
-    int tm, tn;
-    grouped_tile(tile, p.tiles_m, p.tiles_n, tm, tn);
-    const int m0 = tm * 256, n0 = tn * (GEGLU ? 64 : 128);
+    // Workgroup id -> tiles id, id + gridDim.x, ...: the launcher starts one workgroup per tile, or (staggered schedules, PERSISTENT) one per CU walking its tiles --
+    // the XCD remap is taken over the whole tile list, so a workgroup's later tiles are the ones the dispatcher would have handed to its XCD anyway
+    const int ntiles = p.tiles_m * p.tiles_n;
+    auto tile_origin = [&](int idv, int& m0_, int& n0_) {
+        const int xcd = idv & 7, qd = ntiles >> 3, rem = ntiles & 7;
+        const int tile = ((xcd < rem) ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (idv >> 3);
+        int tm, tn;
+        grouped_tile(tile, p.tiles_m, p.tiles_n, tm, tn);
+        m0_ = tm * 256;
+        n0_ = tn * (GEGLU ? 64 : 128);
+    };
+    int m0, n0, xm0 = 0, xn0 = 0;       // this tile and (persistent form) the next one
+    tile_origin(blockIdx.x, m0, n0);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -624,49 +631,57 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
 
     const int srow = lane >> 3, sslot = lane & 7;
-    // which: 0 = W rows n0 .., 1 = X rows m0 .., 2 = X rows m0 + 128 ..   `buffer_load ... lds`, per-lane offsets computed once (see gemm256_kernel)
+    // which: 0 = W rows n0 .., 1 = X rows m0 .., 2 = X rows m0 + 128 ..   `buffer_load ... lds`, per-lane offsets computed once per tile (see gemm256_kernel)
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Xb), 0, 0x7fffffff, 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Wb), 0, 0x7fffffff, 0x00020000);
     const int rowbytes = K * ES;
-    int voff[3][2];
+    int voff[3][2], voffn[3][2];
+    auto offsets = [&](int (&vo)[3][2], int mm0, int nn0) {
 #pragma unroll
-    for (int which = 0; which < 3; ++which)
+        for (int which = 0; which < 3; ++which)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-        {
-            const int row = (i * 8 + wave) * 8 + srow;
-            const int lslot = sslot ^ ((row >> 1) & 7);
-            const int kslot = FP8 ? (((lslot & 3) << 1) | (lslot >> 2)) : lslot;      // as in gemm256_kernel
-            int grow;
-            if (which == 0)
+            for (int i = 0; i < 2; ++i)
             {
-                if constexpr (GEGLU) { const int q = row & 63; grow = (q < 32 ? 0 : p.N - 32) + n0 + (row >> 6) * 32 + q; }   // N = F: up rows start at F
-                else grow = min(n0 + row, p.N - 1);      // W rows past N (a ragged last column tile) re-read row N - 1, never stored
+                const int row = (i * 8 + wave) * 8 + srow;
+                const int lslot = sslot ^ ((row >> 1) & 7);
+                const int kslot = FP8 ? (((lslot & 3) << 1) | (lslot >> 2)) : lslot;      // as in gemm256_kernel
+                int grow;
+                if (which == 0)
+                {
+                    if constexpr (GEGLU) { const int q = row & 63; grow = (q < 32 ? 0 : p.N - 32) + nn0 + (row >> 6) * 32 + q; }   // N = F: up rows start at F
+                    else grow = min(nn0 + row, p.N - 1);      // W rows past N (a ragged last column tile) re-read row N - 1, never stored
+                }
+                else grow = min(mm0 + (which - 1) * 128 + row, p.M - 1);      // X rows past M (ragged last tile-row) re-read row M - 1, never stored
+                vo[which][i] = grow * rowbytes + kslot * 16;
             }
-            else grow = min(m0 + (which - 1) * 128 + row, p.M - 1);      // X rows past M (ragged last tile-row) re-read row M - 1, never stored
-            voff[which][i] = grow * rowbytes + kslot * 16;
-        }
-    auto stage = [&](int kt, int which) {
-        unsigned char* dst_half = smem + (kt % 3) * kStage3Bytes + which * kHalfBytes;
-        const int soff = __builtin_amdgcn_readfirstlane(kt * 128);
+    };
+    offsets(voff, m0, n0);
+    // K-tile `kt` of this tile (kt < nk) or K-tile kt - nk of the workgroup's next tile, into ring slot `flat` % 3 (flat = K-tiles since the workgroup started)
+    auto stage = [&](int flat, int kt, int which) {
+        const bool nxt = kt >= nk;
+        unsigned char* dst_half = smem + (flat % 3) * kStage3Bytes + which * kHalfBytes;
+        const int soff = __builtin_amdgcn_readfirstlane((nxt ? kt - nk : kt) * 128);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
         {
             const int chunk = i * 8 + wave;
-            if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(dst_half + chunk * 1024), 16, voff[0][i], soff, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(dst_half + chunk * 1024), 16, voff[which][i], soff, 0, 0);
+            if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(dst_half + chunk * 1024), 16, nxt ? voffn[0][i] : voff[0][i], soff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(dst_half + chunk * 1024), 16, nxt ? voffn[which][i] : voff[which][i], soff, 0, 0);
         }
     };
-    auto stage_all = [&](int kt) { stage(kt, 0); stage(kt, 1); stage(kt, 2); };
+    auto stage_all = [&](int flat, int kt) { stage(flat, kt, 0); stage(flat, kt, 1); stage(flat, kt, 2); };
 
     f32x4 acc[2][4][2];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int d = 0; d < 2; ++d) acc[b][c][d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                for (int d = 0; d < 2; ++d) acc[b][c][d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    };
+    zero_acc();
 
     s16x8 fa[4][2], fb[2][2], fb1[PP ? 2 : 1][2];          // PP keeps the fragments of both X halves live
     auto frag_slot = [&](int ks) { return ks * 4 + g; };
@@ -726,54 +741,46 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
         if constexpr (PP != 2) __builtin_amdgcn_s_setprio(0);
     };
 
-    stage_all(0);
-    if (nk > 1) stage_all(1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    if constexpr (PP != 0)
-    {
-        if constexpr (PP == 2) { if (wr == 1) __builtin_amdgcn_s_setprio(1); }
-        if (wr == 1) __builtin_amdgcn_s_barrier();
-        for (int t = 0; t < nk; ++t)
+    auto epilogue = [&]() {
+        if constexpr (GEGLU)
         {
-            const bool more = t + 2 < nk;
-            if (more) stage_all(t + 2);
-            load_a(t);
-            load_b(t, 0);
-            load_b(t, 1);
-            if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            mma(0);
-            mma(1);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
+            // fp8 epilogue scales, fetched ONCE before the stores: read inside the store loop they are re-fetched after every store (the compiler cannot
+            // prove that Y does not alias them) -- a dependent global load in front of each of the 16 stores, 7-11 us per tile
+            float ws_ = 1.0f, tsv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+            if constexpr (FP8)
+            {
+                ws_ = *p.w_scale;
+            #pragma unroll
+                for (int hb_ = 0; hb_ < 2; ++hb_)
+            #pragma unroll
+                    for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[min(m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15, p.M - 1)];
+            }
+            auto out4 = [&](int hB, int pt, int qt, int m) -> u32x2 {
+                float v[4];
+                if constexpr (FP8)
+                {
+                    const float ws = ws_, ts = tsv[hB][qt];
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = gelu_tanh(round_bf16(round_bf16(acc[hB][pt][qt][e] * ws) * ts)) * round_bf16(round_bf16(acc[hB][pt + 2][qt][e] * ws) * ts);
+                }
+                else
+                {
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(round_bf16(acc[hB][pt][qt][e])) * round_bf16(acc[hB][pt + 2][qt][e]);
+                }
+                return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            };
+    #pragma unroll
+            for (int hB = 0; hB < 2; ++hB)
+    #pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                {
+                    const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                    store_pair16(p.Y + (size_t)m * p.N + n0 + wr * 32, g, out4(hB, 0, qt, m), out4(hB, 1, qt, m), m < p.M);
+                }
+            return;
         }
-        if (wr == 0) __builtin_amdgcn_s_barrier();
-    }
-    else
-    {
-        for (int t = 0; t < nk; ++t)
-        {
-            const bool more = t + 2 < nk;
-            if (more) stage_all(t + 2);
-            load_a(t);
-            load_b(t, 0);
-            mma(0);
-            load_b(t, 1);
-            mma(1);
-            if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-    }
-
-    if constexpr (GEGLU)
-    {
         // fp8 epilogue scales, fetched ONCE before the stores: read inside the store loop they are re-fetched after every store (the compiler cannot
         // prove that Y does not alias them) -- a dependent global load in front of each of the 16 stores, 7-11 us per tile
         float ws_ = 1.0f, tsv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
@@ -785,122 +792,162 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
         #pragma unroll
                 for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[min(m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15, p.M - 1)];
         }
-        auto out4 = [&](int hB, int pt, int qt, int m) -> u32x2 {
+        auto out4 = [&](int hB, int pt, int qt, int m, int n) -> u32x2 {
             float v[4];
+    #pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[hB][pt][qt][e];
             if constexpr (FP8)
             {
                 const float ws = ws_, ts = tsv[hB][qt];
-#pragma unroll
+    #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    v[e] = gelu_tanh(round_bf16(round_bf16(acc[hB][pt][qt][e] * ws) * ts)) * round_bf16(round_bf16(acc[hB][pt + 2][qt][e] * ws) * ts);
+                {
+                    v[e] = round_bf16(v[e] * ws) * ts;
+                    if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
+                }
             }
-            else
+            else if (p.bias)
             {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(round_bf16(acc[hB][pt][qt][e])) * round_bf16(acc[hB][pt + 2][qt][e]);
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
+            }
+            if (!FP8 && p.act)
+            {
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(round_bf16(v[e]));
             }
             return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         };
-#pragma unroll
-        for (int hB = 0; hB < 2; ++hB)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-            {
-                const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                store_pair16(p.Y + (size_t)m * p.N + n0 + wr * 32, g, out4(hB, 0, qt, m), out4(hB, 1, qt, m), m < p.M);
-            }
-        return;
-    }
-    // fp8 epilogue scales, fetched ONCE before the stores: read inside the store loop they are re-fetched after every store (the compiler cannot
-    // prove that Y does not alias them) -- a dependent global load in front of each of the 16 stores, 7-11 us per tile
-    float ws_ = 1.0f, tsv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
-    if constexpr (FP8)
-    {
-        ws_ = *p.w_scale;
+        if (!FP8 && (p.N & 7) != 0 && n0 + 128 <= p.N)
+        {
+            // an output row pitch that is not a multiple of 16 bytes (GPT-2's lm_head: N = 50257), whole tile: the paired 16-byte stores at 2-byte alignment
     #pragma unroll
-        for (int hb_ = 0; hb_ < 2; ++hb_)
+            for (int hB = 0; hB < 2; ++hB)
     #pragma unroll
-            for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[min(m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15, p.M - 1)];
-    }
-    auto out4 = [&](int hB, int pt, int qt, int m, int n) -> u32x2 {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[hB][pt][qt][e];
-        if constexpr (FP8)
-        {
-            const float ws = ws_, ts = tsv[hB][qt];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-            {
-                v[e] = round_bf16(v[e] * ws) * ts;
-                if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
-            }
+                for (int pp = 0; pp < 4; pp += 2)
+    #pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                    {
+                        const int nb = n0 + wr * 64 + pp * 16;
+                        const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                        store_pair16<false>(p.Y + (size_t)m * p.N + nb, g, out4(hB, pp, qt, m, nb + 4 * g), out4(hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
+                    }
+            return;
         }
-        else if (p.bias)
+        if (!FP8 && n0 + 128 > p.N)
         {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
+            // the ragged last column tile: element stores under a column mask
+    #pragma unroll
+            for (int hB = 0; hB < 2; ++hB)
+    #pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+    #pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                    {
+                        const int n = n0 + wr * 64 + pt * 16 + 4 * g;
+                        const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                        if (m >= p.M) continue;
+                        uint16_t* y = p.Y + (size_t)m * p.N + n;
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N)
+                            {
+                                float v = acc[hB][pt][qt][e];
+                                if (p.bias) v = round_bf16(v) + bf16_bits_to_f32(p.bias[n + e]);
+                                if (p.act) v = gelu_tanh(round_bf16(v));
+                                y[e] = f32_to_bf16_bits(v);
+                            }
+                    }
+            return;
         }
-        if (!FP8 && p.act)
-        {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(round_bf16(v[e]));
-        }
-        return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-    };
-    if (!FP8 && (p.N & 7) != 0 && n0 + 128 <= p.N)
-    {
-        // an output row pitch that is not a multiple of 16 bytes (GPT-2's lm_head: N = 50257), whole tile: the paired 16-byte stores at 2-byte alignment
-#pragma unroll
+    #pragma unroll
         for (int hB = 0; hB < 2; ++hB)
-#pragma unroll
+    #pragma unroll
             for (int pp = 0; pp < 4; pp += 2)
-#pragma unroll
+    #pragma unroll
                 for (int qt = 0; qt < 2; ++qt)
                 {
                     const int nb = n0 + wr * 64 + pp * 16;
                     const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                    store_pair16<false>(p.Y + (size_t)m * p.N + nb, g, out4(hB, pp, qt, m, nb + 4 * g), out4(hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
+                    store_pair16(p.Y + (size_t)m * p.N + nb, g, out4(hB, pp, qt, m, nb + 4 * g), out4(hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
                 }
-        return;
-    }
-    if (!FP8 && n0 + 128 > p.N)
+    };
+
+    stage_all(0, 0);
+    if (nk > 1) stage_all(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    if constexpr (PP != 0)
     {
-        // the ragged last column tile: element stores under a column mask
-#pragma unroll
-        for (int hB = 0; hB < 2; ++hB)
-#pragma unroll
-            for (int pt = 0; pt < 4; ++pt)
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
-                {
-                    const int n = n0 + wr * 64 + pt * 16 + 4 * g;
-                    const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                    if (m >= p.M) continue;
-                    uint16_t* y = p.Y + (size_t)m * p.N + n;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < p.N)
-                        {
-                            float v = acc[hB][pt][qt][e];
-                            if (p.bias) v = round_bf16(v) + bf16_bits_to_f32(p.bias[n + e]);
-                            if (p.act) v = gelu_tanh(round_bf16(v));
-                            y[e] = f32_to_bf16_bits(v);
-                        }
-                }
-        return;
-    }
-#pragma unroll
-    for (int hB = 0; hB < 2; ++hB)
-#pragma unroll
-        for (int pp = 0; pp < 4; pp += 2)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
+        // PERSISTENT (round 3): the K loop runs on across the workgroup's tiles.  The ring keeps turning (slot = K-tiles since the start % 3), the last two K-tiles
+        // of a tile request the first two of the next one, and the epilogue's stores are issued and NOT waited for: they drain under the next tile's first K-tile,
+        // whose wait allows kStores more operations in flight (vmcnt counts loads and stores together, in order).  A tile then costs its K loop and the issue of its
+        // stores -- not a launch, a first-load latency and a store drain per tile, which at K = 768 (GPT-2: 12 K-tiles) were as long as the K loop itself.
+        constexpr int kStores = GEGLU ? 4 : 8;            // 16-byte stores per lane of a whole tile's epilogue
+        if constexpr (PP == 2) { if (wr == 1) __builtin_amdgcn_s_setprio(1); }
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+        int base = 0;                                     // K-tiles before this tile
+        bool prev_edge = false;
+        for (int j = 0; j < my_tiles; ++j)
+        {
+            const bool has_next = j + 1 < my_tiles;
+            if (has_next) { tile_origin(blockIdx.x + (j + 1) * gridDim.x, xm0, xn0); offsets(voffn, xm0, xn0); }
+            for (int t = 0; t < nk; ++t)
             {
-                const int nb = n0 + wr * 64 + pp * 16;
-                const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                store_pair16(p.Y + (size_t)m * p.N + nb, g, out4(hB, pp, qt, m, nb + 4 * g), out4(hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
+                const bool more = t + 2 < nk || (has_next && t + 2 - nk < nk);
+                // the previous tile's stores sit between K-tile 1's requests and K-tile 2's: counted, unless that tile lay on a ragged edge of Y (another number of
+                // stores, possibly fewer: the plain wait retires them all)
+                const bool post = j > 0 && t == 0 && !prev_edge;
+                if (more) stage_all(base + t + 2, t + 2);
+                load_a(base + t);
+                load_b(base + t, 0);
+                load_b(base + t, 1);
+                if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (post) { if constexpr (GEGLU) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                mma(0);
+                mma(1);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
             }
+            epilogue();
+            prev_edge = m0 + 256 > p.M || n0 + (GEGLU ? 64 : 128) > p.N;
+            if (has_next)
+            {
+                m0 = xm0; n0 = xn0; base += nk;
+#pragma unroll
+                for (int w_ = 0; w_ < 3; ++w_)
+#pragma unroll
+                    for (int i_ = 0; i_ < 2; ++i_) voff[w_][i_] = voffn[w_][i_];
+                zero_acc();
+            }
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        static_assert(kStores == (GEGLU ? 4 : 8), "the post waits above are 6 + kStores");
+    }
+    else
+    {
+        for (int t = 0; t < nk; ++t)
+        {
+            const bool more = t + 2 < nk;
+            if (more) stage_all(t + 2, t + 2);
+            load_a(t);
+            load_b(t, 0);
+            mma(0);
+            load_b(t, 1);
+            mma(1);
+            if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        epilogue();
+    }
 }
 
 // the LDS-DMA kernels address their operands through 32-bit buffer offsets (bytes, signed int arithmetic): both tensors must stay below 2 GiB
@@ -923,6 +970,7 @@ bool gemm256x128_ragged_n_applicable(int M, int K, int N)
 }
 
 extern int g_gemm_pingpong;
+extern int g_gemm_persistent;
 
 template <bool FP8, bool GEGLU, int PP>
 static int launch_gemm256x128_tt(const Gemm256Params& p, hipStream_t s)
@@ -935,7 +983,10 @@ static int launch_gemm256x128_tt(const Gemm256Params& p, hipStream_t s)
         if (rc) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256x128_kernel<FP8, GEGLU, PP>), dim3(p.tiles_m * p.tiles_n), dim3(512), 3 * kStage3Bytes, s, p);
+    // staggered schedules walk their tiles PERSISTENTLY (one workgroup per CU) once there are more tiles than CUs and a tile has at least two K-tiles
+    const int tiles = p.tiles_m * p.tiles_n, nk = p.K / (FP8 ? 128 : 64);
+    const int grid = (PP != 0 && nk >= 2 && g_gemm_persistent && tiles > kNumCU) ? kNumCU : tiles;
+    hipLaunchKernelGGL((gemm256x128_kernel<FP8, GEGLU, PP>), dim3(grid), dim3(512), 3 * kStage3Bytes, s, p);
     MILA_LAUNCH_CHECK("gemm256x128");
 }
 template <bool FP8, bool GEGLU = false>

@@ -87,11 +87,12 @@ def test_full_width_prefill_and_decode_compute_the_same_function(six_layers):
 @pytest.mark.parametrize("policy", ["bf16", "fp4"])
 def test_full_size_gemm_schedules_give_the_same_bits(policy, bf16_run):
     """lockstep vs ping-pong schedules accumulate in the same order: identical prefill logits on the real shapes (the fp4 policy
-    compares the two staggered forms that keep its fp8 shapes on the same kernels: 1 vs 3)"""
+    compares the two staggered forms that keep its fp8 shapes on the same kernels: 1 vs 3); and schedule 6 -- the default with one workgroup per tile
+    instead of the persistent tile walk of both LDS-DMA kernels -- gives the same bits again"""
     lib = capi.load()
     outs = []
     try:
-        for sched in ((0, 3) if policy == "bf16" else (1, 3)):
+        for sched in ((0, 3, 6) if policy == "bf16" else (1, 3, 6)):
             capi.check(lib.mila_cdna4_tune_gemm_schedule(sched))       # an inert hook (MILA_CDNA4_TUNING unset) must fail the test, not compare the default with itself
             g = host.Gemma(policy, max_seq=T + 16, max_prefill=T, seed=1234)
             outs.append(g.prefill(TOKS))
@@ -99,6 +100,7 @@ def test_full_size_gemm_schedules_give_the_same_bits(policy, bf16_run):
     finally:
         capi.check(lib.mila_cdna4_tune_gemm_schedule(5))      # the default
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert np.array_equal(outs[2].view(np.uint32), outs[1].view(np.uint32))
     if policy == "bf16":
         assert np.array_equal(outs[1].view(np.uint32), bf16_run["prefill"].view(np.uint32))
 

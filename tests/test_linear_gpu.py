@@ -723,3 +723,50 @@ def test_gemm_with_gelu_epilogue_is_bit_identical_to_gemm_then_gelu(M, K, N, bia
     assert_bf16_close(bits(Y1)[rows], exp, 2, 2e-3, "gemm+gelu vs oracle")
     with pytest.raises(capi.InvalidArgument):
         capi.call("gemm_gelu_bf16", Y1, Xd, Wd, bd, M, K + 4, N)
+
+
+@pytest.mark.parametrize("M,K,N,act", [(2048, 256, 8704, 0),       # 544 tiles of 256 x 128: 2.1 tiles per workgroup
+                                       (8192, 128, 3072, 1),       # GPT-2 fc_1 + GELU: 768 tiles, exactly 3 per workgroup, two K-tiles per tile
+                                       (1024, 192, 50257, 0),      # ragged last tile-column behind whole tiles (odd pitch), three K-tiles (the ring's period)
+                                       (2048, 512, 30720, 0)])     # 960 tiles of 256 x 256 (the two-phase schedule was persistent before round 3)
+def test_persistent_tile_walk_gives_the_bits_of_one_workgroup_per_tile(M, K, N, act):
+    """round 3: the 256 x 128 ring walks its tiles persistently like the 256 x 256 schedule -- one workgroup per CU, the K pipeline running on across tiles, the epilogue's
+    stores draining under the next tile's first K-tile.  Schedule 6 is the same kernels with one workgroup per tile: every output must have the same bits, for bf16
+    (+ bias, + GELU), and for the fp8 x fp8 forms (plain and GeGLU) of the same shapes"""
+    lib = capi.load()
+    rng = np.random.default_rng(N + M)
+    X = orc.round_bf16(rng.uniform(-1, 1, (M, K)).astype(np.float32))
+    Wb = _weights(rng, N, K, "random")
+    bb = orc.to_bf16_bits(rng.uniform(-0.5, 0.5, N).astype(np.float32))
+    Xd, Wd, bd = dev_u16(orc.to_bf16_bits(X)), dev_u16(Wb), dev_u16(bb)
+    fp8 = K % 128 == 0 and N % 256 == 0
+    if fp8:
+        X8 = dev_u8(rng.integers(0, 0x7e, (M, K), dtype=np.uint8) | (rng.integers(0, 2, (M, K), dtype=np.uint8) << 7))      # finite e4m3 codes
+        W8 = dev_u8(rng.integers(0, 0x7e, (N, K), dtype=np.uint8) | (rng.integers(0, 2, (N, K), dtype=np.uint8) << 7))
+        ts_d, ws_d = dev_f32(rng.uniform(0.5, 2.0, M).astype(np.float32)), dev_f32(np.array([0.013], dtype=np.float32))
+    outs = []
+    for sched in (5, 6):
+        capi.check(lib.mila_cdna4_tune_gemm_schedule(sched))
+        try:
+            Y = torch.full((M, N), 0x7fc0, dtype=torch.int16, device="cuda")
+            capi.call("gemm_gelu_bf16" if act else "gemm_bf16", Y, Xd, Wd, bd, M, K, N)
+            o = [bits(Y).copy()]
+            if fp8:
+                Y8 = torch.full((M, N), 0x7fc0, dtype=torch.int16, device="cuda")
+                capi.call("gemm_fp8_scaled", Y8, X8, W8, ts_d, ws_d, bd, M, K, N)
+                o.append(bits(Y8).copy())
+                Yg = torch.full((M, N // 2), 0x7fc0, dtype=torch.int16, device="cuda")
+                capi.call("gemm_geglu_fp8_scaled", Yg, X8, W8, ts_d, ws_d, M, K, N // 2)
+                o.append(bits(Yg).copy())
+            outs.append(o)
+        finally:
+            capi.check(lib.mila_cdna4_tune_gemm_schedule(5))
+    for a, b, what in zip(outs[0], outs[1], ("bf16", "fp8 x fp8", "fp8 x fp8 + GeGLU")):
+        assert not np.any((a & 0x7fff) > 0x7f80), what + ": unwritten (NaN) outputs"
+        assert np.array_equal(a, b), what + ": persistent walk differs from one workgroup per tile"
+    rows = [0, 255, 256, M - 1]
+    exp = orc.round_bf16(orc.linear_bf16w(X[rows], Wb, None)).astype(np.float64) + orc.from_bf16_bits(bb).astype(np.float64)
+    if act:
+        h = orc.round_bf16(exp.astype(np.float32)).astype(np.float64)
+        exp = 0.5 * h * (1 + np.tanh(0.7978845608028654 * (h + 0.044715 * h ** 3)))
+    assert_bf16_close(outs[0][0][rows], exp, 2, 2e-3, "persistent gemm vs oracle")
