@@ -291,7 +291,7 @@ static int glds_kernel_for(int M, int K, int N)
     if (g_gemm_pingpong == 2 && gemm256x128_applicable(M, K, N)) return 1;      // tuning: the 256 x 128 ring wherever it applies
     if (gemm256_applicable(M, K, N)) return 2;
     if (gemm256x128_applicable(M, K, N)) return 1;
-    if (g_gemm_pingpong >= 3 && g_gemm_persistent && gemm256_ragged_n_applicable(M, K, N)) return 2;
+    if (g_gemm_pingpong >= 3 && gemm256_ragged_n_applicable(M, K, N)) return 2;
     if (gemm256x128_ragged_n_applicable(M, K, N)) return 1;
     return 0;
 }

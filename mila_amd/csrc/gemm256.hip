@@ -31,6 +31,7 @@ struct Gemm256Params
     // FP8 mode (W4A8 / W8A8 prefill): X and W are e4m3 bytes [M, K] / [N, K]; y = bf16(float(bf16(acc * *w_scale)) * x_scales[m] + bias)
     const float* x_scales;   // [M] per-token activation scales
     const float* w_scale;    // device scalar: per-tensor weight scale
+    int rowwise = 0;         // 256 x 256 plain bf16, one workgroup per tile: the tile goes through LDS and is written row by row (see rowwise_epilogue)
     int act = 0;             // bf16 plain epilogue: 1 = tanh-GELU on the stored Linear output, y = bf16(gelu(bf16(acc) [+ bias, rounded again])): Linear + Gelu of MLP.ixx:148-161 in one kernel
 #ifdef MILA_GEMM_SKIP
     int dbg = 0;             // diagnostic build (tools/experiments/gemm_skip.sh): leave out the staging (1), the fragment reads (2), the MFMAs (4), the plain epilogue's stores (8)
@@ -423,6 +424,68 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
         }
     };
 
+    // ---- row-wise epilogue (plain bf16, one workgroup per tile, called behind the last barrier: LDS is free) ----
+    // An output whose row pitch is no multiple of 128 bytes (GPT-2's logits: N = 50257) makes every 64-byte piece of the direct epilogue a partial cache line, and a line's
+    // pieces come from two waves at different moments: they reach HBM as read-modify-writes -- 1.4 TB/s where whole lines go at 5.7 (tools/experiments/unaligned_store.hip:
+    // the store WIDTH is irrelevant, 2-byte and 16-byte stores take the same time; what counts is that the pieces of a line are issued back to back).  So the tile is
+    // transposed through LDS ([256][256] bf16 = the two K-tile buffers, 16-byte chunks XOR-swizzled by the row: conflict-free both ways) and every wave writes
+    // whole 512-byte row segments, two rows per instruction: 3.7 TB/s on the odd pitch.
+    auto rowwise_epilogue = [&]() {
+        if constexpr (WABS)
+        {
+#pragma unroll
+            for (int hA = 0; hA < 2; ++hA)
+#pragma unroll
+                for (int hB = 0; hB < 2; ++hB)
+#pragma unroll
+                    for (int pp = 0; pp < 4; pp += 2)
+#pragma unroll
+                        for (int qt = 0; qt < 2; ++qt)
+                        {
+                            u32x2 ab[2];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+                            {
+                                const int n = n0 + hA * 128 + wr * 64 + (pp + h) * 16 + 4 * g;
+                                float v[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                {
+                                    v[e] = acc[hA][hB][pp + h][qt][e];
+                                    if (p.bias) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[min(n + e, p.N - 1)]);
+                                    if (p.act) v[e] = gelu_tanh(round_bf16(v[e]));
+                                }
+                                ab[h] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                            }
+                            // the exchange of store_pair16: an even-g lane ends with columns 4 g .. 4 g + 7 of sub-tile pp, an odd-g lane with 4 (g - 1) .. + 7 of sub-tile pp + 1
+                            const auto r0 = __builtin_amdgcn_permlane16_swap(ab[0][0], ab[1][0], false, false);
+                            const auto r1 = __builtin_amdgcn_permlane16_swap(ab[0][1], ab[1][1], false, false);
+                            const int lr = hB * 128 + wc * 32 + qt * 16 + l15;
+                            const int chunk = (hA * 128 + wr * 64 + pp * 16 + (g & 1) * 16 + 4 * (g & ~1)) >> 3;
+                            *reinterpret_cast<u32x4*>(smem + lr * 512 + ((chunk ^ (lr & 31)) << 4)) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+                        }
+            __syncthreads();
+            const int half = lane >> 5, chunk = lane & 31;
+            const int n = n0 + chunk * 8;
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i)
+            {
+                const int lr = wave * 32 + i * 2 + half;
+                const int m = m0 + lr;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + lr * 512 + ((chunk ^ (lr & 31)) << 4));
+                if (m >= p.M) continue;
+                uint16_t* y = p.Y + (size_t)m * p.N + n;
+                if (n + 8 <= p.N) st16_a2(y, v);
+                else
+                {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < p.N) y[e] = (uint16_t)(v[e >> 1] >> ((e & 1) * 16));
+                }
+            }
+        }
+    };
+
     // ---- prologue: K-tile 0 complete, W0 / X1 of K-tile 1 in flight (PP == 2: W0 / X0 / X1 of K-tile 1) ----
     stage(0, false, 0); stage(0, true, 0); stage(0, true, 1); stage(0, false, 1);
     if (nk > 1) { stage(1, false, 0); if constexpr (P2) stage(1, true, 0); stage(1, true, 1); }
@@ -487,7 +550,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 if (!dnm) { mma(1, 0); mma(1, 1); }
                 mma_end();
             }
-            epilogue();
+            if (!(WABS && p.rowwise)) epilogue();
             prev_edge = m0 + 256 > p.M || n0 + (GEGLU ? 128 : 256) > p.N;
             if (has_next)
             {
@@ -504,6 +567,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
             }
         }
         if (wr == 0) __builtin_amdgcn_s_barrier();
+        if (WABS && p.rowwise) rowwise_epilogue();      // one tile per workgroup (the launcher's rule): every wave is behind its last fragment read, nothing is staged
     }
     else if constexpr (PP == 1)
     {
@@ -985,7 +1049,11 @@ static int launch_gemm256x128_tt(const Gemm256Params& p, hipStream_t s)
     }
     // staggered schedules walk their tiles PERSISTENTLY (one workgroup per CU) once there are more tiles than CUs and a tile has at least two K-tiles
     const int tiles = p.tiles_m * p.tiles_n, nk = p.K / (FP8 ? 128 : 64);
-    const int grid = (PP != 0 && nk >= 2 && g_gemm_persistent && tiles > kNumCU) ? kNumCU : tiles;
+    // (A/B on one box, variants interleaved, tools/bench_gemm_persistent.py -> profiles/r03_persistent_walk.txt: GPT-2 qkv 56.5 -> 54.4 us, fc_1 + GELU 68.5 -> 65.9, the fp4
+    // policy's fc_gate_up + GeGLU 222.4 -> 215.6.  A walking workgroup must retire its tile's stores before its third K-tile -- vmcnt counts loads and stores in one
+    // order -- where a new workgroup starts with a fresh counter, so the walk pays only when several tiles share the saved launches.  Start phases staggered over the
+    // CUs, to spread the store bursts of equal tiles, measured 2-7 % SLOWER on every shape: not kept)
+    const int grid = (PP != 0 && nk >= 2 && g_gemm_persistent && tiles > 2 * kNumCU) ? kNumCU : tiles;
     hipLaunchKernelGGL((gemm256x128_kernel<FP8, GEGLU, PP>), dim3(grid), dim3(512), 3 * kStage3Bytes, s, p);
     MILA_LAUNCH_CHECK("gemm256x128");
 }
@@ -997,7 +1065,7 @@ static int launch_gemm256x128_t(const Gemm256Params& p, hipStream_t s)
 }
 int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act)
 {
-    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, (N + 127) / 128, nullptr, nullptr, act};
+    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, (N + 127) / 128, nullptr, nullptr, 0, act};
     return launch_gemm256x128_t<false>(p, s);
 }
 
@@ -1039,7 +1107,7 @@ static int launch_gemm256_tt(const Gemm256Params& p, hipStream_t s)
     }
     // two-phase schedules run persistent (one workgroup per CU walking its tiles) when the K-tile count is even (the LDS buffer parity then runs on across tiles)
     const int tiles = p.tiles_m * p.tiles_n, nk = p.K / ((MODE == G_FP8 || MODE == G_FP8_GEGLU) ? 128 : 64);
-    const int grid = (PP >= 2 && nk >= 2 && nk % 2 == 0 && g_gemm_persistent) ? (tiles < kNumCU ? tiles : kNumCU) : tiles;
+    const int grid = (PP >= 2 && nk >= 2 && nk % 2 == 0 && g_gemm_persistent && !p.rowwise) ? (tiles < kNumCU ? tiles : kNumCU) : tiles;
 #ifdef MILA_GEMM_SKIP
     static const int dbg = getenv("MILA_GEMM_SKIP") ? atoi(getenv("MILA_GEMM_SKIP")) : 0;
     Gemm256Params q = p;
@@ -1060,7 +1128,9 @@ static int launch_gemm256_t(const Gemm256Params& p, hipStream_t s)
 
 int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act)
 {
-    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, (N + 255) / 256, nullptr, nullptr, act};
+    // a row pitch that is no multiple of 128 bytes: one workgroup per tile and the row-wise epilogue through LDS (two-phase schedules only)
+    const int rowwise = ((N & 63) != 0 && g_gemm_pingpong >= 3) ? 1 : 0;
+    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, (N + 255) / 256, nullptr, nullptr, rowwise, act};
     return launch_gemm256_t<G_PLAIN>(p, s);
 }
 

@@ -653,7 +653,7 @@ def test_ragged_prompt_lengths_split_between_the_lds_dma_and_the_128_tile_kernel
 
 
 @pytest.mark.parametrize("M,K,N,bias", [(768, 192, 50257, True), (768, 192, 50257 - 128 + 3, False),      # 256 x 128 tiles (K-tile count odd)
-                                        (1536, 256, 50257, True), (1280, 128, 50257 - 256 + 8, False)])     # persistent 256 x 256 tiles (round 3: GPT-2's lm_head)
+                                        (1536, 256, 50257, True), (1280, 128, 50257 - 256 + 8, False), (1280, 128, 50264, True)])     # 256 x 256 tiles with the row-wise epilogue through LDS (round 3: GPT-2's lm_head)
 def test_lds_dma_gemm_serves_a_ragged_n_with_an_odd_row_pitch(M, K, N, bias):
     """GPT-2's lm_head (GptTransformer.ixx:854-855: Linear(768 -> 50257), no bias there; bias exercised here too): N is no multiple of the 128-column tile and the output
     row pitch no multiple of 16 bytes -- the 256 x 128 LDS-DMA kernel takes it with a clamped last W tile and element stores under a column mask (round 3; it
@@ -769,4 +769,5 @@ def test_persistent_tile_walk_gives_the_bits_of_one_workgroup_per_tile(M, K, N, 
     if act:
         h = orc.round_bf16(exp.astype(np.float32)).astype(np.float64)
         exp = 0.5 * h * (1 + np.tanh(0.7978845608028654 * (h + 0.044715 * h ** 3)))
-    assert_bf16_close(outs[0][0][rows], exp, 2, 2e-3, "persistent gemm vs oracle")
+    # (the Linear output is rounded to bf16 BEFORE the bias is added: where the two nearly cancel, one ulp of the product is several of the sum -- hence the absolute floor)
+    assert_bf16_close(outs[0][0][rows], exp, 2, 2.0 ** -7 * max(1.0, float(np.abs(exp).max())), "persistent gemm vs oracle")
