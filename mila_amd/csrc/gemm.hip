@@ -281,6 +281,7 @@ int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int 
 static int g_gemm_force128 = 0;
 extern int g_gemm_pingpong;     // gemm256.hip
 extern int g_gemm_persistent;
+extern int g_gemm_rowwise;
 extern int g_gemm_fp8_tail_only;
 extern int g_gemm_fp8_tail_form;      // gemm_fp8_tail.hip
 
@@ -409,7 +410,8 @@ extern "C" {
 int mila_cdna4_tune_gemm(int force_128_tile)
 {
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
-    g_gemm_force128 = force_128_tile;
+    g_gemm_force128 = force_128_tile == 1;
+    g_gemm_rowwise = force_128_tile != 2;      // 2: the direct (unaligned) epilogue stores on an odd output pitch instead of the row-wise one through LDS
     return MILA_OK;
 }
 

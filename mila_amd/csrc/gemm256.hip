@@ -97,6 +97,20 @@ __device__ __forceinline__ void gemm256_w_offsets(int (&vo)[2][2], int wrow0, in
         }
 }
 
+// four consecutive bias values (columns n .. n + 3, n % 4 == 0) as FP32: ONE 8-byte load where the vector is 8-byte aligned and the columns exist (four 2-byte loads per
+// 4 outputs made a biased epilogue 38 % of GPT-2's lm_head-shaped GEMM, tools/bench_gemm_persistent.py vs tools/bench_lm_head.py); columns past N read column N - 1 (never stored)
+__device__ __forceinline__ f32x4 bias4_f32(const uint16_t* bias, int n, int N)
+{
+    u32x2 w;
+    if ((reinterpret_cast<uintptr_t>(bias) & 7) == 0 && n + 4 <= N) w = *reinterpret_cast<const u32x2*>(bias + n);
+    else
+    {
+        const uint32_t b0 = bias[min(n, N - 1)], b1 = bias[min(n + 1, N - 1)], b2 = bias[min(n + 2, N - 1)], b3 = bias[min(n + 3, N - 1)];
+        w = u32x2{b0 | (b1 << 16), b2 | (b3 << 16)};
+    }
+    return f32x4{bf16_lo(w[0]), bf16_hi(w[0]), bf16_lo(w[1]), bf16_hi(w[1])};
+}
+
 // PP (ping-pong): waves 4-7 run one barrier behind waves 0-3 and every phase has TWO barriers, [stage + fragment reads + waits] | A |
 // [16 MFMAs] | B |, so that while one wave of a SIMD multiplies, the other one reads its fragments and issues the staging: LDS
 // reads (28 ds_read_b128 per wave and K-tile, as many LDS cycles per CU as a SIMD has MFMA cycles) leave the critical path.
@@ -309,9 +323,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     #pragma unroll
             for (int hB = 0; hB < 2; ++hB)
     #pragma unroll
-                for (int pp = 0; pp < 4; pp += 2)
+                for (int qt = 0; qt < 2; ++qt)
     #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
+                    for (int pp = 0; pp < 4; pp += 2)      // innermost: the two 64-byte halves of a row's 128-byte line in consecutive instructions
                     {
                         const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
                         store_pair16(p.Y + (size_t)m * p.N + n0 + wr * 64 + pp * 16, g, out4(hB, pp, qt, m), out4(hB, pp + 1, qt, m), m < p.M);
@@ -342,13 +356,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                     for (int e = 0; e < 4; ++e)
                     {
                         v[e] = round_bf16(v[e] * ws) * ts;
-                        if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
+                    }
+                    if (p.bias)
+                    {
+                        const f32x4 b = bias4_f32(p.bias, n, p.N);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += b[e];
                     }
                 }
                 else if (p.bias)
                 {
-    #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
+                    const f32x4 b = bias4_f32(p.bias, n, p.N);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + b[e];
                 }
                 if (!FP8 && p.act)
                 {
@@ -394,9 +414,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     #pragma unroll
                         for (int hB = 0; hB < 2; ++hB)
     #pragma unroll
-                            for (int pp = 0; pp < 4; pp += 2)
+                            for (int qt = 0; qt < 2; ++qt)
     #pragma unroll
-                                for (int qt = 0; qt < 2; ++qt)
+                                for (int pp = 0; pp < 4; pp += 2)      // innermost: the two 64-byte halves of a row's 128-byte line in consecutive instructions
                                 {
                                     const int nb = n0 + hA * 128 + wr * 64 + pp * 16;
                                     const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
@@ -410,9 +430,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     #pragma unroll
                 for (int hB = 0; hB < 2; ++hB)
     #pragma unroll
-                    for (int pp = 0; pp < 4; pp += 2)
+                    for (int qt = 0; qt < 2; ++qt)
     #pragma unroll
-                        for (int qt = 0; qt < 2; ++qt)
+                        for (int pp = 0; pp < 4; pp += 2)      // innermost: the two 64-byte halves of a row's 128-byte line in consecutive instructions
                         {
                             const int nb = n0 + hA * 128 + wr * 64 + pp * 16;       // first column of sub-tile pp
                             const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
@@ -438,9 +458,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 #pragma unroll
                 for (int hB = 0; hB < 2; ++hB)
 #pragma unroll
-                    for (int pp = 0; pp < 4; pp += 2)
+                    for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-                        for (int qt = 0; qt < 2; ++qt)
+                        for (int pp = 0; pp < 4; pp += 2)      // innermost: the two 64-byte halves of a row's 128-byte line in consecutive instructions
                         {
                             u32x2 ab[2];
 #pragma unroll
@@ -448,11 +468,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                             {
                                 const int n = n0 + hA * 128 + wr * 64 + (pp + h) * 16 + 4 * g;
                                 float v[4];
+                                f32x4 b{0.0f, 0.0f, 0.0f, 0.0f};
+                                if (p.bias) b = bias4_f32(p.bias, n, p.N);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
                                 {
                                     v[e] = acc[hA][hB][pp + h][qt][e];
-                                    if (p.bias) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[min(n + e, p.N - 1)]);
+                                    if (p.bias) v[e] = round_bf16(v[e]) + b[e];
                                     if (p.act) v[e] = gelu_tanh(round_bf16(v[e]));
                                 }
                                 ab[h] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -867,13 +889,19 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                 for (int e = 0; e < 4; ++e)
                 {
                     v[e] = round_bf16(v[e] * ws) * ts;
-                    if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
+                }
+                if (p.bias)
+                {
+                    const f32x4 b = bias4_f32(p.bias, n, p.N);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += b[e];
                 }
             }
             else if (p.bias)
             {
-    #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
+                const f32x4 b = bias4_f32(p.bias, n, p.N);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + b[e];
             }
             if (!FP8 && p.act)
             {
@@ -888,9 +916,9 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     #pragma unroll
             for (int hB = 0; hB < 2; ++hB)
     #pragma unroll
-                for (int pp = 0; pp < 4; pp += 2)
+                for (int qt = 0; qt < 2; ++qt)
     #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
+                    for (int pp = 0; pp < 4; pp += 2)      // innermost: the two 64-byte halves of a row's 128-byte line in consecutive instructions
                     {
                         const int nb = n0 + wr * 64 + pp * 16;
                         const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
@@ -927,9 +955,9 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     #pragma unroll
         for (int hB = 0; hB < 2; ++hB)
     #pragma unroll
-            for (int pp = 0; pp < 4; pp += 2)
+            for (int qt = 0; qt < 2; ++qt)
     #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
+                for (int pp = 0; pp < 4; pp += 2)      // innermost: the two 64-byte halves of a row's 128-byte line in consecutive instructions
                 {
                     const int nb = n0 + wr * 64 + pp * 16;
                     const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
@@ -1087,6 +1115,7 @@ bool gemm256_ragged_n_applicable(int M, int K, int N)
     return (int64_t)(M / 256) * ((N + 255) / 256) >= 4 * kNumCU;
 }
 
+int g_gemm_rowwise = 1;       // tuning (mila_cdna4_tune_gemm(2) clears it)
 int g_gemm_persistent = 1;    // tuning: schedule 6 = schedule 5 with one workgroup per tile (not persistent)
 int g_gemm_pingpong = 5;      // tuning hook (mila_cdna4_tune_gemm_schedule): 0 = all eight waves in lockstep; 1 = staggered (ping-pong), four phases per
                               // K-tile in the 256 x 256 kernel; 2 = 1 + prefer the 256 x 128 ring; 3 = staggered, two phases per K-tile in the
@@ -1129,7 +1158,7 @@ static int launch_gemm256_t(const Gemm256Params& p, hipStream_t s)
 int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act)
 {
     // a row pitch that is no multiple of 128 bytes: one workgroup per tile and the row-wise epilogue through LDS (two-phase schedules only)
-    const int rowwise = ((N & 63) != 0 && g_gemm_pingpong >= 3) ? 1 : 0;
+    const int rowwise = ((N & 63) != 0 && g_gemm_pingpong >= 3 && g_gemm_rowwise) ? 1 : 0;
     Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, (N + 255) / 256, nullptr, nullptr, rowwise, act};
     return launch_gemm256_t<G_PLAIN>(p, s);
 }
