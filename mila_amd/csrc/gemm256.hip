@@ -65,6 +65,10 @@ __device__ __forceinline__ void grouped_tile(int tile, int tiles_m, int tiles_n,
     tn = in / gm;
 }
 
+// (Round 3, same-box A/B of two builds -- tools/experiments/ab_prev_lib.py, profiles/r03_epilogue_ab.txt: the ORDER of a quadrant's four stores (a 128-byte line's halves in
+// consecutive instructions, or 16 rows apart) changes nothing in the GEMM although it is worth 3 x in a store-only kernel (tools/experiments/store_drain.hip: 1.5 vs 4.4 us per
+// 128 KB tile and CU); the bias as one 8-byte load per four outputs instead of four 2-byte loads is 10-13 % SLOWER on the biased GPT-2 projections and, hoisted over the
+// 256 x 256 epilogue, spilled 127 registers: both left out.)
 // Epilogue store of two 16-column sub-tiles (pt, pt + 1) of one output row as ONE 16-byte store per lane.  A lane (l15, g) holds columns 4 g .. 4 g + 3 of both
 // sub-tiles (a, b); v_permlane16_swap exchanges the odd lane rows of a with the even lane rows of b, after which an even-g lane holds columns 4 g .. 4 g + 7 of
 // sub-tile pt and an odd-g lane columns 4 (g - 1) .. 4 (g - 1) + 7 of sub-tile pt + 1: half the store instructions, 64 contiguous bytes per row and instruction.
@@ -95,20 +99,6 @@ __device__ __forceinline__ void gemm256_w_offsets(int (&vo)[2][2], int wrow0, in
             const int kslot = FP8 ? (((lslot & 3) << 1) | (lslot >> 2)) : lslot;
             vo[half][i] = (WABS ? min((half ? wrow1 : wrow0) + row, n_rows - 1) : row) * rowbytes + kslot * 16;
         }
-}
-
-// four consecutive bias values (columns n .. n + 3, n % 4 == 0) as FP32: ONE 8-byte load where the vector is 8-byte aligned and the columns exist (four 2-byte loads per
-// 4 outputs made a biased epilogue 38 % of GPT-2's lm_head-shaped GEMM, tools/bench_gemm_persistent.py vs tools/bench_lm_head.py); columns past N read column N - 1 (never stored)
-__device__ __forceinline__ f32x4 bias4_f32(const uint16_t* bias, int n, int N)
-{
-    u32x2 w;
-    if ((reinterpret_cast<uintptr_t>(bias) & 7) == 0 && n + 4 <= N) w = *reinterpret_cast<const u32x2*>(bias + n);
-    else
-    {
-        const uint32_t b0 = bias[min(n, N - 1)], b1 = bias[min(n + 1, N - 1)], b2 = bias[min(n + 2, N - 1)], b3 = bias[min(n + 3, N - 1)];
-        w = u32x2{b0 | (b1 << 16), b2 | (b3 << 16)};
-    }
-    return f32x4{bf16_lo(w[0]), bf16_hi(w[0]), bf16_lo(w[1]), bf16_hi(w[1])};
 }
 
 // PP (ping-pong): waves 4-7 run one barrier behind waves 0-3 and every phase has TWO barriers, [stage + fragment reads + waits] | A |
@@ -323,9 +313,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     #pragma unroll
             for (int hB = 0; hB < 2; ++hB)
     #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
+                for (int pp = 0; pp < 4; pp += 2)
     #pragma unroll
-                    for (int pp = 0; pp < 4; pp += 2)      // innermost: the two 64-byte halves of a row's 128-byte line in consecutive instructions
+                    for (int qt = 0; qt < 2; ++qt)
                     {
                         const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
                         store_pair16(p.Y + (size_t)m * p.N + n0 + wr * 64 + pp * 16, g, out4(hB, pp, qt, m), out4(hB, pp + 1, qt, m), m < p.M);
@@ -356,19 +346,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                     for (int e = 0; e < 4; ++e)
                     {
                         v[e] = round_bf16(v[e] * ws) * ts;
-                    }
-                    if (p.bias)
-                    {
-                        const f32x4 b = bias4_f32(p.bias, n, p.N);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += b[e];
+                        if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
                     }
                 }
                 else if (p.bias)
                 {
-                    const f32x4 b = bias4_f32(p.bias, n, p.N);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + b[e];
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
                 }
                 if (!FP8 && p.act)
                 {
@@ -414,9 +398,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     #pragma unroll
                         for (int hB = 0; hB < 2; ++hB)
     #pragma unroll
-                            for (int qt = 0; qt < 2; ++qt)
+                            for (int pp = 0; pp < 4; pp += 2)
     #pragma unroll
-                                for (int pp = 0; pp < 4; pp += 2)      // innermost: the two 64-byte halves of a row's 128-byte line in consecutive instructions
+                                for (int qt = 0; qt < 2; ++qt)
                                 {
                                     const int nb = n0 + hA * 128 + wr * 64 + pp * 16;
                                     const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
@@ -430,9 +414,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     #pragma unroll
                 for (int hB = 0; hB < 2; ++hB)
     #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
+                    for (int pp = 0; pp < 4; pp += 2)
     #pragma unroll
-                        for (int pp = 0; pp < 4; pp += 2)      // innermost: the two 64-byte halves of a row's 128-byte line in consecutive instructions
+                        for (int qt = 0; qt < 2; ++qt)
                         {
                             const int nb = n0 + hA * 128 + wr * 64 + pp * 16;       // first column of sub-tile pp
                             const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
@@ -458,9 +442,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 #pragma unroll
                 for (int hB = 0; hB < 2; ++hB)
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
+                    for (int pp = 0; pp < 4; pp += 2)
 #pragma unroll
-                        for (int pp = 0; pp < 4; pp += 2)      // innermost: the two 64-byte halves of a row's 128-byte line in consecutive instructions
+                        for (int qt = 0; qt < 2; ++qt)
                         {
                             u32x2 ab[2];
 #pragma unroll
@@ -468,13 +452,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                             {
                                 const int n = n0 + hA * 128 + wr * 64 + (pp + h) * 16 + 4 * g;
                                 float v[4];
-                                f32x4 b{0.0f, 0.0f, 0.0f, 0.0f};
-                                if (p.bias) b = bias4_f32(p.bias, n, p.N);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
                                 {
                                     v[e] = acc[hA][hB][pp + h][qt][e];
-                                    if (p.bias) v[e] = round_bf16(v[e]) + b[e];
+                                    if (p.bias) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[min(n + e, p.N - 1)]);
                                     if (p.act) v[e] = gelu_tanh(round_bf16(v[e]));
                                 }
                                 ab[h] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -889,19 +871,13 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                 for (int e = 0; e < 4; ++e)
                 {
                     v[e] = round_bf16(v[e] * ws) * ts;
-                }
-                if (p.bias)
-                {
-                    const f32x4 b = bias4_f32(p.bias, n, p.N);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += b[e];
+                    if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
                 }
             }
             else if (p.bias)
             {
-                const f32x4 b = bias4_f32(p.bias, n, p.N);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + b[e];
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
             }
             if (!FP8 && p.act)
             {
@@ -916,9 +892,9 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     #pragma unroll
             for (int hB = 0; hB < 2; ++hB)
     #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
+                for (int pp = 0; pp < 4; pp += 2)
     #pragma unroll
-                    for (int pp = 0; pp < 4; pp += 2)      // innermost: the two 64-byte halves of a row's 128-byte line in consecutive instructions
+                    for (int qt = 0; qt < 2; ++qt)
                     {
                         const int nb = n0 + wr * 64 + pp * 16;
                         const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
@@ -955,9 +931,9 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     #pragma unroll
         for (int hB = 0; hB < 2; ++hB)
     #pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
+            for (int pp = 0; pp < 4; pp += 2)
     #pragma unroll
-                for (int pp = 0; pp < 4; pp += 2)      // innermost: the two 64-byte halves of a row's 128-byte line in consecutive instructions
+                for (int qt = 0; qt < 2; ++qt)
                 {
                     const int nb = n0 + wr * 64 + pp * 16;
                     const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;

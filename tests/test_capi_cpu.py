@@ -96,3 +96,30 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(capi, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError, match="no fallback"):
         capi.load()
+
+
+def test_the_prefill_gemm_kernels_keep_their_accumulators_in_registers():
+    """hipcc's kernel-resource-usage remarks for csrc/gemm256.hip (cross-compiled here, no GPU): the bf16 LDS-DMA GEMMs the benchmark runs must not spill -- two waves per SIMD
+    leave 256 registers, 128 of them accumulators, and a few more live values in an epilogue tip the allocator into scratch traffic without any diagnostic (round 3: an
+    8-byte bias load hoisted over the epilogue cost 127 spills and 15-24 % on the plain 256 x 256 kernel before an A/B on one box showed it).  The fp8 forms carry the epilogue
+    scales and are allowed a small spill OUTSIDE the K loop (checked on the ISA when they were introduced); the bound keeps that from growing unnoticed."""
+    import re
+    import subprocess
+    src = os.path.join(ROOT, "mila_amd", "csrc", "gemm256.hip")
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Rpass-analysis=kernel-resource-usage",
+                          "--cuda-device-only", "-c", src, "-o", os.devnull], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900).stdout
+    usage = {}
+    name = None
+    for line in out.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+        m = re.search(r"(VGPRs Spill|ScratchSize \[bytes/lane\]): (\d+)", line)
+        if m and name:
+            usage[name][m.group(1)] = int(m.group(2))
+    default_schedule = {k: v for k, v in usage.items() if ("gemm256_kernelILi" in k and "ELi3EEE" in k) or ("gemm256x128_kernelILb" in k and "ELi2EEE" in k)}
+    assert len(default_schedule) == 7, sorted(usage)       # 4 modes of the 256 x 256 kernel, 3 forms of the 256 x 128 one
+    for k, v in default_schedule.items():
+        fp8_256 = "gemm256_kernelILi2E" in k or "gemm256_kernelILi3E" in k
+        assert v["VGPRs Spill"] <= (24 if fp8_256 else 0), (k, v)
