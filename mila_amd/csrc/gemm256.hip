@@ -669,7 +669,9 @@ constexpr int kStage3Bytes = 3 * kHalfBytes;   // W, X0, X1
 // waves 4-7 one barrier behind waves 0-3.  RAW: K-tile t + 1 is waited for (vmcnt(6)) at the end of the reads of phase t and read in
 // phase t + 1; WAR: ring slot (t + 2) % 3 held K-tile t - 1, whose reads every wave retired before barrier A(t - 1), and group 0
 // restages it behind B(t - 1) = group 1's A(t - 1).
-template <bool FP8, bool GEGLU, int PP>      // PP: 0 lockstep, 1 staggered groups, 2 staggered with a static priority for waves 4-7
+// WALK: the persistent tile walk is compiled in (one workgroup per CU); without it the kernel is the one-tile form, whose K loop carries none of the walk's selects
+// (the walk's bookkeeping in the K loop -- next-tile offsets, the flat ring index -- cost the one-round shapes 15 %: o_proj + fc_down 130 -> 152 us average)
+template <bool FP8, bool GEGLU, int PP, bool WALK>      // PP: 0 lockstep, 1 staggered groups, 2 staggered with a static priority for waves 4-7
 __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -727,7 +729,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     offsets(voff, m0, n0);
     // K-tile `kt` of this tile (kt < nk) or K-tile kt - nk of the workgroup's next tile, into ring slot `flat` % 3 (flat = K-tiles since the workgroup started)
     auto stage = [&](int flat, int kt, int which) {
-        const bool nxt = kt >= nk;
+        const bool nxt = WALK && kt >= nk;
         unsigned char* dst_half = smem + (flat % 3) * kStage3Bytes + which * kHalfBytes;
         const int soff = __builtin_amdgcn_readfirstlane((nxt ? kt - nk : kt) * 128);
 #pragma unroll
@@ -956,19 +958,19 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
         constexpr int kStores = GEGLU ? 4 : 8;            // 16-byte stores per lane of a whole tile's epilogue
         if constexpr (PP == 2) { if (wr == 1) __builtin_amdgcn_s_setprio(1); }
         if (wr == 1) __builtin_amdgcn_s_barrier();
-        const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int my_tiles = WALK ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 1;
         int base = 0;                                     // K-tiles before this tile
         bool prev_edge = false;
         for (int j = 0; j < my_tiles; ++j)
         {
-            const bool has_next = j + 1 < my_tiles;
+            const bool has_next = WALK && j + 1 < my_tiles;
             if (has_next) { tile_origin(blockIdx.x + (j + 1) * gridDim.x, xm0, xn0); offsets(voffn, xm0, xn0); }
             for (int t = 0; t < nk; ++t)
             {
                 const bool more = t + 2 < nk || (has_next && t + 2 - nk < nk);
                 // the previous tile's stores sit between K-tile 1's requests and K-tile 2's: counted, unless that tile lay on a ragged edge of Y (another number of
                 // stores, possibly fewer: the plain wait retires them all)
-                const bool post = j > 0 && t == 0 && !prev_edge;
+                const bool post = WALK && j > 0 && t == 0 && !prev_edge;
                 if (more) stage_all(base + t + 2, t + 2);
                 load_a(base + t);
                 load_b(base + t, 0);
@@ -1046,9 +1048,15 @@ static int launch_gemm256x128_tt(const Gemm256Params& p, hipStream_t s)
     static bool attr_set = false;
     if (!attr_set)
     {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel<FP8, GEGLU, PP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel<FP8, GEGLU, PP, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                3 * kStage3Bytes), "hipFuncSetAttribute(gemm256x128)");
         if (rc) return rc;
+        if constexpr (PP != 0)
+        {
+            rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel<FP8, GEGLU, PP, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               3 * kStage3Bytes), "hipFuncSetAttribute(gemm256x128 walk)");
+            if (rc) return rc;
+        }
         attr_set = true;
     }
     // staggered schedules walk their tiles PERSISTENTLY (one workgroup per CU) once there are more tiles than CUs and a tile has at least two K-tiles
@@ -1058,7 +1066,15 @@ static int launch_gemm256x128_tt(const Gemm256Params& p, hipStream_t s)
     // order -- where a new workgroup starts with a fresh counter, so the walk pays only when several tiles share the saved launches.  Start phases staggered over the
     // CUs, to spread the store bursts of equal tiles, measured 2-7 % SLOWER on every shape: not kept)
     const int grid = (PP != 0 && nk >= 2 && g_gemm_persistent && tiles > 2 * kNumCU) ? kNumCU : tiles;
-    hipLaunchKernelGGL((gemm256x128_kernel<FP8, GEGLU, PP>), dim3(grid), dim3(512), 3 * kStage3Bytes, s, p);
+    if constexpr (PP != 0)
+    {
+        if (grid < tiles)
+        {
+            hipLaunchKernelGGL((gemm256x128_kernel<FP8, GEGLU, PP, true>), dim3(grid), dim3(512), 3 * kStage3Bytes, s, p);
+            MILA_LAUNCH_CHECK("gemm256x128 (walk)");
+        }
+    }
+    hipLaunchKernelGGL((gemm256x128_kernel<FP8, GEGLU, PP, false>), dim3(tiles), dim3(512), 3 * kStage3Bytes, s, p);
     MILA_LAUNCH_CHECK("gemm256x128");
 }
 template <bool FP8, bool GEGLU = false>

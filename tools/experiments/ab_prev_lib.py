@@ -33,6 +33,8 @@ def timed(fn, n=10):
 CASES = [("N = 4096", "plain", 2048, 3840, 4096), ("N = 16384", "plain", 2048, 3840, 16384), ("gpt2 fc_1 + bias", "bias", 8192, 768, 3072), ("gpt2 qkv + bias", "bias", 8192, 768, 2304), ("gpt2 fc_2 + bias", "bias", 8192, 3072, 768), ("gpt2 lm_head", "plain", 8192, 768, 50257), ("gpt2 proj + bias", "bias", 8192, 768, 768),
          ("gemma qkv", "plain", 2048, 3840, 8192), ("gemma o_proj", "plain", 2048, 4096, 3840), ("gemma fc_gate_up + GeGLU", "geglu", 2048, 3840, 30720), ("gemma fc_down", "plain", 2048, 15360, 3840)]
 for name, kind, M, K, N in CASES:
+    if N % 128 != 0 and os.environ.get("AB_SKIP_RAGGED"):      # a "previous" build without the ragged-N staging must not see a ragged N
+        continue
     X = (torch.rand((M, K), device="cuda") * 2 - 1).to(torch.bfloat16).view(torch.int16)
     W = ((torch.rand((N, K), device="cuda") * 2 - 1) / K ** 0.5).to(torch.bfloat16).view(torch.int16)
     b = torch.zeros((N,), dtype=torch.int16, device="cuda") if kind == "bias" else None
