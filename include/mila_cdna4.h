@@ -437,6 +437,15 @@ MILA_API int mila_cdna4_fused_attn_decode_bf16(uint16_t* Y, uint16_t* Kc, uint16
                                                const int32_t* position_dev, int window, float scale, float eps,
                                                mila_stream_t stream);
 
+/* fused_attn_decode_bf16 for B rows decoded at ONE position (the reference's decode kernels take the batch in their grid, Gqa.Decode.Bf16.cu:379-387): batch row b reads
+ * q_raw / k_raw / v_raw + b * raw_b_stride elements and its own caches [b]; Y [B, NH*HS]; scratch from attn_decode_scratch_bytes(B, NH, HS).  Bit-identical, row by row,
+ * to fused_qkv_post on that row's caches + attn_decode_bf16 with the same B. */
+MILA_API int mila_cdna4_fused_attn_decode_batch_bf16(uint16_t* Y, uint16_t* Kc, uint16_t* Vc, const uint16_t* q_raw, const uint16_t* k_raw,
+                                                     const uint16_t* v_raw, int64_t raw_b_stride, const uint16_t* qw, const uint16_t* kw,
+                                                     const uint16_t* vw, const float* cos_cache, const float* sin_cache, void* scratch,
+                                                     size_t scratch_bytes, int B, int NH, int NKV, int HS, int capacity, int position,
+                                                     const int32_t* position_dev, int window, float scale, float eps, mila_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

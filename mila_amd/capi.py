@@ -159,7 +159,7 @@ EXPORTED = [
     "sample_scratch_bytes", "sample_argmax_fp32", "sample_argmax_bf16",
     "sample_stochastic_scratch_bytes", "sample_stochastic_fp32", "sample_stochastic_bf16",
     "fused_norm_matvec", "fused_qkv_post", "fused_qkv_post_prefill", "fused_tail_norm_bf16", "fused_tail_norm_quant_bf16",
-    "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position", "advance_position_snapshot", "snapshot_token", "sample_argmax_advance_fp32", "fused_attn_decode_bf16",
+    "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position", "advance_position_snapshot", "snapshot_token", "sample_argmax_advance_fp32", "fused_attn_decode_batch_bf16", "fused_attn_decode_bf16",
     "dequantize_to_bf16", "gemm_geglu_fp8_scaled",
 ]
 

@@ -72,7 +72,8 @@ struct AttnParams
     float scale;
     const int32_t* pos_dev;   // when set: the position is read from device memory (graph replay)
     // fused prologue (GemmaBlock::decode lines 315-337 folded in): raw projections + norm weights + RoPE cache
-    const uint16_t* q_raw;    // [NH*HS]  (B == 1)
+    int64_t raw_b_stride;     // elements between two batch rows of q_raw / k_raw / v_raw (a packed [B, 1, q | k | v] projection row; unused at B == 1)
+    const uint16_t* q_raw;    // [NH*HS] per batch row
     const uint16_t* k_raw;    // [NKV*HS]
     const uint16_t* v_raw;    // [NKV*HS] (== k_raw on Gemma global layers)
     const uint16_t* qw;
@@ -277,12 +278,12 @@ __global__ __launch_bounds__(kDecodeWaves * 64) void attn_decode_kernel(const At
         for (int r = wave; r < nrows; r += NW)
         {
             if (r < GH)
-                head_row_post<HS>(p.q_raw + (size_t)(h0 + r) * HS, p.qw, true, cos_row, sin_row, p.eps, qs + (size_t)r * HS, nullptr);
+                head_row_post<HS>(p.q_raw + (size_t)b * p.raw_b_stride + (size_t)(h0 + r) * HS, p.qw, true, cos_row, sin_row, p.eps, qs + (size_t)r * HS, nullptr);
             else if (r == GH)
-                head_row_post<HS>(p.k_raw + (size_t)kvh * HS, p.kw, true, cos_row, sin_row, p.eps, qs + (size_t)GH * HS,
+                head_row_post<HS>(p.k_raw + (size_t)b * p.raw_b_stride + (size_t)kvh * HS, p.kw, true, cos_row, sin_row, p.eps, qs + (size_t)GH * HS,
                                   (hg == 0) ? kbase + (size_t)(pos % p.capacity) * HS : nullptr);
             else
-                head_row_post<HS>(p.v_raw + (size_t)kvh * HS, p.vw, false, cos_row, sin_row, p.eps, qs + (size_t)(GH + 1) * HS,
+                head_row_post<HS>(p.v_raw + (size_t)b * p.raw_b_stride + (size_t)kvh * HS, p.vw, false, cos_row, sin_row, p.eps, qs + (size_t)(GH + 1) * HS,
                                   (hg == 0) ? vbase + (size_t)(pos % p.capacity) * HS : nullptr);
         }
         __syncthreads();
@@ -762,6 +763,31 @@ int mila_cdna4_fused_attn_decode_bf16(uint16_t* Y, uint16_t* Kc, uint16_t* Vc, c
     f.eps = eps;
     return run_decode(Y, nullptr, Kc, Vc, scratch, scratch_bytes, 1, NH, NKV, HS, capacity, position, position_dev, window, scale, &f,
                       "fused_attn_decode_bf16", as_stream(stream));
+}
+
+// The same launch for B rows decoded at one position (Gqa.Decode.Bf16.cu:379-387 takes the batch in its grid): batch row b reads its raw projections at
+// q_raw / k_raw / v_raw + b * raw_b_stride (the three pointers into one packed [B, 1, q | k | v] row, or separate dense tensors) and its own caches; Y [B, NH*HS].
+int mila_cdna4_fused_attn_decode_batch_bf16(uint16_t* Y, uint16_t* Kc, uint16_t* Vc, const uint16_t* q_raw, const uint16_t* k_raw,
+                                            const uint16_t* v_raw, int64_t raw_b_stride, const uint16_t* qw, const uint16_t* kw, const uint16_t* vw,
+                                            const float* cos_cache, const float* sin_cache, void* scratch, size_t scratch_bytes, int B,
+                                            int NH, int NKV, int HS, int capacity, int position, const int32_t* position_dev,
+                                            int window, float scale, float eps, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && Kc && Vc && q_raw && k_raw && v_raw && qw && kw && cos_cache && sin_cache, "fused_attn_decode_batch_bf16: null pointer");
+    MILA_REQUIRE(B > 0 && NH > 0 && NKV > 0 && NH % NKV == 0, "fused_attn_decode_batch_bf16: bad sizes (B=%d NH=%d NKV=%d)", B, NH, NKV);
+    MILA_REQUIRE(B == 1 || raw_b_stride >= (int64_t)NKV * HS, "fused_attn_decode_batch_bf16: raw_b_stride %lld is shorter than a K row", (long long)raw_b_stride);
+    MILA_REQUIRE(capacity > 0 && window >= 0 && (position_dev || position >= 0), "fused_attn_decode_batch_bf16: bad sizes");
+    MILA_REQUIRE(HS % 16 == 0, "fused_attn_decode_batch_bf16: HS=%d must be a multiple of 16", HS);
+    if (!position_dev)
+    {
+        const int len = position + 1, band = (window > 0 && window < len) ? window : len;
+        MILA_REQUIRE(band <= capacity, "fused_attn_decode_batch_bf16: live band %d exceeds the cache capacity %d", band, capacity);
+    }
+    AttnParams f{};
+    f.q_raw = q_raw; f.k_raw = k_raw; f.v_raw = v_raw; f.raw_b_stride = raw_b_stride; f.qw = qw; f.kw = kw; f.vw = vw; f.cos_cache = cos_cache; f.sin_cache = sin_cache;
+    f.eps = eps;
+    return run_decode(Y, nullptr, Kc, Vc, scratch, scratch_bytes, B, NH, NKV, HS, capacity, position, position_dev, window, scale, &f,
+                      "fused_attn_decode_batch_bf16", as_stream(stream));
 }
 
 // ---- GPT-2 multi-head attention over a KV cache (CudaMhaOp.ixx:137-380: prefill / decode of IPositionalUnaryOp + IKvCacheLifecycle) ----

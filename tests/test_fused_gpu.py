@@ -165,6 +165,43 @@ def test_fused_attn_decode_equals_qkv_post_plus_attn_decode(NH, NKV, HS, rot, ba
     del hist
 
 
+@pytest.mark.parametrize("B,NH,NKV,HS,rot,base,window,kv_shared", [(3, 16, 8, 256, 0, 1e4, 1024, False), (2, 16, 1, 512, 128, 1e6, 0, True), (5, 4, 2, 64, 0, 1e4, 8, False)])
+@pytest.mark.parametrize("pos", [0, 63, 64, 1500])
+def test_fused_attn_decode_takes_a_batch_like_the_reference_kernels(B, NH, NKV, HS, rot, base, window, kv_shared, pos):
+    """Gqa.Decode.Bf16.cu:379-387 puts the batch in the grid; the one-launch form does too (round 3: it was B == 1): B rows of a packed [B, 1, q | k | v] projection at one
+    position, each on its own caches -- bit for bit the per-row fused_qkv_post + the batched attn_decode_bf16, cache contents included"""
+    rng = np.random.default_rng(HS + pos + B)
+    cap, max_seq = 2048, 2048
+    Kc0 = torch.from_numpy(orc.to_bf16_bits(rng.uniform(-1, 1, (B, NKV, cap, HS)).astype(np.float32) * 0.5).view(np.int16)).cuda()
+    Vc0 = torch.from_numpy(orc.to_bf16_bits(rng.uniform(-1, 1, (B, NKV, cap, HS)).astype(np.float32)).view(np.int16)).cuda()
+    qw_, kw_ = NH * HS, NKV * HS
+    packed = qw_ + kw_ * (1 if kv_shared else 2) + 24                       # + 24: the row stride need not be the sum of the parts
+    rows = _bf(rng.standard_normal((B, packed)))
+    rows_d = _d(rows)
+    q_off, k_off = 0, qw_
+    v_off = k_off if kv_shared else k_off + kw_
+    qw, kw = _d(_bf(1 + 0.1 * rng.uniform(-1, 1, HS))), _d(_bf(1 + 0.1 * rng.uniform(-1, 1, HS)))
+    cos, sin = empty_f32(max_seq, HS // 2), empty_f32(max_seq, HS // 2)
+    capi.call("rope_build_cache", cos, sin, max_seq, HS, float(base), rot)
+    nbytes = capi.load().mila_cdna4_attn_decode_scratch_bytes(B, NH, HS)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    # chain: fused_qkv_post row by row on that row's caches, then the batched decode
+    K0, V0, q0, y0 = Kc0.clone(), Vc0.clone(), empty_u16(B, NH * HS), empty_u16(B, NH * HS)
+    for b in range(B):
+        capi.call("fused_qkv_post", q0[b], K0[b], V0[b], rows_d[b, q_off:], rows_d[b, k_off:], rows_d[b, v_off:], qw, kw, None, cos, sin, NH, NKV, HS, pos, cap, 1e-6)
+    capi.call("attn_decode_bf16", y0, q0, K0, V0, scratch, C.c_size_t(nbytes), B, NH, NKV, HS, cap, pos + 1, window, 1.0)
+    # one launch
+    K1, V1, y1 = Kc0.clone(), Vc0.clone(), empty_u16(B, NH * HS)
+    capi.call("fused_attn_decode_batch_bf16", y1, K1, V1, rows_d[0, q_off:], rows_d[0, k_off:], rows_d[0, v_off:], C.c_int64(packed), qw, kw, None, cos, sin,
+              scratch, C.c_size_t(nbytes), B, NH, NKV, HS, cap, pos, None, window, 1.0, 1e-6)
+    assert np.array_equal(bits(K1), bits(K0)) and np.array_equal(bits(V1), bits(V0)), "cache rows differ"
+    assert np.array_equal(bits(y1), bits(y0)), "attention output differs"
+    # and against the oracle on one row: norm -> rope -> attention over that row's history
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("fused_attn_decode_batch_bf16", y1, K1, V1, rows_d[0, q_off:], rows_d[0, k_off:], rows_d[0, v_off:], C.c_int64(8), qw, kw, None, cos, sin,
+                  scratch, C.c_size_t(nbytes), B, NH, NKV, HS, cap, pos, None, window, 1.0, 1e-6)
+
+
 def _chain_args(**kw):
     a = capi.decode_chain_args()
     for k, v in kw.items():
