@@ -662,6 +662,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
 // (3 x 48 KB): K-tile t + 2 is requested at the top of K-tile t, ONE s_waitcnt vmcnt(6) + barrier per K-tile retires
 // K-tile t + 1 while t + 2 stays in flight.
 constexpr int kStage3Bytes = 3 * kHalfBytes;   // W, X0, X1
+#ifndef MILA_RING_GLOBAL_LOADS
+#define MILA_RING_GLOBAL_LOADS 1
+#endif
+constexpr bool kRingGlobalLoads = MILA_RING_GLOBAL_LOADS;      // how the 256 x 128 ring stages (see its stage())
 
 // GEGLU: the tile's 128 W rows are, per wave half wr, 32 gate rows then the matching 32 up rows (64 output columns per tile:
 // n0 = 64 tn), so a lane's sub-tiles pt = 0,1 / 2,3 hold gate / up of the same outputs.
@@ -736,7 +740,15 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
         for (int i = 0; i < 2; ++i)
         {
             const int chunk = i * 8 + wave;
-            if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(dst_half + chunk * 1024), 16, nxt ? voffn[0][i] : voff[0][i], soff, 0, 0);
+            if constexpr (kRingGlobalLoads)
+            {
+                // `global_load_lds` on base + (offset computed once per tile) + K-tile: measured against the buffer form on one box with the weights rotating through HBM
+                // (tools/experiments/ab_r02_lib.py, profiles/r03_gemm_bisect.txt) -- in THIS kernel the buffer form is 4-5 % slower (o_proj 57.7 vs 60.7 us, fc_down 195.5 vs
+                // 203.9; round 2's per-request address arithmetic: 57.1 / 196.7), in the 256 x 256 kernel it is 2 % faster
+                const unsigned char* src = (which == 0 ? Wb : Xb) + (size_t)(uint32_t)(nxt ? voffn[which][i] : voff[which][i]) + (size_t)(uint32_t)soff;
+                __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(dst_half + chunk * 1024), 16, 0, 0);
+            }
+            else if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(dst_half + chunk * 1024), 16, nxt ? voffn[0][i] : voff[0][i], soff, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(dst_half + chunk * 1024), 16, nxt ? voffn[which][i] : voff[which][i], soff, 0, 0);
         }
     };
@@ -862,6 +874,18 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
         #pragma unroll
                 for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[min(m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15, p.M - 1)];
         }
+        // the bias of this lane's 16 columns (4 sub-tiles x 4), fetched ONCE before the stores like the scales above: read inside the store loop every value is fetched again
+        // after every store (the compiler cannot prove that Y does not alias the bias) -- 64 dependent 2-byte loads per lane and tile, 15 % of GPT-2's biased projections
+        // (same-box A/B, profiles/r03_epilogue_ab.txt run 4: qkv 53.1 -> 45.5 us, fc_1 57.9 -> 48.8).  Columns past N (a ragged last tile-column) read column N - 1; they
+        // are never stored.  (The 256 x 256 plain kernel keeps the loads in its loop: hoisted there, even one W half at a time, they cost 138 spilled registers.)
+        float bv[4][4] = {};
+        if (p.bias)
+        {
+    #pragma unroll
+            for (int pt_ = 0; pt_ < 4; ++pt_)
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) bv[pt_][e] = bf16_bits_to_f32(p.bias[min(n0 + wr * 64 + pt_ * 16 + 4 * g + e, p.N - 1)]);
+        }
         auto out4 = [&](int hB, int pt, int qt, int m, int n) -> u32x2 {
             float v[4];
     #pragma unroll
@@ -873,13 +897,13 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                 for (int e = 0; e < 4; ++e)
                 {
                     v[e] = round_bf16(v[e] * ws) * ts;
-                    if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
+                    if (p.bias) v[e] += bv[pt][e];
                 }
             }
             else if (p.bias)
             {
     #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32(p.bias[n + e]);
+                for (int e = 0; e < 4; ++e) v[e] = round_bf16(v[e]) + bv[pt][e];
             }
             if (!FP8 && p.act)
             {
