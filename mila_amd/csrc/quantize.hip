@@ -9,6 +9,7 @@
 // arithmetic on the fp32 bits (RNE at mantissa bit 20, saturate to 0x7e) so it does not depend on
 // the FP8 hardware-convert overflow mode.
 #include "common.h"
+#include "internal.h"
 
 namespace mila {
 
