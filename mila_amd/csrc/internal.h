@@ -18,8 +18,6 @@ MILA_API int mila_cdna4_tune_gemm(int force_128_tile);
  * 3 = staggered, two phases per K-tile; 4 = 3 + the fp8 shapes on the 256 x 256 kernel wherever it applies; 5 (default) = 4 with a static priority for waves 4-7
  * and persistent tiles; 6 = 5 with one workgroup per tile.  All give the same bits. */
 MILA_API int mila_cdna4_tune_gemm_schedule(int pingpong);
-/* per-token e4m3 activation quantization: 1 (default) = one wave per row for rows of <= 8192 elements, 0 = the workgroup-per-row kernel always (same bytes) */
-MILA_API int mila_cdna4_tune_quantize_act(int wave_rows);
 /* fp8 x fp8 GEMM entry points: 0 (default) = LDS-DMA kernels on the leading multiple of 256 rows, the tail kernels of gemm_fp8_tail.hip on the rest (skinny
  * weight-streaming pieces up to 255 rows, masked 128-row LDS tiles beyond); 1 = EVERY row on the masked 128-row tiles (bit-identical to the LDS-DMA kernels:
  * the test of that statement); 2 = every row as skinny pieces (same products, K-tiles summed in eight interleaved chains: fp32-rounding-level differences). */

@@ -9,7 +9,6 @@
 // arithmetic on the fp32 bits (RNE at mantissa bit 20, saturate to 0x7e) so it does not depend on
 // the FP8 hardware-convert overflow mode.
 #include "common.h"
-#include "internal.h"
 
 namespace mila {
 
@@ -241,52 +240,6 @@ __global__ __launch_bounds__(256) void quantize_fp8_per_token_kernel(uint8_t* __
     }
 }
 
-// The same quantizer with ONE WAVE per row for rows of <= 8192 elements (the attention output in front of o_proj: K = 4096 / 8192): the row sits in NV 16-byte chunks per
-// lane, the maximum is a DPP / permlane butterfly, there is no barrier and no LDS -- one load round trip, then the stores.  (A 2048 x 4096 pass is 25 MB; a workgroup per row
-// with two barriers took 10.5 us of launch-to-launch time whatever the row length up to 8192, tools/bench_quantize_act.py.)  The maximum is exact in any order and the
-// scale / encode arithmetic is the workgroup kernel's: same bytes.
-template <int NV>
-__global__ __launch_bounds__(256) void quantize_fp8_per_token_wave_kernel(uint8_t* __restrict__ dst, float* __restrict__ scales, const uint16_t* __restrict__ src, int M, int K)
-{
-    const int lane = threadIdx.x & 63;
-    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= (size_t)M) return;
-    const uint16_t* s = src + row * K;
-    uint8_t* d = dst + row * K;
-    const int nvec = K / 8;
-    u32x4 keep[NV];
-#pragma unroll
-    for (int k = 0; k < NV; ++k)
-    {
-        const int i = lane + 64 * k;
-        keep[k] = (i < nvec) ? ld16(s + (size_t)i * 8) : u32x4{0u, 0u, 0u, 0u};
-    }
-    float m = 0.0f;
-#pragma unroll
-    for (int k = 0; k < NV; ++k)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(fabsf(bf16_lo(keep[k][e])), fabsf(bf16_hi(keep[k][e]))));
-    m = wave_max(m);
-    const float scale = fmaxf(m, 1e-12f) / 448.0f;
-    if (lane == 0) scales[row] = scale;
-    const float inv = 1.0f / scale;
-#pragma unroll
-    for (int k = 0; k < NV; ++k)
-    {
-        const int i = lane + 64 * k;
-        if (i >= nvec) continue;
-        u32x2 o;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-        {
-            int r = __builtin_amdgcn_cvt_pk_fp8_f32(bf16_lo(keep[k][2 * h]) * inv, bf16_hi(keep[k][2 * h]) * inv, 0, false);
-            r = __builtin_amdgcn_cvt_pk_fp8_f32(bf16_lo(keep[k][2 * h + 1]) * inv, bf16_hi(keep[k][2 * h + 1]) * inv, r, true);
-            o[h] = (uint32_t)r;
-        }
-        *reinterpret_cast<u32x2*>(d + (size_t)i * 8) = o;
-    }
-}
-
 int gemm_fp8_kernel_for(int M, int K, int N);
 int launch_gemm_fp8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
                     int M, int K, int N, hipStream_t s);
@@ -351,28 +304,11 @@ int mila_cdna4_upcast_fp4_to_fp8(uint8_t* out, const uint8_t* packed, const floa
     MILA_LAUNCH_CHECK("upcast_fp4_to_fp8");
 }
 
-static int g_quantize_wave_rows = 1;      // tuning hook: 0 = the workgroup-per-row kernel for every row length (A/B, bit-identity test)
-int mila_cdna4_tune_quantize_act(int wave_rows)
-{
-    if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
-    g_quantize_wave_rows = wave_rows;
-    return MILA_OK;
-}
-
 int mila_cdna4_quantize_fp8_per_token(uint8_t* dst, float* scales, const uint16_t* src, int M, int K, mila_stream_t stream)
 {
     MILA_REQUIRE(dst && scales && src, "quantize_fp8_per_token: null pointer");
     MILA_REQUIRE(M > 0 && K > 0 && K % 8 == 0, "quantize_fp8_per_token: bad sizes (M=%d K=%d)", M, K);
     const int nch = (K / 8 + 255) / 256;
-    if (g_quantize_wave_rows && K <= 8192)
-    {
-        const int nv = (K / 8 + 63) / 64;
-        const dim3 grid((M + 3) / 4), block(256);
-        if (nv <= 4) hipLaunchKernelGGL(quantize_fp8_per_token_wave_kernel<4>, grid, block, 0, as_stream(stream), dst, scales, src, M, K);
-        else if (nv <= 8) hipLaunchKernelGGL(quantize_fp8_per_token_wave_kernel<8>, grid, block, 0, as_stream(stream), dst, scales, src, M, K);
-        else hipLaunchKernelGGL(quantize_fp8_per_token_wave_kernel<16>, grid, block, 0, as_stream(stream), dst, scales, src, M, K);
-        MILA_LAUNCH_CHECK("quantize_fp8_per_token");
-    }
     if (nch <= 2) hipLaunchKernelGGL(quantize_fp8_per_token_kernel<2>, dim3(M), dim3(256), 0, as_stream(stream), dst, scales, src, K);
     else if (nch <= 4) hipLaunchKernelGGL(quantize_fp8_per_token_kernel<4>, dim3(M), dim3(256), 0, as_stream(stream), dst, scales, src, K);
     else if (nch <= 8) hipLaunchKernelGGL(quantize_fp8_per_token_kernel<8>, dim3(M), dim3(256), 0, as_stream(stream), dst, scales, src, K);

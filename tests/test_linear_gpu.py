@@ -771,26 +771,3 @@ def test_persistent_tile_walk_gives_the_bits_of_one_workgroup_per_tile(M, K, N, 
         exp = 0.5 * h * (1 + np.tanh(0.7978845608028654 * (h + 0.044715 * h ** 3)))
     # (the Linear output is rounded to bf16 BEFORE the bias is added: where the two nearly cancel, one ulp of the product is several of the sum -- hence the absolute floor)
     assert_bf16_close(outs[0][0][rows], exp, 2, 2.0 ** -7 * max(1.0, float(np.abs(exp).max())), "persistent gemm vs oracle")
-
-
-@pytest.mark.parametrize("M,K", [(2048, 4096), (2048, 8192), (2048, 3840), (5, 520), (1, 8), (300, 15360)])
-def test_per_token_activation_quantization_wave_rows_give_the_workgroup_kernels_bytes(M, K):
-    """round 3: rows of <= 8192 elements are quantized by one wave each (no barrier, no LDS); the maximum is exact in any order and the scale / encode arithmetic is shared,
-    so codes and scales equal the workgroup-per-row kernel's (forced through mila_cdna4_tune_quantize_act) and the oracle's (CudaFp8Prefill.cu:108-160)"""
-    lib = capi.load()
-    rng = np.random.default_rng(M + K)
-    X = orc.round_bf16((rng.standard_normal((M, K)) * rng.uniform(0.1, 5.0, (M, 1))).astype(np.float32))
-    X[M // 2] = 0.0                                                          # an all-zero token: the 1e-12 guard
-    Xd = dev_u16(orc.to_bf16_bits(X))
-    outs = []
-    for form in (1, 0):
-        capi.check(lib.mila_cdna4_tune_quantize_act(form))
-        try:
-            X8, ts = torch.full((M, K), 0x7f, dtype=torch.uint8, device="cuda"), empty_f32(M)
-            capi.call("quantize_fp8_per_token", X8, ts, Xd, M, K)
-            outs.append((X8.cpu().numpy(), host(ts)))
-        finally:
-            capi.check(lib.mila_cdna4_tune_quantize_act(1))
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), "wave-per-row form differs from the workgroup-per-row form"
-    x8_exp, ts_exp = orc.quantize_act_fp8_per_token(X)
-    assert np.array_equal(outs[0][1], ts_exp) and np.array_equal(outs[0][0], x8_exp)

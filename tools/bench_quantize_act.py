@@ -1,4 +1,6 @@
-"""per-token e4m3 activation quantization (the W4A8 prefill's per-forward pass) by row length at M = 2048: us and GB/s (2 B read + 1 B written per element)
+"""per-token e4m3 activation quantization (the W4A8 prefill's per-forward pass) by row length at M = 2048: us and GB/s (2 B read + 1 B written per element).
+The launch-to-launch time of this Python loop is ~10 us whatever the kernel: read the kernel durations from `rocprofv3 --kernel-trace --stats -- python3 tools/bench_quantize_act.py` (round 3: 6.1 / 6.1 / 9.9 / 17.2 us at K = 3840 / 4096 / 8192 / 15360; a wave-per-row
+form measured 6.7 / 11.2 us at K = 4096 / 8192 -- slower, not kept).
     python tools/bench_quantize_act.py"""
 import json
 import os
