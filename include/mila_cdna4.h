@@ -360,6 +360,12 @@ typedef struct mila_fused_matvec_args {
     float eps;
     int fmt, K, N, group, geglu;
     int f32_out;              /* != 0: y is float[N] (lm_head logits); not combinable with geglu */
+    /* ABI 3, optional (NULL = off), f32_out only: the greedy sampler's first stage in this launch's epilogue -- every workgroup leaves the largest of its logits and its
+     * index (ties to the lowest index, Sampling.cu:23-75) in argmax_scratch (>= sample_scratch_bytes()), *argmax_blocks (host) receives their number;
+     * sample_argmax_final_advance then picks the token: the same token as sample_argmax_fp32 on y, one launch fewer. */
+    void* argmax_scratch;
+    size_t argmax_scratch_bytes;
+    int* argmax_blocks;
 } mila_fused_matvec_args;
 MILA_API int mila_cdna4_fused_norm_matvec(const mila_fused_matvec_args* host_args, mila_stream_t stream);
 
@@ -423,6 +429,11 @@ MILA_API int mila_cdna4_snapshot_token(const int32_t* token, unsigned long long*
 MILA_API int mila_cdna4_sample_argmax_advance_fp32(const float* logits, int32_t* token_out, int vocab, void* scratch, size_t scratch_bytes,
                                                    int32_t* position_dev, unsigned long long* seq_dev, unsigned long long* ring, int ring_size,
                                                    mila_stream_t stream);
+
+/* the final stage of the greedy sampler alone, over the `blocks` partials a fused_norm_matvec launch with argmax_scratch left in `scratch`, with the tail of
+ * sample_argmax_advance_fp32 (*position_dev += 1, publication when ring != NULL) */
+MILA_API int mila_cdna4_sample_argmax_final_advance(int32_t* token_out, const void* scratch, size_t scratch_bytes, int blocks, int32_t* position_dev,
+                                                    unsigned long long* seq_dev, unsigned long long* ring, int ring_size, mila_stream_t stream);
 
 /* One-launch decode attention for one token (B == 1): q/k/v per-head RMSNorm + RoPE + KV append (the
  * work of fused_qkv_post) folded into the flash-decode kernel's prologue, where it overlaps the first

@@ -86,7 +86,8 @@ class fused_matvec_args(C.Structure):
     _fields_ = [("y", C.c_void_p), ("x", C.c_void_p), ("W", C.c_void_p), ("scales", C.c_void_p),
                 ("norm_w", C.c_void_p), ("post_w", C.c_void_p), ("res", C.c_void_p), ("res_out", C.c_void_p),
                 ("post_scale", C.c_float), ("eps", C.c_float), ("fmt", C.c_int), ("K", C.c_int),
-                ("N", C.c_int), ("group", C.c_int), ("geglu", C.c_int), ("f32_out", C.c_int)]
+                ("N", C.c_int), ("group", C.c_int), ("geglu", C.c_int), ("f32_out", C.c_int),
+                ("argmax_scratch", C.c_void_p), ("argmax_scratch_bytes", C.c_size_t), ("argmax_blocks", C.POINTER(C.c_int))]
 
 
 class decode_chain_args(C.Structure):
@@ -159,7 +160,7 @@ EXPORTED = [
     "sample_scratch_bytes", "sample_argmax_fp32", "sample_argmax_bf16",
     "sample_stochastic_scratch_bytes", "sample_stochastic_fp32", "sample_stochastic_bf16",
     "fused_norm_matvec", "fused_qkv_post", "fused_qkv_post_prefill", "fused_tail_norm_bf16", "fused_tail_norm_quant_bf16",
-    "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position", "advance_position_snapshot", "snapshot_token", "sample_argmax_advance_fp32", "fused_attn_decode_batch_bf16", "fused_attn_decode_bf16",
+    "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position", "advance_position_snapshot", "snapshot_token", "sample_argmax_advance_fp32", "sample_argmax_final_advance", "fused_attn_decode_batch_bf16", "fused_attn_decode_bf16",
     "dequantize_to_bf16", "gemm_geglu_fp8_scaled",
 ]
 

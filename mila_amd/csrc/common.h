@@ -31,6 +31,7 @@ static inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + 
 
 constexpr int kWave = 64;
 constexpr int kNumCU = 256;     // MI355X
+constexpr int kArgmaxPartials = 2 * kNumCU;      // per-workgroup (value, index) partials of the greedy sampler's first stage (own kernel, or the lm_head matvec's epilogue)
 
 // ---- vector types ----------------------------------------------------------------------------
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

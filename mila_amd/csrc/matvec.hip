@@ -49,6 +49,7 @@ __global__ __launch_bounds__(1024) void matvec_kernel(const MatvecParams p)
 
 // ---- host side ------------------------------------------------------------------------------
 static int g_tune_R = 0, g_tune_U = 0, g_tune_blocks = 0;
+static thread_local int t_last_matvec_blocks = 0;      // workgroups of this thread's last matvec launch (= the sampler partials a lm_head launch wrote)
 
 template <int FMT, int R, int U, int PRO, bool GEGLU, bool F32OUT, int XC>
 static int launch_xc(const MatvecParams& p, int max_blocks, hipStream_t s)
@@ -62,6 +63,7 @@ static int launch_xc(const MatvecParams& p, int max_blocks, hipStream_t s)
     int blocks = (n_rg + kMatvecWaves - 1) / kMatvecWaves;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
+    t_last_matvec_blocks = blocks;
     hipLaunchKernelGGL((matvec_kernel<FMT, R, U, PRO, GEGLU, F32OUT, XC>), dim3(blocks), dim3(64 * kMatvecWaves), lds, s, p);
     MILA_LAUNCH_CHECK("matvec");
 }
@@ -271,8 +273,27 @@ int mila_cdna4_fused_norm_matvec(const mila_fused_matvec_args* a, mila_stream_t 
                    a->res, a->res_out, a->post_scale, a->eps, a->K, a->N, a->group, 0, 0};
     hipStream_t s = as_stream(stream);
     MILA_REQUIRE(!(a->geglu && a->f32_out), "fused_norm_matvec: geglu and f32_out are exclusive");
+    if (a->argmax_scratch)
+    {
+        // the greedy sampler's first stage in the lm_head's epilogue: one (value, index) partial per workgroup, laid out as sample_argmax_fp32 lays its own
+        // ([kArgmaxPartials] floats, then [kArgmaxPartials] ints); sample_argmax_final_advance reduces *argmax_blocks of them
+        MILA_REQUIRE(a->f32_out, "fused_norm_matvec: argmax_scratch needs f32_out (the logits)");
+        MILA_REQUIRE(a->argmax_blocks != nullptr, "fused_norm_matvec: argmax_blocks is required with argmax_scratch");
+        if (a->argmax_scratch_bytes < mila_cdna4_sample_scratch_bytes())
+            return set_error(MILA_E_SCRATCH_TOO_SMALL, "fused_norm_matvec: argmax scratch %zu bytes < required %zu", a->argmax_scratch_bytes, mila_cdna4_sample_scratch_bytes());
+        p.amax_v = reinterpret_cast<float*>(a->argmax_scratch);
+        p.amax_i = reinterpret_cast<int*>(p.amax_v + kArgmaxPartials);
+    }
     if (a->f32_out)
-        return a->res ? dispatch_fmt<2, false, true>(a->fmt, p, s) : dispatch_fmt<1, false, true>(a->fmt, p, s);
+    {
+        rc = a->res ? dispatch_fmt<2, false, true>(a->fmt, p, s) : dispatch_fmt<1, false, true>(a->fmt, p, s);
+        if (rc == MILA_OK && a->argmax_scratch)
+        {
+            if (t_last_matvec_blocks > kArgmaxPartials) return set_error(MILA_E_RUNTIME, "fused_norm_matvec: %d workgroups exceed the %d sampler partials", t_last_matvec_blocks, kArgmaxPartials);
+            *a->argmax_blocks = t_last_matvec_blocks;
+        }
+        return rc;
+    }
     if (a->res)
         return a->geglu ? dispatch_fmt<2, true, false>(a->fmt, p, s) : dispatch_fmt<2, false, false>(a->fmt, p, s);
     return a->geglu ? dispatch_fmt<1, true, false>(a->fmt, p, s) : dispatch_fmt<1, false, false>(a->fmt, p, s);

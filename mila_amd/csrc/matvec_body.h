@@ -65,7 +65,17 @@ struct MatvecParams
     float post_scale, eps;
     int K, N, group;
     int comb_splits, comb_heads;   // X_COMBINE: x = combine of the decode-attention split partials [heads, splits, HS + 4] at p.x
+    // Y_F32 (lm_head) only, both or neither: the greedy sampler's FIRST stage in this kernel's epilogue -- workgroup b writes the largest of its rows' outputs and its
+    // column (ties to the lowest column, Sampling.cu:23-75) to amax_v[b] / amax_i[b]; the sampler's final stage reduces the gridDim.x partials (one launch fewer per token)
+    float* amax_v = nullptr;
+    int* amax_i = nullptr;
 };
+
+// the sampler's order: strictly larger wins, equal values go to the lower index, NaN never wins (csrc/sampling.hip: better)
+__device__ __forceinline__ void argmax_better(float& bv, int& bi, float v, int i)
+{
+    if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+}
 
 constexpr int kMatvecWaves = 16;   // 1024 threads
 
@@ -341,6 +351,8 @@ __device__ __forceinline__ void matvec_body(const MatvecParams& p, u32x4* xs, fl
         }
     };
 
+    float amax_bv = -3.402823466e+38f;      // lane 0 of each wave: the best (value, column) among the rows this wave has stored (Y_F32 with p.amax_v)
+    int amax_bi = 0x7fffffff;
     auto finish = [&](int rg_) {
         const int col0 = rg_ * R;
 #pragma unroll
@@ -374,7 +386,11 @@ __device__ __forceinline__ void matvec_body(const MatvecParams& p, u32x4* xs, fl
                     const float g = round_bf16(acc[2 * r]), up = round_bf16(acc[2 * r + 1]);
                     v = gelu_tanh(g) * up;
                 }
-                if constexpr (YDST == Y_F32) reinterpret_cast<float*>(p.y)[col] = v;
+                if constexpr (YDST == Y_F32)
+                {
+                    reinterpret_cast<float*>(p.y)[col] = v;
+                    if (p.amax_v) argmax_better(amax_bv, amax_bi, v, col);
+                }
                 else if constexpr (YDST == Y_HANDOFF) handoff_store(reinterpret_cast<uint32_t*>(p.y), col, f32_to_bf16_bits(v));
                 else reinterpret_cast<uint16_t*>(p.y)[col] = f32_to_bf16_bits(v);
             }
@@ -407,6 +423,26 @@ __device__ __forceinline__ void matvec_body(const MatvecParams& p, u32x4* xs, fl
     }
     if (rem >= 2) consume(bb);
     if (rem == 3) consume(ba);
+
+    if constexpr (YDST == Y_F32)
+    {
+        // the sampler's first stage: the workgroup's 16 per-wave candidates through LDS (red_a / red_b are free since the prologue), one partial per workgroup
+        if (p.amax_v)
+        {
+            __syncthreads();
+            if (lane == 0) { red_a[wib] = amax_bv; red_b[wib] = __int_as_float(amax_bi); }
+            __syncthreads();
+            if (tid == 0)
+            {
+                float bv = red_a[0];
+                int bi = __float_as_int(red_b[0]);
+#pragma unroll
+                for (int w = 1; w < kMatvecWaves; ++w) argmax_better(bv, bi, red_a[w], __float_as_int(red_b[w]));
+                p.amax_v[block] = bv;
+                p.amax_i[block] = bi;
+            }
+        }
+    }
 }
 
 }  // namespace mila

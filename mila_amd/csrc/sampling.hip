@@ -7,7 +7,7 @@
 
 namespace mila {
 
-constexpr int kArgmaxBlocks = 256;
+constexpr int kArgmaxBlocks = kArgmaxPartials;      // (common.h) 512: the lm_head matvec runs two workgroups per CU
 
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
@@ -425,6 +425,20 @@ int mila_cdna4_sample_argmax_advance_fp32(const float* logits, int32_t* token_ou
     if (rc) return rc;
     hipLaunchKernelGGL(argmax_final_advance_kernel, dim3(1), dim3(256), 0, as_stream(stream), pv, pi, blocks, token_out, position_dev, seq_dev, ring, ring_size);
     MILA_LAUNCH_CHECK("sample_argmax_advance_fp32");
+}
+
+// only the final stage, over `blocks` partials a lm_head launch left in `scratch` (fused_norm_matvec with argmax_scratch): the captured greedy step's tail in ONE launch
+int mila_cdna4_sample_argmax_final_advance(int32_t* token_out, const void* scratch, size_t scratch_bytes, int blocks, int32_t* position_dev,
+                                           unsigned long long* seq_dev, unsigned long long* ring, int ring_size, mila_stream_t stream)
+{
+    MILA_REQUIRE(token_out && scratch && position_dev, "sample_argmax_final_advance: null pointer");
+    MILA_REQUIRE(blocks > 0 && blocks <= kArgmaxBlocks, "sample_argmax_final_advance: blocks %d out of range (1 .. %d)", blocks, kArgmaxBlocks);
+    MILA_REQUIRE((ring == nullptr) == (seq_dev == nullptr) && (ring == nullptr || ring_size > 0), "sample_argmax_final_advance: seq_dev, ring and ring_size go together");
+    if (scratch_bytes < (size_t)kArgmaxBlocks * 8) return set_error(MILA_E_SCRATCH_TOO_SMALL, "sample_argmax_final_advance: scratch %zu bytes < required %zu", scratch_bytes, (size_t)kArgmaxBlocks * 8);
+    const float* pv = reinterpret_cast<const float*>(scratch);
+    const int* pi = reinterpret_cast<const int*>(pv + kArgmaxBlocks);
+    hipLaunchKernelGGL(argmax_final_advance_kernel, dim3(1), dim3(256), 0, as_stream(stream), pv, pi, blocks, token_out, position_dev, seq_dev, ring, ring_size);
+    MILA_LAUNCH_CHECK("sample_argmax_final_advance");
 }
 
 int mila_cdna4_sample_argmax_bf16(const uint16_t* logits, int32_t* token_out, int vocab, void* scratch, size_t scratch_bytes,

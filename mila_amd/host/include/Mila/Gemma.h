@@ -215,12 +215,14 @@ namespace Mila::Dnn
             hipGraph_t g = nullptr;
             try
             {
-                enqueueFusedStep( token.data(), 0, pos_dev_->data() );
+                // greedy sampler (feeds the next replay) + position bump + publication of the token.  The sampler's FIRST stage runs in the lm_head's epilogue (every
+                // workgroup leaves its best logit and index in the sampler scratch), its final reduction does the other three: one launch behind the head, not three
+                int sampler_partials = 0;
+                enqueueFusedStep( token.data(), 0, pos_dev_->data(), sample_in_graph_ ? &sampler_partials : nullptr );
                 if ( sample_in_graph_ )
-                    // greedy sampler (feeds the next replay) + position bump + publication of the token: the sampler's final reduction does all three
-                    Compute::rocmCheck( mila_cdna4_sample_argmax_advance_fp32( logits_->data(), const_cast<TokenTensor&>( token ).data(), (int)cfg_.vocab_size, sample_scratch_->data(),
-                                                                               sample_scratch_->sizeInBytes(), pos_dev_->data(), token_ring_ ? token_seq_ : nullptr, token_ring_,
-                                                                               token_ring_ ? token_ring_size_ : 0, ctx_->getStream() ) );
+                    Compute::rocmCheck( mila_cdna4_sample_argmax_final_advance( const_cast<TokenTensor&>( token ).data(), sample_scratch_->data(), sample_scratch_->sizeInBytes(), sampler_partials,
+                                                                                pos_dev_->data(), token_ring_ ? token_seq_ : nullptr, token_ring_, token_ring_ ? token_ring_size_ : 0,
+                                                                                ctx_->getStream() ) );
                 else
                     Compute::rocmCheck( mila_cdna4_advance_position( pos_dev_->data(), ctx_->getStream() ) );
             }
@@ -775,7 +777,8 @@ namespace Mila::Dnn
 
         /// x_l (hidden) -> x_{l+1}.  The sandwich tail of layer l-1 (post_ffn_norm, residual, layer scalar)
         /// is the prologue of layer l's qkv kernel; the tail of the last layer is the prologue of the head.
-        void enqueueFusedStep( const int32_t* token_dev, int position, const int32_t* pos_dev )
+        /// sampler_partials != nullptr: the head also runs the greedy sampler's first stage into sample_scratch_ and reports the number of partials
+        void enqueueFusedStep( const int32_t* token_dev, int position, const int32_t* pos_dev, int* sampler_partials = nullptr )
         {
             mila_stream_t st = ctx_->getStream();
             embed( token_dev, 1, *hidden_[ 0 ] );
@@ -823,6 +826,7 @@ namespace Mila::Dnn
                 a.norm_w = final_norm_->getWeight()->data(); a.post_w = prev->post_ffn_norm->getWeight()->data();
                 a.res = res1_->data(); a.res_out = hidden_[ next ]->data(); a.post_scale = prev->layer_scalar; a.eps = cfg_.rms_norm_eps;
                 a.fmt = kTableFmt; a.K = (int)cfg_.embedding_dim; a.N = (int)cfg_.vocab_size; a.group = 0; a.geglu = 0; a.f32_out = 1;
+                if ( sampler_partials ) { a.argmax_scratch = sample_scratch_->data(); a.argmax_scratch_bytes = sample_scratch_->sizeInBytes(); a.argmax_blocks = sampler_partials; }
                 Compute::rocmCheck( mila_cdna4_fused_norm_matvec( &a, st ) );
             }
         }

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import orc
-from gpu_util import assert_bf16_close, bits, dev_f32, dev_u16, dev_u8, empty_f32, empty_u16
+from gpu_util import assert_bf16_close, bits, dev_f32, dev_i32, dev_u16, dev_u8, empty_f32, empty_u16, host
 from mila_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -477,3 +477,65 @@ def test_prefetch_l3_reads_only():
     assert torch.equal(src, keep) and float(sink.abs().sum()) == 0.0
     with pytest.raises(capi.InvalidArgument):
         capi.call("prefetch_l3", src, C.c_size_t(n), 0, sink)
+
+
+@pytest.mark.parametrize("fmt,N,with_res", [(0, 262144, True), (1, 262144, True), (0, 5000, False), (1, 300, False)])
+def test_lm_head_epilogue_runs_the_samplers_first_stage(fmt, N, with_res):
+    """round 3: the lm_head launch (tail + final norm + matvec, FP32 logits) also leaves one (largest logit, index) partial per workgroup in the sampler's scratch, and
+    sample_argmax_final_advance picks the token from them -- the token sample_argmax_fp32 picks from the logits of the same launch (ties to the LOWEST index,
+    Sampling.cu:23-75: duplicated weight rows make exact ties across waves and workgroups), with the position bump and the publication of sample_argmax_advance_fp32"""
+    lib, stream = capi.load(), C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(N + fmt)
+    K = 3840
+    Wb = orc.to_bf16_bits((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    dup = [N - 1, N // 2 + 1, 7] if N > 1000 else [N - 1, 3]
+    best = Wb[5].copy()
+    if fmt == 0:
+        Wd, sd = dev_u16(Wb), None
+    else:
+        q, sc = orc.quantize_fp8_per_channel(Wb)
+        Wd, sd = dev_u8(q), dev_f32(sc)
+    x = _bf(rng.standard_normal(K))
+    nw = _d(_bf(1 + 0.1 * rng.uniform(-1, 1, K)))
+    logits = empty_f32(N)
+    nb = lib.mila_cdna4_sample_scratch_bytes()
+    scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    blocks = C.c_int(0)
+    kw = dict(y=logits, x=_d(x), W=Wd, scales=sd if sd is not None else 0, norm_w=nw, post_w=0, res=0, res_out=0, post_scale=1.0, eps=1e-6, fmt=fmt, K=K, N=N, group=128,
+              geglu=0, f32_out=1)
+    if with_res:
+        res, r_out, pw = _d(_bf(rng.standard_normal(K))), empty_u16(K), _d(_bf(1 + 0.1 * rng.uniform(-1, 1, K)))
+        kw.update(post_w=pw, res=res, res_out=r_out, post_scale=0.75)
+    a = _args(**kw)
+    a.argmax_scratch = scratch.data_ptr(); a.argmax_scratch_bytes = nb; a.argmax_blocks = C.pointer(blocks)
+    capi.check(lib.mila_cdna4_fused_norm_matvec(C.byref(a), stream))
+    lg = host(logits)
+    # make exact ties at the maximum: copy the winning row over a few others and run again
+    win = int(np.argmax(lg))
+    rows = sorted(set(dup + [win]))
+    if fmt == 0:
+        Wd[rows] = Wd[win]
+    else:
+        Wd[rows] = Wd[win]
+        sd[rows] = sd[win]
+    del best
+    capi.check(lib.mila_cdna4_fused_norm_matvec(C.byref(a), stream))
+    lg = host(logits)
+    assert 0 < blocks.value <= nb // 8
+    assert np.all(lg[rows] == lg[win]) and int(np.argmax(lg)) == rows[0], "the tie was not constructed"
+    tok, tok_ref, pos = dev_i32(np.array([-1])), dev_i32(np.array([-1])), dev_i32(np.array([9]))
+    seq = torch.tensor([2], dtype=torch.int64, device="cuda")
+    ring = torch.zeros(4, dtype=torch.int64, device="cuda")
+    capi.call("sample_argmax_final_advance", tok, scratch, C.c_size_t(nb), blocks.value, pos, seq, ring, 4)
+    scratch2 = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    capi.call("sample_argmax_fp32", logits, tok_ref, N, scratch2, C.c_size_t(nb))
+    assert int(host(tok)[0]) == int(host(tok_ref)[0]) == rows[0]
+    assert int(host(pos)[0]) == 10 and int(seq.item()) == 3 and int(ring[3].item()) == (3 << 32) | rows[0]
+    # the logits of a launch with the first stage are the logits of a launch without it
+    b = _args(**kw)
+    logits2 = empty_f32(N)
+    b.y = logits2.data_ptr()
+    capi.check(lib.mila_cdna4_fused_norm_matvec(C.byref(b), stream))
+    assert np.array_equal(host(logits2).view(np.uint32), lg.view(np.uint32))
+    with pytest.raises(capi.InvalidArgument):
+        capi.call("sample_argmax_final_advance", tok, scratch, C.c_size_t(nb), 0, pos, seq, ring, 4)
