@@ -513,11 +513,9 @@ def test_lm_head_epilogue_runs_the_samplers_first_stage(fmt, N, with_res):
     # make exact ties at the maximum: copy the winning row over a few others and run again
     win = int(np.argmax(lg))
     rows = sorted(set(dup + [win]))
-    if fmt == 0:
-        Wd[rows] = Wd[win]
-    else:
-        Wd[rows] = Wd[win]
-        sd[rows] = sd[win]
+    Wd[rows] = Wd[win].clone()
+    if fmt != 0:
+        sd[rows] = sd[win].clone()
     del best
     capi.check(lib.mila_cdna4_fused_norm_matvec(C.byref(a), stream))
     lg = host(logits)
