@@ -23,10 +23,13 @@
 #include "rope_common.h"
 #include "internal.h"
 #include "attention_generic.h"
+#include "attention_tiles.h"
 
 namespace mila {
 
 constexpr int kMaxSplits = 64;
+constexpr int kMaxSplitsMfma = 256;      // the long-context MFMA decode (attn_decode_mfma_kernel): one workgroup per CU
+constexpr int kMfmaMinBand = 4096;        // live band (keys) from which a 16-head group on one KV head takes the MFMA decode
 
 // ---- KV append ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void kv_write_bf16_kernel(uint16_t* __restrict__ Kc, uint16_t* __restrict__ Vc,
@@ -522,6 +525,211 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(uint16_t* __restrict__
     Y[((size_t)b * NH + h) * HS + d] = combine_dim<false>(base, HS, splits, d);
 }
 
+
+// ---- long-context decode on the matrix cores (round 3) ------------------------------------------------------------------------------------------
+// Gemma's global layers put 16 query heads on ONE KV head: at one decode position those 16 heads ARE a 16-row MFMA tile, and K / V rows are shared by all of them.
+// The wave-per-position kernel above costs a 64-lane reduction per (head, key): at 32 768 keys it is vector-ALU-bound, 63.7 us for 67 MB of K / V (1.05 TB/s,
+// profiles/r03_long_context.txt) -- and its 8 head-groups of 2 read every row 8 times from L2.  Here a workgroup takes one split of the keys for all 16 heads:
+// K / V tiles of 32 keys go global -> registers -> LDS (double-buffered images of attention_tiles.h, the next tile's loads in flight during this tile's products),
+// S^T = K Q^T and O^T += V^T P^T run as in the flash prefill (transposed products: a head's keys sit in its lane's registers, the row statistics are in-lane plus two
+// permlane steps, the exponentiated scores ARE the second product's B operand).  The four waves split the OUTPUT dimensions (each computes the whole S^T and softmax
+// of the tile -- identical in all four -- and a quarter of O^T: 32 accumulator registers).  Partials in the layout of the scalar kernel: O (unnormalised, relative
+// to M) | M | L per (head, split); up to 256 splits, merged by attn_combine_many_kernel.  fp32 scores and statistics, P rounded to bf16 for the PV product (as the
+// flash kernels do): within 1 bf16 ulp of the double-precision oracle like them, NOT bit-identical to the scalar kernel -- the choice depends on (window, capacity)
+// only, so every path of a model (reference order, fused, graph replay) takes the same kernel.
+template <int HS>
+__global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnParams p)
+{
+    constexpr int KSTEPS = HS / 32, DT = HS / 16, DTW = DT / 4;
+    constexpr int ROWB = HS * 2, TILE_BYTES = kKeysPerTile * ROWB;
+    constexpr int CH = (kKeysPerTile * (ROWB / 16)) / 256;          // 16-byte chunks each thread stages per tile and operand
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_mfma[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int GS = p.NH / p.NKV, n16 = GS / 16;
+    const int split = blockIdx.x, kvh = blockIdx.y / n16, h0 = kvh * GS + (blockIdx.y % n16) * 16, b = blockIdx.z;
+    const int pos = p.pos_dev ? *p.pos_dev : p.position;
+    const int len = pos + 1;
+    const int band_begin = (p.window > 0) ? max(0, len - p.window) : 0;
+    const int band = len - band_begin;
+    const int chunk = (band + p.splits - 1) / p.splits;
+    const int begin = band_begin + split * chunk;
+    const int end = min(begin + chunk, len);
+    float* part = p.scratch + (((size_t)b * p.NH + h0 + l15) * p.splits + split) * (HS + 4);      // this lane's head row
+
+    f32x4 o[DTW];
+#pragma unroll
+    for (int d = 0; d < DTW; ++d) o[d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    if (begin < end)      // workgroup-uniform
+    {
+        // Q fragments (B operand of S^T = K Q^T): lane holds Q[head l15][32 s + 8 g + j]
+        s16x8 qf[KSTEPS];
+        {
+            const uint16_t* qp = p.Q + (size_t)b * (p.q_b_stride ? (size_t)p.q_b_stride : (size_t)p.NH * HS) + (size_t)(h0 + l15) * HS + 8 * g;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) qf[s] = __builtin_bit_cast(s16x8, ld16(qp + 32 * s));
+        }
+        const uint16_t* kbase = p.K + ((size_t)b * p.NKV + kvh) * p.capacity * HS;
+        const uint16_t* vbase = p.V + ((size_t)b * p.NKV + kvh) * p.capacity * HS;
+        struct StageRegs { u32x4 k[CH], v[CH]; };
+        auto stage_load = [&](StageRegs& r, int kt) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+            {
+                const int c = tid + 256 * i;
+                const int row = c / (ROWB / 16), ch = c % (ROWB / 16);
+                const int key = min(kt + row, end - 1);                 // rows past the split re-read its last key (masked below; a real, finite V row)
+                const size_t off = (size_t)(key % p.capacity) * HS + ch * 8;
+                r.k[i] = ld16(kbase + off);
+                r.v[i] = ld16(vbase + off);
+            }
+        };
+        auto stage_store = [&](const StageRegs& r, unsigned char* ldsK, unsigned char* ldsV) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+            {
+                const int c = tid + 256 * i;
+                const int row = c / (ROWB / 16), ch = c % (ROWB / 16);
+                *reinterpret_cast<u32x4*>(ldsK + k_off<HS>(row, ch)) = r.k[i];
+                *reinterpret_cast<u32x4*>(ldsV + v_off<HS>(row, ch)) = r.v[i];
+            }
+        };
+        const int ntiles = (end - begin + kKeysPerTile - 1) / kKeysPerTile;
+        StageRegs regs;
+        stage_load(regs, begin);
+        for (int t = 0; t < ntiles; ++t)
+        {
+            const int kt = begin + t * kKeysPerTile;
+            // two [K | V] buffers: tile t is stored while slower waves may still read tile t - 1 from the other one (the store follows the barrier of tile t - 1,
+            // which every wave reaches only after its reads of tile t - 2): one barrier per tile
+            unsigned char* ldsK = smem_mfma + (t & 1) * 2 * TILE_BYTES;
+            unsigned char* ldsV = ldsK + TILE_BYTES;
+            stage_store(regs, ldsK, ldsV);
+            __syncthreads();
+            if (t + 1 < ntiles) stage_load(regs, kt + kKeysPerTile);
+
+            f32x4 s0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s)
+            {
+                const s16x8 ka = *reinterpret_cast<const s16x8*>(ldsK + k_off<HS>(l15, 4 * s + g));
+                const s16x8 kb = *reinterpret_cast<const s16x8*>(ldsK + k_off<HS>(16 + l15, 4 * s + g));
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka), __builtin_bit_cast(bf16x8, qf[s]), s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb), __builtin_bit_cast(bf16x8, qf[s]), s1, 0, 0, 0);
+            }
+            // lane holds keys kt + 4 g + r (s0) and kt + 16 + 4 g + r (s1) of head row l15
+            float sv[8], mt = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+            {
+                const int key = kt + ((r < 4) ? (4 * g + r) : (16 + 4 * g + (r - 4)));
+                const float raw = (r < 4) ? s0[r] : s1[r - 4];
+                sv[r] = (key < end) ? raw * p.scale : -INFINITY;
+                mt = fmaxf(mt, sv[r]);
+            }
+            mt = quad_rows_max(mt);
+            const float mn = fmaxf(m_run, mt);                      // finite: every tile holds at least one key of the split
+            const float alpha = __expf(m_run - mn);                 // m_run = -inf -> 0
+            float pe[8], rs = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+            {
+                pe[r] = __expf(sv[r] - mn);
+                rs += pe[r];
+            }
+            rs = quad_rows_sum(rs);
+            l_run = l_run * alpha + rs;
+            m_run = mn;
+            u32x4 pb;
+            pb[0] = pack_bf16x2(pe[0], pe[1]);
+            pb[1] = pack_bf16x2(pe[2], pe[3]);
+            pb[2] = pack_bf16x2(pe[4], pe[5]);
+            pb[3] = pack_bf16x2(pe[6], pe[7]);
+            const bf16x8 pfrag = __builtin_bit_cast(bf16x8, pb);
+            const bool rescale = __any(alpha != 1.0f);
+#pragma unroll
+            for (int dd = 0; dd < DTW; ++dd)
+            {
+                const int d = wave * DTW + dd;
+                const int q4 = l15 >> 2, pp = l15 & 3;
+                const int col = 16 * d + 4 * pp;
+                const int r_lo = 4 * g + q4, r_hi = 16 + 4 * g + q4;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(ldsV + v_off<HS>(r_lo, col >> 3) + ((col & 7) << 1)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(ldsV + v_off<HS>(r_hi, col >> 3) + ((col & 7) << 1)));
+                s16x8 va;
+                va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3];
+                va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
+                if (rescale) { o[dd][0] *= alpha; o[dd][1] *= alpha; o[dd][2] *= alpha; o[dd][3] *= alpha; }
+                o[dd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), pfrag, o[dd], 0, 0, 0);
+            }
+        }
+    }
+    // O^T[dim 16 d + 4 g + r][head l15] -> this head's partial row; (M, L) once per head (an empty split leaves O = 0, M = -inf, L = 0: the merge ignores it)
+#pragma unroll
+    for (int dd = 0; dd < DTW; ++dd) *reinterpret_cast<f32x4*>(part + 16 * (wave * DTW + dd) + 4 * g) = o[dd];
+    if (wave == 0 && g == 0) { part[HS] = m_run; part[HS + 1] = l_run; }
+}
+
+// merge of up to kMaxSplitsMfma partials per head: grid (NH, B, HS / 64), 64 threads -> 64 dims.  Two passes over the (M, L) pairs (broadcast loads), one over the
+// thread's own column; fixed order, so a replay reproduces an eager launch.
+__global__ __launch_bounds__(64) void attn_combine_many_kernel(uint16_t* __restrict__ Y, const float* __restrict__ scratch, int NH, int HS, int splits)
+{
+    const int h = blockIdx.x, b = blockIdx.y, d = blockIdx.z * 64 + threadIdx.x;
+    const int STR = HS + 4;
+    const float* base = scratch + ((size_t)b * NH + h) * splits * STR;
+    float M = -INFINITY;
+    for (int s = 0; s < splits; ++s) M = fmaxf(M, base[(size_t)s * STR + HS]);
+    float L = 0.0f, acc = 0.0f;
+#pragma unroll 8
+    for (int s = 0; s < splits; ++s)
+    {
+        const float ms = base[(size_t)s * STR + HS];
+        const float f = (ms == -INFINITY) ? 0.0f : __expf(ms - M);
+        L = fmaf(base[(size_t)s * STR + HS + 1], f, L);
+        acc = fmaf(base[(size_t)s * STR + d], f, acc);
+    }
+    Y[((size_t)b * NH + h) * HS + d] = f32_to_bf16_bits(L > 0.0f ? acc / L : 0.0f);
+}
+
+static int g_tune_decode_mfma = 1;      // tuning hook (mila_cdna4_tune_attn_split, negative values): 0 = never take the MFMA decode
+
+static bool mfma_decode_applies(int NH, int NKV, int HS, int band_max)
+{
+    return g_tune_decode_mfma && HS == 512 && NKV > 0 && (NH / NKV) % 16 == 0 && band_max >= kMfmaMinBand;
+}
+static int mfma_decode_splits(int B, int NH, int NKV, int band_max)
+{
+    const int groups = NKV * ((NH / NKV) / 16) * B;
+    int s = (band_max + 127) / 128;                      // at least four key tiles per split at the full band
+    const int cap = max(1, kNumCU / groups);
+    if (s > cap) s = cap;
+    if (s > kMaxSplitsMfma) s = kMaxSplitsMfma;
+    return max(s, 1);
+}
+static int launch_decode_mfma(const AttnParams& p, int B, hipStream_t s)
+{
+    constexpr int HS = 512;
+    static bool attr_set = false;
+    const size_t lds = 4 * (size_t)kKeysPerTile * HS * 2;      // two [K | V] tile pairs
+    if (!attr_set)
+    {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_mfma_kernel<HS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(attn_decode_mfma)");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    const int n16 = (p.NH / p.NKV) / 16;
+    hipLaunchKernelGGL((attn_decode_mfma_kernel<HS>), dim3(p.splits, p.NKV * n16, B), dim3(256), lds, s, p);
+    int rc = check_hip(hipGetLastError(), "attn_decode_mfma");
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_combine_many_kernel, dim3(p.NH, B, HS / 64), dim3(64), 0, s, p.Y, p.scratch, p.NH, HS, p.splits);
+    return check_hip(hipGetLastError(), "attn_combine_many");
+}
+
 static int heads_per_group(int GS, int HS) { return HS >= 512 ? (GS >= 2 ? 2 : 1) : (GS >= 4 ? 4 : GS); }
 
 template <int HS, int GH, bool FUSED>
@@ -611,6 +819,33 @@ static int run_decode(uint16_t* Y, const uint16_t* Q, uint16_t* Kc, uint16_t* Vc
     p.splits = decode_splits(B, NH, NKV, HS, band_max);
     p.scale = scale;
     p.pos_dev = pos_dev;
+    if (mfma_decode_applies(NH, NKV, HS, band_max) && !p.tickets && !p.no_combine && !p.warm_a && !p.warm_b)
+    {
+        // 16 heads on one KV head over a long band: the matrix-core decode (attn_decode_mfma_kernel).  The fused form is the CHAIN here -- q/k/v norm + RoPE + KV append
+        // as its own launch, the roped q rows parked behind the partials -- the 4 us it costs are nothing against a band of thousands of keys
+        p.splits = mfma_decode_splits(B, NH, NKV, band_max);
+        const size_t part_floats = (size_t)B * NH * p.splits * (HS + 4);
+        const size_t need = part_floats * sizeof(float) + (fused ? (size_t)B * NH * HS * 2 : 0);
+        if (!scratch || scratch_bytes < need) return set_error(MILA_E_SCRATCH_TOO_SMALL, "%s: scratch %zu bytes < required %zu", who, scratch_bytes, need);
+        if (fused)
+        {
+            uint16_t* q_tmp = reinterpret_cast<uint16_t*>(p.scratch + part_floats);
+            for (int b = 0; b < B; ++b)
+            {
+                uint16_t* kc = Kc + (size_t)b * NKV * capacity * HS;
+                uint16_t* vc = Vc + (size_t)b * NKV * capacity * HS;
+                const size_t ro = (size_t)b * p.raw_b_stride;
+                const int rc = pos_dev ? mila_cdna4_fused_qkv_post_devpos(q_tmp + (size_t)b * NH * HS, kc, vc, p.q_raw + ro, p.k_raw + ro, p.v_raw + ro, p.qw, p.kw, p.vw, p.cos_cache,
+                                                                          p.sin_cache, NH, NKV, HS, pos_dev, capacity, p.eps, reinterpret_cast<mila_stream_t>(stream))
+                                       : mila_cdna4_fused_qkv_post(q_tmp + (size_t)b * NH * HS, kc, vc, p.q_raw + ro, p.k_raw + ro, p.v_raw + ro, p.qw, p.kw, p.vw, p.cos_cache,
+                                                                   p.sin_cache, NH, NKV, HS, position, capacity, p.eps, reinterpret_cast<mila_stream_t>(stream));
+                if (rc) return rc;
+            }
+            p.Q = q_tmp;
+            p.q_b_stride = 0;
+        }
+        return launch_decode_mfma(p, B, stream);
+    }
     const bool split_kernel = HS == 64 || HS == 128 || HS == 256 || HS == 512;
     if (split_kernel && p.splits > 1)
     {
@@ -687,6 +922,8 @@ extern "C" {
 int mila_cdna4_tune_attn_split(int positions_per_split)
 {
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
+    if (positions_per_split == -1) { g_tune_decode_mfma = 0; return MILA_OK; }      // -1 / -2: the long-context MFMA decode off / on (default on)
+    if (positions_per_split == -2) { g_tune_decode_mfma = 1; return MILA_OK; }
     g_tune_positions_per_split = (positions_per_split >= 8) ? positions_per_split : 64;
     return MILA_OK;
 }
@@ -710,7 +947,10 @@ int mila_cdna4_kv_write_bf16(uint16_t* Kc, uint16_t* Vc, const uint16_t* k, cons
 size_t mila_cdna4_attn_decode_scratch_bytes(int B, int NH, int HS)
 {
     if (B <= 0 || NH <= 0 || HS <= 0) return 0;
-    return (size_t)B * NH * kMaxSplits * (HS + 4) * sizeof(float);
+    const size_t scalar = (size_t)B * NH * kMaxSplits * (HS + 4) * sizeof(float);
+    // the long-context MFMA decode (HS 512): up to kMaxSplitsMfma partials per head + the roped q rows of its fused form
+    const size_t mfma = (HS == 512) ? (size_t)B * NH * kMaxSplitsMfma * (HS + 4) * sizeof(float) + (size_t)B * NH * HS * 2 : 0;
+    return scalar > mfma ? scalar : mfma;
 }
 
 int mila_cdna4_attn_decode_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t* Kc, const uint16_t* Vc, void* scratch,

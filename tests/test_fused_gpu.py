@@ -537,3 +537,58 @@ def test_lm_head_epilogue_runs_the_samplers_first_stage(fmt, N, with_res):
     assert np.array_equal(host(logits2).view(np.uint32), lg.view(np.uint32))
     with pytest.raises(capi.InvalidArgument):
         capi.call("sample_argmax_final_advance", tok, scratch, C.c_size_t(nb), 0, pos, seq, ring, 4)
+
+
+@pytest.mark.parametrize("B,pos", [(1, 0), (1, 37), (1, 5000), (1, 8191), (2, 4500)])
+def test_long_band_global_layer_takes_the_matrix_core_decode_and_the_fused_form_is_its_chain(B, pos):
+    """round 3: 16 query heads on one KV head over a band of >= 4096 keys (Gemma's global layers in a long context) decode on the matrix cores (attn_decode_mfma_kernel):
+    the choice depends on (window, capacity) only, so attn_decode_bf16, the fused entry, its device-position form and the batch form all take it -- the fused forms ARE
+    the chain fused_qkv_post + attn_decode_bf16 there, bit for bit -- and the result is within 1 bf16 ulp of the double-precision oracle like the flash prefill's.
+    With the hook off (the wave-per-position kernel) the same call stays within the same bar: two kernels, one function."""
+    lib = capi.load()
+    NH, NKV, HS, cap, window, base, rot = 16, 1, 512, 8192, 0, 1e6, 128
+    rng = np.random.default_rng(pos + B)
+    hist_k = _bf(rng.uniform(-1, 1, (B, NKV, cap, HS)) * 0.5)
+    hist_v = _bf(rng.uniform(-1, 1, (B, NKV, cap, HS)))
+    Kc0, Vc0 = _d(hist_k), _d(hist_v)
+    packed = NH * HS + NKV * HS
+    rows = _bf(rng.standard_normal((B, packed)))
+    rows_d = _d(rows)
+    qw, kw = _d(_bf(1 + 0.1 * rng.uniform(-1, 1, HS))), _d(_bf(1 + 0.1 * rng.uniform(-1, 1, HS)))
+    cos, sin = empty_f32(cap, HS // 2), empty_f32(cap, HS // 2)
+    capi.call("rope_build_cache", cos, sin, cap, HS, float(base), rot)
+    nbytes = lib.mila_cdna4_attn_decode_scratch_bytes(B, NH, HS)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    # chain
+    K0, V0, q0, y0 = Kc0.clone(), Vc0.clone(), empty_u16(B, NH * HS), empty_u16(B, NH * HS)
+    for b in range(B):
+        capi.call("fused_qkv_post", q0[b], K0[b], V0[b], rows_d[b], rows_d[b, NH * HS:], rows_d[b, NH * HS:], qw, kw, None, cos, sin, NH, NKV, HS, pos, cap, 1e-6)
+    capi.call("attn_decode_bf16", y0, q0, K0, V0, scratch, C.c_size_t(nbytes), B, NH, NKV, HS, cap, pos + 1, window, 1.0)
+    # fused forms
+    K1, V1, y1 = Kc0.clone(), Vc0.clone(), empty_u16(B, NH * HS)
+    if B == 1:
+        capi.call("fused_attn_decode_bf16", y1, K1, V1, rows_d[0], rows_d[0, NH * HS:], rows_d[0, NH * HS:], qw, kw, None, cos, sin, scratch, C.c_size_t(nbytes), NH, NKV, HS,
+                  cap, pos, None, window, 1.0, 1e-6)
+    else:
+        capi.call("fused_attn_decode_batch_bf16", y1, K1, V1, rows_d[0], rows_d[0, NH * HS:], rows_d[0, NH * HS:], C.c_int64(packed), qw, kw, None, cos, sin, scratch,
+                  C.c_size_t(nbytes), B, NH, NKV, HS, cap, pos, None, window, 1.0, 1e-6)
+    assert np.array_equal(bits(K1), bits(K0)) and np.array_equal(bits(V1), bits(V0)) and np.array_equal(bits(y1), bits(y0))
+    if B == 1:
+        K2, V2, y2 = Kc0.clone(), Vc0.clone(), empty_u16(B, NH * HS)
+        pd = torch.tensor([pos], dtype=torch.int32, device="cuda")
+        capi.call("fused_attn_decode_bf16", y2, K2, V2, rows_d[0], rows_d[0, NH * HS:], rows_d[0, NH * HS:], qw, kw, None, cos, sin, scratch, C.c_size_t(nbytes), NH, NKV, HS,
+                  cap, 0, pd, window, 1.0, 1e-6)
+        assert np.array_equal(bits(y2), bits(y0)) and np.array_equal(bits(K2), bits(K0))
+    # oracle: the roped q rows against the linear history 0 .. pos (the appended row included)
+    Kh = orc.from_bf16_bits(bits(K0)).reshape(B, NKV, cap, HS)[:, :, :pos + 1].transpose(0, 2, 1, 3)
+    Vh = orc.from_bf16_bits(bits(V0)).reshape(B, NKV, cap, HS)[:, :, :pos + 1].transpose(0, 2, 1, 3)
+    qn = orc.from_bf16_bits(bits(q0)).reshape(B, 1, NH, HS)
+    exp = orc.gqa_attention(qn, np.ascontiguousarray(Kh), np.ascontiguousarray(Vh), pos, window, 1.0)[:, 0]
+    assert_bf16_close(bits(y0), exp, 1, 2e-3, "matrix-core decode vs oracle")
+    capi.check(lib.mila_cdna4_tune_attn_split(-1))            # the wave-per-position kernel on the same inputs
+    try:
+        y3 = empty_u16(B, NH * HS)
+        capi.call("attn_decode_bf16", y3, q0, K0, V0, scratch, C.c_size_t(nbytes), B, NH, NKV, HS, cap, pos + 1, window, 1.0)
+    finally:
+        capi.check(lib.mila_cdna4_tune_attn_split(-2))
+    assert_bf16_close(bits(y3), exp, 1, 2e-3, "wave-per-position decode vs oracle")
