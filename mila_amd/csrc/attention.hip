@@ -565,24 +565,34 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnParams 
 
     if (begin < end)      // workgroup-uniform
     {
-        // Q fragments (B operand of S^T = K Q^T): lane holds Q[head l15][32 s + 8 g + j]
-        s16x8 qf[KSTEPS];
+        // Q: the 16 heads' rows as a 16-row image in LDS (the layout of a K tile's first 16 rows); the fragments of a k-step are read per tile -- held in registers they
+        // cost 64 VGPRs, which buy the second staging set (two tiles of K / V in flight per workgroup instead of one: the kernel is a latency chain of 4-8 tiles)
+        unsigned char* ldsQ = smem_mfma + 4 * TILE_BYTES;
         {
-            const uint16_t* qp = p.Q + (size_t)b * (p.q_b_stride ? (size_t)p.q_b_stride : (size_t)p.NH * HS) + (size_t)(h0 + l15) * HS + 8 * g;
+            const uint16_t* qb = p.Q + (size_t)b * (p.q_b_stride ? (size_t)p.q_b_stride : (size_t)p.NH * HS) + (size_t)h0 * HS;
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) qf[s] = __builtin_bit_cast(s16x8, ld16(qp + 32 * s));
+            for (int i = 0; i < (16 * (ROWB / 16)) / 256; ++i)
+            {
+                const int c = tid + 256 * i;
+                const int row = c / (ROWB / 16), ch = c % (ROWB / 16);
+                *reinterpret_cast<u32x4*>(ldsQ + k_off<HS>(row, ch)) = ld16(qb + (size_t)row * HS + ch * 8);
+            }
         }
         const uint16_t* kbase = p.K + ((size_t)b * p.NKV + kvh) * p.capacity * HS;
         const uint16_t* vbase = p.V + ((size_t)b * p.NKV + kvh) * p.capacity * HS;
+        const bool wraps = end > p.capacity;                          // uniform: an unbounded cache (the global layers) needs no modulo per row
         struct StageRegs { u32x4 k[CH], v[CH]; };
+        const int ntiles = (end - begin + kKeysPerTile - 1) / kKeysPerTile;
+        const int kt_last = begin + (ntiles - 1) * kKeysPerTile;
         auto stage_load = [&](StageRegs& r, int kt) {
+            kt = min(kt, kt_last);                                    // a load past the last tile re-reads it (never stored): branch-free, the waits stay counted
 #pragma unroll
             for (int i = 0; i < CH; ++i)
             {
                 const int c = tid + 256 * i;
                 const int row = c / (ROWB / 16), ch = c % (ROWB / 16);
                 const int key = min(kt + row, end - 1);                 // rows past the split re-read its last key (masked below; a real, finite V row)
-                const size_t off = (size_t)(key % p.capacity) * HS + ch * 8;
+                const size_t off = (size_t)(wraps ? key % p.capacity : key) * HS + ch * 8;
                 r.k[i] = ld16(kbase + off);
                 r.v[i] = ld16(vbase + off);
             }
@@ -597,28 +607,28 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnParams 
                 *reinterpret_cast<u32x4*>(ldsV + v_off<HS>(row, ch)) = r.v[i];
             }
         };
-        const int ntiles = (end - begin + kKeysPerTile - 1) / kKeysPerTile;
-        StageRegs regs;
-        stage_load(regs, begin);
-        for (int t = 0; t < ntiles; ++t)
-        {
+        StageRegs ra, rb;
+        stage_load(ra, begin);
+        stage_load(rb, begin + kKeysPerTile);
+        auto tile = [&](int t, StageRegs& regs) {
             const int kt = begin + t * kKeysPerTile;
             // two [K | V] buffers: tile t is stored while slower waves may still read tile t - 1 from the other one (the store follows the barrier of tile t - 1,
-            // which every wave reaches only after its reads of tile t - 2): one barrier per tile
+            // which every wave reaches only after its reads of tile t - 2): one barrier per tile, which also publishes the Q image before its first read
             unsigned char* ldsK = smem_mfma + (t & 1) * 2 * TILE_BYTES;
             unsigned char* ldsV = ldsK + TILE_BYTES;
             stage_store(regs, ldsK, ldsV);
             __syncthreads();
-            if (t + 1 < ntiles) stage_load(regs, kt + kKeysPerTile);
+            stage_load(regs, kt + 2 * kKeysPerTile);                  // two tiles ahead, in flight during this tile's and the next one's products
 
             f32x4 s0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0;
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s)
             {
+                const s16x8 qf = *reinterpret_cast<const s16x8*>(ldsQ + k_off<HS>(l15, 4 * s + g));
                 const s16x8 ka = *reinterpret_cast<const s16x8*>(ldsK + k_off<HS>(l15, 4 * s + g));
                 const s16x8 kb = *reinterpret_cast<const s16x8*>(ldsK + k_off<HS>(16 + l15, 4 * s + g));
-                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka), __builtin_bit_cast(bf16x8, qf[s]), s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb), __builtin_bit_cast(bf16x8, qf[s]), s1, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka), __builtin_bit_cast(bf16x8, qf), s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb), __builtin_bit_cast(bf16x8, qf), s1, 0, 0, 0);
             }
             // lane holds keys kt + 4 g + r (s0) and kt + 16 + 4 g + r (s1) of head row l15
             float sv[8], mt = -INFINITY;
@@ -667,6 +677,11 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnParams 
                 if (rescale) { o[dd][0] *= alpha; o[dd][1] *= alpha; o[dd][2] *= alpha; o[dd][3] *= alpha; }
                 o[dd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), pfrag, o[dd], 0, 0, 0);
             }
+        };
+        for (int t = 0; t < ntiles; t += 2)
+        {
+            tile(t, ra);
+            if (t + 1 < ntiles) tile(t + 1, rb);
         }
     }
     // O^T[dim 16 d + 4 g + r][head l15] -> this head's partial row; (M, L) once per head (an empty split leaves O = 0, M = -inf, L = 0: the merge ignores it)
@@ -675,25 +690,60 @@ __global__ __launch_bounds__(256) void attn_decode_mfma_kernel(const AttnParams 
     if (wave == 0 && g == 0) { part[HS] = m_run; part[HS + 1] = l_run; }
 }
 
-// merge of up to kMaxSplitsMfma partials per head: grid (NH, B, HS / 64), 64 threads -> 64 dims.  Two passes over the (M, L) pairs (broadcast loads), one over the
-// thread's own column; fixed order, so a replay reproduces an eager launch.
-__global__ __launch_bounds__(64) void attn_combine_many_kernel(uint16_t* __restrict__ Y, const float* __restrict__ scratch, int NH, int HS, int splits)
+// merge of up to kMaxSplitsMfma partials per head: grid (NH, B, HS / 64), 4 waves; wave w merges splits 64 w .. 64 w + 63 as attn_combine_kernel does (lane s holds
+// split s's (M, L); every load of a batch of 16 splits requested before anything is reduced), the four (acc, M, L) triples meet in LDS.  Fixed order: a replay
+// reproduces an eager launch.  (A first form -- 64 threads walking all 256 splits with broadcast loads -- took 51 us for 8.4 MB of partials.)
+__global__ __launch_bounds__(256) void attn_combine_many_kernel(uint16_t* __restrict__ Y, const float* __restrict__ scratch, int NH, int HS, int splits)
 {
-    const int h = blockIdx.x, b = blockIdx.y, d = blockIdx.z * 64 + threadIdx.x;
+    __shared__ float s_acc[4][64], s_m[4], s_l[4];
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = blockIdx.z * 64 + lane;
     const int STR = HS + 4;
-    const float* base = scratch + ((size_t)b * NH + h) * splits * STR;
-    float M = -INFINITY;
-    for (int s = 0; s < splits; ++s) M = fmaxf(M, base[(size_t)s * STR + HS]);
-    float L = 0.0f, acc = 0.0f;
-#pragma unroll 8
-    for (int s = 0; s < splits; ++s)
+    const int s0 = wave * 64, n = min(64, splits - s0);          // this wave's splits (n <= 0: none)
+    const float* base = scratch + (((size_t)b * NH + h) * splits + s0) * STR;
+    float acc = 0.0f, M = -INFINITY, L = 0.0f;
+    if (n > 0)
     {
-        const float ms = base[(size_t)s * STR + HS];
-        const float f = (ms == -INFINITY) ? 0.0f : __expf(ms - M);
-        L = fmaf(base[(size_t)s * STR + HS + 1], f, L);
-        acc = fmaf(base[(size_t)s * STR + d], f, acc);
+        float vals[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) vals[u] = (u < n) ? base[(size_t)u * STR + d] : 0.0f;
+        const float ms = (lane < n) ? base[(size_t)lane * STR + HS] : -INFINITY;
+        const float ls = (lane < n) ? base[(size_t)lane * STR + HS + 1] : 0.0f;
+        M = wave_max(ms);
+        const float fs = (ms == -INFINITY) ? 0.0f : __expf(ms - M);
+        L = wave_sum(ls * fs);
+        const int n16 = (n + 15) & ~15;
+        for (int i0 = 0; i0 < n16; i0 += 16)
+        {
+            if (i0 > 0)
+            {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) vals[u] = (i0 + u < n) ? base[(size_t)(i0 + u) * STR + d] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+            {
+                const float f = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fs), min(i0 + u, 63)));
+                acc = fmaf(vals[u], f, acc);
+            }
+        }
     }
-    Y[((size_t)b * NH + h) * HS + d] = f32_to_bf16_bits(L > 0.0f ? acc / L : 0.0f);
+    s_acc[wave][lane] = acc;
+    if (lane == 0) { s_m[wave] = M; s_l[wave] = L; }
+    __syncthreads();
+    if (wave == 0)
+    {
+        float Mt = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        float Lt = 0.0f, out = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+        {
+            const float f = (s_m[w] == -INFINITY) ? 0.0f : __expf(s_m[w] - Mt);
+            Lt = fmaf(s_l[w], f, Lt);
+            out = fmaf(s_acc[w][lane], f, out);
+        }
+        Y[((size_t)b * NH + h) * HS + d] = f32_to_bf16_bits(Lt > 0.0f ? out / Lt : 0.0f);
+    }
 }
 
 static int g_tune_decode_mfma = 1;      // tuning hook (mila_cdna4_tune_attn_split, negative values): 0 = never take the MFMA decode
@@ -715,7 +765,7 @@ static int launch_decode_mfma(const AttnParams& p, int B, hipStream_t s)
 {
     constexpr int HS = 512;
     static bool attr_set = false;
-    const size_t lds = 4 * (size_t)kKeysPerTile * HS * 2;      // two [K | V] tile pairs
+    const size_t lds = 4 * (size_t)kKeysPerTile * HS * 2 + 16 * (size_t)HS * 2;      // two [K | V] tile pairs + the 16 heads' Q rows
     if (!attr_set)
     {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_mfma_kernel<HS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(attn_decode_mfma)");
@@ -726,7 +776,7 @@ static int launch_decode_mfma(const AttnParams& p, int B, hipStream_t s)
     hipLaunchKernelGGL((attn_decode_mfma_kernel<HS>), dim3(p.splits, p.NKV * n16, B), dim3(256), lds, s, p);
     int rc = check_hip(hipGetLastError(), "attn_decode_mfma");
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_combine_many_kernel, dim3(p.NH, B, HS / 64), dim3(64), 0, s, p.Y, p.scratch, p.NH, HS, p.splits);
+    hipLaunchKernelGGL(attn_combine_many_kernel, dim3(p.NH, B, HS / 64), dim3(256), 0, s, p.Y, p.scratch, p.NH, HS, p.splits);
     return check_hip(hipGetLastError(), "attn_combine_many");
 }
 
