@@ -146,7 +146,10 @@ namespace Mila::Dnn
         void initSynthetic( uint64_t seed, const SyntheticProfile& pr = SyntheticProfile{} )
         {
             destroyGraph();   // layer scalars are baked into the captured launches
-            const size_t max_elems = static_cast<size_t>( std::max( { cfg_.vocab_size * cfg_.embedding_dim, cfg_.embedding_dim * 2 * cfg_.hidden_dim } ) );
+            // the staging buffer holds the largest matrix of the model: the table, fc_gate_up, or -- on geometries whose attention is wider than the stream -- a packed qkv
+            const dim_t attn_w = cfg_.num_heads * std::max( cfg_.head_dim, cfg_.global_head_dim );
+            const dim_t qkv_w = attn_w + 2 * std::max( cfg_.num_kv_heads * cfg_.head_dim, cfg_.num_global_kv_heads * cfg_.global_head_dim );
+            const size_t max_elems = static_cast<size_t>( std::max( { cfg_.vocab_size * cfg_.embedding_dim, cfg_.embedding_dim * 2 * cfg_.hidden_dim, cfg_.embedding_dim * qkv_w } ) );
             TensorType staging( ctx_->getDeviceId(), shape_t{ static_cast<dim_t>( max_elems ) } );
             auto fillLinear = [&]( auto& lin, uint64_t s, float gain )
             {

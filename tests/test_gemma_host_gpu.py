@@ -510,3 +510,28 @@ def test_prefill_from_after_rewind_matches_full_prefill__Gemma_Cuda_cpp_338(poli
                 m.prefill_from(toks, bad)
     finally:
         m.close()
+
+
+def test_a_long_capacity_model_takes_the_matrix_core_decode_on_every_path():
+    """a model whose global layers put 16 heads of size 512 on one KV head, built for a context of 4200: the global layers decode on the matrix cores
+    (attn_decode_mfma_kernel; chosen by (window, capacity), csrc/attention.hip) -- in the reference-order path, the fused schedule and the graph replay alike:
+    bit-identical logits across the three, oracle distance as on the other small models; a prefill in front, so that the decode reads a prefilled cache"""
+    cfg = dict(vocab_size=1024, embedding_dim=256, num_layers=4, num_heads=16, num_kv_heads=8, head_dim=64, hidden_dim=512,
+               global_head_dim=512, num_global_kv_heads=1, window=8, sliding_window_pattern=2, global_rotary_dim=128)
+    max_seq = 4200
+    ref = RefGemma(cfg, "bf16", seed=11, staged_prefill=True)
+    ref.forward(TOKENS[:9], 0, max_seq)
+    models = {m: host.Gemma("bf16", cfg, max_seq=max_seq, max_prefill=16, seed=11) for m in ("reference", "fused", "graph")}
+    for g in models.values():
+        g.prefill(TOKENS[:9])
+    worst = 0.0
+    for i, tok in enumerate(TOKENS[9:]):
+        pos = 9 + i
+        out = {m: g.decode(tok, pos, m) for m, g in models.items()}
+        for m in ("fused", "graph"):
+            assert np.array_equal(out["reference"].view(np.uint32), out[m].view(np.uint32)), "%s != reference-order at %d" % (m, pos)
+        exp = ref.forward([tok], pos, max_seq)
+        worst = max(worst, float(np.abs(out["graph"] - exp).max() / np.abs(exp).max()))
+    assert worst < 1e-1, worst
+    for g in models.values():
+        g.close()
