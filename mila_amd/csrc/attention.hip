@@ -30,6 +30,7 @@ namespace mila {
 constexpr int kMaxSplits = 64;
 constexpr int kMaxSplitsMfma = 256;      // the long-context MFMA decode (attn_decode_mfma_kernel): one workgroup per CU
 constexpr int kMfmaMinBand = 4096;        // live band (keys) from which a 16-head group on one KV head takes the MFMA decode
+static int g_mfma_min_band = kMfmaMinBand;      // tuning hook (mila_cdna4_tune_attn_split(-3 - n)): n * 256 keys
 
 // ---- KV append ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void kv_write_bf16_kernel(uint16_t* __restrict__ Kc, uint16_t* __restrict__ Vc,
@@ -750,7 +751,7 @@ static int g_tune_decode_mfma = 1;      // tuning hook (mila_cdna4_tune_attn_spl
 
 static bool mfma_decode_applies(int NH, int NKV, int HS, int band_max)
 {
-    return g_tune_decode_mfma && HS == 512 && NKV > 0 && (NH / NKV) % 16 == 0 && band_max >= kMfmaMinBand;
+    return g_tune_decode_mfma && HS == 512 && NKV > 0 && (NH / NKV) % 16 == 0 && band_max >= g_mfma_min_band;
 }
 static int mfma_decode_splits(int B, int NH, int NKV, int band_max)
 {
@@ -973,7 +974,8 @@ int mila_cdna4_tune_attn_split(int positions_per_split)
 {
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
     if (positions_per_split == -1) { g_tune_decode_mfma = 0; return MILA_OK; }      // -1 / -2: the long-context MFMA decode off / on (default on)
-    if (positions_per_split == -2) { g_tune_decode_mfma = 1; return MILA_OK; }
+    if (positions_per_split == -2) { g_tune_decode_mfma = 1; g_mfma_min_band = kMfmaMinBand; return MILA_OK; }
+    if (positions_per_split <= -3) { g_mfma_min_band = (-3 - positions_per_split) * 256; return MILA_OK; }      // experiment: the MFMA decode from a shorter band on
     g_tune_positions_per_split = (positions_per_split >= 8) ? positions_per_split : 64;
     return MILA_OK;
 }

@@ -22,7 +22,9 @@ MILA_API int mila_cdna4_tune_gemm_schedule(int pingpong);
  * weight-streaming pieces up to 255 rows, masked 128-row LDS tiles beyond); 1 = EVERY row on the masked 128-row tiles (bit-identical to the LDS-DMA kernels:
  * the test of that statement); 2 = every row as skinny pieces (same products, K-tiles summed in eight interleaved chains: fp32-rounding-level differences). */
 MILA_API int mila_cdna4_tune_gemm_fp8_tail_only(int on);
-/* positions of the live band one flash-decode split covers (default 64; 0 restores it): fewer, longer splits = smaller partial sets */
+/* positions of the live band one flash-decode split covers (default 64; 0 restores it): fewer, longer splits = smaller partial sets.
+ * Negative values steer the long-context matrix-core decode (attn_decode_mfma_kernel): -1 = never take it, -2 = default rule (bands of >= 4096 keys),
+ * -3 - n = take it from bands of n * 256 keys on (experiments) */
 MILA_API int mila_cdna4_tune_attn_split(int positions_per_split);
 /* flash-prefill form: 8 (default) = LDS-DMA kernels (HS 512: 8-wave workgroups, four heads x two d-halves; HS 256: double-buffered 4-wave workgroups);
  * 9 = 8 with 8-wave workgroups at HS 256 too; 2 = HS 512 as 4-wave d-split workgroups; 1 = the register-staged kernels.  All give the same bits. */
