@@ -228,7 +228,7 @@ struct Fp8SkinnyParams
 template <int MG, bool GEGLU, int NR>       // NR: 16-row groups of W per workgroup (2 where N gives the chip enough workgroups anyway: half the prologues / reductions per byte)
 __global__ __launch_bounds__(512) void gemm_fp8_skinny_kernel(const Fp8SkinnyParams p)
 {
-    constexpr int PF = 3;                                   // W fragments requested this many steps ahead
+    constexpr int PF = 3;                                   // W fragments requested this many steps ahead (6 / 8 measured SLOWER: fewer resident workgroups per CU and more pipeline moves -- gate_up tail 29.7 -> 38.9 us, T = 2049 prefill 31.1 -> 31.5 ms)
     constexpr int NG = GEGLU ? 2 : 1;                       // gate / up
     constexpr int NA = NG * NR;                             // A fragments per wave and K-tile
     constexpr int kRows = MG * 16;
