@@ -284,6 +284,7 @@ extern int g_gemm_persistent;
 extern int g_gemm_rowwise;
 extern int g_gemm_fp8_tail_only;
 extern int g_gemm_fp8_tail_form;      // gemm_fp8_tail.hip
+extern int g_skinny_whole_x;
 
 // which direct-to-LDS kernel serves a bf16-weight GEMM of this shape: 2 = 256 x 256, 1 = 256 x 128, 0 = none (128 x 128 register-staged)
 static int glds_kernel_for(int M, int K, int N)
@@ -426,6 +427,8 @@ int mila_cdna4_tune_gemm_schedule(int pingpong)
 int mila_cdna4_tune_gemm_fp8_tail_only(int on)
 {
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
+    if (on == 3) { g_skinny_whole_x = 0; return MILA_OK; }      // 3: the skinny kernel's barrier-free <= 4-row form off (4 turns it back on); the other settings stay
+    if (on == 4) { g_skinny_whole_x = 1; return MILA_OK; }
     g_gemm_fp8_tail_only = on != 0;      // 1: every row on the masked 128-row LDS tiles (bit-identical to the LDS-DMA kernels); 2: every row as skinny pieces
     g_gemm_fp8_tail_form = (on == 1 || on == 2) ? on : 0;
     return MILA_OK;

@@ -225,9 +225,13 @@ struct Fp8SkinnyParams
     int M, K, N;              // M <= 16 MG
 };
 
-template <int MG, bool GEGLU, int NR>       // NR: 16-row groups of W per workgroup (2 where N gives the chip enough workgroups anyway: half the prologues / reductions per byte)
+// XALL (MG == 1, at most 4 rows whose e4m3 image fits the 32 KB of LDS: the 1-row tail of a prefill chunk): ALL of X sits in LDS before the first product, so the K loop
+// has no barrier and no X staging -- eight waves stream their K-tiles of W independently (a decode matvec with an MFMA in it); with the per-step X exchange and its
+// barrier fc_down's tail streamed at 2.5 TB/s.  Same products, same per-wave K order, same wave-order reduction: the bits of the staged form.
+template <int MG, bool GEGLU, int NR, bool XALL = false>       // NR: 16-row groups of W per workgroup (2 where N gives the chip enough workgroups anyway: half the prologues / reductions per byte)
 __global__ __launch_bounds__(512) void gemm_fp8_skinny_kernel(const Fp8SkinnyParams p)
 {
+    static_assert(!XALL || MG == 1, "the whole-X form is the <= 4-row case");
     constexpr int PF = 3;                                   // W fragments requested this many steps ahead (6 / 8 measured SLOWER: fewer resident workgroups per CU and more pipeline moves -- gate_up tail 29.7 -> 38.9 us, T = 2049 prefill 31.1 -> 31.5 ms)
     constexpr int NG = GEGLU ? 2 : 1;                       // gate / up
     constexpr int NA = NG * NR;                             // A fragments per wave and K-tile
@@ -290,6 +294,46 @@ __global__ __launch_bounds__(512) void gemm_fp8_skinny_kernel(const Fp8SkinnyPar
     u32x4 wq[PF][NA][2];
 #pragma unroll
     for (int j = 0; j < PF; ++j) load_w(wq[j], j);          // steps past the end load zeros (masked by k < K)
+    if constexpr (XALL)
+    {
+        // image [K-tile][row < M][128 B], the chunk swizzle of the staged form
+        const int M = p.M, nch = M * nk * 8;
+        for (int c = tid; c < nch; c += 512)
+        {
+            const int ch = c & 7, kt = (c >> 3) % nk, row = (c >> 3) / nk;
+            const int k = kt * 128 + ch * 16;
+            const u32x4 v = (k < K) ? ld16(p.X + (size_t)row * K + k) : u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(smem + (kt * M + row) * 128 + (((((ch & 1) << 2) | (ch >> 1)) ^ ((row >> 1) & 7)) << 4)) = v;
+        }
+        __syncthreads();
+        for (int s = 0; s < steps; ++s)
+        {
+            const int kt = 8 * s + wave;
+            struct Pair { u32x4 lo, hi; };
+            i32x8t fa[NA];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) fa[a] = __builtin_bit_cast(i32x8t, (Pair{wq[0][a][0], wq[0][a][1]}));
+            u32x4 xlo{0u, 0u, 0u, 0u}, xhi{0u, 0u, 0u, 0u};
+            if (l15 < M && kt < nk)
+            {
+                const int sw = (l15 >> 1) & 7;
+                const unsigned char* rowp = smem + (kt * M + l15) * 128;
+                xlo = *reinterpret_cast<const u32x4*>(rowp + ((g ^ sw) << 4));
+                xhi = *reinterpret_cast<const u32x4*>(rowp + (((4 + g) ^ sw) << 4));
+            }
+            const i32x8t fb = __builtin_bit_cast(i32x8t, (Pair{xlo, xhi}));
+#pragma unroll
+            for (int a = 0; a < NA; ++a) acc[a][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[a], fb, acc[a][0], 0, 0, 0, 127, 0, 127);
+#pragma unroll
+            for (int j = 0; j + 1 < PF; ++j)
+#pragma unroll
+                for (int a = 0; a < NA; ++a) { wq[j][a][0] = wq[j + 1][a][0]; wq[j][a][1] = wq[j + 1][a][1]; }
+            load_w(wq[PF - 1], s + PF);
+        }
+        __syncthreads();                                    // every wave is done with the image before the reduction reuses the buffer
+    }
+    else
+    {
     load_x(0);
     store_x(smem);
     __syncthreads();
@@ -319,6 +363,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_skinny_kernel(const Fp8SkinnyPar
         load_w(wq[PF - 1], s + PF);
         if (more) store_x(smem + ((s + 1) & 1) * kStepBytes);
         __syncthreads();
+    }
     }
 
     // ---- the eight K-interleaved partial sums meet in LDS, in wave order ----
@@ -374,11 +419,24 @@ __global__ __launch_bounds__(512) void gemm_fp8_skinny_kernel(const Fp8SkinnyPar
     }
 }
 
+int g_skinny_whole_x = 1;      // tuning (mila_cdna4_tune_gemm_fp8_tail_only(3) clears it, any other value sets it): the barrier-free <= 4-row form of the skinny kernel
+
 template <int MG, bool GEGLU>
 static void launch_skinny_mg(const Fp8SkinnyParams& p, hipStream_t s)
 {
     // two W row groups per workgroup where that still leaves >= 2 workgroups per CU
     constexpr bool kTwoFits = !(GEGLU && MG == 4);       // 4 A fragments x 4 row groups of accumulators + the W pipeline do not fit 256 registers
+    if constexpr (MG == 1)
+    {
+        // <= 4 rows whose whole e4m3 image fits the kernel's 32 KB of LDS: the barrier-free form
+        const int nk = (p.K + 127) / 128;
+        if (g_skinny_whole_x && p.M <= 4 && p.M * nk * 128 <= 32768)
+        {
+            if (kTwoFits && (p.N + 31) / 32 >= 2 * kNumCU) hipLaunchKernelGGL((gemm_fp8_skinny_kernel<1, GEGLU, 2, true>), dim3((p.N + 31) / 32), dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((gemm_fp8_skinny_kernel<1, GEGLU, 1, true>), dim3((p.N + 15) / 16), dim3(512), 0, s, p);
+            return;
+        }
+    }
     if (kTwoFits && (p.N + 31) / 32 >= 2 * kNumCU) hipLaunchKernelGGL((gemm_fp8_skinny_kernel<MG, GEGLU, 2>), dim3((p.N + 31) / 32), dim3(512), 0, s, p);
     else hipLaunchKernelGGL((gemm_fp8_skinny_kernel<MG, GEGLU, 1>), dim3((p.N + 15) / 16), dim3(512), 0, s, p);
 }

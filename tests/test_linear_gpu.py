@@ -771,3 +771,37 @@ def test_persistent_tile_walk_gives_the_bits_of_one_workgroup_per_tile(M, K, N, 
         exp = 0.5 * h * (1 + np.tanh(0.7978845608028654 * (h + 0.044715 * h ** 3)))
     # (the Linear output is rounded to bf16 BEFORE the bias is added: where the two nearly cancel, one ulp of the product is several of the sum -- hence the absolute floor)
     assert_bf16_close(outs[0][0][rows], exp, 2, 2.0 ** -7 * max(1.0, float(np.abs(exp).max())), "persistent gemm vs oracle")
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 3840, 8192), (1, 15360, 3840), (1, 4096, 3840), (2, 3840, 30720), (4, 4096, 3840), (3, 2000 + 48, 1000), (4, 8192, 528)])
+def test_skinny_whole_x_form_gives_the_staged_forms_bits(M, K, N):
+    """round 3: a <= 4-row tail whose e4m3 image fits 32 KB of LDS (the 1-row tail of a prefill chunk) keeps ALL of X in LDS and streams W without a barrier in the K loop;
+    same products per wave in the same K order, same wave-order reduction -> the bits of the staged skinny form (hook 3 turns the new form off), plain and GeGLU,
+    and both within 2 ulp of the restated reference"""
+    lib = capi.load()
+    rng = np.random.default_rng(M + K + N)
+    X, q4, s4, ws, w8, x8, ts = _w4a8_operands(rng, M, K if K % 128 == 0 else (K // 128 + 1) * 128, N)
+    if K % 128 != 0:      # a K that is no multiple of the 128-byte K-tile: drop the padded columns (K % 16 == 0 is what the entry needs)
+        x8, w8 = np.ascontiguousarray(x8[:, :K]), np.ascontiguousarray(w8[:, :K])
+    bb = orc.to_bf16_bits(rng.uniform(-0.1, 0.1, N).astype(np.float32))
+    X8, W8, ts_d, ws_d, bd = dev_u8(x8), dev_u8(w8), dev_f32(ts), dev_f32(np.array([ws], dtype=np.float32)), dev_u16(bb)
+    outs = []
+    for hook in (4, 3):
+        capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(hook))
+        try:
+            Y = torch.full((M, N), 0x7fc0, dtype=torch.int16, device="cuda")
+            capi.call("gemm_fp8_scaled", Y, X8, W8, ts_d, ws_d, bd, M, K, N)
+            o = [bits(Y).copy()]
+            if N % 2 == 0:
+                Yg = torch.full((M, N // 2), 0x7fc0, dtype=torch.int16, device="cuda")
+                capi.call("gemm_geglu_fp8_scaled", Yg, X8, W8, ts_d, ws_d, M, K, N // 2)
+                o.append(bits(Yg).copy())
+            outs.append(o)
+        finally:
+            capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(4))
+    for a, b, what in zip(outs[0], outs[1], ("plain", "GeGLU")):
+        assert not np.any((a & 0x7fff) > 0x7f80), what + ": unwritten (NaN) outputs"
+        assert np.array_equal(a, b), what + ": the whole-X form differs from the staged skinny form"
+    raw = orc.linear_fp8a_fp8w(x8, np.ones(M, dtype=np.float32), w8, None, ws, None)
+    exp = orc.round_bf16(raw.astype(np.float32)).astype(np.float64) * ts.astype(np.float64)[:, None] + orc.from_bf16_bits(bb).astype(np.float64)
+    assert_bf16_close(outs[0][0], exp, 2, 1e-3 * float(np.abs(exp).max()), "whole-X skinny vs restated reference")
