@@ -225,13 +225,13 @@ struct Fp8SkinnyParams
     int M, K, N;              // M <= 16 MG
 };
 
-// XALL (MG == 1, at most 4 rows whose e4m3 image fits the 32 KB of LDS: the 1-row tail of a prefill chunk): ALL of X sits in LDS before the first product, so the K loop
+// XALL (MG == 1: at most 16 rows, and their e4m3 image fits the 32 KB of LDS -- the 1-row tail of a prefill chunk, 8 rows at K = 3840): ALL of X sits in LDS before the first product, so the K loop
 // has no barrier and no X staging -- eight waves stream their K-tiles of W independently (a decode matvec with an MFMA in it); with the per-step X exchange and its
 // barrier fc_down's tail streamed at 2.5 TB/s.  Same products, same per-wave K order, same wave-order reduction: the bits of the staged form.
 template <int MG, bool GEGLU, int NR, bool XALL = false>       // NR: 16-row groups of W per workgroup (2 where N gives the chip enough workgroups anyway: half the prologues / reductions per byte)
 __global__ __launch_bounds__(512) void gemm_fp8_skinny_kernel(const Fp8SkinnyParams p)
 {
-    static_assert(!XALL || MG == 1, "the whole-X form is the <= 4-row case");
+    static_assert(!XALL || MG == 1, "the whole-X form is a one-row-group case");
     constexpr int PF = 3;                                   // W fragments requested this many steps ahead (6 / 8 measured SLOWER: fewer resident workgroups per CU and more pipeline moves -- gate_up tail 29.7 -> 38.9 us, T = 2049 prefill 31.1 -> 31.5 ms)
     constexpr int NG = GEGLU ? 2 : 1;                       // gate / up
     constexpr int NA = NG * NR;                             // A fragments per wave and K-tile
@@ -428,9 +428,9 @@ static void launch_skinny_mg(const Fp8SkinnyParams& p, hipStream_t s)
     constexpr bool kTwoFits = !(GEGLU && MG == 4);       // 4 A fragments x 4 row groups of accumulators + the W pipeline do not fit 256 registers
     if constexpr (MG == 1)
     {
-        // <= 4 rows whose whole e4m3 image fits the kernel's 32 KB of LDS: the barrier-free form
+        // rows whose whole e4m3 image fits the kernel's 32 KB of LDS: the barrier-free form
         const int nk = (p.K + 127) / 128;
-        if (g_skinny_whole_x && p.M <= 4 && p.M * nk * 128 <= 32768)
+        if (g_skinny_whole_x && p.M * nk * 128 <= 32768)      // (M <= 16 here: MG == 1)
         {
             if (kTwoFits && (p.N + 31) / 32 >= 2 * kNumCU) hipLaunchKernelGGL((gemm_fp8_skinny_kernel<1, GEGLU, 2, true>), dim3((p.N + 31) / 32), dim3(512), 0, s, p);
             else hipLaunchKernelGGL((gemm_fp8_skinny_kernel<1, GEGLU, 1, true>), dim3((p.N + 15) / 16), dim3(512), 0, s, p);

@@ -773,7 +773,7 @@ def test_persistent_tile_walk_gives_the_bits_of_one_workgroup_per_tile(M, K, N, 
     assert_bf16_close(outs[0][0][rows], exp, 2, 2.0 ** -7 * max(1.0, float(np.abs(exp).max())), "persistent gemm vs oracle")
 
 
-@pytest.mark.parametrize("M,K,N", [(1, 3840, 8192), (1, 15360, 3840), (1, 4096, 3840), (2, 3840, 30720), (4, 4096, 3840), (3, 2000 + 48, 1000), (4, 8192, 528)])
+@pytest.mark.parametrize("M,K,N", [(1, 3840, 8192), (1, 15360, 3840), (1, 4096, 3840), (2, 3840, 30720), (4, 4096, 3840), (3, 2000 + 48, 1000), (4, 8192, 528), (8, 3840, 8192), (16, 2048, 528)])
 def test_skinny_whole_x_form_gives_the_staged_forms_bits(M, K, N):
     """round 3: a <= 4-row tail whose e4m3 image fits 32 KB of LDS (the 1-row tail of a prefill chunk) keeps ALL of X in LDS and streams W without a barrier in the K loop;
     same products per wave in the same K order, same wave-order reduction -> the bits of the staged skinny form (hook 3 turns the new form off), plain and GeGLU,
