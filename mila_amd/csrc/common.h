@@ -198,6 +198,15 @@ __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4
 struct __attribute__((packed, aligned(2))) u32x4_a2 { uint32_t x, y, z, w; };
 __device__ __forceinline__ void st16_a2(void* p, u32x4 v) { *reinterpret_cast<u32x4_a2*>(p) = u32x4_a2{v[0], v[1], v[2], v[3]}; }
 
+// ---- W4A8 epilogue (CudaFp8Prefill.cu:162-211): y = float(bf16(acc * sB)) * s_m (+ bias) -------------------------------------------------------------------------
+// With a bias the second step is ONE fused multiply-add in every kernel that can serve a row (LDS-DMA tiles, masked tiles, skinny): left to the compiler's contraction
+// each code shape decided for itself, and the 256 x 128 tiles differed from the masked tiles in 2 of 2.4 M outputs (found when short prompts moved between them)
+__device__ __forceinline__ float w4a8_scale_bias(float acc, float ws, float ts, bool has_bias, float b)
+{
+    const float a = round_bf16(acc * ws);
+    return has_bias ? __builtin_fmaf(a, ts, b) : a * ts;
+}
+
 // ---- GELU (tanh) -------------------------------------------------------------------------------
 // Components/Activations/Activation/Kernels/ElementwiseActivation.h:41-50: 0.5 x (1 + tanh(u)), u = sqrt(2 / pi) (x + 0.044715 x^3), as the reference functor writes it
 __device__ __forceinline__ float gelu_tanh_precise(float x)

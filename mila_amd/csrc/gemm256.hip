@@ -345,8 +345,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     #pragma unroll
                     for (int e = 0; e < 4; ++e)
                     {
-                        v[e] = round_bf16(v[e] * ws) * ts;
-                        if (p.bias) v[e] += bf16_bits_to_f32(p.bias[n + e]);
+                        v[e] = w4a8_scale_bias(v[e], ws, ts, p.bias != nullptr, p.bias ? bf16_bits_to_f32(p.bias[n + e]) : 0.0f);
                     }
                 }
                 else if (p.bias)
@@ -896,8 +895,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     #pragma unroll
                 for (int e = 0; e < 4; ++e)
                 {
-                    v[e] = round_bf16(v[e] * ws) * ts;
-                    if (p.bias) v[e] += bv[pt][e];
+                    v[e] = w4a8_scale_bias(v[e], ws, ts, p.bias != nullptr, bv[pt][e]);
                 }
             }
             else if (p.bias)
@@ -1212,16 +1210,26 @@ int launch_gemm_fp8_geglu_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8
 int g_gemm_fp8_tail_only = 0;      // tuning hook (mila_cdna4_tune_gemm_fp8_tail_only): != 0: every row through the tail kernels (gemm_fp8_tail.hip: g_gemm_fp8_tail_form picks which)
 
 // Row counts of any kind (the fp4 policy's prefill is W4A8 for EVERY M > 1, CudaLinearOp.ixx:646-715):
+//   (short prompts, measured with tools/experiments/short_prompt_rules.py, profiles/r03_short_prompts.txt: below 512 rows the LDS-DMA kernels still win wherever their grid
+//    has >= 120 tiles -- qkv, fc_gate_up -- and lose on the N = 3840 shapes, whose 30-60 tiles leave the chip empty; fp4-policy prefill of 300 / 400 / 511 tokens
+//    14.8 / 17.4 / 18.3 -> 11.8 / 13.0 / 13.6 ms, monotonic in T again)
 //   M >= 512 and N % 128 == 0, K % 128 == 0: the LDS-DMA kernels over ceil(M / 256) tile-rows -- a ragged last tile-row stages row M - 1 for the rows past M
 //     and masks its stores (a 208-row tail costs one tile-row, 1/8 of a T = 2048 chunk; on the masked 128-row tiles it cost 40 % of the chunk) -- except that a
 //     tail of <= 64 rows goes to the skinny weight-streaming kernel instead (a 1-row tail: +11 % of the chunk instead of +12.5 %, and no MFMA work on padding);
 //   everything else: the tail kernels of gemm_fp8_tail.hip alone.
 // Rows are independent and the LDS-DMA kernels and the masked tiles run the same instruction chain per output element.
 constexpr int kSkinnyTailRows = 64;
+int g_fp8_big_rule = 3;      // tuning (mila_cdna4_tune_gemm_fp8_tail_only 5 .. 8 = rule 0 .. 3): 0 = LDS-DMA kernels from 512 rows on (round 3's first rule), 1 = from 128 rows on,
+                             // 2 = from 512 rows on or wherever ceil(M / 256) x (W rows / 128) >= 120 tiles, 3 (default) = 2 without the skinny split of a short prompt's remainder
 static int fp8_big_rows(int M, int K, int N_mult, int w_rows)      // rows the LDS-DMA kernels take (0 = none); N_mult: the column granularity the form needs (128, or 64 for 256 x 128 GeGLU)
 {
     if (!lds_dma_addressable(M, K, w_rows)) return 0;
-    if (g_gemm_fp8_tail_only || M < 512 || K % 128 != 0 || N_mult == 0) return 0;      // below two full tile-rows the masked 128-row tiles are as fast (T = 300: 15 ms vs 18 ms)
+    if (g_gemm_fp8_tail_only || K % 128 != 0 || N_mult == 0) return 0;
+    // below two full tile-rows the LDS-DMA kernels pay only where their grid still covers the chip (g_fp8_big_rule: see mila_cdna4_tune_gemm_fp8_tail_only)
+    const int tiles = ((M + 255) / 256) * (w_rows / 128);
+    const bool big = g_fp8_big_rule == 1 ? M >= 128 : (g_fp8_big_rule >= 2 ? (M >= 512 || (M > kSkinnyTailRows && tiles >= 120)) : M >= 512);
+    if (!big) return 0;
+    if (g_fp8_big_rule == 3 && M < 512) return M;        // a short prompt's <= 64-row remainder stays in the ragged tile-row: a skinny pass re-streams every weight, which only a long main part amortises
     const int tail = M % 256;
     return (tail > 0 && tail <= kSkinnyTailRows) ? M - tail : M;
 }

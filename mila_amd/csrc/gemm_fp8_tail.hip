@@ -188,8 +188,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_tail_kernel(const Fp8TailParams 
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                 {
-                    v[e] = round_bf16(acc[pt][qt][e] * ws) * ts;
-                    if (p.bias && n + e < p.N) v[e] += bf16_bits_to_f32(p.bias[n + e]);
+                    v[e] = w4a8_scale_bias(acc[pt][qt][e], ws, ts, p.bias != nullptr, (p.bias && n + e < p.N) ? bf16_bits_to_f32(p.bias[n + e]) : 0.0f);
                 }
             }
             if (vec_ok) *reinterpret_cast<u32x2*>(yrow + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -404,8 +403,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_skinny_kernel(const Fp8SkinnyPar
 #pragma unroll
             for (int e = 0; e < 4; ++e)
             {
-                v[e] = round_bf16(sum[0][e] * ws) * ts;
-                if (p.bias && n + e < p.N) v[e] += bf16_bits_to_f32(p.bias[n + e]);
+                v[e] = w4a8_scale_bias(sum[0][e], ws, ts, p.bias != nullptr, (p.bias && n + e < p.N) ? bf16_bits_to_f32(p.bias[n + e]) : 0.0f);
             }
         }
         uint16_t* y = p.Y + (size_t)row * p.N + n;

@@ -539,7 +539,7 @@ def _w4a8_operands(rng, M, K, N, G=128):
     return X, q4, s4, ws, w8, x8, ts
 
 
-@pytest.mark.parametrize("M,K,N,bias,G", [(2, 3840, 8704, False, 128), (16, 512, 256, True, 128), (33, 192, 250, True, 64), (300, 384, 3840, True, 128),
+@pytest.mark.parametrize("M,K,N,bias,G", [(2, 3840, 8704, False, 128), (16, 512, 256, True, 128), (33, 192, 250, True, 64), (300, 384, 3840, True, 128), (300, 256, 8192, True, 128), (260, 128, 15360, False, 128),
                                           (2000, 256, 8192, False, 128), (2049, 256, 8192, True, 128), (2048 + 77, 128, 3840, False, 128),
                                           (1024 + 255, 256, 30720, True, 128)])
 def test_w4a8_serves_every_row_count_like_the_reference(M, K, N, bias, G):
@@ -583,8 +583,15 @@ def test_w4a8_serves_every_row_count_like_the_reference(M, K, N, bias, G):
         assert_bf16_close(forms[form][rows], exp, 2, 1e-3 * float(np.abs(exp).max()), "fp8 GEMM, tail form %d, vs restated reference" % form)
     # who serves which rows by default (csrc/gemm256.hip: launch_gemm_fp8): with M >= 512 (and K % 128 == N % 128 == 0) the LDS-DMA kernels take every tile-row,
     # a ragged last one masked -- unless the tail is <= 64 rows, which goes to the skinny kernel; below 512 rows: skinny up to 64, masked LDS tiles beyond
+    # -- and below 512 rows wherever their grid still has >= 120 tiles (no skinny split there: the remainder stays in the ragged tile-row)
     tail = M % 256
-    big = 0 if (M < 512 or K % 128 or N % 128) else (M - tail if 0 < tail <= 64 else M)
+    tiles = ((M + 255) // 256) * (N // 128)
+    if K % 128 or N % 128 or not (M >= 512 or (M > 64 and tiles >= 120)):
+        big = 0
+    elif M < 512:
+        big = M
+    else:
+        big = M - tail if 0 < tail <= 64 else M
     assert np.array_equal(forms[1][:big], bits(Y)[:big]), "the masked LDS-tile kernel and the LDS-DMA fp8 kernels differ"
     if M - big > 64:
         assert np.array_equal(forms[1][big:], bits(Y)[big:])
