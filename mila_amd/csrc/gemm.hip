@@ -302,8 +302,10 @@ static int launch_glds(int which, uint16_t* Y, const uint16_t* X, const uint16_t
 {
     return which == 2 ? launch_gemm256(Y, X, W, bias, M, K, N, s, act) : launch_gemm256x128(Y, X, W, bias, M, K, N, s, act);
 }
-// Ragged prompt lengths: the LDS-DMA kernels take M % 256 == 0, so the first floor(M / 256) * 256 rows go to them and the
-// remaining < 256 rows to the register-staged 128-tile kernel (rows are independent; no padding, nothing read past the tensors).
+// Ragged prompt lengths (round 3): the LDS-DMA kernels take ANY M -- a ragged last tile-row stages row M - 1 for the rows past M and masks its stores (the fp8 forms'
+// mechanism) -- so a 2049- or 2000-token prompt stays on them (bf16 policy: 60.6 / 62.5 ms -> one tile-row more / the 2048 time; the register-staged 128-tile
+// kernel streamed a 1-row remainder's weights at 1 TB/s).  Where the whole M does not make an LDS-DMA grid, the leading multiple of 256 rows may still, and the
+// rest goes to the 128-tile kernel (rows are independent; no padding, nothing read past the tensors).
 // Returns the number of leading rows the LDS-DMA kernel serves (0 = none) and which kernel.
 static int glds_rows_for(int M, int K, int N, int* which)
 {

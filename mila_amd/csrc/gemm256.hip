@@ -1048,8 +1048,8 @@ static bool lds_dma_addressable(int M, int K, int w_rows) { return (int64_t)M * 
 // taken when the 256 x 256 grid does not apply and the 256 x 128 grid fills most of one round of CUs (or several)
 bool gemm256x128_applicable(int M, int K, int N)
 {
-    if (M % 256 != 0 || N % 128 != 0 || K % 64 != 0 || !lds_dma_addressable(M, K, N)) return false;
-    const int tiles = (M / 256) * (N / 128);
+    if (M <= 0 || N % 128 != 0 || K % 64 != 0 || !lds_dma_addressable(M, K, N)) return false;
+    const int tiles = ((M + 255) / 256) * (N / 128);      // a ragged last tile-row counts (and costs) whole: rows past M re-read row M - 1, their stores are masked
     const int rounds = (tiles + kNumCU - 1) / kNumCU;
     return tiles >= 160 && tiles >= 0.70 * rounds * kNumCU;      // (192 tiles -- GPT-2's 768-wide projections at B T = 8192 -- beat the 128-tile kernel's 384: 18 / 51 vs 29 / 74 us)
 }
@@ -1057,8 +1057,8 @@ bool gemm256x128_applicable(int M, int K, int N)
 // bf16 only: N of any size (ragged last column tile, any row pitch) when the grid is many rounds deep -- GPT-2's lm_head (N = 50257, 12 576 tiles at M = 8192)
 bool gemm256x128_ragged_n_applicable(int M, int K, int N)
 {
-    if (M % 256 != 0 || K % 64 != 0 || N % 128 == 0 || !lds_dma_addressable(M, K, N)) return false;
-    return (int64_t)(M / 256) * ((N + 127) / 128) >= 4 * kNumCU;
+    if (M <= 0 || K % 64 != 0 || N % 128 == 0 || !lds_dma_addressable(M, K, N)) return false;
+    return (int64_t)((M + 255) / 256) * ((N + 127) / 128) >= 4 * kNumCU;
 }
 
 extern int g_gemm_pingpong;
@@ -1107,15 +1107,15 @@ static int launch_gemm256x128_t(const Gemm256Params& p, hipStream_t s)
 }
 int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act)
 {
-    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, (N + 127) / 128, nullptr, nullptr, 0, act};
+    Gemm256Params p{Y, X, W, bias, M, K, N, (M + 255) / 256, (N + 127) / 128, nullptr, nullptr, 0, act};
     return launch_gemm256x128_t<false>(p, s);
 }
 
 // one 512-thread workgroup per CU: worth it only when the tile count fills whole rounds of 256 CUs
 bool gemm256_applicable(int M, int K, int N)
 {
-    if (M % 256 != 0 || N % 256 != 0 || K % 64 != 0 || !lds_dma_addressable(M, K, N)) return false;
-    const int tiles = (M / 256) * (N / 256);
+    if (M <= 0 || N % 256 != 0 || K % 64 != 0 || !lds_dma_addressable(M, K, N)) return false;
+    const int tiles = ((M + 255) / 256) * (N / 256);
     const int rounds = (tiles + kNumCU - 1) / kNumCU;
     return tiles >= 200 && tiles >= 0.85 * rounds * kNumCU;
 }
@@ -1125,8 +1125,8 @@ bool gemm256_applicable(int M, int K, int N)
 // store drain): the persistent walk overlaps all three with the next tile's K loop
 bool gemm256_ragged_n_applicable(int M, int K, int N)
 {
-    if (M % 256 != 0 || K % 128 != 0 || N % 256 == 0 || !lds_dma_addressable(M, K, N)) return false;
-    return (int64_t)(M / 256) * ((N + 255) / 256) >= 4 * kNumCU;
+    if (M <= 0 || K % 128 != 0 || N % 256 == 0 || !lds_dma_addressable(M, K, N)) return false;
+    return (int64_t)((M + 255) / 256) * ((N + 255) / 256) >= 4 * kNumCU;
 }
 
 int g_gemm_rowwise = 1;       // tuning (mila_cdna4_tune_gemm(2) clears it)
@@ -1173,21 +1173,21 @@ int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint
 {
     // a row pitch that is no multiple of 128 bytes: one workgroup per tile and the row-wise epilogue through LDS (two-phase schedules only)
     const int rowwise = ((N & 63) != 0 && g_gemm_pingpong >= 3 && g_gemm_rowwise) ? 1 : 0;
-    Gemm256Params p{Y, X, W, bias, M, K, N, M / 256, (N + 255) / 256, nullptr, nullptr, rowwise, act};
+    Gemm256Params p{Y, X, W, bias, M, K, N, (M + 255) / 256, (N + 255) / 256, nullptr, nullptr, rowwise, act};
     return launch_gemm256_t<G_PLAIN>(p, s);
 }
 
 // Y[M, F] = GeGLU(X W^T), W = [gate rows 0 .. F-1 | up rows F .. 2F-1]
 bool gemm256_geglu_applicable(int M, int K, int F)
 {
-    if (M % 256 != 0 || F % 128 != 0 || K % 64 != 0 || !lds_dma_addressable(M, K, 2 * F)) return false;
-    const int tiles = (M / 256) * (F / 128);
+    if (M <= 0 || F % 128 != 0 || K % 64 != 0 || !lds_dma_addressable(M, K, 2 * F)) return false;
+    const int tiles = ((M + 255) / 256) * (F / 128);
     const int rounds = (tiles + kNumCU - 1) / kNumCU;
     return tiles >= 200 && tiles >= 0.85 * rounds * kNumCU;
 }
 int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s)
 {
-    Gemm256Params p{Y, X, W, nullptr, M, K, F, M / 256, F / 128, nullptr, nullptr};
+    Gemm256Params p{Y, X, W, nullptr, M, K, F, (M + 255) / 256, F / 128, nullptr, nullptr};
     return launch_gemm256_t<G_GEGLU>(p, s);
 }
 

@@ -635,23 +635,33 @@ def test_w4a8_geglu_form_serves_every_row_count(M, K, F):
 
 @pytest.mark.parametrize("M", [2048 + 77, 1024 + 255, 768 + 1, 512 + 3])
 def test_ragged_prompt_lengths_split_between_the_lds_dma_and_the_128_tile_kernels(M):
-    """M % 256 != 0: the leading multiple of 256 rows runs the LDS-DMA kernel, the tail the 128-tile kernel; every row against
-    the float64 oracle, bf16 and (staged) fp4 weights, with bias"""
+    """M % 256 != 0 (round 3): the LDS-DMA kernels take the whole M -- a ragged last tile-row stages row M - 1 for the rows past M and masks its stores -- where their
+    grid covers the chip, else the 128-tile kernel; rows around every tile-row edge against the float64 oracle, bf16 and (staged) fp4 weights, with bias, and the
+    whole output against the 128-tile kernel within 1 bf16 ulp of the larger magnitude (another MFMA shape, same math); a guard row behind Y stays untouched"""
     K, N = 192, 8192
     rng = np.random.default_rng(M)
     Wb = _weights(rng, N, K, "random")
     X = orc.round_bf16(rng.uniform(-1, 1, (M, K)).astype(np.float32))
     bb = orc.to_bf16_bits(rng.uniform(-0.1, 0.1, N).astype(np.float32))
     Xd = dev_u16(orc.to_bf16_bits(X))
-    Y = empty_u16(M, N)
+    lib = capi.load()
+    Yg = torch.full((M + 1, N), 0x1234, dtype=torch.int16, device="cuda")          # one guard row behind the output: a masked store must not reach it
+    Y = Yg[:M]
     capi.call("gemm_bf16", Y, Xd, dev_u16(Wb), dev_u16(bb), M, K, N)
     rows = [0, 255, 256, M - M % 256 - 1, M - M % 256, M - 1]
     exp = orc.round_bf16(orc.linear_bf16w(X[rows], Wb, None)).astype(np.float64) + orc.from_bf16_bits(bb).astype(np.float64)
     assert_bf16_close(bits(Y)[rows], exp, 2, 2e-3, "ragged gemm_bf16")
-    need = capi.load().mila_cdna4_gemm_staging_bytes(M, K, N)
-    assert need == (N * K * 2 if M >= 768 else 0)                          # 512 leading rows are 128 tiles of 256 x 128: too few for an LDS-DMA grid (768: 192, enough)
-    if need == 0:
-        return
+    assert np.all(Yg[M].cpu().numpy() == 0x1234), "a store past row M - 1"
+    Y2 = empty_u16(M, N)
+    capi.check(lib.mila_cdna4_tune_gemm(1))
+    try:
+        capi.call("gemm_bf16", Y2, Xd, dev_u16(Wb), dev_u16(bb), M, K, N)
+    finally:
+        capi.check(lib.mila_cdna4_tune_gemm(0))
+    a, b = orc.from_bf16_bits(bits(Y)).astype(np.float64), orc.from_bf16_bits(bits(Y2)).astype(np.float64)
+    assert np.abs(a - b).max() <= 2.0 ** -7 * max(np.abs(b).max(), 1e-30)
+    need = lib.mila_cdna4_gemm_staging_bytes(M, K, N)
+    assert need == N * K * 2                                               # ceil(M / 256) x 64 tiles of 256 x 128: an LDS-DMA grid from 3 tile-rows on (192 tiles)
     q4, s4 = orc.quantize_fp4_per_group(Wb, 64)
     scratch = torch.empty(need, dtype=torch.uint8, device="cuda")
     capi.call("gemm_bf16_w4a16_staged", Y, Xd, dev_u8(q4), dev_f32(s4), None, M, K, N, 64, scratch, C.c_size_t(need))
