@@ -277,8 +277,13 @@ bool gemm256x128_ragged_n_applicable(int M, int K, int N);
 bool gemm256_ragged_n_applicable(int M, int K, int N);
 int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act = 0);
 bool gemm256_geglu_applicable(int M, int K, int F);
+// gemm_skinny_bf16.hip: weight streaming for <= 64 rows per launch (any M as 64-row pieces)
+int launch_gemm_bf16_skinny(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, int act, hipStream_t s);
+int launch_gemm_bf16_skinny_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s);
+constexpr int kBf16SkinnyRows = 64;      // a remainder (or a whole prompt) of up to this many rows is a weight stream: the skinny kernel
 int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s);
 static int g_gemm_force128 = 0;
+static int g_bf16_skinny = 1;      // tuning (mila_cdna4_tune_gemm(3) clears it, 4 sets it): the bf16 skinny kernel for <= 64-row prompts and remainders
 extern int g_gemm_pingpong;     // gemm256.hip
 extern int g_gemm_persistent;
 extern int g_gemm_rowwise;
@@ -395,6 +400,20 @@ static int validate_gemm(const char* who, const void* Y, const void* X, const vo
 static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act)
 {
     int which;
+    if (!g_gemm_force128 && g_bf16_skinny)
+    {
+        // few rows: a weight stream (the 128-tile kernel pushed the bf16 model's weights past a 16-row prompt at 1 TB/s)
+        if (M <= kBf16SkinnyRows) return launch_gemm_bf16_skinny(Y, X, W, bias, M, K, N, act, s);
+        // a long prompt's <= 64-row remainder: the LDS-DMA kernels on the leading tile-rows, the skinny kernel on the rest (a ragged tile-row of the N = 3840 shapes
+        // would open a second round of full-length tiles; the 128-tile kernel cost a 1-row remainder +18 ms per prefill)
+        const int tail = M % 256;
+        if (M >= 512 && tail > 0 && tail <= kBf16SkinnyRows && (which = glds_kernel_for(M - tail, K, N)) != 0)
+        {
+            int rc = launch_glds(which, Y, X, W, bias, M - tail, K, N, s, act);
+            if (rc) return rc;
+            return launch_gemm_bf16_skinny(Y + (size_t)(M - tail) * N, X + (size_t)(M - tail) * K, W, bias, tail, K, N, act, s);
+        }
+    }
     const int main_rows = glds_rows_for(M, K, N, &which);
     if (main_rows > 0)
     {
@@ -403,6 +422,29 @@ static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, c
     }
     GemmParams p{Y + (size_t)main_rows * N, X + (size_t)main_rows * K, reinterpret_cast<const uint8_t*>(W), nullptr, bias, M - main_rows, K, N, 0, 0, 0, act};
     return launch_gemm<G_BF16>(p, s);
+}
+
+// Linear + GeGLU over any row count the fused forms serve: the LDS-DMA GeGLU kernel on whole / ragged tile-rows, the skinny GeGLU kernel on <= 64 rows (a short prompt,
+// or the remainder of a long one)
+static bool geglu_rows_applicable(int M, int K, int F)
+{
+    if (gemm256_geglu_applicable(M, K, F)) return true;
+    if (!g_bf16_skinny) return false;
+    if (M <= kBf16SkinnyRows) return true;
+    const int tail = M % 256;
+    return M >= 512 && tail > 0 && tail <= kBf16SkinnyRows && gemm256_geglu_applicable(M - tail, K, F);
+}
+static int launch_geglu_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s)
+{
+    const int tail = M % 256;
+    if (g_bf16_skinny && M <= kBf16SkinnyRows) return launch_gemm_bf16_skinny_geglu(Y, X, W, M, K, F, s);
+    if (g_bf16_skinny && M >= 512 && tail > 0 && tail <= kBf16SkinnyRows && gemm256_geglu_applicable(M - tail, K, F))
+    {
+        int rc = launch_gemm256_geglu(Y, X, W, M - tail, K, F, s);
+        if (rc) return rc;
+        return launch_gemm_bf16_skinny_geglu(Y + (size_t)(M - tail) * F, X + (size_t)(M - tail) * K, W, tail, K, F, s);
+    }
+    return launch_gemm256_geglu(Y, X, W, M, K, F, s);
 }
 
 }  // namespace mila
@@ -414,6 +456,7 @@ extern "C" {
 int mila_cdna4_tune_gemm(int force_128_tile)
 {
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
+    if (force_128_tile == 3 || force_128_tile == 4) { g_bf16_skinny = force_128_tile == 4; return MILA_OK; }
     g_gemm_force128 = force_128_tile == 1;
     g_gemm_rowwise = force_128_tile != 2;      // 2: the direct (unaligned) epilogue stores on an odd output pitch instead of the row-wise one through LDS
     return MILA_OK;
@@ -528,15 +571,15 @@ int mila_cdna4_gemm_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, const uint
 /* ---- Linear + GeGLU in one kernel (prefill fc_gate_up): Y[M, F] = GeGLU(X W^T), W = [gate | up] rows ---- */
 int mila_cdna4_gemm_geglu_applicable(int M, int K, int F)
 {
-    return (M > 0 && K > 0 && F > 0 && !g_gemm_force128 && gemm256_geglu_applicable(M, K, F)) ? 1 : 0;
+    return (M > 0 && K > 0 && F > 0 && K % 8 == 0 && !g_gemm_force128 && geglu_rows_applicable(M, K, F)) ? 1 : 0;
 }
 
 int mila_cdna4_gemm_geglu_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, mila_stream_t stream)
 {
     int rc = validate_gemm("gemm_geglu_bf16", Y, X, W, M, K, F);
     if (rc) return rc;
-    MILA_REQUIRE(gemm256_geglu_applicable(M, K, F), "gemm_geglu_bf16: shape (M=%d, K=%d, F=%d) is outside the fused kernel (ask gemm_geglu_applicable)", M, K, F);
-    return launch_gemm256_geglu(Y, X, W, M, K, F, as_stream(stream));
+    MILA_REQUIRE(geglu_rows_applicable(M, K, F), "gemm_geglu_bf16: shape (M=%d, K=%d, F=%d) is outside the fused kernel (ask gemm_geglu_applicable)", M, K, F);
+    return launch_geglu_rows(Y, X, W, M, K, F, as_stream(stream));
 }
 
 int mila_cdna4_gemm_geglu_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W, const float* scales, int M, int K, int F,
@@ -544,14 +587,14 @@ int mila_cdna4_gemm_geglu_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, cons
 {
     int rc = validate_gemm("gemm_geglu_bf16_w8a16_staged", Y, X, W, M, K, F);
     if (rc) return rc;
-    MILA_REQUIRE(gemm256_geglu_applicable(M, K, F), "gemm_geglu_bf16_w8a16_staged: shape (M=%d, K=%d, F=%d) is outside the fused kernel", M, K, F);
+    MILA_REQUIRE(geglu_rows_applicable(M, K, F), "gemm_geglu_bf16_w8a16_staged: shape (M=%d, K=%d, F=%d) is outside the fused kernel", M, K, F);
     MILA_REQUIRE(scales != nullptr, "gemm_geglu_bf16_w8a16_staged: per-channel scales are required");
     const size_t need = (size_t)2 * F * K * 2;
     if (!scratch || scratch_bytes < need)
         return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_geglu_bf16_w8a16_staged: scratch %zu bytes < required %zu", scratch_bytes, need);
     rc = launch_dequant(1, reinterpret_cast<uint16_t*>(scratch), W, scales, 2 * F, K, 0, as_stream(stream));
     if (rc) return rc;
-    return launch_gemm256_geglu(Y, X, reinterpret_cast<const uint16_t*>(scratch), M, K, F, as_stream(stream));
+    return launch_geglu_rows(Y, X, reinterpret_cast<const uint16_t*>(scratch), M, K, F, as_stream(stream));
 }
 
 int mila_cdna4_gemm_geglu_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed, const float* scales, int M, int K,
@@ -559,7 +602,7 @@ int mila_cdna4_gemm_geglu_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, cons
 {
     int rc = validate_gemm("gemm_geglu_bf16_w4a16_staged", Y, X, W_packed, M, K, F);
     if (rc) return rc;
-    MILA_REQUIRE(gemm256_geglu_applicable(M, K, F), "gemm_geglu_bf16_w4a16_staged: shape (M=%d, K=%d, F=%d) is outside the fused kernel", M, K, F);
+    MILA_REQUIRE(geglu_rows_applicable(M, K, F), "gemm_geglu_bf16_w4a16_staged: shape (M=%d, K=%d, F=%d) is outside the fused kernel", M, K, F);
     MILA_REQUIRE(scales != nullptr, "gemm_geglu_bf16_w4a16_staged: per-group scales are required");
     MILA_REQUIRE(group == 64 || group == 128, "gemm_geglu_bf16_w4a16_staged: group size must be 64 or 128 (got %d)", group);
     MILA_REQUIRE(K % group == 0, "gemm_geglu_bf16_w4a16_staged: K=%d must be a multiple of the group size %d", K, group);
@@ -568,7 +611,7 @@ int mila_cdna4_gemm_geglu_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, cons
         return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_geglu_bf16_w4a16_staged: scratch %zu bytes < required %zu", scratch_bytes, need);
     rc = launch_dequant(2, reinterpret_cast<uint16_t*>(scratch), W_packed, scales, 2 * F, K, group, as_stream(stream));
     if (rc) return rc;
-    return launch_gemm256_geglu(Y, X, reinterpret_cast<const uint16_t*>(scratch), M, K, F, as_stream(stream));
+    return launch_geglu_rows(Y, X, reinterpret_cast<const uint16_t*>(scratch), M, K, F, as_stream(stream));
 }
 
 }  // extern "C"

@@ -822,3 +822,71 @@ def test_skinny_whole_x_form_gives_the_staged_forms_bits(M, K, N):
     raw = orc.linear_fp8a_fp8w(x8, np.ones(M, dtype=np.float32), w8, None, ws, None)
     exp = orc.round_bf16(raw.astype(np.float32)).astype(np.float64) * ts.astype(np.float64)[:, None] + orc.from_bf16_bits(bb).astype(np.float64)
     assert_bf16_close(outs[0][0], exp, 2, 1e-3 * float(np.abs(exp).max()), "whole-X skinny vs restated reference")
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 3840, 8192), (2, 15360, 3840), (16, 768, 3072), (33, 200, 250), (64, 4096, 3840), (7, 64, 96), (100, 256, 520)])
+def test_bf16_skinny_kernel_serves_few_rows(M, K, N):
+    """round 3: up to 64 rows (a 16-token prompt, the 1-row remainder of a 2049-token one) are a weight stream -- gemm_bf16_skinny_kernel: eight waves take every eighth
+    128-byte K-tile of a 16-row strip of W straight from global memory, the partial sums meet in LDS in wave order; one row group whose image fits LDS runs without a
+    barrier in the K loop.  Plain (+ bias), Linear + GELU and Linear + GeGLU against the float64 oracle, and against the 128-tile kernel (hook) within 1 ulp of the magnitude;
+    100 rows = a 64-row and a 36-row launch... only below 65 rows by default: at 100 the tile kernels keep the call (checked through the hook that turns the skinny kernel off)"""
+    lib = capi.load()
+    rng = np.random.default_rng(M * 31 + N)
+    Wb = _weights(rng, N, K, "random")
+    X = orc.round_bf16(rng.uniform(-1, 1, (M, K)).astype(np.float32))
+    bb = orc.to_bf16_bits(rng.uniform(-0.5, 0.5, N).astype(np.float32))
+    Xd, Wd, bd = dev_u16(orc.to_bf16_bits(X)), dev_u16(Wb), dev_u16(bb)
+    guard = torch.full((M + 1, N), 0x1234, dtype=torch.int16, device="cuda")
+    Y = guard[:M]
+    capi.call("gemm_bf16", Y, Xd, Wd, bd, M, K, N)
+    lin = orc.round_bf16(orc.linear_bf16w(X, Wb, None)).astype(np.float64) + orc.from_bf16_bits(bb).astype(np.float64)
+    assert_bf16_close(bits(Y), lin, 2, 2.0 ** -7 * max(1.0, float(np.abs(lin).max())), "skinny gemm_bf16")
+    assert np.all(guard[M].cpu().numpy() == 0x1234)
+    Yt = empty_u16(M, N)
+    capi.check(lib.mila_cdna4_tune_gemm(3))              # the tile kernels on the same call
+    try:
+        capi.call("gemm_bf16", Yt, Xd, Wd, bd, M, K, N)
+    finally:
+        capi.check(lib.mila_cdna4_tune_gemm(4))
+    a, b = orc.from_bf16_bits(bits(Y)).astype(np.float64), orc.from_bf16_bits(bits(Yt)).astype(np.float64)
+    assert np.abs(a - b).max() <= 2.0 ** -7 * max(np.abs(b).max(), 1e-30)
+    if M > 64:
+        assert np.array_equal(bits(Y), bits(Yt)), "above 64 rows the default is the tile kernels"
+        return
+    Yg = empty_u16(M, N)
+    capi.call("gemm_gelu_bf16", Yg, Xd, Wd, bd, M, K, N)
+    h = orc.round_bf16(lin.astype(np.float32)).astype(np.float64)
+    assert_bf16_close(bits(Yg), 0.5 * h * (1 + np.tanh(0.7978845608028654 * (h + 0.044715 * h ** 3))), 2, 2e-2, "skinny gemm_gelu_bf16")
+    if N % 2 == 0 and lib.mila_cdna4_gemm_geglu_applicable(M, K, N // 2) == 1:
+        F = N // 2
+        Ye = empty_u16(M, F)
+        capi.call("gemm_geglu_bf16", Ye, Xd, Wd, M, K, F)
+        gu = orc.round_bf16(orc.linear_bf16w(X, Wb, None).astype(np.float32)).astype(np.float64)
+        g_, u_ = gu[:, :F], gu[:, F:]
+        assert_bf16_close(bits(Ye), 0.5 * g_ * (1 + np.tanh(0.7978845608028654 * (g_ + 0.044715 * g_ ** 3))) * u_, 2, 2e-2, "skinny gemm_geglu_bf16")
+
+
+@pytest.mark.parametrize("M", [2049, 512 + 64, 1024 + 17])
+def test_a_long_prompts_short_remainder_goes_to_the_bf16_skinny_kernel(M):
+    """bf16 policy, M = 256 k + r with r <= 64: the LDS-DMA kernels on the leading tile-rows and the skinny kernel on the remainder -- plain and fused GeGLU; rows on both
+    sides of the seam against the oracle, the leading rows bit-identical to the same call without the remainder"""
+    lib = capi.load()
+    K, F = 256, 15360
+    rng = np.random.default_rng(M)
+    Wb = _weights(rng, 2 * F, K, "random")
+    X = orc.round_bf16(rng.uniform(-1, 1, (M, K)).astype(np.float32))
+    Xd, Wd = dev_u16(orc.to_bf16_bits(X)), dev_u16(Wb)
+    main = M - M % 256
+    assert lib.mila_cdna4_gemm_geglu_applicable(M, K, F) == 1
+    Y, Ym = empty_u16(M, F), empty_u16(main, F)
+    capi.call("gemm_geglu_bf16", Y, Xd, Wd, M, K, F)
+    capi.call("gemm_geglu_bf16", Ym, Xd, Wd, main, K, F)
+    assert np.array_equal(bits(Y)[:main], bits(Ym))
+    rows = [0, main - 1, main, M - 1]
+    gu = orc.round_bf16(orc.linear_bf16w(X[rows], Wb, None).astype(np.float32)).astype(np.float64)
+    g_, u_ = gu[:, :F], gu[:, F:]
+    assert_bf16_close(bits(Y)[rows], 0.5 * g_ * (1 + np.tanh(0.7978845608028654 * (g_ + 0.044715 * g_ ** 3))) * u_, 2, 2e-3, "gemm_geglu_bf16 across the seam")
+    N = 3840
+    Y2 = empty_u16(M, N)
+    capi.call("gemm_bf16", Y2, Xd, Wd[:N], None, M, K, N)
+    assert_bf16_close(bits(Y2)[rows], orc.linear_bf16w(X[rows], Wb[:N], None), 1, 2e-3, "gemm_bf16 across the seam")
