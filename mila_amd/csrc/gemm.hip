@@ -291,6 +291,7 @@ extern int g_gemm_fp8_tail_only;
 extern int g_gemm_fp8_tail_form;      // gemm_fp8_tail.hip
 extern int g_skinny_whole_x;
 extern int g_fp8_big_rule;           // gemm256.hip
+extern int g_ldsdma_loose_tiles;     // gemm256.hip
 
 // which direct-to-LDS kernel serves a bf16-weight GEMM of this shape: 2 = 256 x 256, 1 = 256 x 128, 0 = none (128 x 128 register-staged)
 static int glds_kernel_for(int M, int K, int N)
@@ -413,6 +414,20 @@ static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, c
             if (rc) return rc;
             return launch_gemm_bf16_skinny(Y + (size_t)(M - tail) * N, X + (size_t)(M - tail) * K, W, bias, tail, K, N, act, s);
         }
+        // a longer remainder (65 .. 255 rows) normally rides in a ragged tile-row; but where that row opens a NEW ROUND of the 256 x 128 grid (the N = 3840 shapes: 240
+        // tiles fill the chip, 270 need a second round of full-length tiles) a few 64-row skinny passes over the weights are cheaper: fc_down 180 us vs 4 x 24
+        if (M >= 512 && tail > kBf16SkinnyRows && glds_kernel_for(M - tail, K, N) == 1)
+        {
+            const int tn = (N + 127) / 128, tiles_main = (M / 256) * tn;
+            const bool new_round = (tiles_main + tn + kNumCU - 1) / kNumCU > (tiles_main + kNumCU - 1) / kNumCU;
+            const double round_us = (K / 64) * 0.75, skinny_us = ((tail + 63) / 64) * ((double)N * K * 2 / 5.0e6);
+            if (new_round && skinny_us < round_us)
+            {
+                int rc = launch_glds(1, Y, X, W, bias, M - tail, K, N, s, act);
+                if (rc) return rc;
+                return launch_gemm_bf16_skinny(Y + (size_t)(M - tail) * N, X + (size_t)(M - tail) * K, W, bias, tail, K, N, act, s);
+            }
+        }
     }
     const int main_rows = glds_rows_for(M, K, N, &which);
     if (main_rows > 0)
@@ -457,6 +472,7 @@ int mila_cdna4_tune_gemm(int force_128_tile)
 {
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
     if (force_128_tile == 3 || force_128_tile == 4) { g_bf16_skinny = force_128_tile == 4; return MILA_OK; }
+    if (force_128_tile >= 100) { g_ldsdma_loose_tiles = force_128_tile - 100; return MILA_OK; }      // 100 = the fill rule only; 130 = default
     g_gemm_force128 = force_128_tile == 1;
     g_gemm_rowwise = force_128_tile != 2;      // 2: the direct (unaligned) epilogue stores on an odd output pitch instead of the row-wise one through LDS
     return MILA_OK;
@@ -532,7 +548,10 @@ int mila_cdna4_dequantize_to_bf16(uint16_t* out, const void* W, const float* sca
 size_t mila_cdna4_gemm_staging_bytes(int M, int K, int N)
 {
     int which;
-    return glds_rows_for(M, K, N, &which) ? (size_t)N * K * 2 : 0;
+    if (glds_rows_for(M, K, N, &which)) return (size_t)N * K * 2;
+    // few rows: the staged forms dequantize once and stream the bf16 weights through the skinny kernel (the in-register-dequantizing 128-tile kernel pushed the fp8
+    // policy's weights past a 16-row prompt at 1 TB/s)
+    return (!g_gemm_force128 && g_bf16_skinny && M > 1 && M <= kBf16SkinnyRows && K % 8 == 0) ? (size_t)N * K * 2 : 0;
 }
 
 int mila_cdna4_gemm_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W, const float* scales, const uint16_t* bias,

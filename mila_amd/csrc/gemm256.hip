@@ -1045,12 +1045,16 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
 // the LDS-DMA kernels address their operands through 32-bit buffer offsets (bytes, signed int arithmetic): both tensors must stay below 2 GiB
 static bool lds_dma_addressable(int M, int K, int w_rows) { return (int64_t)M * K * 2 < 0x7fffffffll && (int64_t)w_rows * K * 2 < 0x7fffffffll; }
 
+int g_ldsdma_loose_tiles = 30;     // the 256 x 128 ring applies from this many tiles on whatever the fill of its last round (tuning: mila_cdna4_tune_gemm(100 + n), 100 = the fill rule only).
+                                   // Measured with tools/experiments/bf16_ragged_rules.py (profiles/r03_bf16_ragged.txt): even a 30-tile ring beats the register-staged 128-tile kernel --
+                                   // bf16-policy prefill of 100 / 300 / 511 / 1000 tokens 23.6 / 25.1 / 26.4 / 31.6 -> 16.3 / 17.9 / 21.4 / 26.7 ms
 // taken when the 256 x 256 grid does not apply and the 256 x 128 grid fills most of one round of CUs (or several)
 bool gemm256x128_applicable(int M, int K, int N)
 {
     if (M <= 0 || N % 128 != 0 || K % 64 != 0 || !lds_dma_addressable(M, K, N)) return false;
     const int tiles = ((M + 255) / 256) * (N / 128);      // a ragged last tile-row counts (and costs) whole: rows past M re-read row M - 1, their stores are masked
     const int rounds = (tiles + kNumCU - 1) / kNumCU;
+    if (g_ldsdma_loose_tiles > 0 && tiles >= g_ldsdma_loose_tiles) return true;      // experiment / ragged-M rule: see g_ldsdma_loose_tiles
     return tiles >= 160 && tiles >= 0.70 * rounds * kNumCU;      // (192 tiles -- GPT-2's 768-wide projections at B T = 8192 -- beat the 128-tile kernel's 384: 18 / 51 vs 29 / 74 us)
 }
 
@@ -1117,7 +1121,7 @@ bool gemm256_applicable(int M, int K, int N)
     if (M <= 0 || N % 256 != 0 || K % 64 != 0 || !lds_dma_addressable(M, K, N)) return false;
     const int tiles = ((M + 255) / 256) * (N / 256);
     const int rounds = (tiles + kNumCU - 1) / kNumCU;
-    return tiles >= 200 && tiles >= 0.85 * rounds * kNumCU;
+    return tiles >= 200 && tiles >= 0.80 * rounds * kNumCU;      // (0.80: nine tile-rows of fc_gate_up -- 1080 tiles, 4.2 rounds walked as 5 -- stay on the fused kernel)
 }
 
 // bf16 only: N of any size (ragged last tile-column, any row pitch) on the PERSISTENT 256 x 256 schedule when the grid is many rounds deep -- GPT-2's lm_head
@@ -1183,7 +1187,7 @@ bool gemm256_geglu_applicable(int M, int K, int F)
     if (M <= 0 || F % 128 != 0 || K % 64 != 0 || !lds_dma_addressable(M, K, 2 * F)) return false;
     const int tiles = ((M + 255) / 256) * (F / 128);
     const int rounds = (tiles + kNumCU - 1) / kNumCU;
-    return tiles >= 200 && tiles >= 0.85 * rounds * kNumCU;
+    return tiles >= 200 && tiles >= 0.80 * rounds * kNumCU;
 }
 int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s)
 {
