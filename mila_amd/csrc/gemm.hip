@@ -414,20 +414,9 @@ static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, c
             if (rc) return rc;
             return launch_gemm_bf16_skinny(Y + (size_t)(M - tail) * N, X + (size_t)(M - tail) * K, W, bias, tail, K, N, act, s);
         }
-        // a longer remainder (65 .. 255 rows) normally rides in a ragged tile-row; but where that row opens a NEW ROUND of the 256 x 128 grid (the N = 3840 shapes: 240
-        // tiles fill the chip, 270 need a second round of full-length tiles) a few 64-row skinny passes over the weights are cheaper: fc_down 180 us vs 4 x 24
-        if (M >= 512 && tail > kBf16SkinnyRows && glds_kernel_for(M - tail, K, N) == 1)
-        {
-            const int tn = (N + 127) / 128, tiles_main = (M / 256) * tn;
-            const bool new_round = (tiles_main + tn + kNumCU - 1) / kNumCU > (tiles_main + kNumCU - 1) / kNumCU;
-            const double round_us = (K / 64) * 0.75, skinny_us = ((tail + 63) / 64) * ((double)N * K * 2 / 5.0e6);
-            if (new_round && skinny_us < round_us)
-            {
-                int rc = launch_glds(1, Y, X, W, bias, M - tail, K, N, s, act);
-                if (rc) return rc;
-                return launch_gemm_bf16_skinny(Y + (size_t)(M - tail) * N, X + (size_t)(M - tail) * K, W, bias, tail, K, N, act, s);
-            }
-        }
+        // (a longer remainder, 65 .. 255 rows, rides in a ragged tile-row.  Where that row opens a new round of the grid -- the N = 3840 shapes: 240 tiles fill the chip, 270
+        // need a second round of full-length tiles -- 64-row skinny passes were tried instead and are slower: the staged 64-row form streams at 1.2 TB/s, fc_down 4 x 90 us
+        // against 180 for the extra round; profiles/r03_bf16_ragged.txt.  What that case wants is a split-K tail.)
     }
     const int main_rows = glds_rows_for(M, K, N, &which);
     if (main_rows > 0)

@@ -11,7 +11,7 @@ out = {}
 for pol in policies:
     m = host.Gemma(pol, max_seq=4096, max_prefill=2304, seed=1)
     res = {}
-    for T in (2048, 2049, 2000, 2303, 300, 16):
+    for T in [int(t) for t in os.environ.get("RAGGED_T", "2048,2049,2000,2303,300,16").split(",")]:
         m.time_prefill(T, 1)
         res[T] = round(m.time_prefill(T, 3), 3)
     m.close()
