@@ -1195,17 +1195,6 @@ int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int 
     return launch_gemm256_t<G_GEGLU>(p, s);
 }
 
-// fp8 x fp8 (e4m3 bytes, K % 128 == 0): 2 = the 256 x 256 kernel, 1 = 256 x 128, 0 = no LDS-DMA kernel for this shape
-int gemm_fp8_kernel_for(int M, int K, int N)
-{
-    // at the fp8 rate the 4-barrier-per-K-tile 256 x 256 schedule is barrier-bound (1.36 PFLOP/s on fc_gate_up); the 3-stage
-    // 256 x 128 ring (one barrier per K-tile) reaches 1.8-1.9, so it is preferred wherever its grid fills the chip
-    if (K % 128 != 0) return 0;
-    if (g_gemm_pingpong >= 4 && gemm256_applicable(M, K, N)) return 2;       // tuning: the two-phase 256 x 256 schedule for fp8 too
-    if (gemm256x128_applicable(M, K, N)) return 1;
-    if (gemm256_applicable(M, K, N)) return 2;
-    return 0;
-}
 // gemm_fp8_tail.hip: the same arithmetic for any row count (masked 128-row tiles; skinny weight streaming for <= 64 rows)
 int launch_gemm_fp8_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
                          int M, int K, int N, hipStream_t s);

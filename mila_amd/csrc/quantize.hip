@@ -240,7 +240,6 @@ __global__ __launch_bounds__(256) void quantize_fp8_per_token_kernel(uint8_t* __
     }
 }
 
-int gemm_fp8_kernel_for(int M, int K, int N);
 int launch_gemm_fp8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
                     int M, int K, int N, hipStream_t s);
 bool gemm256_geglu_applicable(int M, int K, int F);
