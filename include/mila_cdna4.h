@@ -103,6 +103,14 @@ MILA_API int mila_cdna4_gemm_bf16(uint16_t* Y, const uint16_t* X, const uint16_t
  * launches kept, so the result is bit-identical to gemm_bf16 followed by gelu_bf16 -- the [M, N] intermediate is neither written nor re-read. */
 MILA_API int mila_cdna4_gemm_gelu_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K,
                                        int N, mila_stream_t stream);
+/* The same GEMM (act 0) / GEMM + tanh-GELU (act 1) with a caller workspace -- the counterpart of the cuBLASLt workspace CudaLinearOp hands every plan
+ * (Linear/CudaLinearOp.ixx:637-638, :817-818; CudaExecutionContext.ixx:337-383, 4 MiB there).  With it, short prompts and the remainders of long ones -- tile lists that
+ * cover a fraction of the CUs -- split K over the idle ones (fp32 partials in the workspace, summed in a fixed order: results do not depend on timing; they may differ
+ * from gemm_bf16's in the last bf16 bit, the fp32 sum being taken in another order).  gemm_workspace_bytes() is what this (M, K, N) needs (0: the call is gemm_bf16 /
+ * gemm_gelu_bf16; never more than 32 MiB); a smaller or unaligned (16 bytes) workspace is MILA_E_SCRATCH_TOO_SMALL / MILA_E_INVALID_ARGUMENT. */
+MILA_API size_t mila_cdna4_gemm_workspace_bytes(int M, int K, int N);
+MILA_API int mila_cdna4_gemm_bf16_ws(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, int act, void* workspace,
+                                     size_t workspace_bytes, mila_stream_t stream);
 MILA_API int mila_cdna4_gemm_bf16_w8a16(uint16_t* Y, const uint16_t* X, const uint8_t* W,
                                         const float* scales, const uint16_t* bias, int M, int K,
                                         int N, mila_stream_t stream);

@@ -292,6 +292,10 @@ extern int g_gemm_fp8_tail_form;      // gemm_fp8_tail.hip
 extern int g_skinny_whole_x;
 extern int g_fp8_big_rule;           // gemm256.hip
 extern int g_ldsdma_loose_tiles;     // gemm256.hip
+extern int g_gemm_splitk;            // gemm256.hip
+int gemm_splitk_for(int M, int K, int N);
+int launch_gemm256x128_splitk(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act, float* partials, int S);
+int g_splitk_min_rows = 17;          // tuning (mila_cdna4_tune_gemm(200 + n)): row counts below this stay on the skinny kernel (a pure weight stream) even with a workspace
 
 // which direct-to-LDS kernel serves a bf16-weight GEMM of this shape: 2 = 256 x 256, 1 = 256 x 128, 0 = none (128 x 128 register-staged)
 static int glds_kernel_for(int M, int K, int N)
@@ -428,6 +432,44 @@ static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, c
     return launch_gemm<G_BF16>(p, s);
 }
 
+// ---- the same GEMM with a caller workspace (mila_cdna4_gemm_bf16_ws): what the split-K form changes ----
+// plan: rows [0, main) as launch_bf16_rows serves them, rows [main, M) split-K with S copies (S = 0: no split-K part, everything as launch_bf16_rows)
+struct Bf16WsPlan { int main_rows, S; };
+static Bf16WsPlan bf16_ws_plan(int M, int K, int N)
+{
+    if (g_gemm_force128 || M < g_splitk_min_rows) return {M, 0};
+    // a short prompt: the whole tile list covers at most half the CUs
+    int S = gemm_splitk_for(M, K, N);
+    if (S) return {0, S};
+    // a long prompt's remainder whose ragged tile-row would open another round of the grid (T = 2303 on the N = 3840 shapes: 240 tiles fill the chip, 270 run two
+    // rounds of full-length tiles -- fc_down 200 -> 400 us): the whole tile-rows as before, the remainder split-K
+    const int tail = M % 256, main_rows = M - tail;
+    if (M < 512 || tail < g_splitk_min_rows) return {M, 0};
+    const int which = glds_kernel_for(main_rows, K, N);
+    if (!which) return {M, 0};
+    const int per_row = which == 2 ? (N + 255) / 256 : (N + 127) / 128, tm = main_rows / 256;
+    const bool new_round = (tm * per_row + kNumCU - 1) / kNumCU < ((tm + 1) * per_row + kNumCU - 1) / kNumCU;
+    if (!new_round) return {M, 0};
+    S = gemm_splitk_for(tail, K, N);
+    return S ? Bf16WsPlan{main_rows, S} : Bf16WsPlan{M, 0};
+}
+static size_t bf16_ws_bytes(int M, int K, int N)
+{
+    const Bf16WsPlan pl = bf16_ws_plan(M, K, N);
+    return pl.S ? (size_t)pl.S * (M - pl.main_rows) * N * sizeof(float) : 0;
+}
+static int launch_bf16_rows_ws(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act, void* ws)
+{
+    const Bf16WsPlan pl = bf16_ws_plan(M, K, N);
+    if (!pl.S) return launch_bf16_rows(Y, X, W, bias, M, K, N, s, act);
+    if (pl.main_rows > 0)
+    {
+        int rc = launch_bf16_rows(Y, X, W, bias, pl.main_rows, K, N, s, act);
+        if (rc) return rc;
+    }
+    return launch_gemm256x128_splitk(Y + (size_t)pl.main_rows * N, X + (size_t)pl.main_rows * K, W, bias, M - pl.main_rows, K, N, s, act, static_cast<float*>(ws), pl.S);
+}
+
 // Linear + GeGLU over any row count the fused forms serve: the LDS-DMA GeGLU kernel on whole / ragged tile-rows, the skinny GeGLU kernel on <= 64 rows (a short prompt,
 // or the remainder of a long one)
 static bool geglu_rows_applicable(int M, int K, int F)
@@ -461,6 +503,8 @@ int mila_cdna4_tune_gemm(int force_128_tile)
 {
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
     if (force_128_tile == 3 || force_128_tile == 4) { g_bf16_skinny = force_128_tile == 4; return MILA_OK; }
+    if (force_128_tile == 5 || force_128_tile == 6) { g_gemm_splitk = force_128_tile == 6; return MILA_OK; }      // the split-K form of gemm_bf16_ws off / on
+    if (force_128_tile >= 200) { g_splitk_min_rows = force_128_tile - 200; return MILA_OK; }      // 217 = default
     if (force_128_tile >= 100) { g_ldsdma_loose_tiles = force_128_tile - 100; return MILA_OK; }      // 100 = the fill rule only; 130 = default
     g_gemm_force128 = force_128_tile == 1;
     g_gemm_rowwise = force_128_tile != 2;      // 2: the direct (unaligned) epilogue stores on an odd output pitch instead of the row-wise one through LDS
@@ -499,6 +543,24 @@ int mila_cdna4_gemm_gelu_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W,
     int rc = validate_gemm("gemm_gelu_bf16", Y, X, W, M, K, N);
     if (rc) return rc;
     return launch_bf16_rows(Y, X, W, bias, M, K, N, as_stream(stream), 1);
+}
+
+size_t mila_cdna4_gemm_workspace_bytes(int M, int K, int N)
+{
+    return (M > 0 && K > 0 && N > 0 && K % 8 == 0) ? bf16_ws_bytes(M, K, N) : 0;
+}
+
+int mila_cdna4_gemm_bf16_ws(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, int act, void* workspace, size_t workspace_bytes,
+                            mila_stream_t stream)
+{
+    int rc = validate_gemm("gemm_bf16_ws", Y, X, W, M, K, N);
+    if (rc) return rc;
+    MILA_REQUIRE(act == 0 || act == 1, "gemm_bf16_ws: act must be 0 (none) or 1 (tanh-GELU), got %d", act);
+    const size_t need = bf16_ws_bytes(M, K, N);
+    if (need && (!workspace || workspace_bytes < need))
+        return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_bf16_ws: workspace %zu bytes < required %zu (ask gemm_workspace_bytes)", workspace_bytes, need);
+    MILA_REQUIRE(!need || (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "gemm_bf16_ws: the workspace must be 16-byte aligned");
+    return launch_bf16_rows_ws(Y, X, W, bias, M, K, N, as_stream(stream), act, workspace);
 }
 
 int mila_cdna4_gemm_bf16_w8a16(uint16_t* Y, const uint16_t* X, const uint8_t* W, const float* scales,

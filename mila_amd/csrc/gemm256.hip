@@ -33,6 +33,8 @@ struct Gemm256Params
     const float* w_scale;    // device scalar: per-tensor weight scale
     int rowwise = 0;         // 256 x 256 plain bf16, one workgroup per tile: the tile goes through LDS and is written row by row (see rowwise_epilogue)
     int act = 0;             // bf16 plain epilogue: 1 = tanh-GELU on the stored Linear output, y = bf16(gelu(bf16(acc) [+ bias, rounded again])): Linear + Gelu of MLP.ixx:148-161 in one kernel
+    float* partials = nullptr;      // split-K form of the 256 x 128 ring: [splitk][M][N] fp32 accumulators (workspace), summed and finished by splitk_reduce_kernel
+    int splitk = 0;
 #ifdef MILA_GEMM_SKIP
     int dbg = 0;             // diagnostic build (tools/experiments/gemm_skip.sh): leave out the staging (1), the fragment reads (2), the MFMAs (4), the plain epilogue's stores (8)
 #endif
@@ -674,9 +676,12 @@ constexpr bool kRingGlobalLoads = MILA_RING_GLOBAL_LOADS;      // how the 256 x 
 // restages it behind B(t - 1) = group 1's A(t - 1).
 // WALK: the persistent tile walk is compiled in (one workgroup per CU); without it the kernel is the one-tile form, whose K loop carries none of the walk's selects
 // (the walk's bookkeeping in the K loop -- next-tile offsets, the flat ring index -- cost the one-round shapes 15 %: o_proj + fc_down 130 -> 152 us average)
-template <bool FP8, bool GEGLU, int PP, bool WALK>      // PP: 0 lockstep, 1 staggered groups, 2 staggered with a static priority for waves 4-7
+// SPLITK (plain bf16, one-tile form): the grid is p.splitk copies of the tile list; copy ks takes K-tiles [ks nk / S, (ks + 1) nk / S) of its tile and writes its fp32
+// accumulators to p.partials[ks] -- few-row prompts and remainders, whose tile list covers a fraction of the CUs, then spread each tile's K over the idle ones
+template <bool FP8, bool GEGLU, int PP, bool WALK, bool SPLITK = false>      // PP: 0 lockstep, 1 staggered groups, 2 staggered with a static priority for waves 4-7
 __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
 {
+    static_assert(!SPLITK || (!FP8 && !GEGLU && !WALK), "split-K: the plain bf16 one-tile form");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ES = FP8 ? 1 : 2;
     constexpr int KT = 128 / ES;
@@ -693,13 +698,19 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
         n0_ = tn * (GEGLU ? 64 : 128);
     };
     int m0, n0, xm0 = 0, xn0 = 0;       // this tile and (persistent form) the next one
-    tile_origin(blockIdx.x, m0, n0);
+    int ks = 0;
+    if constexpr (SPLITK) { ks = (int)blockIdx.x / ntiles; tile_origin((int)blockIdx.x - ks * ntiles, m0, n0); }
+    else tile_origin(blockIdx.x, m0, n0);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, g = lane >> 4;
-    const int K = p.K, nk = K / KT;
+    const int K = p.K, nk_all = K / KT;
+    // this workgroup's K-tiles and the byte offset of its first one in a row
+    const int kt_first = SPLITK ? ks * nk_all / max(p.splitk, 1) : 0;
+    const int nk = SPLITK ? (ks + 1) * nk_all / max(p.splitk, 1) - kt_first : nk_all;
+    const int kbyte0 = kt_first * 128;
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(p.X);
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
 
@@ -726,7 +737,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                     else grow = min(nn0 + row, p.N - 1);      // W rows past N (a ragged last column tile) re-read row N - 1, never stored
                 }
                 else grow = min(mm0 + (which - 1) * 128 + row, p.M - 1);      // X rows past M (ragged last tile-row) re-read row M - 1, never stored
-                vo[which][i] = grow * rowbytes + kslot * 16;
+                vo[which][i] = grow * rowbytes + kslot * 16 + (SPLITK ? kbyte0 : 0);
             }
     };
     offsets(voff, m0, n0);
@@ -823,6 +834,22 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     };
 
     auto epilogue = [&]() {
+        if constexpr (SPLITK)
+        {
+            // the raw fp32 accumulators of this K range: 16 bytes (4 columns) per lane and sub-tile, 64 contiguous bytes per row and instruction
+            float* P = p.partials + (size_t)ks * p.M * p.N;
+    #pragma unroll
+            for (int hB = 0; hB < 2; ++hB)
+    #pragma unroll
+                for (int pt = 0; pt < 4; ++pt)
+    #pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                    {
+                        const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                        if (m < p.M) *reinterpret_cast<f32x4*>(P + (size_t)m * p.N + n0 + wr * 64 + pt * 16 + 4 * g) = acc[hB][pt][qt];
+                    }
+            return;
+        }
         if constexpr (GEGLU)
         {
             // fp8 epilogue scales, fetched ONCE before the stores: read inside the store loop they are re-fetched after every store (the compiler cannot
@@ -1113,6 +1140,69 @@ int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const 
 {
     Gemm256Params p{Y, X, W, bias, M, K, N, (M + 255) / 256, (N + 127) / 128, nullptr, nullptr, 0, act};
     return launch_gemm256x128_t<false>(p, s);
+}
+
+// ---- split-K (round 3): short prompts and the remainders of long ones.  A 300-row prompt gives fc_down (N = 3840, K = 15360) 60 tiles of 240 K-tiles each: 60 CUs
+// busy for a full-length K loop, 196 idle.  The split form starts S copies of the tile list, copy ks taking 1 / S of K, and a second kernel sums the S fp32 partials in
+// a fixed order and applies the epilogue (bias, GELU, bf16) -- same bits whatever the timing.  The partials live in caller workspace (S M N floats, <= 32 MiB since
+// tiles x S <= 256 CUs): the entry that takes one is mila_cdna4_gemm_bf16_ws, the counterpart of the cuBLASLt workspace CudaLinearOp hands its plans
+// (CudaLinearOp.ixx:637-638, CudaExecutionContext.ixx:337).
+int g_gemm_splitk = 1;            // tuning: mila_cdna4_tune_gemm(5) off, (6) on
+int gemm_splitk_for(int M, int K, int N)      // S (>= 2), or 0: no split-K form for this shape
+{
+    if (!g_gemm_splitk || g_gemm_pingpong != 5) return 0;
+    if (M <= 0 || N % 128 != 0 || K % 64 != 0 || !lds_dma_addressable(M, K, N)) return 0;
+    const int tiles = ((M + 255) / 256) * (N / 128), nk = K / 64;
+    if (tiles > kNumCU / 2) return 0;
+    const int S = min(min(kNumCU / tiles, nk / 8), 16);      // at least 8 K-tiles per copy: the ring's fill and drain are 3
+    return S >= 2 ? S : 0;
+}
+
+// y = epilogue(sum over s of P[s]), 8 columns per thread; the epilogue is the 256 x 128 kernel's: bf16(acc) [+ bias, rounded again] [-> GELU of the rounded value]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(uint16_t* __restrict__ Y, const float* __restrict__ P, const uint16_t* __restrict__ bias, int64_t MN, int N, int S,
+                                                            int act)
+{
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= MN) return;
+    f32x4 a = *reinterpret_cast<const f32x4*>(P + i), b = *reinterpret_cast<const f32x4*>(P + i + 4);
+    for (int s_ = 1; s_ < S; ++s_)
+    {
+        a += *reinterpret_cast<const f32x4*>(P + (size_t)s_ * MN + i);
+        b += *reinterpret_cast<const f32x4*>(P + (size_t)s_ * MN + i + 4);
+    }
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    if (bias)
+    {
+        const int n = (int)(i % N);
+        const u32x4 bb = *reinterpret_cast<const u32x4*>(bias + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = round_bf16(v[e]) + bf16_bits_to_f32((uint16_t)(bb[e >> 1] >> ((e & 1) * 16)));
+    }
+    if (act)
+    {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(round_bf16(v[e]));
+    }
+    st16(Y + i, u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
+}
+
+int launch_gemm256x128_splitk(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act, float* partials, int S)
+{
+    static bool attr_set = false;
+    if (!attr_set)
+    {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel<false, false, 2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               3 * kStage3Bytes), "hipFuncSetAttribute(gemm256x128 split-K)");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    Gemm256Params p{Y, X, W, nullptr, M, K, N, (M + 255) / 256, N / 128, nullptr, nullptr, 0, 0, partials, S};
+    hipLaunchKernelGGL((gemm256x128_kernel<false, false, 2, false, true>), dim3(p.tiles_m * p.tiles_n * S), dim3(512), 3 * kStage3Bytes, s, p);
+    int rc = check_hip(hipGetLastError(), "gemm256x128 (split-K)");
+    if (rc) return rc;
+    const int64_t MN = (int64_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, Y, partials, bias, MN, N, S, act);
+    return check_hip(hipGetLastError(), "splitk_reduce");
 }
 
 // one 512-thread workgroup per CU: worth it only when the tile count fills whole rounds of 256 CUs

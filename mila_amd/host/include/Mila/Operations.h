@@ -121,7 +121,7 @@ namespace Mila::Dnn::Compute
             }
             else
             {
-                if constexpr ( kFmt == 0 ) rocmCheck( mila_cdna4_gemm_bf16( y, x, static_cast<const uint16_t*>( weight_ ), bias_, M, K, N, st ) );
+                if constexpr ( kFmt == 0 ) gemmWithWorkspace( y, x, static_cast<const uint16_t*>( weight_ ), M, K, N, 0, st );
                 else
                 {
                     // resident prefill weights: the staging pass was run once, at load (same values => same bits as the staged call)
@@ -129,7 +129,7 @@ namespace Mila::Dnn::Compute
                     {
                         if ( resident_bf16_ && mila_cdna4_gemm_staging_bytes( M, K, N ) != 0 )
                         {
-                            rocmCheck( mila_cdna4_gemm_bf16( y, x, resident_bf16_->data(), bias_, M, K, N, st ) );
+                            gemmWithWorkspace( y, x, resident_bf16_->data(), M, K, N, 0, st );
                             return;
                         }
                     }
@@ -175,8 +175,17 @@ namespace Mila::Dnn::Compute
             const int M = narrowToKernelIndex( static_cast<dim_t>( in.size() ) / cfg_.in_features, "outer size" );
             if ( !fusesGelu( M ) ) throw std::logic_error( "RocmLinearOp::forwardGelu: only unquantized weights at more than one row" );
             if constexpr ( kFmt == 0 )
-                rocmCheck( mila_cdna4_gemm_gelu_bf16( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( in.rawData() ), static_cast<const uint16_t*>( weight_ ), bias_, M, K, N,
-                                                      this->context_->getStream() ) );
+                gemmWithWorkspace( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( in.rawData() ), static_cast<const uint16_t*>( weight_ ), M, K, N, 1,
+                                   this->context_->getStream() );
+        }
+
+        /// the bf16 GEMM with the context's scratch as its workspace, as CudaLinearOp hands context_->getCublasLtWorkspace() to every plan (CudaLinearOp.ixx:637-638,
+        /// :817-818): short prompts and remainders split K through it.  Fetched per forward, never cached.
+        void gemmWithWorkspace( uint16_t* y, const uint16_t* x, const uint16_t* w, int M, int K, int N, int act, mila_stream_t st ) const
+        {
+            const size_t need = mila_cdna4_gemm_workspace_bytes( M, K, N );
+            void* ws = need ? this->context_->getScratch( need ) : nullptr;
+            rocmCheck( mila_cdna4_gemm_bf16_ws( y, x, w, bias_, M, K, N, act, ws, need, st ) );
         }
 
         void backward( const TensorType&, const TensorType&, TensorType& ) const

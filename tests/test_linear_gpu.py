@@ -890,3 +890,68 @@ def test_a_long_prompts_short_remainder_goes_to_the_bf16_skinny_kernel(M):
     Y2 = empty_u16(M, N)
     capi.call("gemm_bf16", Y2, Xd, Wd[:N], None, M, K, N)
     assert_bf16_close(bits(Y2)[rows], orc.linear_bf16w(X[rows], Wb[:N], None), 1, 2e-3, "gemm_bf16 across the seam")
+
+
+@pytest.mark.parametrize("M,K,N,bias,act", [(300, 2048, 3840, True, 0),        # 60 tiles, K split 4 ways
+                                            (100, 2048, 3840, False, 0),       # 30 tiles, 4 ways (8 K-tiles per copy)
+                                            (300, 1536, 768, True, 1),         # 12 tiles, K-tile count (24) over 3 copies; + GELU
+                                            (255, 1600, 384, True, 0),         # 3 tiles, 25 K-tiles over 3 copies: uneven K ranges (8, 8, 9)
+                                            (2048 + 255, 4096, 3840, True, 0),  # a long prompt: 8 whole tile-rows as before + a 255-row remainder split 8 ways
+                                            (1024 + 100, 2048, 8192, False, 1),  # 4 whole tile-rows fill the chip (256 tiles); the 100-row remainder (64 tiles) split 4 ways
+                                            (16, 1024, 3840, True, 0),         # below the split-K row limit: the skinny kernel, no workspace asked for
+                                            (2048, 512, 3840, True, 0)])       # whole tile-rows that fill the chip: no workspace asked for
+def test_gemm_with_a_workspace_splits_k_for_short_prompts_and_remainders(M, K, N, bias, act):
+    """round 3: gemm_bf16_ws = gemm_bf16 / gemm_gelu_bf16 with the counterpart of the cuBLASLt workspace CudaLinearOp passes (CudaLinearOp.ixx:637-638).  Where the tile
+    list covers at most half the CUs, S copies of it take 1 / S of K each and a second kernel sums the fp32 partials in a fixed order and applies the epilogue.  Against
+    the float64 oracle at the bar of the plain call, against the plain call within one bf16 ulp of the magnitude (another fp32 summation order), identical bits on a
+    second run and with a dirty workspace, nothing written past Y, and the size / alignment errors."""
+    lib = capi.load()
+    rng = np.random.default_rng(M * 7 + N + act)
+    Wb = _weights(rng, N, K, "random")
+    X = orc.round_bf16(rng.uniform(-1, 1, (M, K)).astype(np.float32))
+    bb = orc.to_bf16_bits(rng.uniform(-0.5, 0.5, N).astype(np.float32)) if bias else None
+    Xd, Wd, bd = dev_u16(orc.to_bf16_bits(X)), dev_u16(Wb), (dev_u16(bb) if bias else None)
+    need = lib.mila_cdna4_gemm_workspace_bytes(M, K, N)
+    expect_split = M > 16 and not (M == 2048)
+    assert (need > 0) == expect_split, need
+    assert need <= 32 << 20
+    if M == 2048 + 255: assert need == 8 * 255 * N * 4        # the remainder alone, 30 tiles x 8 copies
+    if M == 300 and N == 3840: assert need == 4 * 300 * N * 4
+    if M == 1024 + 100: assert need == 4 * 100 * N * 4
+    ws = torch.full((max(need, 16) // 4 + 4,), float("nan"), dtype=torch.float32, device="cuda")
+    guard = torch.full((M + 1, N), 0x1234, dtype=torch.int16, device="cuda")
+    Y = guard[:M]
+    capi.check(lib.mila_cdna4_gemm_bf16_ws(capi._ptr(Y), capi._ptr(Xd), capi._ptr(Wd), capi._ptr(bd), M, K, N, act, capi._ptr(ws), C.c_size_t(need), capi._stream()))
+    torch.cuda.synchronize()
+    assert np.all(guard[M].cpu().numpy() == 0x1234)
+    first = bits(Y).copy()
+    assert not np.any((first & 0x7fff) > 0x7f80), "unwritten / NaN outputs (a K range or a row not covered)"
+    # plain call on the same operands
+    Yp = empty_u16(M, N)
+    capi.call("gemm_gelu_bf16" if act else "gemm_bf16", Yp, Xd, Wd, bd, M, K, N)
+    a, b = orc.from_bf16_bits(first).astype(np.float64), orc.from_bf16_bits(bits(Yp)).astype(np.float64)
+    assert np.abs(a - b).max() <= 2.0 ** -7 * max(np.abs(b).max(), 1e-30)
+    if not expect_split:
+        assert np.array_equal(first, bits(Yp)), "no workspace asked for: the call is the plain one"
+    # oracle (sampled rows keep it to seconds)
+    rows = sorted(set([0, 1, M // 2, M - M % 256 - 1 if M >= 256 else 0, M - M % 256 if M % 256 else 0, M - 1]))
+    lin = orc.linear_bf16w(X[rows], Wb, None)
+    if bias: lin = orc.round_bf16(lin.astype(np.float32)).astype(np.float64) + orc.from_bf16_bits(bb).astype(np.float64)
+    if act:
+        h = orc.round_bf16(np.asarray(lin, dtype=np.float32)).astype(np.float64)
+        lin = 0.5 * h * (1 + np.tanh(0.7978845608028654 * (h + 0.044715 * h ** 3)))
+    assert_bf16_close(first[rows], lin, 2, 2.0 ** -7 * max(1.0, float(np.abs(lin).max())) if (bias or act) else 2e-3, "gemm_bf16_ws")
+    # the same bits again, with other garbage in the workspace
+    ws.fill_(1.0e30)
+    Y2 = empty_u16(M, N)
+    capi.check(lib.mila_cdna4_gemm_bf16_ws(capi._ptr(Y2), capi._ptr(Xd), capi._ptr(Wd), capi._ptr(bd), M, K, N, act, capi._ptr(ws), C.c_size_t(need), capi._stream()))
+    assert np.array_equal(bits(Y2), first)
+    if need:
+        rc = lib.mila_cdna4_gemm_bf16_ws(capi._ptr(Y2), capi._ptr(Xd), capi._ptr(Wd), capi._ptr(bd), M, K, N, act, capi._ptr(ws), C.c_size_t(need - 1), capi._stream())
+        assert rc == capi.MILA_E_SCRATCH_TOO_SMALL
+        rc = lib.mila_cdna4_gemm_bf16_ws(capi._ptr(Y2), capi._ptr(Xd), capi._ptr(Wd), capi._ptr(bd), M, K, N, act, None, C.c_size_t(0), capi._stream())
+        assert rc == capi.MILA_E_SCRATCH_TOO_SMALL
+        rc = lib.mila_cdna4_gemm_bf16_ws(capi._ptr(Y2), capi._ptr(Xd), capi._ptr(Wd), capi._ptr(bd), M, K, N, act, C.c_void_p(ws.data_ptr() + 4), C.c_size_t(need), capi._stream())
+        assert rc == capi.MILA_E_INVALID_ARGUMENT
+    rc = lib.mila_cdna4_gemm_bf16_ws(capi._ptr(Y2), capi._ptr(Xd), capi._ptr(Wd), capi._ptr(bd), M, K, N, 2, capi._ptr(ws), C.c_size_t(need), capi._stream())
+    assert rc == capi.MILA_E_INVALID_ARGUMENT
