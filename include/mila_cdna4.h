@@ -179,7 +179,9 @@ MILA_API int mila_cdna4_gemm_geglu_fp8_scaled(uint16_t* Y, const uint8_t* X8, co
 /* 2-phase forms for quantized weights (the reference's own structure, Linear/CudaLinearOp.ixx:597-644, :716-764:
  * dequantize to a bf16 scratch, then the bf16 GEMM).  Chosen automatically when the 256 x 256 LDS-DMA GEMM
  * applies to (M,K,N) -- gemm_staging_bytes() says how much scratch that needs (0 = the register-dequantizing kernel is
- * used and no scratch is touched).  Same arithmetic as the fused forms: w = bf16(decode(q) * scale), fp32 accumulate. */
+ * used and no scratch is touched).  Same arithmetic as the fused forms: w = bf16(decode(q) * scale), fp32 accumulate.
+ * The scratch (16-byte aligned) holds the N K bf16 weights and, behind them, gemm_workspace_bytes(M, K, N) of split-K workspace: a staged call gives the bits of
+ * gemm_bf16_ws on weights dequantized ahead of time (dequantize_to_bf16). */
 MILA_API size_t mila_cdna4_gemm_staging_bytes(int M, int K, int N);
 MILA_API int mila_cdna4_gemm_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W, const float* scales,
                                                const uint16_t* bias, int M, int K, int N, void* scratch,

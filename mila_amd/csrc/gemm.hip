@@ -472,19 +472,28 @@ static int launch_bf16_rows_ws(uint16_t* Y, const uint16_t* X, const uint16_t* W
 
 // Linear + GeGLU over any row count the fused forms serve: the LDS-DMA GeGLU kernel on whole / ragged tile-rows, the skinny GeGLU kernel on <= 64 rows (a short prompt,
 // or the remainder of a long one)
+// (rows the skinny GeGLU kernel takes ahead of an applicable LDS-DMA grid: from two 16-row groups on it re-reads X per 16 W rows and streams fc_gate_up at 1.2-2 TB/s,
+// the one-round tile grid at 4.7 -- bf16-policy prefill of 64 tokens 9.1 ms against 8.0 for 100)
+int g_geglu_skinny_rows = 16;      // tuning: mila_cdna4_tune_gemm(300 + n)
 static bool geglu_rows_applicable(int M, int K, int F)
 {
+    // where the plain GEMM over the [2F, K] weight would split K given a workspace, the fused form steps aside: the caller's Linear (gemm_bf16_ws) + GeGLU pair is the
+    // faster one there, and fused and unfused prefill keep identical bits (the fused kernels sum K in one order only)
+    if (bf16_ws_plan(M, K, 2 * F).S) return false;
     if (gemm256_geglu_applicable(M, K, F)) return true;
     if (!g_bf16_skinny) return false;
-    if (M <= kBf16SkinnyRows) return true;
+    // few rows: the skinny GeGLU kernel -- past one 16-row group only where the plain Linear over [2F, K] has no LDS-DMA grid either (with one, Linear + GeGLU as two
+    // launches is the faster pair: fc_gate_up at 64 rows 196 us skinny, ~55 as a one-round tile grid + the elementwise pass)
+    if (M <= kBf16SkinnyRows) return M <= g_geglu_skinny_rows || !glds_kernel_for(M, K, 2 * F);
     const int tail = M % 256;
     return M >= 512 && tail > 0 && tail <= kBf16SkinnyRows && gemm256_geglu_applicable(M - tail, K, F);
 }
 static int launch_geglu_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s)
 {
     const int tail = M % 256;
-    if (g_bf16_skinny && M <= kBf16SkinnyRows) return launch_gemm_bf16_skinny_geglu(Y, X, W, M, K, F, s);
-    if (g_bf16_skinny && M >= 512 && tail > 0 && tail <= kBf16SkinnyRows && gemm256_geglu_applicable(M - tail, K, F))
+    const bool whole = gemm256_geglu_applicable(M, K, F);
+    if (g_bf16_skinny && M <= kBf16SkinnyRows && (M <= g_geglu_skinny_rows || !whole)) return launch_gemm_bf16_skinny_geglu(Y, X, W, M, K, F, s);
+    if (g_bf16_skinny && M >= 512 && tail > 0 && tail <= kBf16SkinnyRows && (tail <= g_geglu_skinny_rows || !whole) && gemm256_geglu_applicable(M - tail, K, F))
     {
         int rc = launch_gemm256_geglu(Y, X, W, M - tail, K, F, s);
         if (rc) return rc;
@@ -504,6 +513,7 @@ int mila_cdna4_tune_gemm(int force_128_tile)
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
     if (force_128_tile == 3 || force_128_tile == 4) { g_bf16_skinny = force_128_tile == 4; return MILA_OK; }
     if (force_128_tile == 5 || force_128_tile == 6) { g_gemm_splitk = force_128_tile == 6; return MILA_OK; }      // the split-K form of gemm_bf16_ws off / on
+    if (force_128_tile >= 300) { g_geglu_skinny_rows = force_128_tile - 300; return MILA_OK; }      // 316 = default
     if (force_128_tile >= 200) { g_splitk_min_rows = force_128_tile - 200; return MILA_OK; }      // 217 = default
     if (force_128_tile >= 100) { g_ldsdma_loose_tiles = force_128_tile - 100; return MILA_OK; }      // 100 = the fill rule only; 130 = default
     g_gemm_force128 = force_128_tile == 1;
@@ -596,13 +606,17 @@ int mila_cdna4_dequantize_to_bf16(uint16_t* out, const void* W, const float* sca
     return launch_dequant(fmt, out, static_cast<const uint8_t*>(W), scales, N, K, group, as_stream(stream));
 }
 
+// the staged forms' scratch: the dequantized [N, K] bf16 weights, then (16-byte aligned: K % 8 == 0) the split-K workspace of the bf16 GEMM over them -- the staged call
+// and gemm_bf16_ws on weights dequantized ahead of time (the host's resident prefill weights) then run the same kernels and give the same bits
 size_t mila_cdna4_gemm_staging_bytes(int M, int K, int N)
 {
+    if (M <= 0 || K <= 0 || N <= 0 || K % 8 != 0) return 0;
     int which;
-    if (glds_rows_for(M, K, N, &which)) return (size_t)N * K * 2;
+    const size_t ws = bf16_ws_bytes(M, K, N);
+    if (ws || glds_rows_for(M, K, N, &which)) return (size_t)N * K * 2 + ws;
     // few rows: the staged forms dequantize once and stream the bf16 weights through the skinny kernel (the in-register-dequantizing 128-tile kernel pushed the fp8
     // policy's weights past a 16-row prompt at 1 TB/s)
-    return (!g_gemm_force128 && g_bf16_skinny && M > 1 && M <= kBf16SkinnyRows && K % 8 == 0) ? (size_t)N * K * 2 : 0;
+    return (!g_gemm_force128 && g_bf16_skinny && M > 1 && M <= kBf16SkinnyRows) ? (size_t)N * K * 2 : 0;
 }
 
 int mila_cdna4_gemm_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W, const float* scales, const uint16_t* bias,
@@ -615,9 +629,10 @@ int mila_cdna4_gemm_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, const uint
     MILA_REQUIRE(scales != nullptr, "gemm_bf16_w8a16_staged: per-channel scales are required");
     if (!scratch || scratch_bytes < need)
         return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_bf16_w8a16_staged: scratch %zu bytes < required %zu", scratch_bytes, need);
+    MILA_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 15) == 0, "gemm_bf16_w8a16_staged: the scratch must be 16-byte aligned");
     rc = launch_dequant(1, reinterpret_cast<uint16_t*>(scratch), W, scales, N, K, 0, as_stream(stream));
     if (rc) return rc;
-    return launch_bf16_rows(Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream));
+    return launch_bf16_rows_ws(Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream), 0, static_cast<unsigned char*>(scratch) + (size_t)N * K * 2);
 }
 
 int mila_cdna4_gemm_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed, const float* scales,
@@ -633,9 +648,10 @@ int mila_cdna4_gemm_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, const uint
     MILA_REQUIRE(K % group == 0, "gemm_bf16_w4a16_staged: K=%d must be a multiple of the group size %d", K, group);
     if (!scratch || scratch_bytes < need)
         return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_bf16_w4a16_staged: scratch %zu bytes < required %zu", scratch_bytes, need);
+    MILA_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 15) == 0, "gemm_bf16_w4a16_staged: the scratch must be 16-byte aligned");
     rc = launch_dequant(2, reinterpret_cast<uint16_t*>(scratch), W_packed, scales, N, K, group, as_stream(stream));
     if (rc) return rc;
-    return launch_bf16_rows(Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream));
+    return launch_bf16_rows_ws(Y, X, reinterpret_cast<const uint16_t*>(scratch), bias, M, K, N, as_stream(stream), 0, static_cast<unsigned char*>(scratch) + (size_t)N * K * 2);
 }
 
 /* ---- Linear + GeGLU in one kernel (prefill fc_gate_up): Y[M, F] = GeGLU(X W^T), W = [gate | up] rows ---- */

@@ -641,7 +641,18 @@ namespace Mila::Dnn
         {
             if constexpr ( kFmt == 2 ) return false;       // the W4A8 path quantizes activations into per-op scratch sized for one call at a time
             if constexpr ( kFmt == 1 ) { for ( auto& L : layers_ ) if ( !L.fc_down->getOperation().residentBf16() ) return false; }
-            return T >= 1024 && T % 512 == 0;
+            if ( !( T >= 1024 && T % 512 == 0 ) ) return false;
+            // ... and so does a GEMM that splits K through the context's workspace (short tile lists: the same idle CUs this form is after); the split also depends on
+            // the row count, so the halves would not carry the whole chunk's bits
+            for ( auto& L : layers_ )
+            {
+                const Compute::LinearOpConfig* cfgs[ 4 ] = { &L.qkv_proj->getOperation().config(), &L.o_proj->getOperation().config(), &L.fc_gate_up->getOperation().config(),
+                                                             &L.fc_down->getOperation().config() };
+                for ( const auto* c : cfgs )
+                    for ( dim_t rows : { T, T / 2 } )
+                        if ( mila_cdna4_gemm_workspace_bytes( static_cast<int>( rows ), static_cast<int>( c->in_features ), static_cast<int>( c->out_features ) ) != 0 ) return false;
+            }
+            return true;
         }
         void halfBlock( Layer& L, int h, bool first_layer, Layer* nextL, int H, int position_offset, int flip, hipEvent_t kv_ready, bool wait_kv )
         {

@@ -426,18 +426,21 @@ def test_split_decode_attention_gives_the_reference_order_bits(policy):
 
 @pytest.mark.parametrize("cfg_name", ["SMALL", "MEDIUM"])
 def test_chunked_prefill_equals_single_chunk_prefill(cfg_name):
-    """a prompt fed as two chunks (the second at position_offset = 16) leaves the same KV caches and produces the same logits as
-    one chunk: every row's arithmetic is independent of the chunk it arrives in (reference-order glue for SMALL, fused glue for MEDIUM)"""
+    """a prompt fed as two chunks (the second at position_offset = 10) leaves the same KV caches and produces the same logits as
+    one chunk: every row's arithmetic is independent of the chunk it arrives in (reference-order glue for SMALL, fused glue for MEDIUM).
+    Bit-for-bit this holds while every chunk stays with one GEMM form -- here the few-row weight stream (<= 16 rows); a longer chunk sums K in
+    another order (tile kernels, split-K), and chunkings that cross forms agree to the last bf16 bit only (tests/test_reference_scenarios_gpu.py holds
+    the 22.5K-token chunked prefill against the oracle)"""
     cfg = {"SMALL": SMALL, "MEDIUM": MEDIUM}[cfg_name]
     V = cfg["vocab_size"]
-    toks = [(17 * i + 4) % V for i in range(24)]
+    toks = [(17 * i + 4) % V for i in range(16)]
     a = host.Gemma("bf16", cfg, max_seq=MAX_SEQ, max_prefill=32, seed=13)
     b = host.Gemma("bf16", cfg, max_seq=MAX_SEQ, max_prefill=32, seed=13)
     la = a.prefill(toks)
-    b.prefill(toks[:16])
-    lb = b.prefill(toks[16:], position_offset=16)
+    b.prefill(toks[:10])
+    lb = b.prefill(toks[10:], position_offset=10)
     assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), "last-position logits differ"
-    da, db = a.decode(3, 24, "fused"), b.decode(3, 24, "fused")
+    da, db = a.decode(3, 16, "fused"), b.decode(3, 16, "fused")
     assert np.array_equal(da.view(np.uint32), db.view(np.uint32)), "the caches differ"
     a.close()
     b.close()
@@ -469,14 +472,21 @@ def test_the_block_is_the_references_graph():
 @pytest.mark.parametrize("policy", ["bf16", "fp8"])
 def test_two_stream_half_chunk_prefill_gives_the_same_bits(policy):
     """setPrefillOverlap: the chunk's halves on two streams, the second half's attention behind an event on the first half's K / V rows: same kernels on
-    the same rows, so the logits and everything decoded afterwards are bit-identical"""
+    the same rows, so the logits and everything decoded afterwards are bit-identical.  The form steps aside where a GEMM would split K through the context's
+    workspace (one call at a time, and a split that depends on the row count) -- this small model's 1280-wide projections do, so the split-K form is
+    switched off for the comparison (with it on, both models run the one-stream path)"""
     cfg = dict(vocab_size=2048, embedding_dim=1280, num_layers=6, num_heads=8, num_kv_heads=4, head_dim=64, hidden_dim=2560,
                global_head_dim=128, num_global_kv_heads=1, window=256, sliding_window_pattern=3, global_rotary_dim=32)
     T = 1024
     toks = (np.arange(T, dtype=np.int64) * 7919 % 2048).astype(np.int32)
+    from mila_amd import capi
+    lib = capi.load()
+    assert lib.mila_cdna4_gemm_workspace_bytes(512, 1280, 1280) > 0
     a = host.Gemma(policy, cfg, max_seq=T + 8, max_prefill=T, seed=3)
     b = host.Gemma(policy, cfg, max_seq=T + 8, max_prefill=T, seed=3)
+    capi.check(lib.mila_cdna4_tune_gemm(5))
     try:
+        assert lib.mila_cdna4_gemm_workspace_bytes(512, 1280, 1280) == 0
         b.set_prefill_overlap(True)
         la, lb = a.prefill(toks), b.prefill(toks)
         assert np.array_equal(la, lb)
@@ -486,6 +496,7 @@ def test_two_stream_half_chunk_prefill_gives_the_same_bits(policy):
             assert np.array_equal(da, db)
             ta, tb = int(np.argmax(da)), int(np.argmax(db))
     finally:
+        capi.check(lib.mila_cdna4_tune_gemm(6))
         a.close()
         b.close()
 
