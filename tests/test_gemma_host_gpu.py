@@ -428,8 +428,8 @@ def test_split_decode_attention_gives_the_reference_order_bits(policy):
 def test_chunked_prefill_equals_single_chunk_prefill(cfg_name):
     """a prompt fed as two chunks (the second at position_offset = 10) leaves the same KV caches and produces the same logits as
     one chunk: every row's arithmetic is independent of the chunk it arrives in (reference-order glue for SMALL, fused glue for MEDIUM).
-    Bit-for-bit this holds while every chunk stays with one GEMM form -- here the few-row weight stream (<= 16 rows); a longer chunk sums K in
-    another order (tile kernels, split-K), and chunkings that cross forms agree to the last bf16 bit only (tests/test_reference_scenarios_gpu.py holds
+    Bit-for-bit this holds while every chunk stays with one GEMM form -- here at most one tile-row each (the same split of K whatever the row count); a chunk of
+    another tile count sums K in another order, and chunkings that cross forms agree to the last bf16 bit only (tests/test_reference_scenarios_gpu.py holds
     the 22.5K-token chunked prefill against the oracle)"""
     cfg = {"SMALL": SMALL, "MEDIUM": MEDIUM}[cfg_name]
     V = cfg["vocab_size"]
