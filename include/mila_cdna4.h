@@ -173,6 +173,12 @@ MILA_API int mila_cdna4_gemm_geglu_bf16_w4a8(uint16_t* Y, const uint16_t* X, con
  * quantize_fp8_per_token per forward). */
 MILA_API int mila_cdna4_dequantize_to_bf16(uint16_t* out, const void* W, const float* scales, int fmt, int N, int K, int group,
                                            mila_stream_t stream);
+/* gemm_fp8_scaled with a caller workspace (see gemm_bf16_ws: the cuBLASLt workspace of CudaLinearOp.ixx:637-638, :706-707): short prompts and long-prompt remainders
+ * split K through it.  gemm_fp8_workspace_bytes() = what (M, K, N) needs (0: the call is gemm_fp8_scaled); gemm_w4a8_scratch_bytes() includes it for gemm_bf16_w4a8,
+ * which therefore gives the same bits. */
+MILA_API size_t mila_cdna4_gemm_fp8_workspace_bytes(int M, int K, int N);
+MILA_API int mila_cdna4_gemm_fp8_scaled_ws(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* token_scales, const float* weight_scale, const uint16_t* bias,
+                                           int M, int K, int N, void* workspace, size_t workspace_bytes, mila_stream_t stream);
 MILA_API int mila_cdna4_gemm_geglu_fp8_scaled(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* token_scales,
                                               const float* weight_scale, int M, int K, int F, mila_stream_t stream);
 

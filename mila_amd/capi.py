@@ -74,6 +74,7 @@ def load():
     main.mila_cdna4_attn_decode_scratch_bytes.restype = C.c_size_t
     main.mila_cdna4_gemm_staging_bytes.restype = C.c_size_t
     main.mila_cdna4_gemm_workspace_bytes.restype = C.c_size_t
+    main.mila_cdna4_gemm_fp8_workspace_bytes.restype = C.c_size_t
     main.mila_cdna4_sample_scratch_bytes.restype = C.c_size_t
     main.mila_cdna4_gemm_w4a8_scratch_bytes.restype = C.c_size_t
     main.mila_cdna4_sample_stochastic_scratch_bytes.restype = C.c_size_t
@@ -148,7 +149,7 @@ EXPORTED = [
     "memcpy_h2d", "memcpy_d2h", "memcpy_d2d", "memset_zero",
     "matvec_bf16", "matvec_bf16_qfp8", "matvec_bf16_qfp4", "matvec_f32out",
     "gemm_bf16", "gemm_gelu_bf16", "gemm_workspace_bytes", "gemm_bf16_ws", "gemm_bf16_w8a16", "gemm_bf16_w4a16", "gemm_staging_bytes", "gemm_bf16_w8a16_staged", "gemm_bf16_w4a16_staged",
-    "fp4_weight_fp8_scale", "upcast_fp4_to_fp8", "quantize_fp8_per_token", "gemm_fp8_applicable", "gemm_fp8_scaled",
+    "fp4_weight_fp8_scale", "upcast_fp4_to_fp8", "quantize_fp8_per_token", "gemm_fp8_applicable", "gemm_fp8_scaled", "gemm_fp8_workspace_bytes", "gemm_fp8_scaled_ws",
     "gemm_w4a8_scratch_bytes", "gemm_bf16_w4a8", "gemm_geglu_w4a8_applicable", "gemm_geglu_bf16_w4a8",
     "gemm_geglu_applicable", "gemm_geglu_bf16", "gemm_geglu_bf16_w8a16_staged", "gemm_geglu_bf16_w4a16_staged",
     "quantize_fp8_per_channel", "quantize_fp4_per_group",

@@ -293,6 +293,7 @@ extern int g_skinny_whole_x;
 extern int g_fp8_big_rule;           // gemm256.hip
 extern int g_ldsdma_loose_tiles;     // gemm256.hip
 extern int g_gemm_splitk;            // gemm256.hip
+extern int g_fp8_splitk_min_rows;    // gemm256.hip
 int gemm_splitk_for(int M, int K, int N);
 int launch_gemm256x128_splitk(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act, float* partials, int S);
 // Few rows (tools/experiments/few_row_rules.sh, profiles/r03_splitk.txt): bf16-policy prefill of 2 / 4 / 8 / 16 tokens with the skinny kernels ahead of the tile grids up
@@ -541,6 +542,7 @@ int mila_cdna4_tune_gemm_fp8_tail_only(int on)
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
     if (on == 3) { g_skinny_whole_x = 0; return MILA_OK; }      // 3: the skinny kernel's barrier-free <= 4-row form off (4 turns it back on); the other settings stay
     if (on == 4) { g_skinny_whole_x = 1; return MILA_OK; }
+    if (on >= 100) { g_fp8_splitk_min_rows = on - 100; return MILA_OK; }      // 133 = default: fewer rows stay off the fp8 split-K form
     if (on >= 5 && on <= 8) { g_fp8_big_rule = on - 5; return MILA_OK; }      // 5 / 6 / 7: which row counts below 512 take the LDS-DMA kernels (gemm256.hip: g_fp8_big_rule 0 / 1 / 2)
     g_gemm_fp8_tail_only = on != 0;      // 1: every row on the masked 128-row LDS tiles (bit-identical to the LDS-DMA kernels); 2: every row as skinny pieces
     g_gemm_fp8_tail_form = (on == 1 || on == 2) ? on : 0;

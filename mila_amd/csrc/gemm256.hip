@@ -676,12 +676,12 @@ constexpr bool kRingGlobalLoads = MILA_RING_GLOBAL_LOADS;      // how the 256 x 
 // restages it behind B(t - 1) = group 1's A(t - 1).
 // WALK: the persistent tile walk is compiled in (one workgroup per CU); without it the kernel is the one-tile form, whose K loop carries none of the walk's selects
 // (the walk's bookkeeping in the K loop -- next-tile offsets, the flat ring index -- cost the one-round shapes 15 %: o_proj + fc_down 130 -> 152 us average)
-// SPLITK (plain bf16, one-tile form): the grid is p.splitk copies of the tile list; copy ks takes K-tiles [ks nk / S, (ks + 1) nk / S) of its tile and writes its fp32
+// SPLITK (plain one-tile forms, bf16 and fp8): the grid is p.splitk copies of the tile list; copy ks takes K-tiles [ks nk / S, (ks + 1) nk / S) of its tile and writes its fp32
 // accumulators to p.partials[ks] -- few-row prompts and remainders, whose tile list covers a fraction of the CUs, then spread each tile's K over the idle ones
 template <bool FP8, bool GEGLU, int PP, bool WALK, bool SPLITK = false>      // PP: 0 lockstep, 1 staggered groups, 2 staggered with a static priority for waves 4-7
 __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
 {
-    static_assert(!SPLITK || (!FP8 && !GEGLU && !WALK), "split-K: the plain bf16 one-tile form");
+    static_assert(!SPLITK || (!GEGLU && !WALK), "split-K: the plain one-tile forms (bf16, fp8)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int ES = FP8 ? 1 : 2;
     constexpr int KT = 128 / ES;
@@ -1094,6 +1094,7 @@ bool gemm256x128_ragged_n_applicable(int M, int K, int N)
 
 extern int g_gemm_pingpong;
 extern int g_gemm_persistent;
+extern int g_gemm_fp8_tail_only;
 
 template <bool FP8, bool GEGLU, int PP>
 static int launch_gemm256x128_tt(const Gemm256Params& p, hipStream_t s)
@@ -1184,6 +1185,58 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(uint16_t* __restrict
         for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(round_bf16(v[e]));
     }
     st16(Y + i, u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
+}
+
+// the W4A8 form: y = bf16(float(bf16(sum * *w_scale)) * x_scales[m] + bias), the epilogue of the fp8 kernels (common.h: w4a8_scale_bias)
+__global__ __launch_bounds__(256) void splitk_reduce_fp8_kernel(uint16_t* __restrict__ Y, const float* __restrict__ P, const uint16_t* __restrict__ bias,
+                                                                const float* __restrict__ x_scales, const float* __restrict__ w_scale, int64_t MN, int N, int S)
+{
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= MN) return;
+    f32x4 a = *reinterpret_cast<const f32x4*>(P + i), b = *reinterpret_cast<const f32x4*>(P + i + 4);
+    for (int s_ = 1; s_ < S; ++s_)
+    {
+        a += *reinterpret_cast<const f32x4*>(P + (size_t)s_ * MN + i);
+        b += *reinterpret_cast<const f32x4*>(P + (size_t)s_ * MN + i + 4);
+    }
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+    const float ws = *w_scale, ts = x_scales[m];
+    u32x4 bb = {0u, 0u, 0u, 0u};
+    if (bias) bb = *reinterpret_cast<const u32x4*>(bias + n);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = w4a8_scale_bias(v[e], ws, ts, bias != nullptr, bf16_bits_to_f32((uint16_t)(bb[e >> 1] >> ((e & 1) * 16))));
+    st16(Y + i, u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
+}
+
+int gemm_fp8_splitk_for(int M, int K, int N)      // S (>= 2), or 0: the fp8 (W4A8) 256 x 128 ring has no split-K form for this shape
+{
+    if (!g_gemm_splitk || g_gemm_pingpong != 5 || g_gemm_fp8_tail_only) return 0;
+    if (M <= 0 || N % 128 != 0 || K % 128 != 0 || !lds_dma_addressable(M, K, N)) return 0;
+    const int tiles = ((M + 255) / 256) * (N / 128), nk = K / 128;
+    if (tiles > kNumCU / 2) return 0;
+    const int S = min(min(kNumCU / tiles, nk / 8), 16);
+    return S >= 2 ? S : 0;
+}
+
+static int launch_gemm256x128_fp8_splitk(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias, int M, int K, int N,
+                                         hipStream_t s, float* partials, int S)
+{
+    static bool attr_set = false;
+    if (!attr_set)
+    {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256x128_kernel<true, false, 2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               3 * kStage3Bytes), "hipFuncSetAttribute(gemm256x128 fp8 split-K)");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    Gemm256Params p{nullptr, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, M, K, N, (M + 255) / 256, N / 128, nullptr, nullptr, 0, 0, partials, S};
+    hipLaunchKernelGGL((gemm256x128_kernel<true, false, 2, false, true>), dim3(p.tiles_m * p.tiles_n * S), dim3(512), 3 * kStage3Bytes, s, p);
+    int rc = check_hip(hipGetLastError(), "gemm256x128 (fp8 split-K)");
+    if (rc) return rc;
+    const int64_t MN = (int64_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_fp8_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, Y, partials, bias, x_scales, w_scale, MN, N, S);
+    return check_hip(hipGetLastError(), "splitk_reduce_fp8");
 }
 
 int launch_gemm256x128_splitk(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act, float* partials, int S)
@@ -1302,6 +1355,10 @@ int g_gemm_fp8_tail_only = 0;      // tuning hook (mila_cdna4_tune_gemm_fp8_tail
 //   everything else: the tail kernels of gemm_fp8_tail.hip alone.
 // Rows are independent and the LDS-DMA kernels and the masked tiles run the same instruction chain per output element.
 constexpr int kSkinnyTailRows = 64;
+// Few rows (tools/experiments/few_row_rules_fp4.sh, profiles/r03_splitk.txt): up to two 16-row groups the skinny kernel -- a weight stream of one byte per weight -- is the
+// fastest form (fp4-policy prefill of 16 / 32 tokens 4.90 / 5.70 ms, against 5.28 / 5.89 with o_proj and fc_down split over K); from 33 rows on the tile grids
+// (>= 120 tiles) and the split-K form are (64 tokens: 7.15 ms skinny)
+int g_fp8_splitk_min_rows = 33;      // tuning (mila_cdna4_tune_gemm_fp8_tail_only(100 + n)): fewer rows stay with the skinny kernel
 int g_fp8_big_rule = 3;      // tuning (mila_cdna4_tune_gemm_fp8_tail_only 5 .. 8 = rule 0 .. 3): 0 = LDS-DMA kernels from 512 rows on (round 3's first rule), 1 = from 128 rows on,
                              // 2 = from 512 rows on or wherever ceil(M / 256) x (W rows / 128) >= 120 tiles, 3 (default) = 2 without the skinny split of a short prompt's remainder
 static int fp8_big_rows(int M, int K, int N_mult, int w_rows)      // rows the LDS-DMA kernels take (0 = none); N_mult: the column granularity the form needs (128, or 64 for 256 x 128 GeGLU)
@@ -1310,7 +1367,7 @@ static int fp8_big_rows(int M, int K, int N_mult, int w_rows)      // rows the L
     if (g_gemm_fp8_tail_only || K % 128 != 0 || N_mult == 0) return 0;
     // below two full tile-rows the LDS-DMA kernels pay only where their grid still covers the chip (g_fp8_big_rule: see mila_cdna4_tune_gemm_fp8_tail_only)
     const int tiles = ((M + 255) / 256) * (w_rows / 128);
-    const bool big = g_fp8_big_rule == 1 ? M >= 128 : (g_fp8_big_rule >= 2 ? (M >= 512 || (M > kSkinnyTailRows && tiles >= 120)) : M >= 512);
+    const bool big = g_fp8_big_rule == 1 ? M >= 128 : (g_fp8_big_rule >= 2 ? (M >= 512 || (M >= g_fp8_splitk_min_rows && tiles >= 120)) : M >= 512);
     if (!big) return 0;
     if (g_fp8_big_rule == 3 && M < 512) return M;        // a short prompt's <= 64-row remainder stays in the ragged tile-row: a skinny pass re-streams every weight, which only a long main part amortises
     const int tail = M % 256;
@@ -1361,5 +1418,44 @@ int launch_gemm_fp8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const flo
     }
     return launch_gemm_fp8_tail(Y + (size_t)rows * N, X8 + (size_t)rows * K, W8, x_scales + rows, w_scale, bias, M - rows, K, N, s);
 }
+
+
+// ---- the same with a caller workspace (mila_cdna4_gemm_fp8_scaled_ws; mirrors gemm.hip's bf16_ws_plan): a short prompt whose tile list covers at most half the CUs
+// splits K whole; a long prompt's remainder whose ragged tile-row would open another round of the grid (T = 2303 on the N = 3840 shapes) splits K alone ----
+struct Fp8WsPlan { int main_rows, S; };
+static Fp8WsPlan fp8_ws_plan(int M, int K, int N)
+{
+    if (M < g_fp8_splitk_min_rows) return {M, 0};
+    int S = gemm_fp8_splitk_for(M, K, N);
+    if (S) return {0, S};
+    const int tail = M % 256, main_rows = M - tail;
+    if (M < 512 || tail < g_fp8_splitk_min_rows) return {M, 0};
+    if (fp8_big_rows(main_rows, K, N % 128 == 0 ? 128 : 0, N) != main_rows) return {M, 0};
+    const int per_row = fp8_pick(main_rows, N) == 2 ? N / 256 : N / 128, tm = main_rows / 256;
+    const bool new_round = (tm * per_row + kNumCU - 1) / kNumCU < ((tm + 1) * per_row + kNumCU - 1) / kNumCU;
+    if (!new_round) return {M, 0};
+    S = gemm_fp8_splitk_for(tail, K, N);
+    return S ? Fp8WsPlan{main_rows, S} : Fp8WsPlan{M, 0};
+}
+size_t gemm_fp8_ws_bytes(int M, int K, int N)
+{
+    const Fp8WsPlan pl = fp8_ws_plan(M, K, N);
+    return pl.S ? (size_t)pl.S * (M - pl.main_rows) * N * sizeof(float) : 0;
+}
+int launch_gemm_fp8_ws(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias, int M, int K, int N, hipStream_t s,
+                       void* ws)
+{
+    const Fp8WsPlan pl = fp8_ws_plan(M, K, N);
+    if (!pl.S) return launch_gemm_fp8(Y, X8, W8, x_scales, w_scale, bias, M, K, N, s);
+    if (pl.main_rows > 0)
+    {
+        int rc = launch_gemm_fp8(Y, X8, W8, x_scales, w_scale, bias, pl.main_rows, K, N, s);
+        if (rc) return rc;
+    }
+    return launch_gemm256x128_fp8_splitk(Y + (size_t)pl.main_rows * N, X8 + (size_t)pl.main_rows * K, W8, x_scales + pl.main_rows, w_scale, bias, M - pl.main_rows, K, N, s,
+                                         static_cast<float*>(ws), pl.S);
+}
+// the fused GeGLU form steps aside where the plain GEMM over [2F, K] would split K (same reason as gemm.hip's geglu_rows_applicable)
+bool gemm_fp8_geglu_steps_aside(int M, int K, int F) { return fp8_ws_plan(M, K, 2 * F).S != 0; }
 
 }  // namespace mila

@@ -245,6 +245,11 @@ int launch_gemm_fp8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const flo
 bool gemm256_geglu_applicable(int M, int K, int F);
 int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
                           hipStream_t s);
+// gemm256.hip: the split-K forms behind a caller workspace
+size_t gemm_fp8_ws_bytes(int M, int K, int N);
+int launch_gemm_fp8_ws(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias, int M, int K, int N, hipStream_t s,
+                       void* ws);
+bool gemm_fp8_geglu_steps_aside(int M, int K, int F);
 
 }  // namespace mila
 
@@ -326,11 +331,33 @@ int mila_cdna4_gemm_fp8_scaled(uint16_t* Y, const uint8_t* X8, const uint8_t* W8
     return launch_gemm_fp8(Y, X8, W8, x_scales, weight_scale, bias, M, K, N, as_stream(stream));
 }
 
+size_t mila_cdna4_gemm_fp8_workspace_bytes(int M, int K, int N)
+{
+    return (M > 0 && K > 0 && N > 0 && K % 16 == 0) ? gemm_fp8_ws_bytes(M, K, N) : 0;
+}
+
+int mila_cdna4_gemm_fp8_scaled_ws(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* weight_scale, const uint16_t* bias, int M, int K, int N,
+                                  void* workspace, size_t workspace_bytes, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X8 && W8 && x_scales && weight_scale, "gemm_fp8_scaled_ws: null pointer");
+    MILA_REQUIRE(mila_cdna4_gemm_fp8_applicable(M, K, N), "gemm_fp8_scaled_ws: shape (M=%d, K=%d, N=%d) has no fp8 MFMA kernel (ask gemm_fp8_applicable)", M, K, N);
+    const size_t need = gemm_fp8_ws_bytes(M, K, N);
+    if (need && (!workspace || workspace_bytes < need))
+        return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_fp8_scaled_ws: workspace %zu bytes < required %zu (ask gemm_fp8_workspace_bytes)", workspace_bytes, need);
+    MILA_REQUIRE(!need || (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "gemm_fp8_scaled_ws: the workspace must be 16-byte aligned");
+    return launch_gemm_fp8_ws(Y, X8, W8, x_scales, weight_scale, bias, M, K, N, as_stream(stream), workspace);
+}
+
+// [e4m3 weights | e4m3 activations | per-token scales | split-K workspace], each part 16-byte aligned
+static size_t w4a8_ws_offset(int M, int K, int N)
+{
+    const size_t w = ((size_t)N * K + 15) & ~(size_t)15, x = ((size_t)M * K + 15) & ~(size_t)15, t = ((size_t)M * 4 + 15) & ~(size_t)15;
+    return w + x + t;
+}
 size_t mila_cdna4_gemm_w4a8_scratch_bytes(int M, int K, int N)
 {
     if (M <= 0 || K <= 0 || N <= 0) return 0;
-    const size_t w = ((size_t)N * K + 15) & ~(size_t)15, x = ((size_t)M * K + 15) & ~(size_t)15;
-    return w + x + (size_t)M * 4;
+    return w4a8_ws_offset(M, K, N) + (K % 16 == 0 ? gemm_fp8_ws_bytes(M, K, N) : 0);
 }
 
 int mila_cdna4_gemm_bf16_w4a8(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed, const float* scales, const float* weight_fp8_scale,
@@ -347,10 +374,12 @@ int mila_cdna4_gemm_bf16_w4a8(uint16_t* Y, const uint16_t* X, const uint8_t* W_p
     if (rc) return rc;
     rc = mila_cdna4_quantize_fp8_per_token(x8, ts, X, M, K, stream);
     if (rc) return rc;
-    return launch_gemm_fp8(Y, x8, w8, ts, weight_fp8_scale, bias, M, K, N, as_stream(stream));
+    MILA_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 15) == 0, "gemm_bf16_w4a8: the scratch must be 16-byte aligned");
+    return launch_gemm_fp8_ws(Y, x8, w8, ts, weight_fp8_scale, bias, M, K, N, as_stream(stream), w8 + w4a8_ws_offset(M, K, N));
 }
 
-int mila_cdna4_gemm_geglu_w4a8_applicable(int M, int K, int F) { return (M > 0 && K > 0 && F > 0 && K % 16 == 0) ? 1 : 0; }
+// (0 also where the plain W4A8 GEMM over [2F, K] would split K given a workspace: Linear + GeGLU as two calls is the faster pair there and keeps the bits of the unfused path)
+int mila_cdna4_gemm_geglu_w4a8_applicable(int M, int K, int F) { return (M > 0 && K > 0 && F > 0 && K % 16 == 0 && !gemm_fp8_geglu_steps_aside(M, K, F)) ? 1 : 0; }
 
 int mila_cdna4_gemm_geglu_fp8_scaled(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* weight_scale, int M, int K, int F,
                                      mila_stream_t stream)

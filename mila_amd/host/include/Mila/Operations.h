@@ -141,10 +141,11 @@ namespace Mila::Dnn::Compute
                         // prefill for this policy (kUseFp8ActivationPrefillPath, CudaLinearOp.ixx:646-715), when an fp8 kernel serves the shape
                         if ( use_fp8_activation_prefill_ && weight_fp8_scale_ && resident_e4m3_ && mila_cdna4_gemm_fp8_applicable( M, K, N ) )
                         {
-                            uint8_t* x8; float* ts;
-                            activationScratch( M, K, x8, ts );
+                            uint8_t* x8; float* ts; void* ws;
+                            const size_t ws_bytes = mila_cdna4_gemm_fp8_workspace_bytes( M, K, N );
+                            activationScratch( M, K, x8, ts, ws_bytes, &ws );
                             rocmCheck( mila_cdna4_quantize_fp8_per_token( x8, ts, x, M, K, st ) );
-                            rocmCheck( mila_cdna4_gemm_fp8_scaled( y, x8, resident_e4m3_->data(), ts, weight_fp8_scale_->data(), bias_, M, K, N, st ) );
+                            rocmCheck( mila_cdna4_gemm_fp8_scaled_ws( y, x8, resident_e4m3_->data(), ts, weight_fp8_scale_->data(), bias_, M, K, N, ws, ws_bytes, st ) );
                             return;
                         }
                         if ( use_fp8_activation_prefill_ && weight_fp8_scale_ && mila_cdna4_gemm_fp8_applicable( M, K, N ) )
@@ -241,18 +242,22 @@ namespace Mila::Dnn::Compute
         }
         /// the W4A8 forward on activations the caller quantized (x8 [M, K] e4m3, ts [M] per-token scales -- exactly what quantize_fp8_per_token gives): the same
         /// GEMM call forward() makes, so the output carries the same bits
+        /// (x8 / ts are the caller's own buffers, NOT context scratch: the GEMM's split-K workspace is taken from there)
         void forwardFp8Activations( const uint8_t* x8, const float* ts, uint16_t* y, int M )
         {
             if ( !acceptsFp8Activations( M ) ) throw std::logic_error( "RocmLinearOp::forwardFp8Activations: the W4A8 path does not serve this call" );
-            rocmCheck( mila_cdna4_gemm_fp8_scaled( y, x8, resident_e4m3_->data(), ts, weight_fp8_scale_->data(), bias_, M, (int)cfg_.in_features, (int)cfg_.out_features,
-                                                   this->context_->getStream() ) );
+            const int K = (int)cfg_.in_features, N = (int)cfg_.out_features;
+            const size_t ws_bytes = mila_cdna4_gemm_fp8_workspace_bytes( M, K, N );
+            void* ws = ws_bytes ? this->context_->getScratch( ws_bytes ) : nullptr;
+            rocmCheck( mila_cdna4_gemm_fp8_scaled_ws( y, x8, resident_e4m3_->data(), ts, weight_fp8_scale_->data(), bias_, M, K, N, ws, ws_bytes, this->context_->getStream() ) );
         }
-        /// scratch for the per-token e4m3 activations + their scales (fetched per forward, never cached)
-        void activationScratch( int M, int K, uint8_t*& x8, float*& ts ) const
+        /// scratch for the per-token e4m3 activations + their scales (+ `extra` bytes behind them, 16-byte aligned: the GEMM's workspace) -- fetched per forward, never cached
+        void activationScratch( int M, int K, uint8_t*& x8, float*& ts, size_t extra = 0, void** extra_out = nullptr ) const
         {
-            const size_t xb = ( (size_t)M * K + 15 ) & ~(size_t)15;
-            auto* base = static_cast<uint8_t*>( this->context_->getScratch( xb + (size_t)M * 4 ) );
+            const size_t xb = ( (size_t)M * K + 15 ) & ~(size_t)15, tb = ( (size_t)M * 4 + 15 ) & ~(size_t)15;
+            auto* base = static_cast<uint8_t*>( this->context_->getScratch( xb + tb + extra ) );
             x8 = base; ts = reinterpret_cast<float*>( base + xb );
+            if ( extra_out ) *extra_out = extra ? base + xb + tb : nullptr;
         }
         /// fp4 policy: W4A8 prefill (default on, as in the reference) or the dequantize -> bf16 GEMM fallback
         void setFp8ActivationPrefill( bool on ) noexcept { use_fp8_activation_prefill_ = on; }

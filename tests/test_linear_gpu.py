@@ -582,11 +582,11 @@ def test_w4a8_serves_every_row_count_like_the_reference(M, K, N, bias, G):
         forms[form] = bits(Yf)
         assert_bf16_close(forms[form][rows], exp, 2, 1e-3 * float(np.abs(exp).max()), "fp8 GEMM, tail form %d, vs restated reference" % form)
     # who serves which rows by default (csrc/gemm256.hip: launch_gemm_fp8): with M >= 512 (and K % 128 == N % 128 == 0) the LDS-DMA kernels take every tile-row,
-    # a ragged last one masked -- unless the tail is <= 64 rows, which goes to the skinny kernel; below 512 rows: skinny up to 64, masked LDS tiles beyond
+    # a ragged last one masked -- unless the tail is <= 64 rows, which goes to the skinny kernel; below 512 rows: skinny up to 32 (64 without a tile grid), masked LDS tiles beyond
     # -- and below 512 rows wherever their grid still has >= 120 tiles (no skinny split there: the remainder stays in the ragged tile-row)
     tail = M % 256
     tiles = ((M + 255) // 256) * (N // 128)
-    if K % 128 or N % 128 or not (M >= 512 or (M > 64 and tiles >= 120)):
+    if K % 128 or N % 128 or not (M >= 512 or (M > 32 and tiles >= 120)):
         big = 0
     elif M < 512:
         big = M
@@ -955,3 +955,61 @@ def test_gemm_with_a_workspace_splits_k_for_short_prompts_and_remainders(M, K, N
         assert rc == capi.MILA_E_INVALID_ARGUMENT
     rc = lib.mila_cdna4_gemm_bf16_ws(capi._ptr(Y2), capi._ptr(Xd), capi._ptr(Wd), capi._ptr(bd), M, K, N, 2, capi._ptr(ws), C.c_size_t(need), capi._stream())
     assert rc == capi.MILA_E_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("M,K,N,bias", [(300, 4096, 3840, True),            # 60 tiles, K (32 K-tiles of 128) split 4 ways
+                                        (100, 2048, 3840, False),           # 30 tiles, 16 K-tiles split 2 ways
+                                        (255, 3200, 384, True),             # 3 tiles, 25 K-tiles over 3 copies (8, 8, 9)
+                                        (2048 + 255, 4096, 3840, True),     # long prompt: 8 whole tile-rows as before + the 255-row remainder split 4 ways
+                                        (32, 4096, 3840, True),             # few rows (up to two 16-row groups): the skinny weight stream keeps them, no workspace asked for
+                                        (2048, 1024, 3840, False)])         # whole tile-rows that fill the chip: none either
+def test_w4a8_gemm_with_a_workspace_splits_k(M, K, N, bias):
+    """gemm_fp8_scaled_ws: the W4A8 GEMM with a caller workspace (the fp4 policy's prefill, CudaLinearOp.ixx:646-715 with the cuBLASLt workspace of :706-707).  The split-K
+    form sums S fp32 partials in a fixed order and applies the kernels' epilogue, y = bf16(float(bf16(acc sB)) s_m + bias): sampled rows against the restated reference, the
+    whole output against the plain call within one bf16 ulp of the magnitude, the same bits again from a dirty workspace and from the one-call form gemm_bf16_w4a8 (whose
+    scratch carries the workspace), nothing written past Y, size / alignment errors"""
+    lib = capi.load()
+    rng = np.random.default_rng(M * 11 + N)
+    X, q4, s4, ws, w8, x8, ts = _w4a8_operands(rng, M, K, N, 128)
+    bb = orc.to_bf16_bits(rng.uniform(-0.1, 0.1, N).astype(np.float32)) if bias else None
+    ws_d = dev_f32(np.array([ws], dtype=np.float32))
+    X8, W8, ts_d, bd = dev_u8(x8), dev_u8(w8), dev_f32(ts), (dev_u16(bb) if bias else None)
+    need = lib.mila_cdna4_gemm_fp8_workspace_bytes(M, K, N)
+    expect = {300: 4 * 300, 100: 2 * 100, 255: 3 * 255, 2048 + 255: 4 * 255, 32: 0, 2048: 0}[M] * N * 4
+    assert need == expect, (need, expect)
+    wsb = torch.full((max(need, 16) // 4 + 4,), float("nan"), dtype=torch.float32, device="cuda")
+    guard = torch.full((M + 1, N), 0x1234, dtype=torch.int16, device="cuda")
+    Y = guard[:M]
+    args = lambda y, w, nb: (capi._ptr(y), capi._ptr(X8), capi._ptr(W8), capi._ptr(ts_d), capi._ptr(ws_d), capi._ptr(bd), M, K, N, w, C.c_size_t(nb), capi._stream())
+    capi.check(lib.mila_cdna4_gemm_fp8_scaled_ws(*args(Y, capi._ptr(wsb), need)))
+    torch.cuda.synchronize()
+    assert np.all(guard[M].cpu().numpy() == 0x1234)
+    first = bits(Y).copy()
+    assert not np.any((first & 0x7fff) > 0x7f80), "unwritten / NaN outputs"
+    Yp = empty_u16(M, N)
+    capi.call("gemm_fp8_scaled", Yp, X8, W8, ts_d, ws_d, bd, M, K, N)
+    a, b = orc.from_bf16_bits(first).astype(np.float64), orc.from_bf16_bits(bits(Yp)).astype(np.float64)
+    assert np.abs(a - b).max() <= 2.0 ** -7 * max(np.abs(b).max(), 1e-30)
+    if not need:
+        assert np.array_equal(first, bits(Yp))
+    main = M - M % 256
+    rows = sorted({0, 1, M // 2, M - 1, max(0, main - 1), min(M - 1, main)})
+    raw = orc.linear_fp8a_fp8w(x8[rows], np.ones(len(rows), dtype=np.float32), w8, None, ws, None)
+    exp = orc.round_bf16(raw.astype(np.float32)).astype(np.float64) * ts[rows].astype(np.float64)[:, None]
+    if bias:
+        exp = exp + orc.from_bf16_bits(bb).astype(np.float64)
+    assert_bf16_close(first[rows], exp, 2, 1e-3 * float(np.abs(exp).max()), "gemm_fp8_scaled_ws vs restated reference")
+    wsb.fill_(-1.0e30)
+    Y2 = empty_u16(M, N)
+    capi.check(lib.mila_cdna4_gemm_fp8_scaled_ws(*args(Y2, capi._ptr(wsb), need)))
+    assert np.array_equal(bits(Y2), first)
+    need1 = lib.mila_cdna4_gemm_w4a8_scratch_bytes(M, K, N)
+    assert need1 >= N * K + M * K + 4 * M + need
+    scratch = torch.empty(need1, dtype=torch.uint8, device="cuda")
+    Y3 = empty_u16(M, N)
+    capi.call("gemm_bf16_w4a8", Y3, dev_u16(orc.to_bf16_bits(X)), dev_u8(q4), dev_f32(s4), ws_d, bd, M, K, N, 128, scratch, C.c_size_t(need1))
+    assert np.array_equal(bits(Y3), first), "the one-call form (workspace inside its scratch) differs"
+    if need:
+        assert lib.mila_cdna4_gemm_fp8_scaled_ws(*args(Y2, capi._ptr(wsb), need - 1)) == capi.MILA_E_SCRATCH_TOO_SMALL
+        assert lib.mila_cdna4_gemm_fp8_scaled_ws(*args(Y2, None, 0)) == capi.MILA_E_SCRATCH_TOO_SMALL
+        assert lib.mila_cdna4_gemm_fp8_scaled_ws(*args(Y2, C.c_void_p(wsb.data_ptr() + 4), need)) == capi.MILA_E_INVALID_ARGUMENT

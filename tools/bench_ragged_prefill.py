@@ -12,6 +12,11 @@ if os.environ.get("RAGGED_TUNE"):      # mila_cdna4_tune_gemm codes (csrc/intern
     from mila_amd import capi
     for code in os.environ["RAGGED_TUNE"].split(","):
         capi.check(capi.load().mila_cdna4_tune_gemm(int(code)))
+if os.environ.get("RAGGED_TUNE_FP8"):      # mila_cdna4_tune_gemm_fp8_tail_only codes
+    os.environ["MILA_CDNA4_TUNING"] = "1"
+    from mila_amd import capi
+    for code in os.environ["RAGGED_TUNE_FP8"].split(","):
+        capi.check(capi.load().mila_cdna4_tune_gemm_fp8_tail_only(int(code)))
 out = {}
 for pol in policies:
     m = host.Gemma(pol, max_seq=4096, max_prefill=2304, seed=1)
