@@ -300,7 +300,7 @@ int launch_gemm256x128_splitk(uint16_t* Y, const uint16_t* X, const uint16_t* W,
 // to 16 rows 7.46 / 7.39 / 7.75 / 7.94 ms, never ahead 7.41 / 7.05 / 7.13 / 7.28 -- a one-round tile grid and the split-K form stream the weights at 3-4 TB/s from two
 // rows on, the skinny kernel's 16-row groups at that rate only for one group.  The skinny kernels keep what has no such grid: a 1-row remainder, narrow outputs, calls
 // without a workspace on the N = 3840 shapes.
-int g_geglu_skinny_rows = 1;         // tuning: mila_cdna4_tune_gemm(300 + n): up to this many rows the skinny kernels go ahead of an applicable tile grid (plain and GeGLU)
+int g_skinny_ahead_rows = 1;         // tuning: mila_cdna4_tune_gemm(300 + n): up to this many rows the skinny kernels go ahead of an applicable tile grid (plain and GeGLU)
 int g_splitk_min_rows = 2;           // tuning (mila_cdna4_tune_gemm(200 + n)): row counts below this stay off the split-K form even with a workspace
 
 // which direct-to-LDS kernel serves a bf16-weight GEMM of this shape: 2 = 256 x 256, 1 = 256 x 128, 0 = none (128 x 128 register-staged)
@@ -414,9 +414,10 @@ static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, c
     if (!g_gemm_force128 && g_bf16_skinny)
     {
         // few rows: a weight stream (the 128-tile kernel pushed the bf16 model's weights past a 16-row prompt at 1 TB/s)
-        // (past one 16-row group the stream re-reads X per 16 W rows and runs at 1.2-2 TB/s: a tile grid that covers half the chip or more is the faster form there --
+        // (past g_skinny_ahead_rows, and above all past one 16-row group -- the stream then re-reads X per 16 W rows and runs at 1.2-2 TB/s -- a tile grid that covers half
+        // the chip or more is the faster form --
         // fc_gate_up at 64 rows 196 us against ~55 as 240 tiles of 256 x 128; on the N = 3840 shapes' 30 tiles the stream still wins)
-        if (M <= kBf16SkinnyRows && (M <= g_geglu_skinny_rows || (int64_t)((N + 127) / 128) < kNumCU / 2 || !glds_kernel_for(M, K, N)))
+        if (M <= kBf16SkinnyRows && (M <= g_skinny_ahead_rows || (int64_t)((N + 127) / 128) < kNumCU / 2 || !glds_kernel_for(M, K, N)))
             return launch_gemm_bf16_skinny(Y, X, W, bias, M, K, N, act, s);
         // a long prompt's <= 64-row remainder: the LDS-DMA kernels on the leading tile-rows, the skinny kernel on the rest (a ragged tile-row of the N = 3840 shapes
         // would open a second round of full-length tiles; the 128-tile kernel cost a 1-row remainder +18 ms per prefill)
@@ -481,8 +482,6 @@ static int launch_bf16_rows_ws(uint16_t* Y, const uint16_t* X, const uint16_t* W
 
 // Linear + GeGLU over any row count the fused forms serve: the LDS-DMA GeGLU kernel on whole / ragged tile-rows, the skinny GeGLU kernel on <= 64 rows (a short prompt,
 // or the remainder of a long one)
-// (rows the skinny GeGLU kernel takes ahead of an applicable LDS-DMA grid: from two 16-row groups on it re-reads X per 16 W rows and streams fc_gate_up at 1.2-2 TB/s,
-// the one-round tile grid at 4.7 -- bf16-policy prefill of 64 tokens 9.1 ms against 8.0 for 100)
 static bool geglu_rows_applicable(int M, int K, int F)
 {
     // where the plain GEMM over the [2F, K] weight would split K given a workspace, the fused form steps aside: the caller's Linear (gemm_bf16_ws) + GeGLU pair is the
@@ -490,9 +489,9 @@ static bool geglu_rows_applicable(int M, int K, int F)
     if (bf16_ws_plan(M, K, 2 * F).S) return false;
     if (gemm256_geglu_applicable(M, K, F)) return true;
     if (!g_bf16_skinny) return false;
-    // few rows: the skinny GeGLU kernel -- past one 16-row group only where the plain Linear over [2F, K] has no LDS-DMA grid either (with one, Linear + GeGLU as two
+    // few rows: the skinny GeGLU kernel -- past g_skinny_ahead_rows only where the plain Linear over [2F, K] has no LDS-DMA grid either (with one, Linear + GeGLU as two
     // launches is the faster pair: fc_gate_up at 64 rows 196 us skinny, ~55 as a one-round tile grid + the elementwise pass)
-    if (M <= kBf16SkinnyRows) return M <= g_geglu_skinny_rows || !glds_kernel_for(M, K, 2 * F);
+    if (M <= kBf16SkinnyRows) return M <= g_skinny_ahead_rows || !glds_kernel_for(M, K, 2 * F);
     const int tail = M % 256;
     return M >= 512 && tail > 0 && tail <= kBf16SkinnyRows && gemm256_geglu_applicable(M - tail, K, F);
 }
@@ -500,8 +499,8 @@ static int launch_geglu_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, 
 {
     const int tail = M % 256;
     const bool whole = gemm256_geglu_applicable(M, K, F);
-    if (g_bf16_skinny && M <= kBf16SkinnyRows && (M <= g_geglu_skinny_rows || !whole)) return launch_gemm_bf16_skinny_geglu(Y, X, W, M, K, F, s);
-    if (g_bf16_skinny && M >= 512 && tail > 0 && tail <= kBf16SkinnyRows && (tail <= g_geglu_skinny_rows || !whole) && gemm256_geglu_applicable(M - tail, K, F))
+    if (g_bf16_skinny && M <= kBf16SkinnyRows && (M <= g_skinny_ahead_rows || !whole)) return launch_gemm_bf16_skinny_geglu(Y, X, W, M, K, F, s);
+    if (g_bf16_skinny && M >= 512 && tail > 0 && tail <= kBf16SkinnyRows && (tail <= g_skinny_ahead_rows || !whole) && gemm256_geglu_applicable(M - tail, K, F))
     {
         int rc = launch_gemm256_geglu(Y, X, W, M - tail, K, F, s);
         if (rc) return rc;
@@ -520,8 +519,8 @@ int mila_cdna4_tune_gemm(int force_128_tile)
 {
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
     if (force_128_tile == 3 || force_128_tile == 4) { g_bf16_skinny = force_128_tile == 4; return MILA_OK; }
-    if (force_128_tile == 5 || force_128_tile == 6) { g_gemm_splitk = force_128_tile == 6; return MILA_OK; }      // the split-K form of gemm_bf16_ws off / on
-    if (force_128_tile >= 300) { g_geglu_skinny_rows = force_128_tile - 300; return MILA_OK; }      // 301 = default
+    if (force_128_tile == 5 || force_128_tile == 6) { g_gemm_splitk = force_128_tile == 6; return MILA_OK; }      // the split-K forms of gemm_bf16_ws and gemm_fp8_scaled_ws off / on
+    if (force_128_tile >= 300) { g_skinny_ahead_rows = force_128_tile - 300; return MILA_OK; }      // 301 = default
     if (force_128_tile >= 200) { g_splitk_min_rows = force_128_tile - 200; return MILA_OK; }      // 202 = default
     if (force_128_tile >= 100) { g_ldsdma_loose_tiles = force_128_tile - 100; return MILA_OK; }      // 100 = the fill rule only; 130 = default
     g_gemm_force128 = force_128_tile == 1;
