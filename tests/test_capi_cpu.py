@@ -92,6 +92,38 @@ def test_validation_rejects_bad_arguments_without_touching_the_device(lib):
     assert lib.mila_cdna4_attn_decode_scratch_bytes(1, 16, 512) == 16 * 256 * 516 * 4 + 16 * 512 * 2      # HS 512: the long-context matrix-core decode's 256 splits + its roped q rows
 
 
+def test_gemm_workspace_planner_is_host_logic(lib):
+    """gemm_workspace_bytes / gemm_fp8_workspace_bytes (the split-K forms' planner; the cuBLASLt-workspace counterpart of CudaLinearOp.ixx:637-638) on Gemma 4's shapes:
+    short prompts split the shapes whose tile list covers at most half the chip, a long prompt's remainder splits alone where its tile-row would open another round of the
+    grid, nothing is asked for where the tile grid fills the chip; never more than 32 MiB; the staged / one-call quantized forms' scratch sizes carry it"""
+    D, F, QKV, AO = 3840, 15360, 8192, 4096
+    ws, ws8 = lib.mila_cdna4_gemm_workspace_bytes, lib.mila_cdna4_gemm_fp8_workspace_bytes
+    # 300 rows: fc_down 60 tiles x 4, o_proj 60 x 4, qkv 128 x 2; fc_gate_up's 480 tiles fill the chip
+    assert ws(300, F, D) == 4 * 300 * D * 4 and ws(300, AO, D) == 4 * 300 * D * 4 and ws(300, D, QKV) == 2 * 300 * QKV * 4 and ws(300, D, 2 * F) == 0
+    # whole tile-rows that fill the chip
+    assert ws(2048, F, D) == 0 and ws(2048, D, QKV) == 0
+    # T = 2303: the N = 3840 shapes' 255-row remainder alone, 30 tiles x 8 copies (fc_down) / 8 (o_proj: 64 K-tiles / 8)
+    assert ws(2303, F, D) == 8 * 255 * D * 4 and ws(2303, AO, D) == 8 * 255 * D * 4
+    # ... and not where nine tile-rows stay within the round count (1000 rows of N = 3840: 120 tiles, split whole instead)
+    assert ws(1000, F, D) == 2 * 1000 * D * 4
+    assert ws(1, F, D) == 0 and ws(2, F, D) == 8 * 2 * D * 4
+    # W4A8: one byte per weight, K-tiles of 128; up to 32 rows stay with the skinny weight stream
+    assert ws8(32, F, D) == 0 and ws8(33, F, D) == 8 * 33 * D * 4 and ws8(300, F, D) == 4 * 300 * D * 4 and ws8(2048, F, D) == 0
+    assert ws8(2303, F, D) == 8 * 255 * D * 4
+    for M in (2, 17, 64, 100, 255, 256, 300, 511, 700, 1000, 1024, 2047, 2303, 4095):
+        for K, N in ((F, D), (AO, D), (D, QKV), (D, 2 * F), (768, 768), (3072, 768), (768, 50257)):
+            assert ws(M, K, N) <= 32 << 20 and ws8(M, K, N) <= 32 << 20, (M, K, N)
+            assert ws(M, K, N) % 16 == 0 and ws8(M, K, N) % 16 == 0
+            if ws(M, K, N):
+                assert lib.mila_cdna4_gemm_staging_bytes(M, K, N) == N * K * 2 + ws(M, K, N)
+            pad = lambda b: (b + 15) & ~15
+            assert lib.mila_cdna4_gemm_w4a8_scratch_bytes(M, K, N) == pad(N * K) + pad(M * K) + pad(M * 4) + ws8(M, K, N)
+    # the fused GeGLU forms step aside exactly where the plain GEMM over [2F, K] would split
+    assert lib.mila_cdna4_gemm_geglu_applicable(300, D, F) == 1 and lib.mila_cdna4_gemm_geglu_w4a8_applicable(300, D, F) == 1
+    assert ws(24, 1280, 5120) > 0 and lib.mila_cdna4_gemm_geglu_applicable(24, 1280, 2560) == 0
+    assert ws8(100, 2560, 5120) > 0 and lib.mila_cdna4_gemm_geglu_w4a8_applicable(100, 2560, 2560) == 0
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(capi, "_lib", None)
     monkeypatch.setattr(capi, "LIB_PATH", str(tmp_path / "nope.so"))
