@@ -301,6 +301,10 @@ int launch_gemm256x128_splitk(uint16_t* Y, const uint16_t* X, const uint16_t* W,
 // rows on, the skinny kernel's 16-row groups at that rate only for one group.  The skinny kernels keep what has no such grid: a 1-row remainder, narrow outputs, calls
 // without a workspace on the N = 3840 shapes.
 int g_skinny_ahead_rows = 1;         // tuning: mila_cdna4_tune_gemm(300 + n): up to this many rows the skinny kernels go ahead of an applicable tile grid (plain and GeGLU)
+int gemm_fewrow_splits(int M, int K, int N);      // gemm_fewrow_bf16.hip
+int launch_gemm_bf16_fewrow(float* partials, const uint16_t* X, const uint16_t* W, int M, int K, int N, int S, hipStream_t s);
+int launch_splitk_reduce(uint16_t* Y, const float* partials, const uint16_t* bias, int M, int N, int S, int act, hipStream_t s);      // gemm256.hip
+int g_fewrow = 1;                    // tuning (mila_cdna4_tune_gemm(9) off, (10) on): the few-row weight-streaming form for <= 32 rows with a workspace
 int g_splitk_min_rows = 2;           // tuning (mila_cdna4_tune_gemm(200 + n)): row counts below this stay off the split-K form even with a workspace
 
 // which direct-to-LDS kernel serves a bf16-weight GEMM of this shape: 2 = 256 x 256, 1 = 256 x 128, 0 = none (128 x 128 register-staged)
@@ -444,24 +448,36 @@ static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, c
 
 // ---- the same GEMM with a caller workspace (mila_cdna4_gemm_bf16_ws): what the split-K form changes ----
 // plan: rows [0, main) as launch_bf16_rows serves them, rows [main, M) split-K with S copies (S = 0: no split-K part, everything as launch_bf16_rows)
-struct Bf16WsPlan { int main_rows, S; };
+struct Bf16WsPlan { int main_rows, S; bool fewrow; };
+// the split-K form for `rows` rows: up to 32 rows the few-row weight stream (gemm_fewrow_bf16.hip), else the 256 x 128 ring over S copies of the tile list
+static Bf16WsPlan splitk_form(int main_rows, int rows, int K, int N)
+{
+    // (a remainder takes it only where the ring form could split too -- at most half a round of tiles: a wide output's remainder stays with the call's other forms,
+    // so that a long prompt's fc_gate_up keeps its fused GeGLU kernel)
+    if (g_fewrow && rows <= 32 && (main_rows == 0 || (N + 127) / 128 <= kNumCU / 2))
+    {
+        const int Sf = gemm_fewrow_splits(rows, K, N);
+        if (Sf) return {main_rows, Sf, true};
+    }
+    return {main_rows, gemm_splitk_for(rows, K, N), false};
+}
 static Bf16WsPlan bf16_ws_plan(int M, int K, int N)
 {
-    if (g_gemm_force128 || M < g_splitk_min_rows) return {M, 0};
-    // a short prompt: the whole tile list covers at most half the CUs
-    int S = gemm_splitk_for(M, K, N);
-    if (S) return {0, S};
+    if (g_gemm_force128 || M < g_splitk_min_rows) return {M, 0, false};
+    // a short prompt: the whole tile list covers at most half the CUs (or the few-row form serves it)
+    Bf16WsPlan pl = splitk_form(0, M, K, N);
+    if (pl.S) return pl;
     // a long prompt's remainder whose ragged tile-row would open another round of the grid (T = 2303 on the N = 3840 shapes: 240 tiles fill the chip, 270 run two
     // rounds of full-length tiles -- fc_down 200 -> 400 us): the whole tile-rows as before, the remainder split-K
     const int tail = M % 256, main_rows = M - tail;
-    if (M < 512 || tail < g_splitk_min_rows) return {M, 0};
+    if (M < 512 || tail < g_splitk_min_rows) return {M, 0, false};
     const int which = glds_kernel_for(main_rows, K, N);
-    if (!which) return {M, 0};
+    if (!which) return {M, 0, false};
     const int per_row = which == 2 ? (N + 255) / 256 : (N + 127) / 128, tm = main_rows / 256;
     const bool new_round = (tm * per_row + kNumCU - 1) / kNumCU < ((tm + 1) * per_row + kNumCU - 1) / kNumCU;
-    if (!new_round) return {M, 0};
-    S = gemm_splitk_for(tail, K, N);
-    return S ? Bf16WsPlan{main_rows, S} : Bf16WsPlan{M, 0};
+    if (!new_round) return {M, 0, false};
+    pl = splitk_form(main_rows, tail, K, N);
+    return pl.S ? pl : Bf16WsPlan{M, 0, false};
 }
 static size_t bf16_ws_bytes(int M, int K, int N)
 {
@@ -477,7 +493,16 @@ static int launch_bf16_rows_ws(uint16_t* Y, const uint16_t* X, const uint16_t* W
         int rc = launch_bf16_rows(Y, X, W, bias, pl.main_rows, K, N, s, act);
         if (rc) return rc;
     }
-    return launch_gemm256x128_splitk(Y + (size_t)pl.main_rows * N, X + (size_t)pl.main_rows * K, W, bias, M - pl.main_rows, K, N, s, act, static_cast<float*>(ws), pl.S);
+    uint16_t* Yt = Y + (size_t)pl.main_rows * N;
+    const uint16_t* Xt = X + (size_t)pl.main_rows * K;
+    const int rows = M - pl.main_rows;
+    if (pl.fewrow)
+    {
+        int rc = launch_gemm_bf16_fewrow(static_cast<float*>(ws), Xt, W, rows, K, N, pl.S, s);
+        if (rc) return rc;
+        return launch_splitk_reduce(Yt, static_cast<const float*>(ws), bias, rows, N, pl.S, act, s);
+    }
+    return launch_gemm256x128_splitk(Yt, Xt, W, bias, rows, K, N, s, act, static_cast<float*>(ws), pl.S);
 }
 
 // Linear + GeGLU over any row count the fused forms serve: the LDS-DMA GeGLU kernel on whole / ragged tile-rows, the skinny GeGLU kernel on <= 64 rows (a short prompt,
@@ -519,6 +544,7 @@ int mila_cdna4_tune_gemm(int force_128_tile)
 {
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
     if (force_128_tile == 3 || force_128_tile == 4) { g_bf16_skinny = force_128_tile == 4; return MILA_OK; }
+    if (force_128_tile == 9 || force_128_tile == 10) { g_fewrow = force_128_tile == 10; return MILA_OK; }      // the few-row (<= 32 rows) weight-streaming form of gemm_bf16_ws off / on
     if (force_128_tile == 5 || force_128_tile == 6) { g_gemm_splitk = force_128_tile == 6; return MILA_OK; }      // the split-K forms of gemm_bf16_ws and gemm_fp8_scaled_ws off / on
     if (force_128_tile >= 300) { g_skinny_ahead_rows = force_128_tile - 300; return MILA_OK; }      // 301 = default
     if (force_128_tile >= 200) { g_splitk_min_rows = force_128_tile - 200; return MILA_OK; }      // 202 = default

@@ -1239,6 +1239,14 @@ static int launch_gemm256x128_fp8_splitk(uint16_t* Y, const uint8_t* X8, const u
     return check_hip(hipGetLastError(), "splitk_reduce_fp8");
 }
 
+// the second kernel on its own (the few-row form of gemm_fewrow_bf16.hip writes the same [S][M][N] partials)
+int launch_splitk_reduce(uint16_t* Y, const float* partials, const uint16_t* bias, int M, int N, int S, int act, hipStream_t s)
+{
+    const int64_t MN = (int64_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, Y, partials, bias, MN, N, S, act);
+    return check_hip(hipGetLastError(), "splitk_reduce");
+}
+
 int launch_gemm256x128_splitk(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act, float* partials, int S)
 {
     static bool attr_set = false;

@@ -12,7 +12,7 @@ extern "C" {
  * maximum workgroups */
 MILA_API int mila_cdna4_tune_matvec(int R, int U, int max_blocks);
 /* (3 / 4: the bf16 skinny weight-streaming kernel for <= 64-row prompts and remainders off / on; 100 + n: the 256 x 128 ring from n tiles on whatever its last round's
- * fill (130 = default, 100 = the fill rule only); 5 / 6: the split-K form of gemm_bf16_ws off / on; 200 + n: row counts below n stay off split-K (202 = default); 300 + n: up to n rows the skinny GeGLU kernel goes ahead of an applicable tile grid (301 = default);
+ * fill (130 = default, 100 = the fill rule only); 5 / 6: the split-K forms of gemm_bf16_ws / gemm_fp8_scaled_ws off / on; 9 / 10: the few-row (<= 32 rows) form of gemm_bf16_ws off / on; 200 + n: row counts below n stay off split-K (202 = default); 300 + n: up to n rows the skinny GeGLU kernel goes ahead of an applicable tile grid (301 = default);
  * each leaves the other settings)
  * 1 = always use the 128 x 128 register-staged GEMM (A/B against the 256 x 256 direct-to-LDS kernel); 2 = default kernels, but an output whose row pitch is no
  * multiple of 128 bytes keeps the direct epilogue stores instead of the row-wise epilogue through LDS; 0 = default */

@@ -898,6 +898,10 @@ def test_a_long_prompts_short_remainder_goes_to_the_bf16_skinny_kernel(M):
                                             (255, 1600, 384, True, 0),         # 3 tiles, 25 K-tiles over 3 copies: uneven K ranges (8, 8, 9)
                                             (2048 + 255, 4096, 3840, True, 0),  # a long prompt: 8 whole tile-rows as before + a 255-row remainder split 8 ways
                                             (1024 + 100, 2048, 8192, False, 1),  # 4 whole tile-rows fill the chip (256 tiles); the 100-row remainder (64 tiles) split 4 ways
+                                            (16, 15360, 3840, True, 0),        # <= 32 rows: the few-row weight stream (fc_down's shape: 30 x 18 workgroups)
+                                            (2, 4096, 3840, False, 1),         # two rows; + GELU
+                                            (32, 3840, 8192, True, 0),         # two 16-row groups per wave
+                                            (9, 2048, 1200, True, 0),          # a ragged last 128-row block of W (1200 = 9 x 128 + 48), N % 128 != 0
                                             (1, 1024, 3840, True, 0),          # one row: no split-K form, no workspace asked for
                                             (2048, 512, 3840, True, 0)])       # whole tile-rows that fill the chip: no workspace asked for
 def test_gemm_with_a_workspace_splits_k_for_short_prompts_and_remainders(M, K, N, bias, act):
@@ -915,6 +919,10 @@ def test_gemm_with_a_workspace_splits_k_for_short_prompts_and_remainders(M, K, N
     expect_split = M > 1 and not (M == 2048)
     assert (need > 0) == expect_split, need
     assert need <= 32 << 20
+    if M <= 32 and M > 1:                                     # the few-row form: about two workgroups per CU, a slice of >= 4 K-tiles whose X image fits 64 KB
+        nk, blocks, nkl_max = K // 64, (N + 127) // 128, 65536 // (M * 128)
+        S = min(max(-(-nk // nkl_max), max(1, 512 // blocks)), max(1, nk // 4))
+        assert need == S * M * N * 4, (need, S)
     if M == 2048 + 255: assert need == 8 * 255 * N * 4        # the remainder alone, 30 tiles x 8 copies
     if M == 300 and N == 3840: assert need == 4 * 300 * N * 4
     if M == 1024 + 100: assert need == 4 * 100 * N * 4
