@@ -567,7 +567,7 @@ int mila_cdna4_tune_gemm_fp8_tail_only(int on)
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
     if (on == 3) { g_skinny_whole_x = 0; return MILA_OK; }      // 3: the skinny kernel's barrier-free <= 4-row form off (4 turns it back on); the other settings stay
     if (on == 4) { g_skinny_whole_x = 1; return MILA_OK; }
-    if (on >= 100) { g_fp8_splitk_min_rows = on - 100; return MILA_OK; }      // 133 = default: fewer rows stay off the fp8 split-K form
+    if (on >= 100) { g_fp8_splitk_min_rows = on - 100; return MILA_OK; }      // 117 = default: fewer rows stay off the fp8 split-K form
     if (on >= 5 && on <= 8) { g_fp8_big_rule = on - 5; return MILA_OK; }      // 5 / 6 / 7: which row counts below 512 take the LDS-DMA kernels (gemm256.hip: g_fp8_big_rule 0 / 1 / 2)
     g_gemm_fp8_tail_only = on != 0;      // 1: every row on the masked 128-row LDS tiles (bit-identical to the LDS-DMA kernels); 2: every row as skinny pieces
     g_gemm_fp8_tail_form = (on == 1 || on == 2) ? on : 0;

@@ -1363,10 +1363,11 @@ int g_gemm_fp8_tail_only = 0;      // tuning hook (mila_cdna4_tune_gemm_fp8_tail
 //   everything else: the tail kernels of gemm_fp8_tail.hip alone.
 // Rows are independent and the LDS-DMA kernels and the masked tiles run the same instruction chain per output element.
 constexpr int kSkinnyTailRows = 64;
-// Few rows (tools/experiments/few_row_rules_fp4.sh, profiles/r03_splitk.txt): up to two 16-row groups the skinny kernel -- a weight stream of one byte per weight -- is the
-// fastest form (fp4-policy prefill of 16 / 32 tokens 4.90 / 5.70 ms, against 5.28 / 5.89 with o_proj and fc_down split over K); from 33 rows on the tile grids
-// (>= 120 tiles) and the split-K form are (64 tokens: 7.15 ms skinny)
-int g_fp8_splitk_min_rows = 33;      // tuning (mila_cdna4_tune_gemm_fp8_tail_only(100 + n)): fewer rows stay with the skinny kernel
+// Few rows (tools/experiments/few_row_rules_fp4.sh, profiles/r03_splitk.txt): one 16-row group stays with the skinny kernel -- a weight stream of one byte per weight
+// (fp4-policy prefill of 8 / 16 tokens 4.83 / 4.92 ms, against 4.95 / 5.02 on the tile forms); from 17 rows on the tile grids (>= 120 tiles) and the split-K form are faster
+// (17 / 24 / 32 tokens 5.39 / 5.50 / 5.69 ms skinny, 5.09 / 5.10 / 5.17 here; 64 tokens 7.15 -> 5.66).  A W4A8 form of the few-row kernel (gemm_fewrow_bf16.hip with
+// e4m3 operands; parity-green) was slower than both on every length -- the skinny kernel's fused GeGLU saves fc_gate_up a reduce and an elementwise pass -- and is not kept.
+int g_fp8_splitk_min_rows = 17;      // tuning (mila_cdna4_tune_gemm_fp8_tail_only(100 + n)): fewer rows stay with the skinny kernel
 int g_fp8_big_rule = 3;      // tuning (mila_cdna4_tune_gemm_fp8_tail_only 5 .. 8 = rule 0 .. 3): 0 = LDS-DMA kernels from 512 rows on (round 3's first rule), 1 = from 128 rows on,
                              // 2 = from 512 rows on or wherever ceil(M / 256) x (W rows / 128) >= 120 tiles, 3 (default) = 2 without the skinny split of a short prompt's remainder
 static int fp8_big_rows(int M, int K, int N_mult, int w_rows)      // rows the LDS-DMA kernels take (0 = none); N_mult: the column granularity the form needs (128, or 64 for 256 x 128 GeGLU)

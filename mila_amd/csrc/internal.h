@@ -25,7 +25,7 @@ MILA_API int mila_cdna4_tune_gemm_schedule(int pingpong);
  * weight-streaming pieces up to 255 rows, masked 128-row LDS tiles beyond); 1 = EVERY row on the masked 128-row tiles (bit-identical to the LDS-DMA kernels:
  * the test of that statement); 2 = every row as skinny pieces (same products, K-tiles summed in eight interleaved chains: fp32-rounding-level differences). */
 /* (3 / 4: the skinny kernel's barrier-free whole-X form off / on; 5 .. 8: which row counts below 512 take the LDS-DMA kernels -- rules 0 .. 3 of csrc/gemm256.hip: g_fp8_big_rule,
- * 8 = default; 100 + n: row counts below n stay off the fp8 split-K form of gemm_fp8_scaled_ws (133 = default); each leaves the other settings) */
+ * 8 = default; 100 + n: row counts below n stay off the fp8 split-K form of gemm_fp8_scaled_ws (117 = default); each leaves the other settings) */
 MILA_API int mila_cdna4_tune_gemm_fp8_tail_only(int on);
 /* positions of the live band one flash-decode split covers (default 64; 0 restores it): fewer, longer splits = smaller partial sets.
  * Negative values steer the long-context matrix-core decode (attn_decode_mfma_kernel): -1 = never take it, -2 = default rule (bands of >= 4096 keys),

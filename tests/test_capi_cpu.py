@@ -108,8 +108,8 @@ def test_gemm_workspace_planner_is_host_logic(lib):
     assert ws(1000, F, D) == 2 * 1000 * D * 4
     # up to 32 rows: the few-row weight stream, 128 W rows per workgroup and about two workgroups per CU (fc_down: 30 blocks x 18 slices of K)
     assert ws(1, F, D) == 0 and ws(2, F, D) == 17 * 2 * D * 4 and ws(16, D, 2 * F) == 2 * 16 * 2 * F * 4 and ws(33, F, D) == 8 * 33 * D * 4
-    # W4A8: one byte per weight, K-tiles of 128; up to 32 rows stay with the skinny weight stream
-    assert ws8(32, F, D) == 0 and ws8(33, F, D) == 8 * 33 * D * 4 and ws8(300, F, D) == 4 * 300 * D * 4 and ws8(2048, F, D) == 0
+    # W4A8: one byte per weight, K-tiles of 128; one 16-row group stays with the skinny weight stream
+    assert ws8(16, F, D) == 0 and ws8(17, F, D) == 8 * 17 * D * 4 and ws8(33, F, D) == 8 * 33 * D * 4 and ws8(300, F, D) == 4 * 300 * D * 4 and ws8(2048, F, D) == 0
     assert ws8(2303, F, D) == 8 * 255 * D * 4
     for M in (2, 17, 64, 100, 255, 256, 300, 511, 700, 1000, 1024, 2047, 2303, 4095):
         for K, N in ((F, D), (AO, D), (D, QKV), (D, 2 * F), (768, 768), (3072, 768), (768, 50257)):

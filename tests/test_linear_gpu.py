@@ -582,11 +582,11 @@ def test_w4a8_serves_every_row_count_like_the_reference(M, K, N, bias, G):
         forms[form] = bits(Yf)
         assert_bf16_close(forms[form][rows], exp, 2, 1e-3 * float(np.abs(exp).max()), "fp8 GEMM, tail form %d, vs restated reference" % form)
     # who serves which rows by default (csrc/gemm256.hip: launch_gemm_fp8): with M >= 512 (and K % 128 == N % 128 == 0) the LDS-DMA kernels take every tile-row,
-    # a ragged last one masked -- unless the tail is <= 64 rows, which goes to the skinny kernel; below 512 rows: skinny up to 32 (64 without a tile grid), masked LDS tiles beyond
+    # a ragged last one masked -- unless the tail is <= 64 rows, which goes to the skinny kernel; below 512 rows: skinny up to 16 (64 without a tile grid), masked LDS tiles beyond
     # -- and below 512 rows wherever their grid still has >= 120 tiles (no skinny split there: the remainder stays in the ragged tile-row)
     tail = M % 256
     tiles = ((M + 255) // 256) * (N // 128)
-    if K % 128 or N % 128 or not (M >= 512 or (M > 32 and tiles >= 120)):
+    if K % 128 or N % 128 or not (M >= 512 or (M > 16 and tiles >= 120)):
         big = 0
     elif M < 512:
         big = M
@@ -969,7 +969,7 @@ def test_gemm_with_a_workspace_splits_k_for_short_prompts_and_remainders(M, K, N
                                         (100, 2048, 3840, False),           # 30 tiles, 16 K-tiles split 2 ways
                                         (255, 3200, 384, True),             # 3 tiles, 25 K-tiles over 3 copies (8, 8, 9)
                                         (2048 + 255, 4096, 3840, True),     # long prompt: 8 whole tile-rows as before + the 255-row remainder split 4 ways
-                                        (32, 4096, 3840, True),             # few rows (up to two 16-row groups): the skinny weight stream keeps them, no workspace asked for
+                                        (16, 4096, 3840, True),             # one 16-row group: the skinny weight stream keeps it, no workspace asked for
                                         (2048, 1024, 3840, False)])         # whole tile-rows that fill the chip: none either
 def test_w4a8_gemm_with_a_workspace_splits_k(M, K, N, bias):
     """gemm_fp8_scaled_ws: the W4A8 GEMM with a caller workspace (the fp4 policy's prefill, CudaLinearOp.ixx:646-715 with the cuBLASLt workspace of :706-707).  The split-K
@@ -983,7 +983,7 @@ def test_w4a8_gemm_with_a_workspace_splits_k(M, K, N, bias):
     ws_d = dev_f32(np.array([ws], dtype=np.float32))
     X8, W8, ts_d, bd = dev_u8(x8), dev_u8(w8), dev_f32(ts), (dev_u16(bb) if bias else None)
     need = lib.mila_cdna4_gemm_fp8_workspace_bytes(M, K, N)
-    expect = {300: 4 * 300, 100: 2 * 100, 255: 3 * 255, 2048 + 255: 4 * 255, 32: 0, 2048: 0}[M] * N * 4
+    expect = {300: 4 * 300, 100: 2 * 100, 255: 3 * 255, 2048 + 255: 4 * 255, 16: 0, 2048: 0}[M] * N * 4
     assert need == expect, (need, expect)
     wsb = torch.full((max(need, 16) // 4 + 4,), float("nan"), dtype=torch.float32, device="cuda")
     guard = torch.full((M + 1, N), 0x1234, dtype=torch.int16, device="cuda")
