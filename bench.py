@@ -164,6 +164,47 @@ def measured_traffic(policy):
     return None, None
 
 
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+PREFILL_UNTIMED, PREFILL_TIMED = 2, 7
+
+
+def timed_prefill(m):
+    """SURVEY.md section 8(d) protocol: >= 2 untimed passes, then the median of >= 7 timed ones (HIP events on the model's stream around one T = 2048 prefill each;
+    host.Gemma.time_prefill runs one more untimed pass in front of every timed one).  Returns (median ms, min ms, spread = max - min)."""
+    for _ in range((PREFILL_UNTIMED + 1) // 2):
+        m.time_prefill(CONTEXT, 1)
+    xs = [m.time_prefill(CONTEXT, 1) for _ in range(PREFILL_TIMED)]
+    return _median(xs), min(xs), max(xs) - min(xs)
+
+
+def launch_boundary_us(capi):
+    """what one more graph node costs when it does no work: a chain of 64 one-thread launches (advance_position) replayed from a hipGraph, microseconds per launch
+    (tools/bench_fixed_cost.py's first case, measured in this process) -- the `fixed_us_per_launch` of the decode design floor"""
+    import torch
+    pos = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        capi.call("advance_position", pos)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(64):
+            capi.call("advance_position", pos)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (20 * 64)
+
+
 def _free_port():
     import socket
     with socket.socket() as so:
@@ -299,14 +340,15 @@ def main():
             m.set_resident_prefill_weights(a.resident)
         info = m.info(ctx)
         r = {"weight_GB": round(info["weight_bytes"] / 1e9, 3), "bytes_per_token_GB": round(info["decode_bytes_per_token"] / 1e9, 3)}
-        # the quantized policies keep their prefill staging resident: HBM it costs beside the quantized weights
+        # the quantized policies keep their prefill staging resident: HBM it costs beside the quantized weights, as the ops report it
         resident = a.resident is None or bool(a.resident)
-        r["resident_prefill_weights_GB"] = round(info["linear_params"] * {"bf16": 0, "fp8": 2, "fp4": 1}[pol] / 1e9, 3) if resident else 0.0
+        r["resident_prefill_weights_GB"] = round(m.resident_staging_bytes() / 1e9, 3)
+        r["total_resident_GB"] = round((info["weight_bytes"] + m.resident_staging_bytes()) / 1e9, 3)      # weights + scales + tied table + the staging above (KV caches / activations aside)
         if not a.no_prefill:
-            # one untimed pass + one pass between HIP events per call; the minimum of three calls (the first policy's first pass follows the CPU leg and the weight
-            # generation: one call alone read 43.2 ms once where the next two runs read 41.3)
-            ms = min(m.time_prefill(CONTEXT, 1) for _ in range(3))
-            r["prefill_timing"] = "min of 3 x (1 untimed + 1 timed pass)"
+            ms, ms_min, spread = timed_prefill(m)
+            r["prefill_timing"] = "median of %d timed passes (HIP events, one T=2048 prefill each, each behind an untimed pass) after %d untimed; min and max - min beside it" % (PREFILL_TIMED, PREFILL_UNTIMED)
+            r["prefill_ms_min"] = round(ms_min, 3)
+            r["prefill_ms_spread"] = round(spread, 3)
             # algorithmic FLOPs: Linear 2*params*T + head (last position) + attention 4*NH*HS*sum(keys)
             lin = 2.0 * info["linear_params"] * CONTEXT + 2.0 * info["table_params"]
             att = 0.0
@@ -323,6 +365,24 @@ def main():
             ideal_ms = (lin / (MFMA_FP8_PEAK_TFLOPS if pol == "fp4" else MFMA_BF16_PEAK_TFLOPS) + att / MFMA_BF16_PEAK_TFLOPS) / 1e9
             r["prefill_mfma_frac"] = round(ideal_ms / ms, 4)
             r["prefill_mfma_peak_TFLOPs"] = {"linear": MFMA_FP8_PEAK_TFLOPS if pol == "fp4" else MFMA_BF16_PEAK_TFLOPS, "attention": MFMA_BF16_PEAK_TFLOPS}
+            if pol in ("fp8", "fp4") and resident:
+                # the reference's semantics (CudaLinearOp.ixx:597-644, :648-715: the staging pass runs inside EVERY forward, on a 12 GB card): the same prefill with the
+                # resident staging off -- same bits, tests/test_gemma_host_gpu.py
+                m.set_resident_prefill_weights(0)
+                r["prefill_ms_per_forward_staging"] = round(timed_prefill(m)[0], 3)
+                m.set_resident_prefill_weights(1)
+            if pol == "fp8":
+                # BASELINE config 4 ("Linear<PerChannelFp8<>> weights, CDNA4 fp8_e4m3 MFMA"): the OPT-IN W8A8 prefill -- the policy's own e4m3 weights + per-channel scales
+                # on the fp8 matrix cores, per-token e4m3 activations, no staging and no bf16 copy (Policies.ixx:39-40).  The default above stays the reference's W8A16.
+                m.set_fp8_activation_prefill(1)
+                ms8, ms8_min, _ = timed_prefill(m)
+                r["prefill_ms_w8a8"] = round(ms8, 3)
+                r["prefill_ms_w8a8_min"] = round(ms8_min, 3)
+                r["prefill_TFLOPs_w8a8"] = round((lin + att) / ms8 / 1e9, 2)
+                r["prefill_mfma_frac_w8a8"] = round((lin / MFMA_FP8_PEAK_TFLOPS + att / MFMA_BF16_PEAK_TFLOPS) / 1e9 / ms8, 4)      # Linears priced at the fp8 peak
+                r["resident_prefill_weights_GB_w8a8"] = round(m.resident_staging_bytes() / 1e9, 3)
+                r["total_resident_GB_w8a8"] = round((info["weight_bytes"] + m.resident_staging_bytes()) / 1e9, 3)
+                m.set_fp8_activation_prefill(0)
             if ctx > CHUNK:
                 # the long prompt as the L6 caller feeds it: chunks of 2048 through the KV caches (Gemma.ixx:234-267); fills the caches to the context
                 cms = m.time_prefill_chunked(ctx)
@@ -336,6 +396,7 @@ def main():
         ranks.barrier()
         t["wall_ms_per_step"] = ranks.max_over_ranks(t["wall_ms_per_step"])      # timing only: max over ranks
         k = m.time_dominant_kernel(3)
+        r["launches_per_token"] = m.graph_node_count() if a.mode == "graph" else None
         r.update({"ms_per_step": round(t["wall_ms_per_step"], 4), "device_ms_per_step": round(t["device_ms_per_step"], 4),
                   "tok_s": round(1e3 / t["wall_ms_per_step"], 2),
                   "token_roofline_frac": round(info["decode_bytes_per_token"] / (t["wall_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -370,13 +431,22 @@ def main():
     stream_read_gbps = round(5 * n / e0.elapsed_time(e1) / 1e6, 1)
     del src
 
+    # the decode design floor: one launch per fused Linear / attention step means every token pays launches_per_token node boundaries on top of its
+    # bytes at the rate a pure stream reaches on this box; what fraction of the 8 TB/s roofline that design can reach at best, per policy
+    fixed_us = round(launch_boundary_us(capi), 3)
+    for pol, r in results.items():
+        if r.get("launches_per_token"):
+            floor_ms = r["bytes_per_token_GB"] / stream_read_gbps * 1e3 + r["launches_per_token"] * fixed_us * 1e-3
+            r["design_floor_ms"] = round(floor_ms, 4)
+            r["design_floor_frac"] = round(r["bytes_per_token_GB"] / HBM_PEAK_GBPS * 1e3 / floor_ms, 4)
+
     head = results[policies[0]]
     out = {
         "metric": "Gemma-4 12B decode tok/s (B=1, context %d), 1xMI355X" % ctx,
         "value": round(head["tok_s"] * world, 2), "unit": "tok/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"bf16": "bf16", "fp8": "bf16 activations x fp8_e4m3 weights", "fp4": "bf16 activations x fp4_e2m1 weights"}[policies[0]],
-        "data": "synthetic (counter-based uniform weights, random-init architecture; KV cache filled by a T=2048 prefill)",
+        "data": "synthetic (counter-based uniform weights, random-init architecture; KV cache filled by %s)" % ("a T=2048 prefill" if ctx == CONTEXT else "a chunked prefill of %d tokens (chunks of 2048)" % ctx),
         "config": {"workload": "Gemma-4 12B, weight policy %s, B=1, prefill T=2048%s then decode at positions %d.." % (policies[0], "" if ctx == CONTEXT else " (chunked to %d)" % ctx, ctx),
                    "decode_mode": a.mode, "replicas": world, "parallelism": "replicas only (no collective)"},
         "roofline": {"bound": "hbm", "achieved": head["dominant_kernel"]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -385,6 +455,10 @@ def main():
                      "kernel": head["dominant_kernel"]["name"], "avg_us": head["dominant_kernel"]["avg_us"],
                      "algorithmic_bytes_per_launch": head["dominant_kernel"]["bytes"],
                      "whole_token_frac": head["token_roofline_frac"],
+                     # the floor of THIS design (one graph node per fused Linear / attention step): bytes at the measured stream rate + launches x the cost of an empty node
+                     "launches_per_token": head.get("launches_per_token"), "fixed_us_per_launch": fixed_us,
+                     "design_floor_frac": {pol: r.get("design_floor_frac") for pol, r in results.items()},
+                     "design_floor": "bytes_per_token / measured_stream_read + launches_per_token x fixed_us_per_launch, as a fraction of bytes_per_token / 8 TB/s",
                      # beside the 8 TB/s datasheet figure: what a read-only pass reaches on this box (the matvec's launch shape, non-temporal 16-byte loads,
                      # 2 GiB: a yardstick measured in the same process) and the guide's float4-copy figure; the whole token against each
                      "measured_stream_read_GBps": stream_read_gbps,

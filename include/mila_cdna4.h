@@ -182,6 +182,26 @@ MILA_API int mila_cdna4_gemm_fp8_scaled_ws(uint16_t* Y, const uint8_t* X8, const
 MILA_API int mila_cdna4_gemm_geglu_fp8_scaled(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* token_scales,
                                               const float* weight_scale, int M, int K, int F, mila_stream_t stream);
 
+/* W8A8 prefill for PerChannelFp8<> weights (ABI 4; opt-in beside the W8A16 forms): the policy's own e4m3 [N, K] weights and fp32 scale[N] are the fp8 matrix cores'
+ * operand as they lie in HBM -- the intent the reference states for this policy (../../../Quantization/Weight/Policies.ixx:39-40: "FP8 matmul consumes weights and scales
+ * natively -- no dequantization on the forward hot path") and BASELINE config 4 names; no staging pass, no bf16 copy of the weights.  Activations per token exactly as on
+ * the W4A8 path (quantize_fp8_per_token; Fp8Prefill/CudaFp8Prefill.cu:108-160):
+ *   y = bf16( (sum_k X8 W8)[m, n] * channel_scales[n] * s_m + bias[n] )      fp32 throughout, ONE rounding (no intermediate bf16 tensor exists here)
+ * The kernels, row-count rules, split-K workspace (gemm_fp8_workspace_bytes) and fused-GeGLU applicability (gemm_geglu_w4a8_applicable) are those of the W4A8 forms; a row's
+ * bits do not depend on which tile form served it.  Not the reference's arithmetic for this policy (that is W8A16, CudaLinearOp.ixx:597-644, and stays RocmLinearOp's default):
+ * the activation quantization puts the result within the reference's own W4A8 bar (1e-1 row_absmax, Tests/.../Linear.Cuda.cpp:760-774) of the W8A16 one.
+ *   gemm_bf16_w8a8 / gemm_geglu_bf16_w8a8: one call from bf16 activations; scratch = [X8 | s_m | workspace] of gemm_w8a8_scratch_bytes(M, K, N) (GeGLU: N = 2 F) bytes.
+ *   channel_scales: 16-byte aligned; the GeGLU forms take [2 F] = [gate rows | up rows]. */
+MILA_API int mila_cdna4_gemm_fp8_w8a8_ws(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* token_scales, const float* channel_scales, const uint16_t* bias,
+                                         int M, int K, int N, void* workspace, size_t workspace_bytes, mila_stream_t stream);
+MILA_API int mila_cdna4_gemm_geglu_fp8_w8a8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* token_scales, const float* channel_scales, int M, int K, int F,
+                                            mila_stream_t stream);
+MILA_API size_t mila_cdna4_gemm_w8a8_scratch_bytes(int M, int K, int N);
+MILA_API int mila_cdna4_gemm_bf16_w8a8(uint16_t* Y, const uint16_t* X, const uint8_t* W8, const float* channel_scales, const uint16_t* bias, int M, int K, int N,
+                                       void* scratch, size_t scratch_bytes, mila_stream_t stream);
+MILA_API int mila_cdna4_gemm_geglu_bf16_w8a8(uint16_t* Y, const uint16_t* X, const uint8_t* W8, const float* channel_scales, int M, int K, int F, void* scratch,
+                                             size_t scratch_bytes, mila_stream_t stream);
+
 /* 2-phase forms for quantized weights (the reference's own structure, Linear/CudaLinearOp.ixx:597-644, :716-764:
  * dequantize to a bf16 scratch, then the bf16 GEMM).  Chosen automatically when the 256 x 256 LDS-DMA GEMM
  * applies to (M,K,N) -- gemm_staging_bytes() says how much scratch that needs (0 = the register-dequantizing kernel is

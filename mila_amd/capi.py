@@ -77,6 +77,7 @@ def load():
     main.mila_cdna4_gemm_fp8_workspace_bytes.restype = C.c_size_t
     main.mila_cdna4_sample_scratch_bytes.restype = C.c_size_t
     main.mila_cdna4_gemm_w4a8_scratch_bytes.restype = C.c_size_t
+    main.mila_cdna4_gemm_w8a8_scratch_bytes.restype = C.c_size_t
     main.mila_cdna4_sample_stochastic_scratch_bytes.restype = C.c_size_t
     main.mila_cdna4_attn_decode_ticket_count.restype = C.c_size_t
     main.mila_cdna4_mha_decode_scratch_bytes.restype = C.c_size_t
@@ -164,6 +165,7 @@ EXPORTED = [
     "fused_norm_matvec", "fused_qkv_post", "fused_qkv_post_prefill", "fused_tail_norm_bf16", "fused_tail_norm_quant_bf16",
     "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position", "advance_position_snapshot", "snapshot_token", "sample_argmax_advance_fp32", "sample_argmax_final_advance", "fused_attn_decode_batch_bf16", "fused_attn_decode_bf16",
     "dequantize_to_bf16", "gemm_geglu_fp8_scaled",
+    "gemm_fp8_w8a8_ws", "gemm_geglu_fp8_w8a8", "gemm_w8a8_scratch_bytes", "gemm_bf16_w8a8", "gemm_geglu_bf16_w8a8",
 ]
 
 # csrc/internal.h: test / tuning hooks and the measured-slower experiments -- exported, but not part of the drop-in ABI

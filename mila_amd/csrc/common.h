@@ -207,6 +207,24 @@ __device__ __forceinline__ float w4a8_scale_bias(float acc, float ws, float ts, 
     return has_bias ? __builtin_fmaf(a, ts, b) : a * ts;
 }
 
+// ---- W8A8 epilogue (PerChannelFp8<> weights consumed natively by the fp8 matrix cores, Quantization/Weight/Policies.ixx:39-40; opt-in beside the reference's W8A16 default):
+// y = (acc * s_c[n]) * s_m (+ bias) in fp32, rounded ONCE at the store -- no intermediate bf16 tensor exists on this path, so none is simulated.  The last step is one explicit
+// FMA when there is a bias, for the reason given above: every kernel form that can serve a row must give the row the same bits.
+__device__ __forceinline__ float w8a8_scale_bias(float acc, float wc, float ts, bool has_bias, float b)
+{
+    const float a = acc * wc;
+    return has_bias ? __builtin_fmaf(a, ts, b) : a * ts;
+}
+// the fp8 x fp8 kernels' epilogue: `pc` (wave-uniform) = the weight scale is a per-channel vector (W8A8), else the per-tensor scalar of W4A8
+__device__ __forceinline__ float fp8_scale_bias(bool pc, float acc, float ws, float ts, bool has_bias, float b)
+{
+    return pc ? w8a8_scale_bias(acc, ws, ts, has_bias, b) : w4a8_scale_bias(acc, ws, ts, has_bias, b);
+}
+// the Linear's stored bf16 output without a bias, as a float (the operand of a fused GeGLU epilogue)
+__device__ __forceinline__ float fp8_linear_out(bool pc, float acc, float ws, float ts) { return round_bf16(fp8_scale_bias(pc, acc, ws, ts, false, 0.0f)); }
+// how the host passes the weight scale through the launchers: p = device scalar (per_channel 0) or a vector over the W rows (per_channel 1; GeGLU forms: [gate rows | up rows])
+struct Fp8WScale { const float* p; int per_channel; };
+
 // ---- GELU (tanh) -------------------------------------------------------------------------------
 // Components/Activations/Activation/Kernels/ElementwiseActivation.h:41-50: 0.5 x (1 + tanh(u)), u = sqrt(2 / pi) (x + 0.044715 x^3), as the reference functor writes it
 __device__ __forceinline__ float gelu_tanh_precise(float x)

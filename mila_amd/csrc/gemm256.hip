@@ -35,6 +35,7 @@ struct Gemm256Params
     int act = 0;             // bf16 plain epilogue: 1 = tanh-GELU on the stored Linear output, y = bf16(gelu(bf16(acc) [+ bias, rounded again])): Linear + Gelu of MLP.ixx:148-161 in one kernel
     float* partials = nullptr;      // split-K form of the 256 x 128 ring: [splitk][M][N] fp32 accumulators (workspace), summed and finished by splitk_reduce_kernel
     int splitk = 0;
+    int w_pc = 0;            // FP8 mode: w_scale is a per-channel vector over the W rows (W8A8: y = bf16((acc * w_scale[n]) * x_scales[m] + bias), common.h) instead of the W4A8 scalar
 #ifdef MILA_GEMM_SKIP
     int dbg = 0;             // diagnostic build (tools/experiments/gemm_skip.sh): leave out the staging (1), the fragment reads (2), the MFMAs (4), the plain epilogue's stores (8)
 #endif
@@ -285,10 +286,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
         {
             // fp8 epilogue scales, fetched ONCE before the stores: read inside the store loop they are re-fetched after every store (the compiler cannot
             // prove that Y does not alias them) -- a dependent global load in front of each of the 16 stores, 7-11 us per tile
-            float ws_ = 1.0f, tsv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+            float tsv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+            f32x4 wsg[4], wsu[4];      // weight scales of this lane's gate / up columns per sub-tile pt (W4A8: the per-tensor scalar in every slot)
+            const bool pc = FP8 && p.w_pc;
             if constexpr (FP8)
             {
-                ws_ = *p.w_scale;
+                if (pc)
+                {
+            #pragma unroll
+                    for (int pt_ = 0; pt_ < 4; ++pt_)
+                    {
+                        const int n_ = n0 + wr * 64 + pt_ * 16 + 4 * g;
+                        wsg[pt_] = *reinterpret_cast<const f32x4*>(p.w_scale + n_);
+                        wsu[pt_] = *reinterpret_cast<const f32x4*>(p.w_scale + p.N + n_);
+                    }
+                }
+                else
+                {
+                    const float ws_ = *p.w_scale;
+            #pragma unroll
+                    for (int pt_ = 0; pt_ < 4; ++pt_) wsg[pt_] = wsu[pt_] = f32x4{ws_, ws_, ws_, ws_};
+                }
             #pragma unroll
                 for (int hb_ = 0; hb_ < 2; ++hb_)
             #pragma unroll
@@ -298,11 +316,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 float v[4];
                 if constexpr (FP8)
                 {
-                    // gate / up as the W4A8 Linear stores them (bf16(float(bf16(acc * sB)) * s_m)), then the GeGLU kernel's product
-                    const float ws = ws_, ts = tsv[hB][qt];
+                    // gate / up as the Linear stores them (W4A8: bf16(float(bf16(acc * sB)) * s_m); W8A8: bf16((acc * s_c[n]) * s_m)), then the GeGLU kernel's product
+                    const float ts = tsv[hB][qt];
     #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        v[e] = gelu_tanh(round_bf16(round_bf16(acc[0][hB][pt][qt][e] * ws) * ts)) * round_bf16(round_bf16(acc[1][hB][pt][qt][e] * ws) * ts);
+                        v[e] = gelu_tanh(fp8_linear_out(pc, acc[0][hB][pt][qt][e], wsg[pt][e], ts)) * fp8_linear_out(pc, acc[1][hB][pt][qt][e], wsu[pt][e], ts);
                 }
                 else
                 {
@@ -327,10 +345,26 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
         {
             // fp8 epilogue scales, fetched ONCE before the stores: read inside the store loop they are re-fetched after every store (the compiler cannot
             // prove that Y does not alias them) -- a dependent global load in front of each of the 16 stores, 7-11 us per tile
-            float ws_ = 1.0f, tsv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+            float tsv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+            f32x4 wsv[2][4];      // weight scales of this lane's columns per (W half, sub-tile) (W4A8: the per-tensor scalar in every slot)
+            const bool pc = FP8 && p.w_pc;
             if constexpr (FP8)
             {
-                ws_ = *p.w_scale;
+                if (pc)
+                {
+            #pragma unroll
+                    for (int ha_ = 0; ha_ < 2; ++ha_)
+            #pragma unroll
+                        for (int pt_ = 0; pt_ < 4; ++pt_) wsv[ha_][pt_] = *reinterpret_cast<const f32x4*>(p.w_scale + n0 + ha_ * 128 + wr * 64 + pt_ * 16 + 4 * g);
+                }
+                else
+                {
+                    const float ws_ = *p.w_scale;
+            #pragma unroll
+                    for (int ha_ = 0; ha_ < 2; ++ha_)
+            #pragma unroll
+                        for (int pt_ = 0; pt_ < 4; ++pt_) wsv[ha_][pt_] = f32x4{ws_, ws_, ws_, ws_};
+                }
             #pragma unroll
                 for (int hb_ = 0; hb_ < 2; ++hb_)
             #pragma unroll
@@ -342,12 +376,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 for (int e = 0; e < 4; ++e) v[e] = acc[hA][hB][pt][qt][e];
                 if constexpr (FP8)
                 {
-                    // the reference's two steps: the GEMM stores bf16(acc * weight scale), the per-token pass rescales (+ bias)
-                    const float ws = ws_, ts = tsv[hB][qt];
+                    // W4A8: the reference's two steps -- the GEMM stores bf16(acc * weight scale), the per-token pass rescales (+ bias); W8A8: (acc * s_c[n]) * s_m (+ bias), one rounding
+                    const float ts = tsv[hB][qt];
     #pragma unroll
                     for (int e = 0; e < 4; ++e)
                     {
-                        v[e] = w4a8_scale_bias(v[e], ws, ts, p.bias != nullptr, p.bias ? bf16_bits_to_f32(p.bias[n + e]) : 0.0f);
+                        v[e] = fp8_scale_bias(pc, v[e], wsv[hA][pt][e], ts, p.bias != nullptr, p.bias ? bf16_bits_to_f32(p.bias[n + e]) : 0.0f);
                     }
                 }
                 else if (p.bias)
@@ -854,10 +888,26 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
         {
             // fp8 epilogue scales, fetched ONCE before the stores: read inside the store loop they are re-fetched after every store (the compiler cannot
             // prove that Y does not alias them) -- a dependent global load in front of each of the 16 stores, 7-11 us per tile
-            float ws_ = 1.0f, tsv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+            float tsv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+            f32x4 wsg[2], wsu[2];      // weight scales of this lane's gate / up columns per sub-tile pt (W4A8: the per-tensor scalar in every slot)
+            const bool pc = FP8 && p.w_pc;
             if constexpr (FP8)
             {
-                ws_ = *p.w_scale;
+                if (pc)
+                {
+            #pragma unroll
+                    for (int pt_ = 0; pt_ < 2; ++pt_)
+                    {
+                        const int n_ = n0 + wr * 32 + pt_ * 16 + 4 * g;
+                        wsg[pt_] = *reinterpret_cast<const f32x4*>(p.w_scale + n_);
+                        wsu[pt_] = *reinterpret_cast<const f32x4*>(p.w_scale + p.N + n_);
+                    }
+                }
+                else
+                {
+                    const float ws_ = *p.w_scale;
+                    wsg[0] = wsg[1] = wsu[0] = wsu[1] = f32x4{ws_, ws_, ws_, ws_};
+                }
             #pragma unroll
                 for (int hb_ = 0; hb_ < 2; ++hb_)
             #pragma unroll
@@ -867,10 +917,10 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                 float v[4];
                 if constexpr (FP8)
                 {
-                    const float ws = ws_, ts = tsv[hB][qt];
+                    const float ts = tsv[hB][qt];
     #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        v[e] = gelu_tanh(round_bf16(round_bf16(acc[hB][pt][qt][e] * ws) * ts)) * round_bf16(round_bf16(acc[hB][pt + 2][qt][e] * ws) * ts);
+                        v[e] = gelu_tanh(fp8_linear_out(pc, acc[hB][pt][qt][e], wsg[pt][e], ts)) * fp8_linear_out(pc, acc[hB][pt + 2][qt][e], wsu[pt][e], ts);
                 }
                 else
                 {
@@ -891,10 +941,22 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
         }
         // fp8 epilogue scales, fetched ONCE before the stores: read inside the store loop they are re-fetched after every store (the compiler cannot
         // prove that Y does not alias them) -- a dependent global load in front of each of the 16 stores, 7-11 us per tile
-        float ws_ = 1.0f, tsv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+        float tsv[2][2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+        f32x4 wsv[4];      // weight scales of this lane's columns per sub-tile (W4A8: the per-tensor scalar in every slot)
+        const bool pc = FP8 && p.w_pc;
         if constexpr (FP8)
         {
-            ws_ = *p.w_scale;
+            if (pc)
+            {
+        #pragma unroll
+                for (int pt_ = 0; pt_ < 4; ++pt_) wsv[pt_] = *reinterpret_cast<const f32x4*>(p.w_scale + n0 + wr * 64 + pt_ * 16 + 4 * g);
+            }
+            else
+            {
+                const float ws_ = *p.w_scale;
+        #pragma unroll
+                for (int pt_ = 0; pt_ < 4; ++pt_) wsv[pt_] = f32x4{ws_, ws_, ws_, ws_};
+            }
         #pragma unroll
             for (int hb_ = 0; hb_ < 2; ++hb_)
         #pragma unroll
@@ -918,11 +980,11 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             for (int e = 0; e < 4; ++e) v[e] = acc[hB][pt][qt][e];
             if constexpr (FP8)
             {
-                const float ws = ws_, ts = tsv[hB][qt];
+                const float ts = tsv[hB][qt];
     #pragma unroll
                 for (int e = 0; e < 4; ++e)
                 {
-                    v[e] = w4a8_scale_bias(v[e], ws, ts, p.bias != nullptr, bv[pt][e]);
+                    v[e] = fp8_scale_bias(pc, v[e], wsv[pt][e], ts, p.bias != nullptr, bv[pt][e]);
                 }
             }
             else if (p.bias)
@@ -1187,9 +1249,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(uint16_t* __restrict
     st16(Y + i, u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
 }
 
-// the W4A8 form: y = bf16(float(bf16(sum * *w_scale)) * x_scales[m] + bias), the epilogue of the fp8 kernels (common.h: w4a8_scale_bias)
+// the fp8 forms: W4A8 y = bf16(float(bf16(sum * *w_scale)) * x_scales[m] + bias), W8A8 (w_pc) y = bf16((sum * w_scale[n]) * x_scales[m] + bias): the epilogue of the fp8 kernels (common.h: fp8_scale_bias)
 __global__ __launch_bounds__(256) void splitk_reduce_fp8_kernel(uint16_t* __restrict__ Y, const float* __restrict__ P, const uint16_t* __restrict__ bias,
-                                                                const float* __restrict__ x_scales, const float* __restrict__ w_scale, int64_t MN, int N, int S)
+                                                                const float* __restrict__ x_scales, const float* __restrict__ w_scale, int w_pc, int64_t MN, int N, int S)
 {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i >= MN) return;
@@ -1201,11 +1263,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_fp8_kernel(uint16_t* __rest
     }
     float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
-    const float ws = *w_scale, ts = x_scales[m];
+    const float ts = x_scales[m];
+    float ws[8];
+    if (w_pc)
+    {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(w_scale + n), w1 = *reinterpret_cast<const f32x4*>(w_scale + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ws[e] = w0[e]; ws[4 + e] = w1[e]; }
+    }
+    else
+    {
+        const float w = *w_scale;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ws[e] = w;
+    }
     u32x4 bb = {0u, 0u, 0u, 0u};
     if (bias) bb = *reinterpret_cast<const u32x4*>(bias + n);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = w4a8_scale_bias(v[e], ws, ts, bias != nullptr, bf16_bits_to_f32((uint16_t)(bb[e >> 1] >> ((e & 1) * 16))));
+    for (int e = 0; e < 8; ++e) v[e] = fp8_scale_bias(w_pc != 0, v[e], ws[e], ts, bias != nullptr, bf16_bits_to_f32((uint16_t)(bb[e >> 1] >> ((e & 1) * 16))));
     st16(Y + i, u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
 }
 
@@ -1219,7 +1294,7 @@ int gemm_fp8_splitk_for(int M, int K, int N)      // S (>= 2), or 0: the fp8 (W4
     return S >= 2 ? S : 0;
 }
 
-static int launch_gemm256x128_fp8_splitk(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias, int M, int K, int N,
+static int launch_gemm256x128_fp8_splitk(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, Fp8WScale w_scale, const uint16_t* bias, int M, int K, int N,
                                          hipStream_t s, float* partials, int S)
 {
     static bool attr_set = false;
@@ -1235,7 +1310,7 @@ static int launch_gemm256x128_fp8_splitk(uint16_t* Y, const uint8_t* X8, const u
     int rc = check_hip(hipGetLastError(), "gemm256x128 (fp8 split-K)");
     if (rc) return rc;
     const int64_t MN = (int64_t)M * N;
-    hipLaunchKernelGGL(splitk_reduce_fp8_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, Y, partials, bias, x_scales, w_scale, MN, N, S);
+    hipLaunchKernelGGL(splitk_reduce_fp8_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, Y, partials, bias, x_scales, w_scale.p, w_scale.per_channel, MN, N, S);
     return check_hip(hipGetLastError(), "splitk_reduce_fp8");
 }
 
@@ -1347,9 +1422,9 @@ int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int 
 }
 
 // gemm_fp8_tail.hip: the same arithmetic for any row count (masked 128-row tiles; skinny weight streaming for <= 64 rows)
-int launch_gemm_fp8_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
+int launch_gemm_fp8_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, Fp8WScale w_scale, const uint16_t* bias,
                          int M, int K, int N, hipStream_t s);
-int launch_gemm_fp8_geglu_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
+int launch_gemm_fp8_geglu_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, Fp8WScale w_scale, int M, int K, int F,
                                hipStream_t s);
 int g_gemm_fp8_tail_only = 0;      // tuning hook (mila_cdna4_tune_gemm_fp8_tail_only): != 0: every row through the tail kernels (gemm_fp8_tail.hip: g_gemm_fp8_tail_form picks which)
 
@@ -1391,7 +1466,7 @@ static int fp8_pick(int rows, int N)
 }
 
 // Y[M, F] = GeGLU of the W4A8 Linear over W8 = [gate rows | up rows] (2F x K e4m3)
-int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
+int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, Fp8WScale w_scale, int M, int K, int F,
                           hipStream_t s)
 {
     const bool form256 = F % 128 == 0 && ((M + 255) / 256) * (F / 128) >= 200;
@@ -1402,26 +1477,29 @@ int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, con
         const int tm = (rows + 255) / 256;
         if (!form256)
         {
-            Gemm256Params q{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, rows, K, F, tm, F / 64, x_scales, w_scale};
+            Gemm256Params q{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, rows, K, F, tm, F / 64, x_scales, w_scale.p};
+            q.w_pc = w_scale.per_channel;
             rc = launch_gemm256x128_t<true, true>(q, s);
         }
         else
         {
-            Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, rows, K, F, tm, F / 128, x_scales, w_scale};
+            Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, rows, K, F, tm, F / 128, x_scales, w_scale.p};
+            p.w_pc = w_scale.per_channel;
             rc = launch_gemm256_t<G_FP8_GEGLU>(p, s);
         }
         if (rc || rows == M) return rc;
     }
     return launch_gemm_fp8_geglu_tail(Y + (size_t)rows * F, X8 + (size_t)rows * K, W8, x_scales + rows, w_scale, M - rows, K, F, s);
 }
-int launch_gemm_fp8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
+int launch_gemm_fp8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, Fp8WScale w_scale, const uint16_t* bias,
                     int M, int K, int N, hipStream_t s)
 {
     const int rows = fp8_big_rows(M, K, N % 128 == 0 ? 128 : 0, N);
     if (rows)
     {
         const int which = fp8_pick(rows, N), tm = (rows + 255) / 256;
-        Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), bias, rows, K, N, tm, which == 2 ? N / 256 : N / 128, x_scales, w_scale};
+        Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), bias, rows, K, N, tm, which == 2 ? N / 256 : N / 128, x_scales, w_scale.p};
+        p.w_pc = w_scale.per_channel;
         const int rc = which == 2 ? launch_gemm256_t<G_FP8>(p, s) : launch_gemm256x128_t<true>(p, s);
         if (rc || rows == M) return rc;
     }
@@ -1451,7 +1529,7 @@ size_t gemm_fp8_ws_bytes(int M, int K, int N)
     const Fp8WsPlan pl = fp8_ws_plan(M, K, N);
     return pl.S ? (size_t)pl.S * (M - pl.main_rows) * N * sizeof(float) : 0;
 }
-int launch_gemm_fp8_ws(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias, int M, int K, int N, hipStream_t s,
+int launch_gemm_fp8_ws(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, Fp8WScale w_scale, const uint16_t* bias, int M, int K, int N, hipStream_t s,
                        void* ws)
 {
     const Fp8WsPlan pl = fp8_ws_plan(M, K, N);

@@ -29,8 +29,9 @@ struct Fp8TailParams
     const uint8_t* W;         // [N, K] e4m3 (GEGLU: [2 F, K], gate rows then up rows, N = F)
     const uint16_t* bias;
     const float* x_scales;    // [M]
-    const float* w_scale;     // device scalar
+    const float* w_scale;     // device scalar (W4A8), or with w_pc the per-channel vector over the W rows (W8A8; GEGLU: [gate rows | up rows])
     int M, K, N, tiles_m, tiles_n;
+    int w_pc = 0;
 };
 typedef int i32x8t __attribute__((ext_vector_type(8)));
 
@@ -162,7 +163,13 @@ __global__ __launch_bounds__(256) void gemm_fp8_tail_kernel(const Fp8TailParams 
     }
 
     // ---- epilogue: D[p = 4 g + e][q = l15] -> Y[m0 + .. + q][n0 + .. + p] ----
-    const float ws = *p.w_scale;
+    const bool pc = p.w_pc != 0;
+    const float ws_scalar = pc ? 1.0f : *p.w_scale;
+    // this lane's weight scales for columns n .. n + 3 (`up`: the GeGLU up rows, F + n); columns past N are never stored
+    auto wscale4 = [&](int n, bool up, float (&w)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pc ? p.w_scale[(up ? p.N : 0) + min(n + e, p.N - 1)] : ws_scalar;
+    };
     const bool vec_ok = (p.N & 3) == 0;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
@@ -176,19 +183,22 @@ __global__ __launch_bounds__(256) void gemm_fp8_tail_kernel(const Fp8TailParams 
         {
             const int n = n0 + wn * (GEGLU ? PT * 8 : PT * 16) + pt * 16 + 4 * g;
             if (n >= p.N) continue;
-            float v[4];
+            float v[4], wg[4];
+            wscale4(n, false, wg);
             if constexpr (GEGLU)
             {
+                float wu[4];
+                wscale4(n, true, wu);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    v[e] = gelu_tanh(round_bf16(round_bf16(acc[pt][qt][e] * ws) * ts)) * round_bf16(round_bf16(acc[pt + PT / 2][qt][e] * ws) * ts);
+                    v[e] = gelu_tanh(fp8_linear_out(pc, acc[pt][qt][e], wg[e], ts)) * fp8_linear_out(pc, acc[pt + PT / 2][qt][e], wu[e], ts);
             }
             else
             {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                 {
-                    v[e] = w4a8_scale_bias(acc[pt][qt][e], ws, ts, p.bias != nullptr, (p.bias && n + e < p.N) ? bf16_bits_to_f32(p.bias[n + e]) : 0.0f);
+                    v[e] = fp8_scale_bias(pc, acc[pt][qt][e], wg[e], ts, p.bias != nullptr, (p.bias && n + e < p.N) ? bf16_bits_to_f32(p.bias[n + e]) : 0.0f);
                 }
             }
             if (vec_ok) *reinterpret_cast<u32x2*>(yrow + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -220,8 +230,9 @@ struct Fp8SkinnyParams
     const uint8_t* W;
     const uint16_t* bias;
     const float* x_scales;
-    const float* w_scale;
+    const float* w_scale;     // as in Fp8TailParams
     int M, K, N;              // M <= 16 MG
+    int w_pc = 0;
 };
 
 // XALL (MG == 1: at most 16 rows, and their e4m3 image fits the 32 KB of LDS -- the 1-row tail of a prefill chunk, 8 rows at K = 3840): ALL of X sits in LDS before the first product, so the K loop
@@ -391,19 +402,27 @@ __global__ __launch_bounds__(512) void gemm_fp8_skinny_kernel(const Fp8SkinnyPar
         }
         const int row = m * 16 + l15, n = n0 + r * 16 + 4 * g;
         if (row >= p.M || n >= p.N) continue;
-        const float ws = *p.w_scale, ts = p.x_scales[row];
-        float v[4];
+        const bool pc = p.w_pc != 0;
+        const float ts = p.x_scales[row];
+        float v[4], wg[4], wu[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+        {
+            const int ne = min(n + e, p.N - 1);       // columns past N are never stored
+            wg[e] = pc ? p.w_scale[ne] : *p.w_scale;
+            wu[e] = (GEGLU && pc) ? p.w_scale[p.N + ne] : wg[e];
+        }
         if constexpr (GEGLU)
         {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(round_bf16(round_bf16(sum[0][e] * ws) * ts)) * round_bf16(round_bf16(sum[1][e] * ws) * ts);
+            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(fp8_linear_out(pc, sum[0][e], wg[e], ts)) * fp8_linear_out(pc, sum[1][e], wu[e], ts);
         }
         else
         {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
             {
-                v[e] = w4a8_scale_bias(sum[0][e], ws, ts, p.bias != nullptr, (p.bias && n + e < p.N) ? bf16_bits_to_f32(p.bias[n + e]) : 0.0f);
+                v[e] = fp8_scale_bias(pc, sum[0][e], wg[e], ts, p.bias != nullptr, (p.bias && n + e < p.N) ? bf16_bits_to_f32(p.bias[n + e]) : 0.0f);
             }
         }
         uint16_t* y = p.Y + (size_t)row * p.N + n;
@@ -477,36 +496,36 @@ constexpr int kSkinnyMaxTail = 64;  // tails up to here run as ONE skinny launch
 
 static bool use_skinny(int M) { return g_gemm_fp8_tail_form == 2 || (g_gemm_fp8_tail_form == 0 && M <= kSkinnyMaxTail); }
 
-int launch_gemm_fp8_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
+int launch_gemm_fp8_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, Fp8WScale w_scale, const uint16_t* bias,
                          int M, int K, int N, hipStream_t s)
 {
     if (use_skinny(M))
     {
         for (int r0 = 0; r0 < M; r0 += kSkinnyRows)
         {
-            Fp8SkinnyParams q{Y + (size_t)r0 * N, X8 + (size_t)r0 * K, W8, bias, x_scales + r0, w_scale, std::min(kSkinnyRows, M - r0), K, N};
+            Fp8SkinnyParams q{Y + (size_t)r0 * N, X8 + (size_t)r0 * K, W8, bias, x_scales + r0, w_scale.p, std::min(kSkinnyRows, M - r0), K, N, w_scale.per_channel};
             const int rc = launch_skinny<false>(q, s);
             if (rc) return rc;
         }
         return MILA_OK;
     }
-    Fp8TailParams p{Y, X8, W8, bias, x_scales, w_scale, M, K, N, 0, 0};
+    Fp8TailParams p{Y, X8, W8, bias, x_scales, w_scale.p, M, K, N, 0, 0, w_scale.per_channel};
     return launch_tail<false>(p, s);
 }
-int launch_gemm_fp8_geglu_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
+int launch_gemm_fp8_geglu_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, Fp8WScale w_scale, int M, int K, int F,
                                hipStream_t s)
 {
     if (use_skinny(M))
     {
         for (int r0 = 0; r0 < M; r0 += kSkinnyRows)
         {
-            Fp8SkinnyParams q{Y + (size_t)r0 * F, X8 + (size_t)r0 * K, W8, nullptr, x_scales + r0, w_scale, std::min(kSkinnyRows, M - r0), K, F};
+            Fp8SkinnyParams q{Y + (size_t)r0 * F, X8 + (size_t)r0 * K, W8, nullptr, x_scales + r0, w_scale.p, std::min(kSkinnyRows, M - r0), K, F, w_scale.per_channel};
             const int rc = launch_skinny<true>(q, s);
             if (rc) return rc;
         }
         return MILA_OK;
     }
-    Fp8TailParams p{Y, X8, W8, nullptr, x_scales, w_scale, M, K, F, 0, 0};
+    Fp8TailParams p{Y, X8, W8, nullptr, x_scales, w_scale.p, M, K, F, 0, 0, w_scale.per_channel};
     return launch_tail<true>(p, s);
 }
 

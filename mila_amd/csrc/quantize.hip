@@ -240,14 +240,14 @@ __global__ __launch_bounds__(256) void quantize_fp8_per_token_kernel(uint8_t* __
     }
 }
 
-int launch_gemm_fp8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias,
+int launch_gemm_fp8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, Fp8WScale w_scale, const uint16_t* bias,
                     int M, int K, int N, hipStream_t s);
 bool gemm256_geglu_applicable(int M, int K, int F);
-int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, int M, int K, int F,
+int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, Fp8WScale w_scale, int M, int K, int F,
                           hipStream_t s);
 // gemm256.hip: the split-K forms behind a caller workspace
 size_t gemm_fp8_ws_bytes(int M, int K, int N);
-int launch_gemm_fp8_ws(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* w_scale, const uint16_t* bias, int M, int K, int N, hipStream_t s,
+int launch_gemm_fp8_ws(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, Fp8WScale w_scale, const uint16_t* bias, int M, int K, int N, hipStream_t s,
                        void* ws);
 bool gemm_fp8_geglu_steps_aside(int M, int K, int F);
 
@@ -328,7 +328,7 @@ int mila_cdna4_gemm_fp8_scaled(uint16_t* Y, const uint8_t* X8, const uint8_t* W8
 {
     MILA_REQUIRE(Y && X8 && W8 && x_scales && weight_scale, "gemm_fp8_scaled: null pointer");
     MILA_REQUIRE(mila_cdna4_gemm_fp8_applicable(M, K, N), "gemm_fp8_scaled: shape (M=%d, K=%d, N=%d) has no fp8 MFMA kernel (ask gemm_fp8_applicable)", M, K, N);
-    return launch_gemm_fp8(Y, X8, W8, x_scales, weight_scale, bias, M, K, N, as_stream(stream));
+    return launch_gemm_fp8(Y, X8, W8, x_scales, Fp8WScale{weight_scale, 0}, bias, M, K, N, as_stream(stream));
 }
 
 size_t mila_cdna4_gemm_fp8_workspace_bytes(int M, int K, int N)
@@ -345,7 +345,7 @@ int mila_cdna4_gemm_fp8_scaled_ws(uint16_t* Y, const uint8_t* X8, const uint8_t*
     if (need && (!workspace || workspace_bytes < need))
         return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_fp8_scaled_ws: workspace %zu bytes < required %zu (ask gemm_fp8_workspace_bytes)", workspace_bytes, need);
     MILA_REQUIRE(!need || (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "gemm_fp8_scaled_ws: the workspace must be 16-byte aligned");
-    return launch_gemm_fp8_ws(Y, X8, W8, x_scales, weight_scale, bias, M, K, N, as_stream(stream), workspace);
+    return launch_gemm_fp8_ws(Y, X8, W8, x_scales, Fp8WScale{weight_scale, 0}, bias, M, K, N, as_stream(stream), workspace);
 }
 
 // [e4m3 weights | e4m3 activations | per-token scales | split-K workspace], each part 16-byte aligned
@@ -375,7 +375,7 @@ int mila_cdna4_gemm_bf16_w4a8(uint16_t* Y, const uint16_t* X, const uint8_t* W_p
     rc = mila_cdna4_quantize_fp8_per_token(x8, ts, X, M, K, stream);
     if (rc) return rc;
     MILA_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 15) == 0, "gemm_bf16_w4a8: the scratch must be 16-byte aligned");
-    return launch_gemm_fp8_ws(Y, x8, w8, ts, weight_fp8_scale, bias, M, K, N, as_stream(stream), w8 + w4a8_ws_offset(M, K, N));
+    return launch_gemm_fp8_ws(Y, x8, w8, ts, Fp8WScale{weight_fp8_scale, 0}, bias, M, K, N, as_stream(stream), w8 + w4a8_ws_offset(M, K, N));
 }
 
 // (0 also where the plain W4A8 GEMM over [2F, K] would split K given a workspace: Linear + GeGLU as two calls is the faster pair there and keeps the bits of the unfused path)
@@ -386,7 +386,7 @@ int mila_cdna4_gemm_geglu_fp8_scaled(uint16_t* Y, const uint8_t* X8, const uint8
 {
     MILA_REQUIRE(Y && X8 && W8 && x_scales && weight_scale, "gemm_geglu_fp8_scaled: null pointer");
     MILA_REQUIRE(mila_cdna4_gemm_geglu_w4a8_applicable(M, K, F), "gemm_geglu_fp8_scaled: shape (M=%d, K=%d, F=%d) is outside the fused kernel", M, K, F);
-    return launch_gemm_fp8_geglu(Y, X8, W8, x_scales, weight_scale, M, K, F, as_stream(stream));
+    return launch_gemm_fp8_geglu(Y, X8, W8, x_scales, Fp8WScale{weight_scale, 0}, M, K, F, as_stream(stream));
 }
 
 int mila_cdna4_gemm_geglu_bf16_w4a8(uint16_t* Y, const uint16_t* X, const uint8_t* W_packed, const float* scales, const float* weight_fp8_scale,
@@ -404,7 +404,76 @@ int mila_cdna4_gemm_geglu_bf16_w4a8(uint16_t* Y, const uint16_t* X, const uint8_
     if (rc) return rc;
     rc = mila_cdna4_quantize_fp8_per_token(x8, ts, X, M, K, stream);
     if (rc) return rc;
-    return launch_gemm_fp8_geglu(Y, x8, w8, ts, weight_fp8_scale, M, K, F, as_stream(stream));
+    return launch_gemm_fp8_geglu(Y, x8, w8, ts, Fp8WScale{weight_fp8_scale, 0}, M, K, F, as_stream(stream));
+}
+
+/* ---- W8A8: the PerChannelFp8<> policy's own e4m3 [N, K] weights + scale[N] consumed by the fp8 matrix cores as they lie in HBM (Quantization/Weight/Policies.ixx:39-40:
+ * "FP8 matmul consumes weights and scales natively -- no dequantization on the forward hot path"); activations per token as on the W4A8 path
+ * (Fp8Prefill/CudaFp8Prefill.cu:108-160).  The same kernels as the W4A8 forms above with the weight scale as a per-channel vector:
+ *   y = bf16( (sum_k X8 W8) * scale[n] * s_m + bias )      (fp32, one rounding; common.h: w8a8_scale_bias)
+ * Opt-in: the reference's arithmetic for this policy is W8A16 (CudaLinearOp.ixx:597-644), which stays the default of RocmLinearOp. ---- */
+int mila_cdna4_gemm_fp8_w8a8_ws(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* channel_scales, const uint16_t* bias, int M, int K, int N,
+                                void* workspace, size_t workspace_bytes, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X8 && W8 && x_scales && channel_scales, "gemm_fp8_w8a8_ws: null pointer");
+    MILA_REQUIRE(mila_cdna4_gemm_fp8_applicable(M, K, N), "gemm_fp8_w8a8_ws: shape (M=%d, K=%d, N=%d) has no fp8 MFMA kernel (ask gemm_fp8_applicable)", M, K, N);
+    MILA_REQUIRE((reinterpret_cast<uintptr_t>(channel_scales) & 15) == 0, "gemm_fp8_w8a8_ws: the per-channel scales must be 16-byte aligned");
+    const size_t need = gemm_fp8_ws_bytes(M, K, N);
+    if (need && (!workspace || workspace_bytes < need))
+        return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_fp8_w8a8_ws: workspace %zu bytes < required %zu (ask gemm_fp8_workspace_bytes)", workspace_bytes, need);
+    MILA_REQUIRE(!need || (reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "gemm_fp8_w8a8_ws: the workspace must be 16-byte aligned");
+    return launch_gemm_fp8_ws(Y, X8, W8, x_scales, Fp8WScale{channel_scales, 1}, bias, M, K, N, as_stream(stream), workspace);
+}
+
+int mila_cdna4_gemm_geglu_fp8_w8a8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, const float* channel_scales, int M, int K, int F, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X8 && W8 && x_scales && channel_scales, "gemm_geglu_fp8_w8a8: null pointer");
+    MILA_REQUIRE(mila_cdna4_gemm_geglu_w4a8_applicable(M, K, F), "gemm_geglu_fp8_w8a8: shape (M=%d, K=%d, F=%d) is outside the fused kernel (ask gemm_geglu_w4a8_applicable)", M, K, F);
+    MILA_REQUIRE((reinterpret_cast<uintptr_t>(channel_scales) & 15) == 0 && F % 4 == 0, "gemm_geglu_fp8_w8a8: the per-channel scales must be 16-byte aligned and F a multiple of 4");
+    return launch_gemm_fp8_geglu(Y, X8, W8, x_scales, Fp8WScale{channel_scales, 1}, M, K, F, as_stream(stream));
+}
+
+// [e4m3 activations | per-token scales | split-K workspace], each part 16-byte aligned
+static size_t w8a8_ws_offset(int M, int K)
+{
+    return (((size_t)M * K + 15) & ~(size_t)15) + (((size_t)M * 4 + 15) & ~(size_t)15);
+}
+size_t mila_cdna4_gemm_w8a8_scratch_bytes(int M, int K, int N)
+{
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    return w8a8_ws_offset(M, K) + (K % 16 == 0 ? gemm_fp8_ws_bytes(M, K, N) : 0);
+}
+
+int mila_cdna4_gemm_bf16_w8a8(uint16_t* Y, const uint16_t* X, const uint8_t* W8, const float* channel_scales, const uint16_t* bias, int M, int K, int N, void* scratch,
+                              size_t scratch_bytes, mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X && W8 && channel_scales, "gemm_bf16_w8a8: null pointer");
+    MILA_REQUIRE(mila_cdna4_gemm_fp8_applicable(M, K, N), "gemm_bf16_w8a8: shape (M=%d, K=%d, N=%d) has no fp8 MFMA kernel (ask gemm_fp8_applicable)", M, K, N);
+    MILA_REQUIRE((reinterpret_cast<uintptr_t>(channel_scales) & 15) == 0, "gemm_bf16_w8a8: the per-channel scales must be 16-byte aligned");
+    const size_t need = mila_cdna4_gemm_w8a8_scratch_bytes(M, K, N);
+    if (!scratch || scratch_bytes < need) return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_bf16_w8a8: scratch %zu bytes < required %zu", scratch_bytes, need);
+    MILA_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 15) == 0, "gemm_bf16_w8a8: the scratch must be 16-byte aligned");
+    uint8_t* x8 = static_cast<uint8_t*>(scratch);
+    float* ts = reinterpret_cast<float*>(x8 + (((size_t)M * K + 15) & ~(size_t)15));
+    int rc = mila_cdna4_quantize_fp8_per_token(x8, ts, X, M, K, stream);
+    if (rc) return rc;
+    return launch_gemm_fp8_ws(Y, x8, W8, ts, Fp8WScale{channel_scales, 1}, bias, M, K, N, as_stream(stream), x8 + w8a8_ws_offset(M, K));
+}
+
+int mila_cdna4_gemm_geglu_bf16_w8a8(uint16_t* Y, const uint16_t* X, const uint8_t* W8, const float* channel_scales, int M, int K, int F, void* scratch, size_t scratch_bytes,
+                                    mila_stream_t stream)
+{
+    MILA_REQUIRE(Y && X && W8 && channel_scales, "gemm_geglu_bf16_w8a8: null pointer");
+    MILA_REQUIRE(mila_cdna4_gemm_geglu_w4a8_applicable(M, K, F), "gemm_geglu_bf16_w8a8: shape (M=%d, K=%d, F=%d) is outside the fused kernel (ask gemm_geglu_w4a8_applicable)", M, K, F);
+    MILA_REQUIRE((reinterpret_cast<uintptr_t>(channel_scales) & 15) == 0 && F % 4 == 0, "gemm_geglu_bf16_w8a8: the per-channel scales must be 16-byte aligned and F a multiple of 4");
+    const size_t need = w8a8_ws_offset(M, K);
+    if (!scratch || scratch_bytes < need) return set_error(MILA_E_SCRATCH_TOO_SMALL, "gemm_geglu_bf16_w8a8: scratch %zu bytes < required %zu", scratch_bytes, need);
+    MILA_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 15) == 0, "gemm_geglu_bf16_w8a8: the scratch must be 16-byte aligned");
+    uint8_t* x8 = static_cast<uint8_t*>(scratch);
+    float* ts = reinterpret_cast<float*>(x8 + (((size_t)M * K + 15) & ~(size_t)15));
+    int rc = mila_cdna4_quantize_fp8_per_token(x8, ts, X, M, K, stream);
+    if (rc) return rc;
+    return launch_gemm_fp8_geglu(Y, x8, W8, ts, Fp8WScale{channel_scales, 1}, M, K, F, as_stream(stream));
 }
 
 }  // extern "C"

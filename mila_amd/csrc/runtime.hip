@@ -42,7 +42,7 @@ extern "C" {
 
 const char* mila_cdna4_last_error(void) { return g_last_error; }
 
-int mila_cdna4_abi_version(void) { return 3; }
+int mila_cdna4_abi_version(void) { return 4; }
 
 int mila_cdna4_device_count(int* count)
 {

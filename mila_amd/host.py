@@ -161,8 +161,26 @@ class Gemma:
         or re-stage it into scratch on every forward as the reference does; identical bits"""
         _check(load().mila_gemma_set_resident_prefill_weights(self.h, int(bool(on))))
 
+    def graph_node_count(self):
+        """nodes of the captured decode graph = launches per token on the graph path (0 before the first graph-mode step)"""
+        lib = load()
+        lib.mila_gemma_graph_node_count.argtypes = [C.c_void_p, C.c_void_p]
+        out = C.c_int64()
+        _check(lib.mila_gemma_graph_node_count(self.h, C.byref(out)))
+        return out.value
+
+    def resident_staging_bytes(self):
+        """bytes of op-owned prefill staging the layer Linears hold right now (fp8 policy: bf16 copies -- 0 while W8A8 is on; fp4 policy: e4m3 copies)"""
+        lib = load()
+        lib.mila_gemma_resident_staging_bytes.argtypes = [C.c_void_p, C.c_void_p]
+        out = C.c_double()
+        _check(lib.mila_gemma_resident_staging_bytes(self.h, C.byref(out)))
+        return out.value
+
     def set_fp8_activation_prefill(self, on):
-        """fp4 policy: W4A8 prefill on the fp8 matrix cores (default, the reference's default) or the exact-weight bf16 fallback"""
+        """fp4 policy: W4A8 prefill on the fp8 matrix cores (default, the reference's default) or the exact-weight bf16 fallback.
+        fp8 policy: the OPT-IN W8A8 prefill (the policy's e4m3 weights + per-channel scales on the fp8 matrix cores, per-token e4m3 activations, no bf16 copy of the
+        weights; default off -- the reference's arithmetic for PerChannelFp8<> is W8A16)"""
         _check(load().mila_gemma_set_fp8_activation_prefill(self.h, int(bool(on))))
 
     def set_fused_prefill(self, on):

@@ -245,6 +245,14 @@ namespace Mila::Dnn
             if ( !graph_exec_ || captured_token_ != token.data() || captured_sample_in_graph_ != sample_in_graph_ || captured_ring_ != token_ring_ ) captureGraph( token, start_position );
         }
         bool graphCaptured() const noexcept { return graph_exec_ != nullptr; }
+        /// kernel nodes of the captured decode step (0 before a capture): the launches one token costs on the graph path
+        size_t graphNodeCount() const
+        {
+            if ( !graph_ ) return 0;
+            size_t n = 0;
+            hipCheck( hipGraphGetNodes( graph_, nullptr, &n ), "hipGraphGetNodes" );
+            return n;
+        }
         bool graphSamples() const noexcept { return graph_exec_ != nullptr && captured_sample_in_graph_; }
         /// when set, every replay ends with the greedy sampler writing the next token into the token buffer the graph reads from:
         /// a closed autoregressive loop with no host round trip.  Takes effect at the next ensureGraph() / captureGraph().
@@ -463,7 +471,7 @@ namespace Mila::Dnn
             for ( int i = 0; i < 2; ++i ) pf_x_[ i ] = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
             pf_norm_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
             pf_norm2_ = std::make_unique<TensorType>( dev, shape_t{ 1, P, D } );
-            if constexpr ( kFmt == 2 )
+            if constexpr ( kFmt != 0 )      // per-token e4m3 rows + scales of the fp8 x fp8 prefill paths (W4A8; W8A8 when the fp8 policy opts in)
                 for ( int i = 0; i < 2; ++i )
                 {
                     pf_q8_[ i ] = std::make_unique<TensorType>( dev, shape_t{ 1, P, ( D + 1 ) / 2 } );
@@ -514,6 +522,30 @@ namespace Mila::Dnn
             bool w4a8 = false;
             if constexpr ( kFmt == 2 )
                 w4a8 = L.fc_gate_up->getOperation().fp8ActivationPrefill() && mila_cdna4_gemm_fp8_applicable( T, (int)D, 2 * (int)cfg_.hidden_dim );
+            if constexpr ( kFmt == 1 )
+            {
+                // W8A8 (opt-in): the policy's e4m3 [2F, D] weights and per-channel scales straight into the fused fp8 x fp8 Linear + GeGLU kernel
+                auto& op = L.fc_gate_up->getOperation();
+                if ( op.fp8ActivationPrefill() && mila_cdna4_gemm_fp8_applicable( T, (int)D, 2 * (int)cfg_.hidden_dim ) )
+                {
+                    w4a8 = true;      // (below: never the bf16 fused form)
+                    if ( mila_cdna4_gemm_geglu_w4a8_applicable( T, (int)D, (int)cfg_.hidden_dim ) )
+                    {
+                        const auto* W8 = static_cast<const uint8_t*>( L.fc_gate_up->getWeight().rawData() );
+                        const float* sc = L.fc_gate_up->getWeightScale()->data();
+                        if ( x8_in && ts_in )
+                        {
+                            Compute::rocmCheck( mila_cdna4_gemm_geglu_fp8_w8a8( act.data(), x8_in, W8, ts_in, sc, T, (int)D, (int)cfg_.hidden_dim, st ) );
+                            return;
+                        }
+                        uint8_t* x8; float* ts;
+                        op.activationScratch( T, (int)D, x8, ts );
+                        Compute::rocmCheck( mila_cdna4_quantize_fp8_per_token( x8, ts, ffn_in.data(), T, (int)D, st ) );
+                        Compute::rocmCheck( mila_cdna4_gemm_geglu_fp8_w8a8( act.data(), x8, W8, ts, sc, T, (int)D, (int)cfg_.hidden_dim, st ) );
+                        return;
+                    }
+                }
+            }
             if constexpr ( kFmt == 2 )
             {
                 if ( w4a8 && mila_cdna4_gemm_geglu_w4a8_applicable( T, (int)D, (int)cfg_.hidden_dim ) && L.fc_gate_up->getOperation().weightFp8Scale() &&
@@ -588,7 +620,7 @@ namespace Mila::Dnn
             if ( !have_normed ) { normed = &L.input_norm->forward( x3 ); pf_q8_normed_ = false; }
             // W4A8 policy: the previous block's second tail wrote these rows quantized as well -- the Linear's own quantization launch is skipped (same bits)
             bool q8_in = false;
-            if constexpr ( kFmt == 2 ) q8_in = have_normed && pf_q8_normed_ && L.qkv_proj->getOperation().acceptsFp8Activations( T );
+            if constexpr ( kFmt != 0 ) q8_in = have_normed && pf_q8_normed_ && L.qkv_proj->getOperation().acceptsFp8Activations( T );
             auto& qkv = q8_in ? L.qkv_proj->forwardFp8Activations( static_cast<const uint8_t*>( pf_q8_[ 1 ]->rawData() ), pf_ts_[ 1 ]->data(), normed->shape() )
                               : L.qkv_proj->forward( *normed );
             auto q = q_->view( shape_t{ 1, T, NH * HD } );
@@ -604,9 +636,9 @@ namespace Mila::Dnn
             auto& o = L.o_proj->forward( attn );
             auto res1 = res1_->view( shape_t{ 1, T, D } );
             auto ffn_in = pf_norm2_->view( shape_t{ 1, T, D } );
-            // W4A8 policy: a tail whose normalised rows feed a Linear on the fp8 x fp8 path writes them quantized per token as well (fused_tail_norm_quant)
+            // W4A8 / W8A8: a tail whose normalised rows feed a Linear on the fp8 x fp8 path writes them quantized per token as well (fused_tail_norm_quant)
             bool q8_ffn = false, q8_next = false;
-            if constexpr ( kFmt == 2 )
+            if constexpr ( kFmt != 0 )
             {
                 auto& gu = L.fc_gate_up->getOperation();
                 q8_ffn = gu.acceptsFp8Activations( T ) && mila_cdna4_gemm_geglu_w4a8_applicable( T, (int)D, (int)cfg_.hidden_dim ) != 0;
@@ -640,7 +672,7 @@ namespace Mila::Dnn
         bool overlapApplicable( dim_t T ) const
         {
             if constexpr ( kFmt == 2 ) return false;       // the W4A8 path quantizes activations into per-op scratch sized for one call at a time
-            if constexpr ( kFmt == 1 ) { for ( auto& L : layers_ ) if ( !L.fc_down->getOperation().residentBf16() ) return false; }
+            if constexpr ( kFmt == 1 ) { for ( auto& L : layers_ ) if ( L.fc_down->getOperation().fp8ActivationPrefill() || !L.fc_down->getOperation().residentBf16() ) return false; }
             if ( !( T >= 1024 && T % 512 == 0 ) ) return false;
             // ... and so does a GEMM that splits K through the context's workspace (short tile lists: the same idle CUs this form is after); the split also depends on
             // the row count, so the halves would not carry the whole chunk's bits
@@ -746,10 +778,12 @@ namespace Mila::Dnn
         /// on (default): prefill runs the fused glue when the configuration fits; off: one launch per reference op.  Same bits.
         void setFusedPrefill( bool on ) { fused_prefill_ = on; }
         /// fp4 policy: W4A8 prefill (fp4 -> e4m3 weights, per-token e4m3 activations, fp8 MFMA; the reference's default) on every
-        /// layer Linear, or the exact-weight fallback (dequantize -> bf16 MFMA).  No effect on the other policies.
+        /// layer Linear, or the exact-weight fallback (dequantize -> bf16 MFMA).
+        /// fp8 policy: W8A8 prefill (the policy's e4m3 weights + per-channel scales on the fp8 matrix cores, no resident bf16 copy; default off -- the reference's
+        /// arithmetic for this policy is W8A16) on every layer Linear.  No effect on unquantized weights.
         void setFp8ActivationPrefill( bool on )
         {
-            if constexpr ( kFmt == 2 )
+            if constexpr ( kFmt != 0 )
                 for ( auto& L : layers_ )
                 {
                     L.qkv_proj->getOperation().setFp8ActivationPrefill( on ); L.o_proj->getOperation().setFp8ActivationPrefill( on );
@@ -1046,6 +1080,14 @@ namespace Mila::Dnn
             for ( auto& L : layers_ )
                 for ( auto* lin : { L.qkv_proj.get(), L.o_proj.get(), L.fc_gate_up.get(), L.fc_down.get() } ) lin->getOperation().setResidentPrefillWeights( on );
             ctx_->synchronize();
+        }
+        /// bytes of op-owned prefill staging the layer Linears hold right now (fp8 policy: bf16 copies, 0 while the W8A8 prefill is on; fp4 policy: e4m3 copies)
+        double residentStagingBytes() const
+        {
+            double b = 0;
+            for ( auto& L : layers_ )
+                for ( auto* lin : { L.qkv_proj.get(), L.o_proj.get(), L.fc_gate_up.get(), L.fc_down.get() } ) b += static_cast<double>( lin->getOperation().residentBytes() );
+            return b;
         }
     private:
         std::string name_{ "gemma" };      // the root's name (metadata.model_name in the reference); dropped from flat tensor names

@@ -124,9 +124,20 @@ namespace Mila::Dnn::Compute
                 if constexpr ( kFmt == 0 ) gemmWithWorkspace( y, x, static_cast<const uint16_t*>( weight_ ), M, K, N, 0, st );
                 else
                 {
-                    // resident prefill weights: the staging pass was run once, at load (same values => same bits as the staged call)
                     if constexpr ( kFmt == 1 )
                     {
+                        // W8A8 (opt-in, setFp8ActivationPrefill): the policy's own e4m3 weights + per-channel scales on the fp8 matrix cores, per-token e4m3 activations --
+                        // "FP8 matmul consumes weights and scales natively" (Quantization/Weight/Policies.ixx:39-40); no staging pass, no bf16 copy of the weights
+                        if ( use_fp8_activation_prefill_ && mila_cdna4_gemm_fp8_applicable( M, K, N ) )
+                        {
+                            uint8_t* x8; float* ts; void* ws;
+                            const size_t ws_bytes = mila_cdna4_gemm_fp8_workspace_bytes( M, K, N );
+                            activationScratch( M, K, x8, ts, ws_bytes, &ws );
+                            rocmCheck( mila_cdna4_quantize_fp8_per_token( x8, ts, x, M, K, st ) );
+                            rocmCheck( mila_cdna4_gemm_fp8_w8a8_ws( y, x8, static_cast<const uint8_t*>( weight_ ), ts, scales_, bias_, M, K, N, ws, ws_bytes, st ) );
+                            return;
+                        }
+                        // resident prefill weights: the staging pass was run once, at load (same values => same bits as the staged call)
                         if ( resident_bf16_ && mila_cdna4_gemm_staging_bytes( M, K, N ) != 0 )
                         {
                             gemmWithWorkspace( y, x, resident_bf16_->data(), M, K, N, 0, st );
@@ -237,7 +248,8 @@ namespace Mila::Dnn::Compute
         /// output already quantized per token (forwardFp8Activations) instead of as bf16
         bool acceptsFp8Activations( int M ) const
         {
-            if constexpr ( kFmt != 2 ) return false;
+            if constexpr ( kFmt == 0 ) return false;
+            else if constexpr ( kFmt == 1 ) return use_fp8_activation_prefill_ && mila_cdna4_gemm_fp8_applicable( M, (int)cfg_.in_features, (int)cfg_.out_features ) != 0;
             else return use_fp8_activation_prefill_ && weight_fp8_scale_ && resident_e4m3_ && mila_cdna4_gemm_fp8_applicable( M, (int)cfg_.in_features, (int)cfg_.out_features ) != 0;
         }
         /// the W4A8 forward on activations the caller quantized (x8 [M, K] e4m3, ts [M] per-token scales -- exactly what quantize_fp8_per_token gives): the same
@@ -245,11 +257,14 @@ namespace Mila::Dnn::Compute
         /// (x8 / ts are the caller's own buffers, NOT context scratch: the GEMM's split-K workspace is taken from there)
         void forwardFp8Activations( const uint8_t* x8, const float* ts, uint16_t* y, int M )
         {
-            if ( !acceptsFp8Activations( M ) ) throw std::logic_error( "RocmLinearOp::forwardFp8Activations: the W4A8 path does not serve this call" );
+            if ( !acceptsFp8Activations( M ) ) throw std::logic_error( "RocmLinearOp::forwardFp8Activations: the fp8 x fp8 path does not serve this call" );
             const int K = (int)cfg_.in_features, N = (int)cfg_.out_features;
             const size_t ws_bytes = mila_cdna4_gemm_fp8_workspace_bytes( M, K, N );
             void* ws = ws_bytes ? this->context_->getScratch( ws_bytes ) : nullptr;
-            rocmCheck( mila_cdna4_gemm_fp8_scaled_ws( y, x8, resident_e4m3_->data(), ts, weight_fp8_scale_->data(), bias_, M, K, N, ws, ws_bytes, this->context_->getStream() ) );
+            if constexpr ( kFmt == 1 )
+                rocmCheck( mila_cdna4_gemm_fp8_w8a8_ws( y, x8, static_cast<const uint8_t*>( weight_ ), ts, scales_, bias_, M, K, N, ws, ws_bytes, this->context_->getStream() ) );
+            else
+                rocmCheck( mila_cdna4_gemm_fp8_scaled_ws( y, x8, resident_e4m3_->data(), ts, weight_fp8_scale_->data(), bias_, M, K, N, ws, ws_bytes, this->context_->getStream() ) );
         }
         /// scratch for the per-token e4m3 activations + their scales (+ `extra` bytes behind them, 16-byte aligned: the GEMM's workspace) -- fetched per forward, never cached
         void activationScratch( int M, int K, uint8_t*& x8, float*& ts, size_t extra = 0, void** extra_out = nullptr ) const
@@ -259,11 +274,26 @@ namespace Mila::Dnn::Compute
             x8 = base; ts = reinterpret_cast<float*>( base + xb );
             if ( extra_out ) *extra_out = extra ? base + xb + tb : nullptr;
         }
-        /// fp4 policy: W4A8 prefill (default on, as in the reference) or the dequantize -> bf16 GEMM fallback
-        void setFp8ActivationPrefill( bool on ) noexcept { use_fp8_activation_prefill_ = on; }
+        /// fp4 policy: W4A8 prefill (default on, as in the reference) or the dequantize -> bf16 GEMM fallback.
+        /// fp8 policy: W8A8 prefill (default OFF: the reference's arithmetic for PerChannelFp8<> is W8A16, CudaLinearOp.ixx:597-644) -- the policy's e4m3 weights and
+        /// per-channel scales consumed by the fp8 matrix cores where they lie (Policies.ixx:39-40); while it is on the op holds no bf16 copy of its weights
+        void setFp8ActivationPrefill( bool on )
+        {
+            use_fp8_activation_prefill_ = on;
+            if constexpr ( kFmt == 1 )
+            {
+                if ( on ) resident_bf16_.reset();
+                else refreshResident();
+            }
+        }
         bool fp8ActivationPrefill() const noexcept { return use_fp8_activation_prefill_; }
         const float* weightFp8Scale() const noexcept { return weight_fp8_scale_ ? weight_fp8_scale_->data() : nullptr; }
 
+        /// bytes of the op-owned resident staging (0 when off, when W8A8 is on, or for unquantized weights)
+        size_t residentBytes() const noexcept
+        {
+            return ( resident_bf16_ ? resident_bf16_->size() * 2 : 0 ) + ( resident_e4m3_ ? resident_e4m3_->size() : 0 ) + ( weight_fp8_scale_ ? sizeof( float ) : 0 );
+        }
         const void* weightPtr() const noexcept { return weight_; }
         const float* scalesPtr() const noexcept { return scales_; }
         const LinearOpConfig& config() const noexcept { return cfg_; }
@@ -274,7 +304,7 @@ namespace Mila::Dnn::Compute
         const uint16_t* bias_{ nullptr };
         const float* scales_{ nullptr };
         bool built_{ false };
-        bool use_fp8_activation_prefill_{ true };
+        bool use_fp8_activation_prefill_{ kFmt == 2 };
         bool resident_{ true };
         std::unique_ptr<Tensor<TensorDataType::FP32, RocmDeviceMemoryResource>> weight_fp8_scale_;
         std::unique_ptr<RocmBf16Tensor> resident_bf16_;
@@ -291,6 +321,7 @@ namespace Mila::Dnn::Compute
             {
                 if constexpr ( kFmt == 1 )
                 {
+                    if ( use_fp8_activation_prefill_ ) return;      // W8A8 reads the policy's own e4m3 weights: nothing to stage
                     if ( !resident_bf16_ ) resident_bf16_ = std::make_unique<RocmBf16Tensor>( this->context_->getDeviceId(), shape_t{ cfg_.out_features, cfg_.in_features } );
                 }
                 else if constexpr ( kFmt == 2 )

@@ -531,6 +531,20 @@ HOST_API int mila_gemma_info( void* h, int64_t context, double* out )
     } );
 }
 
+/// nodes of the captured decode graph (0 before the first graph-mode step)
+HOST_API int mila_gemma_graph_node_count( void* h, int64_t* out )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&] { std::visit( [&]( auto& m ) { *out = static_cast<int64_t>( m->graphNodeCount() ); }, r->model ); } );
+}
+
+/// bytes of op-owned resident prefill staging held by the layer Linears at this moment
+HOST_API int mila_gemma_resident_staging_bytes( void* h, double* out )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&] { std::visit( [&]( auto& m ) { *out = m->residentStagingBytes(); }, r->model ); } );
+}
+
 /// component names of the model, '\n'-separated, in construction order (children of each block, then temb / rmsn_final / lm_head);
 /// returns the length needed (including the terminator); writes at most `cap` bytes
 HOST_API int64_t mila_gemma_component_names( void* h, char* buf, int64_t cap )

@@ -9,6 +9,7 @@ The Linear and attention contractions run on float64 BLAS instead of the C oracl
 1e-16: far below every bf16 rounding boundary that matters); everything else IS tests/ref_gemma.py.
 
     python tests/golden/make_gemma_fullwidth_golden.py            # ~15 minutes on 8 cores, ~20 GB of host memory
+    python tests/golden/make_gemma_fullwidth_golden.py --w8a8     # the fp8 policy with the opt-in W8A8 prefill -> gemma_fullwidth_logits_w8a8.npz (~5 minutes)
 """
 import os
 import sys
@@ -49,6 +50,8 @@ class BlasRef(RefGemma):
         rows = x2.reshape(-1, x2.shape[-1]).shape[0]
         if W[0] == "fp4" and self.w4a8_prefill and round_out and rows > 1:
             return self._linear_w4a8(x2, W)
+        if W[0] == "fp8" and self.w8a8_prefill and round_out and rows > 1:
+            return self._linear_w8a8(x2, W)
         if W[0] != "bf16" and self.staged_prefill and round_out and rows > 1:
             Wf = orc.dequant_fp8(W[1], W[2]) if W[0] == "fp8" else orc.dequant_fp4(W[1], W[2], 128)
             y = x2.astype(np.float64) @ bf(Wf).astype(np.float64).T
@@ -71,6 +74,14 @@ class BlasRef(RefGemma):
         raw = ((orc.E4M3_LUT[x8].astype(np.float64) @ w8f.T) * float(ws)).astype(np.float32)          # sB * acc
         y = bf(raw).astype(np.float32) * ts.astype(np.float32)[:, None]
         return self.r(y).reshape(shp[:-1] + (w8f.shape[0],))
+
+
+    def _linear_w8a8(self, x, W):
+        Wf, post = self._dense(W)                                                                   # e4m3 values, per-channel scales
+        shp = x.shape
+        x8, ts = orc.quantize_act_fp8_per_token(x.reshape(-1, shp[-1]))
+        y = ((orc.E4M3_LUT[x8].astype(np.float64) @ Wf.T) * post[None, :] * ts.astype(np.float64)[:, None]).astype(np.float32)
+        return self.r(y).reshape(shp[:-1] + (Wf.shape[0],))
 
 
 def blas_attention(q, K, V, pos, window, scale):
@@ -96,9 +107,11 @@ def main():
     out = {"cfg_keys": np.array(list(CFG)), "cfg_vals": np.array([CFG[k] for k in CFG], dtype=np.int64), "seed": np.int64(SEED), "tokens": np.array(TOKENS, dtype=np.int32),
            "next_tokens": np.array(NEXT, dtype=np.int32), "max_seq": np.int64(MAX_SEQ),
            "profile_keys": np.array(list(CONDITIONED_PROFILE)), "profile_vals": np.array([CONDITIONED_PROFILE[k] for k in CONDITIONED_PROFILE], dtype=np.float64)}
-    for policy in ("bf16", "fp8", "fp4"):
+    # --w8a8: the fp8 policy with the opt-in W8A8 prefill only, into its own fixture (gemma_fullwidth_logits_w8a8.npz): the decode steps then read the caches THAT prefill wrote
+    w8a8 = "--w8a8" in sys.argv
+    for policy in (("fp8",) if w8a8 else ("bf16", "fp8", "fp4")):
         t0 = time.time()
-        ref = BlasRef(CFG, policy, SEED, profile=CONDITIONED_PROFILE, staged_prefill=True, w4a8_prefill=True)
+        ref = BlasRef(CFG, policy, SEED, profile=CONDITIONED_PROFILE, staged_prefill=True, w4a8_prefill=True, w8a8_prefill=w8a8)
         ref._dense_cache = {}
         rows = [ref.forward(TOKENS, 0, MAX_SEQ)]
         ref._w8 = {}
@@ -108,8 +121,9 @@ def main():
         out["logits_" + policy] = np.stack(rows).astype(np.float32)
         print("%s done: %.0f s, max|logit| %.3f" % (policy, time.time() - t0, float(np.abs(rows[0]).max())), flush=True)
         del ref
-    np.savez_compressed(os.path.join(HERE, "gemma_fullwidth_logits.npz"), **out)
-    print("wrote", os.path.join(HERE, "gemma_fullwidth_logits.npz"))
+    name = "gemma_fullwidth_logits_w8a8.npz" if w8a8 else "gemma_fullwidth_logits.npz"
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", os.path.join(HERE, name))
 
 
 if __name__ == "__main__":

@@ -29,7 +29,7 @@ CONDITIONED_PROFILE = dict(linear_gain=1.0, qk_norm_center=0.35, post_norm_cente
 
 
 class RefGemma:
-    def __init__(self, cfg, policy, seed, exact=False, profile=None, f32_stand_in=False, staged_prefill=False, w4a8_prefill=False, w4a8_f32_order=False):
+    def __init__(self, cfg, policy, seed, exact=False, profile=None, f32_stand_in=False, staged_prefill=False, w4a8_prefill=False, w4a8_f32_order=False, w8a8_prefill=False):
         self.c = dict(cfg)
         self.policy = policy
         self.exact = exact          # True: keep every intermediate in FP32 (the wiring check against the HF FP32 forward)
@@ -42,6 +42,9 @@ class RefGemma:
         # to e4m3 against the per-tensor scale sB, the activations quantized per token to e4m3, an fp8 x fp8 contraction, and the two-step epilogue
         # bf16(float(bf16(acc * sB)) * s_m).  Takes precedence over staged_prefill for fp4 weights.
         self.w4a8_prefill = w4a8_prefill
+        # True (fp8 policy only): a T > 1 forward runs the OPT-IN W8A8 prefill (RocmLinearOp::setFp8ActivationPrefill on PerChannelFp8<>; Policies.ixx:39-40): the policy's own e4m3
+        # weights, per-token e4m3 activations (CudaFp8Prefill.cu:108-160), an fp8 x fp8 contraction, y = bf16((acc * scale[n]) * s_m).  Takes precedence over staged_prefill.
+        self.w8a8_prefill = w8a8_prefill
         self.w4a8_f32_order = w4a8_f32_order      # tests/test_conditioned_cpu.py: the same arithmetic accumulated in FP32 in another order (a second correct implementation)
         self._w8 = {}
         self.f32_stand_in = f32_stand_in   # tools/condition_probe.py only: FP32 BLAS accumulation as a stand-in for another summation order
@@ -95,6 +98,8 @@ class RefGemma:
         rows = np.asarray(x).reshape(-1, np.asarray(x).shape[-1]).shape[0]
         if W[0] == "fp4" and self.w4a8_prefill and round_out and rows > 1:
             return self._linear_w4a8(x, W)
+        if W[0] == "fp8" and self.w8a8_prefill and round_out and rows > 1:
+            return self._linear_w8a8(x, W)
         if W[0] == "bf16":
             y = orc.linear_bf16w(x, W[1])
         elif self.staged_prefill and round_out and np.asarray(x).reshape(-1, np.asarray(x).shape[-1]).shape[0] > 1:
@@ -124,6 +129,14 @@ class RefGemma:
             raw = orc.linear_fp8a_fp8w(x8, np.ones(len(ts), dtype=np.float32), w8, None, ws)      # sB * acc
         y = bf(raw).astype(np.float32) * ts.astype(np.float32)[:, None]
         return self.r(y).reshape(shp[:-1] + (w8.shape[0],))
+
+    def _linear_w8a8(self, x, W):
+        """the fp8 policy's weights as they are stored (e4m3 [N, K] + scale[N]) x per-token e4m3 activations: (acc * scale[n]) * s_m, one rounding (csrc/common.h: w8a8_scale_bias)"""
+        x2 = np.asarray(x, dtype=np.float32)
+        shp = x2.shape
+        x8, ts = orc.quantize_act_fp8_per_token(x2.reshape(-1, shp[-1]))
+        y = orc.linear_fp8a_fp8w(x8, ts, W[1], W[2], 1.0)
+        return self.r(y).reshape(shp[:-1] + (W[1].shape[0],))
 
     def rms(self, x, w):
         return self.r(orc.rmsnorm(x, w, None, eps=1e-6))

@@ -87,7 +87,7 @@ def test_validation_rejects_bad_arguments_without_touching_the_device(lib):
         == capi.MILA_E_INVALID_ARGUMENT
     assert lib.mila_cdna4_rope_forward_bf16(one, null, one, null, one, one, 1, 4, 2, 1, 64, 30, 32, null) \
         == capi.MILA_E_INVALID_ARGUMENT
-    assert lib.mila_cdna4_abi_version() == 3
+    assert lib.mila_cdna4_abi_version() == 4
     assert lib.mila_cdna4_attn_decode_scratch_bytes(1, 16, 256) == 16 * 64 * 260 * 4      # [NH, max splits, HS + 4] floats
     assert lib.mila_cdna4_attn_decode_scratch_bytes(1, 16, 512) == 16 * 256 * 516 * 4 + 16 * 512 * 2      # HS 512: the long-context matrix-core decode's 256 splits + its roped q rows
 

@@ -30,9 +30,16 @@ def _rel(got, exp):
     return float(np.abs(got.astype(np.float64) - exp.astype(np.float64)).max() / np.abs(exp).max())
 
 
-@pytest.mark.parametrize("policy", ["bf16", "fp8", "fp4"])
+FIXTURE_W8A8 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gemma_fullwidth_logits_w8a8.npz")
+
+
+@pytest.mark.parametrize("policy", ["bf16", "fp8", "fp4", "fp8-w8a8"])
 def test_full_width_model_holds_the_logit_bar_on_the_benchmarked_kernels(policy):
-    fx = np.load(FIXTURE, allow_pickle=False)
+    # "fp8-w8a8": the PerChannelFp8<> policy with the opt-in W8A8 prefill (setFp8ActivationPrefill: the policy's own e4m3 weights + per-channel scales on the fp8 matrix
+    # cores, per-token e4m3 activations) against its own fixture -- the same composition with that Linear arithmetic at T > 1 (make_gemma_fullwidth_golden.py --w8a8)
+    w8a8 = policy == "fp8-w8a8"
+    fx = np.load(FIXTURE_W8A8 if w8a8 else FIXTURE, allow_pickle=False)
+    policy = "fp8" if w8a8 else policy
     cfg = {str(k): int(v) for k, v in zip(fx["cfg_keys"], fx["cfg_vals"])}
     profile = {str(k): float(v) for k, v in zip(fx["profile_keys"], fx["profile_vals"])}
     tokens, nxt = fx["tokens"].astype(np.int32), [int(t) for t in fx["next_tokens"]]
@@ -41,9 +48,12 @@ def test_full_width_model_holds_the_logit_bar_on_the_benchmarked_kernels(policy)
     assert cfg["embedding_dim"] == 3840 and cfg["hidden_dim"] == 15360 and cfg["window"] == 1024 and T == 2048
     g = host.Gemma(policy, cfg, max_seq=int(fx["max_seq"]), max_prefill=T, seed=int(fx["seed"]), profile=profile)
     try:
+        if w8a8:
+            g.set_fp8_activation_prefill(True)
+            policy = "fp8-w8a8"
         got = g.prefill(tokens)
         errs = {"prefill T=2048": _rel(got, exp[0])}
-        bar = BAR_W4A8_PREFILL if policy == "fp4" else BAR
+        bar = BAR_W4A8_PREFILL if policy in ("fp4", "fp8-w8a8") else BAR
         assert np.all(np.isfinite(got))
         lines = ["%s prefill T=%d: %.2e of max|logit| (bar %.0e)" % (policy, T, errs["prefill T=2048"], bar)]
         worst_decode = 0.0

@@ -546,3 +546,51 @@ def test_a_long_capacity_model_takes_the_matrix_core_decode_on_every_path():
     assert worst < 1e-1, worst
     for g in models.values():
         g.close()
+
+
+@pytest.mark.parametrize("cfg_name,T", [("MEDIUM", 24), ("WIDE_FFN", 1024)])
+def test_w8a8_opt_in_prefill_of_the_fp8_policy(cfg_name, T):
+    """PerChannelFp8<> with setFp8ActivationPrefill(true) (row g1; Policies.ixx:39-40): every layer Linear of a T > 1 forward runs fp8 x fp8 on the policy's own e4m3
+    weights -- the fused-glue prefill (tails hand over per-token e4m3 rows, fused Linear + GeGLU) and the one-launch-per-op prefill give identical bits; the default stays
+    W8A16 (another function: the logits differ, and switching back restores the default's bits); decode is untouched by the switch"""
+    cfg = {"MEDIUM": MEDIUM, "WIDE_FFN": WIDE_FFN}[cfg_name]
+    toks = [(13 * i + 5) % 2048 for i in range(T)]
+    a = host.Gemma("fp8", cfg, max_seq=T + 8, max_prefill=T, seed=3)
+    b = host.Gemma("fp8", cfg, max_seq=T + 8, max_prefill=T, seed=3)
+    default = a.prefill(toks)
+    d_default = a.decode(11, T, "fused")
+    a.set_fp8_activation_prefill(True)
+    b.set_fp8_activation_prefill(True)
+    b.set_fused_prefill(False)
+    la, lb = a.prefill(toks), b.prefill(toks)
+    assert np.all(np.isfinite(la)) and np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    assert not np.array_equal(la.view(np.uint32), default.view(np.uint32)), "the switch changed nothing"
+    da, db = a.decode(11, T, "fused"), b.decode(11, T, "fused")
+    assert np.array_equal(da.view(np.uint32), db.view(np.uint32))
+    # the same function up to the activation quantization: the reference's own bar for an activation-quantized prefill is 1e-1 of the row's range for ONE Linear
+    # (Linear.Cuda.cpp:760-774); through these random-weight layers the logits stay well correlated
+    assert float(np.dot(la, default) / (np.linalg.norm(la) * np.linalg.norm(default))) > 0.9
+    # off again: the resident bf16 staging is rebuilt and the default's bits return
+    a.set_fp8_activation_prefill(False)
+    assert np.array_equal(a.prefill(toks).view(np.uint32), default.view(np.uint32))
+    assert np.array_equal(a.decode(11, T, "fused").view(np.uint32), d_default.view(np.uint32))
+    a.close()
+    b.close()
+
+
+def test_w8a8_prefill_follows_the_oracle_composition():
+    """the W8A8 prefill against tests/ref_gemma.py with that Linear arithmetic (per-token e4m3 activations x the policy's e4m3 weights, (acc * scale[n]) * s_m): unit-scale
+    random weights amplify a 1-ulp bf16 difference ~1.4x per block and an e4m3 activation step is 6 %, so -- as for the W4A8 leg above -- this guards the ARITHMETIC
+    (W8A16 instead of W8A8 sits several times further away); the conditioned full-width model holds the same path to 1e-3 (tests/test_gemma_fullwidth_gpu.py)"""
+    T = 11
+    a = host.Gemma("fp8", SMALL, max_seq=MAX_SEQ, max_prefill=16, seed=3)
+    a.set_fp8_activation_prefill(True)
+    lp = a.prefill(TOKENS[:T])
+    ref = RefGemma(SMALL, "fp8", seed=3, w8a8_prefill=True)
+    exp = ref.forward(TOKENS[:T], 0, MAX_SEQ)
+    assert np.abs(lp - exp).max() <= 2.5e-1 * np.abs(exp).max()
+    assert float(np.dot(lp, exp) / (np.linalg.norm(lp) * np.linalg.norm(exp))) > 0.97
+    exp1 = ref.forward([TOKENS[T]], T, MAX_SEQ)
+    l1 = a.decode(TOKENS[T], T, "fused")
+    assert np.abs(l1 - exp1).max() <= 2.5e-1 * np.abs(exp1).max()
+    a.close()
