@@ -49,6 +49,24 @@ def _report(tag, got, exp):
     return float(rel.max())
 
 
+def test_fp8_policy_w8a8_opt_in_prefill_on_the_conditioned_model():
+    """PerChannelFp8<> with setFp8ActivationPrefill(true) (row g1): the policy's own e4m3 weights x per-token e4m3 activations on the fp8 matrix cores, against the
+    oracle composition with that Linear arithmetic at T > 1 (RefGemma w8a8_prefill).  Per-token e4m3 activations -> the W4A8 leg's bar (see BAR_W4A8_PREFILL)."""
+    refp = RefGemma(CFG, "fp8", seed=7, profile=CONDITIONED_PROFILE, w8a8_prefill=True)
+    exp = refp.forward(TOKENS, 0, MAX_SEQ)
+    p = host.Gemma("fp8", CFG, max_seq=MAX_SEQ, max_prefill=32, seed=7, profile=CONDITIONED_PROFILE)
+    p.set_fp8_activation_prefill(True)
+    got = p.prefill(TOKENS)
+    assert _report("fp8-w8a8 prefill T=%d" % len(TOKENS), got, exp) <= BAR_W4A8_PREFILL
+    exp1 = refp.forward([5], len(TOKENS), MAX_SEQ)
+    assert _report("fp8-w8a8 decode after prefill", p.decode(5, len(TOKENS), "fused"), exp1) <= BAR_W4A8_PREFILL
+    # and it IS another function than the policy's default W8A16 prefill (tests/test_conditioned_cpu.py measures 3.2e-3 between the two compositions)
+    w8a16 = RefGemma(CFG, "fp8", seed=7, profile=CONDITIONED_PROFILE, staged_prefill=True).forward(TOKENS, 0, MAX_SEQ)
+    _report("fp8-w8a8 prefill vs the W8A16 composition (another function)", got, w8a16)
+    assert np.abs(got - w8a16).max() > BAR * np.abs(w8a16).max()
+    p.close()
+
+
 @pytest.mark.parametrize("policy", ["bf16", "fp8", "fp4"])
 def test_conditioned_12_layer_model_holds_1e3_on_decode_and_prefill(policy):
     ref = RefGemma(CFG, policy, seed=7, profile=CONDITIONED_PROFILE)

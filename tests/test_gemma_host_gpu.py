@@ -576,21 +576,3 @@ def test_w8a8_opt_in_prefill_of_the_fp8_policy(cfg_name, T):
     assert np.array_equal(a.decode(11, T, "fused").view(np.uint32), d_default.view(np.uint32))
     a.close()
     b.close()
-
-
-def test_w8a8_prefill_follows_the_oracle_composition():
-    """the W8A8 prefill against tests/ref_gemma.py with that Linear arithmetic (per-token e4m3 activations x the policy's e4m3 weights, (acc * scale[n]) * s_m): unit-scale
-    random weights amplify a 1-ulp bf16 difference ~1.4x per block and an e4m3 activation step is 6 %, so -- as for the W4A8 leg above -- this guards the ARITHMETIC
-    (W8A16 instead of W8A8 sits several times further away); the conditioned full-width model holds the same path to 1e-3 (tests/test_gemma_fullwidth_gpu.py)"""
-    T = 11
-    a = host.Gemma("fp8", SMALL, max_seq=MAX_SEQ, max_prefill=16, seed=3)
-    a.set_fp8_activation_prefill(True)
-    lp = a.prefill(TOKENS[:T])
-    ref = RefGemma(SMALL, "fp8", seed=3, w8a8_prefill=True)
-    exp = ref.forward(TOKENS[:T], 0, MAX_SEQ)
-    assert np.abs(lp - exp).max() <= 2.5e-1 * np.abs(exp).max()
-    assert float(np.dot(lp, exp) / (np.linalg.norm(lp) * np.linalg.norm(exp))) > 0.97
-    exp1 = ref.forward([TOKENS[T]], T, MAX_SEQ)
-    l1 = a.decode(TOKENS[T], T, "fused")
-    assert np.abs(l1 - exp1).max() <= 2.5e-1 * np.abs(exp1).max()
-    a.close()
