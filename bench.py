@@ -285,12 +285,14 @@ def main():
     ap.add_argument("--attn-split", type=int, default=None, help="tuning hook: positions per flash-decode split (default 64)")
     ap.add_argument("--resident", type=int, default=None, help="1/0: resident prefill staging for the quantized policies (default: the model's = 1)")
     ap.add_argument("--gemm-schedule", type=int, default=None, help="tuning hook: 0 lockstep, 1 ping-pong (4 phases), 3 ping-pong (2 phases, default)")
+    ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE", help="named tuning variable (csrc/internal.h: mila_cdna4_tune), repeatable; experiments only")
+    ap.add_argument("--bounded-local-kv", type=int, default=0, help="1: SlidingWindowKvCache on the sliding-window layers (bounded ring of window + chunk - 1 rows)")
     a = ap.parse_args()
 
     # N > 1 and no launcher env: this process only starts one child per GPU (it never initialises a GPU itself)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_replicas(a.gpus, sys.argv[1:]))
-    if a.attn_split is not None or a.gemm_schedule is not None:
+    if a.attn_split is not None or a.gemm_schedule is not None or a.tune:
         os.environ["MILA_CDNA4_TUNING"] = "1"      # the tuning hooks are inert unless asked for before the library loads (csrc/internal.h)
 
     from mila_amd import host
@@ -300,6 +302,8 @@ def main():
     if a.gpus != world:
         print("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d" % (a.gpus, world, world), file=sys.stderr)
     cfg = dict(host.GEMMA4_12B)
+    if a.bounded_local_kv:
+        cfg["bounded_local_kv"] = 1
     policies = [p for p in a.policies.split(",") if p]
 
     # the CPU baseline FIRST (rank 0 of the single-GPU line only): the GPU phases then run back to back to the end of the process
@@ -329,6 +333,9 @@ def main():
         capi.check(capi.load().mila_cdna4_tune_attn_split(a.attn_split))
     if a.gemm_schedule is not None:
         capi.check(capi.load().mila_cdna4_tune_gemm_schedule(a.gemm_schedule))
+    for kv in a.tune:
+        name, value = kv.split("=", 1)
+        capi.tune(name, int(value))
     results = {}
     CHUNK = CONTEXT                      # the prefill chunk (BASELINE config 3-5: T = 2048)
     ctx = a.context if a.context else CONTEXT
@@ -448,7 +455,8 @@ def main():
         "dtype": {"bf16": "bf16", "fp8": "bf16 activations x fp8_e4m3 weights", "fp4": "bf16 activations x fp4_e2m1 weights"}[policies[0]],
         "data": "synthetic (counter-based uniform weights, random-init architecture; KV cache filled by %s)" % ("a T=2048 prefill" if ctx == CONTEXT else "a chunked prefill of %d tokens (chunks of 2048)" % ctx),
         "config": {"workload": "Gemma-4 12B, weight policy %s, B=1, prefill T=2048%s then decode at positions %d.." % (policies[0], "" if ctx == CONTEXT else " (chunked to %d)" % ctx, ctx),
-                   "decode_mode": a.mode, "replicas": world, "parallelism": "replicas only (no collective)"},
+                   "decode_mode": a.mode, "replicas": world, "parallelism": "replicas only (no collective)", "bounded_local_kv": int(bool(a.bounded_local_kv)),
+                   **({"tune": a.tune} if a.tune else {})},
         "roofline": {"bound": "hbm", "achieved": head["dominant_kernel"]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(head["dominant_kernel"]["GBps"] / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(policies[0])[0],
                      "traffic_source": measured_traffic(policies[0])[1],

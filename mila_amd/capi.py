@@ -117,6 +117,24 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def tune(name, value):
+    """set a named tuning variable (csrc/internal.h; the process must have set MILA_CDNA4_TUNING=1 before the library loaded)"""
+    check(load().mila_cdna4_tune(name.encode(), C.c_int(int(value))))
+
+
+def tune_reset():
+    check(load().mila_cdna4_tune_reset())
+
+
+def last_form():
+    """the kernel forms this thread's Linear / attention entry points ran since the previous call, as a list; clears the record"""
+    lib = load()
+    lib.mila_cdna4_last_form.restype = C.c_size_t
+    buf = C.create_string_buffer(512)
+    lib.mila_cdna4_last_form(buf, C.c_size_t(512))
+    return [f for f in buf.value.decode().split("+") if f]
+
+
 def check(rc):
     if rc == MILA_OK:
         return
@@ -170,6 +188,7 @@ EXPORTED = [
 
 # csrc/internal.h: test / tuning hooks and the measured-slower experiments -- exported, but not part of the drop-in ABI
 INTERNAL = [
+    "tune", "tune_get", "tune_reset", "tune_list", "last_form",
     "tune_matvec", "tune_gemm", "tune_gemm_schedule", "tune_gemm_fp8_tail_only", "tune_attn_split", "tune_flash_dsplit", "decode_engine_debug",
     "selftest_decode", "selftest_wave_reduce", "selftest_mfma_fp8", "stream_copy", "stream_read",
     "attn_decode_split_count", "fused_attn_decode_partials_bf16", "matvec_attn_combine",

@@ -75,6 +75,8 @@ struct AttnParams
     int NH, NKV, capacity, position, window, splits;
     float scale;
     const int32_t* pos_dev;   // when set: the position is read from device memory (graph replay)
+    int flat;                 // XCD-local grid (attn.xcd_local): blockIdx.x = group + ngroups * split, so that every split of a head group -- and the combine
+                              // workgroups of its heads -- carry the same blockIdx.x % 8 and land on one XCD (workgroups are dealt round-robin over the 8 XCDs)
     // fused prologue (GemmaBlock::decode lines 315-337 folded in): raw projections + norm weights + RoPE cache
     int64_t raw_b_stride;     // elements between two batch rows of q_raw / k_raw / v_raw (a packed [B, 1, q | k | v] projection row; unused at B == 1)
     const uint16_t* q_raw;    // [NH*HS] per batch row
@@ -223,14 +225,16 @@ __global__ __launch_bounds__(kDecodeWaves * 64) void attn_decode_kernel(const At
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool owner = lane < ACTIVE;
     const int GS = p.NH / p.NKV, hgroups = GS / GH;
-    if ((int)blockIdx.x >= p.splits)                        // a warm block (block-uniform): no barrier is shared with the others
+    if (!p.flat && (int)blockIdx.x >= p.splits)             // a warm block (block-uniform): no barrier is shared with the others
     {
         const int64_t wb = ((int64_t)(blockIdx.x - p.splits) * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
         warm_lines(p.warm_a, p.warm_a_lines, wb * (NW * 64) + threadIdx.x, (int64_t)p.warm_a_blocks * gridDim.y * gridDim.z * (NW * 64),
                    p.scratch);
         return;
     }
-    const int split = blockIdx.x, kvh = blockIdx.y / hgroups, hg = blockIdx.y % hgroups;
+    const int ngrp = p.NKV * hgroups;
+    const int split = p.flat ? (int)blockIdx.x / ngrp : (int)blockIdx.x, grp = p.flat ? (int)blockIdx.x % ngrp : (int)blockIdx.y;
+    const int kvh = grp / hgroups, hg = grp % hgroups;
     const int h0 = kvh * GS + hg * GH;                     // first query head of this workgroup
     const int b = blockIdx.z;
     const int pos = p.pos_dev ? *p.pos_dev : p.position;
@@ -511,17 +515,26 @@ __global__ __launch_bounds__(kDecodeWaves * 64) void attn_decode_kernel(const At
 // combine split partials: grid (NH, B, HS/64), 64 threads -> 64 dims each; splits <= 64.
 // Every thread reads all (m, l) pairs itself (broadcast loads) and all partial values of its dim in
 // unrolled batches, so the kernel is two dependent memory round trips long.
+// flat_gh > 0 (attn.xcd_local): grid (NH * HS / 64, B): blockIdx.x = group + ngroups * (head in group + flat_gh * dim chunk), groups of flat_gh heads -- the
+// workgroups of a head group share blockIdx.x % 8 with the decode workgroups that wrote its partials
 __global__ __launch_bounds__(64) void attn_combine_kernel(uint16_t* __restrict__ Y, const float* __restrict__ scratch, int NH,
-                                                          int HS, int splits, const uint8_t* __restrict__ warm, int64_t warm_lines_n, int64_t warm_pair)
+                                                          int HS, int splits, const uint8_t* __restrict__ warm, int64_t warm_lines_n, int64_t warm_pair, int flat_gh)
 {
-    const int h = blockIdx.x, b = blockIdx.y;
-    if ((int)blockIdx.z >= HS / 64)                         // warm blocks (see AttnParams::warm_b)
+    int h = blockIdx.x, zc = blockIdx.z;
+    const int b = blockIdx.y;
+    if (flat_gh > 0)
+    {
+        const int ngroups = NH / flat_gh, grp = (int)blockIdx.x % ngroups, r = (int)blockIdx.x / ngroups;
+        h = grp * flat_gh + r % flat_gh;
+        zc = r / flat_gh;
+    }
+    else if ((int)blockIdx.z >= HS / 64)                    // warm blocks (see AttnParams::warm_b)
     {
         const int64_t wb = ((int64_t)(blockIdx.z - HS / 64) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         warm_lines(warm, warm_lines_n, wb * 64 + threadIdx.x, (int64_t)(gridDim.z - HS / 64) * gridDim.y * gridDim.x * 64, nullptr, warm_pair);
         return;
     }
-    const int d = blockIdx.z * 64 + threadIdx.x;
+    const int d = zc * 64 + threadIdx.x;
     const float* base = scratch + ((size_t)b * NH + h) * splits * (HS + 4);
     Y[((size_t)b * NH + h) * HS + d] = combine_dim<false>(base, HS, splits, d);
 }
@@ -781,7 +794,9 @@ static int launch_decode_mfma(const AttnParams& p, int B, hipStream_t s)
     return check_hip(hipGetLastError(), "attn_combine_many");
 }
 
-static int heads_per_group(int GS, int HS) { return HS >= 512 ? (GS >= 2 ? 2 : 1) : (GS >= 4 ? 4 : GS); }
+static int g_attn_gh512 = 2;      // query heads per workgroup at HS 512 (experiment: 4 = half the head groups re-reading each K / V row, twice the accumulators per wave)
+MILA_TUNE("attn.heads_per_group_512", g_attn_gh512);
+static int heads_per_group(int GS, int HS) { return HS >= 512 ? (GS >= g_attn_gh512 && g_attn_gh512 == 4 ? 4 : (GS >= 2 ? 2 : 1)) : (GS >= 4 ? 4 : GS); }
 
 template <int HS, int GH, bool FUSED>
 static int launch_decode(const AttnParams& p, int B, hipStream_t s)
@@ -789,6 +804,15 @@ static int launch_decode(const AttnParams& p, int B, hipStream_t s)
     const int hgroups = (p.NH / p.NKV) / GH;
     const size_t lds = (size_t)kDecodeWaves * GH * (HS + 2) * sizeof(float) + (size_t)(GH + 2) * HS * 2;
     const int wa = (p.warm_a && p.warm_a_lines > 0) ? p.warm_a_blocks : 0;
+    if (p.flat)
+    {
+        // (only taken without warm blocks, tickets or a caller-side combine: run_decode)
+        hipLaunchKernelGGL((attn_decode_kernel<HS, GH, FUSED>), dim3(p.NKV * hgroups * p.splits, 1, B), dim3(kDecodeWaves * 64), lds, s, p);
+        int rc = check_hip(hipGetLastError(), "attn_decode (xcd-local)");
+        if (rc || p.splits <= 1) return rc;
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(p.NH * (HS / 64), B, 1), dim3(64), 0, s, p.Y, p.scratch, p.NH, HS, p.splits, nullptr, 0, 0, GH);
+        return check_hip(hipGetLastError(), "attn_combine (xcd-local)");
+    }
     hipLaunchKernelGGL((attn_decode_kernel<HS, GH, FUSED>), dim3(p.splits + wa, p.NKV * hgroups, B), dim3(kDecodeWaves * 64), lds, s, p);
     int rc = check_hip(hipGetLastError(), "attn_decode");
     if (rc) return rc;
@@ -796,7 +820,7 @@ static int launch_decode(const AttnParams& p, int B, hipStream_t s)
     {
         const int wbk = (p.warm_b && p.warm_b_lines > 0) ? p.warm_b_blocks : 0;
         hipLaunchKernelGGL(attn_combine_kernel, dim3(p.NH, B, HS / 64 + wbk), dim3(64), 0, s, p.Y, p.scratch, p.NH, HS, p.splits, p.warm_b,
-                           p.warm_b_lines, p.warm_b_pair);
+                           p.warm_b_lines, p.warm_b_pair, 0);
         rc = check_hip(hipGetLastError(), "attn_combine");
     }
     return rc;
@@ -841,13 +865,20 @@ static int dispatch_hs(int HS, const AttnParams& p, int B, hipStream_t s)
 }
 
 static int g_tune_positions_per_split = 64;     // tuning hook (mila_cdna4_tune_attn_split): positions one split covers
+MILA_TUNE("attn.positions_per_split", g_tune_positions_per_split);
+// Experiment (round 4): every split of a head group and the combine workgroups of its heads on ONE XCD (blockIdx.x % 8 equal), so that the merge
+// reads the partials from that XCD's L2 instead of across the fabric.  Same arithmetic per workgroup: bit-identical.  Result: profiles/r04_attn_pair_experiments.txt
+static int g_attn_xcd_local = 0;
+MILA_TUNE("attn.xcd_local", g_attn_xcd_local);
+static int g_attn_max_wgs = 256;                // decode_splits: the split count is capped so that a launch has about this many workgroups
+MILA_TUNE("attn.max_workgroups", g_attn_max_wgs);
 
 static int decode_splits(int B, int NH, int NKV, int HS, int band)
 {
     // ~256 workgroups of 8 waves, 64 positions (8 per wave) per split
     const int GS = NH / NKV;
     const int hgroups = GS / heads_per_group(GS, HS);
-    int cap = 256 / (NKV * hgroups * B);
+    int cap = g_attn_max_wgs / (NKV * hgroups * B);
     if (cap < 1) cap = 1;
     int s = (band + g_tune_positions_per_split - 1) / g_tune_positions_per_split;
     if (s > cap) s = cap;
@@ -903,6 +934,11 @@ static int run_decode(uint16_t* Y, const uint16_t* Q, uint16_t* Kc, uint16_t* Vc
         const size_t need = (size_t)B * NH * p.splits * (HS + 4) * sizeof(float);
         if (!scratch || scratch_bytes < need)
             return set_error(MILA_E_SCRATCH_TOO_SMALL, "%s: scratch %zu bytes < required %zu", who, scratch_bytes, need);
+    }
+    {
+        // the XCD-local grid needs the head groups to tile the 8 XCDs (8 groups, or a multiple), and none of the experiment hooks that address the 3-D grid
+        const int GS_ = NH / NKV, ngrp = NKV * (GS_ / heads_per_group(GS_, HS));
+        p.flat = (g_attn_xcd_local && split_kernel && ngrp % 8 == 0 && !p.tickets && !p.no_combine && !p.warm_a && !p.warm_b) ? 1 : 0;
     }
     return fused ? dispatch_hs<true>(HS, p, B, stream) : dispatch_hs<false>(HS, p, B, stream);
 }

@@ -18,6 +18,17 @@ MILA_SHARED_HELPER int set_error(int code, const char* fmt, ...);   // runtime.h
 MILA_SHARED_HELPER bool tuning_hooks_enabled();
 MILA_SHARED_HELPER int check_hip(hipError_t e, const char* what);   // MILA_OK or MILA_E_RUNTIME (+ message)
 
+// Named tuning variables (csrc/internal.h: mila_cdna4_tune / tune_get / tune_reset / tune_list): a launch heuristic that tests and tools may override is an int with a
+// dotted name, registered where it lives -- MILA_TUNE("attn.positions_per_split", g_positions_per_split);  The registry is inert unless tuning_hooks_enabled().
+struct TuneVar { const char* name; int* var; int def; TuneVar* next; };
+MILA_SHARED_HELPER void register_tune_var(TuneVar* v);
+struct TuneReg { TuneVar v; TuneReg(const char* n, int* p) : v{n, p, *p, nullptr} { register_tune_var(&v); } };
+#define MILA_TUNE_CAT2(a, b) a##b
+#define MILA_TUNE_CAT(a, b) MILA_TUNE_CAT2(a, b)
+#define MILA_TUNE(NAME, VAR) static ::mila::TuneReg MILA_TUNE_CAT(mila_tune_reg_, __LINE__)(NAME, &(VAR))
+// which kernel form served the calling thread's most recent Linear / attention entry (tests assert that a dispatch threshold routes a shape where they think it does)
+MILA_SHARED_HELPER void note_form(const char* form);
+
 #define MILA_REQUIRE(cond, ...)                                        \
     do {                                                               \
         if (!(cond)) return ::mila::set_error(MILA_E_INVALID_ARGUMENT, __VA_ARGS__); \

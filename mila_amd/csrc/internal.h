@@ -8,6 +8,17 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* NAMED tuning variables (round 4): every launch heuristic a test or a tool may override is an int with a dotted name, registered next to the rule it steers
+ * (MILA_TUNE in csrc/common.h).  tune(name, value) sets one, tune_get reads it, tune_reset restores every default, tune_list prints "name=value (default d)" lines.
+ *   gemm.*        bf16 / staged GEMM dispatch (csrc/gemm.hip, gemm256.hip)      gemm_fp8.*   fp8 x fp8 (W4A8 / W8A8) dispatch (gemm256.hip, gemm_fp8_tail.hip)
+ *   attn.*        decode attention (csrc/attention.hip)                          flash.*      flash prefill (attention_prefill.hip)
+ * last_form: the kernel forms the calling thread's Linear / attention entry points ran since the previous call ("gemm256+skinny_bf16", "fp8_ldsdma_256x128+fp8_skinny", ...),
+ * so a test can assert WHICH form a row count was routed to. */
+MILA_API int mila_cdna4_tune(const char* name, int value);
+MILA_API int mila_cdna4_tune_get(const char* name, int* value);
+MILA_API int mila_cdna4_tune_reset(void);
+MILA_API size_t mila_cdna4_tune_list(char* buf, size_t cap);
+MILA_API size_t mila_cdna4_last_form(char* buf, size_t cap);
 /* override the matvec launch heuristics (0 = default): rows per wave, chunk positions in flight,
  * maximum workgroups */
 MILA_API int mila_cdna4_tune_matvec(int R, int U, int max_blocks);

@@ -34,6 +34,27 @@ int check_hip(hipError_t e, const char* what)
     return set_error(MILA_E_RUNTIME, "%s: %s", what, hipGetErrorString(e));
 }
 
+static TuneVar*& tune_head() { static TuneVar* head = nullptr; return head; }
+void register_tune_var(TuneVar* v) { v->next = tune_head(); tune_head() = v; }
+static TuneVar* find_tune(const char* name)
+{
+    for (TuneVar* v = tune_head(); v; v = v->next)
+        if (std::strcmp(v->name, name) == 0) return v;
+    return nullptr;
+}
+
+static thread_local char g_last_form[256] = "";
+static thread_local size_t g_last_form_len = 0;
+void note_form(const char* form)
+{
+    // forms of one entry point accumulate, '+'-separated (a call may run a tile kernel on the leading rows and another form on the rest); cleared by last_form()
+    const size_t n = std::strlen(form);
+    if (g_last_form_len + n + 2 >= sizeof(g_last_form)) return;
+    if (g_last_form_len) g_last_form[g_last_form_len++] = '+';
+    std::memcpy(g_last_form + g_last_form_len, form, n + 1);
+    g_last_form_len += n;
+}
+
 }  // namespace mila
 
 using namespace mila;
@@ -43,6 +64,55 @@ extern "C" {
 const char* mila_cdna4_last_error(void) { return g_last_error; }
 
 int mila_cdna4_abi_version(void) { return 4; }
+
+// ---- named tuning hooks (csrc/internal.h; tests / tools only) ----
+#define MILA_TUNING_GATE() do { if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__); } while (0)
+int mila_cdna4_tune(const char* name, int value)
+{
+    MILA_TUNING_GATE();
+    MILA_REQUIRE(name != nullptr, "tune: null name");
+    TuneVar* v = find_tune(name);
+    MILA_REQUIRE(v != nullptr, "tune: no tuning variable named '%s' (mila_cdna4_tune_list names them)", name);
+    *v->var = value;
+    return MILA_OK;
+}
+int mila_cdna4_tune_get(const char* name, int* value)
+{
+    MILA_TUNING_GATE();
+    MILA_REQUIRE(name && value, "tune_get: null argument");
+    TuneVar* v = find_tune(name);
+    MILA_REQUIRE(v != nullptr, "tune_get: no tuning variable named '%s'", name);
+    *value = *v->var;
+    return MILA_OK;
+}
+int mila_cdna4_tune_reset(void)
+{
+    MILA_TUNING_GATE();
+    for (TuneVar* v = tune_head(); v; v = v->next) *v->var = v->def;
+    return MILA_OK;
+}
+/* "name=value (default d)\n" per variable; returns the bytes needed including the terminator */
+size_t mila_cdna4_tune_list(char* buf, size_t cap)
+{
+    size_t need = 1;
+    for (TuneVar* v = tune_head(); v; v = v->next) need += (size_t)snprintf(nullptr, 0, "%s=%d (default %d)\n", v->name, *v->var, v->def);
+    if (buf && cap)
+    {
+        size_t off = 0;
+        buf[0] = 0;
+        for (TuneVar* v = tune_head(); v && off + 1 < cap; v = v->next) off += (size_t)snprintf(buf + off, cap - off, "%s=%d (default %d)\n", v->name, *v->var, v->def);
+    }
+    return need;
+}
+/* the kernel forms noted by this thread's entry points since the last call, '+'-separated; clears the record.  Returns the bytes needed including the terminator */
+size_t mila_cdna4_last_form(char* buf, size_t cap)
+{
+    const size_t need = g_last_form_len + 1;
+    if (buf && cap) { std::strncpy(buf, g_last_form, cap - 1); buf[cap - 1] = 0; }
+    g_last_form[0] = 0;
+    g_last_form_len = 0;
+    return need;
+}
 
 int mila_cdna4_device_count(int* count)
 {

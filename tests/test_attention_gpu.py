@@ -87,6 +87,14 @@ def test_decode_attention(name, NH, NKV, HS, window, scale, length):
               float(scale))
     exp = orc.gqa_attention(q, hk, hv, length - 1, window, scale)[:, 0]
     assert_bf16_close(bits(Y), exp, 1, 2e-3, "decode %s len %d" % (name, length))
+    # the XCD-local grid (experiment, attn.xcd_local: splits of a head group and their combine workgroups share blockIdx.x % 8) is the same arithmetic per workgroup
+    Y2 = empty_u16(B, NH * HS)
+    capi.tune("attn.xcd_local", 1)
+    try:
+        capi.call("attn_decode_bf16", Y2, _d(q), Kc, Vc, scratch, C.c_size_t(nbytes), B, NH, NKV, HS, cap, length, window, float(scale))
+    finally:
+        capi.tune_reset()
+    assert np.array_equal(bits(Y2), bits(Y)), "xcd-local grid changed bits"
 
 
 @pytest.mark.parametrize("window,cap,length", [(8, 8, 30), (16, 23, 100), (1024, 1100, 2600)])
