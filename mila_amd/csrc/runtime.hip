@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "internal.h"
 
 namespace mila {
 
