@@ -271,7 +271,8 @@ static int launch_gemm(GemmParams p, hipStream_t s)
 }
 
 bool gemm256_applicable(int M, int K, int N);
-int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act = 0);
+int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act = 0, int ldy = 0);
+int gemm_colsplit_main(int M, int K, int N, int* S_rest);      // gemm256.hip: columns the whole rounds of 256 x 256 tiles take (0 = no column split), split count of the rest
 bool gemm256x128_applicable(int M, int K, int N);
 bool gemm256x128_ragged_n_applicable(int M, int K, int N);
 bool gemm256_ragged_n_applicable(int M, int K, int N);
@@ -295,7 +296,7 @@ extern int g_ldsdma_loose_tiles;     // gemm256.hip
 extern int g_gemm_splitk;            // gemm256.hip
 extern int g_fp8_splitk_min_rows;    // gemm256.hip
 int gemm_splitk_for(int M, int K, int N);
-int launch_gemm256x128_splitk(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act, float* partials, int S);
+int launch_gemm256x128_splitk(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act, float* partials, int S, int ldy = 0);
 // Few rows (tools/experiments/few_row_rules.sh, profiles/r03_splitk.txt): bf16-policy prefill of 2 / 4 / 8 / 16 tokens with the skinny kernels ahead of the tile grids up
 // to 16 rows 7.46 / 7.39 / 7.75 / 7.94 ms, never ahead 7.41 / 7.05 / 7.13 / 7.28 -- a one-round tile grid and the split-K form stream the weights at 3-4 TB/s from two
 // rows on, the skinny kernel's 16-row groups at that rate only for one group.  The skinny kernels keep what has no such grid: a 1-row remainder, narrow outputs, calls
@@ -448,7 +449,7 @@ static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, c
 
 // ---- the same GEMM with a caller workspace (mila_cdna4_gemm_bf16_ws): what the split-K form changes ----
 // plan: rows [0, main) as launch_bf16_rows serves them, rows [main, M) split-K with S copies (S = 0: no split-K part, everything as launch_bf16_rows)
-struct Bf16WsPlan { int main_rows, S; bool fewrow; };
+struct Bf16WsPlan { int main_rows, S; bool fewrow; int n_main = 0; };      // n_main > 0: the column split (all rows): columns [0, n_main) on 256 x 256 tiles, the rest split-K with S copies
 // the split-K form for `rows` rows: up to 32 rows the few-row weight stream (gemm_fewrow_bf16.hip), else the 256 x 128 ring over S copies of the tile list
 static Bf16WsPlan splitk_form(int main_rows, int rows, int K, int N)
 {
@@ -467,6 +468,12 @@ static Bf16WsPlan bf16_ws_plan(int M, int K, int N)
     // a short prompt: the whole tile list covers at most half the CUs (or the few-row form serves it)
     Bf16WsPlan pl = splitk_form(0, M, K, N);
     if (pl.S) return pl;
+    // a tile list that ends in a nearly empty round (N = 8704 at T = 2048): whole rounds of 256 x 256 tiles + the remaining columns split-K (gemm256.hip: gemm_colsplit_main)
+    {
+        int S_rest = 0;
+        const int n_main = gemm_colsplit_main(M, K, N, &S_rest);
+        if (n_main > 0 && gemm256_applicable(M, K, n_main)) { Bf16WsPlan cs{0, S_rest, false}; cs.n_main = n_main; return cs; }
+    }
     // a long prompt's remainder whose ragged tile-row would open another round of the grid (T = 2303 on the N = 3840 shapes: 240 tiles fill the chip, 270 run two
     // rounds of full-length tiles -- fc_down 200 -> 400 us): the whole tile-rows as before, the remainder split-K
     const int tail = M % 256, main_rows = M - tail;
@@ -482,12 +489,20 @@ static Bf16WsPlan bf16_ws_plan(int M, int K, int N)
 static size_t bf16_ws_bytes(int M, int K, int N)
 {
     const Bf16WsPlan pl = bf16_ws_plan(M, K, N);
+    if (pl.n_main) return (size_t)pl.S * M * (N - pl.n_main) * sizeof(float);
     return pl.S ? (size_t)pl.S * (M - pl.main_rows) * N * sizeof(float) : 0;
 }
 static int launch_bf16_rows_ws(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act, void* ws)
 {
     const Bf16WsPlan pl = bf16_ws_plan(M, K, N);
     if (!pl.S) return launch_bf16_rows(Y, X, W, bias, M, K, N, s, act);
+    if (pl.n_main)
+    {
+        note_form("gemm256_colsplit");
+        int rc = launch_gemm256(Y, X, W, bias, M, K, pl.n_main, s, act, N);
+        if (rc) return rc;
+        return launch_gemm256x128_splitk(Y + pl.n_main, X, W + (size_t)pl.n_main * K, bias ? bias + pl.n_main : nullptr, M, K, N - pl.n_main, s, act, static_cast<float*>(ws), pl.S, N);
+    }
     if (pl.main_rows > 0)
     {
         int rc = launch_bf16_rows(Y, X, W, bias, pl.main_rows, K, N, s, act);

@@ -35,6 +35,7 @@ struct Gemm256Params
     int act = 0;             // bf16 plain epilogue: 1 = tanh-GELU on the stored Linear output, y = bf16(gelu(bf16(acc) [+ bias, rounded again])): Linear + Gelu of MLP.ixx:148-161 in one kernel
     float* partials = nullptr;      // split-K form of the 256 x 128 ring: [splitk][M][N] fp32 accumulators (workspace), summed and finished by splitk_reduce_kernel
     int splitk = 0;
+    int ldy = 0;             // row pitch of Y in elements (0 = N): a column range of a wider output (the column split of launch_*_colsplit: Y + n_first, pitch = the whole N)
     int w_pc = 0;            // FP8 mode: w_scale is a per-channel vector over the W rows (W8A8: y = bf16((acc * w_scale[n]) * x_scales[m] + bias), common.h) instead of the W4A8 scalar
 #ifdef MILA_GEMM_SKIP
     int dbg = 0;             // diagnostic build (tools/experiments/gemm_skip.sh): leave out the staging (1), the fragment reads (2), the MFMAs (4), the plain epilogue's stores (8)
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, g = lane >> 4;
     const int K = p.K, nk = K / KT;
+    const int ldy = p.ldy ? p.ldy : p.N;                   // output row pitch
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(p.X);
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(p.W);
 
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                     for (int qt = 0; qt < 2; ++qt)
                     {
                         const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                        store_pair16(p.Y + (size_t)m * p.N + n0 + wr * 64 + pp * 16, g, out4(hB, pp, qt, m), out4(hB, pp + 1, qt, m), m < p.M);
+                        store_pair16(p.Y + (size_t)m * ldy + n0 + wr * 64 + pp * 16, g, out4(hB, pp, qt, m), out4(hB, pp + 1, qt, m), m < p.M);
                     }
         }
         else
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                                 {
                                     const int n = n0 + hA * 128 + wr * 64 + pt * 16 + 4 * g;
                                     const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                                    uint16_t* y = p.Y + (size_t)m * p.N + n;
+                                    uint16_t* y = p.Y + (size_t)m * ldy + n;
     #pragma unroll
                                     for (int e = 0; e < 4; ++e)
                                         if (n + e < p.N && m < p.M)
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                                 {
                                     const int nb = n0 + hA * 128 + wr * 64 + pp * 16;
                                     const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                                    store_pair16<false>(p.Y + (size_t)m * p.N + nb, g, out4(hA, hB, pp, qt, m, nb + 4 * g), out4(hA, hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
+                                    store_pair16<false>(p.Y + (size_t)m * ldy + nb, g, out4(hA, hB, pp, qt, m, nb + 4 * g), out4(hA, hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
                                 }
                     return;
                 }
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
     #ifdef MILA_GEMM_SKIP
                             if ((p.dbg & 8) && acc[hA][hB][pp][qt][0] != 12345.678f) continue;      // diagnostic: no epilogue stores (8)
     #endif
-                            store_pair16(p.Y + (size_t)m * p.N + nb, g, out4(hA, hB, pp, qt, m, nb + 4 * g), out4(hA, hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
+                            store_pair16(p.Y + (size_t)m * ldy + nb, g, out4(hA, hB, pp, qt, m, nb + 4 * g), out4(hA, hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
                         }
         }
     };
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 const int m = m0 + lr;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(smem + lr * 512 + ((chunk ^ (lr & 31)) << 4));
                 if (m >= p.M) continue;
-                uint16_t* y = p.Y + (size_t)m * p.N + n;
+                uint16_t* y = p.Y + (size_t)m * ldy + n;
                 if (n + 8 <= p.N) st16_a2(y, v);
                 else
                 {
@@ -741,6 +743,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, g = lane >> 4;
     const int K = p.K, nk_all = K / KT;
+    const int ldy = p.ldy ? p.ldy : p.N;                   // output row pitch
     // this workgroup's K-tiles and the byte offset of its first one in a row
     const int kt_first = SPLITK ? ks * nk_all / max(p.splitk, 1) : 0;
     const int nk = SPLITK ? (ks + 1) * nk_all / max(p.splitk, 1) - kt_first : nk_all;
@@ -935,7 +938,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                 for (int qt = 0; qt < 2; ++qt)
                 {
                     const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                    store_pair16(p.Y + (size_t)m * p.N + n0 + wr * 32, g, out4(hB, 0, qt, m), out4(hB, 1, qt, m), m < p.M);
+                    store_pair16(p.Y + (size_t)m * ldy + n0 + wr * 32, g, out4(hB, 0, qt, m), out4(hB, 1, qt, m), m < p.M);
                 }
             return;
         }
@@ -1011,7 +1014,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                     {
                         const int nb = n0 + wr * 64 + pp * 16;
                         const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                        store_pair16<false>(p.Y + (size_t)m * p.N + nb, g, out4(hB, pp, qt, m, nb + 4 * g), out4(hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
+                        store_pair16<false>(p.Y + (size_t)m * ldy + nb, g, out4(hB, pp, qt, m, nb + 4 * g), out4(hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
                     }
             return;
         }
@@ -1028,7 +1031,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                         const int n = n0 + wr * 64 + pt * 16 + 4 * g;
                         const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
                         if (m >= p.M) continue;
-                        uint16_t* y = p.Y + (size_t)m * p.N + n;
+                        uint16_t* y = p.Y + (size_t)m * ldy + n;
     #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (n + e < p.N)
@@ -1050,7 +1053,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                 {
                     const int nb = n0 + wr * 64 + pp * 16;
                     const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                    store_pair16(p.Y + (size_t)m * p.N + nb, g, out4(hB, pp, qt, m, nb + 4 * g), out4(hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
+                    store_pair16(p.Y + (size_t)m * ldy + nb, g, out4(hB, pp, qt, m, nb + 4 * g), out4(hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
                 }
     };
 
@@ -1223,7 +1226,7 @@ int gemm_splitk_for(int M, int K, int N)      // S (>= 2), or 0: no split-K form
 
 // y = epilogue(sum over s of P[s]), 8 columns per thread; the epilogue is the 256 x 128 kernel's: bf16(acc) [+ bias, rounded again] [-> GELU of the rounded value]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(uint16_t* __restrict__ Y, const float* __restrict__ P, const uint16_t* __restrict__ bias, int64_t MN, int N, int S,
-                                                            int act)
+                                                            int act, int ldy)
 {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i >= MN) return;
@@ -1246,12 +1249,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(uint16_t* __restrict
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(round_bf16(v[e]));
     }
-    st16(Y + i, u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
+    st16(Y + (ldy == N ? i : (i / N) * ldy + i % N), u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
 }
 
 // the fp8 forms: W4A8 y = bf16(float(bf16(sum * *w_scale)) * x_scales[m] + bias), W8A8 (w_pc) y = bf16((sum * w_scale[n]) * x_scales[m] + bias): the epilogue of the fp8 kernels (common.h: fp8_scale_bias)
 __global__ __launch_bounds__(256) void splitk_reduce_fp8_kernel(uint16_t* __restrict__ Y, const float* __restrict__ P, const uint16_t* __restrict__ bias,
-                                                                const float* __restrict__ x_scales, const float* __restrict__ w_scale, int w_pc, int64_t MN, int N, int S)
+                                                                const float* __restrict__ x_scales, const float* __restrict__ w_scale, int w_pc, int64_t MN, int N, int S, int ldy)
 {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (i >= MN) return;
@@ -1281,7 +1284,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_fp8_kernel(uint16_t* __rest
     if (bias) bb = *reinterpret_cast<const u32x4*>(bias + n);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = fp8_scale_bias(w_pc != 0, v[e], ws[e], ts, bias != nullptr, bf16_bits_to_f32((uint16_t)(bb[e >> 1] >> ((e & 1) * 16))));
-    st16(Y + i, u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
+    st16(Y + (size_t)m * ldy + n, u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])});
 }
 
 int gemm_fp8_splitk_for(int M, int K, int N)      // S (>= 2), or 0: the fp8 (W4A8) 256 x 128 ring has no split-K form for this shape
@@ -1295,7 +1298,7 @@ int gemm_fp8_splitk_for(int M, int K, int N)      // S (>= 2), or 0: the fp8 (W4
 }
 
 static int launch_gemm256x128_fp8_splitk(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, Fp8WScale w_scale, const uint16_t* bias, int M, int K, int N,
-                                         hipStream_t s, float* partials, int S)
+                                         hipStream_t s, float* partials, int S, int ldy = 0)
 {
     static bool attr_set = false;
     if (!attr_set)
@@ -1310,7 +1313,7 @@ static int launch_gemm256x128_fp8_splitk(uint16_t* Y, const uint8_t* X8, const u
     int rc = check_hip(hipGetLastError(), "gemm256x128 (fp8 split-K)");
     if (rc) return rc;
     const int64_t MN = (int64_t)M * N;
-    hipLaunchKernelGGL(splitk_reduce_fp8_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, Y, partials, bias, x_scales, w_scale.p, w_scale.per_channel, MN, N, S);
+    hipLaunchKernelGGL(splitk_reduce_fp8_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, Y, partials, bias, x_scales, w_scale.p, w_scale.per_channel, MN, N, S, ldy ? ldy : N);
     return check_hip(hipGetLastError(), "splitk_reduce_fp8");
 }
 
@@ -1318,11 +1321,11 @@ static int launch_gemm256x128_fp8_splitk(uint16_t* Y, const uint8_t* X8, const u
 int launch_splitk_reduce(uint16_t* Y, const float* partials, const uint16_t* bias, int M, int N, int S, int act, hipStream_t s)
 {
     const int64_t MN = (int64_t)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, Y, partials, bias, MN, N, S, act);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, Y, partials, bias, MN, N, S, act, N);
     return check_hip(hipGetLastError(), "splitk_reduce");
 }
 
-int launch_gemm256x128_splitk(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act, float* partials, int S)
+int launch_gemm256x128_splitk(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act, float* partials, int S, int ldy)
 {
     static bool attr_set = false;
     if (!attr_set)
@@ -1337,7 +1340,7 @@ int launch_gemm256x128_splitk(uint16_t* Y, const uint16_t* X, const uint16_t* W,
     int rc = check_hip(hipGetLastError(), "gemm256x128 (split-K)");
     if (rc) return rc;
     const int64_t MN = (int64_t)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, Y, partials, bias, MN, N, S, act);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN / 8 + 255) / 256)), dim3(256), 0, s, Y, partials, bias, MN, N, S, act, ldy ? ldy : N);
     return check_hip(hipGetLastError(), "splitk_reduce");
 }
 
@@ -1399,12 +1402,37 @@ static int launch_gemm256_t(const Gemm256Params& p, hipStream_t s)
     return g_gemm_pingpong ? launch_gemm256_tt<MODE, 1>(p, s) : launch_gemm256_tt<MODE, 0>(p, s);
 }
 
-int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act)
+int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act, int ldy)
 {
     // a row pitch that is no multiple of 128 bytes: one workgroup per tile and the row-wise epilogue through LDS (two-phase schedules only)
     const int rowwise = ((N & 63) != 0 && g_gemm_pingpong >= 3 && g_gemm_rowwise) ? 1 : 0;
     Gemm256Params p{Y, X, W, bias, M, K, N, (M + 255) / 256, (N + 255) / 256, nullptr, nullptr, rowwise, act};
+    p.ldy = ldy;
     return launch_gemm256_t<G_PLAIN>(p, s);
+}
+
+// ---- column split (round 4): an output whose 256 x 256 tile list ends in a nearly empty round -- Gemma's global qkv_proj, N = 8704 at T = 2048: 272 tiles on 256 CUs (the
+// 256 x 128 ring ran it as 544 tiles in three rounds for 2.1 rounds of work, 165 us = 0.83 PFLOP/s) -- is cut at the last whole round: columns [0, n_main) as whole rounds
+// of 256 x 256 tiles, the few remaining column tiles through the split-K form of the ring (their S copies cover the idle CUs), both writing their column range of Y with
+// the pitch of the whole row.  Needs the caller's workspace (S M (N - n_main) floats).  n_main = 0: no split for this shape.
+int g_gemm_colsplit = 1;
+MILA_TUNE("gemm.colsplit", g_gemm_colsplit);
+int gemm_splitk_for(int M, int K, int N);
+int gemm_colsplit_main(int M, int K, int N, int* S_rest)
+{
+    *S_rest = 0;
+    if (!g_gemm_colsplit || g_gemm_pingpong != 5 || M < 256 || N % 256 != 0 || K % 64 != 0 || !lds_dma_addressable(M, K, N)) return 0;
+    const int tm = (M + 255) / 256, tn = N / 256, tiles = tm * tn;
+    if (tiles <= kNumCU) return 0;
+    const int rounds = (tiles + kNumCU - 1) / kNumCU;
+    if (tiles >= 0.80 * rounds * kNumCU) return 0;                  // the whole list fills its rounds well enough (gemm256_applicable's rule)
+    const int tn_main = ((tiles / kNumCU) * kNumCU) / tm;           // column tiles of the whole rounds
+    if (tn_main <= 0 || tn_main >= tn) return 0;
+    const int n_main = tn_main * 256, rest = N - n_main;
+    const int S = gemm_splitk_for(M, K, rest);
+    if (S < 2) return 0;
+    *S_rest = S;
+    return n_main;
 }
 
 // Y[M, F] = GeGLU(X W^T), W = [gate rows 0 .. F-1 | up rows F .. 2F-1]
@@ -1509,12 +1537,28 @@ int launch_gemm_fp8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const flo
 
 // ---- the same with a caller workspace (mila_cdna4_gemm_fp8_scaled_ws; mirrors gemm.hip's bf16_ws_plan): a short prompt whose tile list covers at most half the CUs
 // splits K whole; a long prompt's remainder whose ragged tile-row would open another round of the grid (T = 2303 on the N = 3840 shapes) splits K alone ----
-struct Fp8WsPlan { int main_rows, S; };
+struct Fp8WsPlan { int main_rows, S; int n_main = 0; };      // n_main > 0: the column split (see gemm_colsplit_main): columns [0, n_main) on 256 x 256 fp8 tiles, the rest split-K
 static Fp8WsPlan fp8_ws_plan(int M, int K, int N)
 {
     if (M < g_fp8_splitk_min_rows) return {M, 0};
     int S = gemm_fp8_splitk_for(M, K, N);
     if (S) return {0, S};
+    // the 256 x 256 fp8 tile list of N = 8704 at T = 2048 is 272 tiles: one round and sixteen stragglers, walked as two (fp8_pick: 2).  Whole rounds + a split-K rest instead.
+    if (g_gemm_colsplit && g_gemm_pingpong == 5 && !g_gemm_fp8_tail_only && M >= 512 && N % 256 == 0 && K % 128 == 0 && lds_dma_addressable(M, K, N))
+    {
+        const int tm = (M + 255) / 256, tn = N / 256, tiles = tm * tn;
+        const int rounds = (tiles + kNumCU - 1) / kNumCU;
+        if (tiles > kNumCU && tiles < 0.80 * rounds * kNumCU)
+        {
+            const int tn_main = ((tiles / kNumCU) * kNumCU) / tm;
+            if (tn_main > 0 && tn_main < tn)
+            {
+                const int n_main = tn_main * 256;
+                const int Sr = gemm_fp8_splitk_for(M, K, N - n_main);
+                if (Sr >= 2 && fp8_big_rows(M, K, 128, n_main) == M && fp8_pick(M, n_main) == 2) { Fp8WsPlan cs{0, Sr}; cs.n_main = n_main; return cs; }
+            }
+        }
+    }
     const int tail = M % 256, main_rows = M - tail;
     if (M < 512 || tail < g_fp8_splitk_min_rows) return {M, 0};
     if (fp8_big_rows(main_rows, K, N % 128 == 0 ? 128 : 0, N) != main_rows) return {M, 0};
@@ -1527,6 +1571,7 @@ static Fp8WsPlan fp8_ws_plan(int M, int K, int N)
 size_t gemm_fp8_ws_bytes(int M, int K, int N)
 {
     const Fp8WsPlan pl = fp8_ws_plan(M, K, N);
+    if (pl.n_main) return (size_t)pl.S * M * (N - pl.n_main) * sizeof(float);
     return pl.S ? (size_t)pl.S * (M - pl.main_rows) * N * sizeof(float) : 0;
 }
 int launch_gemm_fp8_ws(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, Fp8WScale w_scale, const uint16_t* bias, int M, int K, int N, hipStream_t s,
@@ -1534,6 +1579,18 @@ int launch_gemm_fp8_ws(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const 
 {
     const Fp8WsPlan pl = fp8_ws_plan(M, K, N);
     if (!pl.S) return launch_gemm_fp8(Y, X8, W8, x_scales, w_scale, bias, M, K, N, s);
+    if (pl.n_main)
+    {
+        note_form("fp8_gemm256_colsplit");
+        Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), bias, M, K, pl.n_main, (M + 255) / 256, pl.n_main / 256, x_scales, w_scale.p};
+        p.w_pc = w_scale.per_channel;
+        p.ldy = N;
+        int rc = launch_gemm256_t<G_FP8>(p, s);
+        if (rc) return rc;
+        const Fp8WScale wr{w_scale.per_channel ? w_scale.p + pl.n_main : w_scale.p, w_scale.per_channel};
+        return launch_gemm256x128_fp8_splitk(Y + pl.n_main, X8, W8 + (size_t)pl.n_main * K, x_scales, wr, bias ? bias + pl.n_main : nullptr, M, K, N - pl.n_main, s,
+                                             static_cast<float*>(ws), pl.S, N);
+    }
     if (pl.main_rows > 0)
     {
         int rc = launch_gemm_fp8(Y, X8, W8, x_scales, w_scale, bias, pl.main_rows, K, N, s);

@@ -1021,3 +1021,55 @@ def test_w4a8_gemm_with_a_workspace_splits_k(M, K, N, bias):
         assert lib.mila_cdna4_gemm_fp8_scaled_ws(*args(Y2, capi._ptr(wsb), need - 1)) == capi.MILA_E_SCRATCH_TOO_SMALL
         assert lib.mila_cdna4_gemm_fp8_scaled_ws(*args(Y2, None, 0)) == capi.MILA_E_SCRATCH_TOO_SMALL
         assert lib.mila_cdna4_gemm_fp8_scaled_ws(*args(Y2, C.c_void_p(wsb.data_ptr() + 4), need)) == capi.MILA_E_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("M,K,N", [(2048, 1024, 8704), (2048 + 100, 1024, 8704)])
+def test_column_split_of_a_tile_list_that_ends_in_a_nearly_empty_round(M, K, N):
+    """Gemma's global qkv_proj (N = 8704) at T = 2048 is 272 tiles of 256 x 256 on 256 CUs: with a workspace the first 8192 columns run as whole rounds of 256 x 256 tiles and
+    the last 512 through the split-K ring, both writing their column range of Y with the pitch of the whole row (csrc/gemm256.hip: gemm_colsplit_main).  bf16, W4A8 and W8A8:
+    sampled rows x ALL columns (both sides of the cut) against the float64 oracle, a guard row behind Y, and the form that ran."""
+    lib = capi.load()
+    rng = np.random.default_rng(M + N)
+    Wb = _weights(rng, N, K, "random")
+    X = orc.round_bf16((rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32))
+    bb = orc.to_bf16_bits(rng.uniform(-0.1, 0.1, N).astype(np.float32))
+    rows = [0, 255, 256, M // 2, M - 1]
+    # bf16
+    need = lib.mila_cdna4_gemm_workspace_bytes(M, K, N)
+    assert need == 2 * M * 512 * 4, need                                    # S = 2 copies of the 512-column rest (16 K-tiles: 8 per copy)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    Yg = torch.full((M + 1, N), 0x1234, dtype=torch.int16, device="cuda")
+    capi.last_form()
+    capi.call("gemm_bf16_ws", Yg[:M], dev_u16(orc.to_bf16_bits(X)), dev_u16(Wb), dev_u16(bb), M, K, N, 0, ws, C.c_size_t(need))
+    assert capi.last_form() == ["gemm256_colsplit"]
+    exp = orc.round_bf16(orc.linear_bf16w(X[rows], Wb, None)).astype(np.float64) + orc.from_bf16_bits(bb).astype(np.float64)
+    assert_bf16_close(bits(Yg[:M])[rows], exp, 2, 2e-3, "column-split gemm_bf16_ws")
+    assert np.all(Yg[M].cpu().numpy() == 0x1234), "a store past row M - 1"
+    # without the split (tuning variable) the other kernels agree to the last-bit freedom of another summation order
+    Y0 = empty_u16(M, N)
+    capi.tune("gemm.colsplit", 0)
+    try:
+        assert lib.mila_cdna4_gemm_workspace_bytes(M, K, N) == 0
+        capi.call("gemm_bf16_ws", Y0, dev_u16(orc.to_bf16_bits(X)), dev_u16(Wb), dev_u16(bb), M, K, N, 0, None, C.c_size_t(0))
+    finally:
+        capi.tune_reset()
+    a, b = orc.from_bf16_bits(bits(Yg[:M])).astype(np.float64), orc.from_bf16_bits(bits(Y0)).astype(np.float64)
+    assert np.array_equal(bits(Yg[:M])[:, :8192], bits(Y0)[:, :8192]), "the 256 x 256 tiles and the 256 x 128 ring sum K in one order: same bits left of the cut"
+    assert np.abs(a - b).max() <= 2.0 ** -7 * np.abs(b).max()
+    # fp8 x fp8: W8A8 (per-channel scales, offset with the column range) and W4A8 (per-tensor scale)
+    w8, sc = orc.quantize_fp8_per_channel(Wb)
+    x8, ts = orc.quantize_act_fp8_per_token(X)
+    need8 = lib.mila_cdna4_gemm_fp8_workspace_bytes(M, K, N)
+    assert need8 > 0
+    ws8 = torch.empty(need8, dtype=torch.uint8, device="cuda")
+    Y8 = empty_u16(M, N)
+    capi.last_form()
+    capi.call("gemm_fp8_w8a8_ws", Y8, dev_u8(x8), dev_u8(w8), dev_f32(ts), dev_f32(sc), dev_u16(bb), M, K, N, ws8, C.c_size_t(need8))
+    assert capi.last_form() == ["fp8_gemm256_colsplit"]
+    exp8 = orc.linear_fp8a_fp8w(x8[rows], ts[rows], w8, sc, 1.0, None).astype(np.float64) + orc.from_bf16_bits(bb).astype(np.float64)
+    assert_bf16_close(bits(Y8)[rows], exp8, 2, 1e-3 * float(np.abs(exp8).max()), "column-split W8A8")
+    wsc = dev_f32(np.array([0.37], dtype=np.float32))
+    capi.call("gemm_fp8_scaled_ws", Y8, dev_u8(x8), dev_u8(w8), dev_f32(ts), wsc, dev_u16(bb), M, K, N, ws8, C.c_size_t(need8))
+    raw = orc.linear_fp8a_fp8w(x8[rows], np.ones(len(rows), dtype=np.float32), w8, None, 0.37, None)
+    exp4 = orc.round_bf16(raw.astype(np.float32)).astype(np.float64) * ts[rows].astype(np.float64)[:, None] + orc.from_bf16_bits(bb).astype(np.float64)
+    assert_bf16_close(bits(Y8)[rows], exp4, 2, 1e-3 * float(np.abs(exp4).max()), "column-split W4A8 epilogue")
