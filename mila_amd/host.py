@@ -161,6 +161,16 @@ class Gemma:
         or re-stage it into scratch on every forward as the reference does; identical bits"""
         _check(load().mila_gemma_set_resident_prefill_weights(self.h, int(bool(on))))
 
+    def memory_stats(self):
+        """GemmaTransformer::getRequiredMemory() (from the configuration alone) beside getMemoryStats() (what the built model holds), and the context's scratch high-water
+        mark: {"required": {...}, "actual": {...}, "scratch_bytes": n} with device_parameter_bytes / device_state_bytes / host_state_bytes"""
+        lib = load()
+        lib.mila_gemma_memory_stats.argtypes = [C.c_void_p, C.c_void_p]
+        out = (C.c_double * 7)()
+        _check(lib.mila_gemma_memory_stats(self.h, out))
+        keys = ("device_parameter_bytes", "device_state_bytes", "host_state_bytes")
+        return {"required": {k: int(out[i]) for i, k in enumerate(keys)}, "actual": {k: int(out[3 + i]) for i, k in enumerate(keys)}, "scratch_bytes": int(out[6])}
+
     def graph_node_count(self):
         """nodes of the captured decode graph = launches per token on the graph path (0 before the first graph-mode step)"""
         lib = load()
@@ -350,6 +360,15 @@ class Gpt:
         buf = C.create_string_buffer(need)
         lib.mila_gpt_component_names(self.h, buf, need)
         return buf.value.decode().split("\n")[:-1]
+
+    def memory_stats(self):
+        """GptTransformer::getRequiredMemory() beside getMemoryStats(): {"required": {...}, "actual": {...}} with device_parameter_bytes / device_state_bytes"""
+        lib = load()
+        lib.mila_gpt_memory_stats.argtypes = [C.c_void_p, C.c_void_p]
+        out = (C.c_double * 4)()
+        if lib.mila_gpt_memory_stats(self.h, out):
+            raise RuntimeError(lib.mila_gpt_last_error().decode())
+        return {"required": {"device_parameter_bytes": int(out[0]), "device_state_bytes": int(out[1])}, "actual": {"device_parameter_bytes": int(out[2]), "device_state_bytes": int(out[3])}}
 
     def load_parameters(self, params_bf16_bits):
         lib = load()

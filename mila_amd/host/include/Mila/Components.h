@@ -60,6 +60,11 @@ namespace Mila::Dnn
             built_ = true;
         }
 
+        /// what this component holds on the device right now (Component.ixx getMemoryStats)
+        virtual MemoryStats getMemoryStats() const { return {}; }
+        /// what build( ctx ) would allocate, without allocating (Component.ixx getRequiredMemory); equals getMemoryStats() after that build
+        virtual MemoryStats getRequiredMemory( const BuildContext& ) const { return {}; }
+
         /// host blob in the checkpoint's layout; throws std::invalid_argument for unknown names / sizes
         virtual void loadParameter( const std::string& param_name, const void* host_blob, size_t bytes )
         {
@@ -130,7 +135,7 @@ namespace Mila::Dnn
             validateInputShape( input.shape() );
             auto out_shape = input.shape();
             out_shape.back() = config_.getOutputFeatures();
-            if ( input.shape() == leading_shape_ )
+            if ( input.shape() == leading_shape_ && !output_installed_ )
             {
                 operation_->forward( input, *output_ );
                 return *output_;
@@ -155,7 +160,7 @@ namespace Mila::Dnn
             validateInputShape( input.shape() );
             auto out_shape = input.shape();
             out_shape.back() = config_.getOutputFeatures();
-            if ( input.shape() == leading_shape_ )
+            if ( input.shape() == leading_shape_ && !output_installed_ )
             {
                 operation_->forwardGelu( input, *output_ );
                 return *output_;
@@ -258,6 +263,39 @@ namespace Mila::Dnn
             weight_scale_ = std::move( shared_scales );
         }
         bool hasSharedWeight() const noexcept { return shared_weight_; }
+        /// a model whose layers run one after the other hands every layer's Linear of one role the same output buffer (the reference's pooled block workspace,
+        /// Gemma.ixx allocateBlockWorkspace / installSharedOutput); precedes build(), the owner accounts for the buffer
+        void installSharedOutput( std::shared_ptr<TensorType> output )
+        {
+            if ( this->isBuilt() ) throw std::runtime_error( this->getName() + ": installSharedOutput() must precede build()" );
+            output_ = std::move( output );
+            output_installed_ = true;
+        }
+
+        /// Linear.ixx:692-833.  An installed (tied) weight IS reported -- the tying composite subtracts it exactly once; an installed output is not (its owner counts it).
+        /// State: the output buffer and the op-owned derived state (fp4 tensor scale, resident prefill staging -- present once quantized weights are in place).
+        MemoryStats getMemoryStats() const override
+        {
+            MemoryStats st;
+            st.device_parameter_bytes = tensorBytes( weight_ ) + tensorBytes( weight_scale_ ) + tensorBytes( bias_ );
+            if ( !output_installed_ ) st.device_state_bytes += tensorBytes( output_ );
+            if ( operation_ ) st.device_state_bytes += operation_->stateBytes();
+            return st;
+        }
+        MemoryStats getRequiredMemory( const BuildContext& ctx ) const override
+        {
+            validateInputShape( ctx.inputShape() );
+            MemoryStats st;
+            const size_t N = static_cast<size_t>( config_.getOutputFeatures() ), K = static_cast<size_t>( config_.getInputFeatures() );
+            if ( shared_weight_ ) st.device_parameter_bytes += tensorBytes( weight_ ) + tensorBytes( weight_scale_ );
+            else if constexpr ( !kIsQuantized ) st.device_parameter_bytes += N * K * WeightTensorType::kElemBytes;
+            else if constexpr ( TWeightQuant::kPerChannel ) st.device_parameter_bytes += N * K * WeightTensorType::kElemBytes + N * WeightScaleTensorType::kElemBytes;
+            else st.device_parameter_bytes += N * ( K / 2 ) * WeightTensorType::kElemBytes + N * ( K / Quant::Weight::groupSizeOf<TWeightQuant>() ) * WeightScaleTensorType::kElemBytes;
+            if ( config_.hasBias() ) st.device_parameter_bytes += N * TensorType::kElemBytes;
+            if ( !output_installed_ && !ctx.isOutputInstalled() ) st.device_state_bytes += static_cast<size_t>( shapeSize( ctx.inputShape() ) / ctx.inputShape().back() ) * N * TensorType::kElemBytes;
+            if ( operation_ ) st.device_state_bytes += operation_->requiredStateBytes();
+            return st;
+        }
 
         WeightTensorType& getWeight() { return *weight_; }
         WeightScaleTensorType* getWeightScale() { return weight_scale_.get(); }
@@ -309,7 +347,8 @@ namespace Mila::Dnn
             leading_shape_ = ctx.inputShape();
             auto out_shape = leading_shape_;
             out_shape.back() = N;
-            output_ = std::make_shared<TensorType>( dev, out_shape );
+            if ( !output_installed_ ) output_ = std::make_shared<TensorType>( dev, out_shape );
+            else if ( output_->size() < static_cast<size_t>( shapeSize( out_shape ) ) ) throw std::invalid_argument( this->getName() + ": the installed output is too small" );
         }
 
     private:
@@ -338,7 +377,7 @@ namespace Mila::Dnn
         std::shared_ptr<TensorType> output_;
         std::unique_ptr<TensorType> output_view_;
         shape_t leading_shape_;
-        bool shared_weight_{ false };
+        bool shared_weight_{ false }, output_installed_{ false };
     };
 
     // ---------------------------------------------------------------------------------------
@@ -400,6 +439,31 @@ namespace Mila::Dnn
         TensorType* getWeight() { return weight_.get(); }
         const RmsNormConfig& getConfig() const noexcept { return config_; }
         OpType& getOperation() { return *operation_; }
+        /// see Linear::installSharedOutput
+        void installSharedOutput( std::shared_ptr<TensorType> output )
+        {
+            if ( this->isBuilt() ) throw std::runtime_error( this->getName() + ": installSharedOutput() must precede build()" );
+            output_ = std::move( output );
+            output_installed_ = true;
+        }
+        /// RmsNorm.ixx:329-420: parameters weight (+ bias); state the output buffer (unless installed) + the op's per-slice rstd
+        MemoryStats getMemoryStats() const override
+        {
+            MemoryStats st;
+            st.device_parameter_bytes = tensorBytes( weight_ ) + tensorBytes( bias_ );
+            if ( !output_installed_ ) st.device_state_bytes += tensorBytes( output_ );
+            if ( operation_ ) st.device_state_bytes += operation_->stateBytes();
+            return st;
+        }
+        MemoryStats getRequiredMemory( const BuildContext& ctx ) const override
+        {
+            MemoryStats st;
+            const size_t D = static_cast<size_t>( config_.dim() ), n = static_cast<size_t>( shapeSize( ctx.inputShape() ) );
+            st.device_parameter_bytes = ( config_.hasWeight() ? D : 0 ) * TensorType::kElemBytes + ( config_.hasBias() ? D : 0 ) * TensorType::kElemBytes;
+            if ( !output_installed_ && !ctx.isOutputInstalled() ) st.device_state_bytes += n * TensorType::kElemBytes;
+            st.device_state_bytes += ( n / D ) * TensorType::kElemBytes;      // rstd, one per slice, in the compute dtype
+            return st;
+        }
 
     protected:
         void onExecutionContextSet() override
@@ -414,13 +478,15 @@ namespace Mila::Dnn
             if ( config_.hasBias() ) bias_ = std::make_shared<TensorType>( dev, shape_t{ config_.dim() } );
             operation_->setParameters( weight_.get(), bias_.get() );
             operation_->build( ctx );
-            output_ = std::make_shared<TensorType>( dev, ctx.inputShape() );
+            if ( !output_installed_ ) output_ = std::make_shared<TensorType>( dev, ctx.inputShape() );
+            else if ( output_->size() < static_cast<size_t>( shapeSize( ctx.inputShape() ) ) ) throw std::invalid_argument( this->getName() + ": the installed output is too small" );
         }
     private:
         RmsNormConfig config_;
         std::shared_ptr<OpType> operation_;
         std::shared_ptr<TensorType> weight_, bias_, output_;
         std::unique_ptr<TensorType> view_;
+        bool output_installed_{ false };
     };
 
     // ---------------------------------------------------------------------------------------

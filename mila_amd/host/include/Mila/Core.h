@@ -388,6 +388,31 @@ namespace Mila::Dnn
     }
 
     // ---------------------------------------------------------------------------------------
+    // MemoryStats (Core/Component.MemoryStats.ixx:64-160): the footprint contract every component carries -- getMemoryStats() = what it holds now,
+    // getRequiredMemory(BuildContext) = what build() (and, for quantized Linears, the load that follows) would allocate, without allocating.  The two must
+    // agree after a real build; tests/test_memory_stats_gpu.py is the drift gate (Tests/Dnn/Components/Transformers/Gemma/Gemma.Cuda.cpp:207-239).
+    // ---------------------------------------------------------------------------------------
+    struct MemoryStats
+    {
+        std::size_t device_parameter_bytes{ 0 };      ///< weights, scales, biases
+        std::size_t device_state_bytes{ 0 };          ///< output buffers, KV caches, RoPE tables, op-owned derived state (resident prefill staging)
+        std::size_t device_gradient_bytes{ 0 };       ///< always 0: the CDNA4 backend is inference-only
+        std::size_t host_parameter_bytes{ 0 }, host_state_bytes{ 0 }, host_gradient_bytes{ 0 };
+        [[nodiscard]] std::size_t totalDeviceBytes() const noexcept { return device_parameter_bytes + device_state_bytes + device_gradient_bytes; }
+        [[nodiscard]] std::size_t totalHostBytes() const noexcept { return host_parameter_bytes + host_state_bytes + host_gradient_bytes; }
+        [[nodiscard]] std::size_t totalBytes() const noexcept { return totalDeviceBytes() + totalHostBytes(); }
+        MemoryStats& operator+=( const MemoryStats& r ) noexcept
+        {
+            device_parameter_bytes += r.device_parameter_bytes; device_state_bytes += r.device_state_bytes; device_gradient_bytes += r.device_gradient_bytes;
+            host_parameter_bytes += r.host_parameter_bytes; host_state_bytes += r.host_state_bytes; host_gradient_bytes += r.host_gradient_bytes;
+            return *this;
+        }
+        bool operator==( const MemoryStats& ) const = default;
+    };
+    /// bytes a tensor handle holds (0 for an empty handle)
+    template<typename TPtr> inline std::size_t tensorBytes( const TPtr& t ) { return t ? t->sizeInBytes() : 0; }
+
+    // ---------------------------------------------------------------------------------------
     // BuildContext
     // ---------------------------------------------------------------------------------------
     enum class RuntimeMode : uint8_t { Inference, Training };

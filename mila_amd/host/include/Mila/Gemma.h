@@ -432,6 +432,21 @@ namespace Mila::Dnn
             res2_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, D } );
             geglu_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, cfg_.hidden_dim } );
             for ( int i = 0; i < 2; ++i ) blk_out_[ i ] = std::make_shared<TensorType>( dev, shape_t{ 1, P, D } );
+            // ... and one output buffer per component ROLE, shared by that role's component in every block (blocks run one after the other): the reference's pooled block
+            // workspace (Gemma.ixx allocateBlockWorkspace: normed, qkv, q/k/v_normed, o, o_normed, ffn_in, gate_up, ffn_down, ffn_normed).  Per layer only the KV caches
+            // and the parameters remain (Tests/.../Gemma.Cuda.cpp:494 StateMemory_PerLayerSlopeIsKvCacheNotActivations).
+            const dim_t maxpacked = std::max( cfg_.packedQkvWidth( false ), cfg_.packedQkvWidth( true ) );
+            ws_normed_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, D } );
+            ws_o_normed_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, D } );
+            ws_ffn_in_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, D } );
+            ws_ffn_normed_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, D } );
+            ws_q_normed_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, maxq } );
+            ws_k_normed_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, maxkv } );
+            ws_v_normed_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, maxkv } );
+            ws_qkv_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, maxpacked } );
+            ws_o_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, D } );
+            ws_gate_up_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, 2 * cfg_.hidden_dim } );
+            ws_down_ = std::make_shared<TensorType>( dev, shape_t{ 1, P, D } );
             for ( dim_t i = 0; i < cfg_.num_layers; ++i )
             {
                 const std::string n = name_ + ".tf_layer_" + std::to_string( i );
@@ -450,6 +465,11 @@ namespace Mila::Dnn
                     block->geglu->installSharedOutput( geglu_ );
                     block->res_1->installSharedOutput( res1_ );
                     block->res_2->installSharedOutput( res2_ );
+                    block->input_norm->installSharedOutput( ws_normed_ ); block->post_attn_norm->installSharedOutput( ws_o_normed_ );
+                    block->pre_ffn_norm->installSharedOutput( ws_ffn_in_ ); block->post_ffn_norm->installSharedOutput( ws_ffn_normed_ );
+                    block->q_norm->installSharedOutput( ws_q_normed_ ); block->k_norm->installSharedOutput( ws_k_normed_ ); block->v_norm->installSharedOutput( ws_v_normed_ );
+                    block->qkv_proj->installSharedOutput( ws_qkv_ ); block->o_proj->installSharedOutput( ws_o_ );
+                    block->fc_gate_up->installSharedOutput( ws_gate_up_ ); block->fc_down->installSharedOutput( ws_down_ );
                     block->build( BuildContext( shape_t{ 1, P, D }, RuntimeMode::Inference ) );
                     layers_.push_back( block );
                 };
@@ -1081,6 +1101,86 @@ namespace Mila::Dnn
                 for ( auto* lin : { L.qkv_proj.get(), L.o_proj.get(), L.fc_gate_up.get(), L.fc_down.get() } ) lin->getOperation().setResidentPrefillWeights( on );
             ctx_->synchronize();
         }
+        // ------------------------------------------------------------------------------------
+        // footprint (Gemma.ixx:340-470): getMemoryStats() = what the model holds, getRequiredMemory() = what a model of this configuration, sequence length and
+        // prefill chunk would hold once built and loaded -- computed from the configuration alone.  Two corrections as in the reference: the tied head reports the
+        // shared table, subtracted once; every block reports one owner's RoPE tables, of which one pair per distinct geometry exists.
+        // ------------------------------------------------------------------------------------
+        MemoryStats getMemoryStats() const
+        {
+            MemoryStats st;
+            std::map<const void*, std::pair<size_t, size_t>> rope;      // table -> (blocks sharing it, bytes one owner reports)
+            for ( auto& L : layers_ )
+            {
+                st += L.getMemoryStats();
+                auto& e = rope[ L.rope->getOperation().tableKey() ];
+                e.first += 1; e.second = L.rope->getOperation().stateBytes();
+            }
+            for ( auto& [ key, e ] : rope ) st.device_state_bytes -= ( e.first - 1 ) * e.second;
+            st += temb_->getMemoryStats();
+            st += final_norm_->getMemoryStats();
+            const MemoryStats head = lm_head_->getMemoryStats();
+            st += head;
+            st.device_parameter_bytes -= head.device_parameter_bytes;      // tied: the table is temb's
+            st.device_state_bytes += ownStateBytes();
+            return st;
+        }
+        MemoryStats getRequiredMemory() const
+        {
+            const dim_t D = cfg_.embedding_dim, P = max_prefill_;
+            MemoryStats st;
+            const BuildContext block_ctx( shape_t{ 1, P, D }, RuntimeMode::Inference );
+            std::map<std::tuple<dim_t, uint32_t, dim_t>, std::pair<size_t, size_t>> rope;
+            for ( auto& L : layers_ )
+            {
+                st += L.getRequiredMemory( block_ctx );
+                uint32_t base_bits;
+                const float base = L.rope->getConfig().getBase();
+                std::memcpy( &base_bits, &base, 4 );
+                auto& e = rope[ { L.rope->getConfig().getHeadDim(), base_bits, L.rope->getConfig().getRotaryDim() } ];
+                e.first += 1; e.second = L.rope->getRequiredMemory( block_ctx ).device_state_bytes;
+            }
+            for ( auto& [ key, e ] : rope ) st.device_state_bytes -= ( e.first - 1 ) * e.second;
+            st += temb_->getRequiredMemory( BuildContext( shape_t{ 1, P }, RuntimeMode::Inference ) );
+            st += final_norm_->getRequiredMemory( BuildContext( shape_t{ 1, 1, D }, RuntimeMode::Inference ) );
+            const MemoryStats head = lm_head_->getRequiredMemory( BuildContext( shape_t{ 1, 1, D }, RuntimeMode::Inference ) );
+            st += head;
+            st.device_parameter_bytes -= head.device_parameter_bytes;
+            st.device_state_bytes += requiredOwnStateBytes();
+            return st;
+        }
+    private:
+        /// the transformer's own device buffers: the pooled block workspace, the prefill / fused-step scratch, logits, sampler and position words
+        size_t ownStateBytes() const
+        {
+            size_t b = 0;
+            for ( const auto& t : { q_, k_, v_, attn_out_, res1_, res2_, geglu_, blk_out_[ 0 ], blk_out_[ 1 ], ws_normed_, ws_o_normed_, ws_ffn_in_, ws_ffn_normed_, ws_q_normed_,
+                                    ws_k_normed_, ws_v_normed_, ws_qkv_, ws_o_, ws_gate_up_, ws_down_ } ) b += tensorBytes( t );
+            for ( const auto* t : { hidden_[ 0 ].get(), hidden_[ 1 ].get(), hidden_[ 2 ].get(), pf_x_[ 0 ].get(), pf_x_[ 1 ].get(), pf_norm_.get(), pf_norm2_.get(), pf_q8_[ 0 ].get(),
+                                    pf_q8_[ 1 ].get(), f_qkv_.get(), f_q_.get(), f_o_.get(), f_down_.get(), f_act_.get(), ov_qkv_.get(), ov_o_.get(), ov_gate_up_.get() } ) b += tensorBytes( t );
+            for ( const auto* t : { logits_.get(), sample_scratch_.get(), attn_partials_.get(), pf_ts_[ 0 ].get(), pf_ts_[ 1 ].get() } ) b += tensorBytes( t );
+            b += tensorBytes( pos_dev_.get() );
+            return b;
+        }
+        size_t requiredOwnStateBytes() const
+        {
+            const size_t D = static_cast<size_t>( cfg_.embedding_dim ), P = static_cast<size_t>( max_prefill_ ), F = static_cast<size_t>( cfg_.hidden_dim );
+            const size_t maxq = static_cast<size_t>( std::max( cfg_.qWidth( false ), cfg_.qWidth( true ) ) ), maxkv = static_cast<size_t>( std::max( cfg_.kvWidth( false ), cfg_.kvWidth( true ) ) );
+            const size_t maxpacked = static_cast<size_t>( std::max( cfg_.packedQkvWidth( false ), cfg_.packedQkvWidth( true ) ) );
+            size_t e = 0;      // bf16 elements
+            e += P * ( maxq + 2 * maxkv + maxq + D + D + F + 2 * D );                                       // q k v attn_out res1 res2 geglu blk_out x 2
+            e += P * ( 4 * D + maxq + 2 * maxkv + maxpacked + D + 2 * F + D );                              // the pooled role outputs
+            e += 3 * D + 2 * P * D + 2 * P * D;                                                              // hidden x 3, pf_x x 2, pf_norm, pf_norm2
+            if ( kFmt != 0 ) e += 2 * P * ( ( D + 1 ) / 2 );                                                 // per-token e4m3 rows of the fp8 x fp8 prefill paths
+            e += maxpacked + maxq + D + D + F;                                                               // f_qkv f_q f_o f_down f_act
+            size_t b = e * 2;
+            if ( ov_qkv_ ) b += P * ( maxpacked + D + 2 * F ) * 2;                                           // the two-stream prefill's buffers, once that path has run
+            b += static_cast<size_t>( cfg_.vocab_size ) * 4 + ( ( mila_cdna4_sample_scratch_bytes() / 4 ) * 4 ) + ( ( attnScratchBytes() + 3 ) / 4 ) * 4;
+            if ( kFmt != 0 ) b += 2 * P * 4;
+            b += 4;                                                                                          // the device position word
+            return b;
+        }
+    public:
         /// bytes of op-owned prefill staging the layer Linears hold right now (fp8 policy: bf16 copies, 0 while the W8A8 prefill is on; fp4 policy: e4m3 copies)
         double residentStagingBytes() const
         {
@@ -1100,6 +1200,7 @@ namespace Mila::Dnn
         std::shared_ptr<LmHeadLinearType> lm_head_;
         std::unique_ptr<TensorType> hidden_[ 3 ], pf_x_[ 2 ], f_qkv_, f_q_, f_o_, f_down_, f_act_;
         std::shared_ptr<TensorType> q_, k_, v_, attn_out_, res1_, res2_, geglu_, blk_out_[ 2 ];   // the blocks' shared workspace
+        std::shared_ptr<TensorType> ws_normed_, ws_o_normed_, ws_ffn_in_, ws_ffn_normed_, ws_q_normed_, ws_k_normed_, ws_v_normed_, ws_qkv_, ws_o_, ws_gate_up_, ws_down_;   // ... one output per component role
         std::shared_ptr<TokenEmbeddingType> temb_;
         std::unique_ptr<LogitsTensor> logits_;
         std::unique_ptr<TokenTensor> pos_dev_;

@@ -80,6 +80,9 @@ namespace Mila::Dnn
         const float* sinCache() const noexcept { return operation_->sinCache(); }
         const RopeConfig& getConfig() const noexcept { return config_; }
         OpType& getOperation() { return *operation_; }
+        /// the cos / sin tables: what one owner pays (they are shared through RopeCacheRegistry; a composite subtracts the duplicates, Gemma.ixx:455-462)
+        MemoryStats getMemoryStats() const override { MemoryStats st; if ( operation_ && this->isBuilt() ) st.device_state_bytes = operation_->stateBytes(); return st; }
+        MemoryStats getRequiredMemory( const BuildContext& ) const override { MemoryStats st; if ( operation_ ) st.device_state_bytes = operation_->requiredStateBytes(); return st; }
 
     protected:
         void onExecutionContextSet() override
@@ -176,6 +179,25 @@ namespace Mila::Dnn
         {
             if ( this->isBuilt() ) throw std::runtime_error( this->getName() + ": installSharedOutput() must precede build()" );
             output_ = std::move( output );
+            output_installed_ = true;
+        }
+        /// state: the op-owned K / V caches (capacity rule CudaGqaOp.ixx:552-574) + the output buffer unless installed
+        MemoryStats getMemoryStats() const override
+        {
+            MemoryStats st;
+            if ( operation_ ) st.device_state_bytes += operation_->stateBytes();
+            if ( !output_installed_ ) st.device_state_bytes += tensorBytes( output_ );
+            return st;
+        }
+        MemoryStats getRequiredMemory( const BuildContext& ctx ) const override
+        {
+            const auto& s = ctx.inputShape();
+            if ( s.size() != 3 ) throw std::invalid_argument( this->getName() + ": build shape must be [B, max_seq, packed QKV width]" );
+            const dim_t chunk = ctx.prefillChunkSize() > 0 ? std::min( ctx.prefillChunkSize(), s[ 1 ] ) : s[ 1 ];
+            MemoryStats st;
+            st.device_state_bytes += operation_->requiredStateBytes( static_cast<int>( s[ 0 ] ), s[ 1 ], chunk );
+            if ( !output_installed_ && !ctx.isOutputInstalled() ) st.device_state_bytes += static_cast<size_t>( s[ 0 ] * chunk * config_.getModelDim() ) * TensorType::kElemBytes;
+            return st;
         }
 
         uint16_t* keyCache() noexcept { return operation_->keyCache(); }
@@ -218,7 +240,7 @@ namespace Mila::Dnn
         std::shared_ptr<TensorType> output_;
         std::unique_ptr<TensorType> view_;
         dim_t chunk_{ 0 };
-        bool decode_active_{ false };
+        bool decode_active_{ false }, output_installed_{ false };
     };
 
     // ---------------------------------------------------------------------------------------
@@ -253,7 +275,14 @@ namespace Mila::Dnn
             operation_->forward( input, *view_ );
             return *view_;
         }
-        void installSharedOutput( std::shared_ptr<TensorType> output ) { output_ = std::move( output ); }
+        void installSharedOutput( std::shared_ptr<TensorType> output ) { output_ = std::move( output ); output_installed_ = true; }
+        MemoryStats getMemoryStats() const override { MemoryStats st; if ( !output_installed_ ) st.device_state_bytes = tensorBytes( output_ ); return st; }
+        MemoryStats getRequiredMemory( const BuildContext& ctx ) const override
+        {
+            MemoryStats st;
+            if ( !output_installed_ && !ctx.isOutputInstalled() ) st.device_state_bytes = static_cast<size_t>( shapeSize( ctx.inputShape() ) / 2 ) * TensorType::kElemBytes;
+            return st;
+        }
     protected:
         void onExecutionContextSet() override { operation_ = std::make_shared<OpType>( this->getExecutionContext() ); }
         void onBuilding( const BuildContext& ctx ) override
@@ -268,6 +297,7 @@ namespace Mila::Dnn
         std::shared_ptr<OpType> operation_;
         std::shared_ptr<TensorType> output_;
         std::unique_ptr<TensorType> view_;
+        bool output_installed_{ false };
     };
 
     class ResidualConfig
@@ -303,7 +333,14 @@ namespace Mila::Dnn
             operation_->forward( input_a, input_b, *view_ );
             return *view_;
         }
-        void installSharedOutput( std::shared_ptr<TensorType> output ) { output_ = std::move( output ); }
+        void installSharedOutput( std::shared_ptr<TensorType> output ) { output_ = std::move( output ); output_installed_ = true; }
+        MemoryStats getMemoryStats() const override { MemoryStats st; if ( !output_installed_ ) st.device_state_bytes = tensorBytes( output_ ); return st; }
+        MemoryStats getRequiredMemory( const BuildContext& ctx ) const override
+        {
+            MemoryStats st;
+            if ( !output_installed_ && !ctx.isOutputInstalled() ) st.device_state_bytes = static_cast<size_t>( shapeSize( ctx.inputShape() ) ) * TensorType::kElemBytes;
+            return st;
+        }
     protected:
         void onExecutionContextSet() override { operation_ = std::make_shared<OpType>( this->getExecutionContext() ); }
         void onBuilding( const BuildContext& ctx ) override
@@ -315,6 +352,7 @@ namespace Mila::Dnn
         std::shared_ptr<OpType> operation_;
         std::shared_ptr<TensorType> output_;
         std::unique_ptr<TensorType> view_;
+        bool output_installed_{ false };
     };
 
     // ---------------------------------------------------------------------------------------
@@ -429,6 +467,24 @@ namespace Mila::Dnn
         std::shared_ptr<TableScaleTensorType> getWeightScalesTensorShared() const noexcept requires kIsQuantized { return wte_scale_; }
         const TokenEmbeddingConfig& getConfig() const noexcept { return config_; }
         size_t getParameterBytes() const { return ( wte_ ? wte_->sizeInBytes() : 0 ) + ( wte_scale_ ? wte_scale_->sizeInBytes() : 0 ); }
+        /// parameters: the table (+ one scale per row); state: the [max_batch, max_seq, C] output and the 4-byte index-error flag
+        MemoryStats getMemoryStats() const override
+        {
+            MemoryStats st;
+            st.device_parameter_bytes = getParameterBytes();
+            st.device_state_bytes = tensorBytes( output_ ) + tensorBytes( error_flag_ );
+            return st;
+        }
+        MemoryStats getRequiredMemory( const BuildContext& ctx ) const override
+        {
+            const auto& s = ctx.inputShape();
+            if ( s.size() != 2 ) throw std::invalid_argument( this->getName() + ": build shape must be [B, T] token ids" );
+            const size_t V = static_cast<size_t>( config_.getVocabSize() ), C = static_cast<size_t>( config_.getEmbeddingDim() );
+            MemoryStats st;
+            st.device_parameter_bytes = V * C * TableTensorType::kElemBytes + ( kIsQuantized ? V * TableScaleTensorType::kElemBytes : 0 );
+            st.device_state_bytes = static_cast<size_t>( s[ 0 ] * s[ 1 ] ) * C * EmbeddingTensorType::kElemBytes + TokenIndexType::kElemBytes;
+            return st;
+        }
 
     protected:
         void onExecutionContextSet() override
@@ -620,10 +676,29 @@ namespace Mila::Dnn
         {
             if ( this->isBuilt() ) throw std::runtime_error( this->getName() + ": installSharedWorkspace() must precede build()" );
             q_ = std::move( q ); k_ = std::move( k ); if ( !global ) v_ = std::move( v ); out_ = std::move( stream );
+            workspace_installed_ = true;
+        }
+        /// the block's own split scratch / output stream (unless installed: Gemma.Block.ixx:433-440 sums the children, the owner of a pooled workspace counts it once)
+        size_t ownWorkspaceBytes() const noexcept { return workspace_installed_ ? 0 : tensorBytes( q_ ) + tensorBytes( k_ ) + tensorBytes( v_ ) + tensorBytes( out_ ); }
+        size_t requiredWorkspaceBytes( dim_t B, dim_t P ) const noexcept
+        {
+            if ( workspace_installed_ ) return 0;
+            return static_cast<size_t>( B * P ) * static_cast<size_t>( qProjWidth() + ( global ? 1 : 2 ) * kvWidth() + config_.model_dim ) * TensorType::kElemBytes;
+        }
+        /// every leaf but the attention component, with the BuildContext buildChildren() gives it
+        template<typename F> void forEachLeaf( dim_t B, dim_t P, F&& f ) const
+        {
+            const dim_t D = config_.model_dim, HD = config_.head_dim, NH = config_.num_heads, NKV = config_.num_kv_heads;
+            const auto inf = [&]( const shape_t& shape ) { return BuildContext( shape, RuntimeMode::Inference ); };
+            f( *input_norm, inf( { B, P, D } ) ); f( *q_norm, inf( { B, P * NH, HD } ) ); f( *k_norm, inf( { B, P * NKV, HD } ) ); f( *v_norm, inf( { B, P * NKV, HD } ) );
+            f( *post_attn_norm, inf( { B, P, D } ) ); f( *pre_ffn_norm, inf( { B, P, D } ) ); f( *post_ffn_norm, inf( { B, P, D } ) );
+            f( *qkv_proj, inf( { B, P, D } ) ); f( *rope, inf( { B, P, qProjWidth() } ) ); f( *o_proj, inf( { B, P, qProjWidth() } ) ); f( *res_1, inf( { B, P, D } ) );
+            f( *fc_gate_up, inf( { B, P, D } ) ); f( *geglu, inf( { B, P, 2 * config_.hidden_dim } ) ); f( *fc_down, inf( { B, P, config_.hidden_dim } ) ); f( *res_2, inf( { B, P, D } ) );
         }
     protected:
         GemmaBlockConfig config_;
         std::shared_ptr<TensorType> q_, k_, v_, out_;
+        bool workspace_installed_{ false };
     };
 
     /// kGlobal blocks: K = V (no v_proj, V = v_norm(raw k_proj)), the global head_dim / rotary share / theta, an unbounded cache.
@@ -655,6 +730,27 @@ namespace Mila::Dnn
         float attentionScale() const noexcept override { return attn->scale(); }
         void prefillFromCache( const TensorType& q, TensorType& out, int chunk, int position ) override { attn->prefillFromCache( q, out, chunk, position ); }
         bool rewindKvCache( dim_t position, dim_t written ) override { attn->noteCacheLength( written ); return attn->rewindKvCache( position ); }
+
+        /// Gemma.Block.ixx:433-440 / :464-490: the children's stats + the block's own workspace (unless the owner of a pooled one installed it)
+        MemoryStats getMemoryStats() const override
+        {
+            MemoryStats st;
+            if ( !this->input_norm ) return st;
+            this->forEachLeaf( 1, 1, [&]( const auto& c, const BuildContext& ) { st += c.getMemoryStats(); } );
+            st += attn->getMemoryStats();
+            st.device_state_bytes += this->ownWorkspaceBytes();
+            return st;
+        }
+        MemoryStats getRequiredMemory( const BuildContext& ctx ) const override
+        {
+            const auto& s = ctx.inputShape();
+            if ( s.size() != 3 || s[ 2 ] != this->config_.model_dim ) throw std::invalid_argument( this->getName() + ": input must be rank 3 [B, T, model_dim]" );
+            MemoryStats st;
+            this->forEachLeaf( s[ 0 ], s[ 1 ], [&]( const auto& c, const BuildContext& cc ) { st += c.getRequiredMemory( cc ); } );
+            st += attn->getRequiredMemory( BuildContext( shape_t{ s[ 0 ], this->config_.max_seq, this->packedQKVWidth() }, RuntimeMode::Inference, false, s[ 1 ] ) );
+            st.device_state_bytes += this->requiredWorkspaceBytes( s[ 0 ], s[ 1 ] );
+            return st;
+        }
 
     protected:
         void onExecutionContextSet() override

@@ -77,6 +77,27 @@ namespace Mila::Dnn
         Compute::RocmExecutionContext* context() const noexcept { return ctx_; }
         const GptConfig& config() const noexcept { return cfg_; }
 
+        /// GptTransformer.ixx:469-477: the children's stats (lenc, every block, ln_final, the untied lm_head) + the last-rows scratch of prefill()
+        MemoryStats getMemoryStats() const
+        {
+            MemoryStats st = lenc_->getMemoryStats();
+            for ( auto& b : blocks_ ) st += b->getMemoryStats();
+            st += ln_final_->getMemoryStats();
+            st += lm_head_->getMemoryStats();
+            st.device_state_bytes += tensorBytes( last_rows_.get() );
+            return st;
+        }
+        /// what a model of this configuration, batch and sequence length holds once built (KV caches come with initializeKVCache, as in the reference)
+        MemoryStats getRequiredMemory() const
+        {
+            const BuildContext stream_ctx( shape_t{ B_, T_, cfg_.embedding_dim }, RuntimeMode::Inference );
+            MemoryStats st = lenc_->getRequiredMemory( BuildContext( shape_t{ B_, T_ }, RuntimeMode::Inference ) );
+            for ( auto& b : blocks_ ) st += b->getRequiredMemory( stream_ctx );
+            st += ln_final_->getRequiredMemory( stream_ctx );
+            st += lm_head_->getRequiredMemory( stream_ctx );
+            return st;
+        }
+
         /// parameter order of oracle/mila_oracle.c: orc_cpu_gpt2_forward (bf16 blobs on the host)
         size_t parameterCount() const { return 2 + 12 * blocks_.size() + 3; }
         void loadParameter( size_t index, const void* host_bf16, size_t bytes )

@@ -61,6 +61,15 @@ namespace Mila::Dnn
             copyToDevice( *t, blob, bytes, ctx );
         }
         const LayerNormConfig& getConfig() const noexcept { return config_; }
+        /// LayerNorm.ixx:363: parameters weight (+ bias), state the output buffer (the op keeps no per-row statistics at inference)
+        MemoryStats getMemoryStats() const override { MemoryStats st; st.device_parameter_bytes = tensorBytes( weight_ ) + tensorBytes( bias_ ); st.device_state_bytes = tensorBytes( output_ ); return st; }
+        MemoryStats getRequiredMemory( const BuildContext& ctx ) const override
+        {
+            MemoryStats st;
+            st.device_parameter_bytes = static_cast<size_t>( config_.dim() ) * ( config_.hasBias() ? 2 : 1 ) * TensorType::kElemBytes;
+            st.device_state_bytes = static_cast<size_t>( shapeSize( ctx.inputShape() ) ) * TensorType::kElemBytes;
+            return st;
+        }
     protected:
         void onExecutionContextSet() override
         {
@@ -100,6 +109,8 @@ namespace Mila::Dnn
             operation_->forward( input, *view_ );
             return *view_;
         }
+        MemoryStats getMemoryStats() const override { MemoryStats st; st.device_state_bytes = tensorBytes( output_ ); return st; }
+        MemoryStats getRequiredMemory( const BuildContext& ctx ) const override { MemoryStats st; st.device_state_bytes = static_cast<size_t>( shapeSize( ctx.inputShape() ) ) * TensorType::kElemBytes; return st; }
     protected:
         void onExecutionContextSet() override { operation_ = std::make_shared<OpType>( this->getExecutionContext() ); }
         void onBuilding( const BuildContext& ctx ) override { output_ = std::make_shared<TensorType>( this->getExecutionContext()->getDeviceId(), ctx.inputShape() ); }
@@ -168,6 +179,21 @@ namespace Mila::Dnn
         void resetKVCache() { operation_->resetKvCache(); decode_active_ = false; }
         const MultiHeadAttentionConfig& getConfig() const noexcept { return config_; }
         OpType& getOperation() noexcept { return *operation_; }
+        /// state: the [B, T, C] output, the [B, 1, C] decode output and -- once initializeKVCache() ran -- the op's K / V caches (CudaMhaOp.ixx:112-143: allocated there, not at build)
+        MemoryStats getMemoryStats() const override
+        {
+            MemoryStats st;
+            st.device_state_bytes = tensorBytes( output_ ) + tensorBytes( decode_output_ ) + ( operation_ ? operation_->stateBytes() : 0 );
+            return st;
+        }
+        MemoryStats getRequiredMemory( const BuildContext& ctx ) const override
+        {
+            const auto& s = ctx.inputShape();
+            if ( s.size() != 3 || s[ 2 ] != 3 * config_.getModelDim() ) throw std::invalid_argument( this->getName() + ": build shape must be [B, T, 3 * model_dim]" );
+            MemoryStats st;
+            st.device_state_bytes = static_cast<size_t>( s[ 0 ] * ( s[ 1 ] + 1 ) * config_.getModelDim() ) * TensorType::kElemBytes;
+            return st;
+        }
     protected:
         void onExecutionContextSet() override { operation_ = std::make_shared<OpType>( this->getExecutionContext(), config_.getModelDim(), config_.getNumHeads() ); }
         void onBuilding( const BuildContext& ctx ) override
@@ -261,6 +287,24 @@ namespace Mila::Dnn
             ctx->synchronize();
             return v;
         }
+        /// parameters wte + wpe; state the [B, T, C] output and the 4-byte index-error flag
+        MemoryStats getMemoryStats() const override
+        {
+            MemoryStats st;
+            st.device_parameter_bytes = tensorBytes( wte_ ) + tensorBytes( wpe_ );
+            st.device_state_bytes = tensorBytes( output_ ) + tensorBytes( error_flag_ );
+            return st;
+        }
+        MemoryStats getRequiredMemory( const BuildContext& ctx ) const override
+        {
+            const auto& s = ctx.inputShape();
+            if ( s.size() != 2 ) throw std::invalid_argument( this->getName() + ": build shape must be [B, T <= max_seq_len]" );
+            const size_t C_ = static_cast<size_t>( config_.getEmbeddingDim() );
+            MemoryStats st;
+            st.device_parameter_bytes = static_cast<size_t>( config_.getVocabularyLength() + config_.getMaxSequenceLength() ) * C_ * EmbeddingsTensorType::kElemBytes;
+            st.device_state_bytes = static_cast<size_t>( s[ 0 ] * s[ 1 ] ) * C_ * EmbeddingsTensorType::kElemBytes + TokenIndexType::kElemBytes;
+            return st;
+        }
     protected:
         /// build shape [B, T] of token ids
         void onBuilding( const BuildContext& ctx ) override
@@ -328,6 +372,16 @@ namespace Mila::Dnn
         {
             if ( !this->isBuilt() ) throw std::runtime_error( "MLP must be built before decode()." );
             return fc_2->forward( gelu->forward( fc_1->forward( input ) ) );
+        }
+        MemoryStats getMemoryStats() const override { MemoryStats st; if ( fc_1 ) { st += fc_1->getMemoryStats(); st += gelu->getMemoryStats(); st += fc_2->getMemoryStats(); } return st; }
+        MemoryStats getRequiredMemory( const BuildContext& ctx ) const override
+        {
+            auto s = ctx.inputShape();
+            MemoryStats st = fc_1->getRequiredMemory( BuildContext( s, RuntimeMode::Inference ) );
+            s.back() = config_.getHiddenSize();
+            st += gelu->getRequiredMemory( BuildContext( s, RuntimeMode::Inference ) );
+            st += fc_2->getRequiredMemory( BuildContext( s, RuntimeMode::Inference ) );
+            return st;
         }
     protected:
         void onExecutionContextSet() override
@@ -415,6 +469,26 @@ namespace Mila::Dnn
             attn->initializeKVCache( max_seq_len );
         }
         void resetKVCache() { attn->resetKVCache(); }
+        /// GptBlock.ixx:364-372: the children's stats, summed
+        MemoryStats getMemoryStats() const override
+        {
+            MemoryStats st;
+            if ( !attn ) return st;
+            st += attn->getMemoryStats(); st += ln_1->getMemoryStats(); st += ln_2->getMemoryStats(); st += fc_qkv_proj->getMemoryStats(); st += fc_out_proj->getMemoryStats();
+            st += res_1->getMemoryStats(); st += res_2->getMemoryStats(); st += mlp->getMemoryStats();
+            return st;
+        }
+        MemoryStats getRequiredMemory( const BuildContext& ctx ) const override
+        {
+            const auto& s = ctx.inputShape();
+            if ( s.size() != 3 || s[ 2 ] != config_.model_dim ) throw std::invalid_argument( this->getName() + ": input must be rank 3 [B, T, model_dim]" );
+            const auto inf = [&]( const shape_t& shape ) { return BuildContext( shape, RuntimeMode::Inference ); };
+            MemoryStats st;
+            st += ln_1->getRequiredMemory( inf( s ) ); st += ln_2->getRequiredMemory( inf( s ) ); st += fc_qkv_proj->getRequiredMemory( inf( s ) );
+            st += attn->getRequiredMemory( inf( { s[ 0 ], s[ 1 ], 3 * config_.model_dim } ) ); st += fc_out_proj->getRequiredMemory( inf( s ) );
+            st += res_1->getRequiredMemory( inf( s ) ); st += res_2->getRequiredMemory( inf( s ) ); st += mlp->getRequiredMemory( inf( s ) );
+            return st;
+        }
         std::vector<std::string> childNames() const
         {
             return { attn->getName(), ln_1->getName(), ln_2->getName(), fc_qkv_proj->getName(), fc_out_proj->getName(), res_1->getName(), res_2->getName(), mlp->getName(),

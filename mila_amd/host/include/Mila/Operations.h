@@ -11,6 +11,10 @@
 #pragma once
 
 #include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 #include "Core.h"
 #include "Quantization.h"
@@ -290,9 +294,16 @@ namespace Mila::Dnn::Compute
         const float* weightFp8Scale() const noexcept { return weight_fp8_scale_ ? weight_fp8_scale_->data() : nullptr; }
 
         /// bytes of the op-owned resident staging (0 when off, when W8A8 is on, or for unquantized weights)
-        size_t residentBytes() const noexcept
+        size_t residentBytes() const noexcept { return ( resident_bf16_ ? resident_bf16_->size() * 2 : 0 ) + ( resident_e4m3_ ? resident_e4m3_->size() : 0 ); }
+        /// op-owned device state right now: the resident staging + the fp4 policy's per-tensor e4m3 scale (CudaLinearOp.ixx:1118-1129 owns the same scalar)
+        size_t stateBytes() const noexcept { return residentBytes() + ( weight_fp8_scale_ ? sizeof( float ) : 0 ); }
+        /// ... and once quantized weights are in place, under the current switches (getRequiredStateMemorySize of the reference's ops)
+        size_t requiredStateBytes() const noexcept
         {
-            return ( resident_bf16_ ? resident_bf16_->size() * 2 : 0 ) + ( resident_e4m3_ ? resident_e4m3_->size() : 0 ) + ( weight_fp8_scale_ ? sizeof( float ) : 0 );
+            const size_t N = static_cast<size_t>( cfg_.out_features ), K = static_cast<size_t>( cfg_.in_features );
+            if constexpr ( kFmt == 1 ) return ( resident_ && !use_fp8_activation_prefill_ ) ? N * K * 2 : 0;
+            else if constexpr ( kFmt == 2 ) return sizeof( float ) + ( ( resident_ && K % 32 == 0 ) ? N * K : 0 );
+            else return 0;
         }
         const void* weightPtr() const noexcept { return weight_; }
         const float* scalesPtr() const noexcept { return scales_; }
@@ -395,6 +406,7 @@ namespace Mila::Dnn::Compute
                                                 outer, 1, dim, cfg_.epsilon, cfg_.weight_offset, context_->getStream() ) );
         }
         const TensorType* rstd() const noexcept { return rstd_.get(); }
+        size_t stateBytes() const noexcept { return rstd_ ? rstd_->sizeInBytes() : 0; }
         const uint16_t* weightPtr() const noexcept { return w_; }
         float epsilon() const noexcept { return cfg_.epsilon; }
     private:
@@ -510,6 +522,33 @@ namespace Mila::Dnn::Compute
         dim_t rotary_dim{ 0 };
     };
 
+    /// Process-wide cos / sin tables, one pair per distinct (device, max_seq, head_dim, base, rotary_dim): every layer of a model that rotates with the same geometry
+    /// shares ONE pair (the reference's RopeCacheRegistry, Gemma.ixx:455-462: "only one per distinct key is ever allocated: Gemma has two, the local and global theta").
+    /// Entries are weak: the tables live as long as an op holds them.
+    class RopeCacheRegistry
+    {
+    public:
+        using CacheTensor = Tensor<TensorDataType::FP32, RocmDeviceMemoryResource>;
+        struct Tables { std::shared_ptr<CacheTensor> cos, sin; };
+        /// the shared pair for this key; `created` says whether the caller must fill it
+        static Tables acquire( DeviceId dev, const std::tuple<int, dim_t, dim_t, uint32_t, dim_t>& key, dim_t max_seq, dim_t head_dim, bool& created )
+        {
+            static std::mutex mu;
+            static std::map<std::tuple<int, dim_t, dim_t, uint32_t, dim_t>, std::pair<std::weak_ptr<CacheTensor>, std::weak_ptr<CacheTensor>>> entries;
+            std::lock_guard<std::mutex> lock( mu );
+            auto& e = entries[ key ];
+            Tables t{ e.first.lock(), e.second.lock() };
+            created = !t.cos || !t.sin;
+            if ( created )
+            {
+                t.cos = std::make_shared<CacheTensor>( dev, shape_t{ max_seq, head_dim / 2 } );
+                t.sin = std::make_shared<CacheTensor>( dev, shape_t{ max_seq, head_dim / 2 } );
+                e = { t.cos, t.sin };
+            }
+            return t;
+        }
+    };
+
     class RocmRopeOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
     {
     public:
@@ -522,13 +561,24 @@ namespace Mila::Dnn::Compute
         }
         void build( const BuildContext& )
         {
-            cos_ = std::make_unique<CacheTensor>( context_->getDeviceId(), shape_t{ cfg_.max_seq, cfg_.head_dim / 2 } );
-            sin_ = std::make_unique<CacheTensor>( context_->getDeviceId(), shape_t{ cfg_.max_seq, cfg_.head_dim / 2 } );
-            rocmCheck( mila_cdna4_rope_build_cache( cos_->data(), sin_->data(), narrowToKernelIndex( cfg_.max_seq, "max_seq" ),
-                                                    narrowToKernelIndex( cfg_.head_dim, "head_dim" ), cfg_.base,
-                                                    narrowToKernelIndex( cfg_.rotary_dim, "rotary_dim" ), context_->getStream() ) );
+            uint32_t base_bits;
+            std::memcpy( &base_bits, &cfg_.base, 4 );
+            bool created = false;
+            auto t = RopeCacheRegistry::acquire( context_->getDeviceId(), { context_->getDeviceId().index, cfg_.max_seq, cfg_.head_dim, base_bits, cfg_.rotary_dim }, cfg_.max_seq, cfg_.head_dim, created );
+            cos_ = t.cos; sin_ = t.sin;
+            if ( created )
+            {
+                rocmCheck( mila_cdna4_rope_build_cache( cos_->data(), sin_->data(), narrowToKernelIndex( cfg_.max_seq, "max_seq" ),
+                                                        narrowToKernelIndex( cfg_.head_dim, "head_dim" ), cfg_.base,
+                                                        narrowToKernelIndex( cfg_.rotary_dim, "rotary_dim" ), context_->getStream() ) );
+                context_->synchronize();      // another op (another context's stream) may read the shared tables next
+            }
             built_ = true;
         }
+        /// what ONE owner of these tables pays (Rope.ixx:254: the operation reports one owner's bytes; a composite whose layers share a key subtracts the duplicates)
+        size_t stateBytes() const noexcept { return ( cos_ ? cos_->sizeInBytes() : 0 ) + ( sin_ ? sin_->sizeInBytes() : 0 ); }
+        size_t requiredStateBytes() const noexcept { return 2 * static_cast<size_t>( cfg_.max_seq ) * static_cast<size_t>( cfg_.head_dim / 2 ) * sizeof( float ); }
+        const void* tableKey() const noexcept { return cos_.get(); }      ///< equal for ops that share one pair
         /// rotate q [B,T,NH,HS] and k [B,T,NKV,HS] in place (Components/Encodings/Rope/Rope.ixx:107,160-200)
         void prefill( TensorType& q, TensorType& k, int B, int T, int position_offset ) const
         {
@@ -544,7 +594,7 @@ namespace Mila::Dnn::Compute
         const float* sinCache() const noexcept { return sin_ ? sin_->data() : nullptr; }
     private:
         RopeOpConfig cfg_;
-        std::unique_ptr<CacheTensor> cos_, sin_;
+        std::shared_ptr<CacheTensor> cos_, sin_;
         bool built_{ false };
     };
     template<> struct OperationTraits<OperationType::RopeOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmRopeOp; };
@@ -653,6 +703,12 @@ namespace Mila::Dnn::Compute
             length_ = position + 1;
         }
 
+        size_t stateBytes() const noexcept { return ( k_cache_ ? k_cache_->sizeInBytes() : 0 ) + ( v_cache_ ? v_cache_->sizeInBytes() : 0 ); }
+        size_t requiredStateBytes( int batch, dim_t max_seq, dim_t prefill_chunk ) const
+        {
+            return 2 * static_cast<size_t>( batch ) * static_cast<size_t>( cfg_.num_kv_heads ) * static_cast<size_t>( resolveCacheCapacity( max_seq, cfg_.window, prefill_chunk ) ) *
+                   static_cast<size_t>( cfg_.head_dim ) * 2;
+        }
         uint16_t* keyCache() noexcept { return k_cache_ ? k_cache_->data() : nullptr; }
         uint16_t* valueCache() noexcept { return v_cache_ ? v_cache_->data() : nullptr; }
         const GqaOpConfig& config() const noexcept { return cfg_; }
@@ -727,6 +783,7 @@ namespace Mila::Dnn::Compute
             return true;
         }
         dim_t cacheLength() const noexcept { return cached_seq_len_; }
+        size_t stateBytes() const noexcept { return ( k_cache_ ? k_cache_->sizeInBytes() : 0 ) + ( v_cache_ ? v_cache_->sizeInBytes() : 0 ); }
 
         // ---- IPositionalUnaryOp ----
         /// the whole prompt [B, T' <= max_seq, 3C]: causal attention + the prompt's K / V rows into the cache (CudaMhaOp.ixx:145-232)

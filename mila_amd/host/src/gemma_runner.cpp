@@ -531,6 +531,22 @@ HOST_API int mila_gemma_info( void* h, int64_t context, double* out )
     } );
 }
 
+/// out[0..2] = getRequiredMemory(): device parameter / device state / host state bytes; out[3..5] = getMemoryStats() likewise; out[6] = the context's scratch high-water mark
+HOST_API int mila_gemma_memory_stats( void* h, double* out )
+{
+    auto* r = static_cast<Runner*>( h );
+    return guarded( [&]
+    {
+        std::visit( [&]( auto& m )
+        {
+            const Mila::Dnn::MemoryStats req = m->getRequiredMemory(), act = m->getMemoryStats();
+            out[ 0 ] = static_cast<double>( req.device_parameter_bytes ); out[ 1 ] = static_cast<double>( req.device_state_bytes ); out[ 2 ] = static_cast<double>( req.host_state_bytes );
+            out[ 3 ] = static_cast<double>( act.device_parameter_bytes ); out[ 4 ] = static_cast<double>( act.device_state_bytes ); out[ 5 ] = static_cast<double>( act.host_state_bytes );
+            out[ 6 ] = static_cast<double>( m->context()->getScratchHighWaterBytes() );
+        }, r->model );
+    } );
+}
+
 /// nodes of the captured decode graph (0 before the first graph-mode step)
 HOST_API int mila_gemma_graph_node_count( void* h, int64_t* out )
 {

@@ -51,6 +51,17 @@ HOST_API int mila_gpt_load_parameter( void* h, int64_t index, const void* host_b
 {
     return guarded( [&] { static_cast<GptRunner*>( h )->model->loadParameter( static_cast<size_t>( index ), host_bf16, static_cast<size_t>( bytes ) ); } );
 }
+/// out[0..1] = getRequiredMemory(): device parameter / state bytes; out[2..3] = getMemoryStats() likewise
+HOST_API int mila_gpt_memory_stats( void* h, double* out )
+{
+    return guarded( [&]
+    {
+        auto& m = *static_cast<GptRunner*>( h )->model;
+        const Mila::Dnn::MemoryStats req = m.getRequiredMemory(), act = m.getMemoryStats();
+        out[ 0 ] = static_cast<double>( req.device_parameter_bytes ); out[ 1 ] = static_cast<double>( req.device_state_bytes );
+        out[ 2 ] = static_cast<double>( act.device_parameter_bytes ); out[ 3 ] = static_cast<double>( act.device_state_bytes );
+    } );
+}
 /// tokens [B,T] host int32 -> logits [B,T,V] host bf16 bits; returns 0, or a positive 1-based index of an out-of-range token
 /// component names in construction order, '\n'-separated; returns the bytes needed (with the terminator)
 HOST_API int64_t mila_gpt_component_names( void* h, char* buf, int64_t cap )

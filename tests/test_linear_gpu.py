@@ -1036,7 +1036,9 @@ def test_column_split_of_a_tile_list_that_ends_in_a_nearly_empty_round(M, K, N):
     rows = [0, 255, 256, M // 2, M - 1]
     # bf16
     need = lib.mila_cdna4_gemm_workspace_bytes(M, K, N)
-    assert need == 2 * M * 512 * 4, need                                    # S = 2 copies of the 512-column rest (16 K-tiles: 8 per copy)
+    tm = (M + 255) // 256
+    cut = ((tm * (N // 256)) // 256 * 256) // tm * 256                      # columns of the whole rounds: 8192 at eight tile-rows, 7168 at nine
+    assert need == 2 * M * (N - cut) * 4, need                              # S = 2 copies of the rest (16 K-tiles: 8 per copy)
     ws = torch.empty(need, dtype=torch.uint8, device="cuda")
     Yg = torch.full((M + 1, N), 0x1234, dtype=torch.int16, device="cuda")
     capi.last_form()
@@ -1054,9 +1056,12 @@ def test_column_split_of_a_tile_list_that_ends_in_a_nearly_empty_round(M, K, N):
     finally:
         capi.tune_reset()
     a, b = orc.from_bf16_bits(bits(Yg[:M])).astype(np.float64), orc.from_bf16_bits(bits(Y0)).astype(np.float64)
-    assert np.array_equal(bits(Yg[:M])[:, :8192], bits(Y0)[:, :8192]), "the 256 x 256 tiles and the 256 x 128 ring sum K in one order: same bits left of the cut"
+    assert np.array_equal(bits(Yg[:M])[:, :cut], bits(Y0)[:, :cut]), "the 256 x 256 tiles and the 256 x 128 ring sum K in one order: same bits left of the cut"
     assert np.abs(a - b).max() <= 2.0 ** -7 * np.abs(b).max()
-    # fp8 x fp8: W8A8 (per-channel scales, offset with the column range) and W4A8 (per-tensor scale)
+    # fp8 x fp8: W8A8 (per-channel scales, offset with the column range) and W4A8 (per-tensor scale); a K-tile is 128 bytes there: K = 2048 for two copies of 8 K-tiles
+    K = 2048
+    Wb = _weights(rng, N, K, "random")
+    X = orc.round_bf16((rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32))
     w8, sc = orc.quantize_fp8_per_channel(Wb)
     x8, ts = orc.quantize_act_fp8_per_token(X)
     need8 = lib.mila_cdna4_gemm_fp8_workspace_bytes(M, K, N)
