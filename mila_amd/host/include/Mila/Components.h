@@ -364,7 +364,7 @@ namespace Mila::Dnn
             if ( s.empty() || s.back() != config_.getInputFeatures() )
                 throw std::invalid_argument( this->getName() + ": input feature dimension " + ( s.empty() ? std::string( "<none>" ) : std::to_string( s.back() ) ) +
                                              " does not match in_features " + std::to_string( config_.getInputFeatures() ) );
-            if ( output_ && shapeSize( s ) / s.back() > shapeSize( leading_shape_ ) / leading_shape_.back() )
+            if ( !leading_shape_.empty() && shapeSize( s ) / s.back() > shapeSize( leading_shape_ ) / leading_shape_.back() )
                 throw std::invalid_argument( this->getName() + ": input " + shapeToString( s ) + " exceeds the built shape " + shapeToString( leading_shape_ ) );
         }
 
