@@ -92,17 +92,29 @@ def test_full_size_gemm_schedules_give_the_same_bits(policy, bf16_run):
     lib = capi.load()
     outs = []
     try:
-        for sched in ((0, 3, 6) if policy == "bf16" else (1, 3, 6)):
+        # (the split-K forms -- here the column split of the global qkv_proj, csrc/gemm256.hip: gemm_colsplit_main -- exist under the default schedule only and sum K in
+        # another order: the schedules are compared on ONE decomposition, with the column split off; the default decomposition is compared across its own two forms below)
+        capi.tune("gemm.colsplit", 0)
+        for sched in ((0, 3, 6, 5) if policy == "bf16" else (1, 3, 6, 5)):
             capi.check(lib.mila_cdna4_tune_gemm_schedule(sched))       # an inert hook (MILA_CDNA4_TUNING unset) must fail the test, not compare the default with itself
             g = host.Gemma(policy, max_seq=T + 16, max_prefill=T, seed=1234)
             outs.append(g.prefill(TOKS))
             g.close()
+        capi.tune("gemm.colsplit", 1)
+        capi.check(lib.mila_cdna4_tune_gemm_schedule(6))               # the default decomposition with one workgroup per tile instead of the persistent walk
+        g = host.Gemma(policy, max_seq=T + 16, max_prefill=T, seed=1234)
+        one_per_tile = g.prefill(TOKS)
+        capi.check(lib.mila_cdna4_tune_gemm_schedule(5))
+        default = g.prefill(TOKS)
+        g.close()
     finally:
         capi.check(lib.mila_cdna4_tune_gemm_schedule(5))      # the default
-    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
-    assert np.array_equal(outs[2].view(np.uint32), outs[1].view(np.uint32))
+        capi.tune_reset()
+    for o in outs[1:]:
+        assert np.array_equal(outs[0].view(np.uint32), o.view(np.uint32))
+    assert np.array_equal(one_per_tile.view(np.uint32), default.view(np.uint32))
     if policy == "bf16":
-        assert np.array_equal(outs[1].view(np.uint32), bf16_run["prefill"].view(np.uint32))
+        assert np.array_equal(default.view(np.uint32), bf16_run["prefill"].view(np.uint32))
 
 
 @pytest.mark.parametrize("policy", ["fp8", "fp4"])
