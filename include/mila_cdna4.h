@@ -348,6 +348,26 @@ MILA_API int mila_cdna4_convert_f32_to_bf16(uint16_t* Y, const float* X, int64_t
 MILA_API int mila_cdna4_convert_bf16_to_f32(float* Y, const uint16_t* X, int64_t n, mila_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * FP32 rows (ABI 4).  The reference keeps FP32 paths of these ops "for validation and reference" (OperationTraits.Cuda.ixx:50-54, :108-126, :274-282): with them -- and
+ * layernorm_fp32 / softmax_fp32 / gelu_fp32 / residual_fp32 / rmsnorm_fp32 above -- BASELINE config 1's model (GPT-2 124M, FP32) runs on the device and is compared with
+ * the reference's CPU backend at FP32 tolerance.  fp32 in, fp32 accumulate (ascending K), fp32 out; validation kernels, not performance kernels.
+ *   matvec_fp32 / gemm_fp32: y = x W^T (+ bias) [act 1: + tanh-GELU of the result], W [N, K] row-major -- replaces Linear/Kernels/MatVec/CudaMatVecBias.Fp32.cu:40,
+ *     Linear/Kernels/MatMul/CudaMatMulFp32.cu:31-183;
+ *   mha_fp32 / mha_kv_write_fp32 / mha_decode_fp32: the FP32 twins of mha_bf16 / mha_kv_write_bf16 / mha_decode_bf16 (Attention/MHA/CudaMhaOp.ixx:145-380: FP32 is the
+ *     reference's only CUDA MHA row); caches [B, NH, capacity, HS] fp32; any head size <= 512;
+ *   lpe_fp32: Encodings/Lpe/Kernels/Lpe.Fp32.cu:33-124;  rope_forward_fp32: Encodings/Rope/Kernels/Rope.Fp32.cu:288-321 (tables from rope_build_cache).
+ * ------------------------------------------------------------------------------------------- */
+MILA_API int mila_cdna4_matvec_fp32(float* y, const float* x, const float* W, const float* bias, int K, int N, mila_stream_t stream);
+MILA_API int mila_cdna4_gemm_fp32(float* Y, const float* X, const float* W, const float* bias, int M, int K, int N, int act, mila_stream_t stream);
+MILA_API int mila_cdna4_mha_fp32(float* Y, const float* QKV, int B, int T, int C, int NH, mila_stream_t stream);
+MILA_API int mila_cdna4_mha_kv_write_fp32(float* Kc, float* Vc, const float* QKV, int B, int T, int C, int NH, int start_pos, int capacity, mila_stream_t stream);
+MILA_API int mila_cdna4_mha_decode_fp32(float* Y, const float* QKV, float* Kc, float* Vc, int B, int C, int NH, int capacity, int position, mila_stream_t stream);
+MILA_API int mila_cdna4_lpe_fp32(float* Y, const int32_t* tokens, const float* wte, const float* wpe, int B, int T, int C, int out_stride_T, int vocab,
+                                 int32_t* error_flag, mila_stream_t stream);
+MILA_API int mila_cdna4_rope_forward_fp32(float* Qout, float* Kout, const float* Qin, const float* Kin, const float* cos_cache, const float* sin_cache, int B, int T,
+                                          int NH, int NKV, int HS, int pos_offset, int max_seq, mila_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Greedy device sampler: token_out[0] = argmax(logits), ties to the lowest index.
  * replaces Sampling/Kernels/Sampling.cuh: cuda_sample_argmax_fp32 / _bf16 (Sampling.cu:23-75).  The token stays on
  * the device and feeds the next step's embedding gather (the reference's "decode-ahead", Models/GemmaModel.ixx:497-537).

@@ -184,6 +184,7 @@ EXPORTED = [
     "attn_decode_bf16_devpos", "fused_qkv_post_devpos", "advance_position", "advance_position_snapshot", "snapshot_token", "sample_argmax_advance_fp32", "sample_argmax_final_advance", "fused_attn_decode_batch_bf16", "fused_attn_decode_bf16",
     "dequantize_to_bf16", "gemm_geglu_fp8_scaled",
     "gemm_fp8_w8a8_ws", "gemm_geglu_fp8_w8a8", "gemm_w8a8_scratch_bytes", "gemm_bf16_w8a8", "gemm_geglu_bf16_w8a8",
+    "matvec_fp32", "gemm_fp32", "mha_fp32", "mha_kv_write_fp32", "mha_decode_fp32", "lpe_fp32", "rope_forward_fp32",
 ]
 
 # csrc/internal.h: test / tuning hooks and the measured-slower experiments -- exported, but not part of the drop-in ABI

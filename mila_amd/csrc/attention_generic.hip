@@ -16,7 +16,13 @@ namespace mila {
 constexpr int kGenKeys = 256;      // keys per block
 constexpr int kGenMaxD = 8;        // output dimensions per lane: HS <= 512
 
-__global__ __launch_bounds__(256) void attn_generic_kernel(const GenericAttnParams p)
+__device__ __forceinline__ float elem_f32(uint16_t v) { return bf16_bits_to_f32(v); }
+__device__ __forceinline__ float elem_f32(float v) { return v; }
+__device__ __forceinline__ void elem_store(uint16_t* p, float v) { *p = f32_to_bf16_bits(v); }
+__device__ __forceinline__ void elem_store(float* p, float v) { *p = v; }
+
+template <typename E>
+__global__ __launch_bounds__(256) void attn_generic_kernel(const GenericAttnParamsT<E> p)
 {
     __shared__ float sc[4][kGenKeys];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -29,9 +35,9 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const GenericAttnPara
     const int HS = p.HS, kvh = h / (p.NH / p.NKV);
     const int pos = p.pos_offset + t;
     const int first = (p.window > 0) ? max(0, pos - p.window + 1) : 0;
-    const uint16_t* q = p.Q + (int64_t)b * p.q_b_stride + (int64_t)t * p.q_row_stride + (int64_t)h * HS;
-    const uint16_t* Kb = p.K + (int64_t)b * p.kv_b_stride + (int64_t)kvh * p.kv_h_stride;
-    const uint16_t* Vb = p.V + (int64_t)b * p.kv_b_stride + (int64_t)kvh * p.kv_h_stride;
+    const E* q = p.Q + (int64_t)b * p.q_b_stride + (int64_t)t * p.q_row_stride + (int64_t)h * HS;
+    const E* Kb = p.K + (int64_t)b * p.kv_b_stride + (int64_t)kvh * p.kv_h_stride;
+    const E* Vb = p.V + (int64_t)b * p.kv_b_stride + (int64_t)kvh * p.kv_h_stride;
     float m = -INFINITY, l = 0.0f, acc[kGenMaxD];
 #pragma unroll
     for (int i = 0; i < kGenMaxD; ++i) acc[i] = 0.0f;
@@ -41,9 +47,9 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const GenericAttnPara
         float bm = -INFINITY;
         for (int j = lane; j < nkeys; j += 64)
         {
-            const uint16_t* kr = Kb + (int64_t)((k0 + j) % p.capacity) * p.kv_r_stride;
+            const E* kr = Kb + (int64_t)((k0 + j) % p.capacity) * p.kv_r_stride;
             float s = 0.0f;
-            for (int d = 0; d < HS; ++d) s = fmaf(bf16_bits_to_f32(q[d]), bf16_bits_to_f32(kr[d]), s);
+            for (int d = 0; d < HS; ++d) s = fmaf(elem_f32(q[d]), elem_f32(kr[d]), s);
             s *= p.scale;
             sc[w][j] = s;
             bm = fmaxf(bm, s);
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const GenericAttnPara
             {
                 float a = acc[i] * alpha;
                 for (int j = 0; j < nkeys; ++j)
-                    a = fmaf(sc[w][j], bf16_bits_to_f32(Vb[(int64_t)((k0 + j) % p.capacity) * p.kv_r_stride + d]), a);
+                    a = fmaf(sc[w][j], elem_f32(Vb[(int64_t)((k0 + j) % p.capacity) * p.kv_r_stride + d]), a);
                 acc[i] = a;
             }
         }
@@ -80,12 +86,12 @@ __global__ __launch_bounds__(256) void attn_generic_kernel(const GenericAttnPara
         __builtin_amdgcn_wave_barrier();
     }
     const float inv = l > 0.0f ? 1.0f / l : 0.0f;
-    uint16_t* y = p.Y + ((int64_t)b * p.Tq + t) * ((int64_t)p.NH * HS) + (int64_t)h * HS;
+    E* y = p.Y + ((int64_t)b * p.Tq + t) * ((int64_t)p.NH * HS) + (int64_t)h * HS;
 #pragma unroll
     for (int i = 0; i < kGenMaxD; ++i)
     {
         const int d = lane + 64 * i;
-        if (d < HS) y[d] = f32_to_bf16_bits(acc[i] * inv);
+        if (d < HS) elem_store(y + d, acc[i] * inv);
     }
 }
 
@@ -93,8 +99,15 @@ int launch_attn_generic(const GenericAttnParams& p, hipStream_t s)
 {
     if (p.HS > 64 * kGenMaxD) return set_error(MILA_E_UNSUPPORTED, "attention: head size %d exceeds %d", p.HS, 64 * kGenMaxD);
     const int64_t rows = (int64_t)p.B * p.NH * p.Tq;
-    hipLaunchKernelGGL(attn_generic_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(attn_generic_kernel<uint16_t>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
     MILA_LAUNCH_CHECK("attn_generic");
+}
+int launch_attn_generic_f32(const GenericAttnParamsT<float>& p, hipStream_t s)
+{
+    if (p.HS > 64 * kGenMaxD) return set_error(MILA_E_UNSUPPORTED, "attention (fp32): head size %d exceeds %d", p.HS, 64 * kGenMaxD);
+    const int64_t rows = (int64_t)p.B * p.NH * p.Tq;
+    hipLaunchKernelGGL(attn_generic_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
+    MILA_LAUNCH_CHECK("attn_generic_f32");
 }
 
 }  // namespace mila
