@@ -340,12 +340,18 @@ class GemmaModel:
 
 
 class Gpt:
-    """GptTransformer (GPT-2) on cuda:0, BF16; parameters in the order of oracle orc_cpu_gpt2_forward."""
+    """GptTransformer (GPT-2) on cuda:0; parameters in the order of oracle orc_cpu_gpt2_forward.
+    precision "bf16" (BASELINE config 2): parameters and logits are bf16 bit patterns (uint16); "fp32" (BASELINE config 1's model on the device, through the FP32 rows
+    of Linear / LayerNorm / MHA / GELU / Residual / LPE): float32 parameters and logits."""
 
-    def __init__(self, vocab, max_seq, C_, L, NH, B, T):
+    def __init__(self, vocab, max_seq, C_, L, NH, B, T, precision="bf16"):
         lib = load()
+        lib.mila_gpt_create_p.restype = C.c_void_p
+        lib.mila_gpt_create_p.argtypes = [C.c_int] + [C.c_int64] * 7
         self.shape = (B, T, vocab)
-        self.h = lib.mila_gpt_create(vocab, max_seq, C_, L, NH, B, T)
+        self.precision = precision
+        self.dtype = {"bf16": np.uint16, "fp32": np.float32}[precision]
+        self.h = lib.mila_gpt_create_p({"bf16": 0, "fp32": 1}[precision], vocab, max_seq, C_, L, NH, B, T)
         if not self.h:
             raise (ValueError if b"invalid_argument" in lib.mila_gpt_last_error() else RuntimeError)(lib.mila_gpt_last_error().decode())
 
@@ -374,14 +380,14 @@ class Gpt:
         lib = load()
         assert len(params_bf16_bits) == lib.mila_gpt_parameter_count(self.h)
         for i, p in enumerate(params_bf16_bits):
-            p = np.ascontiguousarray(p, dtype=np.uint16)
+            p = np.ascontiguousarray(p, dtype=self.dtype)
             rc = lib.mila_gpt_load_parameter(self.h, i, p.ctypes.data, p.nbytes)
             if rc:
                 raise ValueError(lib.mila_gpt_last_error().decode())
 
     def forward(self, tokens):
         t = np.ascontiguousarray(tokens, dtype=np.int32)
-        out = np.empty(self.shape, dtype=np.uint16)
+        out = np.empty(self.shape, dtype=self.dtype)
         ms = C.c_double()
         rc = load().mila_gpt_forward(self.h, t.ctypes.data, out.ctypes.data, C.byref(ms))
         if rc < 0:
@@ -407,7 +413,7 @@ class Gpt:
         lib.mila_gpt_prefill.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         t = np.ascontiguousarray(tokens, dtype=np.int32)
         assert t.ndim == 2 and t.shape[0] == self.shape[0]
-        out = np.empty((self.shape[0], self.shape[2]), dtype=np.uint16)
+        out = np.empty((self.shape[0], self.shape[2]), dtype=self.dtype)
         rc = lib.mila_gpt_prefill(self.h, t.ctypes.data, t.shape[1], out.ctypes.data)
         if rc:
             text = lib.mila_gpt_last_error().decode()
@@ -420,7 +426,7 @@ class Gpt:
         lib.mila_gpt_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         t = np.ascontiguousarray(tokens, dtype=np.int32).reshape(-1)
         assert t.size == self.shape[0]
-        out = np.empty((self.shape[0], self.shape[2]), dtype=np.uint16)
+        out = np.empty((self.shape[0], self.shape[2]), dtype=self.dtype)
         rc = lib.mila_gpt_decode(self.h, t.ctypes.data, int(position), out.ctypes.data)
         if rc:
             text = lib.mila_gpt_last_error().decode()

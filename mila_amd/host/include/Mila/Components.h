@@ -198,9 +198,10 @@ namespace Mila::Dnn
             if ( !this->isBuilt() ) throw std::runtime_error( "Linear: build() must precede loadParameter()" );
             auto* ctx = Compute::cast_context<TDeviceType>( this->getExecutionContext() );
             const size_t N = static_cast<size_t>( config_.getOutputFeatures() ), K = static_cast<size_t>( config_.getInputFeatures() );
+            constexpr size_t EB = TensorType::kElemBytes;      // bytes per element of an unquantized blob: 2 (bf16), or 4 on the FP32 row
             if ( param_name == "weight" )
             {
-                if ( bytes == N * K * 2 )
+                if ( bytes == N * K * EB )
                 {
                     if constexpr ( kIsQuantized )
                     {
@@ -216,7 +217,7 @@ namespace Mila::Dnn
                 else if ( kIsQuantized && bytes == weight_->sizeInBytes() )
                     copyToDevice( *weight_, host_blob, bytes, ctx );
                 else
-                    throw std::invalid_argument( this->getName() + ": weight blob has " + std::to_string( bytes ) + " bytes, expected " + std::to_string( N * K * 2 ) );
+                    throw std::invalid_argument( this->getName() + ": weight blob has " + std::to_string( bytes ) + " bytes, expected " + std::to_string( N * K * EB ) );
             }
             else if ( param_name == "weight_scale" )
             {
@@ -231,7 +232,7 @@ namespace Mila::Dnn
             else if ( param_name == "bias" )
             {
                 if ( !bias_ ) throw std::invalid_argument( this->getName() + ": configured without bias" );
-                if ( bytes != N * 2 ) throw std::invalid_argument( this->getName() + ": bias blob size mismatch" );
+                if ( bytes != N * EB ) throw std::invalid_argument( this->getName() + ": bias blob size mismatch" );
                 copyToDevice( *bias_, host_blob, bytes, ctx );
             }
             else

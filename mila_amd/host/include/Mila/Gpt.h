@@ -31,11 +31,13 @@ namespace Mila::Dnn
         }
     };
 
-    class GptTransformer
+    /// TPrecision: BF16 (BASELINE config 2) or FP32 (BASELINE config 1's model on the device: the reference's FP32 rows, OperationTraits.Cuda.ixx:50-54, :274-282)
+    template<TensorDataType TPrecision>
+    class GptTransformerT
     {
     public:
         static constexpr DeviceType kDevice = DeviceType::Rocm;
-        static constexpr TensorDataType kPrecision = TensorDataType::BF16;
+        static constexpr TensorDataType kPrecision = TPrecision;
         using TensorType = Tensor<kPrecision, Compute::RocmDeviceMemoryResource>;
         using TokenTensor = Tensor<TensorDataType::INT32, Compute::RocmDeviceMemoryResource>;
         using LinearType = Linear<kDevice, kPrecision>;
@@ -44,7 +46,7 @@ namespace Mila::Dnn
         using TransformerBlockType = GptBlock<kDevice, kPrecision>;
 
         /// the reference's graph (GptTransformer.ixx:828-858): lenc, tf_layer_<i>, ln_final, lm_head (no bias)
-        GptTransformer( const GptConfig& cfg, dim_t batch, dim_t seq, DeviceId device = Compute::Device::Rocm( 0 ) )
+        GptTransformerT( const GptConfig& cfg, dim_t batch, dim_t seq, DeviceId device = Compute::Device::Rocm( 0 ) )
             : cfg_( cfg ), B_( batch ), T_( seq )
         {
             cfg_.validate();
@@ -148,7 +150,7 @@ namespace Mila::Dnn
             if ( !last_rows_ ) last_rows_ = std::make_unique<TensorType>( ctx_->getDeviceId(), shape_t{ B_, 1, C } );
             for ( dim_t b = 0; b < B_; ++b )      // row (b, T' - 1) of every sequence (the reference's single view is this for B = 1)
                 Compute::rocmCheck( mila_cdna4_memcpy_d2d( last_rows_->data() + static_cast<size_t>( b * C ), x->data() + static_cast<size_t>( ( b * Tp + Tp - 1 ) * C ),
-                                                           static_cast<size_t>( C ) * 2, ctx_->getStream() ) );
+                                                           static_cast<size_t>( C ) * TensorType::kElemBytes, ctx_->getStream() ) );
             return lm_head_->forward( ln_final_->forward( *last_rows_ ) );
         }
         /// inference-only single-token step (GptTransformer.ixx:387-441): tokens [B, 1] at absolute `position`; every block runs decode() (attention over its KV
@@ -189,4 +191,6 @@ namespace Mila::Dnn
         std::shared_ptr<LinearType> lm_head_;
         std::unique_ptr<TensorType> last_rows_;
     };
+    using GptTransformer = GptTransformerT<TensorDataType::BF16>;
+    using GptTransformerFp32 = GptTransformerT<TensorDataType::FP32>;
 }

@@ -252,8 +252,12 @@ namespace Mila::Dnn
             if ( s.size() != 2 || s[ 0 ] > max_batch_ || s[ 1 ] > max_seq_ ) throw std::invalid_argument( this->getName() + ": input " + shapeToString( s ) + " exceeds the built shape" );
             auto* ctx = Compute::cast_context<TDeviceType>( this->getExecutionContext() );
             view_ = std::make_unique<EmbeddingsTensorType>( output_->view( shape_t{ s[ 0 ], s[ 1 ], config_.getEmbeddingDim() } ) );
-            Compute::rocmCheck( mila_cdna4_lpe_bf16( view_->data(), input.data(), wte_->data(), wpe_->data(), (int)s[ 0 ], (int)s[ 1 ], (int)config_.getEmbeddingDim(), (int)s[ 1 ],
-                                                     (int)config_.getVocabularyLength(), error_flag_->data(), ctx->getStream() ) );
+            if constexpr ( TPrecision == TensorDataType::FP32 )
+                Compute::rocmCheck( mila_cdna4_lpe_fp32( view_->data(), input.data(), wte_->data(), wpe_->data(), (int)s[ 0 ], (int)s[ 1 ], (int)config_.getEmbeddingDim(), (int)s[ 1 ],
+                                                         (int)config_.getVocabularyLength(), error_flag_->data(), ctx->getStream() ) );
+            else
+                Compute::rocmCheck( mila_cdna4_lpe_bf16( view_->data(), input.data(), wte_->data(), wpe_->data(), (int)s[ 0 ], (int)s[ 1 ], (int)config_.getEmbeddingDim(), (int)s[ 1 ],
+                                                         (int)config_.getVocabularyLength(), error_flag_->data(), ctx->getStream() ) );
             return *view_;
         }
         /// single-token step: output[b, 0, :] = wte[X[b, 0], :] + wpe[position, :] (Lpe.ixx:240-257; B rows here, the reference's view is [1, 1, C])
@@ -266,8 +270,12 @@ namespace Mila::Dnn
             auto* ctx = Compute::cast_context<TDeviceType>( this->getExecutionContext() );
             const dim_t C = config_.getEmbeddingDim();
             view_ = std::make_unique<EmbeddingsTensorType>( output_->view( shape_t{ s[ 0 ], 1, C } ) );
-            Compute::rocmCheck( mila_cdna4_lpe_bf16( view_->data(), input.data(), wte_->data(), wpe_->data() + static_cast<size_t>( position * C ), (int)s[ 0 ], 1, (int)C, 1,
-                                                     (int)config_.getVocabularyLength(), error_flag_->data(), ctx->getStream() ) );
+            if constexpr ( TPrecision == TensorDataType::FP32 )
+                Compute::rocmCheck( mila_cdna4_lpe_fp32( view_->data(), input.data(), wte_->data(), wpe_->data() + static_cast<size_t>( position * C ), (int)s[ 0 ], 1, (int)C, 1,
+                                                         (int)config_.getVocabularyLength(), error_flag_->data(), ctx->getStream() ) );
+            else
+                Compute::rocmCheck( mila_cdna4_lpe_bf16( view_->data(), input.data(), wte_->data(), wpe_->data() + static_cast<size_t>( position * C ), (int)s[ 0 ], 1, (int)C, 1,
+                                                         (int)config_.getVocabularyLength(), error_flag_->data(), ctx->getStream() ) );
             return *view_;
         }
         void loadParameter( const std::string& n, const void* blob, size_t bytes ) override

@@ -53,6 +53,10 @@ namespace Mila::Dnn::Compute
     };
 
     using RocmBf16Tensor = Tensor<TensorDataType::BF16, RocmDeviceMemoryResource>;
+    template<TensorDataType TPrecision> using RocmTensor = Tensor<TPrecision, RocmDeviceMemoryResource>;
+    /// the precisions the CDNA4 op rows exist for: BF16 (the product path) and FP32 (the reference's "validation and reference" rows, OperationTraits.Cuda.ixx:50-54,
+    /// :108-126, :274-282 -- Linear, LayerNorm, Softmax, GELU, Residual, MHA, LPE, RoPE, RMSNorm; csrc/fp32_rows.hip)
+    template<TensorDataType TPrecision> concept RocmPrecision = TPrecision == TensorDataType::BF16 || TPrecision == TensorDataType::FP32;
 
     // ---------------------------------------------------------------------------------------
     // Linear
@@ -67,9 +71,11 @@ namespace Mila::Dnn::Compute
     template<TensorDataType TPrecision, Quant::Weight::WeightQuantPolicy TWeightQuant>
     class RocmLinearOp : public Operation<DeviceType::Rocm, TPrecision>
     {
-        static_assert( TPrecision == TensorDataType::BF16, "the CDNA4 Linear rows are BF16 activations" );
+        static_assert( TPrecision == TensorDataType::BF16 || ( TPrecision == TensorDataType::FP32 && !TWeightQuant::kIsQuantized ),
+                       "the CDNA4 Linear rows: BF16 activations under every weight policy, FP32 with unquantized weights (the validation row)" );
     public:
-        using TensorType = RocmBf16Tensor;
+        using TensorType = RocmTensor<TPrecision>;
+        static constexpr bool kFp32 = TPrecision == TensorDataType::FP32;
         static constexpr int kFmt = Quant::Weight::abiWeightFormat<TWeightQuant>();
         static constexpr int kGroup = Quant::Weight::groupSizeOf<TWeightQuant>();
 
@@ -86,7 +92,7 @@ namespace Mila::Dnn::Compute
             if ( !weight ) throw std::invalid_argument( "RocmLinearOp::setParameters: weight is required" );
             if ( cfg_.has_bias && !bias ) throw std::invalid_argument( "RocmLinearOp::setParameters: bias is required by the config" );
             weight_ = weight->rawData();
-            bias_ = bias ? static_cast<const uint16_t*>( bias->rawData() ) : nullptr;
+            bias_ = bias ? static_cast<const uint16_t*>( bias->rawData() ) : nullptr;      // (FP32 row: float elements behind the same pointer)
         }
 
         void setWeightScales( ITensor* scales )
@@ -114,9 +120,20 @@ namespace Mila::Dnn::Compute
             const int K = narrowToKernelIndex( cfg_.in_features, "in_features" );
             const int N = narrowToKernelIndex( cfg_.out_features, "out_features" );
             const int M = narrowToKernelIndex( static_cast<dim_t>( in.size() ) / cfg_.in_features, "outer size" );
+            mila_stream_t st = this->context_->getStream();
+            if constexpr ( kFp32 )
+            {
+                // the FP32 row (CudaMatVecBias.Fp32.cu:40, CudaMatMulFp32.cu:31-183): fp32 in / accumulate / out
+                auto* yf = static_cast<float*>( out.rawData() );
+                auto* xf = static_cast<const float*>( in.rawData() );
+                const auto* wf = static_cast<const float*>( weight_ );
+                const auto* bf = reinterpret_cast<const float*>( bias_ );
+                if ( M == 1 ) rocmCheck( mila_cdna4_matvec_fp32( yf, xf, wf, bf, K, N, st ) );
+                else rocmCheck( mila_cdna4_gemm_fp32( yf, xf, wf, bf, M, K, N, 0, st ) );
+                return;
+            }
             auto* y = static_cast<uint16_t*>( out.rawData() );
             auto* x = static_cast<const uint16_t*>( in.rawData() );
-            mila_stream_t st = this->context_->getStream();
             if ( M == 1 )
             {
                 if constexpr ( kFmt == 0 ) rocmCheck( mila_cdna4_matvec_bf16( y, x, static_cast<const uint16_t*>( weight_ ), bias_, K, N, st ) );
@@ -190,7 +207,10 @@ namespace Mila::Dnn::Compute
             const int N = narrowToKernelIndex( cfg_.out_features, "out_features" );
             const int M = narrowToKernelIndex( static_cast<dim_t>( in.size() ) / cfg_.in_features, "outer size" );
             if ( !fusesGelu( M ) ) throw std::logic_error( "RocmLinearOp::forwardGelu: only unquantized weights at more than one row" );
-            if constexpr ( kFmt == 0 )
+            if constexpr ( kFp32 )
+                rocmCheck( mila_cdna4_gemm_fp32( static_cast<float*>( out.rawData() ), static_cast<const float*>( in.rawData() ), static_cast<const float*>( weight_ ),
+                                                 reinterpret_cast<const float*>( bias_ ), M, K, N, 1, this->context_->getStream() ) );
+            else if constexpr ( kFmt == 0 )
                 gemmWithWorkspace( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( in.rawData() ), static_cast<const uint16_t*>( weight_ ), M, K, N, 1,
                                    this->context_->getStream() );
         }
@@ -318,7 +338,7 @@ namespace Mila::Dnn::Compute
         bool use_fp8_activation_prefill_{ kFmt == 2 };
         bool resident_{ true };
         std::unique_ptr<Tensor<TensorDataType::FP32, RocmDeviceMemoryResource>> weight_fp8_scale_;
-        std::unique_ptr<RocmBf16Tensor> resident_bf16_;
+        std::unique_ptr<RocmBf16Tensor> resident_bf16_;      // (quantized policies exist for BF16 activations only)
         std::unique_ptr<Tensor<TensorDataType::FP8_E4M3, RocmDeviceMemoryResource>> resident_e4m3_;
 
         void refreshResident()
@@ -356,6 +376,12 @@ namespace Mila::Dnn::Compute
     struct OperationTraits<OperationType::LinearOp, DeviceType::Rocm, TensorDataType::BF16, TPolicy>
     {
         using type = RocmLinearOp<TensorDataType::BF16, TPolicy>;
+    };
+    /// the FP32 validation row: unquantized weights only (OperationTraits.Cuda.ixx:50-54)
+    template<>
+    struct OperationTraits<OperationType::LinearOp, DeviceType::Rocm, TensorDataType::FP32, Quant::Weight::NoWeightQuant>
+    {
+        using type = RocmLinearOp<TensorDataType::FP32, Quant::Weight::NoWeightQuant>;
     };
     // PerGroupInt4 has no row, like the quantize path of the reference (CudaLinearOp.ixx:385-391)
     template<int G>
@@ -418,15 +444,16 @@ namespace Mila::Dnn::Compute
     };
     template<> struct OperationTraits<OperationType::RmsNormOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmRmsNormOp; };
 
-    class RocmLayerNormOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    template<TensorDataType TPrecision> requires RocmPrecision<TPrecision>
+    class RocmLayerNormOp : public Operation<DeviceType::Rocm, TPrecision>
     {
     public:
-        using TensorType = RocmBf16Tensor;
-        RocmLayerNormOp( IExecutionContext* ctx, const NormOpConfig& cfg ) : Operation( ctx ), cfg_( cfg ) {}
+        using TensorType = RocmTensor<TPrecision>;
+        RocmLayerNormOp( IExecutionContext* ctx, const NormOpConfig& cfg ) : Operation<DeviceType::Rocm, TPrecision>( ctx ), cfg_( cfg ) {}
         void setParameters( ITensor* weight, ITensor* bias )
         {
-            w_ = weight ? static_cast<const uint16_t*>( weight->rawData() ) : nullptr;
-            b_ = bias ? static_cast<const uint16_t*>( bias->rawData() ) : nullptr;
+            w_ = weight ? weight->rawData() : nullptr;
+            b_ = bias ? bias->rawData() : nullptr;
         }
         void build( const BuildContext& ) { built_ = true; }
         void forward( const TensorType& in, TensorType& out ) const
@@ -434,29 +461,39 @@ namespace Mila::Dnn::Compute
             if ( !built_ ) throw std::runtime_error( "RocmLayerNormOp::forward: operation must be built before forward()" );
             const int dim = narrowToKernelIndex( cfg_.dim, "dim" );
             const int outer = narrowToKernelIndex( static_cast<dim_t>( in.size() ) / cfg_.dim, "outer" );
-            rocmCheck( mila_cdna4_layernorm_bf16( static_cast<uint16_t*>( out.rawData() ), nullptr, nullptr, static_cast<const uint16_t*>( in.rawData() ),
-                                                  w_, b_, outer, dim, cfg_.epsilon, context_->getStream() ) );
+            if constexpr ( TPrecision == TensorDataType::FP32 )
+                rocmCheck( mila_cdna4_layernorm_fp32( static_cast<float*>( out.rawData() ), nullptr, nullptr, static_cast<const float*>( in.rawData() ), static_cast<const float*>( w_ ),
+                                                      static_cast<const float*>( b_ ), outer, dim, cfg_.epsilon, this->context_->getStream() ) );
+            else
+                rocmCheck( mila_cdna4_layernorm_bf16( static_cast<uint16_t*>( out.rawData() ), nullptr, nullptr, static_cast<const uint16_t*>( in.rawData() ),
+                                                      static_cast<const uint16_t*>( w_ ), static_cast<const uint16_t*>( b_ ), outer, dim, cfg_.epsilon, this->context_->getStream() ) );
         }
     private:
         NormOpConfig cfg_;
-        const uint16_t* w_{ nullptr };
-        const uint16_t* b_{ nullptr };
+        const void* w_{ nullptr };
+        const void* b_{ nullptr };
         bool built_{ false };
     };
-    template<> struct OperationTraits<OperationType::LayerNormOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmLayerNormOp; };
+    template<TensorDataType TPrecision> requires RocmPrecision<TPrecision>
+    struct OperationTraits<OperationType::LayerNormOp, DeviceType::Rocm, TPrecision> { using type = RocmLayerNormOp<TPrecision>; };
 
-    class RocmGeluOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    template<TensorDataType TPrecision> requires RocmPrecision<TPrecision>
+    class RocmGeluOp : public Operation<DeviceType::Rocm, TPrecision>
     {
     public:
-        using TensorType = RocmBf16Tensor;
-        explicit RocmGeluOp( IExecutionContext* ctx ) : Operation( ctx ) {}
+        using TensorType = RocmTensor<TPrecision>;
+        explicit RocmGeluOp( IExecutionContext* ctx ) : Operation<DeviceType::Rocm, TPrecision>( ctx ) {}
         void forward( const TensorType& in, TensorType& out ) const
         {
-            rocmCheck( mila_cdna4_gelu_bf16( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( in.rawData() ),
-                                             static_cast<int64_t>( in.size() ), context_->getStream() ) );
+            if constexpr ( TPrecision == TensorDataType::FP32 )
+                rocmCheck( mila_cdna4_gelu_fp32( static_cast<float*>( out.rawData() ), static_cast<const float*>( in.rawData() ), static_cast<int64_t>( in.size() ), this->context_->getStream() ) );
+            else
+                rocmCheck( mila_cdna4_gelu_bf16( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( in.rawData() ),
+                                                 static_cast<int64_t>( in.size() ), this->context_->getStream() ) );
         }
     };
-    template<> struct OperationTraits<OperationType::GeluOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmGeluOp; };
+    template<TensorDataType TPrecision> requires RocmPrecision<TPrecision>
+    struct OperationTraits<OperationType::GeluOp, DeviceType::Rocm, TPrecision> { using type = RocmGeluOp<TPrecision>; };
 
     /// Swiglu<..., Gelu> resolves to the GeGLU op (Gemma.Block.ixx:150)
     class RocmGegluOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
@@ -475,25 +512,32 @@ namespace Mila::Dnn::Compute
     };
     template<> struct OperationTraits<OperationType::GegluOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmGegluOp; };
 
-    class RocmResidualOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    template<TensorDataType TPrecision> requires RocmPrecision<TPrecision>
+    class RocmResidualOp : public Operation<DeviceType::Rocm, TPrecision>
     {
     public:
-        using TensorType = RocmBf16Tensor;
-        explicit RocmResidualOp( IExecutionContext* ctx ) : Operation( ctx ) {}
+        using TensorType = RocmTensor<TPrecision>;
+        explicit RocmResidualOp( IExecutionContext* ctx ) : Operation<DeviceType::Rocm, TPrecision>( ctx ) {}
         void forward( const TensorType& a, const TensorType& b, TensorType& out ) const
         {
             if ( a.size() != b.size() ) throw std::invalid_argument( "RocmResidualOp::forward: operand sizes differ" );
-            rocmCheck( mila_cdna4_residual_bf16( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( a.rawData() ),
-                                                 static_cast<const uint16_t*>( b.rawData() ), static_cast<int64_t>( a.size() ), context_->getStream() ) );
+            if constexpr ( TPrecision == TensorDataType::FP32 )
+                rocmCheck( mila_cdna4_residual_fp32( static_cast<float*>( out.rawData() ), static_cast<const float*>( a.rawData() ), static_cast<const float*>( b.rawData() ),
+                                                     static_cast<int64_t>( a.size() ), this->context_->getStream() ) );
+            else
+                rocmCheck( mila_cdna4_residual_bf16( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( a.rawData() ),
+                                                     static_cast<const uint16_t*>( b.rawData() ), static_cast<int64_t>( a.size() ), this->context_->getStream() ) );
         }
     };
-    template<> struct OperationTraits<OperationType::ResidualOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmResidualOp; };
+    template<TensorDataType TPrecision> requires RocmPrecision<TPrecision>
+    struct OperationTraits<OperationType::ResidualOp, DeviceType::Rocm, TPrecision> { using type = RocmResidualOp<TPrecision>; };
 
-    class RocmSoftmaxOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    template<TensorDataType TPrecision> requires RocmPrecision<TPrecision>
+    class RocmSoftmaxOp : public Operation<DeviceType::Rocm, TPrecision>
     {
     public:
-        using TensorType = RocmBf16Tensor;
-        RocmSoftmaxOp( IExecutionContext* ctx, int axis ) : Operation( ctx ), axis_( axis ) {}
+        using TensorType = RocmTensor<TPrecision>;
+        RocmSoftmaxOp( IExecutionContext* ctx, int axis ) : Operation<DeviceType::Rocm, TPrecision>( ctx ), axis_( axis ) {}
         void forward( const TensorType& in, TensorType& out ) const
         {
             const auto& s = in.shape();
@@ -503,14 +547,19 @@ namespace Mila::Dnn::Compute
             dim_t outer = 1, inner = 1;
             for ( int i = 0; i < ax; ++i ) outer *= s[ i ];
             for ( int i = ax + 1; i < rank; ++i ) inner *= s[ i ];
-            rocmCheck( mila_cdna4_softmax_bf16( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( in.rawData() ),
-                                                narrowToKernelIndex( outer, "outer" ), narrowToKernelIndex( s[ ax ], "dim" ),
-                                                narrowToKernelIndex( inner, "inner" ), context_->getStream() ) );
+            if constexpr ( TPrecision == TensorDataType::FP32 )
+                rocmCheck( mila_cdna4_softmax_fp32( static_cast<float*>( out.rawData() ), static_cast<const float*>( in.rawData() ), narrowToKernelIndex( outer, "outer" ),
+                                                    narrowToKernelIndex( s[ ax ], "dim" ), narrowToKernelIndex( inner, "inner" ), this->context_->getStream() ) );
+            else
+                rocmCheck( mila_cdna4_softmax_bf16( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( in.rawData() ),
+                                                    narrowToKernelIndex( outer, "outer" ), narrowToKernelIndex( s[ ax ], "dim" ),
+                                                    narrowToKernelIndex( inner, "inner" ), this->context_->getStream() ) );
         }
     private:
         int axis_;
     };
-    template<> struct OperationTraits<OperationType::SoftmaxOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmSoftmaxOp; };
+    template<TensorDataType TPrecision> requires RocmPrecision<TPrecision>
+    struct OperationTraits<OperationType::SoftmaxOp, DeviceType::Rocm, TPrecision> { using type = RocmSoftmaxOp<TPrecision>; };
 
     // ---------------------------------------------------------------------------------------
     // RoPE (IPositionalPairedOp) -- cache built once per (max_seq, head_dim, base, rotary_dim)
@@ -549,12 +598,14 @@ namespace Mila::Dnn::Compute
         }
     };
 
-    class RocmRopeOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    template<TensorDataType TPrecision> requires RocmPrecision<TPrecision>
+    class RocmRopeOp : public Operation<DeviceType::Rocm, TPrecision>
     {
+        using Operation<DeviceType::Rocm, TPrecision>::context_;
     public:
-        using TensorType = RocmBf16Tensor;
+        using TensorType = RocmTensor<TPrecision>;
         using CacheTensor = Tensor<TensorDataType::FP32, RocmDeviceMemoryResource>;
-        RocmRopeOp( IExecutionContext* ctx, const RopeOpConfig& cfg ) : Operation( ctx ), cfg_( cfg )
+        RocmRopeOp( IExecutionContext* ctx, const RopeOpConfig& cfg ) : Operation<DeviceType::Rocm, TPrecision>( ctx ), cfg_( cfg )
         {
             if ( cfg.head_dim <= 0 || cfg.head_dim % 2 != 0 ) throw std::invalid_argument( "RocmRopeOp: head_dim must be positive and even" );
             if ( cfg.max_seq <= 0 ) throw std::invalid_argument( "RocmRopeOp: max_seq must be positive" );
@@ -583,11 +634,22 @@ namespace Mila::Dnn::Compute
         void prefill( TensorType& q, TensorType& k, int B, int T, int position_offset ) const
         {
             if ( !built_ ) throw std::runtime_error( "RocmRopeOp: not built" );
-            auto* qp = static_cast<uint16_t*>( q.rawData() );
-            auto* kp = static_cast<uint16_t*>( k.rawData() );
-            rocmCheck( mila_cdna4_rope_forward_bf16( qp, kp, qp, kp, cos_->data(), sin_->data(), B, T, narrowToKernelIndex( cfg_.num_heads, "NH" ),
-                                                     narrowToKernelIndex( cfg_.num_kv_heads, "NKV" ), narrowToKernelIndex( cfg_.head_dim, "HS" ),
-                                                     position_offset, narrowToKernelIndex( cfg_.max_seq, "max_seq" ), context_->getStream() ) );
+            if constexpr ( TPrecision == TensorDataType::FP32 )
+            {
+                auto* qp = static_cast<float*>( q.rawData() );
+                auto* kp = static_cast<float*>( k.rawData() );
+                rocmCheck( mila_cdna4_rope_forward_fp32( qp, kp, qp, kp, cos_->data(), sin_->data(), B, T, narrowToKernelIndex( cfg_.num_heads, "NH" ),
+                                                         narrowToKernelIndex( cfg_.num_kv_heads, "NKV" ), narrowToKernelIndex( cfg_.head_dim, "HS" ),
+                                                         position_offset, narrowToKernelIndex( cfg_.max_seq, "max_seq" ), context_->getStream() ) );
+            }
+            else
+            {
+                auto* qp = static_cast<uint16_t*>( q.rawData() );
+                auto* kp = static_cast<uint16_t*>( k.rawData() );
+                rocmCheck( mila_cdna4_rope_forward_bf16( qp, kp, qp, kp, cos_->data(), sin_->data(), B, T, narrowToKernelIndex( cfg_.num_heads, "NH" ),
+                                                         narrowToKernelIndex( cfg_.num_kv_heads, "NKV" ), narrowToKernelIndex( cfg_.head_dim, "HS" ),
+                                                         position_offset, narrowToKernelIndex( cfg_.max_seq, "max_seq" ), context_->getStream() ) );
+            }
         }
         void decode( TensorType& q, TensorType& k, int B, int position ) const { prefill( q, k, B, 1, position ); }
         const float* cosCache() const noexcept { return cos_ ? cos_->data() : nullptr; }
@@ -597,7 +659,8 @@ namespace Mila::Dnn::Compute
         std::shared_ptr<CacheTensor> cos_, sin_;
         bool built_{ false };
     };
-    template<> struct OperationTraits<OperationType::RopeOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmRopeOp; };
+    template<TensorDataType TPrecision> requires RocmPrecision<TPrecision>
+    struct OperationTraits<OperationType::RopeOp, DeviceType::Rocm, TPrecision> { using type = RocmRopeOp<TPrecision>; };
 
     // ---------------------------------------------------------------------------------------
     // Grouped-query attention over an op-owned KV cache (IKvInference)
@@ -737,11 +800,14 @@ namespace Mila::Dnn::Compute
 
     /// GPT-2 attention on packed QKV (new BF16 row; the reference's CUDA MHA is FP32-only, OPS/OperationTraits.Cuda.ixx:274-282) with the KV-cache
     /// interface of CudaMultiHeadAttentionOp (OPS/Attention/MHA/CudaMhaOp.ixx:107-380: IPositionalUnaryOp::prefill / decode + IKvCacheLifecycle)
-    class RocmMultiHeadAttentionOp : public Operation<DeviceType::Rocm, TensorDataType::BF16>
+    template<TensorDataType TPrecision> requires RocmPrecision<TPrecision>
+    class RocmMultiHeadAttentionOp : public Operation<DeviceType::Rocm, TPrecision>
     {
+        using Operation<DeviceType::Rocm, TPrecision>::context_;
+        static constexpr bool kFp32 = TPrecision == TensorDataType::FP32;      // the reference's own (and only) CUDA MHA row is FP32 (OperationTraits.Cuda.ixx:274-282)
     public:
-        using TensorType = RocmBf16Tensor;
-        RocmMultiHeadAttentionOp( IExecutionContext* ctx, dim_t model_dim, dim_t num_heads ) : Operation( ctx ), C_( model_dim ), NH_( num_heads )
+        using TensorType = RocmTensor<TPrecision>;
+        RocmMultiHeadAttentionOp( IExecutionContext* ctx, dim_t model_dim, dim_t num_heads ) : Operation<DeviceType::Rocm, TPrecision>( ctx ), C_( model_dim ), NH_( num_heads )
         {
             if ( model_dim <= 0 || num_heads <= 0 || model_dim % num_heads != 0 ) throw std::invalid_argument( "RocmMultiHeadAttentionOp: model_dim must be a positive multiple of num_heads" );
         }
@@ -757,7 +823,8 @@ namespace Mila::Dnn::Compute
         {
             const auto& s = qkv.shape();
             if ( s.size() != 3 || s[ 2 ] != 3 * C_ ) throw std::invalid_argument( "RocmMultiHeadAttentionOp::forward: expected [B, T, 3C]" );
-            rocmCheck( mila_cdna4_mha_bf16( out.data(), static_cast<const uint16_t*>( qkv.rawData() ), (int)s[ 0 ], (int)s[ 1 ], (int)C_, (int)NH_, context_->getStream() ) );
+            if constexpr ( kFp32 ) rocmCheck( mila_cdna4_mha_fp32( static_cast<float*>( out.rawData() ), static_cast<const float*>( qkv.rawData() ), (int)s[ 0 ], (int)s[ 1 ], (int)C_, (int)NH_, context_->getStream() ) );
+            else rocmCheck( mila_cdna4_mha_bf16( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( qkv.rawData() ), (int)s[ 0 ], (int)s[ 1 ], (int)C_, (int)NH_, context_->getStream() ) );
         }
 
         // ---- IKvCacheLifecycle (CudaMhaOp.ixx:112-143) ----
@@ -793,10 +860,21 @@ namespace Mila::Dnn::Compute
             const auto& s = qkv.shape();
             if ( s.size() != 3 || s[ 0 ] != B_ || s[ 2 ] != 3 * C_ || s[ 1 ] <= 0 || s[ 1 ] > active_max_seq_len_ )
                 throw std::invalid_argument( "RocmMultiHeadAttentionOp::prefill: input must be [B, T <= max_sequence_length, 3C]" );
-            const auto* x = static_cast<const uint16_t*>( qkv.rawData() );
             mila_stream_t st = context_->getStream();
-            rocmCheck( mila_cdna4_mha_bf16( out.data(), x, (int)B_, (int)s[ 1 ], (int)C_, (int)NH_, st ) );
-            rocmCheck( mila_cdna4_mha_kv_write_bf16( k_cache_->data(), v_cache_->data(), x, (int)B_, (int)s[ 1 ], (int)C_, (int)NH_, 0, (int)active_max_seq_len_, st ) );
+            if constexpr ( kFp32 )
+            {
+                const auto* x = static_cast<const float*>( qkv.rawData() );
+                rocmCheck( mila_cdna4_mha_fp32( static_cast<float*>( out.rawData() ), x, (int)B_, (int)s[ 1 ], (int)C_, (int)NH_, st ) );
+                rocmCheck( mila_cdna4_mha_kv_write_fp32( static_cast<float*>( k_cache_->rawData() ), static_cast<float*>( v_cache_->rawData() ), x, (int)B_, (int)s[ 1 ], (int)C_, (int)NH_, 0,
+                                                         (int)active_max_seq_len_, st ) );
+            }
+            else
+            {
+                const auto* x = static_cast<const uint16_t*>( qkv.rawData() );
+                rocmCheck( mila_cdna4_mha_bf16( static_cast<uint16_t*>( out.rawData() ), x, (int)B_, (int)s[ 1 ], (int)C_, (int)NH_, st ) );
+                rocmCheck( mila_cdna4_mha_kv_write_bf16( static_cast<uint16_t*>( k_cache_->rawData() ), static_cast<uint16_t*>( v_cache_->rawData() ), x, (int)B_, (int)s[ 1 ], (int)C_, (int)NH_, 0,
+                                                         (int)active_max_seq_len_, st ) );
+            }
             cached_seq_len_ = s[ 1 ];
         }
         /// one token per sequence [B, 1, 3C] at absolute `position`: appends its K / V, attends to keys 0 .. position (CudaMhaOp.ixx:252-380)
@@ -806,10 +884,17 @@ namespace Mila::Dnn::Compute
             const auto& s = qkv.shape();
             if ( s.size() != 3 || s[ 0 ] != B_ || s[ 1 ] != 1 || s[ 2 ] != 3 * C_ ) throw std::invalid_argument( "RocmMultiHeadAttentionOp::decode: input must be [B, 1, 3C]" );
             if ( position < 0 || position >= active_max_seq_len_ ) throw std::invalid_argument( "RocmMultiHeadAttentionOp::decode position out of range" );
-            const size_t need = mila_cdna4_mha_decode_scratch_bytes( (int)B_, (int)C_, (int)NH_ );
-            void* scratch = context_->getScratch( need );      // fetched per call, never cached
-            rocmCheck( mila_cdna4_mha_decode_bf16( out.data(), static_cast<const uint16_t*>( qkv.rawData() ), k_cache_->data(), v_cache_->data(), scratch, need, (int)B_, (int)C_,
-                                                   (int)NH_, (int)active_max_seq_len_, (int)position, context_->getStream() ) );
+            if constexpr ( kFp32 )
+                rocmCheck( mila_cdna4_mha_decode_fp32( static_cast<float*>( out.rawData() ), static_cast<const float*>( qkv.rawData() ), static_cast<float*>( k_cache_->rawData() ),
+                                                       static_cast<float*>( v_cache_->rawData() ), (int)B_, (int)C_, (int)NH_, (int)active_max_seq_len_, (int)position, context_->getStream() ) );
+            else
+            {
+                const size_t need = mila_cdna4_mha_decode_scratch_bytes( (int)B_, (int)C_, (int)NH_ );
+                void* scratch = context_->getScratch( need );      // fetched per call, never cached
+                rocmCheck( mila_cdna4_mha_decode_bf16( static_cast<uint16_t*>( out.rawData() ), static_cast<const uint16_t*>( qkv.rawData() ), static_cast<uint16_t*>( k_cache_->rawData() ),
+                                                       static_cast<uint16_t*>( v_cache_->rawData() ), scratch, need, (int)B_, (int)C_, (int)NH_, (int)active_max_seq_len_, (int)position,
+                                                       context_->getStream() ) );
+            }
             if ( position + 1 > cached_seq_len_ ) cached_seq_len_ = position + 1;
         }
     private:
@@ -819,5 +904,6 @@ namespace Mila::Dnn::Compute
         bool kv_cache_enabled_{ false };
         std::unique_ptr<TensorType> k_cache_, v_cache_;
     };
-    template<> struct OperationTraits<OperationType::MultiHeadAttentionOp, DeviceType::Rocm, TensorDataType::BF16> { using type = RocmMultiHeadAttentionOp; };
+    template<TensorDataType TPrecision> requires RocmPrecision<TPrecision>
+    struct OperationTraits<OperationType::MultiHeadAttentionOp, DeviceType::Rocm, TPrecision> { using type = RocmMultiHeadAttentionOp<TPrecision>; };
 }

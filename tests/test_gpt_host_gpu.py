@@ -47,6 +47,42 @@ def test_gpt2_forward_matches_the_restated_cpu_backend(V, maxT, C_, L, NH, B, T)
     g.close()
 
 
+@pytest.mark.parametrize("V,maxT,C_,L,NH,B,T,Tp", [(512, 64, 128, 2, 2, 2, 24, 9), (50257, 1024, 768, 12, 12, 1, 64, 40)], ids=["small", "config1_gpt2_124M_B1_T64"])
+def test_gpt2_fp32_on_the_device_matches_the_reference_cpu_backend__config_1(V, maxT, C_, L, NH, B, T, Tp):
+    """BASELINE config 1's model -- GPT-2 124M, FP32, B = 1, T = 64 -- ON THE DEVICE, through the FP32 rows the reference keeps "for validation and reference"
+    (OperationTraits.Cuda.ixx:50-54, :108-126, :274-282; csrc/fp32_rows.hip), against the reference's CPU backend restated (orc_cpu_gpt2_forward) on the SAME float
+    parameters: FP32 against FP32, so the bar is the reference's FP32 one -- 1e-3 + 1e-4 |y| per logit (Linear.Cpu.cpp:278 holds one Linear to
+    1e-4 absolute on unit-scale data) -- instead of bf16's 5e-2.  Forward, then the prefill / decode session over the FP32 KV caches."""
+    rng = np.random.default_rng(C_ + T)
+    params = [orc.from_bf16_bits(p) for p in make_params(rng, V, maxT, C_, L)]      # float32 values (bf16-representable: the bf16 model below sees the same numbers)
+    tokens = rng.integers(0, V, (B, T)).astype(np.int32)
+    exp = orc.cpu_gpt2_forward(tokens, params, C_, L, NH, V, maxT)
+    g = host.Gpt(V, maxT, C_, L, NH, B, T, precision="fp32")
+    g.load_parameters(params)
+    got = g.forward(tokens)
+    assert got.dtype == np.float32 and np.all(np.isfinite(got))
+    err = np.abs(got - exp)
+    assert np.all(err <= 1e-3 + 1e-4 * np.abs(exp)), float(err.max())
+    print("fp32 GPT-2 (C=%d, L=%d) on the device vs the CPU backend: max |err| %.2e, max |logit| %.2f, forward %.2f ms" % (C_, L, float(err.max()), float(np.abs(exp).max()), g.last_ms))
+    assert np.array_equal(got.argmax(-1), exp.argmax(-1)) or float(err.max()) < 1e-4
+    # the KV-cache session: prefill, then decode to the end
+    lp = g.prefill(tokens[:, :Tp])
+    assert np.all(np.abs(lp - exp[:, Tp - 1]) <= 1e-3 + 1e-4 * np.abs(exp[:, Tp - 1]))
+    for pos in range(Tp, min(T, Tp + 6)):
+        ld = g.decode(tokens[:, pos], pos)
+        assert np.all(np.abs(ld - exp[:, pos]) <= 1e-3 + 1e-4 * np.abs(exp[:, pos])), pos
+    st = g.memory_stats()
+    assert st["actual"]["device_parameter_bytes"] == sum(p.size for p in params) * 4
+    g.close()
+    # the bf16 row of the same model on the same values sits two orders of magnitude further from the CPU backend: what the FP32 rows buy as a validation path
+    if C_ <= 128:
+        b = host.Gpt(V, maxT, C_, L, NH, B, T)
+        b.load_parameters([orc.to_bf16_bits(p) for p in params])
+        eb = float(np.abs(orc.from_bf16_bits(b.forward(tokens)) - exp).max())
+        b.close()
+        assert eb > 20 * float(err.max())
+
+
 def test_gpt2_124m_full_width_single_block_row():
     """config-2 widths (C=768, NH=12, V=50257) on a short sequence: every Linear/LayerNorm/MHA/LPE row at
     its real size against the CPU reference (the full B=8, T=1024 forward is 2 TFLOP on the FP32 CPU path)."""
