@@ -266,6 +266,7 @@ static int launch_gemm(GemmParams p, hipStream_t s)
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     const int nwg = p.tiles_m * p.tiles_n;
+    note_form(FMT == G_BF16 ? "gemm128" : (FMT == G_FP8 ? "gemm128_w8a16" : "gemm128_w4a16"));
     hipLaunchKernelGGL(gemm_kernel<FMT>, dim3(nwg), dim3(256), 4 * kTileBytes, s, p);
     MILA_LAUNCH_CHECK("gemm");
 }
@@ -513,6 +514,7 @@ static int launch_bf16_rows_ws(uint16_t* Y, const uint16_t* X, const uint16_t* W
     const int rows = M - pl.main_rows;
     if (pl.fewrow)
     {
+        note_form("fewrow_bf16");
         int rc = launch_gemm_bf16_fewrow(static_cast<float*>(ws), Xt, W, rows, K, N, pl.S, s);
         if (rc) return rc;
         return launch_splitk_reduce(Yt, static_cast<const float*>(ws), bias, rows, N, pl.S, act, s);

@@ -1204,6 +1204,7 @@ static int launch_gemm256x128_t(const Gemm256Params& p, hipStream_t s)
 }
 int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act)
 {
+    note_form("gemm256x128");
     Gemm256Params p{Y, X, W, bias, M, K, N, (M + 255) / 256, (N + 127) / 128, nullptr, nullptr, 0, act};
     return launch_gemm256x128_t<false>(p, s);
 }
@@ -1308,6 +1309,7 @@ static int launch_gemm256x128_fp8_splitk(uint16_t* Y, const uint8_t* X8, const u
         if (rc) return rc;
         attr_set = true;
     }
+    note_form("fp8_gemm256x128_splitk");
     Gemm256Params p{nullptr, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, M, K, N, (M + 255) / 256, N / 128, nullptr, nullptr, 0, 0, partials, S};
     hipLaunchKernelGGL((gemm256x128_kernel<true, false, 2, false, true>), dim3(p.tiles_m * p.tiles_n * S), dim3(512), 3 * kStage3Bytes, s, p);
     int rc = check_hip(hipGetLastError(), "gemm256x128 (fp8 split-K)");
@@ -1335,6 +1337,7 @@ int launch_gemm256x128_splitk(uint16_t* Y, const uint16_t* X, const uint16_t* W,
         if (rc) return rc;
         attr_set = true;
     }
+    note_form("gemm256x128_splitk");
     Gemm256Params p{Y, X, W, nullptr, M, K, N, (M + 255) / 256, N / 128, nullptr, nullptr, 0, 0, partials, S};
     hipLaunchKernelGGL((gemm256x128_kernel<false, false, 2, false, true>), dim3(p.tiles_m * p.tiles_n * S), dim3(512), 3 * kStage3Bytes, s, p);
     int rc = check_hip(hipGetLastError(), "gemm256x128 (split-K)");
@@ -1406,6 +1409,7 @@ int launch_gemm256(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint
 {
     // a row pitch that is no multiple of 128 bytes: one workgroup per tile and the row-wise epilogue through LDS (two-phase schedules only)
     const int rowwise = ((N & 63) != 0 && g_gemm_pingpong >= 3 && g_gemm_rowwise) ? 1 : 0;
+    note_form("gemm256");
     Gemm256Params p{Y, X, W, bias, M, K, N, (M + 255) / 256, (N + 255) / 256, nullptr, nullptr, rowwise, act};
     p.ldy = ldy;
     return launch_gemm256_t<G_PLAIN>(p, s);
@@ -1445,6 +1449,7 @@ bool gemm256_geglu_applicable(int M, int K, int F)
 }
 int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s)
 {
+    note_form("gemm256_geglu");
     Gemm256Params p{Y, X, W, nullptr, M, K, F, (M + 255) / 256, F / 128, nullptr, nullptr};
     return launch_gemm256_t<G_GEGLU>(p, s);
 }
@@ -1507,12 +1512,14 @@ int launch_gemm_fp8_geglu(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, con
         {
             Gemm256Params q{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, rows, K, F, tm, F / 64, x_scales, w_scale.p};
             q.w_pc = w_scale.per_channel;
+            note_form("fp8_gemm256x128_geglu");
             rc = launch_gemm256x128_t<true, true>(q, s);
         }
         else
         {
             Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), nullptr, rows, K, F, tm, F / 128, x_scales, w_scale.p};
             p.w_pc = w_scale.per_channel;
+            note_form("fp8_gemm256_geglu");
             rc = launch_gemm256_t<G_FP8_GEGLU>(p, s);
         }
         if (rc || rows == M) return rc;
@@ -1528,6 +1535,7 @@ int launch_gemm_fp8(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const flo
         const int which = fp8_pick(rows, N), tm = (rows + 255) / 256;
         Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), bias, rows, K, N, tm, which == 2 ? N / 256 : N / 128, x_scales, w_scale.p};
         p.w_pc = w_scale.per_channel;
+        note_form(which == 2 ? "fp8_gemm256" : "fp8_gemm256x128");
         const int rc = which == 2 ? launch_gemm256_t<G_FP8>(p, s) : launch_gemm256x128_t<true>(p, s);
         if (rc || rows == M) return rc;
     }
@@ -1582,6 +1590,7 @@ int launch_gemm_fp8_ws(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const 
     if (pl.n_main)
     {
         note_form("fp8_gemm256_colsplit");
+        note_form("fp8_gemm256");
         Gemm256Params p{Y, reinterpret_cast<const uint16_t*>(X8), reinterpret_cast<const uint16_t*>(W8), bias, M, K, pl.n_main, (M + 255) / 256, pl.n_main / 256, x_scales, w_scale.p};
         p.w_pc = w_scale.per_channel;
         p.ldy = N;

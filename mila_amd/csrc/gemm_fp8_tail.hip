@@ -462,6 +462,7 @@ template <bool GEGLU>
 static int launch_skinny(const Fp8SkinnyParams& p, hipStream_t s)
 {
     const int groups = (p.M + 15) / 16;
+    note_form(GEGLU ? "fp8_skinny_geglu" : "fp8_skinny");
     if (groups <= 1) launch_skinny_mg<1, GEGLU>(p, s);
     else if (groups == 2) launch_skinny_mg<2, GEGLU>(p, s);
     else launch_skinny_mg<4, GEGLU>(p, s);
@@ -474,6 +475,7 @@ static int launch_tail_t(Fp8TailParams p, hipStream_t s)
     constexpr int BO = (GEGLU ? WN * PT * 8 : WN * PT * 16);
     p.tiles_m = (p.M + 127) / 128;
     p.tiles_n = (p.N + BO - 1) / BO;
+    note_form(GEGLU ? "fp8_tail_geglu" : "fp8_tail");
     hipLaunchKernelGGL((gemm_fp8_tail_kernel<WN, PT, QT, GEGLU>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
     MILA_LAUNCH_CHECK("gemm_fp8_tail");
 }

@@ -254,11 +254,13 @@ static int launch_bf16_skinny_rows(Bf16SkinnyParams p, int M, hipStream_t s)
 // Y[M, N] = (act ? gelu : id)(X W^T + bias), any M (64 rows per launch), K % 8 == 0
 int launch_gemm_bf16_skinny(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, int act, hipStream_t s)
 {
+    note_form("skinny_bf16");
     return launch_bf16_skinny_rows<false>(Bf16SkinnyParams{Y, X, W, bias, 0, K, N, act}, M, s);
 }
 // Y[M, F] = GeGLU(X W^T), W = [gate rows | up rows]
 int launch_gemm_bf16_skinny_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s)
 {
+    note_form("skinny_bf16_geglu");
     return launch_bf16_skinny_rows<true>(Bf16SkinnyParams{Y, X, W, nullptr, 0, K, F, 0}, M, s);
 }
 

@@ -64,6 +64,7 @@ static int launch_xc(const MatvecParams& p, int max_blocks, hipStream_t s)
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     t_last_matvec_blocks = blocks;
+    note_form("matvec");
     hipLaunchKernelGGL((matvec_kernel<FMT, R, U, PRO, GEGLU, F32OUT, XC>), dim3(blocks), dim3(64 * kMatvecWaves), lds, s, p);
     MILA_LAUNCH_CHECK("matvec");
 }

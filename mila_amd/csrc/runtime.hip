@@ -48,6 +48,7 @@ static thread_local char g_last_form[256] = "";
 static thread_local size_t g_last_form_len = 0;
 void note_form(const char* form)
 {
+    if (!tuning_hooks_enabled()) return;      // a record for tests and tools only: a product process keeps none
     // forms of one entry point accumulate, '+'-separated (a call may run a tile kernel on the leading rows and another form on the rest); cleared by last_form()
     const size_t n = std::strlen(form);
     if (g_last_form_len + n + 2 >= sizeof(g_last_form)) return;

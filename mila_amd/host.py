@@ -502,3 +502,118 @@ def pretrained_to_milabin(src, dst, metadata_json=None):
 def pretrained_metadata_roundtrip(json_text):
     """host-only: toMetadataJSON(parseMetadataJSON(text))"""
     return _text_call(load().mila_pretrained_metadata_roundtrip, json_text.encode())
+
+
+class LinearComponent:
+    """ONE Linear<Rocm, BF16, policy> of the host mirror (libmila_host: host/src/linear_runner.cpp): load a weight as the reference's loadParameter does (bf16 blob ->
+    quantize-on-load under a quantized policy, or the policy's storage form + weight_scale), then forward() at any row count through RocmLinearOp::forward."""
+
+    def __init__(self, policy, K, N, max_rows, bias=False, device=0):
+        lib = load()
+        lib.mila_linear_create.restype = C.c_void_p
+        lib.mila_linear_create.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int]
+        lib.mila_linear_destroy.argtypes = [C.c_void_p]
+        lib.mila_linear_load.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+        lib.mila_linear_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.mila_linear_set.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.mila_linear_forward.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        lib.mila_linear_last_error.restype = C.c_char_p
+        self.K, self.N, self.policy = K, N, policy
+        self.h = lib.mila_linear_create(POLICIES[policy], K, N, max_rows, int(bool(bias)), device)
+        if not self.h:
+            raise RuntimeError(lib.mila_linear_last_error().decode())
+
+    def _check(self, rc):
+        if rc:
+            text = load().mila_linear_last_error().decode()
+            raise (ValueError if rc == capi.MILA_E_INVALID_ARGUMENT else (TypeError if rc == capi.MILA_E_UNSUPPORTED else RuntimeError))(text)
+
+    def load(self, name, blob):
+        b = np.ascontiguousarray(blob)
+        self._check(load().mila_linear_load(self.h, name.encode(), b.ctypes.data, b.nbytes))
+
+    def read(self):
+        """(stored weight bytes as uint8, scales as float32 or None)"""
+        lib = load()
+        wb, sb = C.c_int64(), C.c_int64()
+        self._check(lib.mila_linear_read(self.h, None, C.byref(wb), None, C.byref(sb)))
+        w = np.empty(wb.value, dtype=np.uint8)
+        s = np.empty(sb.value // 4, dtype=np.float32)
+        self._check(lib.mila_linear_read(self.h, w.ctypes.data, None, s.ctypes.data if sb.value else None, None))
+        return w, (s if sb.value else None)
+
+    def set(self, fp8_activation_prefill=None, resident=None):
+        self._check(load().mila_linear_set(self.h, -1 if fp8_activation_prefill is None else int(bool(fp8_activation_prefill)), -1 if resident is None else int(bool(resident))))
+
+    def forward(self, x_bf16_bits):
+        x = np.ascontiguousarray(x_bf16_bits, dtype=np.uint16)
+        M = x.size // self.K
+        y = np.empty((M, self.N), dtype=np.uint16)
+        self._check(load().mila_linear_forward(self.h, M, x.ctypes.data, y.ctypes.data))
+        return y
+
+    def close(self):
+        if self.h:
+            load().mila_linear_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def linear_install_shared_probe(policy, which):
+    """Linear<policy>::installSharedWeight( nullptr ) (which 0) / ( nullptr, nullptr ) (which 1) on an unbuilt component: returns "logic_error", "invalid_argument" or "ok" """
+    lib = load()
+    lib.mila_linear_install_shared_probe.argtypes = [C.c_int, C.c_int]
+    rc = lib.mila_linear_install_shared_probe(POLICIES[policy], which)
+    return {0: "ok", capi.MILA_E_UNSUPPORTED: "logic_error", capi.MILA_E_INVALID_ARGUMENT: "invalid_argument"}.get(rc, "error %d" % rc)
+
+
+class Sampler:
+    """RocmSamplingOp (counterpart of CudaSamplingOp<FP32>): sample() = forward + readback; sample_enqueued() = enqueueForward + awaitToken; await_token() alone raises TypeError
+    (std::logic_error) when nothing is outstanding"""
+
+    def __init__(self, vocab, softcap=0.0, device=0):
+        lib = load()
+        lib.mila_sampler_create.restype = C.c_void_p
+        lib.mila_sampler_create.argtypes = [C.c_int64, C.c_float, C.c_int]
+        lib.mila_sampler_destroy.argtypes = [C.c_void_p]
+        lib.mila_sampler_set_logits.argtypes = [C.c_void_p, C.c_void_p]
+        lib.mila_sampler_sample.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        lib.mila_linear_last_error.restype = C.c_char_p
+        self.vocab = vocab
+        self.h = lib.mila_sampler_create(vocab, softcap, device)
+        if not self.h:
+            raise RuntimeError(lib.mila_linear_last_error().decode())
+
+    def set_logits(self, logits):
+        lg = np.ascontiguousarray(logits, dtype=np.float32)
+        assert lg.size == self.vocab
+        self._keep = lg          # the copy is asynchronous on the context stream
+        if load().mila_sampler_set_logits(self.h, lg.ctypes.data):
+            raise RuntimeError(load().mila_linear_last_error().decode())
+
+    def _run(self, mode, temperature, top_k, top_p, r):
+        tok = C.c_int32()
+        rc = load().mila_sampler_sample(self.h, mode, temperature, top_k, top_p, r, C.byref(tok))
+        if rc:
+            text = load().mila_linear_last_error().decode()
+            raise (TypeError if rc == capi.MILA_E_UNSUPPORTED else (ValueError if rc == capi.MILA_E_INVALID_ARGUMENT else RuntimeError))(text)
+        return tok.value
+
+    def sample(self, temperature=1.0, top_k=0, top_p=1.0, r=0.5):
+        return self._run(0, temperature, top_k, top_p, r)
+
+    def sample_enqueued(self, temperature=1.0, top_k=0, top_p=1.0, r=0.5):
+        return self._run(1, temperature, top_k, top_p, r)
+
+    def await_token(self):
+        return self._run(2, 0.0, 0, 1.0, 0.0)
+
+    def close(self):
+        if self.h:
+            load().mila_sampler_destroy(self.h)
+            self.h = None

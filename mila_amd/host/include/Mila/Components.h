@@ -249,19 +249,30 @@ namespace Mila::Dnn
         }
 
         /// adopt another component's table instead of allocating (the tied lm_head: Linear.ixx:614-680, Gemma.ixx:659-684); precedes build()
-        void installSharedWeight( std::shared_ptr<WeightTensorType> shared_weight ) requires ( !kIsQuantized )
+        /// Tying contract (Linear.ixx:614-680; Tests/.../Linear.Cuda.cpp:618-641): an unquantized Linear adopts a weight; a per-channel FP8 one adopts (weight, scales) --
+        /// the per-output-channel scale axis IS the vocab row a tied embedding gathers; a quantized weight WITHOUT scales, and every per-group policy (input-axis scales
+        /// do not transfer to a row gather), are rejected with std::logic_error before anything is dereferenced
+        void installSharedWeight( std::shared_ptr<WeightTensorType> shared_weight )
         {
-            checkShared( shared_weight.get() );
-            weight_ = std::move( shared_weight );
+            if constexpr ( kIsQuantized ) throw std::logic_error( this->getName() + ": a quantized Linear cannot adopt a weight without its scales" );
+            else
+            {
+                checkShared( shared_weight.get() );
+                weight_ = std::move( shared_weight );
+            }
         }
-        void installSharedWeight( std::shared_ptr<WeightTensorType> shared_weight, std::shared_ptr<WeightScaleTensorType> shared_scales ) requires kIsQuantized
+        void installSharedWeight( std::shared_ptr<WeightTensorType> shared_weight, std::shared_ptr<WeightScaleTensorType> shared_scales )
         {
-            static_assert( !kIsQuantized || TWeightQuant::kPerChannel, "a shared quantized weight carries one scale per output row" );
+            if constexpr ( !kIsQuantized ) throw std::logic_error( this->getName() + ": an unquantized Linear has no weight scales to adopt" );
+            else if constexpr ( !TWeightQuant::kPerChannel ) throw std::logic_error( this->getName() + ": per-group scales run along the input axis and cannot be tied to a row gather" );
+            else
+            {
             checkShared( shared_weight.get() );
             if ( !shared_scales || shared_scales->size() != static_cast<size_t>( config_.getOutputFeatures() ) )
                 throw std::invalid_argument( this->getName() + ": installSharedWeight needs one scale per output feature" );
             weight_ = std::move( shared_weight );
             weight_scale_ = std::move( shared_scales );
+            }
         }
         bool hasSharedWeight() const noexcept { return shared_weight_; }
         /// a model whose layers run one after the other hands every layer's Linear of one role the same output buffer (the reference's pooled block workspace,

@@ -10,6 +10,7 @@
 // forward.  Every forward() ends in exactly one C-ABI call (include/mila_cdna4.h).
 #pragma once
 
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -797,6 +798,77 @@ namespace Mila::Dnn::Compute
     {
         using type = RocmGqaOp<TKvPolicy::kBoundedRing>;
     };
+
+    // ---------------------------------------------------------------------------------------
+    // Sampling (row f3): counterpart of CudaSamplingOp<FP32> (OPS/Sampling/CudaSamplingOp.ixx; Tests/Dnn/Samplers/Sampling.Cuda.cpp:40-150).
+    // forward(): sample on the context's stream into a device token.  enqueueForward() / awaitToken(): the decode-ahead half of the pipelined generation loop --
+    // the token is ALSO published to a host-visible slot by the sampler's stream (no host synchronize between forward and sample), awaitToken() blocks until it is
+    // there; awaitToken() without an outstanding enqueueForward() is a caller bug: std::logic_error, not UB (Sampling.Cuda.cpp:503-509).
+    // ---------------------------------------------------------------------------------------
+    struct SamplingOpConfig { dim_t vocab_size{ 0 }; float final_logit_softcap{ 0.0f }; };
+    struct SamplingParams { float temperature{ 1.0f }; int top_k{ 0 }; float top_p{ 1.0f }; };      ///< Components/Transformers/SamplingParams.ixx: temperature <= 0 = greedy
+
+    class RocmSamplingOp : public Operation<DeviceType::Rocm, TensorDataType::FP32>
+    {
+    public:
+        using LogitsTensor = Tensor<TensorDataType::FP32, RocmDeviceMemoryResource>;
+        using TokenTensor = Tensor<TensorDataType::INT32, RocmDeviceMemoryResource>;
+        RocmSamplingOp( IExecutionContext* ctx, const SamplingOpConfig& cfg ) : Operation( ctx ), cfg_( cfg )
+        {
+            if ( cfg.vocab_size <= 0 ) throw std::invalid_argument( "RocmSamplingOp: vocabulary size must be positive" );
+            scratch_bytes_ = std::max( mila_cdna4_sample_scratch_bytes(), mila_cdna4_sample_stochastic_scratch_bytes( narrowToKernelIndex( cfg.vocab_size, "vocab" ) ) );
+            scratch_ = std::make_unique<Tensor<TensorDataType::UINT8, RocmDeviceMemoryResource>>( context_->getDeviceId(), shape_t{ static_cast<dim_t>( scratch_bytes_ ) } );
+            seq_dev_ = std::make_unique<Tensor<TensorDataType::FP32, RocmDeviceMemoryResource>>( context_->getDeviceId(), shape_t{ 2 } );      // one 64-bit counter
+            rocmCheck( mila_cdna4_memset_zero( seq_dev_->rawData(), 8, context_->getStream() ) );
+            void* host = nullptr;
+            rocmCheck( mila_cdna4_host_alloc_pinned( &host, sizeof( unsigned long long ) * kSlots ) );
+            ring_ = static_cast<unsigned long long*>( host );
+            for ( int i = 0; i < kSlots; ++i ) ring_[ i ] = 0;
+            context_->synchronize();
+        }
+        ~RocmSamplingOp() override { if ( ring_ ) mila_cdna4_host_free_pinned( ring_ ); }
+
+        /// logits [.., vocab] -> token_out[0]; r in [0, 1) is drawn by the caller (the reference injects it the same way)
+        void forward( const LogitsTensor& logits, TokenTensor& token_out, const SamplingParams& sp, float r ) const
+        {
+            const int V = narrowToKernelIndex( cfg_.vocab_size, "vocab" );
+            if ( static_cast<dim_t>( logits.size() ) < cfg_.vocab_size ) throw std::invalid_argument( "RocmSamplingOp::forward: logits are shorter than the vocabulary" );
+            if ( sp.temperature <= 0.0f || sp.top_k == 1 )
+                rocmCheck( mila_cdna4_sample_argmax_fp32( logits.data(), token_out.data(), V, scratch_->rawData(), scratch_bytes_, context_->getStream() ) );
+            else
+                rocmCheck( mila_cdna4_sample_stochastic_fp32( logits.data(), token_out.data(), V, cfg_.final_logit_softcap, sp.temperature, sp.top_k, sp.top_p, r, scratch_->rawData(),
+                                                              scratch_bytes_, context_->getStream() ) );
+        }
+        void enqueueForward( const LogitsTensor& logits, TokenTensor& token_out, const SamplingParams& sp, float r )
+        {
+            forward( logits, token_out, sp, r );
+            rocmCheck( mila_cdna4_snapshot_token( token_out.data(), reinterpret_cast<unsigned long long*>( seq_dev_->rawData() ), ring_, kSlots, context_->getStream() ) );
+            ++enqueued_;
+        }
+        int32_t awaitToken()
+        {
+            if ( awaited_ >= enqueued_ ) throw std::logic_error( "RocmSamplingOp::awaitToken: no outstanding enqueueForward()" );
+            const uint64_t seq = ++awaited_;
+            volatile unsigned long long* slot = ring_ + ( seq % kSlots );
+            const auto t0 = std::chrono::steady_clock::now();
+            for ( uint64_t spins = 0;; ++spins )
+            {
+                const unsigned long long v = __atomic_load_n( slot, __ATOMIC_ACQUIRE );
+                if ( ( v >> 32 ) == ( seq & 0xffffffffull ) ) return static_cast<int32_t>( static_cast<uint32_t>( v ) );
+                if ( ( spins & 1023 ) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds( 20 ) )
+                    throw std::runtime_error( "RocmSamplingOp::awaitToken: the device did not publish a token within 20 s" );
+            }
+        }
+    private:
+        static constexpr int kSlots = 4;
+        SamplingOpConfig cfg_;
+        size_t scratch_bytes_{ 0 };
+        std::unique_ptr<Tensor<TensorDataType::UINT8, RocmDeviceMemoryResource>> scratch_;
+        std::unique_ptr<Tensor<TensorDataType::FP32, RocmDeviceMemoryResource>> seq_dev_;
+        unsigned long long* ring_{ nullptr };
+        uint64_t enqueued_{ 0 }, awaited_{ 0 };
+    };
+    template<> struct OperationTraits<OperationType::SamplingOp, DeviceType::Rocm, TensorDataType::FP32> { using type = RocmSamplingOp; };
 
     /// GPT-2 attention on packed QKV (new BF16 row; the reference's CUDA MHA is FP32-only, OPS/OperationTraits.Cuda.ixx:274-282) with the KV-cache
     /// interface of CudaMultiHeadAttentionOp (OPS/Attention/MHA/CudaMhaOp.ixx:107-380: IPositionalUnaryOp::prefill / decode + IKvCacheLifecycle)

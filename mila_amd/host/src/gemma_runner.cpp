@@ -37,6 +37,16 @@ namespace
     }
 }
 
+// Gemma.Cuda.cpp:456-480 (KvPolicy_RoutesBoundedRingToLocalLayersOnly), the compile-time half: the sliding-window KV policy reaches the LOCAL block type only; global
+// (full-attention) blocks are never bounded, whatever the policy.  (The byte footprint of the routing: tests/test_reference_scenarios_r4_gpu.py.)
+namespace
+{
+    using ProbeNet = Mila::Dnn::GemmaTransformer<Mila::Dnn::Quant::Weight::NoWeightQuant>;
+    static_assert( std::is_same_v<ProbeNet::BoundedLocalBlockType::AttentionType::OpType, Mila::Dnn::Compute::RocmGqaOp<true>>, "SlidingWindowKvCache must reach the local (sliding) layers" );
+    static_assert( std::is_same_v<ProbeNet::LocalBlockType::AttentionType::OpType, Mila::Dnn::Compute::RocmGqaOp<false>>, "the default policy keeps local layers unbounded" );
+    static_assert( std::is_same_v<ProbeNet::GlobalBlockType::AttentionType::OpType, Mila::Dnn::Compute::RocmGqaOp<false>>, "global (full-attention) layers must never be bounded" );
+}
+
 extern "C" {
 
 #define HOST_API __attribute__((visibility("default")))
