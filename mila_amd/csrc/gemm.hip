@@ -450,7 +450,8 @@ static int launch_bf16_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, c
 
 // ---- the same GEMM with a caller workspace (mila_cdna4_gemm_bf16_ws): what the split-K form changes ----
 // plan: rows [0, main) as launch_bf16_rows serves them, rows [main, M) split-K with S copies (S = 0: no split-K part, everything as launch_bf16_rows)
-struct Bf16WsPlan { int main_rows, S; bool fewrow; int n_main = 0; };      // n_main > 0: the column split (all rows): columns [0, n_main) on 256 x 256 tiles, the rest split-K with S copies
+struct Bf16WsPlan { int main_rows, S; bool fewrow; int n_main = 0, cs_rows = 0; };      // n_main > 0: the column split over rows [0, cs_rows): columns [0, n_main) on 256 x 256 tiles, the
+                                                                                        // rest split-K with S copies; rows [cs_rows, M) (a <= 64-row remainder) as launch_bf16_rows serves them
 // the split-K form for `rows` rows: up to 32 rows the few-row weight stream (gemm_fewrow_bf16.hip), else the 256 x 128 ring over S copies of the tile list
 static Bf16WsPlan splitk_form(int main_rows, int rows, int K, int N)
 {
@@ -470,10 +471,12 @@ static Bf16WsPlan bf16_ws_plan(int M, int K, int N)
     Bf16WsPlan pl = splitk_form(0, M, K, N);
     if (pl.S) return pl;
     // a tile list that ends in a nearly empty round (N = 8704 at T = 2048): whole rounds of 256 x 256 tiles + the remaining columns split-K (gemm256.hip: gemm_colsplit_main)
+    // (a long prompt's <= 64-row remainder stays with the skinny kernel -- the dispatch ladder showed T = 2049 turning its ONE extra row into a ninth tile-row of the split)
     {
+        const int tail_ = M % 256, rows = (M >= 512 && tail_ > 0 && tail_ <= kBf16SkinnyRows && g_bf16_skinny) ? M - tail_ : M;
         int S_rest = 0;
-        const int n_main = gemm_colsplit_main(M, K, N, &S_rest);
-        if (n_main > 0 && gemm256_applicable(M, K, n_main)) { Bf16WsPlan cs{0, S_rest, false}; cs.n_main = n_main; return cs; }
+        const int n_main = gemm_colsplit_main(rows, K, N, &S_rest);
+        if (n_main > 0 && gemm256_applicable(rows, K, n_main)) { Bf16WsPlan cs{0, S_rest, false}; cs.n_main = n_main; cs.cs_rows = rows; return cs; }
     }
     // a long prompt's remainder whose ragged tile-row would open another round of the grid (T = 2303 on the N = 3840 shapes: 240 tiles fill the chip, 270 run two
     // rounds of full-length tiles -- fc_down 200 -> 400 us): the whole tile-rows as before, the remainder split-K
@@ -490,7 +493,7 @@ static Bf16WsPlan bf16_ws_plan(int M, int K, int N)
 static size_t bf16_ws_bytes(int M, int K, int N)
 {
     const Bf16WsPlan pl = bf16_ws_plan(M, K, N);
-    if (pl.n_main) return (size_t)pl.S * M * (N - pl.n_main) * sizeof(float);
+    if (pl.n_main) return (size_t)pl.S * pl.cs_rows * (N - pl.n_main) * sizeof(float);
     return pl.S ? (size_t)pl.S * (M - pl.main_rows) * N * sizeof(float) : 0;
 }
 static int launch_bf16_rows_ws(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N, hipStream_t s, int act, void* ws)
@@ -500,9 +503,12 @@ static int launch_bf16_rows_ws(uint16_t* Y, const uint16_t* X, const uint16_t* W
     if (pl.n_main)
     {
         note_form("gemm256_colsplit");
-        int rc = launch_gemm256(Y, X, W, bias, M, K, pl.n_main, s, act, N);
+        const int R = pl.cs_rows;
+        int rc = launch_gemm256(Y, X, W, bias, R, K, pl.n_main, s, act, N);
         if (rc) return rc;
-        return launch_gemm256x128_splitk(Y + pl.n_main, X, W + (size_t)pl.n_main * K, bias ? bias + pl.n_main : nullptr, M, K, N - pl.n_main, s, act, static_cast<float*>(ws), pl.S, N);
+        rc = launch_gemm256x128_splitk(Y + pl.n_main, X, W + (size_t)pl.n_main * K, bias ? bias + pl.n_main : nullptr, R, K, N - pl.n_main, s, act, static_cast<float*>(ws), pl.S, N);
+        if (rc || R == M) return rc;
+        return launch_bf16_rows(Y + (size_t)R * N, X + (size_t)R * K, W, bias, M - R, K, N, s, act);
     }
     if (pl.main_rows > 0)
     {

@@ -617,3 +617,28 @@ class Sampler:
         if self.h:
             load().mila_sampler_destroy(self.h)
             self.h = None
+
+
+class activation_tap:
+    """context manager: records the per-token e4m3 activations (bytes + scales) every Linear on an fp8 x fp8 prefill path consumed while it is open
+    (Compute::ActivationTap; test instrument) -> .records = [(M, K, N, x8 [M, K] uint8, ts [M] float32)] in call order"""
+
+    def __enter__(self):
+        lib = load()
+        lib.mila_linear_tap_count.restype = C.c_int64
+        lib.mila_linear_tap_get.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.mila_linear_tap_begin()
+        self.records = []
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        lib.mila_linear_tap_end()
+        for i in range(lib.mila_linear_tap_count()):
+            dims = (C.c_int32 * 3)()
+            lib.mila_linear_tap_get(i, dims, None, None)
+            M, K, N = dims[0], dims[1], dims[2]
+            x8, ts = np.empty((M, K), dtype=np.uint8), np.empty(M, dtype=np.float32)
+            lib.mila_linear_tap_get(i, None, x8.ctypes.data, ts.ctypes.data)
+            self.records.append((M, K, N, x8, ts))
+        return False

@@ -16,6 +16,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 #include "Core.h"
 #include "Quantization.h"
@@ -67,6 +68,16 @@ namespace Mila::Dnn::Compute
         dim_t in_features{ 0 }, out_features{ 0 };
         bool has_bias{ false };
     };
+
+    /// Test instrument (off unless a test installs one): records the per-token e4m3 activations a Linear on an fp8 x fp8 prefill path (W4A8, W8A8) consumed -- the bytes
+    /// and the scales, copied to the host behind a stream synchronize.  A teacher-forced oracle then multiplies THOSE bytes layer by layer, so that a whole-model logit
+    /// comparison is not at the mercy of e4m3 code flips upstream (tests/test_gemma_conditioned_gpu.py).  One pointer test per forward when off.
+    struct ActivationTap
+    {
+        struct Record { int M, K, N; std::vector<uint8_t> x8; std::vector<float> ts; };
+        std::vector<Record> records;
+    };
+    inline ActivationTap*& activationTap() { static ActivationTap* tap = nullptr; return tap; }
 
     /// counterpart of CudaLinearOp<Prec, TWeightQuant> (OPS/Linear/CudaLinearOp.ixx:107-1287)
     template<TensorDataType TPrecision, Quant::Weight::WeightQuantPolicy TWeightQuant>
@@ -156,6 +167,7 @@ namespace Mila::Dnn::Compute
                             const size_t ws_bytes = mila_cdna4_gemm_fp8_workspace_bytes( M, K, N );
                             activationScratch( M, K, x8, ts, ws_bytes, &ws );
                             rocmCheck( mila_cdna4_quantize_fp8_per_token( x8, ts, x, M, K, st ) );
+                            recordTap( x8, ts, M, K, N );
                             rocmCheck( mila_cdna4_gemm_fp8_w8a8_ws( y, x8, static_cast<const uint8_t*>( weight_ ), ts, scales_, bias_, M, K, N, ws, ws_bytes, st ) );
                             return;
                         }
@@ -178,6 +190,7 @@ namespace Mila::Dnn::Compute
                             const size_t ws_bytes = mila_cdna4_gemm_fp8_workspace_bytes( M, K, N );
                             activationScratch( M, K, x8, ts, ws_bytes, &ws );
                             rocmCheck( mila_cdna4_quantize_fp8_per_token( x8, ts, x, M, K, st ) );
+                            recordTap( x8, ts, M, K, N );
                             rocmCheck( mila_cdna4_gemm_fp8_scaled_ws( y, x8, resident_e4m3_->data(), ts, weight_fp8_scale_->data(), bias_, M, K, N, ws, ws_bytes, st ) );
                             return;
                         }
@@ -290,6 +303,17 @@ namespace Mila::Dnn::Compute
                 rocmCheck( mila_cdna4_gemm_fp8_w8a8_ws( y, x8, static_cast<const uint8_t*>( weight_ ), ts, scales_, bias_, M, K, N, ws, ws_bytes, this->context_->getStream() ) );
             else
                 rocmCheck( mila_cdna4_gemm_fp8_scaled_ws( y, x8, resident_e4m3_->data(), ts, weight_fp8_scale_->data(), bias_, M, K, N, ws, ws_bytes, this->context_->getStream() ) );
+        }
+        /// the test instrument above: copy this call's e4m3 activations and scales to the host when a tap is installed
+        void recordTap( const uint8_t* x8, const float* ts, int M, int K, int N ) const
+        {
+            ActivationTap* tap = activationTap();
+            if ( !tap ) return;
+            ActivationTap::Record r{ M, K, N, std::vector<uint8_t>( static_cast<size_t>( M ) * K ), std::vector<float>( static_cast<size_t>( M ) ) };
+            rocmCheck( mila_cdna4_memcpy_d2h( r.x8.data(), x8, r.x8.size(), this->context_->getStream() ) );
+            rocmCheck( mila_cdna4_memcpy_d2h( r.ts.data(), ts, r.ts.size() * 4, this->context_->getStream() ) );
+            this->context_->synchronize();
+            tap->records.push_back( std::move( r ) );
         }
         /// scratch for the per-token e4m3 activations + their scales (+ `extra` bytes behind them, 16-byte aligned: the GEMM's workspace) -- fetched per forward, never cached
         void activationScratch( int M, int K, uint8_t*& x8, float*& ts, size_t extra = 0, void** extra_out = nullptr ) const

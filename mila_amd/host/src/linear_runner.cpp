@@ -168,6 +168,24 @@ HOST_API int mila_sampler_sample( void* h, int enqueued, float temperature, int 
     } );
 }
 
+// ---- the activation tap (Operations.h: ActivationTap): begin -> run any prefill on this thread -> count / get -> end ----
+namespace { Compute::ActivationTap g_tap; }
+HOST_API void mila_linear_tap_begin( void ) { g_tap.records.clear(); Compute::activationTap() = &g_tap; }
+HOST_API void mila_linear_tap_end( void ) { Compute::activationTap() = nullptr; }
+HOST_API int64_t mila_linear_tap_count( void ) { return static_cast<int64_t>( g_tap.records.size() ); }
+/// dims[3] = {M, K, N}; x8_out [M, K] / ts_out [M] may be NULL (size query)
+HOST_API int mila_linear_tap_get( int64_t i, int32_t* dims, uint8_t* x8_out, float* ts_out )
+{
+    return guarded( [&]
+    {
+        if ( i < 0 || i >= static_cast<int64_t>( g_tap.records.size() ) ) throw std::invalid_argument( "mila_linear_tap_get: no such record" );
+        const auto& r = g_tap.records[ static_cast<size_t>( i ) ];
+        if ( dims ) { dims[ 0 ] = r.M; dims[ 1 ] = r.K; dims[ 2 ] = r.N; }
+        if ( x8_out ) std::memcpy( x8_out, r.x8.data(), r.x8.size() );
+        if ( ts_out ) std::memcpy( ts_out, r.ts.data(), r.ts.size() * 4 );
+    } );
+}
+
 /// Linear::forward on M host rows (bf16 bits) -> M x N host rows
 HOST_API int mila_linear_forward( void* h, int64_t M, const uint16_t* x_host, uint16_t* y_host )
 {

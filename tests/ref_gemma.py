@@ -45,6 +45,10 @@ class RefGemma:
         # True (fp8 policy only): a T > 1 forward runs the OPT-IN W8A8 prefill (RocmLinearOp::setFp8ActivationPrefill on PerChannelFp8<>; Policies.ixx:39-40): the policy's own e4m3
         # weights, per-token e4m3 activations (CudaFp8Prefill.cu:108-160), an fp8 x fp8 contraction, y = bf16((acc * scale[n]) * s_m).  Takes precedence over staged_prefill.
         self.w8a8_prefill = w8a8_prefill
+        # teacher forcing (tests/test_gemma_conditioned_gpu.py): an iterator of (M, K, N, x8, ts) records -- the per-token e4m3 activations the GPU's Linears consumed,
+        # in call order (host.activation_tap) -- which the fp8 x fp8 Linears below multiply INSTEAD of quantizing their own input: the comparison then measures
+        # everything but upstream e4m3 code flips
+        self.forced = None
         self.w4a8_f32_order = w4a8_f32_order      # tests/test_conditioned_cpu.py: the same arithmetic accumulated in FP32 in another order (a second correct implementation)
         self._w8 = {}
         self.f32_stand_in = f32_stand_in   # tools/condition_probe.py only: FP32 BLAS accumulation as a stand-in for another summation order
@@ -120,7 +124,7 @@ class RefGemma:
         w8, ws = self._w8[key]
         x2 = np.asarray(x, dtype=np.float32)
         shp = x2.shape
-        x8, ts = orc.quantize_act_fp8_per_token(x2.reshape(-1, shp[-1]))
+        x8, ts = self._activations(x2.reshape(-1, shp[-1]), w8.shape[0])
         if self.w4a8_f32_order:
             a = orc.E4M3_LUT[x8].astype(np.float32)[:, ::-1]
             b = np.ascontiguousarray(orc.E4M3_LUT[w8].astype(np.float32)[:, ::-1].T)
@@ -134,9 +138,20 @@ class RefGemma:
         """the fp8 policy's weights as they are stored (e4m3 [N, K] + scale[N]) x per-token e4m3 activations: (acc * scale[n]) * s_m, one rounding (csrc/common.h: w8a8_scale_bias)"""
         x2 = np.asarray(x, dtype=np.float32)
         shp = x2.shape
-        x8, ts = orc.quantize_act_fp8_per_token(x2.reshape(-1, shp[-1]))
+        x8, ts = self._activations(x2.reshape(-1, shp[-1]), W[1].shape[0])
         y = orc.linear_fp8a_fp8w(x8, ts, W[1], W[2], 1.0)
         return self.r(y).reshape(shp[:-1] + (W[1].shape[0],))
+
+    def _activations(self, x2, N):
+        """per-token e4m3 activations of an fp8 x fp8 Linear: the oracle's own quantization, or -- teacher-forced -- the next record of the GPU's"""
+        if self.forced is None:
+            return orc.quantize_act_fp8_per_token(x2)
+        M, K, Nr, x8, ts = next(self.forced)
+        assert (M, K, Nr) == (x2.shape[0], x2.shape[1], N), "teacher forcing out of step: GPU record %s, oracle Linear %s" % ((M, K, Nr), (x2.shape[0], x2.shape[1], N))
+        own8, own_ts = orc.quantize_act_fp8_per_token(x2)
+        self.forced_flips = getattr(self, "forced_flips", 0) + int(np.count_nonzero(own8 != x8))
+        self.forced_codes = getattr(self, "forced_codes", 0) + int(x8.size)
+        return x8, ts
 
     def rms(self, x, w):
         return self.r(orc.rmsnorm(x, w, None, eps=1e-6))

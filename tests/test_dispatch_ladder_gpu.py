@@ -74,7 +74,7 @@ def test_every_row_count_reaches_a_tested_form_and_the_oracle(policy, shape):
             forms = capi.last_form()
             assert forms, "no kernel form was noted for M = %d" % M
             table["%s/%s/%d" % (policy, name, M)] = forms
-            rows = sorted({0, M // 2, M - 1})
+            rows = sorted({0, M - 1})
             exp = _expected(policy, M, X[rows] if M > 1 else X, Wb, q)
             assert_bf16_close(Y[rows], exp, 2, 2e-3 * float(np.abs(exp).max()), "%s %s M=%d via %s" % (policy, name, M, "+".join(forms)))
     finally:
