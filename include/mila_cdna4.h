@@ -494,7 +494,9 @@ MILA_API int mila_cdna4_sample_argmax_final_advance(int32_t* token_out, const vo
 /* One-launch decode attention for one token (B == 1): q/k/v per-head RMSNorm + RoPE + KV append (the
  * work of fused_qkv_post) folded into the flash-decode kernel's prologue, where it overlaps the first
  * K/V round trip.  q_raw [NH*HS], k_raw / v_raw [NKV*HS] are the raw projections (v_raw == k_raw on Gemma
- * global layers).  position_dev != NULL selects the graph-replay form.  Bit-identical to
+ * global layers).  position_dev != NULL selects the graph-replay form; `position` is then an upper bound on the live length (position + 1) the captured
+ * launch will be replayed at, 0 = the capacity: an unwindowed layer's launch geometry is chosen per BUCKET of the live length (4096, 8192, 16384, ... keys, clipped to
+ * the capacity; the eager form uses position + 1), so a caller whose positions leave the bucket re-captures (GemmaTransformer::ensureGraph).  Bit-identical to
  * fused_qkv_post + attn_decode_bf16. */
 MILA_API int mila_cdna4_fused_attn_decode_bf16(uint16_t* Y, uint16_t* Kc, uint16_t* Vc, const uint16_t* q_raw,
                                                const uint16_t* k_raw, const uint16_t* v_raw, const uint16_t* qw,

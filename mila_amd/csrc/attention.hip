@@ -29,8 +29,9 @@ namespace mila {
 
 constexpr int kMaxSplits = 64;
 constexpr int kMaxSplitsMfma = 256;      // the long-context MFMA decode (attn_decode_mfma_kernel): one workgroup per CU
-constexpr int kMfmaMinBand = 4096;        // live band (keys) from which a 16-head group on one KV head takes the MFMA decode
+constexpr int kMfmaMinBand = 8192;        // band bucket (keys) from which a 16-head group on one KV head takes the MFMA decode (see band_bucket; profiles/r04_attn_band.txt)
 static int g_mfma_min_band = kMfmaMinBand;      // tuning hook (mila_cdna4_tune_attn_split(-3 - n)): n * 256 keys
+MILA_TUNE("attn.mfma_min_band", g_mfma_min_band);
 
 // ---- KV append ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void kv_write_bf16_kernel(uint16_t* __restrict__ Kc, uint16_t* __restrict__ Vc,
@@ -761,6 +762,7 @@ __global__ __launch_bounds__(256) void attn_combine_many_kernel(uint16_t* __rest
 }
 
 static int g_tune_decode_mfma = 1;      // tuning hook (mila_cdna4_tune_attn_split, negative values): 0 = never take the MFMA decode
+MILA_TUNE("attn.mfma_decode", g_tune_decode_mfma);
 
 static bool mfma_decode_applies(int NH, int NKV, int HS, int band_max)
 {
@@ -778,6 +780,7 @@ static int mfma_decode_splits(int B, int NH, int NKV, int band_max)
 static int launch_decode_mfma(const AttnParams& p, int B, hipStream_t s)
 {
     constexpr int HS = 512;
+    note_form("attn_decode_mfma");
     static bool attr_set = false;
     const size_t lds = 4 * (size_t)kKeysPerTile * HS * 2 + 16 * (size_t)HS * 2;      // two [K | V] tile pairs + the 16 heads' Q rows
     if (!attr_set)
@@ -802,6 +805,7 @@ template <int HS, int GH, bool FUSED>
 static int launch_decode(const AttnParams& p, int B, hipStream_t s)
 {
     const int hgroups = (p.NH / p.NKV) / GH;
+    note_form("attn_decode");
     const size_t lds = (size_t)kDecodeWaves * GH * (HS + 2) * sizeof(float) + (size_t)(GH + 2) * HS * 2;
     const int wa = (p.warm_a && p.warm_a_lines > 0) ? p.warm_a_blocks : 0;
     if (p.flat)
@@ -887,17 +891,33 @@ static int decode_splits(int B, int NH, int NKV, int HS, int band)
     return s;
 }
 
+// The launch geometry of an unwindowed layer (split count, and whether the matrix-core decode serves it) is chosen from a BUCKET of the live length, not from the cache
+// capacity: 4096, 8192, 16384, ... keys, clipped to the capacity.  (chosen from the capacity alone, a 32K-capacity cache decoding at position 2K ran the
+// matrix-core kernel with 256 splits of 8 keys each -- 28.5 us against the scalar kernel's 23.9; the crossover is at ~8K keys, profiles/r04_attn_band.txt.)  A bucket is a
+// function of the position only, so eager launches and a captured graph agree as long as the graph is re-captured when the position leaves its bucket
+// (GemmaTransformer::ensureGraph does); inside a bucket the geometry is static, which is what a graph needs.  Caches of <= 4096 rows (the benchmark's) have one bucket.
+static int band_bucket(int len, int capacity)
+{
+    int b = 4096;
+    while (b < len && b < capacity) b <<= 1;
+    return min(b, capacity);
+}
+
+// len_hint: an upper bound on the live length this launch is for -- position + 1 in the eager forms; in the device-position forms what the caller captured the graph
+// for (0 = the capacity)
 static int run_decode(uint16_t* Y, const uint16_t* Q, uint16_t* Kc, uint16_t* Vc, void* scratch, size_t scratch_bytes, int B,
                       int NH, int NKV, int HS, int capacity, int position, const int32_t* pos_dev, int window, float scale,
-                      const AttnParams* fused, const char* who, hipStream_t stream)
+                      const AttnParams* fused, const char* who, hipStream_t stream, int len_hint = 0)
 {
     AttnParams p{};
     if (fused) p = *fused;
     p.Y = Y; p.Q = Q; p.K = Kc; p.V = Vc; p.scratch = reinterpret_cast<float*>(scratch);
     p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.position = position; p.window = window;
-    // the split count depends only on (window, capacity), never on the current length, so that eager
+    // the split count depends only on (window, band bucket), never on the current length inside a bucket, so that eager
     // launches and a graph captured once (the _devpos forms) reduce in the same order: bit-identical
-    const int band_max = (window > 0 && window < capacity) ? window : capacity;
+    const int hint = pos_dev ? len_hint : position + 1;
+    const int band_limit = hint > 0 ? band_bucket(hint, capacity) : capacity;
+    const int band_max = (window > 0 && window < capacity) ? window : band_limit;
     p.splits = decode_splits(B, NH, NKV, HS, band_max);
     p.scale = scale;
     p.pos_dev = pos_dev;
@@ -1066,7 +1086,7 @@ int mila_cdna4_attn_decode_bf16_devpos(uint16_t* Y, const uint16_t* Q, const uin
     const int band = (window > 0 && window < max_len) ? window : max_len;
     MILA_REQUIRE(band <= capacity, "attn_decode_bf16_devpos: live band %d exceeds the cache capacity %d", band, capacity);
     return run_decode(Y, Q, const_cast<uint16_t*>(Kc), const_cast<uint16_t*>(Vc), scratch, scratch_bytes, B, NH, NKV, HS, capacity, 0,
-                      position_dev, window, scale, nullptr, "attn_decode_bf16_devpos", as_stream(stream));
+                      position_dev, window, scale, nullptr, "attn_decode_bf16_devpos", as_stream(stream), max_len);
 }
 
 // Fused decode attention for one token (B == 1): per-head q/k/v RMSNorm + RoPE + KV append + flash-decode.
@@ -1090,7 +1110,7 @@ int mila_cdna4_fused_attn_decode_bf16(uint16_t* Y, uint16_t* Kc, uint16_t* Vc, c
     f.q_raw = q_raw; f.k_raw = k_raw; f.v_raw = v_raw; f.qw = qw; f.kw = kw; f.vw = vw; f.cos_cache = cos_cache; f.sin_cache = sin_cache;
     f.eps = eps;
     return run_decode(Y, nullptr, Kc, Vc, scratch, scratch_bytes, 1, NH, NKV, HS, capacity, position, position_dev, window, scale, &f,
-                      "fused_attn_decode_bf16", as_stream(stream));
+                      "fused_attn_decode_bf16", as_stream(stream), position_dev ? position : 0);
 }
 
 // The same launch for B rows decoded at one position (Gqa.Decode.Bf16.cu:379-387 takes the batch in its grid): batch row b reads its raw projections at
@@ -1115,7 +1135,7 @@ int mila_cdna4_fused_attn_decode_batch_bf16(uint16_t* Y, uint16_t* Kc, uint16_t*
     f.q_raw = q_raw; f.k_raw = k_raw; f.v_raw = v_raw; f.raw_b_stride = raw_b_stride; f.qw = qw; f.kw = kw; f.vw = vw; f.cos_cache = cos_cache; f.sin_cache = sin_cache;
     f.eps = eps;
     return run_decode(Y, nullptr, Kc, Vc, scratch, scratch_bytes, B, NH, NKV, HS, capacity, position, position_dev, window, scale, &f,
-                      "fused_attn_decode_batch_bf16", as_stream(stream));
+                      "fused_attn_decode_batch_bf16", as_stream(stream), position_dev ? position : 0);
 }
 
 // ---- GPT-2 multi-head attention over a KV cache (CudaMhaOp.ixx:137-380: prefill / decode of IPositionalUnaryOp + IKvCacheLifecycle) ----

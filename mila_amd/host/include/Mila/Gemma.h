@@ -221,7 +221,8 @@ namespace Mila::Dnn
                 // greedy sampler (feeds the next replay) + position bump + publication of the token.  The sampler's FIRST stage runs in the lm_head's epilogue (every
                 // workgroup leaves its best logit and index in the sampler scratch), its final reduction does the other three: one launch behind the head, not three
                 int sampler_partials = 0;
-                enqueueFusedStep( token.data(), 0, pos_dev_->data(), sample_in_graph_ ? &sampler_partials : nullptr );
+                captured_band_end_ = bandBucket( start_position );
+                enqueueFusedStep( token.data(), static_cast<int>( captured_band_end_ ), pos_dev_->data(), sample_in_graph_ ? &sampler_partials : nullptr );
                 if ( sample_in_graph_ )
                     Compute::rocmCheck( mila_cdna4_sample_argmax_final_advance( const_cast<TokenTensor&>( token ).data(), sample_scratch_->data(), sample_scratch_->sizeInBytes(), sampler_partials,
                                                                                 pos_dev_->data(), token_ring_ ? token_seq_ : nullptr, token_ring_, token_ring_ ? token_ring_size_ : 0,
@@ -240,9 +241,20 @@ namespace Mila::Dnn
         }
         /// capture on first use, and again whenever the captured graph no longer matches what a replay must do: another token
         /// buffer, or a different sampler setting (a graph captured without the sampler node never writes the next token)
+        /// ... or a position outside the band bucket the attention launches were captured for (csrc/attention.hip: band_bucket -- 4096, 8192, 16384, ... keys: an unwindowed
+        /// layer's split geometry and kernel form follow the live length bucket, not the cache capacity).  Cheap: callers invoke it before every replay.
         void ensureGraph( const TokenTensor& token, dim_t start_position )
         {
-            if ( !graph_exec_ || captured_token_ != token.data() || captured_sample_in_graph_ != sample_in_graph_ || captured_ring_ != token_ring_ ) captureGraph( token, start_position );
+            if ( !graph_exec_ || captured_token_ != token.data() || captured_sample_in_graph_ != sample_in_graph_ || captured_ring_ != token_ring_ ||
+                 start_position + 1 > captured_band_end_ || ( start_position + 1 <= captured_band_end_ / 2 && captured_band_end_ > 4096 ) )
+                captureGraph( token, start_position );
+        }
+        /// the live-length bucket of a position (the rule of csrc/attention.hip: band_bucket)
+        dim_t bandBucket( dim_t position ) const
+        {
+            dim_t b = 4096;
+            while ( b < position + 1 && b < max_seq_ ) b <<= 1;
+            return std::min( b, max_seq_ );
         }
         bool graphCaptured() const noexcept { return graph_exec_ != nullptr; }
         /// kernel nodes of the captured decode step (0 before a capture): the launches one token costs on the graph path
@@ -1223,6 +1235,7 @@ namespace Mila::Dnn
         hipGraph_t graph_{ nullptr };
         hipGraphExec_t graph_exec_{ nullptr };
         const int32_t* captured_token_{ nullptr };      // what the captured graph was built for: ensureGraph() re-captures on a mismatch
+        dim_t captured_band_end_{ 0 };                  // ... and the live-length bucket (exclusive end) its attention launches were shaped for
         bool captured_sample_in_graph_{ false };
         unsigned long long* token_ring_{ nullptr };
         unsigned long long* token_seq_{ nullptr };

@@ -318,6 +318,7 @@ namespace Mila::Dnn
                 const uint64_t mine = published_;          // the sample this iteration reports
                 if ( ahead )
                 {
+                    net.ensureGraph( *decode_token_device_, position );      // (re-captures only when the position leaves the captured live-length bucket)
                     net.replayGraph();
                     if ( greedy ) ++published_;      // the captured step ends with sampler + publish: the NEXT token
                 }

@@ -346,7 +346,7 @@ HOST_API int mila_gemma_time_decode( void* h, int64_t start_position, int steps,
             {
                 if ( mode == 0 ) { m->decode( *r->tokens, pos ); m->sampleGreedy( *r->tokens ); }
                 else if ( mode == 1 ) { m->decodeFused( *r->tokens, pos ); m->sampleGreedy( *r->tokens ); }
-                else m->replayGraph();
+                else { m->ensureGraph( *r->tokens, pos ); m->replayGraph(); }
             };
             int64_t pos = start_position;
             for ( int i = 0; i < warmup; ++i ) step( pos++ );
@@ -484,7 +484,7 @@ HOST_API int mila_gemma_generate( void* h, int32_t first_token, int64_t start_po
                 const int64_t pos = start_position + i;
                 if ( mode == 0 ) { m->decode( *r->tokens, pos ); m->sampleGreedy( *r->tokens ); }
                 else if ( mode == 1 ) { m->decodeFused( *r->tokens, pos ); m->sampleGreedy( *r->tokens ); }
-                else m->replayGraph();
+                else { m->ensureGraph( *r->tokens, pos ); m->replayGraph(); }
                 Compute::rocmCheck( mila_cdna4_memcpy_d2h( host_out + i, r->tokens->data(), 4, ctx->getStream() ) );
                 ctx->synchronize();
             }

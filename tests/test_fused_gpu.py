@@ -547,6 +547,9 @@ def test_long_band_global_layer_takes_the_matrix_core_decode_and_the_fused_form_
     With the hook off (the wave-per-position kernel) the same call stays within the same bar: two kernels, one function."""
     lib = capi.load()
     NH, NKV, HS, cap, window, base, rot = 16, 1, 512, 8192, 0, 1e6, 128
+    # round 4: the launch geometry follows the live-length BUCKET (4096, 8192, ... keys; csrc/attention.hip: band_bucket), and the matrix-core decode starts at the 8192
+    # bucket: positions >= 4096 of this cache take it, earlier ones the wave-per-position kernel -- asserted through last_form below
+    want_form = "attn_decode_mfma" if pos + 1 > 4096 else "attn_decode"
     rng = np.random.default_rng(pos + B)
     hist_k = _bf(rng.uniform(-1, 1, (B, NKV, cap, HS)) * 0.5)
     hist_v = _bf(rng.uniform(-1, 1, (B, NKV, cap, HS)))
@@ -563,7 +566,9 @@ def test_long_band_global_layer_takes_the_matrix_core_decode_and_the_fused_form_
     K0, V0, q0, y0 = Kc0.clone(), Vc0.clone(), empty_u16(B, NH * HS), empty_u16(B, NH * HS)
     for b in range(B):
         capi.call("fused_qkv_post", q0[b], K0[b], V0[b], rows_d[b], rows_d[b, NH * HS:], rows_d[b, NH * HS:], qw, kw, None, cos, sin, NH, NKV, HS, pos, cap, 1e-6)
+    capi.last_form()
     capi.call("attn_decode_bf16", y0, q0, K0, V0, scratch, C.c_size_t(nbytes), B, NH, NKV, HS, cap, pos + 1, window, 1.0)
+    assert capi.last_form() == [want_form]
     # fused forms
     K1, V1, y1 = Kc0.clone(), Vc0.clone(), empty_u16(B, NH * HS)
     if B == 1:
@@ -576,19 +581,26 @@ def test_long_band_global_layer_takes_the_matrix_core_decode_and_the_fused_form_
     if B == 1:
         K2, V2, y2 = Kc0.clone(), Vc0.clone(), empty_u16(B, NH * HS)
         pd = torch.tensor([pos], dtype=torch.int32, device="cuda")
+        # the device-position form: `position` carries the live-length bound the launch was captured for (any value of the same bucket gives the eager form's bits)
         capi.call("fused_attn_decode_bf16", y2, K2, V2, rows_d[0], rows_d[0, NH * HS:], rows_d[0, NH * HS:], qw, kw, None, cos, sin, scratch, C.c_size_t(nbytes), NH, NKV, HS,
-                  cap, 0, pd, window, 1.0, 1e-6)
+                  cap, 4096 if pos + 1 <= 4096 else 8192, pd, window, 1.0, 1e-6)
         assert np.array_equal(bits(y2), bits(y0)) and np.array_equal(bits(K2), bits(K0))
     # oracle: the roped q rows against the linear history 0 .. pos (the appended row included)
     Kh = orc.from_bf16_bits(bits(K0)).reshape(B, NKV, cap, HS)[:, :, :pos + 1].transpose(0, 2, 1, 3)
     Vh = orc.from_bf16_bits(bits(V0)).reshape(B, NKV, cap, HS)[:, :, :pos + 1].transpose(0, 2, 1, 3)
     qn = orc.from_bf16_bits(bits(q0)).reshape(B, 1, NH, HS)
     exp = orc.gqa_attention(qn, np.ascontiguousarray(Kh), np.ascontiguousarray(Vh), pos, window, 1.0)[:, 0]
-    assert_bf16_close(bits(y0), exp, 1, 2e-3, "matrix-core decode vs oracle")
-    capi.check(lib.mila_cdna4_tune_attn_split(-1))            # the wave-per-position kernel on the same inputs
+    assert_bf16_close(bits(y0), exp, 1, 2e-3, "%s vs oracle" % want_form)
+    # the OTHER kernel on the same inputs (the matrix-core decode forced from the first bucket on / switched off): two kernels, one function
+    y3 = empty_u16(B, NH * HS)
     try:
-        y3 = empty_u16(B, NH * HS)
+        if want_form == "attn_decode_mfma":
+            capi.tune("attn.mfma_decode", 0)
+        else:
+            capi.tune("attn.mfma_min_band", 4096)
+        capi.last_form()
         capi.call("attn_decode_bf16", y3, q0, K0, V0, scratch, C.c_size_t(nbytes), B, NH, NKV, HS, cap, pos + 1, window, 1.0)
+        assert capi.last_form() == ["attn_decode" if want_form == "attn_decode_mfma" else "attn_decode_mfma"]
     finally:
-        capi.check(lib.mila_cdna4_tune_attn_split(-2))
-    assert_bf16_close(bits(y3), exp, 1, 2e-3, "wave-per-position decode vs oracle")
+        capi.tune_reset()
+    assert_bf16_close(bits(y3), exp, 1, 2e-3, "the other decode kernel vs oracle")

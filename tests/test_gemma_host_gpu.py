@@ -530,20 +530,53 @@ def test_a_long_capacity_model_takes_the_matrix_core_decode_on_every_path():
     cfg = dict(vocab_size=1024, embedding_dim=256, num_layers=4, num_heads=16, num_kv_heads=8, head_dim=64, hidden_dim=512,
                global_head_dim=512, num_global_kv_heads=1, window=8, sliding_window_pattern=2, global_rotary_dim=128)
     max_seq = 4200
+    from mila_amd import capi
     ref = RefGemma(cfg, "bf16", seed=11, staged_prefill=True)
     ref.forward(TOKENS[:9], 0, max_seq)
     models = {m: host.Gemma("bf16", cfg, max_seq=max_seq, max_prefill=16, seed=11) for m in ("reference", "fused", "graph")}
     for g in models.values():
         g.prefill(TOKENS[:9])
     worst = 0.0
-    for i, tok in enumerate(TOKENS[9:]):
-        pos = 9 + i
-        out = {m: g.decode(tok, pos, m) for m, g in models.items()}
+    try:
+        capi.tune("attn.mfma_min_band", 4096)          # (round 4: the default starts the matrix-core decode at the 8192-key bucket; here from the first bucket on)
+        for i, tok in enumerate(TOKENS[9:]):
+            pos = 9 + i
+            capi.last_form()
+            out = {m: g.decode(tok, pos, m) for m, g in models.items()}
+            assert "attn_decode_mfma" in capi.last_form()
+            for m in ("fused", "graph"):
+                assert np.array_equal(out["reference"].view(np.uint32), out[m].view(np.uint32)), "%s != reference-order at %d" % (m, pos)
+            exp = ref.forward([tok], pos, max_seq)
+            worst = max(worst, float(np.abs(out["graph"] - exp).max() / np.abs(exp).max()))
+    finally:
+        capi.tune_reset()
+    assert worst < 1e-1, worst
+    for g in models.values():
+        g.close()
+
+
+def test_decode_across_a_live_length_bucket_re_captures_the_graph_and_keeps_the_three_paths_identical():
+    """an unwindowed layer's decode geometry -- split count, wave-per-position vs matrix-core kernel -- follows the live-length bucket (4096, 8192, ...
+    keys), not the cache capacity: a model built for 8300 positions decodes positions 4090 .. 4100 across the first bucket boundary; the captured graph is re-captured
+    there (GemmaTransformer::ensureGraph) and reference-order, fused and graph-replay logits stay bit-identical on both sides; the global layers change kernels at 4096"""
+    from mila_amd import capi
+    cfg = dict(vocab_size=1024, embedding_dim=256, num_layers=2, num_heads=16, num_kv_heads=8, head_dim=64, hidden_dim=512,
+               global_head_dim=512, num_global_kv_heads=1, window=8, sliding_window_pattern=2, global_rotary_dim=128)
+    max_seq, start = 8300, 4090
+    toks = [(7 * i + 3) % 1024 for i in range(start + 12)]
+    models = {m: host.Gemma("bf16", cfg, max_seq=max_seq, max_prefill=1024, seed=11) for m in ("reference", "fused", "graph")}
+    for g in models.values():
+        for o in range(0, start, 1024):
+            g.prefill(toks[o:min(o + 1024, start)], o)
+    seen = set()
+    for pos in range(start, start + 12):
+        capi.last_form()
+        out = {m: g.decode(toks[pos], pos, m) for m, g in models.items()}
+        forms = capi.last_form()
+        seen.add(("attn_decode_mfma" in forms, pos + 1 > 4096))
         for m in ("fused", "graph"):
             assert np.array_equal(out["reference"].view(np.uint32), out[m].view(np.uint32)), "%s != reference-order at %d" % (m, pos)
-        exp = ref.forward([tok], pos, max_seq)
-        worst = max(worst, float(np.abs(out["graph"] - exp).max() / np.abs(exp).max()))
-    assert worst < 1e-1, worst
+    assert seen == {(False, False), (True, True)}, seen                 # the matrix-core decode exactly from the 8192-key bucket on
     for g in models.values():
         g.close()
 
