@@ -25,11 +25,26 @@
 
 #include "common.h"
 #include <type_traits>
+#include <utility>
 #include "internal.h"
 #include "attention_generic.h"
 #include "attention_tiles.h"
 
 namespace mila {
+
+// the V^T fragments of DT output tiles from the tile image at LDS byte address vimg: compile-time offsets (d >> 3) * 256 and + 16 rows
+template <int ROWB, int BASE, int... I>
+__device__ __forceinline__ void read_vt_frags(const unsigned (&addr)[8], s16x8* va, std::integer_sequence<int, I...>)
+{
+    auto one = [&](auto ic) {
+        constexpr int d = decltype(ic)::value;
+        const s16x4 lo = lds_read_tr16<BASE + (d >> 3) * 256>(addr[d & 7]);
+        const s16x4 hi = lds_read_tr16<BASE + (d >> 3) * 256 + 16 * ROWB>(addr[d & 7]);
+        va[d][0] = lo[0]; va[d][1] = lo[1]; va[d][2] = lo[2]; va[d][3] = lo[3];
+        va[d][4] = hi[0]; va[d][5] = hi[1]; va[d][6] = hi[2]; va[d][7] = hi[3];
+    };
+    (one(std::integral_constant<int, I>{}), ...);
+}
 
 struct FlashParams
 {
@@ -286,6 +301,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
     static_assert(NW == 4 || (NW == 8 && ((HB == 4 && DS == 2) || (HB == 2 && DS == 1))), "workgroup shapes");
     // double-buffered tiles, one barrier per tile: the 8-wave form, and every HS <= 256 form (two [K | V] pairs are 64 KB there: two workgroups still share a CU)
     constexpr bool DB = (NW == 8) || (HS <= 256);
+    constexpr bool ASM_TR = !(HS >= 512 && DS == 1);         // V^T fragments by inline-assembly reads (every form but the spilling one, see the tile body)
     constexpr int QB = NW / (HB * DS);
     static_assert(QB >= 1, "at most NW (head, d-half) pairs per workgroup");
     constexpr int QROWS = 16 * QB;
@@ -300,6 +316,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
     static_assert(DMAS >= 1, "tile too small for the wave count");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [K tile | V tile] (NW = 8: two of them)
+#ifdef MILA_FLASH_STAMPS
+    const unsigned long long entry_ = __builtin_amdgcn_s_memtime();
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
@@ -350,25 +369,30 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
     const uint16_t* vbase = p.V + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride;
 
     const bool ring = pos_last >= p.capacity;                   // uniform: only a bounded ring wraps inside one prefill
-    // K / V tiles go global -> LDS by LDS-DMA, no staging registers: wave w requests rows w, w + 4, ... of a tile, one row per instruction; a lane's LDS slot
-    // is linear (M0 base + 16 lane), so the swizzle of k_off / v_off -- an involution on the chunk index -- is applied to the SOURCE chunk it fetches.
+    // K / V tiles go global -> LDS by LDS-DMA, no staging registers: wave w requests rows w, w + NW, ... of a tile, RPI rows (1 KiB) per instruction; a lane's LDS
+    // slot is linear (M0 base + 16 lane), so the swizzle of k_off / v_off -- an involution on the chunk index -- is applied to the SOURCE chunk it fetches.
     // Every tile requests all its rows, so the request counts the waits rely on are constant: a row beyond the last key any row of this workgroup may see
     // re-reads that last key (a finite in-band row; the mask works on key positions, not contents).
-    // Source addresses: a tile that lies whole below pos_last on an unwrapped cache (all but the last one or two) is fetched from the lane's first-tile address
-    // advanced by whole tiles -- one 64-bit add per instruction instead of the clamp / modulo / 64-bit multiply chain.  A wave's consecutive instructions are
-    // STEP rows apart and the swizzles repeat every 16 rows, so instructions i and i + 16 / STEP differ by exactly 16 rows: one or two first addresses per
-    // matrix (element offsets from kbase / vbase) cover them all.  (Kept in scalars, not arrays: this compiler silently drops the kernel's host stub when a
-    // lambda captures an array declared here.)
+    // (round 4) The requests are buffer loads (buffer_load_dwordx4 ... offen lds) on one resource per matrix, based at this (batch, KV head): a lane's 32-bit
+    // byte offset -- its row inside a 16-row group and its swizzled chunk, fixed for the whole kernel -- rides in the vector offset, the tile's rows in the
+    // SCALAR offset: a request of a whole in-band tile costs one scalar add where the global_load_lds form rebuilt a 64-bit vector address per request
+    // (v_lshl_add_u64 pairs, eight long-lived address registers -- at HS = 512 the kernel spilled for them).  A wave's consecutive instructions are STEP rows
+    // apart and the swizzles repeat every 16 rows, so instructions i and i + 16 / STEP differ by exactly 16 rows: one or two lane offsets per matrix cover them.
+    // The last one or two tiles of a band and a wrapped ring take the general form: per-lane clamp / modulo in 32-bit arithmetic, scalar offset 0.
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const auto rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(kbase), 0, 0x7fffffff, 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(vbase), 0, 0x7fffffff, 0x00020000);
+    const int rstride = (int)(p.kv_r_stride * 2);                // row pitch in bytes (the launcher checks that a cache's rows fit 31 bits of byte offset)
     constexpr int STEP = RPI * NW, NB = 16 / STEP;
     static_assert(!DB || NB == 1 || NB == 2, "the double-buffered forms issue whole 16-row groups per one or two instructions");
-    int64_t ks0 = 0, ks1 = 0, vs0 = 0, vs1 = 0;
+    int ks0 = 0, ks1 = 0, vs0 = 0, vs1 = 0;
     {
         const int slot = lane % CPR;
         const int r0 = RPI * wave + lane / CPR, r1 = r0 + STEP;
-        ks0 = (int64_t)(kt0 + r0) * p.kv_r_stride + ((k_off<HS>(r0, slot) - r0 * ROWB) >> 4) * 8;
-        vs0 = (int64_t)(kt0 + r0) * p.kv_r_stride + ((v_off<HS>(r0, slot) - r0 * ROWB) >> 4) * 8;
-        ks1 = (int64_t)(kt0 + r1) * p.kv_r_stride + ((k_off<HS>(r1, slot) - r1 * ROWB) >> 4) * 8;
-        vs1 = (int64_t)(kt0 + r1) * p.kv_r_stride + ((v_off<HS>(r1, slot) - r1 * ROWB) >> 4) * 8;
+        ks0 = r0 * rstride + (k_off<HS>(r0, slot) - r0 * ROWB);
+        vs0 = r0 * rstride + (v_off<HS>(r0, slot) - r0 * ROWB);
+        ks1 = r1 * rstride + (k_off<HS>(r1, slot) - r1 * ROWB);
+        vs1 = r1 * rstride + (v_off<HS>(r1, slot) - r1 * ROWB);
     }
     auto stage_k = [&](int kt, unsigned char* ldsK) {
 #pragma unroll
@@ -376,8 +400,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
         {
             const int row0 = RPI * (NW * i + wave);                       // the instruction's first row: RPI consecutive rows = 1 KiB of LDS
             const int row = row0 + lane / CPR, slot = lane % CPR, pos = min(kt + row, pos_last);
-            const uint16_t* src = kbase + (size_t)(ring ? pos % p.capacity : pos) * p.kv_r_stride + (size_t)((k_off<HS>(row, slot) - row * ROWB) >> 4) * 8;
-            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(ldsK + row0 * ROWB), 16, 0, 0);
+            const int voff = (ring ? pos % p.capacity : pos) * rstride + (k_off<HS>(row, slot) - row * ROWB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)(ldsK + row0 * ROWB), 16, voff, 0, 0, 0);
         }
     };
     auto stage_v = [&](int kt, unsigned char* ldsV) {
@@ -386,8 +410,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
         {
             const int row0 = RPI * (NW * i + wave);
             const int row = row0 + lane / CPR, slot = lane % CPR, pos = min(kt + row, pos_last);
-            const uint16_t* src = vbase + (size_t)(ring ? pos % p.capacity : pos) * p.kv_r_stride + (size_t)((v_off<HS>(row, slot) - row * ROWB) >> 4) * 8;
-            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(ldsV + row0 * ROWB), 16, 0, 0);
+            const int voff = (ring ? pos % p.capacity : pos) * rstride + (v_off<HS>(row, slot) - row * ROWB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)(ldsV + row0 * ROWB), 16, voff, 0, 0, 0);
         }
     };
     // Per-lane LDS offsets of the fragment reads, once: the swizzles touch only the low four bits of the chunk index, so the offsets repeat every 16 chunks
@@ -400,6 +424,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
     {
         const int col = 16 * (dsel * DT + i) + 4 * (l15 & 3);          // lane 4 q + pp of a 16-lane group supplies row q, columns 4 pp .. 4 pp + 3 of the block
         vaddr[i] = v_off<HS>(4 * g + (l15 >> 2), col >> 3) + ((col & 7) << 1);
+    }
+    unsigned vaddr_lds[8];                                      // the same as LDS byte addresses (the assembly reads take addresses, not pointers)
+    {
+        const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vaddr_lds[i] = smem_lds + (unsigned)vaddr[i];
     }
     const int wpos0 = p.pos_offset + wq0;                        // position of this wave's first row (uniform)
     const bool rows_ok = wq0 + 16 <= p.Tq;
@@ -451,15 +481,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
                         const int ktn = kt + kKeysPerTile;
                         if (!ring && ktn + kKeysPerTile - 1 <= pos_last)
                         {
-                            const int64_t adv = (int64_t)(ktn - kt0) * p.kv_r_stride;
+                            const int adv = ktn * rstride;                                    // bytes, wave-uniform
 #pragma unroll
                             for (int i = 0; i < DMAS; ++i)
-                                __builtin_amdgcn_global_load_lds(kbase + (((NB == 2 && (i & 1)) ? ks1 : ks0) + adv + (int64_t)(i / NB) * 16 * p.kv_r_stride),
-                                                                 (__attribute__((address_space(3))) void*)(nxt + RPI * (NW * i + wave) * ROWB), 16, 0, 0);
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)(nxt + RPI * (NW * i + wave) * ROWB), 16, (NB == 2 && (i & 1)) ? ks1 : ks0,
+                                                                         adv + (i / NB) * 16 * rstride, 0, 0);
 #pragma unroll
                             for (int i = 0; i < DMAS; ++i)
-                                __builtin_amdgcn_global_load_lds(vbase + (((NB == 2 && (i & 1)) ? vs1 : vs0) + adv + (int64_t)(i / NB) * 16 * p.kv_r_stride),
-                                                                 (__attribute__((address_space(3))) void*)(nxt + TILE_BYTES + RPI * (NW * i + wave) * ROWB), 16, 0, 0);
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)(nxt + TILE_BYTES + RPI * (NW * i + wave) * ROWB), 16, (NB == 2 && (i & 1)) ? vs1 : vs0,
+                                                                         adv + (i / NB) * 16 * rstride, 0, 0);
                         }
                         else
                         {
@@ -487,12 +517,34 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
         }
         // ---- V^T fragments of the wave's d tiles, requested here so that they land under the softmax ----
         // A operand: V^T[dim 16 d + l15][keys]: two transposing reads (keys 4 g .. and 16 + 4 g ..)
-        s16x4 vlo[DT], vhi[DT];
-#pragma unroll
-        for (int d = 0; d < DT; ++d)
+        // (inline-assembly reads: the intrinsic form would wait here for the NEXT tile's LDS-DMA, see attention_tiles.h.  NOT in the form that keeps a whole
+        // HS = 512 head in one wave -- it spills, and a register the compiler spills between an assembly read and its wait is stored before the data has landed;
+        // tests/test_capi_cpu.py holds every form that uses the assembly reads to zero spills)
+        s16x8 va[DT];
+        if constexpr (!ASM_TR)
         {
-            vlo[d] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + vaddr[d & 7] + (d >> 3) * 256));
-            vhi[d] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + vaddr[d & 7] + (d >> 3) * 256 + 16 * ROWB));
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+            {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + vaddr[d & 7] + (d >> 3) * 256));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ldsV + vaddr[d & 7] + (d >> 3) * 256 + 16 * ROWB));
+                va[d][0] = lo[0]; va[d][1] = lo[1]; va[d][2] = lo[2]; va[d][3] = lo[3];
+                va[d][4] = hi[0]; va[d][5] = hi[1]; va[d][6] = hi[2]; va[d][7] = hi[3];
+            }
+        }
+        else
+        {
+            constexpr int VOFF = BUF * 2 * TILE_BYTES + TILE_BYTES;           // this buffer's V image
+            constexpr int SPAN = ((DT - 1) >> 3) * 256 + 16 * ROWB;
+            if constexpr (VOFF + SPAN < 65536)
+                read_vt_frags<ROWB, VOFF>(vaddr_lds, va, std::make_integer_sequence<int, DT>{});
+            else
+            {
+                unsigned vb[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vb[i] = vaddr_lds[i] + VOFF;
+                read_vt_frags<ROWB, 0>(vb, va, std::make_integer_sequence<int, DT>{});
+            }
         }
 #ifdef MILA_FLASH_STAMPS
         if (stamping && s0[0] == 12345.678f) seg[4] += 1;          // the stamp waits for the products
@@ -549,14 +601,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
             asm volatile("" ::: "memory");                     // keeps the block a branch target (no if-conversion into 4 DT selects)
         }
         FLASH_STAMP(3);
+        if constexpr (ASM_TR) lds_tr_wait(va);
 #pragma unroll
         for (int d = 0; d < DT; ++d)
-        {
-            s16x8 va;
-            va[0] = vlo[d][0]; va[1] = vlo[d][1]; va[2] = vlo[d][2]; va[3] = vlo[d][3];
-            va[4] = vhi[d][0]; va[5] = vhi[d][1]; va[6] = vhi[d][2]; va[7] = vhi[d][3];
-            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va), pfrag, o[d], 0, 0, 0);
-        }
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va[d]), pfrag, o[d], 0, 0, 0);
 #ifdef MILA_FLASH_STAMPS
         if (stamping && o[DT - 1][0] == 12345.678f) seg[0] += 1;
 #endif
@@ -585,6 +633,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
         for (int d = 0; d < DT; ++d)
             *reinterpret_cast<u32x2*>(y + 16 * d) = u32x2{pack_bf16x2(o[d][0] * inv, o[d][1] * inv), pack_bf16x2(o[d][2] * inv, o[d][3] * inv)};
     }
+#ifdef MILA_FLASH_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (stamping && lane == 0) g_flash_stamps[7] = __builtin_amdgcn_s_memtime() - entry_;        // the stamped wave, entry to its last store retired
+#endif
 }
 
 static int g_tune_flash_form = 8;      // tuning hook (mila_cdna4_tune_flash_dsplit): 8 = the LDS-DMA forms (default: 8-wave workgroups at HS = 512, double-buffered; 9 = 8 with 8-wave workgroups at HS = 256 too

@@ -25,4 +25,27 @@ __device__ __forceinline__ int v_off(int row, int chunk)      // ds_read_b64_tr_
     return row * ROWB + ((chunk ^ f) << 4);
 }
 
+// ds_read_b64_tr_b16 as inline assembly, for kernels whose tiles arrive by LDS-DMA.  In front of the INTRINSIC form of this read the compiler places an
+// s_waitcnt vmcnt(0) whenever a global_load_lds is outstanding (it cannot tell that the read's buffer is not the one being filled; plain ds_read_b128 of the same
+// buffers get no such wait) -- in a double-buffered kernel that is a wait for the NEXT tile, issued a few instructions earlier, in front of every tile's V fragments:
+// the prefetch was serialised (round 4: 1 125 of a tile's 3 541 cycles).  The compiler does not count these reads in lgkmcnt: lds_tr_wait() retires them and ties
+// the fragment registers to the wait (a consumer cannot be scheduled above it); the compiler's own waits for its counted reads only become stricter.
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_read_tr16(unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void lds_tr_wait(s16x8 (&v)[N])
+{
+    static_assert(N % 8 == 0, "fragments in groups of eight (the operand limit of one asm statement)");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; i += 8)
+        asm volatile("" : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]), "+v"(v[i + 4]), "+v"(v[i + 5]), "+v"(v[i + 6]), "+v"(v[i + 7]));
+}
+
 }  // namespace mila

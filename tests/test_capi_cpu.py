@@ -157,3 +157,29 @@ def test_the_prefill_gemm_kernels_keep_their_accumulators_in_registers():
     for k, v in default_schedule.items():
         fp8_256 = "gemm256_kernelILi2E" in k or "gemm256_kernelILi3E" in k
         assert v["VGPRs Spill"] <= (24 if fp8_256 else 0), (k, v)
+
+
+def test_the_flash_prefill_forms_with_assembly_lds_reads_do_not_spill():
+    """csrc/attention_prefill.hip reads its V^T fragments with inline-assembly ds_read_b64_tr_b16 (round 4: the intrinsic form makes the compiler wait for the NEXT tile's
+    LDS-DMA in front of every tile's reads).  The compiler does not know that such a register is pending until lds_tr_wait(): if it SPILLED one in between, the scratch store
+    would read the register before the data has landed (seen on the one-wave-per-head HS = 512 form, which therefore keeps the intrinsic).  Every other LDS-DMA form must
+    compile without a single spill -- checked on hipcc's resource-usage remarks, no GPU."""
+    import re
+    import subprocess
+    src = os.path.join(ROOT, "mila_amd", "csrc", "attention_prefill.hip")
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Rpass-analysis=kernel-resource-usage",
+                          "--cuda-device-only", "-c", src, "-o", os.devnull], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900).stdout
+    usage, name = {}, None
+    for line in out.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+        m = re.search(r"(VGPRs Spill|ScratchSize \[bytes/lane\]): (\d+)", line)
+        if m and name:
+            usage[name][m.group(1)] = int(m.group(2))
+    dma = {k: v for k, v in usage.items() if "flash_prefill_kernel_s1ILi" in k}
+    asm_forms = {k: v for k, v in dma.items() if not re.search(r"s1ILi512ELi\dELi1ELi4E", k)}
+    assert len(dma) == 10 and len(asm_forms) == 7, sorted(dma)
+    for k, v in asm_forms.items():
+        assert v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)

@@ -26,5 +26,12 @@ for name, NH, NKV, HS, window in (("local", 16, 8, 256, 1024), ("global", 16, 1,
     assert lib.mila_dbg_flash_stamps(out) == 0
     seg, ntiles, total = list(out[:5]), out[5], out[6]
     names = ["wait + barrier", "staging issue", "QK^T", "softmax", "PV"]
-    print(json.dumps({"shape": name, "tiles": ntiles, "cycles_per_tile": round(total / max(ntiles, 1)),
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        capi.call("attn_prefill_bf16", Y, q, K, V, 1, T, NH, NKV, HS, T, 0, window, 1.0)
+    e1.record()
+    torch.cuda.synchronize()
+    print(json.dumps({"shape": name, "tiles": ntiles, "kernel_us": round(e0.elapsed_time(e1) * 100, 1), "stamped_wave_cycles": out[7], "tile_loop_cycles": total,
+                      "cycles_per_tile": round(total / max(ntiles, 1)),
                       "segments_per_tile": {n: round(c / max(ntiles, 1)) for n, c in zip(names, seg)}}), flush=True)
