@@ -32,9 +32,16 @@
 
 namespace mila {
 
-// the V^T fragments of DT output tiles from the tile image at LDS byte address vimg: compile-time offsets (d >> 3) * 256 and + 16 rows
-template <int ROWB, int BASE, int... I>
-__device__ __forceinline__ void read_vt_frags(const unsigned (&addr)[8], s16x8* va, std::integer_sequence<int, I...>)
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a compile-time constant in the body (assembly offsets, if constexpr)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// the V^T fragments of DT output tiles from the tile image at LDS byte address vimg: compile-time offsets (d >> 3) * 256 and + 16 rows; after(d) runs behind the
+// reads of tile d (the kernels issue the next tile's LDS-DMA requests there, a few reads apart)
+template <int ROWB, int BASE, typename After, int... I>
+__device__ __forceinline__ void read_vt_frags(const unsigned (&addr)[8], s16x8* va, After&& after, std::integer_sequence<int, I...>)
 {
     auto one = [&](auto ic) {
         constexpr int d = decltype(ic)::value;
@@ -42,8 +49,34 @@ __device__ __forceinline__ void read_vt_frags(const unsigned (&addr)[8], s16x8* 
         const s16x4 hi = lds_read_tr16<BASE + (d >> 3) * 256 + 16 * ROWB>(addr[d & 7]);
         va[d][0] = lo[0]; va[d][1] = lo[1]; va[d][2] = lo[2]; va[d][3] = lo[3];
         va[d][4] = hi[0]; va[d][5] = hi[1]; va[d][6] = hi[2]; va[d][7] = hi[3];
+        after(ic);
     };
     (one(std::integral_constant<int, I>{}), ...);
+}
+
+// One tile's online-softmax step on the 8 scores a lane holds of its query row (tv: scores x scale x log2 e, -inf where masked), shared by both kernels so that
+// every form produces the same bits.  Round 4: the log2 domain (exp2 is the hardware's own function: no multiplication in front of each exponential), and the
+// row sum stays PER LANE -- the four lanes of a row rescale their partial sums by the same alpha, so they are added once, in the epilogue, instead of through
+// two cross-lane exchanges per tile.  Returns the bf16 P fragment; alpha = the factor of the accumulators (exactly 1 where the row's maximum did not move).
+__device__ __forceinline__ bf16x8 softmax_tile_step(const float (&tv)[8], float& m_run, float& l_lane, float& alpha)
+{
+    float mt = fmaxf(fmaxf(fmaxf(tv[0], tv[1]), fmaxf(tv[2], tv[3])), fmaxf(fmaxf(tv[4], tv[5]), fmaxf(tv[6], tv[7])));
+    mt = quad_rows_max(mt);                                 // the row's other keys sit on lanes l ^ 16, l ^ 32, l ^ 48
+    const float mn = fmaxf(m_run, mt);
+    const float msafe = (mn == -INFINITY) ? 0.0f : mn;      // row with nothing visible yet
+    alpha = __builtin_amdgcn_exp2f(m_run - msafe);          // m_run = -inf -> 0
+    float pe[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) pe[r] = __builtin_amdgcn_exp2f(tv[r] - msafe);
+    l_lane = l_lane * alpha + (((pe[0] + pe[1]) + (pe[2] + pe[3])) + ((pe[4] + pe[5]) + (pe[6] + pe[7])));
+    m_run = mn;
+    // B operand of O^T += V^T P^T: element j <-> key (j < 4 ? 4 g + j : 16 + 4 g + j - 4)
+    u32x4 pb;
+    pb[0] = pack_bf16x2(pe[0], pe[1]);
+    pb[1] = pack_bf16x2(pe[2], pe[3]);
+    pb[2] = pack_bf16x2(pe[4], pe[5]);
+    pb[3] = pack_bf16x2(pe[6], pe[7]);
+    return __builtin_bit_cast(bf16x8, pb);
 }
 
 struct FlashParams
@@ -111,7 +144,8 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
     f32x4 o[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d) o[d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    float m_run = -INFINITY, l_run = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;                       // running maximum (log2 domain) of the lane's row; the LANE's share of the row sum
+    const float c2 = p.scale * 1.4426950408889634f;              // scores x scale x log2 e: p = exp2(. - m)
 
     // key range needed by the workgroup (union over its rows)
     const int pos_first = p.pos_offset + q0;
@@ -196,38 +230,17 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
             s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb), __builtin_bit_cast(bf16x8, qf[s]), s1, 0, 0, 0);
         }
         // lane holds keys kt + 4 g + r (s0) and kt + 16 + 4 g + r (s1) of query row l15
-        float sv[8];
-        float mt = -INFINITY;
+        float tv[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r)
         {
             const int key = kt + ((r < 4) ? (4 * g + r) : (16 + 4 * g + (r - 4)));
             const float raw = (r < 4) ? s0[r] : s1[r - 4];
             const bool vis = row_valid && key <= my_pos && (p.window == 0 || key > my_pos - p.window);
-            sv[r] = vis ? raw * p.scale : -INFINITY;
-            mt = fmaxf(mt, sv[r]);
+            tv[r] = vis ? raw * c2 : -INFINITY;
         }
-        mt = quad_rows_max(mt);                                 // the row's other keys sit on lanes l ^ 16, l ^ 32, l ^ 48
-        const float mn = fmaxf(m_run, mt);
-        const float msafe = (mn == -INFINITY) ? 0.0f : mn;      // row with nothing visible yet
-        const float alpha = __expf(m_run - msafe);              // m_run = -inf -> 0
-        float pe[8], rs = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-        {
-            pe[r] = __expf(sv[r] - msafe);
-            rs += pe[r];
-        }
-        rs = quad_rows_sum(rs);
-        l_run = l_run * alpha + rs;
-        m_run = mn;
-        // B operand of O^T += V^T P^T: element j <-> key (j < 4 ? 4 g + j : 16 + 4 g + j - 4)
-        u32x4 pb;
-        pb[0] = pack_bf16x2(pe[0], pe[1]);
-        pb[1] = pack_bf16x2(pe[2], pe[3]);
-        pb[2] = pack_bf16x2(pe[4], pe[5]);
-        pb[3] = pack_bf16x2(pe[6], pe[7]);
-        const bf16x8 pfrag = __builtin_bit_cast(bf16x8, pb);
+        float alpha;
+        const bf16x8 pfrag = softmax_tile_step(tv, m_run, l_run, alpha);
         const bool rescale = __any(alpha != 1.0f);
 #pragma unroll
         for (int d = 0; d < DT; ++d)
@@ -265,9 +278,10 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
     }
 
     // ---- epilogue: O^T[dim 16 d + 4 g + r][row l15] -> Y[row][h*HS + dim] ----
+    const float l_row = quad_rows_sum(l_run);                   // the four lanes of a row
     if (row_valid)
     {
-        const float inv = (l_run > 0.0f) ? 1.0f / l_run : 0.0f;
+        const float inv = (l_row > 0.0f) ? 1.0f / l_row : 0.0f;
         uint16_t* y = p.Y + (((size_t)b * p.Tq + my_row) * p.NH + h) * HS + 4 * g;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
@@ -356,7 +370,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
     f32x4 o[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d) o[d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    float m_run = -INFINITY, l_run = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;                       // running maximum (log2 domain) of the lane's row; the LANE's share of the row sum
+    const float c2 = p.scale * 1.4426950408889634f;              // scores x scale x log2 e: p = exp2(. - m)
 
     // key range needed by the workgroup (union over its rows)
     const int pos_first = p.pos_offset + q0;
@@ -448,67 +463,94 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
     auto tile_body = [&](int t, auto buf_c) {
         constexpr int BUF = DB ? decltype(buf_c)::value : 0;
         const int kt = kt0 + t * kKeysPerTile;
+        // what this tile requests for tile t + 1 (uniform): nothing behind the last tile; a whole in-band tile of an unwrapped cache by lane offsets + a scalar
+        // (all but the last one or two tiles of a band); else the general form.  Chosen by a scalar branch around each request: as template forms of the
+        // body the variants' live ranges merge in the one loop and the allocator spills.
+        const bool has_next = DB && t + 1 < ntiles;
+        const bool fast_next = !ring && kt + 2 * kKeysPerTile - 1 <= pos_last;
         unsigned char* ldsK = smem + BUF * 2 * TILE_BYTES;
         unsigned char* ldsV = ldsK + TILE_BYTES;
+        unsigned char* nxt = smem + (BUF ^ 1) * 2 * TILE_BYTES;
+        const int ktn = kt + kKeysPerTile;
+        const int adv = ktn * rstride;                                    // bytes, wave-uniform
+        // Double-buffered forms: request i of tile t + 1's K (V) rows.  Round 4: the requests are issued ONE AT A TIME between the fragment reads of this tile --
+        // K requests among the K fragment reads, V requests among the V^T fragment reads -- instead of all eight in a row behind the K reads: a workgroup's
+        // waves reach this point together, their 32 requests take the CU's address path (64 B / clk) ~ 500 cycles during which every wave stood in the issue
+        // queue with nothing else running (735 of a tile's 2 576 cycles on the stamped wave); spread out, the LDS reads and the requests feed two pipes at once.
+        auto next_k = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (DB && i < DMAS)
+            {
+                __builtin_amdgcn_sched_barrier(0);
+                if (!has_next) {}
+                else if (fast_next)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)(nxt + RPI * (NW * i + wave) * ROWB), 16, (NB == 2 && (i & 1)) ? ks1 : ks0,
+                                                             adv + (i / NB) * 16 * rstride, 0, 0);
+                else
+                {
+                    // (an opaque copy of the lane id: the last tiles' address arithmetic is redone in place -- hoisted out of the loop, its per-request
+                    // invariants cost the registers the fragments need)
+                    int lz = lane;
+                    asm volatile("" : "+v"(lz));
+                    const int row0 = RPI * (NW * i + wave);
+                    const int row = row0 + lz / CPR, slot = lz % CPR, pos = min(ktn + row, pos_last);
+                    const int voff = (ring ? pos % p.capacity : pos) * rstride + (k_off<HS>(row, slot) - row * ROWB);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)(nxt + row0 * ROWB), 16, voff, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto next_v = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (DB && i < DMAS)
+            {
+                if (!has_next) {}
+                else if (fast_next)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)(nxt + TILE_BYTES + RPI * (NW * i + wave) * ROWB), 16, (NB == 2 && (i & 1)) ? vs1 : vs0,
+                                                             adv + (i / NB) * 16 * rstride, 0, 0);
+                else
+                {
+                    int lz = lane;
+                    asm volatile("" : "+v"(lz));
+                    const int row0 = RPI * (NW * i + wave);
+                    const int row = row0 + lz / CPR, slot = lz % CPR, pos = min(ktn + row, pos_last);
+                    const int voff = (ring ? pos % p.capacity : pos) * rstride + (v_off<HS>(row, slot) - row * ROWB);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)(nxt + TILE_BYTES + row0 * ROWB), 16, voff, 0, 0, 0);
+                }
+            }
+        };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows of tile t (NW = 4: its K rows; nothing else is in flight here)
         __syncthreads();
         FLASH_STAMP(0);
 
-        // ---- S^T = K Q^T : two 16-key groups; the fragments of KB k-steps are requested together, then multiplied.  The next tile's staging is issued
-        // between the first requests and their use: its address arithmetic runs under the LDS latency ----
+        // ---- S^T = K Q^T : two 16-key groups; the fragments of KB k-steps are requested together, then multiplied ----
         f32x4 s0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0;
         constexpr int KB = (HS >= 512) ? 4 : 8;                  // k-steps whose fragments are fetched together (registers: HS = 512 holds 64 of Q)
-#pragma unroll
-        for (int s8 = 0; s8 < KSTEPS; s8 += KB)
-        {
+        constexpr int KPER = KSTEPS / DMAS;                      // one K request behind every KPER k-steps of fragment reads
+        static_assert(KSTEPS % DMAS == 0 && DT % DMAS == 0, "requests spread evenly over the fragment reads");
+        auto k_group = [&](auto s8c) {
+            constexpr int s8 = decltype(s8c)::value;
             s16x8 ka[KB], kb[KB];
-#pragma unroll
-            for (int j = 0; j < KB; ++j)
-            {
+            auto rd = [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
                 // A operand: K[key l15 (+16)][32 s + 8 g .. +7] -> chunk 4 s + g
-                const int s_ = s8 + j;
+                constexpr int s_ = s8 + j;
                 ka[j] = *reinterpret_cast<const s16x8*>(ldsK + kaddr[s_ & 3] + (s_ >> 2) * 256);
                 kb[j] = *reinterpret_cast<const s16x8*>(ldsK + kaddr[s_ & 3] + (s_ >> 2) * 256 + 16 * ROWB);
-            }
+                if constexpr ((s_ + 1) % KPER == 0) next_k(std::integral_constant<int, (s_ + 1) / KPER - 1>{});
+            };
+            static_for<KB>(rd);
             __builtin_amdgcn_sched_barrier(0);
-            if (s8 == 0)
-            {
-                if constexpr (DB)
-                {
-                    if (t + 1 < ntiles)
-                    {
-                        unsigned char* nxt = smem + (BUF ^ 1) * 2 * TILE_BYTES;
-                        const int ktn = kt + kKeysPerTile;
-                        if (!ring && ktn + kKeysPerTile - 1 <= pos_last)
-                        {
-                            const int adv = ktn * rstride;                                    // bytes, wave-uniform
-#pragma unroll
-                            for (int i = 0; i < DMAS; ++i)
-                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)(nxt + RPI * (NW * i + wave) * ROWB), 16, (NB == 2 && (i & 1)) ? ks1 : ks0,
-                                                                         adv + (i / NB) * 16 * rstride, 0, 0);
-#pragma unroll
-                            for (int i = 0; i < DMAS; ++i)
-                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)(nxt + TILE_BYTES + RPI * (NW * i + wave) * ROWB), 16, (NB == 2 && (i & 1)) ? vs1 : vs0,
-                                                                         adv + (i / NB) * 16 * rstride, 0, 0);
-                        }
-                        else
-                        {
-                            stage_k(ktn, nxt);
-                            stage_v(ktn, nxt + TILE_BYTES);
-                        }
-                    }
-                }
-                else stage_v(kt, ldsV);
-                FLASH_STAMP(1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            if constexpr (!DB && s8 == 0) { stage_v(kt, ldsV); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (s8 == 0) FLASH_STAMP(1);
 #pragma unroll
             for (int j = 0; j < KB; ++j)
             {
                 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s1, 0, 0, 0);
             }
-        }
+        };
+        static_for<KSTEPS / KB>([&](auto gc) { k_group(std::integral_constant<int, decltype(gc)::value * KB>{}); });
         if constexpr (!DB)
         {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's V rows of tile t
@@ -536,14 +578,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
         {
             constexpr int VOFF = BUF * 2 * TILE_BYTES + TILE_BYTES;           // this buffer's V image
             constexpr int SPAN = ((DT - 1) >> 3) * 256 + 16 * ROWB;
+            constexpr int DPER = DT / DMAS;                                   // one V request behind every DPER d tiles of fragment reads
+            auto after = [&](auto dc) {
+                constexpr int d = decltype(dc)::value;
+                if constexpr ((d + 1) % DPER == 0) next_v(std::integral_constant<int, (d + 1) / DPER - 1>{});
+            };
             if constexpr (VOFF + SPAN < 65536)
-                read_vt_frags<ROWB, VOFF>(vaddr_lds, va, std::make_integer_sequence<int, DT>{});
+                read_vt_frags<ROWB, VOFF>(vaddr_lds, va, after, std::make_integer_sequence<int, DT>{});
             else
             {
                 unsigned vb[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) vb[i] = vaddr_lds[i] + VOFF;
-                read_vt_frags<ROWB, 0>(vb, va, std::make_integer_sequence<int, DT>{});
+                read_vt_frags<ROWB, 0>(vb, va, after, std::make_integer_sequence<int, DT>{});
             }
         }
 #ifdef MILA_FLASH_STAMPS
@@ -551,13 +598,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
 #endif
         FLASH_STAMP(2);
         // lane holds keys kt + 4 g + r (s0) and kt + 16 + 4 g + r (s1) of query row l15
-        float sv[8];
+        float tv[8];
         // a tile every row of this wave sees whole (the interior of the band: most tiles) needs no mask
         const bool whole = rows_ok && kt + kKeysPerTile - 1 <= wpos0 && (p.window == 0 || kt > wpos0 + 15 - p.window);
         if (whole)
         {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) sv[r] = ((r < 4) ? s0[r] : s1[r - 4]) * p.scale;
+            for (int r = 0; r < 8; ++r) tv[r] = ((r < 4) ? s0[r] : s1[r - 4]) * c2;
         }
         else
         {
@@ -567,31 +614,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
                 const int key = kt + ((r < 4) ? (4 * g + r) : (16 + 4 * g + (r - 4)));
                 const float raw = (r < 4) ? s0[r] : s1[r - 4];
                 const bool vis = row_valid && key <= my_pos && (p.window == 0 || key > my_pos - p.window);
-                sv[r] = vis ? raw * p.scale : -INFINITY;
+                tv[r] = vis ? raw * c2 : -INFINITY;
             }
         }
-        float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-        mt = quad_rows_max(mt);                                 // the row's other keys sit on lanes l ^ 16, l ^ 32, l ^ 48
-        const float mn = fmaxf(m_run, mt);
-        const float msafe = (mn == -INFINITY) ? 0.0f : mn;      // row with nothing visible yet
-        const float alpha = __expf(m_run - msafe);              // m_run = -inf -> 0
-        float pe[8], rs = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-        {
-            pe[r] = __expf(sv[r] - msafe);
-            rs += pe[r];
-        }
-        rs = quad_rows_sum(rs);
-        l_run = l_run * alpha + rs;
-        m_run = mn;
-        // B operand of O^T += V^T P^T: element j <-> key (j < 4 ? 4 g + j : 16 + 4 g + j - 4)
-        u32x4 pb;
-        pb[0] = pack_bf16x2(pe[0], pe[1]);
-        pb[1] = pack_bf16x2(pe[2], pe[3]);
-        pb[2] = pack_bf16x2(pe[4], pe[5]);
-        pb[3] = pack_bf16x2(pe[6], pe[7]);
-        const bf16x8 pfrag = __builtin_bit_cast(bf16x8, pb);
+        float alpha;
+        const bf16x8 pfrag = softmax_tile_step(tv, m_run, l_run, alpha);
         // the running maximum of a row moves in its first tiles and then rarely: the accumulators are rescaled only in a tile where some row's did
         // (a real branch: alpha is exactly 1 everywhere otherwise, so skipping the multiplications changes no bit)
         if (__any(alpha != 1.0f))
@@ -625,9 +652,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
 #endif
 
     // ---- epilogue: O^T[dim 16 d + 4 g + r][row l15] -> Y[row][h*HS + dim] ----
+    const float l_row = quad_rows_sum(l_run);                   // the four lanes of a row
     if (row_valid)
     {
-        const float inv = (l_run > 0.0f) ? 1.0f / l_run : 0.0f;
+        const float inv = (l_row > 0.0f) ? 1.0f / l_row : 0.0f;
         uint16_t* y = p.Y + (((size_t)b * p.Tq + my_row) * p.NH + h) * HS + 16 * dsel * DT + 4 * g;
 #pragma unroll
         for (int d = 0; d < DT; ++d)

@@ -17,11 +17,20 @@ __device__ __forceinline__ int k_off(int row, int chunk)      // ds_read_b128 of
     const int x = (NCH >= 16) ? (row & 15) : ((row >> 1) & (NCH - 1));
     return row * ROWB + (((chunk & ~(NCH >= 16 ? 15 : NCH - 1)) | ((chunk ^ x) & (NCH >= 16 ? 15 : NCH - 1))) << 4);
 }
+// V image: ds_read_b64_tr_b16 blocks of 4 rows x 16 columns.  A transposing read is served in two halves of 32 lanes, each lane 8 bytes = one bank PAIR of the 32
+// pairs: lane (g, q4 = row & 3 within its 4-row block, pp) of a half reads row 4 g + q4, columns 16 d + 4 pp .., i.e. pair index
+//     [ (row pitch in dwords) row  mod 64 ] / 2  +  2 ((chunk ^ f) & 15) + (pp & 1),      chunk = 2 d + (pp >> 1).
+// pp supplies the two low bits; the other three must come from q4 (2 bits) and the half's one bit of g = (row >> 2) & 1.  Round 4: f = q4 << 2 | g's bit << 1.
+// (Rounds 1-3 put g into bit 0, where pp >> 1 already sits: lanes (pp >> 1, g) = (0, 0) and (1, 1) met on one pair -- every transposing read 2-way conflicted,
+// SQ_LDS_BANK_CONFLICT = a third of the flash prefill's LDS cycles, profiles/r04_flash_prefill.txt.)  A 128-byte row (HS = 64) contributes row & 1 to bit 4 itself:
+// f = (q4 >> 1) << 2 | g's bit << 1 there.
 template <int HS>
-__device__ __forceinline__ int v_off(int row, int chunk)      // ds_read_b64_tr_b16 blocks of 4 rows x 16 cols
+__device__ __forceinline__ int v_off(int row, int chunk)
 {
     constexpr int ROWB = HS * 2, NCH = ROWB / 16;
-    const int f = (((row & 3) << 2) | ((row >> 2) & 3)) & (NCH >= 16 ? 15 : NCH - 1);
+    static_assert(NCH >= 8, "head sizes from 64");
+    const int gbit = ((row >> 2) & 1) << 1;
+    const int f = (NCH >= 16) ? (((row & 3) << 2) | gbit) : ((((row >> 1) & 1) << 2) | gbit);
     return row * ROWB + ((chunk ^ f) << 4);
 }
 
