@@ -58,11 +58,21 @@ __device__ __forceinline__ void read_vt_frags(const unsigned (&addr)[8], s16x8* 
 // every form produces the same bits.  Round 4: the log2 domain (exp2 is the hardware's own function: no multiplication in front of each exponential), and the
 // row sum stays PER LANE -- the four lanes of a row rescale their partial sums by the same alpha, so they are added once, in the epilogue, instead of through
 // two cross-lane exchanges per tile.  Returns the bf16 P fragment; alpha = the factor of the accumulators (exactly 1 where the row's maximum did not move).
+// (maxima as the bare instructions: fmaxf() quiets a possible signalling NaN with a v_max x, x in front of every operand that is not known to come from
+// arithmetic -- 11 instructions for the maximum of 8 values and 4 more around the lane exchanges, where 4 + 3 do; a wave issues one instruction per 4 cycles)
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ bf16x8 softmax_tile_step(const float (&tv)[8], float& m_run, float& l_lane, float& alpha)
 {
-    float mt = fmaxf(fmaxf(fmaxf(tv[0], tv[1]), fmaxf(tv[2], tv[3])), fmaxf(fmaxf(tv[4], tv[5]), fmaxf(tv[6], tv[7])));
-    mt = quad_rows_max(mt);                                 // the row's other keys sit on lanes l ^ 16, l ^ 32, l ^ 48
-    const float mn = fmaxf(m_run, mt);
+    float mt = vmax2(vmax3(vmax3(vmax3(tv[0], tv[1], tv[2]), tv[3], tv[4]), tv[5], tv[6]), tv[7]);
+    {
+        // the row's other keys sit on lanes l ^ 16, l ^ 32, l ^ 48
+        const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+        mt = vmax2(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+        const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+        mt = vmax2(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+    }
+    const float mn = vmax2(m_run, mt);
     const float msafe = (mn == -INFINITY) ? 0.0f : mn;      // row with nothing visible yet
     alpha = __builtin_amdgcn_exp2f(m_run - msafe);          // m_run = -inf -> 0
     float pe[8];
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
 // Diagnostic build only (-DMILA_FLASH_STAMPS, never the product library): wave 0 of workgroup 0 of flash_prefill_kernel_s1 accumulates the shader cycles of each
 // segment of its tile loop (wait + barrier | staging issue | QK^T | softmax | PV) into g_flash_stamps; read back with mila_dbg_flash_stamps().
 #ifdef MILA_FLASH_STAMPS
-__device__ unsigned long long g_flash_stamps[8];
+__device__ unsigned long long g_flash_stamps[16];
 #define FLASH_STAMP(i) do { if (stamping) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); seg[i] += now_ - last_; last_ = now_; } } while (0)
 #else
 #define FLASH_STAMP(i) do { } while (0)
@@ -413,8 +423,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
 #pragma unroll
         for (int i = 0; i < DMAS; ++i)
         {
+            // (an opaque copy of the lane id: this address arithmetic -- first tile, the last tiles of a band -- is redone in place; hoisted out of the tile
+            // loops, its per-request invariants cost the registers the fragments need)
+            int lz = lane;
+            asm volatile("" : "+v"(lz));
             const int row0 = RPI * (NW * i + wave);                       // the instruction's first row: RPI consecutive rows = 1 KiB of LDS
-            const int row = row0 + lane / CPR, slot = lane % CPR, pos = min(kt + row, pos_last);
+            const int row = row0 + lz / CPR, slot = lz % CPR, pos = min(kt + row, pos_last);
             const int voff = (ring ? pos % p.capacity : pos) * rstride + (k_off<HS>(row, slot) - row * ROWB);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)(ldsK + row0 * ROWB), 16, voff, 0, 0, 0);
         }
@@ -423,8 +437,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
 #pragma unroll
         for (int i = 0; i < DMAS; ++i)
         {
+            int lz = lane;
+            asm volatile("" : "+v"(lz));
             const int row0 = RPI * (NW * i + wave);
-            const int row = row0 + lane / CPR, slot = lane % CPR, pos = min(kt + row, pos_last);
+            const int row = row0 + lz / CPR, slot = lz % CPR, pos = min(kt + row, pos_last);
             const int voff = (ring ? pos % p.capacity : pos) * rstride + (v_off<HS>(row, slot) - row * ROWB);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)(ldsV + row0 * ROWB), 16, voff, 0, 0, 0);
         }
@@ -441,11 +457,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
         vaddr[i] = v_off<HS>(4 * g + (l15 >> 2), col >> 3) + ((col & 7) << 1);
     }
     unsigned vaddr_lds[8];                                      // the same as LDS byte addresses (the assembly reads take addresses, not pointers)
-    {
-        const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned smem_lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) vaddr_lds[i] = smem_lds + (unsigned)vaddr[i];
-    }
+    for (int i = 0; i < 8; ++i) vaddr_lds[i] = smem_lds0 + (unsigned)vaddr[i];
     const int wpos0 = p.pos_offset + wq0;                        // position of this wave's first row (uniform)
     const bool rows_ok = wq0 + 16 <= p.Tq;
 
@@ -460,36 +474,41 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
     unsigned long long seg[5] = {0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
     const unsigned long long first_ = last_;
 #endif
-    auto tile_body = [&](int t, auto buf_c) {
-        constexpr int BUF = DB ? decltype(buf_c)::value : 0;
+    // MODE 0 (double-buffered forms, main loop): the buffer is a template constant and the tile requests a WHOLE in-band successor of an unwrapped cache -- no
+    //        branch, no address arithmetic: scalar tile offset + the lane's fixed offsets, one request at a time between the fragment reads.  (Round 4: the
+    //        per-request choice of form cost ~ 56 of a tile's 74 scalar instructions -- a wave issues one instruction per four cycles, whatever its kind.)
+    // MODE 1 (double-buffered forms, the last two or three tiles of a band, every tile of a wrapped ring): buffer by the tile's parity at run time; the
+    //        successor, if any, is requested in the general form (per-row clamp / modulo) at the top of the tile.
+    // MODE 2: the single-buffered forms (two barriers per tile).
+    auto tile_body = [&](int t, auto buf_c, auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+        constexpr int BUF = (MODE == 0 || MODE == 3) ? decltype(buf_c)::value : 0;
         const int kt = kt0 + t * kKeysPerTile;
-        // what this tile requests for tile t + 1 (uniform): nothing behind the last tile; a whole in-band tile of an unwrapped cache by lane offsets + a scalar
-        // (all but the last one or two tiles of a band); else the general form.  Chosen by a scalar branch around each request: as template forms of the
-        // body the variants' live ranges merge in the one loop and the allocator spills.
-        const bool has_next = DB && t + 1 < ntiles;
-        const bool fast_next = !ring && kt + 2 * kKeysPerTile - 1 <= pos_last;
-        unsigned char* ldsK = smem + BUF * 2 * TILE_BYTES;
+        const int rbuf = (MODE == 1) ? (t & 1) * 2 * TILE_BYTES : BUF * 2 * TILE_BYTES;      // this tile's [K | V] pair
+        unsigned char* ldsK = smem + rbuf;
         unsigned char* ldsV = ldsK + TILE_BYTES;
-        unsigned char* nxt = smem + (BUF ^ 1) * 2 * TILE_BYTES;
+        unsigned char* nxt = smem + ((MODE == 1) ? 2 * TILE_BYTES - rbuf : (BUF ^ 1) * 2 * TILE_BYTES);
         const int ktn = kt + kKeysPerTile;
         const int adv = ktn * rstride;                                    // bytes, wave-uniform
-        // Double-buffered forms: request i of tile t + 1's K (V) rows.  Round 4: the requests are issued ONE AT A TIME between the fragment reads of this tile --
-        // K requests among the K fragment reads, V requests among the V^T fragment reads -- instead of all eight in a row behind the K reads: a workgroup's
-        // waves reach this point together, their 32 requests take the CU's address path (64 B / clk) ~ 500 cycles during which every wave stood in the issue
-        // queue with nothing else running (735 of a tile's 2 576 cycles on the stamped wave); spread out, the LDS reads and the requests feed two pipes at once.
+        // MODE 0: request i of tile t + 1's K (V) rows, issued ONE AT A TIME between the fragment reads of this tile -- K requests among the K fragment reads, V
+        // requests among the V^T fragment reads -- instead of all eight in a row behind the K reads: a workgroup's waves reach this point together, their 32
+        // requests take the CU's address path (64 B / clk) ~ 500 cycles during which every wave stood in the issue queue with nothing else running; spread out,
+        // the LDS reads and the requests feed two pipes at once.
+        // MODE 3 (HS = 512, whose registers do not hold a second kind of body next to the main loop's): one loop over all tiles, the request form chosen by
+        // scalar branches around each request
+        const bool has_next = t + 1 < ntiles;
+        const bool fast_next = !ring && kt + 2 * kKeysPerTile - 1 <= pos_last;
         auto next_k = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if constexpr (DB && i < DMAS)
+            if constexpr ((MODE == 0 || MODE == 3) && i < DMAS)
             {
                 __builtin_amdgcn_sched_barrier(0);
-                if (!has_next) {}
-                else if (fast_next)
+                if (MODE == 3 && !has_next) {}
+                else if (MODE == 0 || fast_next)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)(nxt + RPI * (NW * i + wave) * ROWB), 16, (NB == 2 && (i & 1)) ? ks1 : ks0,
                                                              adv + (i / NB) * 16 * rstride, 0, 0);
                 else
                 {
-                    // (an opaque copy of the lane id: the last tiles' address arithmetic is redone in place -- hoisted out of the loop, its per-request
-                    // invariants cost the registers the fragments need)
                     int lz = lane;
                     asm volatile("" : "+v"(lz));
                     const int row0 = RPI * (NW * i + wave);
@@ -502,10 +521,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
         };
         auto next_v = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if constexpr (DB && i < DMAS)
+            if constexpr ((MODE == 0 || MODE == 3) && i < DMAS)
             {
-                if (!has_next) {}
-                else if (fast_next)
+                if (MODE == 3 && !has_next) {}
+                else if (MODE == 0 || fast_next)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)(nxt + TILE_BYTES + RPI * (NW * i + wave) * ROWB), 16, (NB == 2 && (i & 1)) ? vs1 : vs0,
                                                              adv + (i / NB) * 16 * rstride, 0, 0);
                 else
@@ -522,6 +541,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows of tile t (NW = 4: its K rows; nothing else is in flight here)
         __syncthreads();
         FLASH_STAMP(0);
+        if constexpr (MODE == 1)
+        {
+            if (t + 1 < ntiles) { stage_k(ktn, nxt); stage_v(ktn, nxt + TILE_BYTES); }
+        }
 
         // ---- S^T = K Q^T : two 16-key groups; the fragments of KB k-steps are requested together, then multiplied ----
         f32x4 s0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0;
@@ -541,7 +564,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
             };
             static_for<KB>(rd);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!DB && s8 == 0) { stage_v(kt, ldsV); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (MODE == 2 && s8 == 0) { stage_v(kt, ldsV); __builtin_amdgcn_sched_barrier(0); }
             if constexpr (s8 == 0) FLASH_STAMP(1);
 #pragma unroll
             for (int j = 0; j < KB; ++j)
@@ -551,7 +574,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
             }
         };
         static_for<KSTEPS / KB>([&](auto gc) { k_group(std::integral_constant<int, decltype(gc)::value * KB>{}); });
-        if constexpr (!DB)
+        if constexpr (MODE == 2)
         {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's V rows of tile t
             __syncthreads();                                     // every wave is done with K(t), and V(t) is complete
@@ -583,13 +606,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
                 constexpr int d = decltype(dc)::value;
                 if constexpr ((d + 1) % DPER == 0) next_v(std::integral_constant<int, (d + 1) / DPER - 1>{});
             };
-            if constexpr (VOFF + SPAN < 65536)
+            if constexpr (MODE != 1 && VOFF + SPAN < 65536)
                 read_vt_frags<ROWB, VOFF>(vaddr_lds, va, after, std::make_integer_sequence<int, DT>{});
             else
             {
                 unsigned vb[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) vb[i] = vaddr_lds[i] + VOFF;
+                for (int i = 0; i < 8; ++i) vb[i] = vaddr_lds[i] + (unsigned)(rbuf + TILE_BYTES);
                 read_vt_frags<ROWB, 0>(vb, va, after, std::make_integer_sequence<int, DT>{});
             }
         }
@@ -637,10 +660,29 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
 #endif
         FLASH_STAMP(4);
     };
-    for (int t = 0; t < ntiles; t += 2)
+    if constexpr (DB && HS >= 512)
     {
-        tile_body(t, std::integral_constant<int, 0>{});
-        if (t + 1 < ntiles) tile_body(t + 1, std::integral_constant<int, 1>{});
+        for (int t = 0; t < ntiles; t += 2)
+        {
+            tile_body(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+            if (t + 1 < ntiles) tile_body(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{});
+        }
+    }
+    else if constexpr (DB)
+    {
+        // every tile but the last one of a band is whole and in band; pairs whose requested successors (t + 1, t + 2) are such tiles run in the lean loop
+        int t = 0;
+        if (!ring)
+            for (; t + 4 <= ntiles; t += 2)
+            {
+                tile_body(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                tile_body(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+            }
+        for (; t < ntiles; ++t) tile_body(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    }
+    else
+    {
+        for (int t = 0; t < ntiles; ++t) tile_body(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
     }
 #ifdef MILA_FLASH_STAMPS
     if (stamping && lane == 0)
@@ -665,6 +707,304 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (stamping && lane == 0) g_flash_stamps[7] = __builtin_amdgcn_s_memtime() - entry_;        // the stamped wave, entry to its last store retired
 #endif
+}
+
+// PING-PONG form (round 4): one 8-wave workgroup per CU whose two wave groups (waves 0-3 / 4-7: the two waves of every SIMD) run HALF A TILE APART.
+//   phase A(t): K fragments of tile t (ds_read_b128) -> S^T = K Q^T on the matrix cores
+//   phase B(t): V^T fragments of tile t (transposing reads, requested first) -> softmax step on the vector ALU -> O^T += V^T P^T
+//   slot 2t    : group 0 runs A(t),  group 1 runs B(t - 1)        slot 2t + 1 : group 0 runs B(t),  group 1 runs A(t)        one s_barrier between slots
+// In the lockstep forms all waves of a workgroup read their fragments together (an LDS burst with idle matrix cores), multiply together, and run the softmax's
+// dependent vector chain together (idle matrix cores again); two independent workgroups per CU only overlap by accident, and the kernel's time was the time of
+// its heaviest workgroup, one wave per SIMD, 2 600 cycles per tile for 512 cycles of matrix work (SQ counters: 31 % of the wave cycles parked at a barrier or a
+// waitcnt, 30 % issue stalls).  Here every SIMD always has one wave in a matrix phase while its partner reads, exponentiates or waits for LDS, and BOTH waves
+// of a SIMD work on the heaviest item.  The same instructions per output element as the lockstep forms: identical bits.
+// Tiles are double-buffered ([K | V] x 2); all eight waves share the request work: K(t + 1) is requested during slot 2t, V(t + 1) during slot 2t + 1,
+// `s_waitcnt vmcnt(requests of the newest batch)` + the barrier at the end of a slot retire the batch before it.
+//   WAR: K(t + 1) overwrites K(t - 1), last read in slot 2t - 1 (group 1's A(t - 1));  V(t + 1) overwrites V(t - 1), last read in slot 2t (group 1's B(t - 1)).
+//   RAW: K(t + 1) is first read in slot 2t + 2, V(t + 1) in slot 2t + 3: each batch has a whole slot in flight behind the one that requests it.
+// Workgroup = HB heads x DS d-shares x QB = 8 / (HB DS) blocks of 16 query rows: HS 256: 2 heads x 4 row blocks (group 1 owns the later rows);
+// HS 512: 4 heads x 2 d-halves x 1 row block (group 1 owns the upper half of the output dimensions).
+template <int HS, int HB, int DS>
+__global__ __launch_bounds__(512, 1) void flash_prefill_pp_kernel(const FlashParams p)
+{
+    constexpr int NW = 8;
+    constexpr int QB = NW / (HB * DS);
+    static_assert((HB * DS) % 4 == 0 || (HB * DS) == 2, "a wave group holds whole (head, d-share) sets or whole row blocks");
+    constexpr int QROWS = 16 * QB;
+    constexpr int KSTEPS = HS / 32, DT = HS / 16 / DS, ROWB = HS * 2, TILE_BYTES = kKeysPerTile * ROWB;
+    constexpr int RPI = 1024 / ROWB, CPR = ROWB / 16, DMAS = kKeysPerTile / NW / RPI;
+    static_assert(RPI == 1 || RPI == 2, "HS = 512 or 256");
+    constexpr int STEP = RPI * NW, NB = 16 / STEP;
+    static_assert(NB == 1 || NB == 2, "whole 16-row groups per one or two requests");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x [K tile | V tile]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                                 // waves w and w + 4 share a SIMD
+    const int l15 = lane & 15, g = lane >> 4;
+    const int GS = p.NH / p.NKV;
+    const int item = blockIdx.x;                               // heavy -> light: the dispatcher hands the next item to the CU that frees up first
+    const int qt = p.n_qtiles - 1 - item / p.n_hblk;
+    const int hblk = item % p.n_hblk, b = blockIdx.z;
+    const int h = hblk * HB + (wave % HB);
+    const int dsel = (wave / HB) % DS;
+    const int kvh = (hblk * HB) / GS;
+    const int q0 = qt * QROWS;
+    const int wq0 = q0 + 16 * (wave / (HB * DS));
+    const int my_row = wq0 + l15;
+    const bool row_valid = my_row < p.Tq;
+    const int my_pos = p.pos_offset + (row_valid ? my_row : p.Tq - 1);
+
+    s16x8 qf[KSTEPS];
+    {
+        const uint16_t* qp = p.Q + ((size_t)b * p.Tq + (row_valid ? my_row : 0)) * p.q_row_stride + (size_t)h * HS + 8 * g;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+        {
+            const u32x4 v = row_valid ? ld16(qp + 32 * s) : u32x4{0u, 0u, 0u, 0u};
+            qf[s] = __builtin_bit_cast(s16x8, v);
+        }
+    }
+    f32x4 o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) o[d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float c2 = p.scale * 1.4426950408889634f;
+
+    const int pos_first = p.pos_offset + q0;
+    const int pos_last = p.pos_offset + min(q0 + QROWS, p.Tq) - 1;
+    const int kmin = (p.window > 0) ? max(0, pos_first - p.window + 1) : 0;
+    const int kt0 = kmin & ~(kKeysPerTile - 1);
+    const int ntiles = (pos_last - kt0) / kKeysPerTile + 1;
+    const uint16_t* kbase = p.K + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride;
+    const uint16_t* vbase = p.V + (size_t)b * p.kv_b_stride + (size_t)kvh * p.kv_h_stride;
+    const bool ring = pos_last >= p.capacity;
+
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const auto rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(kbase), 0, 0x7fffffff, 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(vbase), 0, 0x7fffffff, 0x00020000);
+    const int rstride = (int)(p.kv_r_stride * 2);
+    int ks0, ks1, vs0, vs1;                                    // lane offsets of a request's rows inside a 16-row group (see flash_prefill_kernel_s1)
+    {
+        const int slot = lane % CPR;
+        const int r0 = RPI * wave + lane / CPR, r1 = r0 + STEP;
+        ks0 = r0 * rstride + (k_off<HS>(r0, slot) - r0 * ROWB);
+        vs0 = r0 * rstride + (v_off<HS>(r0, slot) - r0 * ROWB);
+        ks1 = r1 * rstride + (k_off<HS>(r1 & 15, slot) - (r1 & 15) * ROWB);
+        vs1 = r1 * rstride + (v_off<HS>(r1 & 15, slot) - (r1 & 15) * ROWB);
+    }
+    // request i (0 .. DMAS - 1) of this wave's share of tile tn's K (V) rows into buffer tn & 1; nothing behind the last tile
+    auto request = [&](auto isk, auto ic, int tn) {
+        constexpr bool ISK = decltype(isk)::value;
+        constexpr int i = decltype(ic)::value;
+        if (tn >= ntiles) return;
+        const int ktn = kt0 + tn * kKeysPerTile;
+        unsigned char* img = smem + (tn & 1) * 2 * TILE_BYTES + (ISK ? 0 : TILE_BYTES);
+        const int row0 = RPI * (NW * i + wave);
+        if (!ring && ktn + kKeysPerTile - 1 <= pos_last)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ISK ? rsK : rsV, (lds_ptr_t)(img + row0 * ROWB), 16,
+                                                     ISK ? ((NB == 2 && (i & 1)) ? ks1 : ks0) : ((NB == 2 && (i & 1)) ? vs1 : vs0),
+                                                     (ktn + (i / NB) * 16) * rstride, 0, 0);
+        else
+        {
+            int lz = lane;
+            asm volatile("" : "+v"(lz));                       // (the last tiles' address arithmetic stays in place, see flash_prefill_kernel_s1)
+            const int row = row0 + lz / CPR, slot = lz % CPR, pos = min(ktn + row, pos_last);
+            const int voff = (ring ? pos % p.capacity : pos) * rstride + ((ISK ? k_off<HS>(row, slot) : v_off<HS>(row, slot)) - row * ROWB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ISK ? rsK : rsV, (lds_ptr_t)(img + row0 * ROWB), 16, voff, 0, 0, 0);
+        }
+    };
+    int kaddr[4];
+    unsigned vaddr_lds[8];
+    {
+        const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kaddr[i] = k_off<HS>(l15, 4 * i + g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+        {
+            const int col = 16 * (dsel * DT + i) + 4 * (l15 & 3);
+            vaddr_lds[i] = smem_lds + (unsigned)(v_off<HS>(4 * g + (l15 >> 2), col >> 3) + ((col & 7) << 1));
+        }
+    }
+    const int wpos0 = p.pos_offset + wq0;
+    const bool rows_ok = wq0 + 16 <= p.Tq;
+
+#ifdef MILA_FLASH_STAMPS
+    const bool stamping = blockIdx.x == 0 && (wave & 3) == 0;    // wave 0 (group 0) and wave 4 (group 1) of the heaviest item: [A body, A slot end, B body, B slot end]
+    unsigned long long seg[5] = {0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#endif
+    f32x4 s0, s1;                                              // S^T of the tile between its phase A and its phase B
+    s16x8 va[DT];                                              // ... and its V^T fragments: requested at the end of phase A, they land across the barrier
+    // ---- phase A(t): S^T = K Q^T, then the V^T fragment reads; requests of tile tn (REQ) issued between the fragment reads ----
+    auto phase_a = [&](int t, auto buf_c, auto req_c, int tn) {
+        constexpr int BUF = decltype(buf_c)::value;
+        constexpr bool REQ = decltype(req_c)::value;
+        unsigned char* ldsK = smem + BUF * 2 * TILE_BYTES;
+        s0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; s1 = s0;
+        constexpr int KB = (HS >= 512) ? 4 : 8;
+        constexpr int KPER = KSTEPS / DMAS;
+        static_for<KSTEPS / KB>([&](auto gc) {
+            constexpr int s8 = decltype(gc)::value * KB;
+            s16x8 ka[KB], kb[KB];
+            static_for<KB>([&](auto jc) {
+                constexpr int s_ = s8 + decltype(jc)::value;
+                ka[s_ - s8] = *reinterpret_cast<const s16x8*>(ldsK + kaddr[s_ & 3] + (s_ >> 2) * 256);
+                kb[s_ - s8] = *reinterpret_cast<const s16x8*>(ldsK + kaddr[s_ & 3] + (s_ >> 2) * 256 + 16 * ROWB);
+                if constexpr (REQ && (s_ + 1) % KPER == 0)
+                {
+                    __builtin_amdgcn_sched_barrier(0);
+                    request(std::true_type{}, std::integral_constant<int, (s_ + 1) / KPER - 1>{}, tn);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+            {
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s1, 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        });
+        {
+            constexpr int VOFF = BUF * 2 * TILE_BYTES + TILE_BYTES;
+            constexpr int SPAN = ((DT - 1) >> 3) * 256 + 16 * ROWB;
+            constexpr int DPER = DT / DMAS;
+            auto after = [&](auto dc) {
+                constexpr int d = decltype(dc)::value;
+                if constexpr (REQ && (d + 1) % DPER == 0) request(std::false_type{}, std::integral_constant<int, (d + 1) / DPER - 1>{}, tn);
+            };
+            if constexpr (VOFF + SPAN < 65536)
+                read_vt_frags<ROWB, VOFF>(vaddr_lds, va, after, std::make_integer_sequence<int, DT>{});
+            else
+            {
+                unsigned vb[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vb[i] = vaddr_lds[i] + VOFF;
+                read_vt_frags<ROWB, 0>(vb, va, after, std::make_integer_sequence<int, DT>{});
+            }
+        }
+        // the fragments are in registers before the barrier: the next slot's requests overwrite this V image's partner, and the slot after it this one
+        lds_tr_wait(va);
+#ifdef MILA_FLASH_STAMPS
+        if (stamping && s0[0] == 12345.678f && s1[0] == 12345.678f) seg[4] += 1;          // the stamp waits for the products
+#endif
+    };
+    // ---- phase B(t): the softmax step, then O^T += V^T P^T; group 1 issues its share of tile tn's requests here (REQ) ----
+    auto phase_b = [&](int t, auto req_c, int tn) {
+        constexpr bool REQ = decltype(req_c)::value;
+        const int kt = kt0 + t * kKeysPerTile;
+        if constexpr (REQ)
+        {
+            static_for<DMAS>([&](auto ic) { request(std::true_type{}, ic, tn); });
+            static_for<DMAS>([&](auto ic) { request(std::false_type{}, ic, tn); });
+        }
+        float tv[8];
+        const bool whole = rows_ok && kt + kKeysPerTile - 1 <= wpos0 && (p.window == 0 || kt > wpos0 + 15 - p.window);
+        if (whole)
+        {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) tv[r] = ((r < 4) ? s0[r] : s1[r - 4]) * c2;
+        }
+        else
+        {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+            {
+                const int key = kt + ((r < 4) ? (4 * g + r) : (16 + 4 * g + (r - 4)));
+                const float raw = (r < 4) ? s0[r] : s1[r - 4];
+                const bool vis = row_valid && key <= my_pos && (p.window == 0 || key > my_pos - p.window);
+                tv[r] = vis ? raw * c2 : -INFINITY;
+            }
+        }
+        float alpha;
+        const bf16x8 pfrag = softmax_tile_step(tv, m_run, l_run, alpha);
+        if (__any(alpha != 1.0f))
+        {
+#pragma unroll
+            for (int d = 0; d < DT; ++d) { o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha; }
+            asm volatile("" ::: "memory");
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va[d]), pfrag, o[d], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+#ifdef MILA_FLASH_STAMPS
+        if (stamping && o[DT - 1][0] == 12345.678f) seg[4] += 1;
+#endif
+    };
+    // end of a slot.  EVEN slots carry the requests (K and V of the next tile: group 0 among its phase-A reads, group 1 at the top of its phase B), ODD slots
+    // retire them: a batch has the rest of its slot and the whole next one in flight.
+    auto slot_end = [&](bool retire) {
+#ifndef MILA_FLASH_EXP_NOWAIT
+        if (retire) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // prologue: K(0) and V(0) have landed everywhere before slot 0
+    static_for<DMAS>([&](auto ic) { request(std::true_type{}, ic, 0); });
+    static_for<DMAS>([&](auto ic) { request(std::false_type{}, ic, 0); });
+    slot_end(true);
+    constexpr std::integral_constant<int, 0> B0{};
+    constexpr std::integral_constant<int, 1> B1{};
+#ifdef MILA_FLASH_STAMPS
+    last_ = __builtin_amdgcn_s_memtime();
+#endif
+    if (grp == 0)
+    {
+        // slot 2t: A(t) + the requests of tile t + 1; slot 2t + 1: B(t)
+        for (int t = 0; t < ntiles; t += 2)
+        {
+            phase_a(t, B0, std::true_type{}, t + 1);       FLASH_STAMP(0); slot_end(false); FLASH_STAMP(1);
+            phase_b(t, std::false_type{}, 0);              FLASH_STAMP(2); slot_end(true);  FLASH_STAMP(3);
+            if (t + 1 < ntiles)
+            {
+                phase_a(t + 1, B1, std::true_type{}, t + 2);   FLASH_STAMP(0); slot_end(false); FLASH_STAMP(1);
+                phase_b(t + 1, std::false_type{}, 0);          FLASH_STAMP(2); slot_end(true);  FLASH_STAMP(3);
+            }
+        }
+        slot_end(false);                                       // slot 2 ntiles: group 1's last phase B
+    }
+    else
+    {
+        // slot 0: the requests of tile 1 only; slot 2t + 1: A(t); slot 2t + 2: B(t) + the requests of tile t + 2
+        static_for<DMAS>([&](auto ic) { request(std::true_type{}, ic, 1); });
+        static_for<DMAS>([&](auto ic) { request(std::false_type{}, ic, 1); });
+        slot_end(false);
+#ifdef MILA_FLASH_STAMPS
+        last_ = __builtin_amdgcn_s_memtime();
+#endif
+        for (int t = 0; t < ntiles; t += 2)
+        {
+            phase_a(t, B0, std::false_type{}, 0);          FLASH_STAMP(0); slot_end(true);  FLASH_STAMP(1);
+            phase_b(t, std::true_type{}, t + 2);           FLASH_STAMP(2); slot_end(false); FLASH_STAMP(3);
+            if (t + 1 < ntiles)
+            {
+                phase_a(t + 1, B1, std::false_type{}, 0);      FLASH_STAMP(0); slot_end(true);  FLASH_STAMP(1);
+                phase_b(t + 1, std::true_type{}, t + 3);       FLASH_STAMP(2); slot_end(false); FLASH_STAMP(3);
+            }
+        }
+    }
+#ifdef MILA_FLASH_STAMPS
+    if (stamping && lane == 0)
+    {
+        for (int i = 0; i < 4; ++i) g_flash_stamps[8 + 4 * grp + i] = seg[i];
+        g_flash_stamps[5] = (unsigned long long)ntiles;
+    }
+#endif
+
+    const float l_row = quad_rows_sum(l_run);
+    if (row_valid)
+    {
+        const float inv = (l_row > 0.0f) ? 1.0f / l_row : 0.0f;
+        uint16_t* y = p.Y + (((size_t)b * p.Tq + my_row) * p.NH + h) * HS + 16 * dsel * DT + 4 * g;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+            *reinterpret_cast<u32x2*>(y + 16 * d) = u32x2{pack_bf16x2(o[d][0] * inv, o[d][1] * inv), pack_bf16x2(o[d][2] * inv, o[d][3] * inv)};
+    }
 }
 
 static int g_tune_flash_form = 8;      // tuning hook (mila_cdna4_tune_flash_dsplit): 8 = the LDS-DMA forms (default: 8-wave workgroups at HS = 512, double-buffered; 9 = 8 with 8-wave workgroups at HS = 256 too
@@ -706,10 +1046,30 @@ static int launch_flash_dma(const FlashParams& p, int B, hipStream_t s)
     MILA_LAUNCH_CHECK("flash_prefill");
 }
 
+template <int HS, int HB, int DS>
+static int launch_flash_pp(const FlashParams& p, int B, hipStream_t s)
+{
+    constexpr int QROWS = 16 * (8 / (HB * DS));
+    const size_t lds = (size_t)4 * kKeysPerTile * HS * 2;
+    FlashParams q = p;
+    q.n_qtiles = (p.Tq + QROWS - 1) / QROWS;
+    q.n_hblk = p.NH / HB;
+    const dim3 grid(q.n_qtiles * q.n_hblk, 1, B);
+    if (lds > 65536)
+    {
+        static const hipError_t allowed = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_prefill_pp_kernel<HS, HB, DS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (allowed != hipSuccess) return check_hip(allowed, "flash_prefill: hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    hipLaunchKernelGGL((flash_prefill_pp_kernel<HS, HB, DS>), grid, dim3(512), lds, s, q);
+    MILA_LAUNCH_CHECK("flash_prefill");
+}
+
 template <int HS>
 static int dispatch_hb(const FlashParams& p, int B, hipStream_t s)
 {
     const int GS = p.NH / p.NKV;
+    if constexpr (HS == 512) { if (g_tune_flash_form == 10 && GS % 4 == 0) return launch_flash_pp<HS, 4, 2>(p, B, s); }
+    if constexpr (HS == 256) { if (g_tune_flash_form == 10 && GS % 2 == 0) return launch_flash_pp<HS, 2, 1>(p, B, s); }
     if constexpr (HS == 512)
     {
         if (g_tune_flash_form >= 8 && GS % 4 == 0) return launch_flash_dma<HS, 4, 2, 8>(p, B, s);      // four heads x two d-halves, double-buffered tiles
@@ -787,7 +1147,7 @@ int mila_cdna4_attn_prefill_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t*
 int mila_cdna4_tune_flash_dsplit(int ds)
 {
     if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
-    MILA_REQUIRE(ds == 1 || ds == 2 || ds == 8 || ds == 9, "tune_flash_dsplit: 1, 2, 8 or 9");
+    MILA_REQUIRE(ds == 1 || ds == 2 || ds == 8 || ds == 9 || ds == 10, "tune_flash_dsplit: 1, 2, 8, 9 or 10");
     g_tune_flash_form = ds;
     return MILA_OK;
 }
@@ -813,6 +1173,6 @@ int mila_cdna4_mha_bf16(uint16_t* Y, const uint16_t* QKV, int B, int T, int C, i
 #ifdef MILA_FLASH_STAMPS
 extern "C" MILA_API int mila_dbg_flash_stamps(unsigned long long* out8)
 {
-    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(mila::g_flash_stamps), 8 * sizeof(unsigned long long));
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(mila::g_flash_stamps), 16 * sizeof(unsigned long long));
 }
 #endif

@@ -6,6 +6,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mila_amd import capi
 T = 2048
+if os.environ.get("MILA_FLASH_LIB"):          # an experiment build of the library (tools/experiments/flash_stamps.sh with FLASH_DEFS=...)
+    capi.LIB_PATH = os.environ["MILA_FLASH_LIB"]
 if os.environ.get("MILA_FLASH_DSPLIT"):
     capi.check(capi.load().mila_cdna4_tune_flash_dsplit(int(os.environ["MILA_FLASH_DSPLIT"])))      # 1: register-staged kernels; 2: HS = 512 as 4-wave d-split workgroups; 8 (default); 9: 8-wave workgroups at HS = 256 too
 for name, NH, NKV, HS, window in (("local", 16, 8, 256, 1024), ("global", 16, 1, 512, 0)):
