@@ -72,6 +72,9 @@ __device__ __forceinline__ bf16x8 softmax_tile_step(const float (&tv)[8], float&
         const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
         mt = vmax2(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
     }
+    // (A LAZY reference -- keep m until a tile exceeds it by 2^8, so that the accumulators are rescaled in a few tiles instead of 40-60 % of them -- was tried in
+    // round 4: mathematically the same O / l, but P is then rounded to bf16 at another, non-power-of-two scale than the reference's flash kernels round it, and
+    // 15 of 573 440 outputs of the HS 512 chunked test left the 1 ulp + 2e-3 bar (2 ulp).  The true running maximum stays.)
     const float mn = vmax2(m_run, mt);
     const float msafe = (mn == -INFINITY) ? 0.0f : mn;      // row with nothing visible yet
     alpha = __builtin_amdgcn_exp2f(m_run - msafe);          // m_run = -inf -> 0
