@@ -330,9 +330,9 @@ def main():
     capi.load()
     capi.check(capi.load().mila_cdna4_set_device(local_rank))
     if a.attn_split is not None:
-        capi.check(capi.load().mila_cdna4_tune_attn_split(a.attn_split))
+        capi.tune("attn.positions_per_split", a.attn_split)
     if a.gemm_schedule is not None:
-        capi.check(capi.load().mila_cdna4_tune_gemm_schedule(a.gemm_schedule))
+        capi.tune("gemm.schedule", a.gemm_schedule)
     for kv in a.tune:
         name, value = kv.split("=", 1)
         capi.tune(name, int(value))

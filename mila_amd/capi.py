@@ -190,7 +190,7 @@ EXPORTED = [
 # csrc/internal.h: test / tuning hooks and the measured-slower experiments -- exported, but not part of the drop-in ABI
 INTERNAL = [
     "tune", "tune_get", "tune_reset", "tune_list", "last_form",
-    "tune_matvec", "tune_gemm", "tune_gemm_schedule", "tune_gemm_fp8_tail_only", "tune_attn_split", "tune_flash_dsplit", "decode_engine_debug",
+    "decode_engine_debug",
     "selftest_decode", "selftest_wave_reduce", "selftest_mfma_fp8", "stream_copy", "stream_read",
     "attn_decode_split_count", "fused_attn_decode_partials_bf16", "matvec_attn_combine",
     "decode_chain_scratch_bytes", "decode_chain_init", "decode_chain_status", "decode_chain",

@@ -30,7 +30,7 @@ namespace mila {
 constexpr int kMaxSplits = 64;
 constexpr int kMaxSplitsMfma = 256;      // the long-context MFMA decode (attn_decode_mfma_kernel): one workgroup per CU
 constexpr int kMfmaMinBand = 8192;        // band bucket (keys) from which a 16-head group on one KV head takes the MFMA decode (see band_bucket; profiles/r04_attn_band.txt)
-static int g_mfma_min_band = kMfmaMinBand;      // tuning hook (mila_cdna4_tune_attn_split(-3 - n)): n * 256 keys
+static int g_mfma_min_band = kMfmaMinBand;      // tuning "attn.mfma_min_band" (keys)
 MILA_TUNE("attn.mfma_min_band", g_mfma_min_band);
 
 // ---- KV append ------------------------------------------------------------------------------------
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256) void attn_combine_many_kernel(uint16_t* __rest
     }
 }
 
-static int g_tune_decode_mfma = 1;      // tuning hook (mila_cdna4_tune_attn_split, negative values): 0 = never take the MFMA decode
+static int g_tune_decode_mfma = 1;      // tuning "attn.mfma_decode": 0 = never take the MFMA decode
 MILA_TUNE("attn.mfma_decode", g_tune_decode_mfma);
 
 static bool mfma_decode_applies(int NH, int NKV, int HS, int band_max)
@@ -868,7 +868,7 @@ static int dispatch_hs(int HS, const AttnParams& p, int B, hipStream_t s)
     }
 }
 
-static int g_tune_positions_per_split = 64;     // tuning hook (mila_cdna4_tune_attn_split): positions one split covers
+static int g_tune_positions_per_split = 64;     // tuning "attn.positions_per_split": positions one split covers
 MILA_TUNE("attn.positions_per_split", g_tune_positions_per_split);
 // Experiment (round 4): every split of a head group and the combine workgroups of its heads on ONE XCD (blockIdx.x % 8 equal), so that the merge
 // reads the partials from that XCD's L2 instead of across the fabric.  Same arithmetic per workgroup: bit-identical.  Result: profiles/r04_attn_pair_experiments.txt
@@ -884,7 +884,8 @@ static int decode_splits(int B, int NH, int NKV, int HS, int band)
     const int hgroups = GS / heads_per_group(GS, HS);
     int cap = g_attn_max_wgs / (NKV * hgroups * B);
     if (cap < 1) cap = 1;
-    int s = (band + g_tune_positions_per_split - 1) / g_tune_positions_per_split;
+    const int pps = g_tune_positions_per_split >= 8 ? g_tune_positions_per_split : 64;      // (a tuning value below 8 means the default)
+    int s = (band + pps - 1) / pps;
     if (s > cap) s = cap;
     if (s > kMaxSplits) s = kMaxSplits;
     if (s < 1) s = 1;
@@ -1025,16 +1026,6 @@ __global__ __launch_bounds__(256) void mha_kv_write_vec_kernel(uint16_t* __restr
 using namespace mila;
 
 extern "C" {
-
-int mila_cdna4_tune_attn_split(int positions_per_split)
-{
-    if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
-    if (positions_per_split == -1) { g_tune_decode_mfma = 0; return MILA_OK; }      // -1 / -2: the long-context MFMA decode off / on (default on)
-    if (positions_per_split == -2) { g_tune_decode_mfma = 1; g_mfma_min_band = kMfmaMinBand; return MILA_OK; }
-    if (positions_per_split <= -3) { g_mfma_min_band = (-3 - positions_per_split) * 256; return MILA_OK; }      // experiment: the MFMA decode from a shorter band on
-    g_tune_positions_per_split = (positions_per_split >= 8) ? positions_per_split : 64;
-    return MILA_OK;
-}
 
 int mila_cdna4_kv_write_bf16(uint16_t* Kc, uint16_t* Vc, const uint16_t* k, const uint16_t* v, int B, int chunk, int NKV,
                              int HS, int start_pos, int capacity, mila_stream_t stream)

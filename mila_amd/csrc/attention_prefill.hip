@@ -1010,8 +1010,10 @@ __global__ __launch_bounds__(512, 1) void flash_prefill_pp_kernel(const FlashPar
     }
 }
 
-static int g_tune_flash_form = 8;      // tuning hook (mila_cdna4_tune_flash_dsplit): 8 = the LDS-DMA forms (default: 8-wave workgroups at HS = 512, double-buffered; 9 = 8 with 8-wave workgroups at HS = 256 too
-                                       // 4-wave ones at HS = 256), 2 = HS = 512 as 4-wave d-split workgroups, 1 = the register-staged kernels
+static int g_tune_flash_form = 8;      // tuning "flash.form": 8 (default) = the LDS-DMA forms (HS 512: 8-wave workgroups, four heads x two d-halves; HS 256: double-buffered 4-wave
+                                       // workgroups, two per CU); 9 = 8 with lockstep 8-wave workgroups at HS 256 too; 10 = the ping-pong 8-wave form at both head sizes; 2 = HS 512 as 4-wave
+                                       // d-split workgroups; 1 = the register-staged kernels.  All give the same bits.
+MILA_TUNE("flash.form", g_tune_flash_form);
 
 // the register-staged kernels (HS <= 256; every head size under form 1)
 template <int HS, int HB>
@@ -1145,14 +1147,6 @@ int mila_cdna4_attn_prefill_bf16(uint16_t* Y, const uint16_t* Q, const uint16_t*
     p.Tq = chunk; p.NH = NH; p.NKV = NKV; p.capacity = capacity; p.pos_offset = pos_offset; p.window = window;
     p.scale = scale;
     return flash_dispatch(HS, p, B, as_stream(stream));
-}
-
-int mila_cdna4_tune_flash_dsplit(int ds)
-{
-    if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
-    MILA_REQUIRE(ds == 1 || ds == 2 || ds == 8 || ds == 9 || ds == 10, "tune_flash_dsplit: 1, 2, 8, 9 or 10");
-    g_tune_flash_form = ds;
-    return MILA_OK;
 }
 
 int mila_cdna4_mha_bf16(uint16_t* Y, const uint16_t* QKV, int B, int T, int C, int NH, mila_stream_t stream)

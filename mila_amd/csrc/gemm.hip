@@ -284,12 +284,13 @@ int launch_gemm_bf16_skinny(uint16_t* Y, const uint16_t* X, const uint16_t* W, c
 int launch_gemm_bf16_skinny_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s);
 constexpr int kBf16SkinnyRows = 64;      // a remainder (or a whole prompt) of up to this many rows is a weight stream: the skinny kernel
 int launch_gemm256_geglu(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s);
-static int g_gemm_force128 = 0;
-static int g_bf16_skinny = 1;      // tuning (mila_cdna4_tune_gemm(3) clears it, 4 sets it): the bf16 skinny kernel for <= 64-row prompts and remainders
+static int g_gemm_force128 = 0;      // tuning "gemm.force128": 1 = always the 128 x 128 register-staged GEMM (A/B against the LDS-DMA kernels)
+MILA_TUNE("gemm.force128", g_gemm_force128);
+static int g_bf16_skinny = 1;      // tuning "gemm.bf16_skinny": the bf16 skinny kernel for <= 64-row prompts and remainders
+MILA_TUNE("gemm.bf16_skinny", g_bf16_skinny);
 extern int g_gemm_pingpong;     // gemm256.hip
 extern int g_gemm_persistent;
 extern int g_gemm_rowwise;
-extern int g_gemm_fp8_tail_only;
 extern int g_gemm_fp8_tail_form;      // gemm_fp8_tail.hip
 extern int g_skinny_whole_x;
 extern int g_fp8_big_rule;           // gemm256.hip
@@ -302,12 +303,15 @@ int launch_gemm256x128_splitk(uint16_t* Y, const uint16_t* X, const uint16_t* W,
 // to 16 rows 7.46 / 7.39 / 7.75 / 7.94 ms, never ahead 7.41 / 7.05 / 7.13 / 7.28 -- a one-round tile grid and the split-K form stream the weights at 3-4 TB/s from two
 // rows on, the skinny kernel's 16-row groups at that rate only for one group.  The skinny kernels keep what has no such grid: a 1-row remainder, narrow outputs, calls
 // without a workspace on the N = 3840 shapes.
-int g_skinny_ahead_rows = 1;         // tuning: mila_cdna4_tune_gemm(300 + n): up to this many rows the skinny kernels go ahead of an applicable tile grid (plain and GeGLU)
+int g_skinny_ahead_rows = 1;         // tuning "gemm.skinny_ahead_rows": up to this many rows the skinny kernels go ahead of an applicable tile grid (plain and GeGLU)
+MILA_TUNE("gemm.skinny_ahead_rows", g_skinny_ahead_rows);
 int gemm_fewrow_splits(int M, int K, int N);      // gemm_fewrow_bf16.hip
 int launch_gemm_bf16_fewrow(float* partials, const uint16_t* X, const uint16_t* W, int M, int K, int N, int S, hipStream_t s);
 int launch_splitk_reduce(uint16_t* Y, const float* partials, const uint16_t* bias, int M, int N, int S, int act, hipStream_t s);      // gemm256.hip
-int g_fewrow = 1;                    // tuning (mila_cdna4_tune_gemm(9) off, (10) on): the few-row weight-streaming form for <= 32 rows with a workspace
-int g_splitk_min_rows = 2;           // tuning (mila_cdna4_tune_gemm(200 + n)): row counts below this stay off the split-K form even with a workspace
+int g_fewrow = 1;                    // tuning "gemm.fewrow": the few-row weight-streaming form for <= 32 rows with a workspace
+MILA_TUNE("gemm.fewrow", g_fewrow);
+int g_splitk_min_rows = 2;           // tuning "gemm.splitk_min_rows": row counts below this stay off the split-K form even with a workspace
+MILA_TUNE("gemm.splitk_min_rows", g_splitk_min_rows);
 
 // which direct-to-LDS kernel serves a bf16-weight GEMM of this shape: 2 = 256 x 256, 1 = 256 x 128, 0 = none (128 x 128 register-staged)
 static int glds_kernel_for(int M, int K, int N)
@@ -562,40 +566,6 @@ static int launch_geglu_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, 
 using namespace mila;
 
 extern "C" {
-
-int mila_cdna4_tune_gemm(int force_128_tile)
-{
-    if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
-    if (force_128_tile == 3 || force_128_tile == 4) { g_bf16_skinny = force_128_tile == 4; return MILA_OK; }
-    if (force_128_tile == 9 || force_128_tile == 10) { g_fewrow = force_128_tile == 10; return MILA_OK; }      // the few-row (<= 32 rows) weight-streaming form of gemm_bf16_ws off / on
-    if (force_128_tile == 5 || force_128_tile == 6) { g_gemm_splitk = force_128_tile == 6; return MILA_OK; }      // the split-K forms of gemm_bf16_ws and gemm_fp8_scaled_ws off / on
-    if (force_128_tile >= 300) { g_skinny_ahead_rows = force_128_tile - 300; return MILA_OK; }      // 301 = default
-    if (force_128_tile >= 200) { g_splitk_min_rows = force_128_tile - 200; return MILA_OK; }      // 202 = default
-    if (force_128_tile >= 100) { g_ldsdma_loose_tiles = force_128_tile - 100; return MILA_OK; }      // 100 = the fill rule only; 130 = default
-    g_gemm_force128 = force_128_tile == 1;
-    g_gemm_rowwise = force_128_tile != 2;      // 2: the direct (unaligned) epilogue stores on an odd output pitch instead of the row-wise one through LDS
-    return MILA_OK;
-}
-
-int mila_cdna4_tune_gemm_schedule(int pingpong)
-{
-    if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
-    g_gemm_persistent = pingpong != 6;
-    g_gemm_pingpong = pingpong == 6 ? 5 : pingpong;
-    return MILA_OK;
-}
-
-int mila_cdna4_tune_gemm_fp8_tail_only(int on)
-{
-    if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
-    if (on == 3) { g_skinny_whole_x = 0; return MILA_OK; }      // 3: the skinny kernel's barrier-free <= 4-row form off (4 turns it back on); the other settings stay
-    if (on == 4) { g_skinny_whole_x = 1; return MILA_OK; }
-    if (on >= 100) { g_fp8_splitk_min_rows = on - 100; return MILA_OK; }      // 117 = default: fewer rows stay off the fp8 split-K form
-    if (on >= 5 && on <= 8) { g_fp8_big_rule = on - 5; return MILA_OK; }      // 5 / 6 / 7: which row counts below 512 take the LDS-DMA kernels (gemm256.hip: g_fp8_big_rule 0 / 1 / 2)
-    g_gemm_fp8_tail_only = on != 0;      // 1: every row on the masked 128-row LDS tiles (bit-identical to the LDS-DMA kernels); 2: every row as skinny pieces
-    g_gemm_fp8_tail_form = (on == 1 || on == 2) ? on : 0;
-    return MILA_OK;
-}
 
 int mila_cdna4_gemm_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, const uint16_t* bias, int M, int K, int N,
                          mila_stream_t stream)

@@ -1137,7 +1137,8 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
 // the LDS-DMA kernels address their operands through 32-bit buffer offsets (bytes, signed int arithmetic): both tensors must stay below 2 GiB
 static bool lds_dma_addressable(int M, int K, int w_rows) { return (int64_t)M * K * 2 < 0x7fffffffll && (int64_t)w_rows * K * 2 < 0x7fffffffll; }
 
-int g_ldsdma_loose_tiles = 30;     // the 256 x 128 ring applies from this many tiles on whatever the fill of its last round (tuning: mila_cdna4_tune_gemm(100 + n), 100 = the fill rule only).
+int g_ldsdma_loose_tiles = 30;     // the 256 x 128 ring applies from this many tiles on whatever the fill of its last round (tuning "gemm.ldsdma_loose_tiles"; 0 = the fill rule only).
+MILA_TUNE("gemm.ldsdma_loose_tiles", g_ldsdma_loose_tiles);
                                    // Measured with tools/experiments/bf16_ragged_rules.py (profiles/r03_bf16_ragged.txt): even a 30-tile ring beats the register-staged 128-tile kernel --
                                    // bf16-policy prefill of 100 / 300 / 511 / 1000 tokens 23.6 / 25.1 / 26.4 / 31.6 -> 16.3 / 17.9 / 21.4 / 26.7 ms
 // taken when the 256 x 256 grid does not apply and the 256 x 128 grid fills most of one round of CUs (or several)
@@ -1159,7 +1160,7 @@ bool gemm256x128_ragged_n_applicable(int M, int K, int N)
 
 extern int g_gemm_pingpong;
 extern int g_gemm_persistent;
-extern int g_gemm_fp8_tail_only;
+extern int g_gemm_fp8_tail_form;      // gemm_fp8_tail.hip: != 0 sends every row through the tail kernels
 
 template <bool FP8, bool GEGLU, int PP>
 static int launch_gemm256x128_tt(const Gemm256Params& p, hipStream_t s)
@@ -1214,7 +1215,8 @@ int launch_gemm256x128(uint16_t* Y, const uint16_t* X, const uint16_t* W, const 
 // a fixed order and applies the epilogue (bias, GELU, bf16) -- same bits whatever the timing.  The partials live in caller workspace (S M N floats, <= 32 MiB since
 // tiles x S <= 256 CUs): the entry that takes one is mila_cdna4_gemm_bf16_ws, the counterpart of the cuBLASLt workspace CudaLinearOp hands its plans
 // (CudaLinearOp.ixx:637-638, CudaExecutionContext.ixx:337).
-int g_gemm_splitk = 1;            // tuning: mila_cdna4_tune_gemm(5) off, (6) on
+int g_gemm_splitk = 1;            // tuning "gemm.splitk": the split-K forms of gemm_bf16_ws / gemm_fp8_scaled_ws
+MILA_TUNE("gemm.splitk", g_gemm_splitk);
 int gemm_splitk_for(int M, int K, int N)      // S (>= 2), or 0: no split-K form for this shape
 {
     if (!g_gemm_splitk || g_gemm_pingpong != 5) return 0;
@@ -1290,7 +1292,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_fp8_kernel(uint16_t* __rest
 
 int gemm_fp8_splitk_for(int M, int K, int N)      // S (>= 2), or 0: the fp8 (W4A8) 256 x 128 ring has no split-K form for this shape
 {
-    if (!g_gemm_splitk || g_gemm_pingpong != 5 || g_gemm_fp8_tail_only) return 0;
+    if (!g_gemm_splitk || g_gemm_pingpong != 5 || g_gemm_fp8_tail_form != 0) return 0;
     if (M <= 0 || N % 128 != 0 || K % 128 != 0 || !lds_dma_addressable(M, K, N)) return 0;
     const int tiles = ((M + 255) / 256) * (N / 128), nk = K / 128;
     if (tiles > kNumCU / 2) return 0;
@@ -1365,13 +1367,16 @@ bool gemm256_ragged_n_applicable(int M, int K, int N)
     return (int64_t)((M + 255) / 256) * ((N + 255) / 256) >= 4 * kNumCU;
 }
 
-int g_gemm_rowwise = 1;       // tuning (mila_cdna4_tune_gemm(2) clears it)
-int g_gemm_persistent = 1;    // tuning: schedule 6 = schedule 5 with one workgroup per tile (not persistent)
-int g_gemm_pingpong = 5;      // tuning hook (mila_cdna4_tune_gemm_schedule): 0 = all eight waves in lockstep; 1 = staggered (ping-pong), four phases per
+int g_gemm_rowwise = 1;       // tuning "gemm.rowwise_epilogue": 0 = an output whose row pitch is no multiple of 128 bytes keeps the direct epilogue stores
+MILA_TUNE("gemm.rowwise_epilogue", g_gemm_rowwise);
+int g_gemm_persistent = 1;    // tuning "gemm.persistent": 0 = one workgroup per tile instead of the persistent tile walk
+MILA_TUNE("gemm.persistent", g_gemm_persistent);
+int g_gemm_pingpong = 5;      // tuning "gemm.schedule": 0 = all eight waves in lockstep; 1 = staggered (ping-pong), four phases per
                               // K-tile in the 256 x 256 kernel; 2 = 1 + prefer the 256 x 128 ring; 3 = staggered, two phases per K-tile in the
                               // 256 x 256 kernel; 4 = 3 + fp8 x fp8 shapes take the 256 x 256 kernel wherever it applies; 5 (default) = 4 with ONE
                               // s_setprio 1 for waves 4-7 (the later-dispatched half loses every issue arbitration by age) instead of a raise around
                               // every MFMA block: 0.5-1 % on each bf16 shape, nothing on fp8; same bits
+MILA_TUNE("gemm.schedule", g_gemm_pingpong);
 
 template <int MODE, int PP>
 static int launch_gemm256_tt(const Gemm256Params& p, hipStream_t s)
@@ -1459,7 +1464,6 @@ int launch_gemm_fp8_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, cons
                          int M, int K, int N, hipStream_t s);
 int launch_gemm_fp8_geglu_tail(uint16_t* Y, const uint8_t* X8, const uint8_t* W8, const float* x_scales, Fp8WScale w_scale, int M, int K, int F,
                                hipStream_t s);
-int g_gemm_fp8_tail_only = 0;      // tuning hook (mila_cdna4_tune_gemm_fp8_tail_only): != 0: every row through the tail kernels (gemm_fp8_tail.hip: g_gemm_fp8_tail_form picks which)
 
 // Row counts of any kind (the fp4 policy's prefill is W4A8 for EVERY M > 1, CudaLinearOp.ixx:646-715):
 //   (short prompts, measured with tools/experiments/short_prompt_rules.py, profiles/r03_short_prompts.txt: below 512 rows the LDS-DMA kernels still win wherever their grid
@@ -1475,14 +1479,16 @@ constexpr int kSkinnyTailRows = 64;
 // (fp4-policy prefill of 8 / 16 tokens 4.83 / 4.92 ms, against 4.95 / 5.02 on the tile forms); from 17 rows on the tile grids (>= 120 tiles) and the split-K form are faster
 // (17 / 24 / 32 tokens 5.39 / 5.50 / 5.69 ms skinny, 5.09 / 5.10 / 5.17 here; 64 tokens 7.15 -> 5.66).  A W4A8 form of the few-row kernel (gemm_fewrow_bf16.hip with
 // e4m3 operands; parity-green) was slower than both on every length -- the skinny kernel's fused GeGLU saves fc_gate_up a reduce and an elementwise pass -- and is not kept.
-int g_fp8_splitk_min_rows = 17;      // tuning (mila_cdna4_tune_gemm_fp8_tail_only(100 + n)): fewer rows stay with the skinny kernel
-int g_fp8_big_rule = 3;      // tuning (mila_cdna4_tune_gemm_fp8_tail_only 5 .. 8 = rule 0 .. 3): 0 = LDS-DMA kernels from 512 rows on (round 3's first rule), 1 = from 128 rows on,
+int g_fp8_splitk_min_rows = 17;      // tuning "gemm_fp8.splitk_min_rows": fewer rows stay with the skinny kernel
+MILA_TUNE("gemm_fp8.splitk_min_rows", g_fp8_splitk_min_rows);
+int g_fp8_big_rule = 3;      // tuning "gemm_fp8.big_rule": 0 = LDS-DMA kernels from 512 rows on (round 3's first rule), 1 = from 128 rows on,
                              // 2 = from 512 rows on or wherever ceil(M / 256) x (W rows / 128) >= 120 tiles, 3 (default) = 2 without the skinny split of a short prompt's remainder
+MILA_TUNE("gemm_fp8.big_rule", g_fp8_big_rule);
 static int fp8_big_rows(int M, int K, int N_mult, int w_rows)      // rows the LDS-DMA kernels take (0 = none); N_mult: the column granularity the form needs (128, or 64 for 256 x 128 GeGLU)
 {
     if (!lds_dma_addressable(M, K, w_rows)) return 0;
-    if (g_gemm_fp8_tail_only || K % 128 != 0 || N_mult == 0) return 0;
-    // below two full tile-rows the LDS-DMA kernels pay only where their grid still covers the chip (g_fp8_big_rule: see mila_cdna4_tune_gemm_fp8_tail_only)
+    if (g_gemm_fp8_tail_form != 0 || K % 128 != 0 || N_mult == 0) return 0;
+    // below two full tile-rows the LDS-DMA kernels pay only where their grid still covers the chip (tuning variable gemm_fp8.big_rule)
     const int tiles = ((M + 255) / 256) * (w_rows / 128);
     const bool big = g_fp8_big_rule == 1 ? M >= 128 : (g_fp8_big_rule >= 2 ? (M >= 512 || (M >= g_fp8_splitk_min_rows && tiles >= 120)) : M >= 512);
     if (!big) return 0;
@@ -1552,7 +1558,7 @@ static Fp8WsPlan fp8_ws_plan(int M, int K, int N)
     int S = gemm_fp8_splitk_for(M, K, N);
     if (S) return {0, S};
     // the 256 x 256 fp8 tile list of N = 8704 at T = 2048 is 272 tiles: one round and sixteen stragglers, walked as two (fp8_pick: 2).  Whole rounds + a split-K rest instead.
-    if (g_gemm_colsplit && g_gemm_pingpong == 5 && !g_gemm_fp8_tail_only && M >= 512 && N % 256 == 0 && K % 128 == 0 && lds_dma_addressable(M, K, N))
+    if (g_gemm_colsplit && g_gemm_pingpong == 5 && g_gemm_fp8_tail_form == 0 && M >= 512 && N % 256 == 0 && K % 128 == 0 && lds_dma_addressable(M, K, N))
     {
         const int tm = (M + 255) / 256, tn = N / 256, tiles = tm * tn;
         const int rounds = (tiles + kNumCU - 1) / kNumCU;

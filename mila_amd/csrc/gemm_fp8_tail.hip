@@ -436,7 +436,8 @@ __global__ __launch_bounds__(512) void gemm_fp8_skinny_kernel(const Fp8SkinnyPar
     }
 }
 
-int g_skinny_whole_x = 1;      // tuning (mila_cdna4_tune_gemm_fp8_tail_only(3) clears it, any other value sets it): the barrier-free <= 4-row form of the skinny kernel
+int g_skinny_whole_x = 1;      // tuning "gemm_fp8.skinny_whole_x": the barrier-free <= 4-row form of the skinny kernel
+MILA_TUNE("gemm_fp8.skinny_whole_x", g_skinny_whole_x);
 
 template <int MG, bool GEGLU>
 static void launch_skinny_mg(const Fp8SkinnyParams& p, hipStream_t s)
@@ -492,7 +493,9 @@ static int launch_tail(const Fp8TailParams& p, hipStream_t s)
     return launch_tail_t<1, 2, 2, GEGLU>(p, s);
 }
 
-int g_gemm_fp8_tail_form = 0;       // tuning hook (mila_cdna4_tune_gemm_fp8_tail_only): 0 = by row count, 1 = the 128-row LDS tiles for every row, 2 = skinny pieces for every row
+int g_gemm_fp8_tail_form = 0;       // tuning "gemm_fp8.tail_form": 0 = LDS-DMA kernels on the leading rows, the tail kernels by row count on the rest; 1 = EVERY row on the masked 128-row
+                                    // LDS tiles (bit-identical to the LDS-DMA kernels: the test of that statement); 2 = every row as skinny pieces
+MILA_TUNE("gemm_fp8.tail_form", g_gemm_fp8_tail_form);
 constexpr int kSkinnyRows = 64;     // rows one skinny launch takes
 constexpr int kSkinnyMaxTail = 64;  // tails up to here run as ONE skinny launch; longer ones on the 128-row LDS tiles (measured: four skinny pieces of a 208-row tail cost more than two LDS tile rows)
 

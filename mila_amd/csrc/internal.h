@@ -19,32 +19,26 @@ MILA_API int mila_cdna4_tune_get(const char* name, int* value);
 MILA_API int mila_cdna4_tune_reset(void);
 MILA_API size_t mila_cdna4_tune_list(char* buf, size_t cap);
 MILA_API size_t mila_cdna4_last_form(char* buf, size_t cap);
-/* override the matvec launch heuristics (0 = default): rows per wave, chunk positions in flight,
- * maximum workgroups */
-MILA_API int mila_cdna4_tune_matvec(int R, int U, int max_blocks);
-/* (3 / 4: the bf16 skinny weight-streaming kernel for <= 64-row prompts and remainders off / on; 100 + n: the 256 x 128 ring from n tiles on whatever its last round's
- * fill (130 = default, 100 = the fill rule only); 5 / 6: the split-K forms of gemm_bf16_ws / gemm_fp8_scaled_ws off / on; 9 / 10: the few-row (<= 32 rows) form of gemm_bf16_ws off / on; 200 + n: row counts below n stay off split-K (202 = default); 300 + n: up to n rows the skinny GeGLU kernel goes ahead of an applicable tile grid (301 = default);
- * each leaves the other settings)
- * 1 = always use the 128 x 128 register-staged GEMM (A/B against the 256 x 256 direct-to-LDS kernel); 2 = default kernels, but an output whose row pitch is no
- * multiple of 128 bytes keeps the direct epilogue stores instead of the row-wise epilogue through LDS; 0 = default */
-MILA_API int mila_cdna4_tune_gemm(int force_128_tile);
-/* schedule of the LDS-DMA GEMMs: 0 = all eight waves in lockstep; 1 = staggered (ping-pong), four phases per K-tile; 2 = 1, preferring the 256 x 128 ring;
- * 3 = staggered, two phases per K-tile; 4 = 3 + the fp8 shapes on the 256 x 256 kernel wherever it applies; 5 (default) = 4 with a static priority for waves 4-7
- * and persistent tiles; 6 = 5 with one workgroup per tile.  All give the same bits. */
-MILA_API int mila_cdna4_tune_gemm_schedule(int pingpong);
-/* fp8 x fp8 GEMM entry points: 0 (default) = LDS-DMA kernels on the leading multiple of 256 rows, the tail kernels of gemm_fp8_tail.hip on the rest (skinny
- * weight-streaming pieces up to 255 rows, masked 128-row LDS tiles beyond); 1 = EVERY row on the masked 128-row tiles (bit-identical to the LDS-DMA kernels:
- * the test of that statement); 2 = every row as skinny pieces (same products, K-tiles summed in eight interleaved chains: fp32-rounding-level differences). */
-/* (3 / 4: the skinny kernel's barrier-free whole-X form off / on; 5 .. 8: which row counts below 512 take the LDS-DMA kernels -- rules 0 .. 3 of csrc/gemm256.hip: g_fp8_big_rule,
- * 8 = default; 100 + n: row counts below n stay off the fp8 split-K form of gemm_fp8_scaled_ws (117 = default); each leaves the other settings) */
-MILA_API int mila_cdna4_tune_gemm_fp8_tail_only(int on);
-/* positions of the live band one flash-decode split covers (default 64; 0 restores it): fewer, longer splits = smaller partial sets.
- * Negative values steer the long-context matrix-core decode (attn_decode_mfma_kernel): -1 = never take it, -2 = default rule (bands of >= 4096 keys),
- * -3 - n = take it from bands of n * 256 keys on (experiments) */
-MILA_API int mila_cdna4_tune_attn_split(int positions_per_split);
-/* flash-prefill form: 8 (default) = LDS-DMA kernels (HS 512: 8-wave workgroups, four heads x two d-halves; HS 256: double-buffered 4-wave workgroups);
- * 9 = 8 with 8-wave workgroups at HS 256 too; 2 = HS 512 as 4-wave d-split workgroups; 1 = the register-staged kernels.  All give the same bits. */
-MILA_API int mila_cdna4_tune_flash_dsplit(int ds);
+/* The names (tune_list prints them with their values and defaults; each is documented where it is registered):
+ *   matvec.rows_per_wave, matvec.chunks_in_flight, matvec.max_workgroups                 0 = the default rule                                         (csrc/matvec.hip)
+ *   gemm.force128          1 = always the 128 x 128 register-staged GEMM (A/B against the LDS-DMA kernels)                                           (csrc/gemm.hip)
+ *   gemm.bf16_skinny       the bf16 skinny weight-streaming kernel for <= 64-row prompts and remainders (default 1)
+ *   gemm.fewrow            the few-row (<= 32 rows) form of gemm_bf16_ws (default 1)
+ *   gemm.skinny_ahead_rows up to this many rows the skinny kernels go ahead of an applicable tile grid (default 1)
+ *   gemm.splitk, gemm.splitk_min_rows      the split-K forms of gemm_bf16_ws / gemm_fp8_scaled_ws; row counts below the minimum stay off them (1, 2)
+ *   gemm.ldsdma_loose_tiles  the 256 x 128 ring from this many tiles on whatever its last round's fill (30; 0 = the fill rule only)                   (csrc/gemm256.hip)
+ *   gemm.rowwise_epilogue  0 = an output whose row pitch is no multiple of 128 bytes keeps the direct epilogue stores (default 1: row-wise through LDS)
+ *   gemm.schedule          0 = all eight waves in lockstep; 1 = staggered (ping-pong), four phases per K-tile; 2 = 1, preferring the 256 x 128 ring; 3 = staggered, two
+ *                          phases per K-tile; 4 = 3 + the fp8 shapes on the 256 x 256 kernel wherever it applies; 5 (default) = 4 with a static priority for waves 4-7.  Same bits.
+ *   gemm.persistent        0 = one workgroup per tile instead of the persistent tile walk (default 1).  Same bits.
+ *   gemm.colsplit          the column split of a tile list whose last round is nearly empty (default 1)
+ *   gemm_fp8.tail_form     0 (default) = LDS-DMA kernels on the leading multiple of 256 rows, the tail kernels of gemm_fp8_tail.hip on the rest; 1 = EVERY row on the masked
+ *                          128-row tiles (bit-identical to the LDS-DMA kernels: the test of that statement); 2 = every row as skinny pieces (fp32-rounding-level differences)
+ *   gemm_fp8.skinny_whole_x, gemm_fp8.big_rule, gemm_fp8.splitk_min_rows      the skinny kernel's barrier-free <= 4-row form (1); which row counts below 512 take the LDS-DMA
+ *                          kernels (rules 0 .. 3 of gemm256.hip: fp8_big_rows; 3); row counts below this stay off the fp8 split-K form (17)
+ *   attn.positions_per_split, attn.max_workgroups, attn.heads_per_group_512, attn.xcd_local, attn.mfma_decode, attn.mfma_min_band      decode attention (csrc/attention.hip)
+ *   flash.form             8 (default) = the LDS-DMA forms; 9 = lockstep 8-wave workgroups at HS 256 too; 10 = the ping-pong 8-wave form; 2 = HS 512 as 4-wave d-split
+ *                          workgroups; 1 = the register-staged kernels.  Same bits.                                                       (csrc/attention_prefill.hip) */
 /* engine diagnostics: the next decode_engine launches write wall-clock stamps (100 MHz) of the first 8 workgroups' 8 waves, 16 slots each */
 MILA_API int mila_cdna4_decode_engine_debug(unsigned long long* buf);
 /* decode all 256 byte values with the hardware converts used by the kernels:

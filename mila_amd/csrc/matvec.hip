@@ -48,7 +48,10 @@ __global__ __launch_bounds__(1024) void matvec_kernel(const MatvecParams p)
 }
 
 // ---- host side ------------------------------------------------------------------------------
-static int g_tune_R = 0, g_tune_U = 0, g_tune_blocks = 0;
+static int g_tune_R = 0, g_tune_U = 0, g_tune_blocks = 0;      // named tuning variables (0 = the default rule): rows per wave, chunk positions in flight, maximum workgroups
+MILA_TUNE("matvec.rows_per_wave", g_tune_R);
+MILA_TUNE("matvec.chunks_in_flight", g_tune_U);
+MILA_TUNE("matvec.max_workgroups", g_tune_blocks);
 static thread_local int t_last_matvec_blocks = 0;      // workgroups of this thread's last matvec launch (= the sampler partials a lm_head launch wrote)
 
 template <int FMT, int R, int U, int PRO, bool GEGLU, bool F32OUT, int XC>
@@ -195,15 +198,6 @@ static int dispatch_fmt(int fmt, const MatvecParams& p, hipStream_t s)
 using namespace mila;
 
 extern "C" {
-
-int mila_cdna4_tune_matvec(int R, int U, int max_blocks)
-{
-    if (!::mila::tuning_hooks_enabled()) return ::mila::set_error(MILA_E_UNSUPPORTED, "%s: tuning hooks are inert unless MILA_CDNA4_TUNING=1 was set when the library was loaded", __func__);
-    g_tune_R = R;
-    g_tune_U = U;
-    g_tune_blocks = max_blocks;
-    return MILA_OK;
-}
 
 int mila_cdna4_matvec_bf16(uint16_t* y, const uint16_t* x, const uint16_t* W, const uint16_t* bias, int K,
                            int N, mila_stream_t stream)

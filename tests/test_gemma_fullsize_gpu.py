@@ -87,28 +87,28 @@ def test_full_width_prefill_and_decode_compute_the_same_function(six_layers):
 @pytest.mark.parametrize("policy", ["bf16", "fp4"])
 def test_full_size_gemm_schedules_give_the_same_bits(policy, bf16_run):
     """lockstep vs ping-pong schedules accumulate in the same order: identical prefill logits on the real shapes (the fp4 policy
-    compares the two staggered forms that keep its fp8 shapes on the same kernels: 1 vs 3); and schedule 6 -- the default with one workgroup per tile
-    instead of the persistent tile walk of both LDS-DMA kernels -- gives the same bits again"""
+    compares the two staggered forms that keep its fp8 shapes on the same kernels: 1 vs 3); and the default schedule with one workgroup per tile
+    instead of the persistent tile walk of both LDS-DMA kernels (gemm.persistent = 0) gives the same bits again"""
     lib = capi.load()
     outs = []
     try:
         # (the split-K forms -- here the column split of the global qkv_proj, csrc/gemm256.hip: gemm_colsplit_main -- exist under the default schedule only and sum K in
         # another order: the schedules are compared on ONE decomposition, with the column split off; the default decomposition is compared across its own two forms below)
         capi.tune("gemm.colsplit", 0)
-        for sched in ((0, 3, 6, 5) if policy == "bf16" else (1, 3, 6, 5)):
-            capi.check(lib.mila_cdna4_tune_gemm_schedule(sched))       # an inert hook (MILA_CDNA4_TUNING unset) must fail the test, not compare the default with itself
+        for sched, persistent in (((0, 1), (3, 1), (5, 0), (5, 1)) if policy == "bf16" else ((1, 1), (3, 1), (5, 0), (5, 1))):
+            capi.tune("gemm.schedule", sched)       # an inert hook (MILA_CDNA4_TUNING unset) must fail the test, not compare the default with itself
+            capi.tune("gemm.persistent", persistent)
             g = host.Gemma(policy, max_seq=T + 16, max_prefill=T, seed=1234)
             outs.append(g.prefill(TOKS))
             g.close()
         capi.tune("gemm.colsplit", 1)
-        capi.check(lib.mila_cdna4_tune_gemm_schedule(6))               # the default decomposition with one workgroup per tile instead of the persistent walk
+        capi.tune("gemm.persistent", 0)               # the default decomposition with one workgroup per tile instead of the persistent walk
         g = host.Gemma(policy, max_seq=T + 16, max_prefill=T, seed=1234)
         one_per_tile = g.prefill(TOKS)
-        capi.check(lib.mila_cdna4_tune_gemm_schedule(5))
+        capi.tune("gemm.persistent", 1)
         default = g.prefill(TOKS)
         g.close()
     finally:
-        capi.check(lib.mila_cdna4_tune_gemm_schedule(5))      # the default
         capi.tune_reset()
     for o in outs[1:]:
         assert np.array_equal(outs[0].view(np.uint32), o.view(np.uint32))

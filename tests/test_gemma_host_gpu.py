@@ -484,7 +484,7 @@ def test_two_stream_half_chunk_prefill_gives_the_same_bits(policy):
     assert lib.mila_cdna4_gemm_workspace_bytes(512, 1280, 1280) > 0
     a = host.Gemma(policy, cfg, max_seq=T + 8, max_prefill=T, seed=3)
     b = host.Gemma(policy, cfg, max_seq=T + 8, max_prefill=T, seed=3)
-    capi.check(lib.mila_cdna4_tune_gemm(5))
+    capi.tune("gemm.splitk", 0)
     try:
         assert lib.mila_cdna4_gemm_workspace_bytes(512, 1280, 1280) == 0
         b.set_prefill_overlap(True)
@@ -496,7 +496,7 @@ def test_two_stream_half_chunk_prefill_gives_the_same_bits(policy):
             assert np.array_equal(da, db)
             ta, tb = int(np.argmax(da)), int(np.argmax(db))
     finally:
-        capi.check(lib.mila_cdna4_tune_gemm(6))
+        capi.tune_reset()
         a.close()
         b.close()
 

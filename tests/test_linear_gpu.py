@@ -104,7 +104,9 @@ def test_matvec_every_launch_shape_gives_the_same_answer(R, U):
     xd = dev_u16(orc.to_bf16_bits(x))
     lib = capi.load()
     try:
-        capi.check(lib.mila_cdna4_tune_matvec(R, U, 3))
+        capi.tune("matvec.rows_per_wave", R)
+        capi.tune("matvec.chunks_in_flight", U)
+        capi.tune("matvec.max_workgroups", 3)
         y = empty_u16(N)
         capi.call("matvec_bf16", y, xd, dev_u16(Wb), None, K, N)
         assert_bf16_close(bits(y), orc.linear_bf16w(x[None], Wb)[0], 1, 1e-5, "bf16 R%d U%d" % (R, U))
@@ -113,7 +115,7 @@ def test_matvec_every_launch_shape_gives_the_same_answer(R, U):
         capi.call("matvec_bf16_qfp4", y, xd, dev_u8(q4), dev_f32(s4), None, K, N, G)
         assert_bf16_close(bits(y), orc.linear_fp4w(x[None], q4, s4, G)[0], 1, 1e-5, "fp4 R%d U%d" % (R, U))
     finally:
-        capi.check(lib.mila_cdna4_tune_matvec(0, 0, 0))
+        capi.tune_reset()
 
 
 @pytest.mark.parametrize("fmt", [0, 1, 2])
@@ -342,10 +344,10 @@ def test_gemm_256_tile_kernel_agrees_with_the_128_tile_kernel(M, K, N, bias):
     Y256, Y128 = empty_u16(M, N), empty_u16(M, N)
     capi.call("gemm_bf16", Y256, Xi, Wi, bi, M, K, N)
     try:
-        capi.check(lib.mila_cdna4_tune_gemm(1))
+        capi.tune("gemm.force128", 1)
         capi.call("gemm_bf16", Y128, Xi, Wi, bi, M, K, N)
     finally:
-        capi.check(lib.mila_cdna4_tune_gemm(0))
+        capi.tune_reset()
     a = bits(Y256).astype(np.int32)
     c = bits(Y128).astype(np.int32)
     oa = np.where(a & 0x8000, -(a & 0x7fff), a)
@@ -574,11 +576,11 @@ def test_w4a8_serves_every_row_count_like_the_reference(M, K, N, bias, G):
     forms = {}
     for form in (1, 2):
         Yf = empty_u16(M, N)
-        capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(form))
+        capi.tune("gemm_fp8.tail_form", form)
         try:
             capi.call("gemm_fp8_scaled", Yf, X8, W8, ts_d, ws_d, dev_u16(bb) if bias else None, M, K, N)
         finally:
-            capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(0))
+            capi.tune_reset()
         forms[form] = bits(Yf)
         assert_bf16_close(forms[form][rows], exp, 2, 1e-3 * float(np.abs(exp).max()), "fp8 GEMM, tail form %d, vs restated reference" % form)
     # who serves which rows by default (csrc/gemm256.hip: launch_gemm_fp8): with M >= 512 (and K % 128 == N % 128 == 0) the LDS-DMA kernels take every tile-row,
@@ -621,13 +623,13 @@ def test_w4a8_geglu_form_serves_every_row_count(M, K, F):
     capi.call("gemm_geglu_bf16_w4a8", Y1, X, dev_u8(q4), dev_f32(s4), ws, M, K, F, 128, scratch, C.c_size_t(need))
     assert np.array_equal(bits(Y0), bits(Y1))
     for form in (1, 2):
-        capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(form))
+        capi.tune("gemm_fp8.tail_form", form)
         try:
             capi.call("gemm_geglu_bf16_w4a8", Y2, X, dev_u8(q4), dev_f32(s4), ws, M, K, F, 128, scratch, C.c_size_t(need))
             capi.call("gemm_bf16_w4a8", GU, X, dev_u8(q4), dev_f32(s4), ws, None, M, K, 2 * F, 128, scratch, C.c_size_t(need))
             capi.call("geglu_bf16", Y0, GU, M, F)
         finally:
-            capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(0))
+            capi.tune_reset()
         assert np.array_equal(bits(Y2), bits(Y0)), "tail form %d: fused GeGLU epilogue != Linear + GeGLU" % form      # per form, the fusion changes no bit
         a, b = orc.from_bf16_bits(bits(Y2)).astype(np.float64), orc.from_bf16_bits(bits(Y1)).astype(np.float64)
         assert np.abs(a - b).max() <= 2.0 ** -5 * max(np.abs(b).max(), 1e-30), "tail form %d differs from the default by more than rounding" % form
@@ -653,11 +655,11 @@ def test_ragged_prompt_lengths_split_between_the_lds_dma_and_the_128_tile_kernel
     assert_bf16_close(bits(Y)[rows], exp, 2, 2e-3, "ragged gemm_bf16")
     assert np.all(Yg[M].cpu().numpy() == 0x1234), "a store past row M - 1"
     Y2 = empty_u16(M, N)
-    capi.check(lib.mila_cdna4_tune_gemm(1))
+    capi.tune("gemm.force128", 1)
     try:
         capi.call("gemm_bf16", Y2, Xd, dev_u16(Wb), dev_u16(bb), M, K, N)
     finally:
-        capi.check(lib.mila_cdna4_tune_gemm(0))
+        capi.tune_reset()
     a, b = orc.from_bf16_bits(bits(Y)).astype(np.float64), orc.from_bf16_bits(bits(Y2)).astype(np.float64)
     assert np.abs(a - b).max() <= 2.0 ** -7 * max(np.abs(b).max(), 1e-30)
     need = lib.mila_cdna4_gemm_staging_bytes(M, K, N)
@@ -694,18 +696,18 @@ def test_lds_dma_gemm_serves_a_ragged_n_with_an_odd_row_pitch(M, K, N, bias):
     assert_bf16_close(got[rows], exp, 2 if bias else 1, 2e-3, "ragged-N gemm_bf16")
     if K % 128 == 0:      # the 256 x 256 and the 256 x 128 LDS-DMA kernels accumulate every output in the same order: same bits
         Y3 = torch.empty((M, N), dtype=torch.int16, device="cuda")
-        capi.check(lib.mila_cdna4_tune_gemm_schedule(2))
+        capi.tune("gemm.schedule", 2)
         try:
             capi.call("gemm_bf16", Y3, Xd, Wd, dev_u16(bb) if bias else None, M, K, N)
         finally:
-            capi.check(lib.mila_cdna4_tune_gemm_schedule(5))
+            capi.tune_reset()
         assert np.array_equal(got, bits(Y3)), "256 x 256 ragged-N tiles differ from the 256 x 128 ones"
     Y2 = torch.empty((M, N), dtype=torch.int16, device="cuda")
-    capi.check(lib.mila_cdna4_tune_gemm(1))
+    capi.tune("gemm.force128", 1)
     try:
         capi.call("gemm_bf16", Y2, Xd, Wd, dev_u16(bb) if bias else None, M, K, N)
     finally:
-        capi.check(lib.mila_cdna4_tune_gemm(0))
+        capi.tune_reset()
     a, b = orc.from_bf16_bits(got).astype(np.float64), orc.from_bf16_bits(bits(Y2)).astype(np.float64)
     assert np.abs(a - b).max() <= 2.0 ** -7 * max(np.abs(b).max(), 1e-30)
     assert np.all(guard.cpu().numpy() == 0x1234)
@@ -762,8 +764,8 @@ def test_persistent_tile_walk_gives_the_bits_of_one_workgroup_per_tile(M, K, N, 
         W8 = dev_u8(rng.integers(0, 0x7e, (N, K), dtype=np.uint8) | (rng.integers(0, 2, (N, K), dtype=np.uint8) << 7))
         ts_d, ws_d = dev_f32(rng.uniform(0.5, 2.0, M).astype(np.float32)), dev_f32(np.array([0.013], dtype=np.float32))
     outs = []
-    for sched in (5, 6):
-        capi.check(lib.mila_cdna4_tune_gemm_schedule(sched))
+    for persistent in (1, 0):
+        capi.tune("gemm.persistent", persistent)
         try:
             Y = torch.full((M, N), 0x7fc0, dtype=torch.int16, device="cuda")
             capi.call("gemm_gelu_bf16" if act else "gemm_bf16", Y, Xd, Wd, bd, M, K, N)
@@ -777,7 +779,7 @@ def test_persistent_tile_walk_gives_the_bits_of_one_workgroup_per_tile(M, K, N, 
                 o.append(bits(Yg).copy())
             outs.append(o)
         finally:
-            capi.check(lib.mila_cdna4_tune_gemm_schedule(5))
+            capi.tune_reset()
     for a, b, what in zip(outs[0], outs[1], ("bf16", "fp8 x fp8", "fp8 x fp8 + GeGLU")):
         assert not np.any((a & 0x7fff) > 0x7f80), what + ": unwritten (NaN) outputs"
         assert np.array_equal(a, b), what + ": persistent walk differs from one workgroup per tile"
@@ -793,7 +795,7 @@ def test_persistent_tile_walk_gives_the_bits_of_one_workgroup_per_tile(M, K, N, 
 @pytest.mark.parametrize("M,K,N", [(1, 3840, 8192), (1, 15360, 3840), (1, 4096, 3840), (2, 3840, 30720), (4, 4096, 3840), (3, 2000 + 48, 1000), (4, 8192, 528), (8, 3840, 8192), (16, 2048, 528)])
 def test_skinny_whole_x_form_gives_the_staged_forms_bits(M, K, N):
     """round 3: a <= 4-row tail whose e4m3 image fits 32 KB of LDS (the 1-row tail of a prefill chunk) keeps ALL of X in LDS and streams W without a barrier in the K loop;
-    same products per wave in the same K order, same wave-order reduction -> the bits of the staged skinny form (hook 3 turns the new form off), plain and GeGLU,
+    same products per wave in the same K order, same wave-order reduction -> the bits of the staged skinny form (gemm_fp8.skinny_whole_x = 0 turns the new form off), plain and GeGLU,
     and both within 2 ulp of the restated reference"""
     lib = capi.load()
     rng = np.random.default_rng(M + K + N)
@@ -803,8 +805,8 @@ def test_skinny_whole_x_form_gives_the_staged_forms_bits(M, K, N):
     bb = orc.to_bf16_bits(rng.uniform(-0.1, 0.1, N).astype(np.float32))
     X8, W8, ts_d, ws_d, bd = dev_u8(x8), dev_u8(w8), dev_f32(ts), dev_f32(np.array([ws], dtype=np.float32)), dev_u16(bb)
     outs = []
-    for hook in (4, 3):
-        capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(hook))
+    for whole_x in (1, 0):
+        capi.tune("gemm_fp8.skinny_whole_x", whole_x)
         try:
             Y = torch.full((M, N), 0x7fc0, dtype=torch.int16, device="cuda")
             capi.call("gemm_fp8_scaled", Y, X8, W8, ts_d, ws_d, bd, M, K, N)
@@ -815,7 +817,7 @@ def test_skinny_whole_x_form_gives_the_staged_forms_bits(M, K, N):
                 o.append(bits(Yg).copy())
             outs.append(o)
         finally:
-            capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(4))
+            capi.tune_reset()
     for a, b, what in zip(outs[0], outs[1], ("plain", "GeGLU")):
         assert not np.any((a & 0x7fff) > 0x7f80), what + ": unwritten (NaN) outputs"
         assert np.array_equal(a, b), what + ": the whole-X form differs from the staged skinny form"
@@ -843,11 +845,11 @@ def test_bf16_skinny_kernel_serves_few_rows(M, K, N):
     assert_bf16_close(bits(Y), lin, 2, 2.0 ** -7 * max(1.0, float(np.abs(lin).max())), "skinny gemm_bf16")
     assert np.all(guard[M].cpu().numpy() == 0x1234)
     Yt = empty_u16(M, N)
-    capi.check(lib.mila_cdna4_tune_gemm(3))              # the tile kernels on the same call
+    capi.tune("gemm.bf16_skinny", 0)              # the tile kernels on the same call
     try:
         capi.call("gemm_bf16", Yt, Xd, Wd, bd, M, K, N)
     finally:
-        capi.check(lib.mila_cdna4_tune_gemm(4))
+        capi.tune_reset()
     a, b = orc.from_bf16_bits(bits(Y)).astype(np.float64), orc.from_bf16_bits(bits(Yt)).astype(np.float64)
     assert np.abs(a - b).max() <= 2.0 ** -7 * max(np.abs(b).max(), 1e-30)
     if M > 64:

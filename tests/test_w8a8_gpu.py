@@ -86,11 +86,11 @@ def test_w8a8_prefill_matches_the_oracle_at_every_row_count(M, K, N, bias):
     forms = {}
     for form in (1, 2):
         Yf = empty_u16(M, N)
-        capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(form))
+        capi.tune("gemm_fp8.tail_form", form)
         try:
             capi.call("gemm_fp8_w8a8_ws", Yf, X8, W8, TS, SC, bd, M, K, N, None, C.c_size_t(0))
         finally:
-            capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(0))
+            capi.tune_reset()
         forms[form] = bits(Yf)
         assert_bf16_close(forms[form][rows], exp, 2, 1e-3 * float(np.abs(exp).max()), "W8A8 GEMM, tail form %d" % form)
     if need_ws == 0:
@@ -138,13 +138,13 @@ def test_w8a8_geglu_form_is_bit_identical_to_linear_then_geglu(M, K, F):
     exp = orc.geglu(gu)
     assert_bf16_close(bits(Y1)[rows], exp, 2, 2e-3 * float(np.abs(exp).max()), "W8A8 Linear + GeGLU vs the float64 composition")
     for form in (1, 2):
-        capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(form))
+        capi.tune("gemm_fp8.tail_form", form)
         try:
             capi.call("gemm_geglu_fp8_w8a8", Y2, X8, W8, TS, SC, M, K, F)
             capi.call("gemm_fp8_w8a8_ws", GU, X8, W8, TS, SC, None, M, K, 2 * F, None, C.c_size_t(0))
             capi.call("geglu_bf16", Y0, GU, M, F)
         finally:
-            capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(0))
+            capi.tune_reset()
         assert np.array_equal(bits(Y2), bits(Y0)), "tail form %d: fused GeGLU epilogue != Linear + GeGLU" % form
 
 

@@ -48,7 +48,7 @@ def main():
             x = torch.randn(K, device="cuda").to(torch.bfloat16).view(torch.int16)
             y = torch.empty(N, dtype=torch.int16, device="cuda")
             for mb in (0, 64, 128):
-                lib.mila_cdna4_tune_matvec(0, 0, mb)
+                capi.tune("matvec.max_workgroups", mb)
 
                 def call(i):
                     if fmt == 0:
@@ -57,7 +57,7 @@ def main():
                         capi.call("matvec_bf16_qfp4", y, x, Ws[i % nb], Ss[i % nb], None, K, N, 128)
                 out["matvec %s K=%d N=%d max_blocks=%d" % (fname, K, N, mb)] = round(time_chain(call, n=nb * 2), 2)
             del Ws, Ss
-    lib.mila_cdna4_tune_matvec(0, 0, 0)
+    capi.tune_reset()
     for k, v in out.items():
         print(json.dumps({"case": k, "us_per_launch": round(v, 2)}), flush=True)
 

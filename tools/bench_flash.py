@@ -1,4 +1,4 @@
-"""Time the flash prefill kernel on the Gemma-4 12B attention shapes (T = 2048).  MILA_FLASH_DSPLIT selects a kernel form (tuning hook);
+"""Time the flash prefill kernel on the Gemma-4 12B attention shapes (T = 2048).  MILA_FLASH_DSPLIT selects a kernel form (tuning variable flash.form);
 where the cycles of a tile go: tools/experiments/flash_stamps.sh + flash_stamps.py (a diagnostic build with in-kernel stamps)."""
 import json, os, sys
 os.environ.setdefault("MILA_CDNA4_TUNING", "1")
@@ -9,7 +9,7 @@ T = 2048
 if os.environ.get("MILA_FLASH_LIB"):          # an experiment build of the library (tools/experiments/flash_stamps.sh with FLASH_DEFS=...)
     capi.LIB_PATH = os.environ["MILA_FLASH_LIB"]
 if os.environ.get("MILA_FLASH_DSPLIT"):
-    capi.check(capi.load().mila_cdna4_tune_flash_dsplit(int(os.environ["MILA_FLASH_DSPLIT"])))      # 1: register-staged kernels; 2: HS = 512 as 4-wave d-split workgroups; 8 (default); 9: 8-wave workgroups at HS = 256 too
+    capi.tune("flash.form", int(os.environ["MILA_FLASH_DSPLIT"]))      # csrc/internal.h: 8 default; 9 lockstep 8-wave workgroups at HS 256; 10 ping-pong; 2 / 1 the older forms
 for name, NH, NKV, HS, window in (("local", 16, 8, 256, 1024), ("global", 16, 1, 512, 0)):
     q = (torch.randn((T, NH * HS), device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)
     K = (torch.randn((1, NKV, T, HS), device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)

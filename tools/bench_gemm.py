@@ -19,7 +19,7 @@ for name, K, N in SHAPES:
     W = ((torch.rand((N, K), device="cuda") * 2 - 1) / K ** 0.5).to(torch.bfloat16).view(torch.int16)
     Y = torch.empty((M, N), dtype=torch.int16, device="cuda")
     for force in (0, 1):
-        lib.mila_cdna4_tune_gemm(force)
+        capi.tune("gemm.force128", force)
         for _ in range(3):
             capi.call("gemm_bf16", Y, X, W, None, M, K, N)
         torch.cuda.synchronize()
@@ -32,4 +32,4 @@ for name, K, N in SHAPES:
         ms = e0.elapsed_time(e1) / 10
         print(json.dumps({"shape": name, "M": M, "K": K, "N": N, "kernel": "128x128 regstage" if force else "auto (256x256 glds if applicable)",
                           "us": round(ms * 1e3, 1), "TFLOPs": round(2.0 * M * K * N / ms / 1e9, 1)}), flush=True)
-lib.mila_cdna4_tune_gemm(0)
+capi.tune_reset()

@@ -13,7 +13,7 @@ from mila_amd import capi  # noqa: E402
 M = 2048
 lib = capi.load()
 if len(sys.argv) > 1:
-    lib.mila_cdna4_tune_gemm_schedule(int(sys.argv[1]))      # 3: fp8 shapes prefer the 256 x 128 ring; 4 (default): the two-phase 256 x 256 kernel wherever it applies
+    capi.tune("gemm.schedule", int(sys.argv[1]))      # 3: fp8 shapes prefer the 256 x 128 ring; 4 (default): the two-phase 256 x 256 kernel wherever it applies
 
 
 def timed(fn, n=30):

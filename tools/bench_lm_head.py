@@ -33,11 +33,11 @@ for N in (50176, 50264, 50257):
         X = (torch.rand((M, K), device="cuda") * 2 - 1).to(torch.bfloat16).view(torch.int16)
         W = ((torch.rand((N, K), device="cuda") * 2 - 1) / K ** 0.5).to(torch.bfloat16).view(torch.int16)
         Y = torch.empty((M, N), dtype=torch.int16, device="cuda")
-        for tag, sched, form in (("default", 5, 0), ("direct_stores_persistent", 5, 2), ("direct_stores_one_wg_per_tile", 6, 2), ("ring_256x128", 2, 0)):
-            capi.check(lib.mila_cdna4_tune_gemm_schedule(sched))
-            capi.check(lib.mila_cdna4_tune_gemm(form))
+        for tag, sched, persistent, rowwise in (("default", 5, 1, 1), ("direct_stores_persistent", 5, 1, 0), ("direct_stores_one_wg_per_tile", 5, 0, 0), ("ring_256x128", 2, 1, 1)):
+            capi.tune("gemm.schedule", sched)
+            capi.tune("gemm.persistent", persistent)
+            capi.tune("gemm.rowwise_epilogue", rowwise)
             row["K%d_%s_us" % (K, tag)] = round(timed(lambda: capi.call("gemm_bf16", Y, X, W, None, M, K, N)), 1)
-        capi.check(lib.mila_cdna4_tune_gemm_schedule(5))
-        capi.check(lib.mila_cdna4_tune_gemm(0))
+        capi.tune_reset()
         del X, W, Y
     print(json.dumps(row), flush=True)

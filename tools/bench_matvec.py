@@ -42,7 +42,9 @@ def run(fmt, K, N, R, U, iters, lib, max_blocks=0, hot=False):
         Ss = [torch.rand(N, K // 128, device="cuda") for _ in range(nbuf)]
     x = torch.randn(K, device="cuda").to(torch.bfloat16).view(torch.int16)
     y = torch.empty(N, dtype=torch.int16, device="cuda")
-    lib.mila_cdna4_tune_matvec(R, U, max_blocks)
+    capi.tune("matvec.rows_per_wave", R)
+    capi.tune("matvec.chunks_in_flight", U)
+    capi.tune("matvec.max_workgroups", max_blocks)
 
     def call(i):
         W, s = Ws[i % nbuf], Ss[i % nbuf]
@@ -119,7 +121,7 @@ def main():
                     us, gbps = run(fmt, K, N, R, U, a.iters if N < 100000 else 30, lib, MB, hot=True)
                     print(json.dumps({"kernel": "matvec_hot", "fmt": ["bf16", "fp8", "fp4"][fmt], "shape": name, "K": K, "N": N,
                                       "R": R, "U": U, "us": round(us, 2), "GBps": round(gbps, 1)}), flush=True)
-    lib.mila_cdna4_tune_matvec(0, 0, 0)
+    capi.tune_reset()
 
 
 if __name__ == "__main__":

@@ -7,16 +7,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mila_amd import host
 
 policies = sys.argv[1].split(",") if len(sys.argv) > 1 else ["fp4"]
-if os.environ.get("RAGGED_TUNE"):      # mila_cdna4_tune_gemm codes (csrc/internal.h), e.g. "205" = no split-K, "208,308" = the skinny kernels up to 8 rows only
+if os.environ.get("RAGGED_TUNE"):      # named tuning variables (csrc/internal.h), e.g. "gemm.splitk=0" = no split-K, "gemm.skinny_ahead_rows=8,gemm.splitk_min_rows=9"
     os.environ["MILA_CDNA4_TUNING"] = "1"
     from mila_amd import capi
-    for code in os.environ["RAGGED_TUNE"].split(","):
-        capi.check(capi.load().mila_cdna4_tune_gemm(int(code)))
-if os.environ.get("RAGGED_TUNE_FP8"):      # mila_cdna4_tune_gemm_fp8_tail_only codes
-    os.environ["MILA_CDNA4_TUNING"] = "1"
-    from mila_amd import capi
-    for code in os.environ["RAGGED_TUNE_FP8"].split(","):
-        capi.check(capi.load().mila_cdna4_tune_gemm_fp8_tail_only(int(code)))
+    for kv in os.environ["RAGGED_TUNE"].split(","):
+        name, value = kv.split("=", 1)
+        capi.tune(name, int(value))
 out = {}
 for pol in policies:
     m = host.Gemma(pol, max_seq=4096, max_prefill=2304, seed=1)

@@ -48,17 +48,17 @@ def main():
         fl = 2.0 * M * K * N
         lib = capi.load()
         tv = timeit(vendor)
-        lib.mila_cdna4_tune_gemm_schedule(0)
+        capi.tune("gemm.schedule", 0)
         t0 = timeit(ours)
-        lib.mila_cdna4_tune_gemm_schedule(1)
+        capi.tune("gemm.schedule", 1)
         t1 = timeit(ours)
-        lib.mila_cdna4_tune_gemm_schedule(5)      # the default: two phases per K-tile, static priority
+        capi.tune("gemm.schedule", 5)      # the default: two phases per K-tile, static priority
         t2 = timeit(ours)
         i[0] = 0; ours()
         y3 = Y.clone()
         # same accumulation order in both schedules: the outputs must be bit-identical
-        lib.mila_cdna4_tune_gemm_schedule(0); i[0] = 0; ours(); y0 = Y.clone()
-        lib.mila_cdna4_tune_gemm_schedule(1); i[0] = 0; ours(); same = bool(torch.equal(y0, Y)) and bool(torch.equal(y0, y3))
+        capi.tune("gemm.schedule", 0); i[0] = 0; ours(); y0 = Y.clone()
+        capi.tune("gemm.schedule", 1); i[0] = 0; ours(); same = bool(torch.equal(y0, Y)) and bool(torch.equal(y0, y3))
         ref = (X.float() @ Ws[1].float().t())
         err = float((Y.float() - ref).abs().max() / ref.abs().max())
         print(json.dumps({"shape": name, "M": M, "K": K, "N": N, "vendor_us": round(tv, 1), "vendor_TFLOPs": round(fl / tv / 1e6, 1),

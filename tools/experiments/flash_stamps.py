@@ -14,7 +14,7 @@ from mila_amd import capi  # noqa: E402
 capi.LIB_PATH = os.path.join(ROOT, "tools", "experiments", "_build", "libmila_cdna4_stamps.so")
 lib = capi.load()
 if os.environ.get("MILA_FLASH_DSPLIT"):
-    capi.check(lib.mila_cdna4_tune_flash_dsplit(int(os.environ["MILA_FLASH_DSPLIT"])))
+    capi.tune("flash.form", int(os.environ["MILA_FLASH_DSPLIT"]))
 T = 2048
 for name, NH, NKV, HS, window in (("local", 16, 8, 256, 1024), ("global", 16, 1, 512, 0)):
     q = (torch.randn((T, NH * HS), device="cuda") * 0.5).to(torch.bfloat16).view(torch.int16)

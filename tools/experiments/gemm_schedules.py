@@ -1,4 +1,4 @@
-"""gemm256_kernel schedules side by side on the Gemma prefill shapes: tune_gemm_schedule 4 (two phases per K-tile) against 5 / 6 (8 / 16 of a
+"""gemm256_kernel schedules side by side on the Gemma prefill shapes: gemm.schedule 4 (two phases per K-tile) against 5 / 6 (6 = 5 with gemm.persistent = 0) (8 / 16 of a
 phase's MFMAs issued behind its closing barrier).  Same instruction sequence per accumulator => the outputs must be bit-identical."""
 import os
 os.environ.setdefault("MILA_CDNA4_TUNING", "1")
@@ -20,7 +20,8 @@ for name, K, N in (("qkv_local", 3840, 8192), ("gate_up", 3840, 30720), ("o_loca
     ref = None
     for rep in range(4):
         for sc in scheds:
-            lib.mila_cdna4_tune_gemm_schedule(sc)
+            capi.tune("gemm.schedule", 5 if sc == 6 else sc)
+            capi.tune("gemm.persistent", 0 if sc == 6 else 1)
             for _ in range(5):
                 capi.call("gemm_bf16", Y, X, W, None, M, K, N)
             torch.cuda.synchronize()
@@ -35,4 +36,4 @@ for name, K, N in (("qkv_local", 3840, 8192), ("gate_up", 3840, 30720), ("o_loca
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 30
             print(json.dumps({"shape": name, "schedule": sc, "rep": rep, "us": round(ms * 1e3, 1), "TFLOPs": round(2.0 * M * K * N / ms / 1e9, 1), "same_bits": same}), flush=True)
-lib.mila_cdna4_tune_gemm_schedule(5)      # the default
+capi.tune_reset()

@@ -1,4 +1,4 @@
-"""fp4-policy prefill of SHORT prompts by dispatch rule of the W4A8 GEMMs below 512 rows (mila_cdna4_tune_gemm_fp8_tail_only 5 / 6 / 7):
+"""fp4-policy prefill of SHORT prompts by dispatch rule of the W4A8 GEMMs below 512 rows (gemm_fp8.big_rule 0 / 1 / 2 / 3):
 0 = masked 128-row tiles (default), 1 = LDS-DMA kernels from 128 rows on, 2 = LDS-DMA kernels where their grid has >= 120 tiles.
     MILA_CDNA4_TUNING=1 python tools/experiments/short_prompt_rules.py"""
 import json
@@ -13,13 +13,13 @@ lib = capi.load()
 m = host.Gemma("fp4", max_seq=2048, max_prefill=1024, seed=1)
 out = {}
 for rule in (0, 1, 2, 3):
-    capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(5 + rule))
+    capi.tune("gemm_fp8.big_rule", rule)
     res = {}
     for T in (65, 100, 200, 300, 320, 400, 511, 700, 1000):
         m.time_prefill(T, 1)
         res[T] = round(m.time_prefill(T, 3), 3)
     out["rule%d" % rule] = res
     print(rule, res, flush=True)
-capi.check(lib.mila_cdna4_tune_gemm_fp8_tail_only(5))
+capi.tune_reset()
 m.close()
 print(json.dumps(out))

@@ -12,7 +12,7 @@ from mila_amd import capi  # noqa: E402
 K, N = int(sys.argv[1]), int(sys.argv[2])
 lib = capi.load()
 if len(sys.argv) > 3:
-    lib.mila_cdna4_tune_gemm_schedule(int(sys.argv[3]))
+    capi.tune("gemm.schedule", int(sys.argv[3]))
 M = 2048
 X = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
 Ws = [(torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16) for _ in range(3)]
