@@ -125,6 +125,9 @@ static int dispatch_RU(const MatvecParams& p, hipStream_t s)
     if (g_tune_R > 0) R = g_tune_R;
     if (g_tune_U > 0) U = g_tune_U;
     if (g_tune_blocks > 0) max_blocks = g_tune_blocks;
+    // the argmax epilogue writes one (value, index) partial per WORKGROUP into the sampler's scratch of kArgmaxPartials slots: the grid is capped BEFORE the launch
+    // (the count was only checked afterwards -- a tuned or future workgroup rule beyond 512 would have overrun the scratch first)
+    if (p.amax_v && max_blocks > kArgmaxPartials) max_blocks = kArgmaxPartials;
     if (GEGLU && R > 2) R = 2;
     if (R == 1 && U == 1) return launch<FMT, 1, 1, PRO, GEGLU, F32OUT>(p, max_blocks, s);
     if (R == 1 && U == 2) return launch<FMT, 1, 2, PRO, GEGLU, F32OUT>(p, max_blocks, s);

@@ -537,6 +537,17 @@ def test_lm_head_epilogue_runs_the_samplers_first_stage(fmt, N, with_res):
     assert np.array_equal(host(logits2).view(np.uint32), lg.view(np.uint32))
     with pytest.raises(capi.InvalidArgument):
         capi.call("sample_argmax_final_advance", tok, scratch, C.c_size_t(nb), 0, pos, seq, ring, 4)
+    # a workgroup rule beyond the sampler's 512 partial slots (here a tuned 2048) is capped BEFORE the launch -- the scratch's guard bytes stay, the token is the same
+    guarded = torch.full((nb + 4096,), 0x5A, dtype=torch.uint8, device="cuda")
+    a.argmax_scratch = guarded.data_ptr()
+    try:
+        capi.tune("matvec.max_workgroups", 2048)
+        capi.check(lib.mila_cdna4_fused_norm_matvec(C.byref(a), stream))
+    finally:
+        capi.tune_reset()
+    assert 0 < blocks.value <= nb // 8 and bool((guarded[nb:] == 0x5A).all()), "the argmax epilogue wrote past its partial slots"
+    capi.call("sample_argmax_final_advance", tok, guarded[:nb], C.c_size_t(nb), blocks.value, pos, seq, ring, 4)
+    assert int(host(tok)[0]) == rows[0]
 
 
 @pytest.mark.parametrize("B,pos", [(1, 0), (1, 37), (1, 5000), (1, 8191), (2, 4500)])

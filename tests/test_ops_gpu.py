@@ -128,6 +128,36 @@ def test_gelu_residual_scale(n):
     assert np.array_equal(bits(Y), orc.to_bf16_bits(X * np.float32(s)))     # static_cast<T>(float(x)*s)
 
 
+def test_gelu_over_every_finite_bf16_input():
+    """the device evaluates the reference's GELU functor (ElementwiseActivation.h:41-50: 0.5 x (1 + tanhf(u))) as x / (1 + exp(-2 u)) on v_exp_f32 + v_rcp_f32.
+    All 65 280 finite bf16 inputs: the rounded results are IDENTICAL to the functor's except on a bounded set inside x in [-10, -2.98] -- the negative tail, where the
+    functor's (1 + tanhf) cancels (its absolute error 0.5 |x| 2^-24 is then a large fraction of |y| < 4e-3, and it returns -0 below x ~ -5.2 where the function is -6e-8).
+    There: at most 1 bf16 ulp for x >= -4.54, at most 1e-7 absolute below; no more than 160 such inputs (measured 150); and against the float64 formula the device form is
+    the closer of the two (72 inputs differ from round(float64), the functor's 92).  The deviation is stated in DESIGN.md / INTEGRATION.md."""
+    allb = np.arange(65536, dtype=np.uint32).astype(np.uint16)
+    x = orc.from_bf16_bits(allb)
+    fin = np.isfinite(x)
+    xb, xf = allb[fin], x[fin]
+    assert xb.size == 65280
+    Y = empty_u16(xb.size)
+    capi.call("gelu_bf16", Y, dev_u16(xb), C.c_int64(xb.size))
+    got_b = bits(Y)
+    exp_b = orc.to_bf16_bits(orc.cpu_gelu(xf))
+    got, exp = orc.from_bf16_bits(got_b).astype(np.float64), orc.from_bf16_bits(exp_b).astype(np.float64)
+    differ = got_b != exp_b
+    differ &= ~((got == 0) & (exp == 0))                      # (+0 / -0)
+    assert int(differ.sum()) <= 160, int(differ.sum())
+    assert np.all((xf[differ] >= -10.0) & (xf[differ] <= -2.98)), (float(xf[differ].min()), float(xf[differ].max()))
+    ulp = np.abs(exp) * 2.0 ** -7                              # (an upper bound of one bf16 ulp of the expected value)
+    err = np.abs(got - exp)
+    assert np.all(err[differ] <= np.maximum(ulp[differ], 1e-7)), float((err[differ] - np.maximum(ulp[differ], 1e-7)).max())
+    hi = differ & (xf >= -4.54)
+    assert np.all(err[hi] <= ulp[hi])
+    x64 = xf.astype(np.float64)
+    f64 = orc.to_bf16_bits((0.5 * x64 * (1 + np.tanh(0.7978845608028654 * (x64 + 0.044715 * x64 ** 3)))).astype(np.float32))
+    assert int((got_b != f64).sum()) <= int((exp_b != f64).sum())
+
+
 @pytest.mark.parametrize("tokens,half", [(3, 8), (1, 15360), (5, 1024)])
 def test_geglu(tokens, half):
     rng = np.random.default_rng(half)
