@@ -121,9 +121,12 @@ MILA_API int mila_cdna4_gemm_bf16_w4a16(uint16_t* Y, const uint16_t* X, const ui
 /* Linear + GeGLU in ONE kernel for the prefill fc_gate_up (Components/Transformers/Gemma/Gemma.Block.ixx:343-348: the
  * Linear writes [M, 2F] = [gate | up], the GeGLU kernel reads it back): Y[M, F] = bf16(gelu_tanh(bf16(gate)) * bf16(up)),
  * gate = X W[0:F]^T, up = X W[F:2F]^T.  A tile pairs 128 gate rows with the matching 128 up rows; results are
- * bit-identical to gemm_bf16 + geglu_bf16.  gemm_geglu_applicable() != 0 says the fused kernel serves (M, K, F); the
- * _staged forms dequantize the whole [2F, K] weight to `scratch` (2 * F * K * 2 bytes) first. */
+ * bit-identical to gemm_bf16 + geglu_bf16.  gemm_geglu_applicable() != 0 says the fused kernels serve (M, K, F) -- every shape they can run; the
+ * _staged forms dequantize the whole [2F, K] weight to `scratch` (2 * F * K * 2 bytes) first.
+ * gemm_geglu_preferred() != 0: for a caller that holds the gemm_bf16_ws workspace the fused form is also the FASTER choice; 0 where that caller's
+ * gemm_bf16_ws (split-K) + geglu_bf16 pair wins (few-row prompts, short tile lists) -- RocmLinearOp / GemmaBlock ask this one. */
 MILA_API int mila_cdna4_gemm_geglu_applicable(int M, int K, int F);
+MILA_API int mila_cdna4_gemm_geglu_preferred(int M, int K, int F);
 MILA_API int mila_cdna4_gemm_geglu_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F,
                                         mila_stream_t stream);
 MILA_API int mila_cdna4_gemm_geglu_bf16_w8a16_staged(uint16_t* Y, const uint16_t* X, const uint8_t* W,

@@ -170,7 +170,7 @@ EXPORTED = [
     "gemm_bf16", "gemm_gelu_bf16", "gemm_workspace_bytes", "gemm_bf16_ws", "gemm_bf16_w8a16", "gemm_bf16_w4a16", "gemm_staging_bytes", "gemm_bf16_w8a16_staged", "gemm_bf16_w4a16_staged",
     "fp4_weight_fp8_scale", "upcast_fp4_to_fp8", "quantize_fp8_per_token", "gemm_fp8_applicable", "gemm_fp8_scaled", "gemm_fp8_workspace_bytes", "gemm_fp8_scaled_ws",
     "gemm_w4a8_scratch_bytes", "gemm_bf16_w4a8", "gemm_geglu_w4a8_applicable", "gemm_geglu_bf16_w4a8",
-    "gemm_geglu_applicable", "gemm_geglu_bf16", "gemm_geglu_bf16_w8a16_staged", "gemm_geglu_bf16_w4a16_staged",
+    "gemm_geglu_applicable", "gemm_geglu_preferred", "gemm_geglu_bf16", "gemm_geglu_bf16_w8a16_staged", "gemm_geglu_bf16_w4a16_staged",
     "quantize_fp8_per_channel", "quantize_fp4_per_group",
     "kv_write_bf16", "attn_decode_scratch_bytes", "attn_decode_bf16", "attn_prefill_bf16", "mha_bf16", "mha_kv_write_bf16", "mha_decode_scratch_bytes", "mha_decode_bf16",
     "rmsnorm_bf16", "rmsnorm_fp32", "layernorm_bf16", "layernorm_fp32", "softmax_fp32", "softmax_bf16",

@@ -534,18 +534,23 @@ static int launch_bf16_rows_ws(uint16_t* Y, const uint16_t* X, const uint16_t* W
 
 // Linear + GeGLU over any row count the fused forms serve: the LDS-DMA GeGLU kernel on whole / ragged tile-rows, the skinny GeGLU kernel on <= 64 rows (a short prompt,
 // or the remainder of a long one)
-static bool geglu_rows_applicable(int M, int K, int F)
+static bool geglu_rows_applicable(int M, int K, int F)      // what the fused kernels can run
 {
-    // where the plain GEMM over the [2F, K] weight would split K given a workspace, the fused form steps aside: the caller's Linear (gemm_bf16_ws) + GeGLU pair is the
-    // faster one there, and fused and unfused prefill keep identical bits (the fused kernels sum K in one order only)
-    if (bf16_ws_plan(M, K, 2 * F).S) return false;
     if (gemm256_geglu_applicable(M, K, F)) return true;
     if (!g_bf16_skinny) return false;
-    // few rows: the skinny GeGLU kernel -- past g_skinny_ahead_rows only where the plain Linear over [2F, K] has no LDS-DMA grid either (with one, Linear + GeGLU as two
-    // launches is the faster pair: fc_gate_up at 64 rows 196 us skinny, ~55 as a one-round tile grid + the elementwise pass)
-    if (M <= kBf16SkinnyRows) return M <= g_skinny_ahead_rows || !glds_kernel_for(M, K, 2 * F);
+    if (M <= kBf16SkinnyRows) return true;                  // few rows: the skinny GeGLU kernel
     const int tail = M % 256;
     return M >= 512 && tail > 0 && tail <= kBf16SkinnyRows && gemm256_geglu_applicable(M - tail, K, F);
+}
+// ... and where they are also the faster choice for a caller that holds the gemm_bf16_ws workspace (RocmLinearOp / GemmaBlock): not where the plain GEMM over the
+// [2F, K] weight would split K (that Linear + GeGLU pair is faster, and fused and unfused prefill keep identical bits: the fused kernels sum K in one order only), and,
+// past g_skinny_ahead_rows, not where the plain Linear has an LDS-DMA grid (fc_gate_up at 64 rows: 196 us skinny, ~55 as a one-round tile grid + the elementwise pass)
+static bool geglu_rows_preferred(int M, int K, int F)
+{
+    if (!geglu_rows_applicable(M, K, F) || bf16_ws_plan(M, K, 2 * F).S) return false;
+    if (gemm256_geglu_applicable(M, K, F)) return true;
+    if (M <= kBf16SkinnyRows) return M <= g_skinny_ahead_rows || !glds_kernel_for(M, K, 2 * F);
+    return true;
 }
 static int launch_geglu_rows(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, hipStream_t s)
 {
@@ -685,6 +690,13 @@ int mila_cdna4_gemm_bf16_w4a16_staged(uint16_t* Y, const uint16_t* X, const uint
 int mila_cdna4_gemm_geglu_applicable(int M, int K, int F)
 {
     return (M > 0 && K > 0 && F > 0 && K % 8 == 0 && !g_gemm_force128 && geglu_rows_applicable(M, K, F)) ? 1 : 0;
+}
+// for a caller that HOLDS the gemm_bf16_ws workspace: where the plain GEMM over the [2F, K] weight would split K (few-row prompts, short tile lists), its
+// Linear (gemm_bf16_ws) + GeGLU pair is the faster one and the fused form steps aside -- a host decision (it used to hide inside gemm_geglu_applicable,
+// so a caller WITHOUT a workspace lost the fused kernels on those shapes for nothing)
+int mila_cdna4_gemm_geglu_preferred(int M, int K, int F)
+{
+    return (mila_cdna4_gemm_geglu_applicable(M, K, F) && geglu_rows_preferred(M, K, F)) ? 1 : 0;
 }
 
 int mila_cdna4_gemm_geglu_bf16(uint16_t* Y, const uint16_t* X, const uint16_t* W, int M, int K, int F, mila_stream_t stream)

@@ -607,7 +607,7 @@ namespace Mila::Dnn
                     return;
                 }
             }
-            if ( !w4a8 && mila_cdna4_gemm_geglu_applicable( T, (int)D, (int)cfg_.hidden_dim ) )
+            if ( !w4a8 && mila_cdna4_gemm_geglu_preferred( T, (int)D, (int)cfg_.hidden_dim ) )      // (this caller holds the split-K workspace)
             {
                 // Linear + GeGLU in one kernel: the [T, 2F] gate|up intermediate never reaches memory (bit-identical to the pair)
                 const int F = (int)cfg_.hidden_dim;

@@ -119,9 +119,9 @@ def test_gemm_workspace_planner_is_host_logic(lib):
                 assert lib.mila_cdna4_gemm_staging_bytes(M, K, N) == N * K * 2 + ws(M, K, N)
             pad = lambda b: (b + 15) & ~15
             assert lib.mila_cdna4_gemm_w4a8_scratch_bytes(M, K, N) == pad(N * K) + pad(M * K) + pad(M * 4) + ws8(M, K, N)
-    # the fused GeGLU forms step aside exactly where the plain GEMM over [2F, K] would split
-    assert lib.mila_cdna4_gemm_geglu_applicable(300, D, F) == 1 and lib.mila_cdna4_gemm_geglu_w4a8_applicable(300, D, F) == 1
-    assert ws(24, 1280, 5120) > 0 and lib.mila_cdna4_gemm_geglu_applicable(24, 1280, 2560) == 0
+    # a caller WITH a workspace prefers the Linear + GeGLU pair exactly where the plain GEMM over [2F, K] would split K; the fused entry still serves the shape
+    assert lib.mila_cdna4_gemm_geglu_applicable(300, D, F) == 1 and lib.mila_cdna4_gemm_geglu_preferred(300, D, F) == 1 and lib.mila_cdna4_gemm_geglu_w4a8_applicable(300, D, F) == 1
+    assert ws(24, 1280, 5120) > 0 and lib.mila_cdna4_gemm_geglu_preferred(24, 1280, 2560) == 0 and lib.mila_cdna4_gemm_geglu_applicable(24, 1280, 2560) == 1
     assert ws8(100, 2560, 5120) > 0 and lib.mila_cdna4_gemm_geglu_w4a8_applicable(100, 2560, 2560) == 0
 
 
