@@ -329,13 +329,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
     // double-buffered tiles, one barrier per tile: the 8-wave form, and every HS <= 256 form (two [K | V] pairs are 64 KB there: two workgroups still share a CU)
     constexpr bool DB = (NW == 8) || (HS <= 256);
     constexpr bool ASM_TR = !(HS >= 512 && DS == 1);         // V^T fragments by inline-assembly reads (every form but the spilling one, see the tile body)
+    // HS = 512 (round 4): S^T is the SUM OF TWO half-dimension products in every form, so that all forms give the same bits.  With DS = 2 the two d-share waves
+    // of a (head, row block) each multiply ONE half -- half the K fragment reads, half the QK^T MFMAs, half the Q fragment registers -- and exchange their
+    // partial scores through 2 KB of LDS per wave (both then add own + partner: the same two numbers); before, each of them computed the whole product.
+    constexpr bool HALVES = HS >= 512;
+    constexpr bool XCH = HALVES && DS == 2;
     constexpr int QB = NW / (HB * DS);
     static_assert(QB >= 1, "at most NW (head, d-half) pairs per workgroup");
     constexpr int QROWS = 16 * QB;
     constexpr int KSTEPS = HS / 32;          // MFMA k-steps of the QK^T product
+    constexpr int KOWN = XCH ? KSTEPS / 2 : KSTEPS;      // ... of which this wave multiplies (its half under the exchange)
     constexpr int DT = HS / 16 / DS;         // 16-wide d tiles of O^T this wave owns
     constexpr int ROWB = HS * 2;
     constexpr int TILE_BYTES = kKeysPerTile * ROWB;
+    constexpr int XCH_OFF = ((NW == 8) || (HS <= 256) ? 4 : 2) * TILE_BYTES;      // the exchange area behind the tile buffers: [wave][lane][8 floats]
     constexpr int RPI = 1024 / ROWB;                     // K / V rows one LDS-DMA wave-instruction (64 lanes x 16 bytes) covers
     static_assert(RPI == 1 || RPI == 2, "HS = 512 or 256");
     constexpr int CPR = ROWB / 16;                       // 16-byte chunks per row
@@ -368,12 +375,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
     const bool row_valid = my_row < p.Tq;
     const int my_pos = p.pos_offset + (row_valid ? my_row : p.Tq - 1);
 
-    // ---- Q fragments: B operand of S^T = K Q^T: lane holds Q[row l15][32 s + 8 g + j] ----
-    s16x8 qf[KSTEPS];
+    // ---- Q fragments: B operand of S^T = K Q^T: lane holds Q[row l15][32 s + 8 g + j]; under the exchange only this wave's half of the dimensions ----
+    s16x8 qf[KOWN];
     {
-        const uint16_t* qp = p.Q + ((size_t)b * p.Tq + (row_valid ? my_row : 0)) * p.q_row_stride + (size_t)h * HS + 8 * g;
+        const uint16_t* qp = p.Q + ((size_t)b * p.Tq + (row_valid ? my_row : 0)) * p.q_row_stride + (size_t)h * HS + 8 * g + (XCH ? dsel * (HS / 2) : 0);
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
+        for (int s = 0; s < KOWN; ++s)
         {
             const u32x4 v = row_valid ? ld16(qp + 32 * s) : u32x4{0u, 0u, 0u, 0u};
             qf[s] = __builtin_bit_cast(s16x8, v);
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
     // (256 bytes) and the second 16-key group of a tile is 16 rows further: four K and eight V offsets per lane, everything else is an immediate.
     int kaddr[4], vaddr[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) kaddr[i] = k_off<HS>(l15, 4 * i + g);
+    for (int i = 0; i < 4; ++i) kaddr[i] = k_off<HS>(l15, 4 * i + g) + (XCH ? dsel * (KOWN / 4) * 256 : 0);      // (under the exchange: this wave's half of the k-steps)
 #pragma unroll
     for (int i = 0; i < 8; ++i)
     {
@@ -551,9 +558,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
 
         // ---- S^T = K Q^T : two 16-key groups; the fragments of KB k-steps are requested together, then multiplied ----
         f32x4 s0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, s1 = s0;
+        f32x4 h0 = s0, h1 = s0;                                  // HALVES without the exchange (one wave per head): the upper half's product, added below
         constexpr int KB = (HS >= 512) ? 4 : 8;                  // k-steps whose fragments are fetched together (registers: HS = 512 holds 64 of Q)
-        constexpr int KPER = KSTEPS / DMAS;                      // one K request behind every KPER k-steps of fragment reads
-        static_assert(KSTEPS % DMAS == 0 && DT % DMAS == 0, "requests spread evenly over the fragment reads");
+        constexpr int KPER = (KOWN >= DMAS) ? KOWN / DMAS : 1;   // one K request behind every KPER k-steps of fragment reads
+        static_assert((KOWN % DMAS == 0 || DMAS % KOWN == 0) && DT % DMAS == 0, "requests spread evenly over the fragment reads");
+        constexpr int RPK = (DMAS > KOWN) ? DMAS / KOWN : 1;     // ... or RPK requests behind every k-step where a wave has more requests than k-steps
         auto k_group = [&](auto s8c) {
             constexpr int s8 = decltype(s8c)::value;
             s16x8 ka[KB], kb[KB];
@@ -563,7 +572,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
                 constexpr int s_ = s8 + j;
                 ka[j] = *reinterpret_cast<const s16x8*>(ldsK + kaddr[s_ & 3] + (s_ >> 2) * 256);
                 kb[j] = *reinterpret_cast<const s16x8*>(ldsK + kaddr[s_ & 3] + (s_ >> 2) * 256 + 16 * ROWB);
-                if constexpr ((s_ + 1) % KPER == 0) next_k(std::integral_constant<int, (s_ + 1) / KPER - 1>{});
+                if constexpr ((s_ + 1) % KPER == 0)
+                    static_for<RPK>([&](auto rc) { next_k(std::integral_constant<int, ((s_ + 1) / KPER - 1) * RPK + decltype(rc)::value>{}); });
             };
             static_for<KB>(rd);
             __builtin_amdgcn_sched_barrier(0);
@@ -572,17 +582,33 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
 #pragma unroll
             for (int j = 0; j < KB; ++j)
             {
-                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s1, 0, 0, 0);
+                if (HALVES && !XCH && s8 + j >= KSTEPS / 2)
+                {
+                    h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), h0, 0, 0, 0);
+                    h1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), h1, 0, 0, 0);
+                }
+                else
+                {
+                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s1, 0, 0, 0);
+                }
             }
         };
-        static_for<KSTEPS / KB>([&](auto gc) { k_group(std::integral_constant<int, decltype(gc)::value * KB>{}); });
+        static_for<KOWN / KB>([&](auto gc) { k_group(std::integral_constant<int, decltype(gc)::value * KB>{}); });
+        if constexpr (HALVES && !XCH) { s0 += h0; s1 += h1; }
+        if constexpr (XCH)
+        {
+            // this wave's half of the scores out to LDS; the partner's (wave ^ HB: the other d-share of the same head and rows) back after the barrier
+            f32x4* xw = reinterpret_cast<f32x4*>(smem + XCH_OFF) + (wave * 64 + lane) * 2;
+            xw[0] = s0; xw[1] = s1;
+        }
         if constexpr (MODE == 2)
         {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's V rows of tile t
             __syncthreads();                                     // every wave is done with K(t), and V(t) is complete
             if (t + 1 < ntiles) stage_k(kt + kKeysPerTile, ldsK);      // in flight during the softmax and the PV product
         }
+        else if constexpr (XCH) __syncthreads();                 // (double-buffered forms: a second barrier per tile, for the exchange only)
         // ---- V^T fragments of the wave's d tiles, requested here so that they land under the softmax ----
         // A operand: V^T[dim 16 d + l15][keys]: two transposing reads (keys 4 g .. and 16 + 4 g ..)
         // (inline-assembly reads: the intrinsic form would wait here for the NEXT tile's LDS-DMA, see attention_tiles.h.  NOT in the form that keeps a whole
@@ -618,6 +644,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
                 for (int i = 0; i < 8; ++i) vb[i] = vaddr_lds[i] + (unsigned)(rbuf + TILE_BYTES);
                 read_vt_frags<ROWB, 0>(vb, va, after, std::make_integer_sequence<int, DT>{});
             }
+        }
+        if constexpr (XCH)
+        {
+            const f32x4* xr = reinterpret_cast<const f32x4*>(smem + XCH_OFF) + ((wave ^ HB) * 64 + lane) * 2;
+            s0 += xr[0]; s1 += xr[1];
         }
 #ifdef MILA_FLASH_STAMPS
         if (stamping && s0[0] == 12345.678f) seg[4] += 1;          // the stamp waits for the products
@@ -663,7 +694,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
 #endif
         FLASH_STAMP(4);
     };
-    if constexpr (DB && HS >= 512)
+    if constexpr (DB && HS >= 512 && !XCH)
     {
         for (int t = 0; t < ntiles; t += 2)
         {
@@ -845,6 +876,7 @@ __global__ __launch_bounds__(512, 1) void flash_prefill_pp_kernel(const FlashPar
         constexpr bool REQ = decltype(req_c)::value;
         unsigned char* ldsK = smem + BUF * 2 * TILE_BYTES;
         s0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; s1 = s0;
+        f32x4 h0 = s0, h1 = s0;
         constexpr int KB = (HS >= 512) ? 4 : 8;
         constexpr int KPER = KSTEPS / DMAS;
         static_for<KSTEPS / KB>([&](auto gc) {
@@ -865,11 +897,20 @@ __global__ __launch_bounds__(512, 1) void flash_prefill_pp_kernel(const FlashPar
 #pragma unroll
             for (int j = 0; j < KB; ++j)
             {
-                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s1, 0, 0, 0);
+                if constexpr (HS >= 512 && s8 >= KSTEPS / 2)
+                {
+                    h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), h0, 0, 0, 0);
+                    h1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), h1, 0, 0, 0);
+                }
+                else
+                {
+                    s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), s1, 0, 0, 0);
+                }
             }
             __builtin_amdgcn_s_setprio(0);
         });
+        if constexpr (HS >= 512) { s0 += h0; s1 += h1; }       // HS = 512: S^T is the sum of the two half-dimension products in every form (same bits as the exchanging forms)
         {
             constexpr int VOFF = BUF * 2 * TILE_BYTES + TILE_BYTES;
             constexpr int SPAN = ((DT - 1) >> 3) * 256 + 16 * ROWB;
@@ -1020,7 +1061,7 @@ template <int HS, int HB>
 static int launch_flash(const FlashParams& p, int B, hipStream_t s)
 {
     constexpr int QROWS = 16 * (4 / HB);
-    const size_t lds = (size_t)(HS >= 512 ? 2 : 4) * kKeysPerTile * HS * 2;      // HS <= 256: two [K | V] buffers
+    const size_t lds = (size_t)(HS >= 512 ? 2 : 4) * kKeysPerTile * HS * 2;      // HS <= 256: two [K | V] buffers (HS = 512 here: one wave per head, no exchange area)
     FlashParams q = p;
     q.n_qtiles = (p.Tq + QROWS - 1) / QROWS;
     q.n_hblk = p.NH / HB;
@@ -1036,7 +1077,7 @@ static int launch_flash_dma(const FlashParams& p, int B, hipStream_t s)
 {
     constexpr int QROWS = 16 * (NW / (HB * DS));
     constexpr bool DB = (NW == 8) || (HS <= 256);
-    const size_t lds = (size_t)(DB ? 4 : 2) * kKeysPerTile * HS * 2;
+    const size_t lds = (size_t)(DB ? 4 : 2) * kKeysPerTile * HS * 2 + ((HS >= 512 && DS == 2) ? (size_t)NW * 2048 : 0);      // + the score-exchange area
     FlashParams q = p;
     q.n_qtiles = (p.Tq + QROWS - 1) / QROWS;
     q.n_hblk = p.NH / HB;
