@@ -321,9 +321,10 @@ __device__ unsigned long long g_flash_stamps[16];
 // NW = 8 (HB = 4, DS = 2): ONE 8-wave workgroup per CU -- four heads x two d-halves share every K / V tile (half the L2 -> LDS traffic per FLOP of the 4-wave
 // form), the tiles are double-buffered in 128 KB of LDS, so tile t + 1 is requested at the top of tile t and lands under a whole tile of arithmetic, and
 // one barrier per tile suffices (it says both "tile t is here" and "everybody is done with tile t - 1").
-template <int HS, int HB, int DS, int NW = 4>
+template <int HS, int HB, int DS, int NW = 4, bool PIPE = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void flash_prefill_kernel_s1(const FlashParams p)
 {
+    static_assert(!PIPE || (NW == 8) || (HS <= 256), "the software-pipelined loop is a form of the double-buffered kernels");
     static_assert(DS == 1 || DS == 2, "d-split");
     static_assert(NW == 4 || (NW == 8 && ((HB == 4 && DS == 2) || (HB == 2 && DS == 1))), "workgroup shapes");
     // double-buffered tiles, one barrier per tile: the 8-wave form, and every HS <= 256 form (two [K | V] pairs are 64 KB there: two workgroups still share a CU)
@@ -342,7 +343,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
     constexpr int DT = HS / 16 / DS;         // 16-wide d tiles of O^T this wave owns
     constexpr int ROWB = HS * 2;
     constexpr int TILE_BYTES = kKeysPerTile * ROWB;
-    constexpr int XCH_OFF = ((NW == 8) || (HS <= 256) ? 4 : 2) * TILE_BYTES;      // the exchange area behind the tile buffers: [wave][lane][8 floats]
+    constexpr int XCH_OFF = ((NW == 8) || (HS <= 256) ? 4 : 2) * TILE_BYTES;      // the exchange area behind the tile buffers: [wave][lane][8 floats] (PIPE: two of them, by tile parity)
+    constexpr int XCH_BYTES = NW * 2048;
     constexpr int RPI = 1024 / ROWB;                     // K / V rows one LDS-DMA wave-instruction (64 lanes x 16 bytes) covers
     static_assert(RPI == 1 || RPI == 2, "HS = 512 or 256");
     constexpr int CPR = ROWB / 16;                       // 16-byte chunks per row
@@ -694,7 +696,203 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
 #endif
         FLASH_STAMP(4);
     };
-    if constexpr (DB && HS >= 512 && !XCH)
+    // ---- PIPE: the software-pipelined loop of the double-buffered forms.  K runs ONE TILE AHEAD of V: iteration t multiplies K(t + 1) Q^T (matrix cores) while the
+    // vector ALU runs the softmax step of tile t -- the two are independent, where the plain loop's tile is a chain K reads -> QK^T -> softmax -> PV with idle
+    // matrix cores under the softmax -- and, under the exchange, the partner's half of S^T(t) was written a whole iteration earlier, so the exchange needs no
+    // barrier of its own (one barrier per tile again; the exchange area is double-buffered by tile parity).
+    //   iteration t:   wait + barrier | K(t + 2) -> K slot of buffer t & 1 (K(t) was multiplied in iteration t - 1), V(t + 1) -> V slot of buffer (t + 1) & 1
+    //                  S(t + 1) = K(t + 1) Q^T from buffer (t + 1) & 1  ||  softmax(S(t))  |  O += V(t)^T P from buffer t & 1
+    //   landed: K(t + 1) and V(t) were requested in iteration t - 1 and waited for at the top of iteration t.
+    f32x4 sc0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, sc1 = sc0;         // S^T of the tile whose softmax comes next (this wave's half under the exchange)
+    // S^T(tq) from the K image at `img` into (a0, a1); MODE 0 interleaves the requests of K(tq + 1)
+    auto qk_tile = [&](unsigned char* img, f32x4& a0, f32x4& a1, auto reqs) {
+        a0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; a1 = a0;
+        f32x4 h0 = a0, h1 = a0;
+        constexpr int KB = (HS >= 512) ? 4 : 8;
+        constexpr int KPER = (KOWN >= DMAS) ? KOWN / DMAS : 1;
+        constexpr int RPK = (DMAS > KOWN) ? DMAS / KOWN : 1;
+        static_for<KOWN / KB>([&](auto gc) {
+            constexpr int s8 = decltype(gc)::value * KB;
+            s16x8 ka[KB], kb[KB];
+            static_for<KB>([&](auto jc) {
+                constexpr int s_ = s8 + decltype(jc)::value;
+                ka[s_ - s8] = *reinterpret_cast<const s16x8*>(img + kaddr[s_ & 3] + (s_ >> 2) * 256);
+                kb[s_ - s8] = *reinterpret_cast<const s16x8*>(img + kaddr[s_ & 3] + (s_ >> 2) * 256 + 16 * ROWB);
+                if constexpr ((s_ + 1) % KPER == 0)
+                    static_for<RPK>([&](auto rc) { reqs(std::integral_constant<int, ((s_ + 1) / KPER - 1) * RPK + decltype(rc)::value>{}); });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+            {
+                if (HALVES && !XCH && s8 + j >= KSTEPS / 2)
+                {
+                    h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), h0, 0, 0, 0);
+                    h1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), h1, 0, 0, 0);
+                }
+                else
+                {
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ka[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kb[j]), __builtin_bit_cast(bf16x8, qf[s8 + j]), a1, 0, 0, 0);
+                }
+            }
+        });
+        if constexpr (HALVES && !XCH) { a0 += h0; a1 += h1; }
+    };
+    auto pipe_body = [&](int t, auto buf_c, auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;              // 0: lean (template buffer, branch-free requests); 1: buffer by parity at run time, general requests at the top
+        constexpr int BUF = (MODE == 0) ? decltype(buf_c)::value : 0;
+        const int kt = kt0 + t * kKeysPerTile;
+        const int vbuf = (MODE == 1) ? (t & 1) * 2 * TILE_BYTES : BUF * 2 * TILE_BYTES;      // V(t) sits in the V slot of this buffer; its K slot takes K(t + 2)
+        const int kbuf = 2 * TILE_BYTES - vbuf;                                               // K(t + 1) sits in the K slot of the other one; its V slot takes V(t + 1)
+        unsigned char* ldsKn = smem + ((MODE == 1) ? kbuf : (BUF ^ 1) * 2 * TILE_BYTES);
+        const bool more = t + 1 < ntiles;                          // (MODE 0: always)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        FLASH_STAMP(0);
+        if constexpr (MODE == 1)
+        {
+            // requests at the top of the tile; a whole tile of an unwrapped cache by lane offsets + a scalar (one uniform branch per matrix), the band's last tile
+            // and a wrapped ring in the general form
+            auto top_requests = [&](auto isk, int tn, unsigned char* img) {
+                constexpr bool ISK = decltype(isk)::value;
+                const int ktn = kt0 + tn * kKeysPerTile;
+                if (!ring && ktn + kKeysPerTile - 1 <= pos_last)
+                {
+#pragma unroll
+                    for (int i = 0; i < DMAS; ++i)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(ISK ? rsK : rsV, (lds_ptr_t)(img + RPI * (NW * i + wave) * ROWB), 16,
+                                                                 ISK ? ((NB == 2 && (i & 1)) ? ks1 : ks0) : ((NB == 2 && (i & 1)) ? vs1 : vs0),
+                                                                 (ktn + (i / NB) * 16) * rstride, 0, 0);
+                }
+                else if constexpr (ISK) stage_k(ktn, img);
+                else stage_v(ktn, img);
+            };
+            if (t + 2 < ntiles) top_requests(std::true_type{}, t + 2, smem + vbuf);
+            if (more) top_requests(std::false_type{}, t + 1, smem + kbuf + TILE_BYTES);
+        }
+        if constexpr (XCH)
+        {
+            const f32x4* xr = reinterpret_cast<const f32x4*>(smem + XCH_OFF + (t & 1) * XCH_BYTES) + ((wave ^ HB) * 64 + lane) * 2;
+            sc0 += xr[0]; sc1 += xr[1];
+        }
+        f32x4 n0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, n1 = n0;
+        auto req_k = [&](auto ic) {                                // K(t + 2) -> K slot of V(t)'s buffer
+            constexpr int i = decltype(ic)::value;
+            if constexpr (MODE == 0 && i < DMAS)
+            {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)(smem + BUF * 2 * TILE_BYTES + RPI * (NW * i + wave) * ROWB), 16, (NB == 2 && (i & 1)) ? ks1 : ks0,
+                                                         (kt + 2 * kKeysPerTile + (i / NB) * 16) * rstride, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto req_v = [&](auto ic) {                                // V(t + 1) -> V slot of K(t + 1)'s buffer
+            constexpr int i = decltype(ic)::value;
+            if constexpr (MODE == 0 && i < DMAS)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)(smem + (BUF ^ 1) * 2 * TILE_BYTES + TILE_BYTES + RPI * (NW * i + wave) * ROWB), 16,
+                                                         (NB == 2 && (i & 1)) ? vs1 : vs0, (kt + kKeysPerTile + (i / NB) * 16) * rstride, 0, 0);
+        };
+        if (MODE == 0 || more)
+        {
+            qk_tile(ldsKn, n0, n1, req_k);
+            if constexpr (XCH)
+            {
+                f32x4* xw = reinterpret_cast<f32x4*>(smem + XCH_OFF + ((t + 1) & 1) * XCH_BYTES) + (wave * 64 + lane) * 2;
+                xw[0] = n0; xw[1] = n1;
+            }
+        }
+        FLASH_STAMP(1);
+        s16x8 va[DT];
+        {
+            constexpr int VOFF = BUF * 2 * TILE_BYTES + TILE_BYTES;
+            constexpr int SPAN = ((DT - 1) >> 3) * 256 + 16 * ROWB;
+            constexpr int DPER = DT / DMAS;
+            auto after = [&](auto dc) {
+                constexpr int d = decltype(dc)::value;
+                if constexpr ((d + 1) % DPER == 0) req_v(std::integral_constant<int, (d + 1) / DPER - 1>{});
+            };
+            if constexpr (MODE != 1 && VOFF + SPAN < 65536)
+                read_vt_frags<ROWB, VOFF>(vaddr_lds, va, after, std::make_integer_sequence<int, DT>{});
+            else
+            {
+                unsigned vb[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vb[i] = vaddr_lds[i] + (unsigned)(vbuf + TILE_BYTES);
+                read_vt_frags<ROWB, 0>(vb, va, after, std::make_integer_sequence<int, DT>{});
+            }
+        }
+        FLASH_STAMP(2);
+        float tv[8];
+        // MODE 0 runs only tiles that every row of the workgroup sees whole (the driver below keeps the band's first two and last three tiles, and a workgroup
+        // with rows past the chunk, in MODE 1): no mask, no branch -- the scores' scaling sits in ONE block with the K(t + 1) Q^T products in front of it
+        const bool whole = MODE == 0 || (rows_ok && kt + kKeysPerTile - 1 <= wpos0 && (p.window == 0 || kt > wpos0 + 15 - p.window));
+        if (whole)
+        {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) tv[r] = ((r < 4) ? sc0[r] : sc1[r - 4]) * c2;
+        }
+        else
+        {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+            {
+                const int key = kt + ((r < 4) ? (4 * g + r) : (16 + 4 * g + (r - 4)));
+                const float raw = (r < 4) ? sc0[r] : sc1[r - 4];
+                const bool vis = row_valid && key <= my_pos && (p.window == 0 || key > my_pos - p.window);
+                tv[r] = vis ? raw * c2 : -INFINITY;
+            }
+        }
+        float alpha;
+        const bf16x8 pfrag = softmax_tile_step(tv, m_run, l_run, alpha);
+        if (__any(alpha != 1.0f))
+        {
+#pragma unroll
+            for (int d = 0; d < DT; ++d) { o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha; }
+            asm volatile("" ::: "memory");
+        }
+        FLASH_STAMP(3);
+        lds_tr_wait(va);
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, va[d]), pfrag, o[d], 0, 0, 0);
+        sc0 = n0; sc1 = n1;
+#ifdef MILA_FLASH_STAMPS
+        if (stamping && o[DT - 1][0] == 12345.678f) seg[0] += 1;
+#endif
+        FLASH_STAMP(4);
+    };
+    if constexpr (PIPE)
+    {
+        static_assert(ASM_TR, "the pipelined forms read V^T by inline assembly");
+        // prologue: K(1) on its way, S^T(0) from K(0) (both requested above in the general form; V(0) lands under the first product)
+        if (ntiles > 1) stage_k(kt0 + kKeysPerTile, smem + 2 * TILE_BYTES);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        qk_tile(smem, sc0, sc1, [](auto) {});
+        if constexpr (XCH)
+        {
+            f32x4* xw = reinterpret_cast<f32x4*>(smem + XCH_OFF) + (wave * 64 + lane) * 2;
+            xw[0] = sc0; xw[1] = sc1;
+        }
+        // lean pairs (MODE 0): the tiles they request -- K(t + 2), K(t + 3), V(t + 1), V(t + 2) -- are whole tiles of an unwrapped cache (every tile but a band's
+        // last one is), and the tiles they MASK are seen whole by every row of the workgroup: with <= 32 rows per workgroup that holds from the band's third
+        // tile (a window's lower edge crosses at most the first two: 32 t >= QROWS + 30) to its fourth from last (the causal edge crosses at most the last two)
+        static_assert(QROWS <= 32, "the whole-tile range of the lean loop is derived for <= 32 query rows per workgroup");
+        int t = 0;
+        if (!ring && q0 + QROWS <= p.Tq)
+        {
+            if (p.window > 0)
+                for (; t < 2 && t < ntiles; ++t) pipe_body(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            for (; t + 5 <= ntiles; t += 2)
+            {
+                pipe_body(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                pipe_body(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+            }
+        }
+        for (; t < ntiles; ++t) pipe_body(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    }
+    else if constexpr (DB && HS >= 512 && !XCH)
     {
         for (int t = 0; t < ntiles; t += 2)
         {
@@ -1052,7 +1250,8 @@ __global__ __launch_bounds__(512, 1) void flash_prefill_pp_kernel(const FlashPar
 }
 
 static int g_tune_flash_form = 8;      // tuning "flash.form": 8 (default) = the LDS-DMA forms (HS 512: 8-wave workgroups, four heads x two d-halves; HS 256: double-buffered 4-wave
-                                       // workgroups, two per CU); 9 = 8 with lockstep 8-wave workgroups at HS 256 too; 10 = the ping-pong 8-wave form at both head sizes; 2 = HS 512 as 4-wave
+                                       // workgroups, two per CU); 9 = 8 with lockstep 8-wave workgroups at HS 256 too; 10 = the ping-pong 8-wave form at both head sizes; 11 = the
+                                       // software-pipelined loop (K one tile ahead of V; HS 512: 2 % faster at the whole 160 KB of LDS, HS 256: 6 % slower); 2 = HS 512 as 4-wave
                                        // d-split workgroups; 1 = the register-staged kernels.  All give the same bits.
 MILA_TUNE("flash.form", g_tune_flash_form);
 
@@ -1072,12 +1271,12 @@ static int launch_flash(const FlashParams& p, int B, hipStream_t s)
 }
 
 // the LDS-DMA kernel (HS = 256 or 512): HB heads x DS d-shares x (NW / (HB DS)) row blocks per workgroup of NW waves
-template <int HS, int HB, int DS, int NW>
+template <int HS, int HB, int DS, int NW, bool PIPE = false>
 static int launch_flash_dma(const FlashParams& p, int B, hipStream_t s)
 {
     constexpr int QROWS = 16 * (NW / (HB * DS));
     constexpr bool DB = (NW == 8) || (HS <= 256);
-    const size_t lds = (size_t)(DB ? 4 : 2) * kKeysPerTile * HS * 2 + ((HS >= 512 && DS == 2) ? (size_t)NW * 2048 : 0);      // + the score-exchange area
+    const size_t lds = (size_t)(DB ? 4 : 2) * kKeysPerTile * HS * 2 + ((HS >= 512 && DS == 2) ? (size_t)NW * 2048 * (PIPE ? 2 : 1) : 0);      // + the score-exchange area(s)
     FlashParams q = p;
     q.n_qtiles = (p.Tq + QROWS - 1) / QROWS;
     q.n_hblk = p.NH / HB;
@@ -1085,10 +1284,10 @@ static int launch_flash_dma(const FlashParams& p, int B, hipStream_t s)
     if (lds > 65536)
     {
         // more than 64 KB of dynamic LDS must be allowed once per process (never inside a stream capture: the first prefill of a model is eager)
-        static const hipError_t allowed = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_prefill_kernel_s1<HS, HB, DS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        static const hipError_t allowed = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_prefill_kernel_s1<HS, HB, DS, NW, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (allowed != hipSuccess) return check_hip(allowed, "flash_prefill: hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
-    hipLaunchKernelGGL((flash_prefill_kernel_s1<HS, HB, DS, NW>), grid, dim3(64 * NW), lds, s, q);
+    hipLaunchKernelGGL((flash_prefill_kernel_s1<HS, HB, DS, NW, PIPE>), grid, dim3(64 * NW), lds, s, q);
     MILA_LAUNCH_CHECK("flash_prefill");
 }
 
@@ -1116,6 +1315,8 @@ static int dispatch_hb(const FlashParams& p, int B, hipStream_t s)
     const int GS = p.NH / p.NKV;
     if constexpr (HS == 512) { if (g_tune_flash_form == 10 && GS % 4 == 0) return launch_flash_pp<HS, 4, 2>(p, B, s); }
     if constexpr (HS == 256) { if (g_tune_flash_form == 10 && GS % 2 == 0) return launch_flash_pp<HS, 2, 1>(p, B, s); }
+    if constexpr (HS == 512) { if (g_tune_flash_form == 11 && GS % 4 == 0) return launch_flash_dma<HS, 4, 2, 8, true>(p, B, s); }
+    if constexpr (HS == 256) { if (g_tune_flash_form == 11 && GS % 2 == 0) return launch_flash_dma<HS, 2, 1, 4, true>(p, B, s); }
     if constexpr (HS == 512)
     {
         if (g_tune_flash_form >= 8 && GS % 4 == 0) return launch_flash_dma<HS, 4, 2, 8>(p, B, s);      // four heads x two d-halves, double-buffered tiles

@@ -37,7 +37,7 @@ MILA_API size_t mila_cdna4_last_form(char* buf, size_t cap);
  *   gemm_fp8.skinny_whole_x, gemm_fp8.big_rule, gemm_fp8.splitk_min_rows      the skinny kernel's barrier-free <= 4-row form (1); which row counts below 512 take the LDS-DMA
  *                          kernels (rules 0 .. 3 of gemm256.hip: fp8_big_rows; 3); row counts below this stay off the fp8 split-K form (17)
  *   attn.positions_per_split, attn.max_workgroups, attn.heads_per_group_512, attn.xcd_local, attn.mfma_decode, attn.mfma_min_band      decode attention (csrc/attention.hip)
- *   flash.form             8 (default) = the LDS-DMA forms; 9 = lockstep 8-wave workgroups at HS 256 too; 10 = the ping-pong 8-wave form; 2 = HS 512 as 4-wave d-split
+ *   flash.form             8 (default) = the LDS-DMA forms; 9 = lockstep 8-wave workgroups at HS 256 too; 10 = the ping-pong 8-wave form; 11 = the software-pipelined loop; 2 = HS 512 as 4-wave d-split
  *                          workgroups; 1 = the register-staged kernels.  Same bits.                                                       (csrc/attention_prefill.hip) */
 /* engine diagnostics: the next decode_engine launches write wall-clock stamps (100 MHz) of the first 8 workgroups' 8 waves, 16 slots each */
 MILA_API int mila_cdna4_decode_engine_debug(unsigned long long* buf);

@@ -187,14 +187,14 @@ def test_flash_prefill_forms_give_the_same_bits(name, NH, NKV, HS, window):
     lib = capi.load()
     outs = {}
     try:
-        for form in (8, 9, 10, 2, 1):
+        for form in (8, 9, 10, 11, 2, 1):
             capi.tune("flash.form", form)
             Y = empty_u16(B, T, NH * HS)
             capi.call("attn_prefill_bf16", Y, q, K, V, B, T, NH, NKV, HS, cap, off, window, 1.0)
             outs[form] = bits(Y).copy()
     finally:
         capi.tune_reset()
-    for form in (9, 10, 2, 1):
+    for form in (9, 10, 11, 2, 1):
         assert np.array_equal(outs[8], outs[form]), "form %d differs from the default" % form
 
 

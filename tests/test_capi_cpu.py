@@ -178,8 +178,8 @@ def test_the_flash_prefill_forms_with_assembly_lds_reads_do_not_spill():
         m = re.search(r"(VGPRs Spill|ScratchSize \[bytes/lane\]): (\d+)", line)
         if m and name:
             usage[name][m.group(1)] = int(m.group(2))
-    dma = {k: v for k, v in usage.items() if "flash_prefill_kernel_s1ILi" in k}
+    dma = {k: v for k, v in usage.items() if "flash_prefill_kernel_s1ILi" in k or "flash_prefill_pp_kernelILi" in k}
     asm_forms = {k: v for k, v in dma.items() if not re.search(r"s1ILi512ELi\dELi1ELi4E", k)}
-    assert len(dma) == 10 and len(asm_forms) == 7, sorted(dma)
+    assert len(dma) == 14 and len(asm_forms) == 11, sorted(dma)      # 10 lockstep forms + 2 software-pipelined ones (flash.form 11) + 2 ping-pong ones (form 10); 3 keep the intrinsic
     for k, v in asm_forms.items():
         assert v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
