@@ -18,6 +18,7 @@
 //     the steady state.  A staged slot is read one phase after the wait + barrier that retires it.
 //   * fragments: ds_read_b128, 12 / 4 / 8 / 4 per phase (the W or X fragments of the previous phase are reused).
 #include "common.h"
+#include <type_traits>
 
 namespace mila {
 
@@ -564,8 +565,49 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 x_offsets(voffXn, xm0);
                 if constexpr (WABS) w_offsets(voffWn, xn0, xwrow1);
             }
-            for (int t = 0; t < nk; ++t)
-            {
+            // INTERIOR K-tiles (round 4): 1 <= t <= nk - 3 -- every staging request belongs to THIS tile, the waits are the steady ones, nothing of the previous
+            // tile's stores is counted -- run in pairs with the buffer parity as a template constant: no choice of wait, no next-tile test, no parity arithmetic
+            // on the LDS addresses.  (SQ counters: 60 of a K-tile's ~165 instructions per wave were scalar, 12 more vector adds for the parity; a wave issues one
+            // instruction per four cycles and a phase's reads + requests must fit under the partner wave's 512 MFMA cycles.)  Same instructions on the data: same bits.
+            const int sw0 = WABS ? 0 : n0 * rowbytes, sw1 = WABS ? 0 : wrow1 * rowbytes;      // (relative W offsets: the half-tile's first row rides in the scalar offset)
+            auto stage_in = [&](auto par_c, int koff, bool isX, int half) {
+                constexpr int PARB = decltype(par_c)::value;
+                unsigned char* dst_half = smem + PARB * kBufBytes + half_off(isX, half);
+                const int soff = (isX || WABS) ? koff : (half ? sw1 : sw0) + koff;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                {
+                    const int chunk = i * 8 + wave;
+                    if (isX) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(dst_half + chunk * 1024), 16, voffX[half][i], soff, 0, 0);
+                    else if constexpr (WABS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(dst_half + chunk * 1024), 16, voffW[half][i], soff, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(dst_half + chunk * 1024), 16, voffW[0][i], soff, 0, 0);
+                }
+            };
+            auto ktile_in = [&](int t, auto par_c) {
+                constexpr int PARB = decltype(par_c)::value;
+                constexpr std::integral_constant<int, PARB> same{};
+                constexpr std::integral_constant<int, PARB ^ 1> other{};
+                auto reads_done = [&]() {
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                const int k1 = (t + 1) * 128, k2 = k1 + 128;
+                // phase A: quadrants (0,0) (0,1)
+                stage_in(other, k1, false, 1);
+                load_a(PARB, 0); load_b(PARB, 0); load_b(PARB, 1);
+                reads_done();
+                mma(0, 0); mma(0, 1);
+                mma_end();
+                // phase B: quadrants (1,0) (1,1)
+                stage_in(same, k2, false, 0); stage_in(same, k2, true, 0); stage_in(same, k2, true, 1);
+                load_a(PARB, 1);
+                reads_done();
+                mma(1, 0); mma(1, 1);
+                mma_end();
+            };
+            auto ktile_general = [&](int t) {
                 const bool steady = (t + 2 < nk) || has_next;
                 // the previous tile's stores are still in flight -- kEpilogueStores of them, counted; a tile on the ragged edge of Y issues another number (masked rows:
                 // possibly fewer), so behind such a tile the wait is the plain one (its stores are retired with it)
@@ -590,6 +632,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 reads_done();
                 if (!dnm) { mma(1, 0); mma(1, 1); }
                 mma_end();
+            };
+            {
+                int t = 0;
+                ktile_general(t++);                                   // K-tile 0: behind the previous tile's stores
+#ifndef MILA_GEMM_SKIP
+                // (bf16 modes only: with the fp8 operands' 8-register tuples a second loop body makes the allocator spill inside the loop -- fc_gate_up fp8 234 -> 507 us)
+                if constexpr (!FP8)
+                    for (; t + 4 <= nk; t += 2)                      // (t odd here)
+                    {
+                        ktile_in(t, std::integral_constant<int, 1>{});
+                        ktile_in(t + 1, std::integral_constant<int, 0>{});
+                    }
+#endif
+                for (; t < nk; ++t) ktile_general(t);                // the last K-tiles: the next tile's first requests, the un-steady waits
             }
             if (!(WABS && p.rowwise)) epilogue();
             prev_edge = m0 + 256 > p.M || n0 + (GEGLU ? 128 : 256) > p.N;
@@ -1079,8 +1135,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
         {
             const bool has_next = WALK && j + 1 < my_tiles;
             if (has_next) { tile_origin(blockIdx.x + (j + 1) * gridDim.x, xm0, xn0); offsets(voffn, xm0, xn0); }
-            for (int t = 0; t < nk; ++t)
-            {
+            auto ktile_general = [&](int t) {
                 const bool more = t + 2 < nk || (has_next && t + 2 - nk < nk);
                 // the previous tile's stores sit between K-tile 1's requests and K-tile 2's: counted, unless that tile lay on a ragged edge of Y (another number of
                 // stores, possibly fewer: the plain wait retires them all)
@@ -1099,6 +1154,45 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                 mma(1);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
+            };
+            // INTERIOR K-tiles (round 4, as in gemm256_kernel): 1 <= t <= nk - 3 -- the request is this tile's K-tile t + 2, the wait the steady one -- run in triples
+            // with the ring slot as a template constant (three rotations of the loop, chosen once per tile by the slot of its K-tile 1): no modulo, no next-tile
+            // test, no choice of wait per K-tile.  Same instructions on the data: same bits.
+            auto ktile_in = [&](int t, auto slot_c) {
+                constexpr int SLOT = decltype(slot_c)::value % 3, NEXT = (SLOT + 2) % 3;
+                stage(NEXT, t + 2, 0); stage(NEXT, t + 2, 1); stage(NEXT, t + 2, 2);
+                load_a(SLOT);
+                load_b(SLOT, 0);
+                load_b(SLOT, 1);
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                mma(0);
+                mma(1);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            };
+            auto interior = [&](int& t, auto s0c) {
+                constexpr int S0 = decltype(s0c)::value;
+                for (; t + 5 <= nk; t += 3)
+                {
+                    ktile_in(t, std::integral_constant<int, S0>{});
+                    ktile_in(t + 1, std::integral_constant<int, S0 + 1>{});
+                    ktile_in(t + 2, std::integral_constant<int, S0 + 2>{});
+                }
+            };
+            {
+                int t = 0;
+                ktile_general(t++);
+                if constexpr (!(FP8 && WALK))                        // (the walking fp8 forms spill with the extra loop bodies)
+                {
+                    const int s1 = (base + 1) % 3;                   // ring slot of K-tile 1
+                    if (s1 == 0) interior(t, std::integral_constant<int, 0>{});
+                    else if (s1 == 1) interior(t, std::integral_constant<int, 1>{});
+                    else interior(t, std::integral_constant<int, 2>{});
+                }
+                for (; t < nk; ++t) ktile_general(t);
             }
             epilogue();
             prev_edge = m0 + 256 > p.M || n0 + (GEGLU ? 64 : 128) > p.N;

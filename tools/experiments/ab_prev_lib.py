@@ -55,3 +55,33 @@ for name, kind, M, K, N in CASES:
     for tag, _, _ in variants:
         row[tag + "_us"] = round(best[tag], 1)
     print(json.dumps(row), flush=True)
+
+
+# fp8 x fp8 forms (W4A8 / W8A8 prefill): the same A/B
+def e4m3_bytes(shape):
+    b = torch.randint(0, 256, shape, device="cuda", dtype=torch.uint8)
+    return torch.where((b & 0x7F) == 0x7F, b & 0xFE, b)
+
+
+for name, kind, M, K, N in (("gemma qkv fp8", "fp8", 2048, 3840, 8192), ("gemma o_proj fp8", "fp8", 2048, 4096, 3840), ("gemma fc_gate_up + GeGLU fp8", "fp8geglu", 2048, 3840, 30720),
+                            ("gemma fc_down fp8", "fp8", 2048, 15360, 3840)):
+    X8, W8 = e4m3_bytes((M, K)), e4m3_bytes((N, K))
+    ts = torch.full((M,), 1e-3, device="cuda", dtype=torch.float32)
+    ws = torch.full((1,), 1e-3, device="cuda", dtype=torch.float32)
+    Y = torch.empty((M, N // 2 if kind == "fp8geglu" else N), dtype=torch.int16, device="cuda")
+    outs, best = {}, {}
+    variants = (("previous", "previous"), ("current", "current"))
+    for rnd in range(4):
+        for tag, which in (variants if rnd % 2 == 0 else variants[::-1]):
+            lib = libs[which]
+            if kind == "fp8geglu":
+                fn = lambda: lib.mila_cdna4_gemm_geglu_fp8_scaled(P(Y), P(X8), P(W8), P(ts), P(ws), M, K, N // 2, None)
+            else:
+                fn = lambda: lib.mila_cdna4_gemm_fp8_scaled(P(Y), P(X8), P(W8), P(ts), P(ws), None, M, K, N, None)
+            assert fn() == 0
+            best[tag] = min(best.get(tag, 1e30), timed(fn))
+            outs[tag] = Y.clone()
+    row = {"case": name, "M": M, "K": K, "N": N, "same_bits": bool(torch.equal(outs["previous"], outs["current"]))}
+    for tag, _ in variants:
+        row[tag + "_us"] = round(best[tag], 1)
+    print(json.dumps(row), flush=True)
