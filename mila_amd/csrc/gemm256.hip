@@ -262,6 +262,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                     const i32x8 b8 = __builtin_bit_cast(i32x8, (Pair{fbx[qt][0], fbx[qt][1]}));
                     acc[hA][hB][pt][qt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[hA][hB][pt][qt], 0, 0, 0, 127, 0, 127);
                 }
+            // PIN the products to their phase (round 4).  The scaled-MFMA calls are pure, and the compiler SANK the 16 of phase A below that phase's end barrier and
+            // phase B's reads, into phase B's MFMA slot (the kernel's barrier-to-barrier instruction counts read 0 / 32 MFMAs where the bf16 modes read 16 / 16
+            // -- sched_barrier(0) does not hold them): one slot of every K-tile then held 32 x 32 cycles of matrix work with the partner wave idle behind it, the next
+            // none -- the staggered schedule was a lockstep one for every fp8 x fp8 GEMM (1.79 us per K-tile against bf16's 1.46 for the same bytes and MFMA cycles).
+            // An empty volatile statement that takes the accumulators as in / out operands keeps each block in front of its own barrier; no instruction is emitted.
+            asm volatile("" : "+v"(acc[hA][hB][0][0]), "+v"(acc[hA][hB][0][1]), "+v"(acc[hA][hB][1][0]), "+v"(acc[hA][hB][1][1]),
+                              "+v"(acc[hA][hB][2][0]), "+v"(acc[hA][hB][2][1]), "+v"(acc[hA][hB][3][0]), "+v"(acc[hA][hB][3][1]));
         }
         else
         {
@@ -911,6 +918,9 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                     const i32x8 b8 = __builtin_bit_cast(i32x8, (Pair{fbx[qt][0], fbx[qt][1]}));
                     acc[hB][pt][qt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[hB][pt][qt], 0, 0, 0, 127, 0, 127);
                 }
+            // (the products pinned in front of their barrier, as in gemm256_kernel: the compiler sinks the pure scaled-MFMA calls across barriers)
+            asm volatile("" : "+v"(acc[hB][0][0]), "+v"(acc[hB][0][1]), "+v"(acc[hB][1][0]), "+v"(acc[hB][1][1]),
+                              "+v"(acc[hB][2][0]), "+v"(acc[hB][2][1]), "+v"(acc[hB][3][0]), "+v"(acc[hB][3][1]));
         }
         else
         {
