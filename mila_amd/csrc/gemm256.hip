@@ -644,8 +644,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 int t = 0;
                 ktile_general(t++);                                   // K-tile 0: behind the previous tile's stores
 #ifndef MILA_GEMM_SKIP
-                // (bf16 modes only: with the fp8 operands' 8-register tuples a second loop body makes the allocator spill inside the loop -- fc_gate_up fp8 234 -> 507 us)
-                if constexpr (!FP8)
+                // (not the fp8 GeGLU mode: with its epilogue's scale vectors a second loop body makes the allocator spill inside the loop -- fc_gate_up fp8 234 -> 507 us)
+                if constexpr (MODE != G_FP8_GEGLU)
                     for (; t + 4 <= nk; t += 2)                      // (t odd here)
                     {
                         ktile_in(t, std::integral_constant<int, 1>{});

@@ -135,8 +135,8 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 def test_the_prefill_gemm_kernels_keep_their_accumulators_in_registers():
     """hipcc's kernel-resource-usage remarks for csrc/gemm256.hip (cross-compiled here, no GPU): the bf16 LDS-DMA GEMMs the benchmark runs must not spill -- two waves per SIMD
     leave 256 registers, 128 of them accumulators, and a few more live values in an epilogue tip the allocator into scratch traffic without any diagnostic (round 3: an
-    8-byte bias load hoisted over the epilogue cost 127 spills and 15-24 % on the plain 256 x 256 kernel before an A/B on one box showed it).  The fp8 forms carry the epilogue
-    scales and are allowed a small spill OUTSIDE the K loop (checked on the ISA when they were introduced); the bound keeps that from growing unnoticed."""
+    8-byte bias load hoisted over the epilogue cost 127 spills and 15-24 % on the plain 256 x 256 kernel before an A/B on one box showed it).  Round 4 adds a second / third body
+    of the K loop (interior K-tiles) to most forms: the ones that would spill with it keep the single body (csrc/gemm256.hip), and every default-schedule kernel is held to zero."""
     import re
     import subprocess
     src = os.path.join(ROOT, "mila_amd", "csrc", "gemm256.hip")
@@ -154,9 +154,10 @@ def test_the_prefill_gemm_kernels_keep_their_accumulators_in_registers():
             usage[name][m.group(1)] = int(m.group(2))
     default_schedule = {k: v for k, v in usage.items() if ("gemm256_kernelILi" in k and "ELi3EEE" in k) or ("gemm256x128_kernelILb" in k and "ELi2ELb" in k)}
     assert len(default_schedule) == 12, sorted(usage)      # 4 modes of the 256 x 256 kernel, 3 forms of the 256 x 128 one with and without the tile walk, its two split-K forms
+    # (round 4: none of them spills any more -- the fp8 modes' 24 spilled registers went with the scaled-MFMA products that the compiler had sunk across their phase's
+    # barrier, csrc/gemm256.hip: mma)
     for k, v in default_schedule.items():
-        fp8_256 = "gemm256_kernelILi2E" in k or "gemm256_kernelILi3E" in k
-        assert v["VGPRs Spill"] <= (24 if fp8_256 else 0), (k, v)
+        assert v["VGPRs Spill"] == 0, (k, v)
 
 
 def test_the_flash_prefill_forms_with_assembly_lds_reads_do_not_spill():
