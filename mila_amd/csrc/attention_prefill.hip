@@ -176,6 +176,9 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
     // the clamped V row is a real, finite row), so the compiler keeps the other set's loads in flight across the wait.
     struct StageRegs { u32x4 k[CH_PER_THREAD], v[CH_PER_THREAD]; };
     const int kt_last = kt0 + (ntiles - 1) * kKeysPerTile;
+    const bool ring = pos_last >= p.capacity;                   // uniform: only a bounded ring wraps inside one prefill
+    const int wpos0 = p.pos_offset + wq0;                        // position of this wave's first row (uniform)
+    const bool rows_ok = wq0 + 16 <= p.Tq;
     auto stage_load = [&](StageRegs& r, int kt) {
         if constexpr (DEEP) kt = min(kt, kt_last);
 #pragma unroll
@@ -186,7 +189,8 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
             if constexpr (DEEP)
             {
                 const int pos = min(kt + row, pos_last);
-                const size_t off = (size_t)(pos % p.capacity) * p.kv_r_stride + chunk * 8;
+                // (round 4: the modulo only where a bounded ring can wrap inside this prefill -- 10 vector instructions per request otherwise spent on pos % capacity)
+                const size_t off = (size_t)(ring ? pos % p.capacity : pos) * p.kv_r_stride + chunk * 8;
                 r.k[i] = ld16(kbase + off);
                 r.v[i] = ld16(vbase + off);
             }
@@ -244,13 +248,24 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
         }
         // lane holds keys kt + 4 g + r (s0) and kt + 16 + 4 g + r (s1) of query row l15
         float tv[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
+        // a tile every row of this wave sees whole (the interior of the band: most tiles) needs no mask (round 4: this kernel masked every tile -- 67 of its 214
+        // instructions per tile for 8 MFMAs; same values either way)
+        const bool whole = rows_ok && kt + kKeysPerTile - 1 <= wpos0 && (p.window == 0 || kt > wpos0 + 15 - p.window);
+        if (whole)
         {
-            const int key = kt + ((r < 4) ? (4 * g + r) : (16 + 4 * g + (r - 4)));
-            const float raw = (r < 4) ? s0[r] : s1[r - 4];
-            const bool vis = row_valid && key <= my_pos && (p.window == 0 || key > my_pos - p.window);
-            tv[r] = vis ? raw * c2 : -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) tv[r] = ((r < 4) ? s0[r] : s1[r - 4]) * c2;
+        }
+        else
+        {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+            {
+                const int key = kt + ((r < 4) ? (4 * g + r) : (16 + 4 * g + (r - 4)));
+                const float raw = (r < 4) ? s0[r] : s1[r - 4];
+                const bool vis = row_valid && key <= my_pos && (p.window == 0 || key > my_pos - p.window);
+                tv[r] = vis ? raw * c2 : -INFINITY;
+            }
         }
         float alpha;
         const bf16x8 pfrag = softmax_tile_step(tv, m_run, l_run, alpha);
