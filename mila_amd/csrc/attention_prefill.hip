@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
     // MODE 2: the single-buffered forms (two barriers per tile).
     auto tile_body = [&](int t, auto buf_c, auto mode_c) {
         constexpr int MODE = decltype(mode_c)::value;
-        constexpr int BUF = (MODE == 0 || MODE == 3) ? decltype(buf_c)::value : 0;
+        constexpr int BUF = (MODE == 0) ? decltype(buf_c)::value : 0;
         const int kt = kt0 + t * kKeysPerTile;
         const int rbuf = (MODE == 1) ? (t & 1) * 2 * TILE_BYTES : BUF * 2 * TILE_BYTES;      // this tile's [K | V] pair
         unsigned char* ldsK = smem + rbuf;
@@ -521,49 +521,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
         // requests among the V^T fragment reads -- instead of all eight in a row behind the K reads: a workgroup's waves reach this point together, their 32
         // requests take the CU's address path (64 B / clk) ~ 500 cycles during which every wave stood in the issue queue with nothing else running; spread out,
         // the LDS reads and the requests feed two pipes at once.
-        // MODE 3 (HS = 512, whose registers do not hold a second kind of body next to the main loop's): one loop over all tiles, the request form chosen by
-        // scalar branches around each request
-        const bool has_next = t + 1 < ntiles;
-        const bool fast_next = !ring && kt + 2 * kKeysPerTile - 1 <= pos_last;
         auto next_k = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if constexpr ((MODE == 0 || MODE == 3) && i < DMAS)
+            if constexpr (MODE == 0 && i < DMAS)
             {
                 __builtin_amdgcn_sched_barrier(0);
-                if (MODE == 3 && !has_next) {}
-                else if (MODE == 0 || fast_next)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)(nxt + RPI * (NW * i + wave) * ROWB), 16, (NB == 2 && (i & 1)) ? ks1 : ks0,
-                                                             adv + (i / NB) * 16 * rstride, 0, 0);
-                else
-                {
-                    int lz = lane;
-                    asm volatile("" : "+v"(lz));
-                    const int row0 = RPI * (NW * i + wave);
-                    const int row = row0 + lz / CPR, slot = lz % CPR, pos = min(ktn + row, pos_last);
-                    const int voff = (ring ? pos % p.capacity : pos) * rstride + (k_off<HS>(row, slot) - row * ROWB);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)(nxt + row0 * ROWB), 16, voff, 0, 0, 0);
-                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)(nxt + RPI * (NW * i + wave) * ROWB), 16, (NB == 2 && (i & 1)) ? ks1 : ks0,
+                                                         adv + (i / NB) * 16 * rstride, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
         auto next_v = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            if constexpr ((MODE == 0 || MODE == 3) && i < DMAS)
-            {
-                if (MODE == 3 && !has_next) {}
-                else if (MODE == 0 || fast_next)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)(nxt + TILE_BYTES + RPI * (NW * i + wave) * ROWB), 16, (NB == 2 && (i & 1)) ? vs1 : vs0,
-                                                             adv + (i / NB) * 16 * rstride, 0, 0);
-                else
-                {
-                    int lz = lane;
-                    asm volatile("" : "+v"(lz));
-                    const int row0 = RPI * (NW * i + wave);
-                    const int row = row0 + lz / CPR, slot = lz % CPR, pos = min(ktn + row, pos_last);
-                    const int voff = (ring ? pos % p.capacity : pos) * rstride + (v_off<HS>(row, slot) - row * ROWB);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)(nxt + TILE_BYTES + row0 * ROWB), 16, voff, 0, 0, 0);
-                }
-            }
+            if constexpr (MODE == 0 && i < DMAS)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)(nxt + TILE_BYTES + RPI * (NW * i + wave) * ROWB), 16, (NB == 2 && (i & 1)) ? vs1 : vs0,
+                                                         adv + (i / NB) * 16 * rstride, 0, 0);
         };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows of tile t (NW = 4: its K rows; nothing else is in flight here)
         __syncthreads();
@@ -906,14 +878,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HS <= 256 ? 2 : DS)) void f
             }
         }
         for (; t < ntiles; ++t) pipe_body(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-    }
-    else if constexpr (DB && HS >= 512 && !XCH)
-    {
-        for (int t = 0; t < ntiles; t += 2)
-        {
-            tile_body(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
-            if (t + 1 < ntiles) tile_body(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{});
-        }
     }
     else if constexpr (DB)
     {
