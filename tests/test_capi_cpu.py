@@ -184,3 +184,41 @@ def test_the_flash_prefill_forms_with_assembly_lds_reads_do_not_spill():
     assert len(dma) == 14 and len(asm_forms) == 11, sorted(dma)      # 10 lockstep forms + 2 software-pipelined ones (flash.form 11) + 2 ping-pong ones (form 10); 3 keep the intrinsic
     for k, v in asm_forms.items():
         assert v["VGPRs Spill"] == 0 and v["ScratchSize [bytes/lane]"] == 0, (k, v)
+
+
+def test_the_staggered_gemm_schedules_keep_their_mfma_blocks_between_their_barriers():
+    """Round 4 (EXPERIMENTS.md 10.7): the fp8 x fp8 GEMMs' staggered schedule had silently become a lockstep one -- the compiler had sunk phase A's 16 scaled-MFMA
+    products (pure calls; sched_barrier(0) does not hold them) below that phase's end barrier into phase B's slot.  Found by counting instructions between consecutive
+    s_barrier in the ISA; this test does the same on every default-schedule LDS-DMA kernel (cross-compiled here, no GPU): inside the K loops no barrier-to-barrier stretch
+    may hold MORE matrix instructions than one phase issues (256 x 256: 32 bf16 / 16 fp8 per phase; 256 x 128 ring: 32 / 16 per K-tile), and stretches with fragment
+    reads hold none."""
+    import re
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "mila_amd", "csrc", "gemm256.hip")
+    with tempfile.TemporaryDirectory() as d:
+        asm = os.path.join(d, "g.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"),
+                        "-S", "--cuda-device-only", src, "-o", asm], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        text = open(asm).read()
+    kernels = re.findall(r"^(_ZN4mila(?:14gemm256_kernelILi\dELi3E|18gemm256x128_kernelILb[01]ELb[01]ELi2ELb[01]ELb0E)EEvNS_13Gemm256ParamsE):\s", text, re.M)
+    assert len(kernels) >= 10, kernels
+    for k in kernels:
+        body = text[text.index("\n" + k + ":"):]
+        body = body[:body.index("s_endpgm")]
+        fp8 = "gemm256_kernelILi2E" in k or "gemm256_kernelILi3E" in k or "gemm256x128_kernelILb1E" in k
+        per_phase = 16 if fp8 else 32
+        stretches, m, r = [], 0, 0
+        for line in body.splitlines():
+            t = line.strip()
+            if t.startswith("v_mfma"):
+                m += 1
+            elif t.startswith("ds_read"):
+                r += 1
+            elif t.startswith("s_barrier"):
+                stretches.append((m, r))
+                m = r = 0
+        loop = [x for x in stretches if x != (0, 0)]
+        assert loop, k
+        assert max(x[0] for x in loop) <= per_phase, (k, loop[:12])                # no phase's products merged into a neighbour's slot
+        assert all(x[0] <= 1 for x in loop if x[1] >= 8), (k, loop[:12])            # (one product may ride in front of a read phase's barrier; a block may not)
