@@ -1170,10 +1170,16 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             // test, no choice of wait per K-tile.  Same instructions on the data: same bits.
             auto ktile_in = [&](int t, auto slot_c) {
                 constexpr int SLOT = decltype(slot_c)::value % 3, NEXT = (SLOT + 2) % 3;
-                stage(NEXT, t + 2, 0); stage(NEXT, t + 2, 1); stage(NEXT, t + 2, 2);
+                // the fragment reads go FIRST, the six staging requests behind them: an LDS-DMA request costs the issuing wave 100-185 cycles while the phase's ds_reads are
+                // queued behind it and 25-60 once they are out (MI355X_MICROARCH.md, LDS-DMA piece issue cost); this phase must fit under the partner group's 512 MFMA
+                // cycles and does not (SQ counters: the matrix cores are busy 65 % of this kernel's cycles, 79-85 % of the 256 x 256 kernel's, which stages a third fewer
+                // bytes per FLOP).  A/B of two builds: o_proj 51.1 -> 50.1, fc_down 171.3 -> 167.2, fp8 o_proj / fc_down 32.3 / 97.5 -> 31.2 / 94.1 us, same bits.
+                // (Two of the six requests between the MFMA blocks instead: +2.4 %.  The buffer_load form of the requests: +0.5-1 %.  Without any request -- timing
+                // only -- fc_down takes 143 us, without the wait for them the same 167: the requests' issue, not their latency, is what the phase pays.)
                 load_a(SLOT);
                 load_b(SLOT, 0);
                 load_b(SLOT, 1);
+                stage(NEXT, t + 2, 0); stage(NEXT, t + 2, 1); stage(NEXT, t + 2, 2);
                 asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -1264,6 +1270,10 @@ bool gemm256x128_ragged_n_applicable(int M, int K, int N)
 
 extern int g_gemm_pingpong;
 extern int g_gemm_persistent;
+// (round 4, with the interior K-tiles in both forms: 576 tiles 45.9 one workgroup per tile / 47.5 walking, 768 tiles 59.8 / 60.4, 544 tiles (N = 8704) 137.0 / 150.2 us,
+// 12 576 tiles equal -- profiles/r04_persistent_walk.txt: the walk starts above three rounds)
+int g_gemm_walk_min_tiles = 3 * kNumCU + 1;      // tuning "gemm.walk_min_tiles": the 256 x 128 ring walks its tiles from this many on
+MILA_TUNE("gemm.walk_min_tiles", g_gemm_walk_min_tiles);
 extern int g_gemm_fp8_tail_form;      // gemm_fp8_tail.hip: != 0 sends every row through the tail kernels
 
 template <bool FP8, bool GEGLU, int PP>
@@ -1289,7 +1299,7 @@ static int launch_gemm256x128_tt(const Gemm256Params& p, hipStream_t s)
     // policy's fc_gate_up + GeGLU 222.4 -> 215.6.  A walking workgroup must retire its tile's stores before its third K-tile -- vmcnt counts loads and stores in one
     // order -- where a new workgroup starts with a fresh counter, so the walk pays only when several tiles share the saved launches.  Start phases staggered over the
     // CUs, to spread the store bursts of equal tiles, measured 2-7 % SLOWER on every shape: not kept)
-    const int grid = (PP != 0 && nk >= 2 && g_gemm_persistent && tiles > 2 * kNumCU) ? kNumCU : tiles;
+    const int grid = (PP != 0 && nk >= 2 && g_gemm_persistent && tiles >= g_gemm_walk_min_tiles) ? kNumCU : tiles;
     if constexpr (PP != 0)
     {
         if (grid < tiles)

@@ -766,6 +766,7 @@ def test_persistent_tile_walk_gives_the_bits_of_one_workgroup_per_tile(M, K, N, 
     outs = []
     for persistent in (1, 0):
         capi.tune("gemm.persistent", persistent)
+        capi.tune("gemm.walk_min_tiles", 257)      # (the ring's default walks from 769 tiles on; the 544- and 768-tile cases must walk here)
         try:
             Y = torch.full((M, N), 0x7fc0, dtype=torch.int16, device="cuda")
             capi.call("gemm_gelu_bf16" if act else "gemm_bf16", Y, Xd, Wd, bd, M, K, N)

@@ -17,6 +17,6 @@ M = 2048
 X = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
 Ws = [(torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16) for _ in range(3)]
 Y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-for i in range(9):
+for i in range(int(os.environ.get("MILA_GEMM_LAUNCHES", "9"))):
     capi.call("gemm_bf16", Y.view(torch.int16), X.view(torch.int16), Ws[i % 3].view(torch.int16), None, M, K, N)
 torch.cuda.synchronize()
