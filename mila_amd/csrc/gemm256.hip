@@ -303,10 +303,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
             {
                 if (pc)
                 {
+                    // the lane id re-derived HERE (mbcnt on an opaque zero): the column arithmetic below is then not hoisted out of the tile loop, where it -- or the
+                    // lane id kept live for it -- cost the one register this mode does not have (a spill whose reload sits behind an s_waitcnt vmcnt(0))
+                    int lz = 0;
+                    asm volatile("" : "+v"(lz));
+                    const int lq = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)lz));
             #pragma unroll
                     for (int pt_ = 0; pt_ < 4; ++pt_)
                     {
-                        const int n_ = n0 + wr * 64 + pt_ * 16 + 4 * g;
+                        const int n_ = n0 + wr * 64 + pt_ * 16 + 4 * (lq >> 4);
                         wsg[pt_] = *reinterpret_cast<const f32x4*>(p.w_scale + n_);
                         wsu[pt_] = *reinterpret_cast<const f32x4*>(p.w_scale + p.N + n_);
                     }
@@ -580,7 +585,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
             auto stage_in = [&](auto par_c, int koff, bool isX, int half) {
                 constexpr int PARB = decltype(par_c)::value;
                 unsigned char* dst_half = smem + PARB * kBufBytes + half_off(isX, half);
-                const int soff = (isX || WABS) ? koff : (half ? sw1 : sw0) + koff;
+                int soff = (isX || WABS) ? koff : (half ? sw1 : sw0) + koff;
+                // (fp8 GeGLU: its scalar registers are full, the allocator had moved the half-tile's row offset into a VECTOR register, and every request of an interior
+                // K-tile became a readfirstlane WATERFALL LOOP around a scratch reload -- 49 spilled registers, fc_gate_up fp8 234 -> 507 us; pinned scalar here, the other
+                // modes stay as they are: an explicit readfirstlane costs them 1-5 %)
+                if constexpr (MODE == G_FP8_GEGLU) soff = __builtin_amdgcn_readfirstlane(soff);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                 {
@@ -644,13 +653,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 int t = 0;
                 ktile_general(t++);                                   // K-tile 0: behind the previous tile's stores
 #ifndef MILA_GEMM_SKIP
-                // (not the fp8 GeGLU mode: with its epilogue's scale vectors a second loop body makes the allocator spill inside the loop -- fc_gate_up fp8 234 -> 507 us)
-                if constexpr (MODE != G_FP8_GEGLU)
-                    for (; t + 4 <= nk; t += 2)                      // (t odd here)
-                    {
-                        ktile_in(t, std::integral_constant<int, 1>{});
-                        ktile_in(t + 1, std::integral_constant<int, 0>{});
-                    }
+                // (the fp8 GeGLU mode takes them since its staging offsets are pinned scalar -- stage_in -- and its epilogue re-derives the lane id: 216 -> 202 us)
+                for (; t + 4 <= nk; t += 2)                          // (t odd here)
+                {
+                    ktile_in(t, std::integral_constant<int, 1>{});
+                    ktile_in(t + 1, std::integral_constant<int, 0>{});
+                }
 #endif
                 for (; t < nk; ++t) ktile_general(t);                // the last K-tiles: the next tile's first requests, the un-steady waits
             }
