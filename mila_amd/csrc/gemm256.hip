@@ -117,6 +117,10 @@ __device__ __forceinline__ void gemm256_w_offsets(int (&vo)[2][2], int wrow0, in
 //        wave retires its own fragment reads (lgkmcnt(0)) BEFORE barrier A of the reading phase, and group 0's ph0 staging is
 //        issued behind its barrier B(ph3) = group 1's A(ph3).
 //
+// EPILOGUE_LOADS_FIRST (round 4).  Everything an epilogue loads (per-token and per-channel scales, the ring's bias) is pinned into its registers -- an empty asm with the
+// values as in / out operands -- BEFORE the first store.  The compiler waits for a load at its first use and its vmcnt bookkeeping does not count the stores issued in
+// between, while the hardware counts loads and stores in one order: a scale first used behind five stores came with an s_waitcnt vmcnt(0) that retired all five before the
+// sixth was issued -- the tile's write burst ran one store at a time (fp8 qkv: 17.7 of 75 us were the epilogue, 10 of the bf16 kernel's 116; tools/experiments/gemm_skip.py).
 // PP == 2: the same stagger with TWO phases per K-tile (32 MFMAs per slot, half the barriers, 24 fragment reads per K-tile: the
 // fragments of both X halves stay live).  Phase A(t): stage W1(t+1); read W0, X0, X1 of t; quadrants (0,0) (0,1).
 // Phase B(t): stage W0, X0, X1 of t+2; read W1 of t; quadrants (1,0) (1,1).  vmcnt(8) = the stages of the two youngest phases stay
@@ -315,6 +319,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                         wsg[pt_] = *reinterpret_cast<const f32x4*>(p.w_scale + n_);
                         wsu[pt_] = *reinterpret_cast<const f32x4*>(p.w_scale + p.N + n_);
                     }
+                    asm volatile("" : "+v"(wsg[0]), "+v"(wsg[1]), "+v"(wsg[2]), "+v"(wsg[3]), "+v"(wsu[0]), "+v"(wsu[1]), "+v"(wsu[2]), "+v"(wsu[3]));
                 }
                 else
                 {
@@ -326,16 +331,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 for (int hb_ = 0; hb_ < 2; ++hb_)
             #pragma unroll
                     for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[min(m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15, p.M - 1)];
+                asm volatile("" : "+v"(tsv[0][0]), "+v"(tsv[0][1]), "+v"(tsv[1][0]), "+v"(tsv[1][1]));      // (in their registers before the first store: EPILOGUE_LOADS_FIRST)
             }
-            auto out4 = [&](int hB, int pt, int qt, int m) -> u32x2 {
+            auto out4 = [&](int hB, int pt, int qt, int m, auto pc_c) -> u32x2 {
                 float v[4];
                 if constexpr (FP8)
                 {
                     // gate / up as the Linear stores them (W4A8: bf16(float(bf16(acc * sB)) * s_m); W8A8: bf16((acc * s_c[n]) * s_m)), then the GeGLU kernel's product
+                    // (the weight-scale kind is chosen once per tile, not per element)
+                    constexpr bool PC = decltype(pc_c)::value;
                     const float ts = tsv[hB][qt];
     #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        v[e] = gelu_tanh(fp8_linear_out(pc, acc[0][hB][pt][qt][e], wsg[pt][e], ts)) * fp8_linear_out(pc, acc[1][hB][pt][qt][e], wsu[pt][e], ts);
+                        v[e] = gelu_tanh(fp8_linear_out(PC, acc[0][hB][pt][qt][e], wsg[pt][e], ts)) * fp8_linear_out(PC, acc[1][hB][pt][qt][e], wsu[pt][e], ts);
                 }
                 else
                 {
@@ -345,16 +353,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 }
                 return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             };
+            auto stores = [&](auto pc_c) {
     #pragma unroll
-            for (int hB = 0; hB < 2; ++hB)
+                for (int hB = 0; hB < 2; ++hB)
     #pragma unroll
-                for (int pp = 0; pp < 4; pp += 2)
+                    for (int pp = 0; pp < 4; pp += 2)
     #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
-                    {
-                        const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                        store_pair16(p.Y + (size_t)m * ldy + n0 + wr * 64 + pp * 16, g, out4(hB, pp, qt, m), out4(hB, pp + 1, qt, m), m < p.M);
-                    }
+                        for (int qt = 0; qt < 2; ++qt)
+                        {
+                            const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                            store_pair16(p.Y + (size_t)m * ldy + n0 + wr * 64 + pp * 16, g, out4(hB, pp, qt, m, pc_c), out4(hB, pp + 1, qt, m, pc_c), m < p.M);
+                        }
+            };
+            if (pc) stores(std::true_type{}); else stores(std::false_type{});
         }
         else
         {
@@ -371,6 +382,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                     for (int ha_ = 0; ha_ < 2; ++ha_)
             #pragma unroll
                         for (int pt_ = 0; pt_ < 4; ++pt_) wsv[ha_][pt_] = *reinterpret_cast<const f32x4*>(p.w_scale + n0 + ha_ * 128 + wr * 64 + pt_ * 16 + 4 * g);
+                    asm volatile("" : "+v"(wsv[0][0]), "+v"(wsv[0][1]), "+v"(wsv[0][2]), "+v"(wsv[0][3]), "+v"(wsv[1][0]), "+v"(wsv[1][1]), "+v"(wsv[1][2]), "+v"(wsv[1][3]));
                 }
                 else
                 {
@@ -384,19 +396,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 for (int hb_ = 0; hb_ < 2; ++hb_)
             #pragma unroll
                     for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[min(m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15, p.M - 1)];
+                asm volatile("" : "+v"(tsv[0][0]), "+v"(tsv[0][1]), "+v"(tsv[1][0]), "+v"(tsv[1][1]));      // (in their registers before the first store: EPILOGUE_LOADS_FIRST)
             }
-            auto out4 = [&](int hA, int hB, int pt, int qt, int m, int n) -> u32x2 {
+            // fp8: the weight-scale kind and the bias are chosen ONCE per tile (fp8_stores below), not per element: with both as runtime flags inside the store loop
+            // every output carried both formulas, a select and two branches -- 153 instructions per 16-byte store where the arithmetic needs ~40
+            auto out4f = [&](int hA, int hB, int pt, int qt, int m, int n, auto pc_c, auto bias_c) -> u32x2 {
                 float v[4];
     #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[hA][hB][pt][qt][e];
                 if constexpr (FP8)
                 {
                     // W4A8: the reference's two steps -- the GEMM stores bf16(acc * weight scale), the per-token pass rescales (+ bias); W8A8: (acc * s_c[n]) * s_m (+ bias), one rounding
+                    constexpr bool PC = decltype(pc_c)::value, HB = decltype(bias_c)::value;
                     const float ts = tsv[hB][qt];
     #pragma unroll
                     for (int e = 0; e < 4; ++e)
                     {
-                        v[e] = fp8_scale_bias(pc, v[e], wsv[hA][pt][e], ts, p.bias != nullptr, p.bias ? bf16_bits_to_f32(p.bias[n + e]) : 0.0f);
+                        const float b = HB ? bf16_bits_to_f32(p.bias[n + e]) : 0.0f;
+                        v[e] = PC ? w8a8_scale_bias(v[e], wsv[hA][pt][e], ts, HB, b) : w4a8_scale_bias(v[e], wsv[hA][pt][e], ts, HB, b);
                     }
                 }
                 else if (p.bias)
@@ -411,6 +428,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                 }
                 return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             };
+            auto out4 = [&](int hA, int hB, int pt, int qt, int m, int n) -> u32x2 { return out4f(hA, hB, pt, qt, m, n, std::false_type{}, std::false_type{}); };      // (the bf16 forms)
             if constexpr (!FP8)
             {
                 if (n0 + 256 > p.N)
@@ -459,22 +477,30 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const Gemm256Params p)
                     return;
                 }
             }
+            auto stores = [&](auto pc_c, auto bias_c) {
     #pragma unroll
-            for (int hA = 0; hA < 2; ++hA)
+                for (int hA = 0; hA < 2; ++hA)
     #pragma unroll
-                for (int hB = 0; hB < 2; ++hB)
+                    for (int hB = 0; hB < 2; ++hB)
     #pragma unroll
-                    for (int pp = 0; pp < 4; pp += 2)
+                        for (int pp = 0; pp < 4; pp += 2)
     #pragma unroll
-                        for (int qt = 0; qt < 2; ++qt)
-                        {
-                            const int nb = n0 + hA * 128 + wr * 64 + pp * 16;       // first column of sub-tile pp
-                            const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                            for (int qt = 0; qt < 2; ++qt)
+                            {
+                                const int nb = n0 + hA * 128 + wr * 64 + pp * 16;       // first column of sub-tile pp
+                                const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
     #ifdef MILA_GEMM_SKIP
-                            if ((p.dbg & 8) && acc[hA][hB][pp][qt][0] != 12345.678f) continue;      // diagnostic: no epilogue stores (8)
+                                if ((p.dbg & 8) && acc[hA][hB][pp][qt][0] != 12345.678f) continue;      // diagnostic: no epilogue stores (8)
     #endif
-                            store_pair16(p.Y + (size_t)m * ldy + nb, g, out4(hA, hB, pp, qt, m, nb + 4 * g), out4(hA, hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
-                        }
+                                store_pair16(p.Y + (size_t)m * ldy + nb, g, out4f(hA, hB, pp, qt, m, nb + 4 * g, pc_c, bias_c), out4f(hA, hB, pp + 1, qt, m, nb + 16 + 4 * g, pc_c, bias_c), m < p.M);
+                            }
+            };
+            if constexpr (FP8)
+            {
+                if (pc) { if (p.bias) stores(std::true_type{}, std::true_type{}); else stores(std::true_type{}, std::false_type{}); }
+                else { if (p.bias) stores(std::false_type{}, std::true_type{}); else stores(std::false_type{}, std::false_type{}); }
+            }
+            else stores(std::false_type{}, std::false_type{});
         }
     };
 
@@ -979,6 +1005,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                         wsg[pt_] = *reinterpret_cast<const f32x4*>(p.w_scale + n_);
                         wsu[pt_] = *reinterpret_cast<const f32x4*>(p.w_scale + p.N + n_);
                     }
+                    asm volatile("" : "+v"(wsg[0]), "+v"(wsg[1]), "+v"(wsu[0]), "+v"(wsu[1]));
                 }
                 else
                 {
@@ -989,15 +1016,17 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                 for (int hb_ = 0; hb_ < 2; ++hb_)
             #pragma unroll
                     for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[min(m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15, p.M - 1)];
+                asm volatile("" : "+v"(tsv[0][0]), "+v"(tsv[0][1]), "+v"(tsv[1][0]), "+v"(tsv[1][1]));      // (in their registers before the first store: EPILOGUE_LOADS_FIRST)
             }
-            auto out4 = [&](int hB, int pt, int qt, int m) -> u32x2 {
+            auto out4 = [&](int hB, int pt, int qt, int m, auto pc_c) -> u32x2 {
                 float v[4];
                 if constexpr (FP8)
                 {
+                    constexpr bool PC = decltype(pc_c)::value;
                     const float ts = tsv[hB][qt];
     #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        v[e] = gelu_tanh(fp8_linear_out(pc, acc[hB][pt][qt][e], wsg[pt][e], ts)) * fp8_linear_out(pc, acc[hB][pt + 2][qt][e], wsu[pt][e], ts);
+                        v[e] = gelu_tanh(fp8_linear_out(PC, acc[hB][pt][qt][e], wsg[pt][e], ts)) * fp8_linear_out(PC, acc[hB][pt + 2][qt][e], wsu[pt][e], ts);
                 }
                 else
                 {
@@ -1006,14 +1035,17 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                 }
                 return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             };
+            auto stores = [&](auto pc_c) {
     #pragma unroll
-            for (int hB = 0; hB < 2; ++hB)
+                for (int hB = 0; hB < 2; ++hB)
     #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
-                {
-                    const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                    store_pair16(p.Y + (size_t)m * ldy + n0 + wr * 32, g, out4(hB, 0, qt, m), out4(hB, 1, qt, m), m < p.M);
-                }
+                    for (int qt = 0; qt < 2; ++qt)
+                    {
+                        const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                        store_pair16(p.Y + (size_t)m * ldy + n0 + wr * 32, g, out4(hB, 0, qt, m, pc_c), out4(hB, 1, qt, m, pc_c), m < p.M);
+                    }
+            };
+            if (pc) stores(std::true_type{}); else stores(std::false_type{});
             return;
         }
         // fp8 epilogue scales, fetched ONCE before the stores: read inside the store loop they are re-fetched after every store (the compiler cannot
@@ -1027,6 +1059,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             {
         #pragma unroll
                 for (int pt_ = 0; pt_ < 4; ++pt_) wsv[pt_] = *reinterpret_cast<const f32x4*>(p.w_scale + n0 + wr * 64 + pt_ * 16 + 4 * g);
+                asm volatile("" : "+v"(wsv[0]), "+v"(wsv[1]), "+v"(wsv[2]), "+v"(wsv[3]));
             }
             else
             {
@@ -1038,6 +1071,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             for (int hb_ = 0; hb_ < 2; ++hb_)
         #pragma unroll
                 for (int qt_ = 0; qt_ < 2; ++qt_) tsv[hb_][qt_] = p.x_scales[min(m0 + hb_ * 128 + wc * 32 + qt_ * 16 + l15, p.M - 1)];
+            asm volatile("" : "+v"(tsv[0][0]), "+v"(tsv[0][1]), "+v"(tsv[1][0]), "+v"(tsv[1][1]));      // (in their registers before the first store: EPILOGUE_LOADS_FIRST)
         }
         // the bias of this lane's 16 columns (4 sub-tiles x 4), fetched ONCE before the stores like the scales above: read inside the store loop every value is fetched again
         // after every store (the compiler cannot prove that Y does not alias the bias) -- 64 dependent 2-byte loads per lane and tile, 15 % of GPT-2's biased projections
@@ -1050,19 +1084,20 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             for (int pt_ = 0; pt_ < 4; ++pt_)
     #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[pt_][e] = bf16_bits_to_f32(p.bias[min(n0 + wr * 64 + pt_ * 16 + 4 * g + e, p.N - 1)]);
+            asm volatile("" : "+v"(bv[0][0]), "+v"(bv[0][1]), "+v"(bv[0][2]), "+v"(bv[0][3]), "+v"(bv[1][0]), "+v"(bv[1][1]), "+v"(bv[1][2]), "+v"(bv[1][3]),
+                              "+v"(bv[2][0]), "+v"(bv[2][1]), "+v"(bv[2][2]), "+v"(bv[2][3]), "+v"(bv[3][0]), "+v"(bv[3][1]), "+v"(bv[3][2]), "+v"(bv[3][3]));
         }
-        auto out4 = [&](int hB, int pt, int qt, int m, int n) -> u32x2 {
+        // (fp8: weight-scale kind and bias chosen once per tile, as in gemm256_kernel's epilogue)
+        auto out4f = [&](int hB, int pt, int qt, int m, int n, auto pc_c, auto bias_c) -> u32x2 {
             float v[4];
     #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[hB][pt][qt][e];
             if constexpr (FP8)
             {
+                constexpr bool PC = decltype(pc_c)::value, HB = decltype(bias_c)::value;
                 const float ts = tsv[hB][qt];
     #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                {
-                    v[e] = fp8_scale_bias(pc, v[e], wsv[pt][e], ts, p.bias != nullptr, bv[pt][e]);
-                }
+                for (int e = 0; e < 4; ++e) v[e] = PC ? w8a8_scale_bias(v[e], wsv[pt][e], ts, HB, bv[pt][e]) : w4a8_scale_bias(v[e], wsv[pt][e], ts, HB, bv[pt][e]);
             }
             else if (p.bias)
             {
@@ -1076,6 +1111,7 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
             }
             return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         };
+        auto out4 = [&](int hB, int pt, int qt, int m, int n) -> u32x2 { return out4f(hB, pt, qt, m, n, std::false_type{}, std::false_type{}); };      // (the bf16 forms)
         if (!FP8 && (p.N & 7) != 0 && n0 + 128 <= p.N)
         {
             // an output row pitch that is not a multiple of 16 bytes (GPT-2's lm_head: N = 50257), whole tile: the paired 16-byte stores at 2-byte alignment
@@ -1118,17 +1154,25 @@ __global__ __launch_bounds__(512) void gemm256x128_kernel(const Gemm256Params p)
                     }
             return;
         }
+        auto stores = [&](auto pc_c, auto bias_c) {
     #pragma unroll
-        for (int hB = 0; hB < 2; ++hB)
+            for (int hB = 0; hB < 2; ++hB)
     #pragma unroll
-            for (int pp = 0; pp < 4; pp += 2)
+                for (int pp = 0; pp < 4; pp += 2)
     #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
-                {
-                    const int nb = n0 + wr * 64 + pp * 16;
-                    const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
-                    store_pair16(p.Y + (size_t)m * ldy + nb, g, out4(hB, pp, qt, m, nb + 4 * g), out4(hB, pp + 1, qt, m, nb + 16 + 4 * g), m < p.M);
-                }
+                    for (int qt = 0; qt < 2; ++qt)
+                    {
+                        const int nb = n0 + wr * 64 + pp * 16;
+                        const int m = m0 + hB * 128 + wc * 32 + qt * 16 + l15;
+                        store_pair16(p.Y + (size_t)m * ldy + nb, g, out4f(hB, pp, qt, m, nb + 4 * g, pc_c, bias_c), out4f(hB, pp + 1, qt, m, nb + 16 + 4 * g, pc_c, bias_c), m < p.M);
+                    }
+        };
+        if constexpr (FP8)
+        {
+            if (pc) { if (p.bias) stores(std::true_type{}, std::true_type{}); else stores(std::true_type{}, std::false_type{}); }
+            else { if (p.bias) stores(std::false_type{}, std::true_type{}); else stores(std::false_type{}, std::false_type{}); }
+        }
+        else stores(std::false_type{}, std::false_type{});
     };
 
     stage_all(0, 0);
