@@ -191,7 +191,7 @@ def test_the_staggered_gemm_schedules_keep_their_mfma_blocks_between_their_barri
     products (pure calls; sched_barrier(0) does not hold them) below that phase's end barrier into phase B's slot.  Found by counting instructions between consecutive
     s_barrier in the ISA; this test does the same on every default-schedule LDS-DMA kernel (cross-compiled here, no GPU): inside the K loops no barrier-to-barrier stretch
     may hold MORE matrix instructions than one phase issues (256 x 256: 32 bf16 / 16 fp8 per phase; 256 x 128 ring: 32 / 16 per K-tile), and stretches with fragment
-    reads hold none."""
+    reads hold none.  Also: no LDS-DMA request sits inside a waterfall loop."""
     import re
     import subprocess
     import tempfile
@@ -222,3 +222,10 @@ def test_the_staggered_gemm_schedules_keep_their_mfma_blocks_between_their_barri
         assert loop, k
         assert max(x[0] for x in loop) <= per_phase, (k, loop[:12])                # no phase's products merged into a neighbour's slot
         assert all(x[0] <= 1 for x in loop if x[1] >= 8), (k, loop[:12])            # (one product may ride in front of a read phase's barrier; a block may not)
+        # EXPERIMENTS.md 10.9: no staging request inside a readfirstlane WATERFALL loop (a uniform offset the allocator had moved into a vector register when the scalar
+        # registers ran out: the fp8 GeGLU mode's "49 spilled registers")
+        lines = [ln.strip() for ln in body.splitlines()]
+        for i, t in enumerate(lines):
+            if t.startswith("s_cbranch_execnz"):
+                back = " ".join(lines[max(0, i - 12):i])
+                assert not ("v_readfirstlane" in back and "lds" in back), (k, lines[max(0, i - 12):i + 1])
