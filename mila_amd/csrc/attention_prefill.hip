@@ -269,7 +269,9 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const FlashParams
         }
         float alpha;
         const bf16x8 pfrag = softmax_tile_step(tv, m_run, l_run, alpha);
-        const bool rescale = __any(alpha != 1.0f);
+        // few output tiles (HS = 64: DT = 4): the rescale is multiplied in unconditionally -- alpha is exactly 1 where the row's maximum did not move, so the bits are
+        // the same, and 16 multiplies cost less than the vote plus the 16 selects the compiler made of the guarded form (round 4: 54 v_cndmask per pair of tiles)
+        const bool rescale = DT <= 4 || __any(alpha != 1.0f);
 #pragma unroll
         for (int d = 0; d < DT; ++d)
         {
