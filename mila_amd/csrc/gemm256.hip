@@ -1516,12 +1516,14 @@ int launch_gemm256x128_splitk(uint16_t* Y, const uint16_t* X, const uint16_t* W,
 }
 
 // one 512-thread workgroup per CU: worth it only when the tile count fills whole rounds of 256 CUs
+int g_gemm256_min_fill = 80;      // tuning "gemm.tile256_min_fill": the 256 x 256 grid applies when its tiles fill at least this many percent of their rounds of CUs
+MILA_TUNE("gemm.tile256_min_fill", g_gemm256_min_fill);
 bool gemm256_applicable(int M, int K, int N)
 {
     if (M <= 0 || N % 256 != 0 || K % 64 != 0 || !lds_dma_addressable(M, K, N)) return false;
     const int tiles = ((M + 255) / 256) * (N / 256);
     const int rounds = (tiles + kNumCU - 1) / kNumCU;
-    return tiles >= 200 && tiles >= 0.80 * rounds * kNumCU;      // (0.80: nine tile-rows of fc_gate_up -- 1080 tiles, 4.2 rounds walked as 5 -- stay on the fused kernel)
+    return tiles >= 200 && tiles * 100 >= g_gemm256_min_fill * rounds * kNumCU;      // (80 %: nine tile-rows of fc_gate_up -- 1080 tiles, 4.2 rounds walked as 5 -- stay on the fused kernel)
 }
 
 // bf16 only: N of any size (ragged last tile-column, any row pitch) on the PERSISTENT 256 x 256 schedule when the grid is many rounds deep -- GPT-2's lm_head

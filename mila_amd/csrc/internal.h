@@ -31,6 +31,8 @@ MILA_API size_t mila_cdna4_last_form(char* buf, size_t cap);
  *   gemm.schedule          0 = all eight waves in lockstep; 1 = staggered (ping-pong), four phases per K-tile; 2 = 1, preferring the 256 x 128 ring; 3 = staggered, two
  *                          phases per K-tile; 4 = 3 + the fp8 shapes on the 256 x 256 kernel wherever it applies; 5 (default) = 4 with a static priority for waves 4-7.  Same bits.
  *   gemm.persistent        0 = one workgroup per tile instead of the persistent tile walk (default 1).  Same bits.
+ *   gemm.tile256_min_fill  the 256 x 256 grid applies when its tiles fill at least this many percent of their rounds of CUs (default 80; profiles/r04_tile256_fill_rule.txt:
+ *                          at 75 % -- GPT-2's fc_1, 384 tiles -- the 256 x 128 ring is 56 us against 74).  Same bits.
  *   gemm.walk_min_tiles    the 256 x 128 ring walks its tiles from this many on (default 3 x 256 + 1: up to three rounds one workgroup per tile is as fast or faster).  Same bits.
  *   gemm.colsplit          the column split of a tile list whose last round is nearly empty (default 1)
  *   gemm_fp8.tail_form     0 (default) = LDS-DMA kernels on the leading multiple of 256 rows, the tail kernels of gemm_fp8_tail.hip on the rest; 1 = EVERY row on the masked
