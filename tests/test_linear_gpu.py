@@ -512,8 +512,9 @@ def test_w4a8_prefill_matches_the_restated_reference(M, K, N, bias):
         capi.call("gemm_bf16_w4a8", Y2, dev_u16(orc.to_bf16_bits(X)), dev_u8(q4), dev_f32(s4), ws_d, None, M, K, N, 128, scratch, C.c_size_t(64))
 
 
-def test_w4a8_gemm_with_geglu_epilogue_is_bit_identical_to_w4a8_gemm_then_geglu():
-    M, K, F = 512, 256, 15360
+# (the longer K: five and more fp8 K-tiles run the interior K-tile bodies of the fp8 GeGLU mode, round 4; 2048 x 1024 walks 4 / 3 tiles per workgroup)
+@pytest.mark.parametrize("M,K,F", [(512, 256, 15360), (512, 1024, 15360), (2048, 1024, 15360), (512, 1152, 15360)])
+def test_w4a8_gemm_with_geglu_epilogue_is_bit_identical_to_w4a8_gemm_then_geglu(M, K, F):
     lib = capi.load()
     assert lib.mila_cdna4_gemm_geglu_w4a8_applicable(M, K, F) == 1
     rng = np.random.default_rng(5)

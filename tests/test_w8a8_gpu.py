@@ -111,7 +111,8 @@ def test_w8a8_prefill_matches_the_oracle_at_every_row_count(M, K, N, bias):
     assert np.all(np.abs(got - ref16).max(axis=1) <= 1e-1 * np.maximum(np.abs(ref16).max(axis=1), 1e-6))
 
 
-@pytest.mark.parametrize("M,K,F", [(512, 256, 15360), (2048, 128, 15360), (2, 256, 15360), (100, 384, 1000), (512 + 100, 256, 15360), (2049, 128, 15360), (300, 256, 4096)])
+@pytest.mark.parametrize("M,K,F", [(512, 256, 15360), (2048, 128, 15360), (2, 256, 15360), (100, 384, 1000), (512 + 100, 256, 15360), (2049, 128, 15360), (300, 256, 4096),
+                                   (512, 1024, 15360), (2048, 1024, 15360), (512, 1152, 15360)])      # (the last three: the interior K-tile bodies of the fp8 GeGLU mode, even and odd K-tile counts)
 def test_w8a8_geglu_form_is_bit_identical_to_linear_then_geglu(M, K, F):
     """fc_gate_up + GeGLU in one kernel (Gemma.Block.ixx:343-348) on the W8A8 path: the gate rows use scale[n], the up rows scale[F + n]; same bits as the Linear over
     [2F, K] followed by geglu_bf16, whichever tile form serves the rows"""
